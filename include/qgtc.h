@@ -1,0 +1,130 @@
+/*
+ * qgtc.h — C-ABI of libqgtc_hip.so, the MI355X (gfx950) implementation of the QGTC bit-GEMM
+ * hot path. This is the drop-in boundary: plain pointers and sizes, no torch types. The
+ * `QGTC` PyTorch extension (qgtc_ppopp22_amd/csrc/qgtc_torch.cpp) is a thin binding over
+ * these entry points; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * reference checkout, YukeWang96/QGTC_PPoPP22 @ v1).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers on the device that is current when the call is made;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream); every
+ *     call is asynchronous on that stream unless stated otherwise;
+ *   - packed tensors are flat arrays of 32-bit words; element i of a packed line lives in
+ *     word i>>5, bit 31-(i&31) (reference kernel.h:98,234);
+ *   - "rows layout"  of an HxW matrix with b planes: [b][PAD8(H)][STEP128(W)*4] words
+ *     (QGTC_device.cu:115);  "cols layout": [b][PAD128(W)][STEP128(H)*4] words
+ *     (QGTC_device.cu:97), or [b][PAD8(W)][STEP128(H)*4] with output_layer (QGTC_device.cu:83);
+ *   - every packed pointer must be 16-byte aligned (torch allocations are);
+ *   - reads are bounds-safe: a word index >= the stated *_words reads as 0, so mis-sized or
+ *     mis-laid operands (the reference reads raw memory there) can never fault;
+ *   - bit widths (nbits, bit1, bit2, output_bit) must lie in [1, 32]; the reference publishes
+ *     results for 1..8 only;
+ *   - return value: QGTC_OK or a QGTC_E* code; qgtc_strerror() describes it. The reference
+ *     printf()s and exit(-1)s instead (QGTC_device.cu:67-71).
+ */
+#ifndef QGTC_H
+#define QGTC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QGTC_ABI_VERSION 1
+
+enum {
+    QGTC_OK = 0,
+    QGTC_EINVAL = 1,   /* bad dimension / bit width / NULL pointer            */
+    QGTC_ESIZE = 2,    /* output buffer smaller than the op's result          */
+    QGTC_EALIGN = 3,   /* packed pointer not 16-byte aligned                  */
+    QGTC_EHIP = 4,     /* HIP runtime error (see qgtc_last_hip_error())       */
+    QGTC_ENODEVICE = 5 /* no gfx950 device / kernels not loadable             */
+};
+
+/* flags for qgtc_bitmm2bit */
+#define QGTC_OUT_COLS 0x1u     /* pack the result in the cols layout (bitMM2Bit_col)      */
+#define QGTC_NO_ZERO_SKIP 0x2u /* do not skip all-zero X tiles (result is identical)      */
+
+int qgtc_abi_version(void);
+const char *qgtc_strerror(int code);
+const char *qgtc_last_hip_error(void);
+
+/* Shape algebra — utility.h:33-45 (STEP8/STEP128/PAD8/PAD128) and the allocation rules of
+ * QGTC_device.cu:83,97,115,223,456. */
+size_t qgtc_rows_words(int H, int W, int nbits);
+size_t qgtc_cols_words(int H, int W, int nbits, int output_layer);
+
+/* val2bit — replaces val2bit_cuda (QGTC_device.cu:44-130; binding QGTC_host.cpp:229-238):
+ * Quantize_val (kernel.h:49-71) fused with QGTC_layer_input (kernel.h:204-242, rows layout)
+ * or PackFcWeight128 (kernel.h:75-106, cols layout). x: float32 [H,W] row-major.
+ * Writes every word of `out` (padding included); out_words must be >= qgtc_rows_words /
+ * qgtc_cols_words. */
+int qgtc_val2bit(const float *x, int H, int W, int nbits, int col_major, int output_layer,
+                 uint32_t *out, size_t out_words, void *stream);
+
+/* bit2val — replaces bit2val_cuda (QGTC_device.cu:135-206; QGTC_host.cpp:244-256):
+ * UnPackFcOutput128 (kernel.h:173-201) / UnPackFcWeight128 (kernel.h:109-139).
+ * out: int32 [H,W] row-major, fully written. */
+int qgtc_bit2val(const uint32_t *bits, size_t bits_words, int nbits, int H, int W,
+                 int col_major, int output_layer, int32_t *out, void *stream);
+
+/* bitMM2Bit / bitMM2Bit_col — replaces bitMM2Bit_cuda (QGTC_device.cu:211-266) and
+ * bitMM2Bit_col_cuda (QGTC_device.cu:441-489), i.e. kernels QGTC_layer_hidden
+ * (kernel.h:245-391) and QGTC_layer_hidden_col (kernel.h:651-810):
+ *   C = sum_{pa<bit1,pw<bit2} 2^(pa+pw) * popc-product(X plane pa, W plane pw)   (int32)
+ *   out = pack(requant(C, output_bit))  in the rows layout, or the cols layout with
+ *   QGTC_OUT_COLS.  X: rows layout of MxK with bit1 planes; W: cols layout of KxN with bit2
+ *   planes (plane stride STEP128(K)*PAD128(N)*4). Writes every word of `out`. */
+int qgtc_bitmm2bit(const uint32_t *X, size_t x_words, const uint32_t *W, size_t w_words,
+                   int M, int K, int N, int bit1, int bit2, int output_bit,
+                   uint32_t *out, size_t out_words, unsigned flags, void *stream);
+
+/* bitMM2Int — replaces bitMM2Int_cuda (QGTC_device.cu:495-542): QGTC_layer_output_PAD8
+ * (kernel.h:816-932; W plane stride STEP128(K)*PAD8(N)*4) when pad_128 == 0, else
+ * QGTC_layer_output_PAD128 (kernel.h:938-1054). out: float32 [M,N] = (float)C. */
+int qgtc_bitmm2int(const uint32_t *X, size_t x_words, const uint32_t *W, size_t w_words,
+                   int M, int K, int N, int bit1, int bit2, int pad_128,
+                   float *out, size_t out_elems, unsigned flags, void *stream);
+
+/* bitMM2Bit_profile — replaces bitMM2Bit_cuda_profile (QGTC_device.cu:379-434): `reps`
+ * back-to-back launches between two events; BLOCKS until they finish and returns the elapsed
+ * milliseconds in *elapsed_ms (the reference hard-codes reps = 200 and printf()s TFLOPs). */
+int qgtc_bitmm2bit_profile(const uint32_t *X, size_t x_words, const uint32_t *W, size_t w_words,
+                           int M, int K, int N, int bit1, int bit2, int output_bit,
+                           uint32_t *out, size_t out_words, unsigned flags, int reps,
+                           float *elapsed_ms, void *stream);
+
+/* Tile counters — replaces the `counter_global` / `counter` device globals that
+ * QGTC_layer_hidden_base_cnt (kernel.h:394-512, :452) and QGTC_layer_hidden_zerojump_cnt
+ * (kernel.h:516-648, :574-592) bump; per call, in the reference's 8-row x 128-bit tile units:
+ *   counters[0] = STEP8(M)*STEP8(N)*STEP128(K)*bit1*bit2
+ *   counters[1] = steps whose 8x128-bit X tile is non-zero (x STEP8(N)*bit2)
+ * `counters` is a device pointer to two uint64; it is overwritten (not accumulated). */
+int qgtc_tile_counters(const uint32_t *X, size_t x_words, int M, int K, int N, int bit1,
+                       int bit2, uint64_t *counters, void *stream);
+
+/* Batched bit-GEMM: `count` independent products in ONE launch (the Cluster-GCN / Batched-GIN
+ * epoch loop of main_qgtc.py:112-155 issues one bitMM2Bit per cluster batch; on MI355X the
+ * launch boundary dominates those, so the engine groups them). `problems` is a DEVICE array.
+ * mode: 0 = rows-layout bits, 1 = cols-layout bits, 2 = float32 (bitMM2Int). */
+typedef struct qgtc_problem {
+    const uint32_t *X;
+    const uint32_t *W;
+    void *out;
+    uint64_t x_words, w_words;
+    int32_t M, K, N;
+    int32_t w_lines; /* lines per W plane: PAD128(N), or PAD8(N) for bitMM2Int pad_128=0 */
+} qgtc_problem;
+
+int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int max_K, int max_N,
+                       int bit1, int bit2, int output_bit, int mode, unsigned flags,
+                       void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

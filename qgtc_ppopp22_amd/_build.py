@@ -1,0 +1,76 @@
+"""In-tree build of the native pieces (called by __graft_entry__.build()).
+
+  libqgtc_hip.so                    hipcc --offload-arch=gfx950  csrc/qgtc_hip.hip   (C-ABI + kernels)
+  QGTC.cpython-*.so                 g++                          csrc/qgtc_torch.cpp (pybind11 binding)
+
+Both land next to this file so that they travel with the repo snapshot to the GPU box (they are
+git-ignored, not gpurun-ignored). hipcc cross-compiles gfx950 without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+import sysconfig
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+INC = os.path.join(ROOT, "include")
+
+HIP_LIB = os.path.join(PKG, "libqgtc_hip.so")
+EXT_SUFFIX = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+TORCH_EXT = os.path.join(PKG, "QGTC" + EXT_SUFFIX)
+
+
+def _newer(target: str, sources: list[str]) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _run(cmd: list[str]) -> None:
+    print("[qgtc build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def build_hip(force: bool = False) -> str:
+    src = [os.path.join(CSRC, "qgtc_hip.hip"), os.path.join(INC, "qgtc.h")]
+    if not force and _newer(HIP_LIB, src):
+        return HIP_LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+          "-Wno-unused-value", f"-I{INC}", "-o", HIP_LIB, src[0]])
+    return HIP_LIB
+
+
+def build_torch_ext(force: bool = False) -> str:
+    src = [os.path.join(CSRC, "qgtc_torch.cpp"), os.path.join(INC, "qgtc.h")]
+    if not force and _newer(TORCH_EXT, src + [HIP_LIB]):
+        return TORCH_EXT
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    incs = [f"-I{p}" for p in ce.include_paths()] + [f"-I{INC}", "-I/opt/rocm/include",
+                                                      f"-I{sysconfig.get_paths()['include']}"]
+    abi = int(torch.compiled_with_cxx11_abi())
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=QGTC",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={abi}",
+           *incs, src[0], "-o", TORCH_EXT,
+           f"-L{PKG}", "-lqgtc_hip", f"-L{tlib}", "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu",
+           "-ltorch_hip", "-ltorch_python",
+           "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}", "-Wl,-rpath,/opt/rocm/lib"]
+    _run(cmd)
+    return TORCH_EXT
+
+
+def build_all(force: bool = False) -> dict:
+    return {"hip": build_hip(force), "torch_ext": build_torch_ext(force)}
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv))

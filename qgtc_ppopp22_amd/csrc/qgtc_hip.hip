@@ -1,0 +1,824 @@
+// qgtc_hip.hip — MI355X (gfx950 / CDNA4) kernels and C-ABI of the QGTC bit-GEMM hot path.
+//
+// What is here (reference file:line each piece replaces is in include/qgtc.h):
+//   * fused quantise + bit-plane pack          (val2bit, rows and cols layouts)
+//   * bit-plane unpack                         (bit2val)
+//   * multi-plane 1-bit GEMM: AND + popcount (v_and_b32 / v_bcnt_u32_b32) with shift-accumulate
+//     into int32, in-workgroup split-K, zero-tile skipping, and a fused epilogue that either
+//     re-quantises and re-packs (rows / cols layout) or converts to float32
+//   * tile counters, the 200-rep profile loop, and a grouped (batched) launch.
+//
+// Design notes live in DESIGN.md; the short version of the GEMM kernel:
+//   - a workgroup owns a TM x TN output tile for the whole K range (no inter-workgroup
+//     reduction, so results are exact and order-independent); its WK waves split each staged
+//     K chunk among themselves and are summed through LDS at the end;
+//   - both operands are staged global -> LDS in 16-byte granules (= 128 bits of one packed
+//     row), laid out [plane][k-quad][row] so that the 8 distinct granules a wave reads per
+//     ds_read_b128 are contiguous (conflict-free) and the staging ds_write_b128 of 8
+//     consecutive k-quads hits 8 distinct 4-bank groups (row count padded to odd);
+//   - each lane keeps an R x C register micro-tile: per k-quad it reads R + C granules and
+//     issues R*C*4 v_and_b32 + v_bcnt_u32_b32 pairs;
+//   - while staging X the wave ballots "granule != 0" and ORs a per-k-quad occupancy bitmap
+//     into LDS; compute waves skip k-quads whose TM x 128-bit X tile is all zero (wave-uniform
+//     scalar branch, no divergence).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "qgtc.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// shape algebra (reference utility.h:33-45)
+// ------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int step8(int x) { return (x + 7) >> 3; }
+__host__ __device__ constexpr int step128(int x) { return (x + 127) >> 7; }
+__host__ __device__ constexpr int pad8(int x) { return step8(x) << 3; }
+__host__ __device__ constexpr int pad128(int x) { return step128(x) << 7; }
+
+thread_local char g_hip_err[256] = "";
+
+int hip_fail(hipError_t e, const char *where) {
+    snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", where, hipGetErrorString(e));
+    return QGTC_EHIP;
+}
+#define HIP_TRY(expr)                                        \
+    do {                                                     \
+        hipError_t e_ = (expr);                              \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr);    \
+    } while (0)
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool bits_ok(int b) { return b >= 1 && b <= 32; }
+
+// bounds-safe word / granule loads: indices past the buffer read as zero
+__device__ __forceinline__ uint32_t ldw(const uint32_t *__restrict__ p, unsigned long long n,
+                                        unsigned long long i) {
+    return i < n ? p[i] : 0u;
+}
+__device__ __forceinline__ uint4 ldg4(const uint32_t *__restrict__ p, unsigned long long n,
+                                      unsigned long long i) {
+    if (i + 4 <= n) return *reinterpret_cast<const uint4 *>(p + i);
+    return make_uint4(ldw(p, n, i), ldw(p, n, i + 1), ldw(p, n, i + 2), ldw(p, n, i + 3));
+}
+
+// ------------------------------------------------------------------------------------------
+// quantisation (reference kernel.h:39-44 clip, :68 __float2int_rn)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t quant1(float x, float ub, float ubm1) {
+    float y = x;
+    if (x < 0.0f) y = 1.0f;       // negative -> lb + 1
+    else if (x > ub) y = ubm1;    // above 2^b -> 2^b - 1 (float arithmetic)
+    if (y != y) return 0u;        // NaN converts to 0
+    const float r = rintf(y);     // v_rndne_f32: round-half-to-even
+    return r >= 4294967296.0f ? 0u : static_cast<uint32_t>(r);  // low 32 bits (nbits >= 31 only)
+}
+
+// ------------------------------------------------------------------------------------------
+// val2bit, rows layout: out[p][r][c>>5] bit(31-(c&31)) = bit p of quant(x[r][c])
+// One wave per (row, 256-column chunk): 4 coalesced loads per lane, one 64-bit ballot per
+// (plane, load), two bit-reversed words per ballot; lanes 0..7 store the chunk's 8 words.
+// Every word of the padded output is written.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_val2bit_rows(const float *__restrict__ x, int H, int W,
+                                                      int nbits, float ub, float ubm1,
+                                                      uint32_t *__restrict__ out, int rows_pad,
+                                                      int row_words) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = (static_cast<long>(gridDim.x) * blockDim.x) >> 6;
+    const int chunks = (row_words + 7) >> 3;
+    const long units = static_cast<long>(rows_pad) * chunks;
+    const size_t plane = static_cast<size_t>(rows_pad) * row_words;
+    for (long u = wave; u < units; u += nwaves) {
+        const int r = static_cast<int>(u / chunks);
+        const int ch = static_cast<int>(u % chunks);
+        uint32_t q[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int c = ch * 256 + i * 64 + lane;
+            q[i] = (r < H && c < W) ? quant1(x[static_cast<size_t>(r) * W + c], ub, ubm1) : 0u;
+        }
+        const int wi = ch * 8 + lane;  // word this lane stores (lanes 0..7)
+        for (int p = 0; p < nbits; p++) {
+            unsigned long long m[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) m[i] = __ballot((q[i] >> p) & 1u);
+            const int sel = (lane >> 1) & 3;
+            const unsigned long long mm = sel == 0 ? m[0] : sel == 1 ? m[1] : sel == 2 ? m[2] : m[3];
+            const uint32_t half = (lane & 1) ? static_cast<uint32_t>(mm >> 32) : static_cast<uint32_t>(mm);
+            if (lane < 8 && wi < row_words)
+                out[p * plane + static_cast<size_t>(r) * row_words + wi] = __brev(half);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// val2bit, cols layout: out[p][c][r>>5] bit(31-(r&31)) = bit p of quant(x[r][c])
+// One wave per (64-column chunk, 32-row group): lane = column, 32 coalesced row reads, each
+// lane assembles its column's word per plane in registers. NB = compile-time bound on nbits.
+// ------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256) void k_val2bit_cols(const float *__restrict__ x, int H, int W,
+                                                      int nbits, float ub, float ubm1,
+                                                      uint32_t *__restrict__ out, int lines,
+                                                      int line_words) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = (static_cast<long>(gridDim.x) * blockDim.x) >> 6;
+    const int cchunks = (lines + 63) >> 6;
+    const long units = static_cast<long>(cchunks) * line_words;
+    const size_t plane = static_cast<size_t>(lines) * line_words;
+    for (long u = wave; u < units; u += nwaves) {
+        const int cg = static_cast<int>(u % cchunks);
+        const int rw = static_cast<int>(u / cchunks);
+        const int c = cg * 64 + lane;
+        uint32_t wd[NB];
+#pragma unroll
+        for (int p = 0; p < NB; p++) wd[p] = 0u;
+#pragma unroll 8
+        for (int rr = 0; rr < 32; rr++) {
+            const int r = rw * 32 + rr;
+            const uint32_t q =
+                (r < H && c < W) ? quant1(x[static_cast<size_t>(r) * W + c], ub, ubm1) : 0u;
+#pragma unroll
+            for (int p = 0; p < NB; p++) wd[p] |= ((q >> p) & 1u) << (31 - rr);
+        }
+        if (c < lines) {
+#pragma unroll
+            for (int p = 0; p < NB; p++)
+                if (p < nbits) out[p * plane + static_cast<size_t>(c) * line_words + rw] = wd[p];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// bit2val (reference kernel.h:109-139, :173-201): one thread per output element
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bit2val(const uint32_t *__restrict__ bits,
+                                                 unsigned long long words, int nbits, int H, int W,
+                                                 int col_major, size_t plane, int line_words,
+                                                 int32_t *__restrict__ out) {
+    const size_t total = static_cast<size_t>(H) * W;
+    for (size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+         idx += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const int r = static_cast<int>(idx / W), c = static_cast<int>(idx % W);
+        const int line = col_major ? c : r, pos = col_major ? r : c;
+        uint32_t v = 0;
+        for (int p = 0; p < nbits; p++) {
+            const uint32_t wd =
+                ldw(bits, words, p * plane + static_cast<size_t>(line) * line_words + (pos >> 5));
+            v += ((wd >> (31 - (pos & 31))) & 1u) << p;
+        }
+        out[idx] = static_cast<int32_t>(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// tile counters (reference kernel.h:452, :574-592): one thread per (plane, 8-row block, k-step)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_counters(const uint32_t *__restrict__ X,
+                                                       unsigned long long x_words, int M, int K,
+                                                       int a, unsigned long long mult_total,
+                                                       unsigned long long mult_nz,
+                                                       unsigned long long *__restrict__ counters) {
+    const int gdx = step8(M), gdk = step128(K);
+    const size_t kw = static_cast<size_t>(gdk) * 4;
+    const size_t x_plane = static_cast<size_t>(pad8(M)) * kw;
+    const size_t total = static_cast<size_t>(a) * gdx * gdk;
+    unsigned long long local = 0;
+    for (size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
+         t += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const size_t i = t % gdk, bx = (t / gdk) % gdx, pa = t / (static_cast<size_t>(gdk) * gdx);
+        uint32_t any = 0;
+        for (int r = 0; r < 8; r++) {
+            const uint4 g = ldg4(X, x_words, pa * x_plane + (bx * 8 + r) * kw + i * 4);
+            any |= g.x | g.y | g.z | g.w;
+        }
+        local += any ? 1u : 0u;
+    }
+    // wave reduce, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&counters[1], local * mult_nz);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[0], mult_total);
+}
+
+// ------------------------------------------------------------------------------------------
+// the bit-GEMM
+// ------------------------------------------------------------------------------------------
+struct MMShape {           // per-launch constants
+    int a, w, ob;          // planes of X, planes of W, output planes
+    int mode;              // 0 rows-layout bits, 1 cols-layout bits, 2 float32
+    int qc;                // k-quads (128-bit steps) staged per chunk: power of two, WK..64
+    int ab, wb;            // plane blocking (planes staged at once)
+    float maxv, maxm1;     // 2^ob and 2^ob - 1 as float (requant)
+};
+
+__device__ __forceinline__ int requant(int c, float maxv, float maxm1) {
+    // reference kernel.h:31-37 called as quantize(c, ob, 1<<ob, 0): float compare, then the
+    // (val-min)*2^ob/(max-min) scaling, which is the identity for min=0, max=2^ob.
+    float val = static_cast<float>(c);
+    if (val > maxv) val = maxm1;
+    if (val < 0.0f) val = 1.0f;
+    return val >= 2147483648.0f ? 2147483647 : static_cast<int>(val);
+}
+
+template <int R, int C, int WK>
+struct MMCfg {
+    static constexpr int LM = 8, LN = 8;
+    static constexpr int TM = LM * R, TN = LN * C;
+    static constexpr int NT = 64 * WK;
+    static constexpr int XR = TM + 1, WR = TN + 1;  // odd row counts: conflict-free staging writes
+    static constexpr int TNP = TN + 8;              // reduction row pitch (words)
+    static constexpr int RED_BYTES = WK * TM * TNP * 4;
+    static constexpr int FLAG_BYTES = 2 * 32 * 8;   // double-buffered per-plane occupancy bitmaps
+};
+
+template <int R, int C, int WK>
+__host__ __device__ constexpr size_t mm_lds_bytes(int ab, int wb, int qc) {
+    using Cfg = MMCfg<R, C, WK>;
+    size_t stage = static_cast<size_t>(ab * Cfg::XR + wb * Cfg::WR) * qc * 16;
+    size_t body = stage > static_cast<size_t>(Cfg::RED_BYTES) ? stage : Cfg::RED_BYTES;
+    return Cfg::FLAG_BYTES + body;
+}
+
+// One output tile (tm, tn) of one problem. All threads of the workgroup call this.
+template <int R, int C, int WK, bool ZS>
+__device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &sh, int tm, int tn,
+                                        int tiles_m, int tiles_n, unsigned char *smem) {
+    using Cfg = MMCfg<R, C, WK>;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::NT, XR = Cfg::XR, WR = Cfg::WR,
+                  TNP = Cfg::TNP;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wk = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane >> 3, ln = lane & 7;
+
+    const int M = pr.M, K = pr.K, N = pr.N;
+    const int kq = step128(K);                   // k-quads per packed row
+    const unsigned long long kw = static_cast<unsigned long long>(kq) * 4;
+    const unsigned long long x_plane = static_cast<unsigned long long>(pad8(M)) * kw;
+    const unsigned long long w_plane = static_cast<unsigned long long>(pr.w_lines) * kw;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int qc = sh.qc, lqc = 31 - __clz(qc);
+    const int qw = qc / WK;                      // k-quads per wave per chunk
+
+    unsigned long long *flags = reinterpret_cast<unsigned long long *>(smem);  // [2][32]
+    uint4 *Xs = reinterpret_cast<uint4 *>(smem + Cfg::FLAG_BYTES);
+    uint4 *Ws = Xs + static_cast<size_t>(sh.ab) * qc * XR;
+    int *red = reinterpret_cast<int *>(smem + Cfg::FLAG_BYTES);
+
+    uint32_t tot[R][C];  // unsigned: the reference's int32 accumulation wraps on overflow
+#pragma unroll
+    for (int i = 0; i < R; i++)
+#pragma unroll
+        for (int j = 0; j < C; j++) tot[i][j] = 0u;
+
+    if (ZS && tid < 64) flags[tid] = 0ull;
+    __syncthreads();
+
+    int chunk_id = 0;
+    for (int pa0 = 0; pa0 < sh.a; pa0 += sh.ab) {
+        const int na = min(sh.ab, sh.a - pa0);
+        for (int pw0 = 0; pw0 < sh.w; pw0 += sh.wb) {
+            const int nw = min(sh.wb, sh.w - pw0);
+            for (int q0 = 0; q0 < kq; q0 += qc, chunk_id++) {
+                unsigned long long *fl = flags + (chunk_id & 1) * 32;
+                // ---- stage X planes [pa0, pa0+na): granule g -> (plane, row, q), q fastest ----
+                const int xg_total = na * TM * qc;
+                for (int g = tid; g < xg_total; g += NT) {
+                    const int q = g & (qc - 1);
+                    const int t = g >> lqc;
+                    const int row = t & (TM - 1);
+                    const int pl = t / TM;
+                    const int grow = m0 + row, gq = q0 + q;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (grow < M && gq < kq)
+                        v = ldg4(pr.X, pr.x_words,
+                                 (pa0 + pl) * x_plane + static_cast<unsigned long long>(grow) * kw +
+                                     static_cast<unsigned long long>(gq) * 4);
+                    Xs[(static_cast<size_t>(pl) * qc + q) * XR + row] = v;
+                    if (ZS) {
+                        // when TM*qc is a multiple of 64 all lanes of a wave are in the same
+                        // plane and lane l holds k-quad (l & (qc-1)): fold the ballot to one
+                        // bit per k-quad and OR it into the plane's bitmap.
+                        unsigned long long f = __ballot((v.x | v.y | v.z | v.w) != 0u);
+                        if (TM * qc >= 64) {
+                            if (qc <= 32) f |= f >> 32;
+                            if (qc <= 16) f |= f >> 16;
+                            if (qc <= 8) f |= f >> 8;
+                            if (qc <= 4) f |= f >> 4;
+                            if (qc <= 2) f |= f >> 2;
+                            if (qc <= 1) f |= f >> 1;
+                            if (qc < 64) f &= (1ull << qc) - 1ull;
+                            if (lane == 0 && f) atomicOr(&fl[pl], f);
+                        } else {
+                            // TM * qc == 32 (qc == 1): each 32-lane half is one plane
+                            const uint32_t h = lane < 32 ? static_cast<uint32_t>(f) : static_cast<uint32_t>(f >> 32);
+                            if ((lane & 31) == 0 && h) atomicOr(&fl[pl], 1ull);
+                        }
+                    }
+                }
+                // ---- stage W planes [pw0, pw0+nw) ----
+                const int wg_total = nw * TN * qc;
+                for (int g = tid; g < wg_total; g += NT) {
+                    const int q = g & (qc - 1);
+                    const int t = g >> lqc;
+                    const int row = t & (TN - 1);
+                    const int pl = t / TN;
+                    const int gline = n0 + row, gq = q0 + q;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (gline < N && gq < kq)
+                        v = ldg4(pr.W, pr.w_words,
+                                 (pw0 + pl) * w_plane + static_cast<unsigned long long>(gline) * kw +
+                                     static_cast<unsigned long long>(gq) * 4);
+                    Ws[(static_cast<size_t>(pl) * qc + q) * WR + row] = v;
+                }
+                __syncthreads();
+                if (ZS && tid < 32) flags[((chunk_id + 1) & 1) * 32 + tid] = 0ull;
+
+                // ---- compute: this wave's k-quads [wk*qw, wk*qw+qw) of the chunk ----
+                const int qlo = wk * qw;
+                const int qn = min(qc, kq - q0);  // k-quads of this chunk that exist
+                for (int pa = 0; pa < na; pa++) {
+                    unsigned long long f = ~0ull;
+                    if (ZS) {
+                        const unsigned long long fv = fl[pa];
+                        const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(fv));
+                        const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(fv >> 32));
+                        f = (static_cast<unsigned long long>(hi) << 32) | lo;
+                        const unsigned long long mine =
+                            (qw >= 64 ? ~0ull : ((1ull << qw) - 1ull)) << qlo;
+                        if ((f & mine) == 0ull) continue;  // whole X plane slice is zero
+                    }
+                    for (int pw = 0; pw < nw; pw++) {
+                        uint32_t part[R][C];
+#pragma unroll
+                        for (int i = 0; i < R; i++)
+#pragma unroll
+                            for (int j = 0; j < C; j++) part[i][j] = 0u;
+                        for (int qq = 0; qq < qw; qq++) {
+                            const int q = qlo + qq;
+                            if (q >= qn) break;                      // past the end of K
+                            if (ZS && !((f >> q) & 1ull)) continue;  // zero X tile: skip
+                            const uint4 *xp = Xs + (static_cast<size_t>(pa) * qc + q) * XR + lm;
+                            const uint4 *wp = Ws + (static_cast<size_t>(pw) * qc + q) * WR + ln;
+                            uint4 xg[R], wg[C];
+#pragma unroll
+                            for (int i = 0; i < R; i++) xg[i] = xp[i * Cfg::LM];
+#pragma unroll
+                            for (int j = 0; j < C; j++) wg[j] = wp[j * Cfg::LN];
+#pragma unroll
+                            for (int i = 0; i < R; i++)
+#pragma unroll
+                                for (int j = 0; j < C; j++) {
+                                    part[i][j] += __popc(xg[i].x & wg[j].x);
+                                    part[i][j] += __popc(xg[i].y & wg[j].y);
+                                    part[i][j] += __popc(xg[i].z & wg[j].z);
+                                    part[i][j] += __popc(xg[i].w & wg[j].w);
+                                }
+                        }
+                        const int s = pa0 + pa + pw0 + pw;  // reference kernel.h:295,340
+                        if (s < 32) {
+#pragma unroll
+                            for (int i = 0; i < R; i++)
+#pragma unroll
+                                for (int j = 0; j < C; j++)
+                                    tot[i][j] += part[i][j] << s;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- in-workgroup split-K reduction through LDS ----
+#pragma unroll
+    for (int i = 0; i < R; i++)
+#pragma unroll
+        for (int j = 0; j < C; j++)
+            red[(wk * TM + lm + i * Cfg::LM) * TNP + ln + j * Cfg::LN] = static_cast<int>(tot[i][j]);
+    __syncthreads();
+
+    const bool last_n = tn == tiles_n - 1, last_m = tm == tiles_m - 1;
+    if (sh.mode == 2) {
+        // float32 [M,N] (reference kernel.h:915-930)
+        float *out = static_cast<float *>(pr.out);
+        for (int e = tid; e < TM * TN; e += NT) {
+            const int row = e / TN, col = e % TN;
+            int v = 0;
+#pragma unroll
+            for (int k = 0; k < WK; k++) v += red[(k * TM + row) * TNP + col];
+            const int m = m0 + row, n = n0 + col;
+            if (m < M && n < N) out[static_cast<size_t>(m) * N + n] = static_cast<float>(v);
+        }
+    } else if (sh.mode == 0) {
+        // rows layout [ob][PAD8(M)][STEP128(N)*4] (reference kernel.h:357-389)
+        uint32_t *out = static_cast<uint32_t *>(pr.out);
+        const int rows_pad = pad8(M), row_words = step128(N) * 4;
+        const size_t oplane = static_cast<size_t>(rows_pad) * row_words;
+        for (int e = tid; e < TM * TN; e += NT) {
+            const int row = e / TN, col = e % TN;  // each 32-lane half: 32 columns of one row
+            int v = 0;
+#pragma unroll
+            for (int k = 0; k < WK; k++) v += red[(k * TM + row) * TNP + col];
+            const int m = m0 + row, n = n0 + col;
+            const int qv = (m < M && n < N) ? requant(v, sh.maxv, sh.maxm1) : 0;
+            for (int p = 0; p < sh.ob; p++) {
+                const unsigned long long mk = __ballot((qv >> p) & 1);
+                if ((lane & 31) == 0 && m < rows_pad) {
+                    const uint32_t half = lane ? static_cast<uint32_t>(mk >> 32) : static_cast<uint32_t>(mk);
+                    out[p * oplane + static_cast<size_t>(m) * row_words + (n >> 5)] = __brev(half);
+                }
+            }
+        }
+        if (last_n) {  // zero the row words beyond the last column tile
+            const int w0 = tiles_n * (TN / 32), nz = row_words - w0;
+            for (int e = tid; e < sh.ob * TM * nz; e += NT) {
+                const int wi = e % nz, row = (e / nz) % TM, p = e / (nz * TM);
+                if (m0 + row < rows_pad)
+                    out[p * oplane + static_cast<size_t>(m0 + row) * row_words + w0 + wi] = 0u;
+            }
+        }
+    } else {
+        // cols layout [ob][PAD128(N)][STEP128(M)*4] (intended semantics of kernel.h:651-810)
+        uint32_t *out = static_cast<uint32_t *>(pr.out);
+        const int lines = pad128(N), line_words = step128(M) * 4;
+        const size_t oplane = static_cast<size_t>(lines) * line_words;
+        for (int e = tid; e < TM * TN; e += NT) {
+            const int row = e % TM, col = e / TM;  // each 32-lane half: 32 rows of one column
+            int v = 0;
+#pragma unroll
+            for (int k = 0; k < WK; k++) v += red[(k * TM + row) * TNP + col];
+            const int m = m0 + row, n = n0 + col;
+            const int qv = (m < M && n < N) ? requant(v, sh.maxv, sh.maxm1) : 0;
+            for (int p = 0; p < sh.ob; p++) {
+                const unsigned long long mk = __ballot((qv >> p) & 1);
+                if ((lane & 31) == 0 && n < lines && (m >> 5) < line_words) {
+                    const uint32_t half = lane ? static_cast<uint32_t>(mk >> 32) : static_cast<uint32_t>(mk);
+                    out[p * oplane + static_cast<size_t>(n) * line_words + (m >> 5)] = __brev(half);
+                }
+            }
+        }
+        // zero what no tile computes: lines past the last column tile, words past the last row tile
+        const int l_end = last_n ? lines : min(lines, n0 + TN);
+        const int w_core0 = m0 >> 5, w_core1 = min(line_words, (m0 + TM) >> 5);
+        const int w_end = last_m ? line_words : w_core1;
+        const int nl = l_end - n0, nwd = w_end - w_core0;
+        for (int e = tid; e < sh.ob * nl * nwd; e += NT) {
+            const int wi = w_core0 + e % nwd, line = n0 + (e / nwd) % nl, p = e / (nwd * nl);
+            const bool core = line < n0 + TN && wi < w_core1;
+            if (!core) out[p * oplane + static_cast<size_t>(line) * line_words + wi] = 0u;
+        }
+    }
+}
+
+template <int R, int C, int WK, bool ZS>
+__global__ __launch_bounds__(64 * WK) void k_bitmm(qgtc_problem pr, MMShape sh, int tiles_m,
+                                                   int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tile = blockIdx.x;
+    mm_tile<R, C, WK, ZS>(pr, sh, tile / tiles_n, tile % tiles_n, tiles_m, tiles_n, smem);
+}
+
+// grouped launch: blockIdx.y = problem, blockIdx.x = tile (surplus tiles exit at once)
+template <int R, int C, int WK, bool ZS>
+__global__ __launch_bounds__(64 * WK) void k_bitmm_batched(const qgtc_problem *__restrict__ prs,
+                                                           MMShape sh) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using Cfg = MMCfg<R, C, WK>;
+    const qgtc_problem pr = prs[blockIdx.y];
+    const int tiles_m = (pr.M + Cfg::TM - 1) / Cfg::TM, tiles_n = (pr.N + Cfg::TN - 1) / Cfg::TN;
+    const int tile = blockIdx.x;
+    if (tile >= tiles_m * tiles_n) return;
+    mm_tile<R, C, WK, ZS>(pr, sh, tile / tiles_n, tile % tiles_n, tiles_m, tiles_n, smem);
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launch plumbing
+// ------------------------------------------------------------------------------------------
+constexpr size_t kLdsBudget = 80 * 1024;  // keeps two workgroups per CU resident (160 KiB LDS)
+
+struct Plan {
+    int wk;  // waves per workgroup (split-K factor)
+    MMShape sh;
+    size_t lds;
+};
+
+inline int pow2_floor(int x) {
+    int p = 1;
+    while (p * 2 <= x) p *= 2;
+    return p;
+}
+
+template <int R, int C, int WK>
+bool plan_for(int K, int a, int w, int ob, int mode, Plan *pl) {
+    const int kq = step128(K);
+    MMShape sh{};
+    sh.a = a;
+    sh.w = w;
+    sh.ob = ob;
+    sh.mode = mode;
+    sh.maxv = std::ldexp(1.0f, ob);
+    sh.maxm1 = sh.maxv - 1.0f;
+    // k-quads per chunk: power of two, >= max(8, WK), no larger than needed, within the budget
+    int qc = 64;
+    const int qmin = WK;
+    while (qc > qmin && qc / 2 >= kq) qc /= 2;
+    int ab = a > 32 ? 32 : a, wb = w > 32 ? 32 : w;
+    for (;;) {
+        if (mm_lds_bytes<R, C, WK>(ab, wb, qc) <= kLdsBudget) break;
+        if (qc > qmin) qc /= 2;
+        else if (wb >= ab && wb > 1) wb = (wb + 1) / 2;
+        else if (ab > 1) ab = (ab + 1) / 2;
+        else return false;
+    }
+    sh.qc = qc;
+    sh.ab = ab;
+    sh.wb = wb;
+    pl->wk = WK;
+    pl->sh = sh;
+    pl->lds = mm_lds_bytes<R, C, WK>(ab, wb, qc);
+    return true;
+}
+
+template <int R, int C, int WK, bool ZS>
+int launch_single(const qgtc_problem &pr, const Plan &pl, hipStream_t st) {
+    using Cfg = MMCfg<R, C, WK>;
+    const int tiles_m = (pr.M + Cfg::TM - 1) / Cfg::TM, tiles_n = (pr.N + Cfg::TN - 1) / Cfg::TN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm<R, C, WK, ZS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(kLdsBudget)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_bitmm<R, C, WK, ZS>), dim3(tiles_m * tiles_n), dim3(Cfg::NT), pl.lds, st,
+                       pr, pl.sh, tiles_m, tiles_n);
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
+template <int R, int C, int WK, bool ZS>
+int launch_batched(const qgtc_problem *prs, int count, int max_M, int max_N, const Plan &pl,
+                   hipStream_t st) {
+    using Cfg = MMCfg<R, C, WK>;
+    const int tiles = ((max_M + Cfg::TM - 1) / Cfg::TM) * ((max_N + Cfg::TN - 1) / Cfg::TN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_batched<R, C, WK, ZS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(kLdsBudget)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_bitmm_batched<R, C, WK, ZS>), dim3(tiles, count), dim3(Cfg::NT), pl.lds,
+                       st, prs, pl.sh);
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
+// Pick the split-K factor from the K extent: short K (feature/weight products, K <= 512 bits)
+// has too few k-quads to feed 8 waves.
+inline int choose_wk(int K) {
+    const int kq = step128(K);
+    if (kq >= 8) return 8;
+    if (kq >= 4) return 4;
+    if (kq >= 2) return 2;
+    return 1;
+}
+
+template <bool ZS>
+int dispatch_single(const qgtc_problem &pr, int K, int a, int w, int ob, int mode, hipStream_t st) {
+    Plan pl;
+    switch (choose_wk(K)) {
+        case 8:
+            if (!plan_for<4, 4, 8>(K, a, w, ob, mode, &pl)) return QGTC_EINVAL;
+            return launch_single<4, 4, 8, ZS>(pr, pl, st);
+        case 4:
+            if (!plan_for<4, 4, 4>(K, a, w, ob, mode, &pl)) return QGTC_EINVAL;
+            return launch_single<4, 4, 4, ZS>(pr, pl, st);
+        case 2:
+            if (!plan_for<4, 4, 2>(K, a, w, ob, mode, &pl)) return QGTC_EINVAL;
+            return launch_single<4, 4, 2, ZS>(pr, pl, st);
+        default:
+            if (!plan_for<4, 4, 1>(K, a, w, ob, mode, &pl)) return QGTC_EINVAL;
+            return launch_single<4, 4, 1, ZS>(pr, pl, st);
+    }
+}
+
+template <bool ZS>
+int dispatch_batched(const qgtc_problem *prs, int count, int max_M, int max_N, int K_hint, int a,
+                     int w, int ob, int mode, hipStream_t st) {
+    Plan pl;
+    switch (choose_wk(K_hint)) {
+        case 8:
+            if (!plan_for<4, 4, 8>(K_hint, a, w, ob, mode, &pl)) return QGTC_EINVAL;
+            return launch_batched<4, 4, 8, ZS>(prs, count, max_M, max_N, pl, st);
+        case 4:
+            if (!plan_for<4, 4, 4>(K_hint, a, w, ob, mode, &pl)) return QGTC_EINVAL;
+            return launch_batched<4, 4, 4, ZS>(prs, count, max_M, max_N, pl, st);
+        case 2:
+            if (!plan_for<4, 4, 2>(K_hint, a, w, ob, mode, &pl)) return QGTC_EINVAL;
+            return launch_batched<4, 4, 2, ZS>(prs, count, max_M, max_N, pl, st);
+        default:
+            if (!plan_for<4, 4, 1>(K_hint, a, w, ob, mode, &pl)) return QGTC_EINVAL;
+            return launch_batched<4, 4, 1, ZS>(prs, count, max_M, max_N, pl, st);
+    }
+}
+
+int check_mm_args(const uint32_t *X, const uint32_t *W, const void *out, int M, int K, int N,
+                  int a, int w) {
+    if (!X || !W || !out) return QGTC_EINVAL;
+    if (M <= 0 || K <= 0 || N <= 0) return QGTC_EINVAL;
+    if (!bits_ok(a) || !bits_ok(w)) return QGTC_EINVAL;
+    if (!aligned16(X) || !aligned16(W)) return QGTC_EALIGN;
+    return QGTC_OK;
+}
+
+int grid_for(size_t work_items, int per_block) {
+    size_t blocks = (work_items + per_block - 1) / per_block;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 resident blocks, grid-stride the rest
+    return static_cast<int>(blocks);
+}
+
+}  // namespace
+
+// ============================================================================================
+// C-ABI
+// ============================================================================================
+extern "C" {
+
+int qgtc_abi_version(void) { return QGTC_ABI_VERSION; }
+
+const char *qgtc_strerror(int code) {
+    switch (code) {
+        case QGTC_OK: return "ok";
+        case QGTC_EINVAL: return "invalid argument (dimension, bit width or NULL pointer)";
+        case QGTC_ESIZE: return "output buffer too small";
+        case QGTC_EALIGN: return "packed tensor pointer is not 16-byte aligned";
+        case QGTC_EHIP: return "HIP runtime error";
+        case QGTC_ENODEVICE: return "no usable gfx950 device";
+        default: return "unknown error";
+    }
+}
+
+const char *qgtc_last_hip_error(void) { return g_hip_err; }
+
+size_t qgtc_rows_words(int H, int W, int nbits) {
+    return static_cast<size_t>(nbits) * pad8(H) * step128(W) * 4u;
+}
+
+size_t qgtc_cols_words(int H, int W, int nbits, int output_layer) {
+    return static_cast<size_t>(nbits) * step128(H) * 4u * (output_layer ? pad8(W) : pad128(W));
+}
+
+int qgtc_val2bit(const float *x, int H, int W, int nbits, int col_major, int output_layer,
+                 uint32_t *out, size_t out_words, void *stream) {
+    if (!x || !out || H <= 0 || W <= 0 || !bits_ok(nbits)) return QGTC_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float ub = std::ldexp(1.0f, nbits), ubm1 = ub - 1.0f;
+    if (!col_major) {
+        if (out_words < qgtc_rows_words(H, W, nbits)) return QGTC_ESIZE;
+        const int rows_pad = pad8(H), row_words = step128(W) * 4;
+        const size_t units = static_cast<size_t>(rows_pad) * ((row_words + 7) / 8);
+        hipLaunchKernelGGL(k_val2bit_rows, dim3(grid_for(units, 4)), dim3(256), 0, st, x, H, W, nbits,
+                           ub, ubm1, out, rows_pad, row_words);
+    } else {
+        if (out_words < qgtc_cols_words(H, W, nbits, output_layer)) return QGTC_ESIZE;
+        const int lines = output_layer ? pad8(W) : pad128(W), line_words = step128(H) * 4;
+        const size_t units = static_cast<size_t>((lines + 63) / 64) * line_words;
+        const dim3 g(grid_for(units, 4)), b(256);
+        if (nbits <= 1)
+            hipLaunchKernelGGL(k_val2bit_cols<1>, g, b, 0, st, x, H, W, nbits, ub, ubm1, out, lines, line_words);
+        else if (nbits <= 2)
+            hipLaunchKernelGGL(k_val2bit_cols<2>, g, b, 0, st, x, H, W, nbits, ub, ubm1, out, lines, line_words);
+        else if (nbits <= 4)
+            hipLaunchKernelGGL(k_val2bit_cols<4>, g, b, 0, st, x, H, W, nbits, ub, ubm1, out, lines, line_words);
+        else if (nbits <= 8)
+            hipLaunchKernelGGL(k_val2bit_cols<8>, g, b, 0, st, x, H, W, nbits, ub, ubm1, out, lines, line_words);
+        else
+            hipLaunchKernelGGL(k_val2bit_cols<32>, g, b, 0, st, x, H, W, nbits, ub, ubm1, out, lines, line_words);
+    }
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
+int qgtc_bit2val(const uint32_t *bits, size_t bits_words, int nbits, int H, int W, int col_major,
+                 int output_layer, int32_t *out, void *stream) {
+    if (!bits || !out || H <= 0 || W <= 0 || !bits_ok(nbits)) return QGTC_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    size_t plane;
+    int line_words;
+    if (col_major) {
+        line_words = step128(H) * 4;
+        plane = static_cast<size_t>(output_layer ? pad8(W) : pad128(W)) * line_words;
+    } else {
+        line_words = step128(W) * 4;
+        plane = static_cast<size_t>(pad8(H)) * line_words;
+    }
+    const size_t total = static_cast<size_t>(H) * W;
+    hipLaunchKernelGGL(k_bit2val, dim3(grid_for(total, 256)), dim3(256), 0, st, bits,
+                       static_cast<unsigned long long>(bits_words), nbits, H, W, col_major, plane,
+                       line_words, out);
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
+int qgtc_bitmm2bit(const uint32_t *X, size_t x_words, const uint32_t *W, size_t w_words, int M,
+                   int K, int N, int bit1, int bit2, int output_bit, uint32_t *out,
+                   size_t out_words, unsigned flags, void *stream) {
+    int rc = check_mm_args(X, W, out, M, K, N, bit1, bit2);
+    if (rc != QGTC_OK) return rc;
+    if (!bits_ok(output_bit)) return QGTC_EINVAL;
+    const bool cols = flags & QGTC_OUT_COLS;
+    const size_t need = cols ? qgtc_cols_words(M, N, output_bit, 0) : qgtc_rows_words(M, N, output_bit);
+    if (out_words < need) return QGTC_ESIZE;
+    qgtc_problem pr{X, W, out, x_words, w_words, M, K, N, pad128(N)};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (flags & QGTC_NO_ZERO_SKIP)
+        return dispatch_single<false>(pr, K, bit1, bit2, output_bit, cols ? 1 : 0, st);
+    return dispatch_single<true>(pr, K, bit1, bit2, output_bit, cols ? 1 : 0, st);
+}
+
+int qgtc_bitmm2int(const uint32_t *X, size_t x_words, const uint32_t *W, size_t w_words, int M,
+                   int K, int N, int bit1, int bit2, int pad_128, float *out, size_t out_elems,
+                   unsigned flags, void *stream) {
+    int rc = check_mm_args(X, W, out, M, K, N, bit1, bit2);
+    if (rc != QGTC_OK) return rc;
+    if (out_elems < static_cast<size_t>(M) * N) return QGTC_ESIZE;
+    qgtc_problem pr{X, W, out, x_words, w_words, M, K, N, pad_128 ? pad128(N) : pad8(N)};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (flags & QGTC_NO_ZERO_SKIP) return dispatch_single<false>(pr, K, bit1, bit2, 1, 2, st);
+    return dispatch_single<true>(pr, K, bit1, bit2, 1, 2, st);
+}
+
+int qgtc_bitmm2bit_profile(const uint32_t *X, size_t x_words, const uint32_t *W, size_t w_words,
+                           int M, int K, int N, int bit1, int bit2, int output_bit, uint32_t *out,
+                           size_t out_words, unsigned flags, int reps, float *elapsed_ms,
+                           void *stream) {
+    if (reps <= 0 || !elapsed_ms) return QGTC_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // one untimed launch validates the arguments and sets the kernel attributes
+    int rc = qgtc_bitmm2bit(X, x_words, W, w_words, M, K, N, bit1, bit2, output_bit, out, out_words,
+                            flags, stream);
+    if (rc != QGTC_OK) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int i = 0; i < reps && rc == QGTC_OK; i++)
+        rc = qgtc_bitmm2bit(X, x_words, W, w_words, M, K, N, bit1, bit2, output_bit, out, out_words,
+                            flags, stream);
+    hipError_t e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != QGTC_OK) return rc;
+    if (e != hipSuccess) return hip_fail(e, "profile events");
+    *elapsed_ms = ms;
+    return QGTC_OK;
+}
+
+int qgtc_tile_counters(const uint32_t *X, size_t x_words, int M, int K, int N, int bit1, int bit2,
+                       uint64_t *counters, void *stream) {
+    if (!X || !counters || M <= 0 || K <= 0 || N <= 0 || !bits_ok(bit1) || !bits_ok(bit2))
+        return QGTC_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(counters, 0, 2 * sizeof(uint64_t), st));
+    const unsigned long long gdx = step8(M), gdy = step8(N), gdk = step128(K);
+    const unsigned long long total = gdx * gdy * gdk * bit1 * bit2;
+    const size_t items = static_cast<size_t>(bit1) * gdx * gdk;
+    hipLaunchKernelGGL(k_tile_counters, dim3(grid_for(items, 256)), dim3(256), 0, st, X,
+                       static_cast<unsigned long long>(x_words), M, K, bit1, total,
+                       gdy * static_cast<unsigned long long>(bit2),
+                       reinterpret_cast<unsigned long long *>(counters));
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
+int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int max_K, int max_N,
+                       int bit1, int bit2, int output_bit, int mode, unsigned flags,
+                       void *stream) {
+    if (!problems || count <= 0 || max_M <= 0 || max_K <= 0 || max_N <= 0) return QGTC_EINVAL;
+    if (!bits_ok(bit1) || !bits_ok(bit2) || mode < 0 || mode > 2) return QGTC_EINVAL;
+    if (mode != 2 && !bits_ok(output_bit)) return QGTC_EINVAL;
+    if (count > 65535) return QGTC_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // K is per problem; the split-K factor and chunk size are chosen for the longest K. Any
+    // choice is correct; this only affects speed.
+    const int k_hint = max_K;
+    if (flags & QGTC_NO_ZERO_SKIP)
+        return dispatch_batched<false>(problems, count, max_M, max_N, k_hint, bit1, bit2,
+                                       mode == 2 ? 1 : output_bit, mode, st);
+    return dispatch_batched<true>(problems, count, max_M, max_N, k_hint, bit1, bit2,
+                                  mode == 2 ? 1 : output_bit, mode, st);
+}
+
+}  // extern "C"

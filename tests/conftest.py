@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (plain C via ctypes). Test infrastructure only."""
+    from oracle.qgtc_oracle import Oracle
+
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def qgtc():
+    """The compiled QGTC extension on a real GPU. No fallback: a missing .so is an error."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    import QGTC
+
+    return QGTC
