@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the QGTC bit-GEMM hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE bitMM2Bit launch over the whole workload named in BASELINE.json's north star and
+BASELINE.md §1's bold row: a 1-bit 4096x4096 adjacency times a 1-bit 4096x64 feature matrix
+(M=K=4096, N=64, output 1 bit), operands already bit-packed and resident in HBM. The metric is the
+reference's own (QGTC_device.cu:420-422): effective tera-ops = 2*M*K*N per launch / time. Inputs
+are seeded random bits (the reference's all-ones inputs are reported beside it in `extras`).
+
+With N>1 ranks every GPU runs its own copy of the workload (cluster batches are independent, so
+the path shards with no data-path collective): weak scaling, value = all ranks' ops / max time;
+RCCL is used only to take the max time and to gather per-rank result checksums.
+
+Rank 0 prints one JSON line (contract fields + `roofline`, `cpu_baseline`, `extras`).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+REF_TFLOPS_4096_64 = {1: 46.768, 2: 26.818, 4: 14.196, 8: 7.324}
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+# VALU issue rate of the v_and_b32 + v_bcnt_u32_b32 pair measured on MI355X with
+# tools/valu_peak.hip (4.2e13 lane-instr/s at 8 waves/SIMD); one pair = 32 bit-MACs = 64 bit-ops.
+VALU_PEAK_BITOPS = 4.2e13 * 32
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--bits", type=int, default=1, help="feature bit width w of the headline workload")
+    p.add_argument("--no-extras", action="store_true", help="skip the width sweep / epoch / CPU legs")
+    p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget")
+    return p.parse_args()
+
+
+def make_workload(Q, M, K, N, w, device, seed, ones=False):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    if ones:      # 2_7c_QGTC_GEMM_INT8.py:6-12
+        A = torch.ones((M, K))
+        X = torch.ones((K, N))
+    else:
+        A = (torch.rand((M, K), generator=g) < 0.5).float()
+        X = torch.randint(0, 2 ** w, (K, N), generator=g).float()
+    bit_A = Q.val2bit(A.to(device), 1, False, False)
+    bit_X = Q.val2bit(X.to(device), w, True, False)
+    return A, X, bit_A, bit_X
+
+
+def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier):
+    """warmup untimed launches, then EXACTLY `steps` launches between barrier+synchronize pairs.
+    Returns (wall seconds, mean kernel-stream time per launch in seconds from HIP events recorded
+    on the stream the kernels are launched on)."""
+    Q.bitMM2Bit_enqueue(out, bit_A, bit_X, M, K, N, 1, w, w, max(warmup, 1))
+    torch.cuda.synchronize()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    Q.bitMM2Bit_enqueue(out, bit_A, bit_X, M, K, N, 1, w, w, steps)
+    ev1.record()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    return t1 - t0, ev0.elapsed_time(ev1) * 1e-3 / steps
+
+
+def cpu_baseline(M, K, N, w, A, X, budget_s):
+    """The C oracle (a port, not the reference: the reference has no CPU bit path) on the host
+    cores, same workload, repeated until ~budget_s of CPU time."""
+    from oracle.qgtc_oracle import Oracle
+
+    try:
+        O = Oracle(native=True, out_dir="/tmp")   # -march=native build made on this host
+    except Exception:
+        O = Oracle()
+    bx = O.val2bit(A.numpy(), 1, False, False)
+    bw = O.val2bit(X.numpy(), w, True, False)
+    t0 = time.perf_counter()
+    O.bitmm2bit(bx, bw, M, K, N, 1, w, w)
+    one = time.perf_counter() - t0
+    reps = max(1, min(2000, int(budget_s / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ref = O.bitmm2bit(bx, bw, M, K, N, 1, w, w)
+    dt = time.perf_counter() - t0
+    return {"value": round(2.0 * M * K * N * reps / dt / 1e12, 4), "unit": "effective TOPS",
+            "cores": O.num_threads(), "kind": "port",
+            "sample": f"full {M}x{K}x{N} {w}-bit workload x {reps} reps ({dt:.1f} s, OpenMP C oracle)"}, ref
+
+
+def epoch_leg(Q, rank, world, device_index):
+    """Cluster-GCN epoch (BASELINE.json configs 3/5): ogbn-arxiv-sized synthetic graph, 75 batches,
+    2-bit, hidden 128; batches sharded round-robin over the ranks; per-batch launches (the
+    reference's structure) and grouped launches."""
+    from qgtc_ppopp22_amd import dist as D, driver, graph as G
+
+    base = ["--dataset", "ogbn-arxiv", "--n-hidden", "128", "--n-classes", "10", "--bit_width", "2",
+            "--use_QGTC", "--gpu", str(device_index), "--quiet", "--n-epochs", "20"]
+    graph = G.make_graph("ogbn-arxiv", 1500)
+    ids = D.shard_round_robin(1500 // 20, rank, world)
+    res = {}
+    for name, extra in (("per_batch_reference_chain", []), ("batched_reference_chain", ["--batched"]),
+                        ("batched_correct_chain", ["--batched", "--chain", "correct"])):
+        args = driver.build_parser().parse_args(base + extra)
+        driver.run(args, Q=Q, batch_ids=ids, graph=graph)          # warm-up (allocator, attributes)
+        D.barrier()
+        r = driver.run(args, Q=Q, batch_ids=ids, graph=graph)
+        res[name + "_ms"] = round(D.max_over_ranks(r["avg_epoch_ms"], torch.device("cuda", device_index)), 4)
+    if world > 1:   # the one exchange of the path: gather per-batch checksums (RCCL over xGMI)
+        outs = r["outs"]
+        local = torch.stack([torch.stack([o.double().sum(), torch.tensor(float(o.numel()), device=o.device,
+                                                                         dtype=torch.float64)]) for o in outs])
+        allsum = D.gather_batch_summaries(local, 1500 // 20, rank, world)
+        res["gathered_batches"] = int(allsum.size(0))
+    return res, graph
+
+
+def main():
+    args = parse()
+    from qgtc_ppopp22_amd import dist as D
+
+    rank, world, local = D.init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    import QGTC as Q
+
+    M = K = 4096
+    N, w = 64, args.bits
+    A, X, bit_A, bit_X = make_workload(Q, M, K, N, w, device, seed=3 + rank)
+    out = Q.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w)
+    wall, kern = time_steps(Q, out, bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier)
+    wall_max = D.max_over_ranks(wall, device)
+    eff_ops = 2.0 * M * K * N
+    value = world * args.steps * eff_ops / wall_max / 1e12
+
+    # result checksum of every rank, gathered over RCCL (the only collective of the path)
+    csum = torch.tensor([[float(out.to(torch.int64).sum().item())]], dtype=torch.float64, device=device)
+    sums = D.gather_batch_summaries(csum, world, rank, world) if world > 1 else csum
+
+    algo_bytes = 1 * M * K / 8 + w * K * N / 8 + w * M * N / 8      # a*M*K/8 + w*K*N/8 + ob*M*N/8
+    roofline = {"bound": "hbm", "kernel": "k_bitmm<4,4,8>", "achieved": round(algo_bytes / kern / 1e9, 2),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo_bytes / kern / 1e9 / HBM_PEAK_GBS, 5),
+                "traffic": None, "algorithmic_bytes_per_launch": int(algo_bytes),
+                "avg_launch_us": round(kern * 1e6, 3),
+                "valu": {"achieved_bitops": round(eff_ops * w / kern, 1), "peak_bitops": VALU_PEAK_BITOPS,
+                         "frac": round(eff_ops * w / kern / VALU_PEAK_BITOPS, 4),
+                         "note": "binding roofline of the popcount path: v_and_b32+v_bcnt_u32_b32 issue, peak measured by tools/valu_peak.hip"}}
+
+    line = {
+        "metric": "effective bit-GEMM TOPS (2*M*K*N/t), 1-bit A x %d-bit X, M=K=4096, N=64" % w,
+        "value": round(value, 3), "unit": "TOPS", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(wall_max * 1e3 / args.steps, 6),
+        "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": round(value / REF_TFLOPS_4096_64[w], 3) if w in REF_TFLOPS_4096_64 else None,
+        "dtype": "u32 bit-planes (AND+popcount into int32)", "data": "synthetic",
+        "config": {"workload": f"bitMM2Bit {M}x{K}x{N}, a=1, w={w}, ob={w} (BASELINE.json configs[1], 2_7c shape)",
+                   "inputs": "seeded Bernoulli(0.5) adjacency, uniform w-bit features, packed and resident in HBM",
+                   "parallelism": f"replica-per-GPU x{world}, no data-path collective"},
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        cb, ref = cpu_baseline(M, K, N, w, A, X, args.cpu_seconds)
+        line["cpu_baseline"] = cb
+        got = out.cpu().numpy().view(np.uint32).reshape(-1)
+        line["parity_vs_oracle"] = bool((got == ref).all())
+    extras = {}
+    if not args.no_extras:
+        if rank == 0 and world == 1:
+            sweep = {}
+            for ww in (1, 2, 4, 8):
+                for label, ones in (("random", False), ("ones", True)):
+                    _, _, ba, bx = make_workload(Q, M, K, N, ww, device, seed=3, ones=ones)
+                    Q.profile(ba, bx, M, K, N, 1, ww, ww, 20)
+                    ms = min(Q.profile(ba, bx, M, K, N, 1, ww, ww, 200) for _ in range(3))
+                    sweep[f"w{ww}_{label}"] = {"TOPS": round(eff_ops * 200 / (ms * 1e-3) / 1e12, 2),
+                                               "us_per_launch": round(ms * 1e3 / 200, 3),
+                                               "ref_sm86_TFLOPs": REF_TFLOPS_4096_64[ww]}
+            extras["width_sweep_4096x4096x64"] = sweep
+        ep, graph = epoch_leg(Q, rank, world, local)
+        extras["cluster_gcn_epoch_ogbn_arxiv_shape"] = ep
+        if rank == 0 and world == 1:
+            from oracle.dgl_cpu_baseline import graphsage_cpu_epoch
+            from qgtc_ppopp22_amd import graph as G
+
+            par = G.partition_list(graph, 1500)
+            graphsage_cpu_epoch(graph, par, 1500, 20, 128, 10, n_batches=2)
+            secs, nb = graphsage_cpu_epoch(graph, par, 1500, 20, 128, 10, n_batches=15)
+            extras["dgl_style_fp32_cpu_epoch_ms"] = {"value": round(secs * 1e3 * 75 / nb, 2), "cores": torch.get_num_threads(),
+                                                      "sample": f"{nb} of 75 batches, scaled x{75 / nb:.0f}",
+                                                      "kind": "port (torch-CPU GraphSAGE-sum x3; DGL not installable)"}
+    if world > 1:
+        extras["rank_checksums"] = [float(v) for v in sums.view(-1).tolist()]
+    line["extras"] = extras
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

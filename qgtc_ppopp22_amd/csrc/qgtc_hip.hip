@@ -209,6 +209,16 @@ __global__ __launch_bounds__(256) void k_tile_counters(const uint32_t *__restric
 // ------------------------------------------------------------------------------------------
 // the bit-GEMM
 // ------------------------------------------------------------------------------------------
+#ifdef QGTC_STAMPS  // diagnostic build only (tools/kbench.hip): per-phase s_memtime stamps
+__device__ unsigned long long g_stamps[1024 * 32];
+#define STAMP(slot)                                                                      \
+    do {                                                                                 \
+        if (threadIdx.x == 0 && (slot) < 32) g_stamps[blockIdx.x % 1024 * 32 + (slot)] = clock64(); \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 struct MMShape {           // per-launch constants
     int a, w, ob;          // planes of X, planes of W, output planes
     int mode;              // 0 rows-layout bits, 1 cols-layout bits, 2 float32
@@ -216,6 +226,13 @@ struct MMShape {           // per-launch constants
     int ab, wb;            // plane blocking (planes staged at once)
     float maxv, maxm1;     // 2^ob and 2^ob - 1 as float (requant)
 };
+
+// acc += popcount(x & w): v_and_b32 + v_bcnt_u32_b32 with the accumulator as the add operand
+// (hipcc otherwise emits v_bcnt(...,0) + v_add3_u32, 2.5 instructions per pair instead of 2).
+__device__ __forceinline__ void and_popc_acc(uint32_t &acc, uint32_t x, uint32_t w) {
+    const uint32_t t = x & w;
+    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(t));
+}
 
 __device__ __forceinline__ int requant(int c, float maxv, float maxm1) {
     // reference kernel.h:31-37 called as quantize(c, ob, 1<<ob, 0): float compare, then the
@@ -234,24 +251,46 @@ struct MMCfg {
     static constexpr int XR = TM + 1, WR = TN + 1;  // odd row counts: conflict-free staging writes
     static constexpr int TNP = TN + 8;              // reduction row pitch (words)
     static constexpr int RED_BYTES = WK * TM * TNP * 4;
-    static constexpr int FLAG_BYTES = 2 * 32 * 8;   // double-buffered per-plane occupancy bitmaps
+    static constexpr int GPT = 8;                   // granules a thread may prefetch per stage
 };
+
+// bytes of one LDS staging buffer (there are two)
+template <int R, int C, int WK>
+__host__ __device__ constexpr size_t mm_stage_bytes(int ab, int wb, int qc) {
+    using Cfg = MMCfg<R, C, WK>;
+    return static_cast<size_t>(ab * Cfg::XR + wb * Cfg::WR) * qc * 16;
+}
 
 template <int R, int C, int WK>
 __host__ __device__ constexpr size_t mm_lds_bytes(int ab, int wb, int qc) {
     using Cfg = MMCfg<R, C, WK>;
-    size_t stage = static_cast<size_t>(ab * Cfg::XR + wb * Cfg::WR) * qc * 16;
-    size_t body = stage > static_cast<size_t>(Cfg::RED_BYTES) ? stage : Cfg::RED_BYTES;
-    return Cfg::FLAG_BYTES + body;
+    size_t stage2 = 2 * mm_stage_bytes<R, C, WK>(ab, wb, qc);
+    size_t body = stage2 > static_cast<size_t>(Cfg::RED_BYTES) ? stage2 : Cfg::RED_BYTES;
+    return body;
 }
 
+// Position in the (X plane block, W plane block, K chunk) iteration space.
+struct MMCursor {
+    int pa0, pw0, q0;
+    bool valid;
+};
+
 // One output tile (tm, tn) of one problem. All threads of the workgroup call this.
+//
+// Software pipeline, one barrier per stage: while the waves compute stage s out of LDS buffer
+// s&1, the global loads of stage s+1 are in flight into registers (GPT granules per thread);
+// they are written to buffer (s+1)&1 at the top of the next iteration.
+//
+// Zero-tile skipping (ZS): before a wave spends R*C*4 AND+popcount pairs on a k-quad it ORs the
+// R granules each lane just read from LDS and ballots: if the whole TM x 128-bit X tile is zero
+// the wave skips the k-quad (wave-uniform scalar branch). For products with several W planes
+// the test is hoisted out of the plane loop (one pre-pass over the wave's k-quads per X plane).
 template <int R, int C, int WK, bool ZS>
 __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &sh, int tm, int tn,
                                         int tiles_m, int tiles_n, unsigned char *smem) {
     using Cfg = MMCfg<R, C, WK>;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::NT, XR = Cfg::XR, WR = Cfg::WR,
-                  TNP = Cfg::TNP;
+                  TNP = Cfg::TNP, GPT = Cfg::GPT;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wk = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -259,17 +298,99 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
 
     const int M = pr.M, K = pr.K, N = pr.N;
     const int kq = step128(K);                   // k-quads per packed row
-    const unsigned long long kw = static_cast<unsigned long long>(kq) * 4;
-    const unsigned long long x_plane = static_cast<unsigned long long>(pad8(M)) * kw;
-    const unsigned long long w_plane = static_cast<unsigned long long>(pr.w_lines) * kw;
+    const uint32_t kw = static_cast<uint32_t>(kq) * 4u;
+    const uint32_t x_plane = static_cast<uint32_t>(pad8(M)) * kw;  // < 2^32 (checked on the host)
+    const uint32_t w_plane = static_cast<uint32_t>(pr.w_lines) * kw;
     const int m0 = tm * TM, n0 = tn * TN;
     const int qc = sh.qc, lqc = 31 - __clz(qc);
     const int qw = qc / WK;                      // k-quads per wave per chunk
 
-    unsigned long long *flags = reinterpret_cast<unsigned long long *>(smem);  // [2][32]
-    uint4 *Xs = reinterpret_cast<uint4 *>(smem + Cfg::FLAG_BYTES);
-    uint4 *Ws = Xs + static_cast<size_t>(sh.ab) * qc * XR;
-    int *red = reinterpret_cast<int *>(smem + Cfg::FLAG_BYTES);
+    const uint32_t stage_granules = static_cast<uint32_t>(sh.ab * XR + sh.wb * WR) * qc;
+    uint4 *stage_base = reinterpret_cast<uint4 *>(smem);
+    int *red = reinterpret_cast<int *>(smem);
+
+    auto advance = [&](MMCursor &c) {
+        c.q0 += qc;
+        if (c.q0 >= kq) {
+            c.q0 = 0;
+            c.pw0 += sh.wb;
+            if (c.pw0 >= sh.w) {
+                c.pw0 = 0;
+                c.pa0 += sh.ab;
+                if (c.pa0 >= sh.a) c.valid = false;
+            }
+        }
+    };
+
+    // Per-thread slot table, computed once per tile: slot u of this thread is granule
+    // g = tid + u*NT of a (full) stage. X granules come first — (plane, row, k-quad) with the
+    // k-quad fastest, so consecutive lanes load consecutive 16 bytes of a packed row — then W.
+    // Only the stage origin (plane block, first k-quad) changes from stage to stage.
+    const int xg_full = sh.ab * TM * qc, total_full = xg_full + sh.wb * TN * qc;
+    const int nslots = (total_full + NT - 1) / NT;  // wave-uniform, <= GPT (plan_for)
+    uint32_t s_goff[GPT];  // word offset from the stage origin in X / W
+    uint32_t s_meta[GPT];  // bit0 X, bit1 W, bit2 row in range, bits 8..15 plane, bits 16.. k-quad
+#pragma unroll
+    for (int u = 0; u < GPT; u++) {
+        s_goff[u] = 0u;
+        s_meta[u] = 0u;
+        if (u >= nslots) continue;
+        const int g = tid + u * NT;
+        if (g < xg_full) {
+            const uint32_t q = g & (qc - 1), t = g >> lqc;
+            const uint32_t row = t & (TM - 1), pl = t / TM;
+            s_goff[u] = pl * x_plane + static_cast<uint32_t>(m0 + row) * kw + q * 4u;
+            s_meta[u] = 1u | ((m0 + static_cast<int>(row) < M) ? 4u : 0u) | (pl << 8) | (q << 16);
+        } else if (g < total_full) {
+            const uint32_t g2 = g - xg_full;
+            const uint32_t q = g2 & (qc - 1), t = g2 >> lqc;
+            const uint32_t row = t & (TN - 1), pl = t / TN;
+            s_goff[u] = pl * w_plane + static_cast<uint32_t>(n0 + row) * kw + q * 4u;
+            s_meta[u] = 2u | ((n0 + static_cast<int>(row) < N) ? 4u : 0u) | (pl << 8) | (q << 16);
+        }
+    }
+
+    // issue the global loads of one stage into registers; out-of-range rows / planes / k-quads /
+    // words read as zero.
+    uint4 pre[GPT];
+    auto issue = [&](const MMCursor &c) {
+        const int na = min(sh.ab, sh.a - c.pa0), nw = min(sh.wb, sh.w - c.pw0);
+        const unsigned long long xbase =
+            static_cast<unsigned long long>(c.pa0) * x_plane + static_cast<unsigned long long>(c.q0) * 4;
+        const unsigned long long wbase =
+            static_cast<unsigned long long>(c.pw0) * w_plane + static_cast<unsigned long long>(c.q0) * 4;
+#pragma unroll
+        for (int u = 0; u < GPT; u++) {
+            if (u >= nslots) break;
+            const uint32_t meta = s_meta[u];
+            const int pl = (meta >> 8) & 0xff, q = meta >> 16;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if ((meta & 4u) && c.q0 + q < kq) {
+                if ((meta & 1u) && pl < na) v = ldg4(pr.X, pr.x_words, xbase + s_goff[u]);
+                else if ((meta & 2u) && pl < nw) v = ldg4(pr.W, pr.w_words, wbase + s_goff[u]);
+            }
+            pre[u] = v;
+        }
+    };
+
+    MMCursor cur{0, 0, 0, true};
+    STAMP(0);
+    issue(cur);
+    STAMP(1);
+
+    // LDS granule index of each slot ([plane][k-quad][row], X block then W block); computed
+    // while the first loads are in flight
+    uint32_t s_loff[GPT];
+#pragma unroll
+    for (int u = 0; u < GPT; u++) {
+        const uint32_t meta = s_meta[u];
+        const uint32_t pl = (meta >> 8) & 0xff, q = meta >> 16;
+        const int g = tid + u * NT;
+        uint32_t loff = 0;
+        if (meta & 1u) loff = (pl * qc + q) * XR + ((g >> lqc) & (TM - 1));
+        else if (meta & 2u) loff = sh.ab * qc * XR + (pl * qc + q) * WR + (((g - xg_full) >> lqc) & (TN - 1));
+        s_loff[u] = loff;
+    }
 
     uint32_t tot[R][C];  // unsigned: the reference's int32 accumulation wraps on overflow
 #pragma unroll
@@ -277,124 +398,103 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
 #pragma unroll
         for (int j = 0; j < C; j++) tot[i][j] = 0u;
 
-    if (ZS && tid < 64) flags[tid] = 0ull;
-    __syncthreads();
-
-    int chunk_id = 0;
-    for (int pa0 = 0; pa0 < sh.a; pa0 += sh.ab) {
-        const int na = min(sh.ab, sh.a - pa0);
-        for (int pw0 = 0; pw0 < sh.w; pw0 += sh.wb) {
-            const int nw = min(sh.wb, sh.w - pw0);
-            for (int q0 = 0; q0 < kq; q0 += qc, chunk_id++) {
-                unsigned long long *fl = flags + (chunk_id & 1) * 32;
-                // ---- stage X planes [pa0, pa0+na): granule g -> (plane, row, q), q fastest ----
-                const int xg_total = na * TM * qc;
-                for (int g = tid; g < xg_total; g += NT) {
-                    const int q = g & (qc - 1);
-                    const int t = g >> lqc;
-                    const int row = t & (TM - 1);
-                    const int pl = t / TM;
-                    const int grow = m0 + row, gq = q0 + q;
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (grow < M && gq < kq)
-                        v = ldg4(pr.X, pr.x_words,
-                                 (pa0 + pl) * x_plane + static_cast<unsigned long long>(grow) * kw +
-                                     static_cast<unsigned long long>(gq) * 4);
-                    Xs[(static_cast<size_t>(pl) * qc + q) * XR + row] = v;
-                    if (ZS) {
-                        // when TM*qc is a multiple of 64 all lanes of a wave are in the same
-                        // plane and lane l holds k-quad (l & (qc-1)): fold the ballot to one
-                        // bit per k-quad and OR it into the plane's bitmap.
-                        unsigned long long f = __ballot((v.x | v.y | v.z | v.w) != 0u);
-                        if (TM * qc >= 64) {
-                            if (qc <= 32) f |= f >> 32;
-                            if (qc <= 16) f |= f >> 16;
-                            if (qc <= 8) f |= f >> 8;
-                            if (qc <= 4) f |= f >> 4;
-                            if (qc <= 2) f |= f >> 2;
-                            if (qc <= 1) f |= f >> 1;
-                            if (qc < 64) f &= (1ull << qc) - 1ull;
-                            if (lane == 0 && f) atomicOr(&fl[pl], f);
-                        } else {
-                            // TM * qc == 32 (qc == 1): each 32-lane half is one plane
-                            const uint32_t h = lane < 32 ? static_cast<uint32_t>(f) : static_cast<uint32_t>(f >> 32);
-                            if ((lane & 31) == 0 && h) atomicOr(&fl[pl], 1ull);
-                        }
-                    }
-                }
-                // ---- stage W planes [pw0, pw0+nw) ----
-                const int wg_total = nw * TN * qc;
-                for (int g = tid; g < wg_total; g += NT) {
-                    const int q = g & (qc - 1);
-                    const int t = g >> lqc;
-                    const int row = t & (TN - 1);
-                    const int pl = t / TN;
-                    const int gline = n0 + row, gq = q0 + q;
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (gline < N && gq < kq)
-                        v = ldg4(pr.W, pr.w_words,
-                                 (pw0 + pl) * w_plane + static_cast<unsigned long long>(gline) * kw +
-                                     static_cast<unsigned long long>(gq) * 4);
-                    Ws[(static_cast<size_t>(pl) * qc + q) * WR + row] = v;
-                }
-                __syncthreads();
-                if (ZS && tid < 32) flags[((chunk_id + 1) & 1) * 32 + tid] = 0ull;
-
-                // ---- compute: this wave's k-quads [wk*qw, wk*qw+qw) of the chunk ----
-                const int qlo = wk * qw;
-                const int qn = min(qc, kq - q0);  // k-quads of this chunk that exist
-                for (int pa = 0; pa < na; pa++) {
-                    unsigned long long f = ~0ull;
-                    if (ZS) {
-                        const unsigned long long fv = fl[pa];
-                        const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(fv));
-                        const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(fv >> 32));
-                        f = (static_cast<unsigned long long>(hi) << 32) | lo;
-                        const unsigned long long mine =
-                            (qw >= 64 ? ~0ull : ((1ull << qw) - 1ull)) << qlo;
-                        if ((f & mine) == 0ull) continue;  // whole X plane slice is zero
-                    }
-                    for (int pw = 0; pw < nw; pw++) {
-                        uint32_t part[R][C];
+    for (int it = 0; cur.valid; it++) {
+        const int buf = it & 1;
+        {   // write the prefetched granules into LDS buffer `buf`
+            uint4 *dst = stage_base + buf * stage_granules;
 #pragma unroll
-                        for (int i = 0; i < R; i++)
-#pragma unroll
-                            for (int j = 0; j < C; j++) part[i][j] = 0u;
-                        for (int qq = 0; qq < qw; qq++) {
-                            const int q = qlo + qq;
-                            if (q >= qn) break;                      // past the end of K
-                            if (ZS && !((f >> q) & 1ull)) continue;  // zero X tile: skip
-                            const uint4 *xp = Xs + (static_cast<size_t>(pa) * qc + q) * XR + lm;
-                            const uint4 *wp = Ws + (static_cast<size_t>(pw) * qc + q) * WR + ln;
-                            uint4 xg[R], wg[C];
-#pragma unroll
-                            for (int i = 0; i < R; i++) xg[i] = xp[i * Cfg::LM];
-#pragma unroll
-                            for (int j = 0; j < C; j++) wg[j] = wp[j * Cfg::LN];
-#pragma unroll
-                            for (int i = 0; i < R; i++)
-#pragma unroll
-                                for (int j = 0; j < C; j++) {
-                                    part[i][j] += __popc(xg[i].x & wg[j].x);
-                                    part[i][j] += __popc(xg[i].y & wg[j].y);
-                                    part[i][j] += __popc(xg[i].z & wg[j].z);
-                                    part[i][j] += __popc(xg[i].w & wg[j].w);
-                                }
-                        }
-                        const int s = pa0 + pa + pw0 + pw;  // reference kernel.h:295,340
-                        if (s < 32) {
-#pragma unroll
-                            for (int i = 0; i < R; i++)
-#pragma unroll
-                                for (int j = 0; j < C; j++)
-                                    tot[i][j] += part[i][j] << s;
-                        }
-                    }
-                }
-                __syncthreads();
+            for (int u = 0; u < GPT; u++) {
+                if (u >= nslots) break;
+                if (s_meta[u] & 3u) dst[s_loff[u]] = pre[u];
             }
         }
+        STAMP(2 + it * 4);
+        __syncthreads();
+        STAMP(3 + it * 4);
+
+        MMCursor nxt = cur;
+        advance(nxt);
+        if (nxt.valid) issue(nxt);  // loads fly while this stage is computed
+        STAMP(4 + it * 4);
+
+        // ---- compute: this wave's k-quads [wk*qw, wk*qw+qw) of the stage ----
+        const int na = min(sh.ab, sh.a - cur.pa0), nw = min(sh.wb, sh.w - cur.pw0);
+        const uint4 *Xs = stage_base + buf * stage_granules;
+        const uint4 *Ws = Xs + sh.ab * qc * XR;
+        const int qlo = wk * qw;
+        const int qhi = min(qlo + qw, min(qc, kq - cur.q0));  // k-quads of this chunk that exist
+        for (int pa = 0; pa < na; pa++) {
+            // occupancy of this wave's k-quads of X plane pa (bit q - qlo); hoisted out of the
+            // W-plane loop when there are several W planes, tested inline otherwise
+            unsigned long long occ = ~0ull;
+            const bool prepass = ZS && nw > 2;
+            if (prepass) {
+                occ = 0ull;
+                for (int q = qlo; q < qhi; q++) {
+                    const uint4 *xp = Xs + (pa * qc + q) * XR + lm;
+                    uint32_t any = 0u;
+#pragma unroll
+                    for (int i = 0; i < R; i++) {
+                        const uint4 g = xp[i * Cfg::LM];
+                        any |= (g.x | g.y) | (g.z | g.w);
+                    }
+                    if (__ballot(any != 0u)) occ |= 1ull << (q - qlo);
+                }
+                if (occ == 0ull) continue;  // this wave's slice of the X plane is all zero
+            }
+            for (int pw = 0; pw < nw; pw++) {
+                uint32_t part[R][C];
+#pragma unroll
+                for (int i = 0; i < R; i++)
+#pragma unroll
+                    for (int j = 0; j < C; j++) part[i][j] = 0u;
+                for (int q = qlo; q < qhi; q++) {
+                    if (prepass && !((occ >> (q - qlo)) & 1ull)) continue;  // zero X tile: skip
+                    const uint4 *xp = Xs + (pa * qc + q) * XR + lm;
+                    const uint4 *wp = Ws + (pw * qc + q) * WR + ln;
+                    uint4 xg[R], wg[C];
+#pragma unroll
+                    for (int i = 0; i < R; i++) xg[i] = xp[i * Cfg::LM];
+                    if (ZS && !prepass) {
+                        uint32_t any = 0u;
+#pragma unroll
+                        for (int i = 0; i < R; i++) any |= (xg[i].x | xg[i].y) | (xg[i].z | xg[i].w);
+                        if (__ballot(any != 0u) == 0ull) continue;  // zero X tile: skip
+                    }
+#pragma unroll
+                    for (int j = 0; j < C; j++) wg[j] = wp[j * Cfg::LN];
+                    // word-major order: consecutive v_bcnt hit different accumulators
+#pragma unroll
+                    for (int i = 0; i < R; i++)
+#pragma unroll
+                        for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xg[i].x, wg[j].x);
+#pragma unroll
+                    for (int i = 0; i < R; i++)
+#pragma unroll
+                        for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xg[i].y, wg[j].y);
+#pragma unroll
+                    for (int i = 0; i < R; i++)
+#pragma unroll
+                        for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xg[i].z, wg[j].z);
+#pragma unroll
+                    for (int i = 0; i < R; i++)
+#pragma unroll
+                        for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xg[i].w, wg[j].w);
+                }
+                const int s = cur.pa0 + pa + cur.pw0 + pw;  // reference kernel.h:295,340
+                if (s < 32) {
+#pragma unroll
+                    for (int i = 0; i < R; i++)
+#pragma unroll
+                        for (int j = 0; j < C; j++) tot[i][j] += part[i][j] << s;
+                }
+            }
+        }
+        STAMP(5 + it * 4);
+        cur = nxt;
     }
+    __syncthreads();  // every wave is done with the staging buffers: reuse them for the reduction
+    STAMP(28);
 
     // ---- in-workgroup split-K reduction through LDS ----
 #pragma unroll
@@ -403,6 +503,7 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
         for (int j = 0; j < C; j++)
             red[(wk * TM + lm + i * Cfg::LM) * TNP + ln + j * Cfg::LN] = static_cast<int>(tot[i][j]);
     __syncthreads();
+    STAMP(29);
 
     const bool last_n = tn == tiles_n - 1, last_m = tm == tiles_m - 1;
     if (sh.mode == 2) {
@@ -475,13 +576,25 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
             if (!core) out[p * oplane + static_cast<size_t>(line) * line_words + wi] = 0u;
         }
     }
+    STAMP(30);
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so blocks b and b+8
+// share an L2. Map block ids to tiles so that each XCD owns a contiguous range of tile ids: the
+// column tiles of one row tile (which read the same X rows) then hit the same L2. Bijective for
+// any grid size; placement only affects speed, never results.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    constexpr int NX = 8;
+    const int q = nblocks / NX, r = nblocks % NX;
+    const int xcd = bid % NX, idx = bid / NX;
+    return xcd * q + min(xcd, r) + idx;
 }
 
 template <int R, int C, int WK, bool ZS>
 __global__ __launch_bounds__(64 * WK) void k_bitmm(qgtc_problem pr, MMShape sh, int tiles_m,
                                                    int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tile = blockIdx.x;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
     mm_tile<R, C, WK, ZS>(pr, sh, tile / tiles_n, tile % tiles_n, tiles_m, tiles_n, smem);
 }
 
@@ -517,6 +630,7 @@ inline int pow2_floor(int x) {
 
 template <int R, int C, int WK>
 bool plan_for(int K, int a, int w, int ob, int mode, Plan *pl) {
+    using Cfg = MMCfg<R, C, WK>;
     const int kq = step128(K);
     MMShape sh{};
     sh.a = a;
@@ -525,18 +639,24 @@ bool plan_for(int K, int a, int w, int ob, int mode, Plan *pl) {
     sh.mode = mode;
     sh.maxv = std::ldexp(1.0f, ob);
     sh.maxm1 = sh.maxv - 1.0f;
-    // k-quads per chunk: power of two, >= max(8, WK), no larger than needed, within the budget
-    int qc = 64;
-    const int qmin = WK;
-    while (qc > qmin && qc / 2 >= kq) qc /= 2;
-    int ab = a > 32 ? 32 : a, wb = w > 32 ? 32 : w;
-    for (;;) {
-        if (mm_lds_bytes<R, C, WK>(ab, wb, qc) <= kLdsBudget) break;
-        if (qc > qmin) qc /= 2;
-        else if (wb >= ab && wb > 1) wb = (wb + 1) / 2;
+    // k-quads per stage: a power of two >= WK (every wave gets >= 1), as small as the pipeline
+    // allows (more stages = earlier first compute); planes are blocked until one stage fits the
+    // per-thread prefetch registers (GPT granules) and two stages fit the LDS budget.
+    int qc = WK > 8 ? WK : 8;
+    while (qc > WK && qc / 2 >= kq) qc /= 2;
+    int ab = a, wb = w;
+    auto fits = [&](int ab_, int wb_, int qc_) {
+        return (ab_ * Cfg::TM + wb_ * Cfg::TN) * qc_ <= Cfg::GPT * Cfg::NT &&
+               mm_lds_bytes<R, C, WK>(ab_, wb_, qc_) <= kLdsBudget;
+    };
+    while (!fits(ab, wb, qc)) {
+        if (wb >= ab && wb > 1) wb = (wb + 1) / 2;
         else if (ab > 1) ab = (ab + 1) / 2;
+        else if (qc > WK) qc /= 2;
         else return false;
     }
+    // with room to spare, stage more K per barrier (fewer barriers) up to 64 k-quads
+    while (qc < 64 && qc < kq && fits(ab, wb, qc * 2)) qc *= 2;
     sh.qc = qc;
     sh.ab = ab;
     sh.wb = wb;
@@ -639,6 +759,11 @@ int check_mm_args(const uint32_t *X, const uint32_t *W, const void *out, int M, 
     return QGTC_OK;
 }
 
+// in-kernel offsets inside one operand are 32-bit words
+inline bool words_ok(size_t x_words, size_t w_words) {
+    return x_words < (1ull << 32) && w_words < (1ull << 32);
+}
+
 int grid_for(size_t work_items, int per_block) {
     size_t blocks = (work_items + per_block - 1) / per_block;
     if (blocks < 1) blocks = 1;
@@ -734,7 +859,7 @@ int qgtc_bitmm2bit(const uint32_t *X, size_t x_words, const uint32_t *W, size_t 
                    size_t out_words, unsigned flags, void *stream) {
     int rc = check_mm_args(X, W, out, M, K, N, bit1, bit2);
     if (rc != QGTC_OK) return rc;
-    if (!bits_ok(output_bit)) return QGTC_EINVAL;
+    if (!bits_ok(output_bit) || !words_ok(x_words, w_words)) return QGTC_EINVAL;
     const bool cols = flags & QGTC_OUT_COLS;
     const size_t need = cols ? qgtc_cols_words(M, N, output_bit, 0) : qgtc_rows_words(M, N, output_bit);
     if (out_words < need) return QGTC_ESIZE;
@@ -750,6 +875,7 @@ int qgtc_bitmm2int(const uint32_t *X, size_t x_words, const uint32_t *W, size_t 
                    unsigned flags, void *stream) {
     int rc = check_mm_args(X, W, out, M, K, N, bit1, bit2);
     if (rc != QGTC_OK) return rc;
+    if (!words_ok(x_words, w_words)) return QGTC_EINVAL;
     if (out_elems < static_cast<size_t>(M) * N) return QGTC_ESIZE;
     qgtc_problem pr{X, W, out, x_words, w_words, M, K, N, pad_128 ? pad128(N) : pad8(N)};
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -151,6 +151,25 @@ std::pair<torch::Tensor, double> profile_impl(const torch::Tensor &bit_X1, const
     return {out, ms};
 }
 
+// Enqueue `reps` launches writing into a caller-provided packed output (no allocation, no
+// synchronisation): the lean launch path used by bench.py and by steady-state serving loops.
+void bitMM2Bit_enqueue(torch::Tensor out, torch::Tensor bit_X1, torch::Tensor bit_X2, int M, int K,
+                       int N, int bit1, int bit2, int ob, int reps) {
+    CHECK_INPUT(out);
+    CHECK_INPUT(bit_X1);
+    CHECK_INPUT(bit_X2);
+    check_bits_tensor(out, "out");
+    check_bits_tensor(bit_X1, "bit_X1");
+    check_bits_tensor(bit_X2, "bit_X2");
+    TORCH_CHECK(reps > 0, "reps must be positive");
+    c10::DeviceGuard guard(bit_X1.device());
+    void *st = current_stream(bit_X1);
+    for (int i = 0; i < reps; i++)
+        check_rc(qgtc_bitmm2bit(words(bit_X1), bit_X1.numel(), words(bit_X2), bit_X2.numel(), M, K, N,
+                                bit1, bit2, ob, words_mut(out), out.numel(), mm_flags(), st),
+                 "bitMM2Bit_enqueue");
+}
+
 torch::Tensor bitMM2Bit_profile(torch::Tensor bit_X1, torch::Tensor bit_X2, const int X1_height,
                                 const int X1_width, const int X2_width, const int bit1,
                                 const int bit2, const int output_bit) {
@@ -326,6 +345,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                         int ob, int reps) { return profile_impl(a, b, M, K, N, bit1, bit2, ob, reps).second; },
           "time `reps` bitMM2Bit launches; returns elapsed milliseconds (blocking)");
     m.def("last_profile_ms", [] { return g_last_profile_ms; });
+    m.def("bitMM2Bit_enqueue", &bitMM2Bit_enqueue,
+          "enqueue `reps` bitMM2Bit launches into a preallocated output (asynchronous)");
     m.def("tile_counters", [](torch::Tensor x, int M, int K, int N, int bit1, int bit2) {
         CHECK_INPUT(x);
         check_bits_tensor(x, "x");

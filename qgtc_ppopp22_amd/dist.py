@@ -1,0 +1,69 @@
+"""Multi-GPU sharding of the cluster batches: one process per GPU, no collective on the data path.
+
+Cluster batches are independent (main_qgtc.py:113-154 carries nothing from one batch to the next),
+so batch i runs on rank i mod world_size with the (tiny) packed weights replicated. The only
+exchange is an end-of-epoch gather of per-batch results — RCCL over xGMI on the GPU box
+(backend "nccl"), gloo in the CPU tests. The reference has no distributed code at all.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/LOCAL_RANK/MASTER_* (torchrun). Returns
+    (rank, world_size, local_rank); a single process needs no process group."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_round_robin(n_batches: int, rank: int, world: int):
+    """Batch ids owned by `rank`: i with i % world == rank (BASELINE.json config 5)."""
+    return list(range(rank, n_batches, world))
+
+
+def owner_of(batch_id: int, world: int) -> int:
+    return batch_id % world
+
+
+def gather_batch_summaries(local: torch.Tensor, n_batches: int, rank: int, world: int) -> torch.Tensor:
+    """End-of-epoch gather. `local` is [n_local, D] (one row of D summary values — checksum, shape,
+    timing — per batch this rank owns, in shard order). Returns [n_batches, D] on every rank, rows
+    in global batch order. One all_gather on buffers padded to the largest shard."""
+    if world == 1:
+        return local
+    d = local.size(1)
+    per = (n_batches + world - 1) // world
+    buf = torch.zeros((per, d), dtype=local.dtype, device=local.device)
+    buf[: local.size(0)] = local
+    out = torch.empty((world * per, d), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, buf)
+    out = out.view(world, per, d)
+    rows = [out[owner_of(i, world), i // world] for i in range(n_batches)]
+    return torch.stack(rows)
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()

@@ -1,0 +1,251 @@
+"""Cluster-GCN / Batched-GIN inference driver — counterpart of the reference's main_qgtc.py.
+
+Same command-line flags and the same per-batch operator chains (main_qgtc.py:112-155, six QGTC
+calls per cluster batch), printing the same ``Avg. Epoch: {:.3f} ms`` line (main_qgtc.py:159) that
+parse_time.py consumes. DGL/OGB/METIS are not available here, so the graph is a synthetic one of the
+named dataset's size (qgtc_ppopp22_amd/graph.py).
+
+Three ways to run the same math:
+
+* ``--chain reference`` (default): the reference's literal call sequence. Its operand layouts are
+  inconsistent (a cols-layout X is fed as a left operand, rows-layout results as
+  right operands); the kernels read those operands bounds-safely, so the timing-relevant work is
+  the same as the reference's but the numbers are not A·X·W.
+* ``--chain correct``: the layout-correct chain (X·W re-packed in the cols layout by
+  ``bitMM2Bit_col`` before A·(XW), as unitest.py:100-109 does).
+* ``--batched``: either chain, with each of the six operators issued ONCE for all cluster batches
+  (grouped launch): 6 launches per epoch instead of 6 x 75 — on MI355X the ~1.5 us dependent-launch
+  boundary, not the arithmetic, dominates these small products.
+"""
+from __future__ import annotations
+
+import argparse
+import random
+import time
+
+import numpy as np
+import torch
+
+from . import graph as G
+from .sampler import ClusterIter
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="QGTC Cluster-GCN / Batched-GIN inference on MI355X")
+    # dgl.data.register_data_args equivalent (main_qgtc.py:22)
+    p.add_argument("--dataset", type=str, default="ogbn-arxiv",
+                   help=f"synthetic stand-in of this dataset's size {sorted(G.PRESETS)} or a .npz edge list")
+    # main_qgtc.py:23-41, identical names and defaults
+    p.add_argument("--gpu", type=int, default=0, help="gpu")
+    p.add_argument("--n-epochs", type=int, default=20, help="number of training epochs")
+    p.add_argument("--batch-size", type=int, default=20, help="batch size")
+    p.add_argument("--psize", type=int, default=1500, help="number of partitions")
+    p.add_argument("--dim", type=int, default=10, help="input dimension of each dataset (default=10)")
+    p.add_argument("--n-hidden", type=int, default=16, help="number of hidden gcn units (default=16)")
+    p.add_argument("--n-classes", type=int, default=10, help="number of classes (default=10)")
+    p.add_argument("--n-layers", type=int, default=1, help="number of hidden gcn layers (default=1)")
+    p.add_argument("--bit_width", type=int, default=2, help="bitwidth for QGTC quantization (default=2)")
+    p.add_argument("--use-pp", action="store_true", help="whether to use precomputation")
+    p.add_argument("--regular", action="store_true", help="whether to use DGL")
+    p.add_argument("--run_GIN", action="store_true", help="whether to run GIN model")
+    p.add_argument("--use_QGTC", action="store_true", help="whether to use QGTC")
+    p.add_argument("--zerotile_jump", action="store_true", help="whether to profile zero-tile jumping")
+    # additions
+    p.add_argument("--chain", choices=["reference", "correct"], default="reference")
+    p.add_argument("--batched", action="store_true", help="one grouped launch per operator per epoch")
+    p.add_argument("--non-resident", action="store_true",
+                   help="park packed batches on the CPU and upload them every iteration (main_qgtc.py:115)")
+    p.add_argument("--quiet", action="store_true")
+    return p
+
+
+def pack_weights(Q, feat, hidden, classes, bw, device):
+    """main_qgtc.py:100-110: all-ones weights, cols layout, W3 with output_layer=True."""
+    W1 = torch.ones((feat, hidden), device=device)
+    W2 = torch.ones((hidden, hidden), device=device)
+    W3 = torch.ones((hidden, classes), device=device)
+    return {
+        "W1": Q.val2bit(W1, bw, True, False), "W2": Q.val2bit(W2, bw, True, False),
+        "W3": Q.val2bit(W3, bw, True, True),          # main_qgtc.py:110
+        "W3h": Q.val2bit(W3, bw, True, False),        # hidden-style W3 for the layout-correct GCN chain
+        "feat": feat, "hidden": hidden, "classes": classes,
+    }
+
+
+# ---------------------------------------------------------------------------------------------
+# per-batch chains (six extension calls each)
+# ---------------------------------------------------------------------------------------------
+def gcn_reference(Q, ct, param, W, b):
+    """main_qgtc.py:147-154, literally."""
+    A0, A1, X0, X1 = param
+    H, C = W["hidden"], W["classes"]
+    t0 = Q.bitMM2Bit(ct.bit_X, W["W1"], X0, X1, H, b, b, b)
+    t1 = Q.bitMM2Bit(ct.bit_A, t0, A0, A1, H, 1, b, b)
+    t2 = Q.bitMM2Bit(t1, W["W2"], A0, H, H, b, b, b)
+    t3 = Q.bitMM2Bit(ct.bit_A, t2, A0, A0, H, 1, b, b)
+    t4 = Q.bitMM2Bit(t3, W["W3"], A0, H, C, b, b, b)
+    return Q.bitMM2Int(ct.bit_A, t4, A0, A0, H, 1, b, False)
+
+
+def gin_reference(Q, ct, param, W, b):
+    """main_qgtc.py:131-138, literally."""
+    A0, A1, X0, X1 = param
+    H, C = W["hidden"], W["classes"]
+    t0 = Q.bitMM2Bit(ct.bit_A, ct.bit_X, A0, A0, X1, 1, b, b)
+    t1 = Q.bitMM2Bit(t0, W["W1"], A0, X1, H, b, b, b)
+    t2 = Q.bitMM2Bit(ct.bit_A, t1, A0, A0, H, 1, b, b)
+    t3 = Q.bitMM2Bit(t2, W["W2"], A0, H, H, b, b, b)
+    t4 = Q.bitMM2Bit(ct.bit_A, t3, A0, A0, H, 1, b, b)
+    return Q.bitMM2Int(t4, W["W3"], A0, H, C, b, b, False)
+
+
+def gcn_correct(Q, ct, param, W, b):
+    """A·((A·((A·(X·W1))·W2))·W3) with every right operand in the cols layout."""
+    n, _, _, F = param
+    H, C = W["hidden"], W["classes"]
+    xw = Q.bitMM2Bit_col(ct.bit_X_rows, W["W1"], n, F, H, b, b, b)
+    h1 = Q.bitMM2Bit(ct.bit_A, xw, n, n, H, 1, b, b)
+    hw = Q.bitMM2Bit_col(h1, W["W2"], n, H, H, b, b, b)
+    h2 = Q.bitMM2Bit(ct.bit_A, hw, n, n, H, 1, b, b)
+    hw3 = Q.bitMM2Bit_col(h2, W["W3h"], n, H, C, b, b, b)
+    return Q.bitMM2Int(ct.bit_A, hw3, n, n, C, 1, b, True)
+
+
+def gin_correct(Q, ct, param, W, b):
+    """(A·((A·((A·X)·W1))·W2))·W3 with every right operand in the cols layout."""
+    n, _, _, F = param
+    H, C = W["hidden"], W["classes"]
+    ax = Q.bitMM2Bit(ct.bit_A, ct.bit_X, n, n, F, 1, b, b)
+    h1 = Q.bitMM2Bit_col(ax, W["W1"], n, F, H, b, b, b)
+    a1 = Q.bitMM2Bit(ct.bit_A, h1, n, n, H, 1, b, b)
+    h2 = Q.bitMM2Bit_col(a1, W["W2"], n, H, H, b, b, b)
+    a2 = Q.bitMM2Bit(ct.bit_A, h2, n, n, H, 1, b, b)
+    return Q.bitMM2Int(a2, W["W3"], n, H, C, b, b, False)
+
+
+CHAINS = {("reference", False): gcn_reference, ("reference", True): gin_reference,
+          ("correct", False): gcn_correct, ("correct", True): gin_correct}
+
+
+# ---------------------------------------------------------------------------------------------
+# grouped launches: the same six operators, each issued once for all batches
+# ---------------------------------------------------------------------------------------------
+class BatchedEpoch:
+    """Builds the six grouped GEMMs of an epoch once (outputs preallocated and chained); run()
+    issues six launches."""
+
+    def __init__(self, Q, cts, params, W, b, chain: str, run_gin: bool):
+        H, C = W["hidden"], W["classes"]
+        bitA = [c.bit_A for c in cts]
+        bitX = [c.bit_X for c in cts]
+        n = [p[0] for p in params]
+        F = params[0][3]
+        BG = Q.BatchedGemm
+
+        def dims(k, c):  # (M=n_i, K=k or n_i, N=c)
+            return [(ni, ni if k is None else k, c) for ni in n]
+
+        if chain == "reference" and not run_gin:
+            x0x1 = [(p[2], p[3], H) for p in params]
+            g0 = BG(bitX, [W["W1"]], x0x1, b, b, b, 0, False)
+            g1 = BG(bitA, g0.outs, dims(None, H), 1, b, b, 0, False)
+            g2 = BG(g1.outs, [W["W2"]], dims(H, H), b, b, b, 0, False)
+            g3 = BG(bitA, g2.outs, dims(None, H), 1, b, b, 0, False)
+            g4 = BG(g3.outs, [W["W3"]], dims(H, C), b, b, b, 0, False)
+            g5 = BG(bitA, g4.outs, dims(None, H), 1, b, 1, 2, False)
+        elif chain == "reference":
+            g0 = BG(bitA, bitX, dims(None, F), 1, b, b, 0, False)
+            g1 = BG(g0.outs, [W["W1"]], dims(F, H), b, b, b, 0, False)
+            g2 = BG(bitA, g1.outs, dims(None, H), 1, b, b, 0, False)
+            g3 = BG(g2.outs, [W["W2"]], dims(H, H), b, b, b, 0, False)
+            g4 = BG(bitA, g3.outs, dims(None, H), 1, b, b, 0, False)
+            g5 = BG(g4.outs, [W["W3"]], dims(H, C), b, b, 1, 2, False)
+        elif not run_gin:
+            bitXr = [c.bit_X_rows for c in cts]
+            g0 = BG(bitXr, [W["W1"]], dims(F, H), b, b, b, 1, False)
+            g1 = BG(bitA, g0.outs, dims(None, H), 1, b, b, 0, False)
+            g2 = BG(g1.outs, [W["W2"]], dims(H, H), b, b, b, 1, False)
+            g3 = BG(bitA, g2.outs, dims(None, H), 1, b, b, 0, False)
+            g4 = BG(g3.outs, [W["W3h"]], dims(H, C), b, b, b, 1, False)
+            g5 = BG(bitA, g4.outs, dims(None, C), 1, b, 1, 2, True)
+        else:
+            g0 = BG(bitA, bitX, dims(None, F), 1, b, b, 0, False)
+            g1 = BG(g0.outs, [W["W1"]], dims(F, H), b, b, b, 1, False)
+            g2 = BG(bitA, g1.outs, dims(None, H), 1, b, b, 0, False)
+            g3 = BG(g2.outs, [W["W2"]], dims(H, H), b, b, b, 1, False)
+            g4 = BG(bitA, g3.outs, dims(None, H), 1, b, b, 0, False)
+            g5 = BG(g4.outs, [W["W3"]], dims(H, C), b, b, 1, 2, False)
+        self.stages = [g0, g1, g2, g3, g4, g5]
+        self.outs = g5.outs
+
+    def run(self):
+        for g in self.stages:
+            g.run()
+        return self.outs
+
+
+# ---------------------------------------------------------------------------------------------
+def run(args, Q=None, batch_ids=None, graph=None):
+    """Runs the epoch loop; returns a dict with avg_epoch_ms, the last epoch's per-batch outputs
+    and the iterator. `batch_ids` restricts this process to a shard of the batches."""
+    if Q is None:
+        import QGTC as Q
+    torch.manual_seed(3)      # main_qgtc.py:45-47
+    np.random.seed(2)
+    random.seed(2)
+    device = torch.device(f"cuda:{args.gpu}")
+    torch.cuda.set_device(device)
+
+    if graph is None:
+        if args.dataset.endswith(".npz"):
+            graph = G.load_npz_graph(args.dataset, args.dim, args.psize)
+        else:
+            graph = G.make_graph(args.dataset, args.psize)
+    feat_size = graph.feat.shape[1]
+    b = args.bit_width
+    it = ClusterIter(args.dataset, graph, args.psize, args.batch_size, bit_width=b,
+                     run_GIN=args.run_GIN, device=device, resident=not args.non_resident, qgtc=Q,
+                     batch_ids=batch_ids, with_rows_X=(args.chain == "correct"))
+    torch.cuda.synchronize()
+
+    start_time = time.time()  # main_qgtc.py:96 — the clock starts before the weights are packed
+    W = pack_weights(Q, feat_size, args.n_hidden, args.n_classes, b, device)
+    chain = CHAINS[(args.chain, args.run_GIN)]
+    outs = []
+    if args.zerotile_jump:    # main_qgtc.py:142-145 / cluster_gcn.py:208-211
+        for ct, param in it:
+            ct = ct.to(device)
+            A0, A1 = param[0], param[1]
+            t0 = Q.bitMM2Bit(ct.bit_X, W["W1"], param[2], param[3], W["hidden"], b, b, b)
+            Q.bitMM2Bit_base_cnt(ct.bit_A, t0, A0, A1, W["hidden"], 1, b, b)
+            Q.bitMM2Bit_zerojump_cnt(ct.bit_A, t0, A0, A1, W["hidden"], 1, b, b)
+        return {"avg_epoch_ms": float("nan"), "outs": [], "iter": it, "counters": Q.get_counters()}
+
+    if args.batched:
+        cts = [c.to(device) for c in it.cTensor_li]
+        plan = BatchedEpoch(Q, cts, it.cluster_param_li, W, b, args.chain, args.run_GIN)
+        for _ in range(args.n_epochs):
+            outs = plan.run()
+    else:
+        for _ in range(args.n_epochs):
+            outs = []
+            for ct, param in it:
+                ct = ct.to(device, non_blocking=True)   # main_qgtc.py:115 (no-op when resident)
+                outs.append(chain(Q, ct, param, W, b))
+    torch.cuda.synchronize()
+    end_time = time.time()
+    avg = (end_time - start_time) * 1000 / args.n_epochs
+    if not args.quiet:
+        print("Avg. Epoch: {:.3f} ms".format(avg))       # main_qgtc.py:159
+    return {"avg_epoch_ms": avg, "outs": outs, "iter": it}
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if not args.quiet:
+        print(args)   # main_qgtc.py:42 — parse_time.py greps `dataset=` from this line
+    return run(args)
+
+
+if __name__ == "__main__":
+    main()
