@@ -29,3 +29,80 @@ def to_dev(torch, arr_u32, shape, device="cuda"):
 
 def to_np_u32(t):
     return t.detach().cpu().numpy().view(np.uint32).reshape(-1)
+
+
+# ---------------------------------------------------------------------------------------------
+# oracle-side restatement of the driver's six-operator chains (qgtc_ppopp22_amd/driver.py), used to
+# check whole cluster batches
+# ---------------------------------------------------------------------------------------------
+def oracle_batch_inputs(oracle, graph, par_li, cid, psize, batch_size, bits):
+    from qgtc_ppopp22_amd import graph as G
+
+    nodes = G.batch_nodes(par_li, cid, psize, batch_size)
+    row, col = G.induced_edges(graph, nodes)
+    n = nodes.size
+    A = np.zeros((n, n), dtype=np.float32)
+    np.add.at(A, (row, col), 1.0)
+    X = graph.feat[nodes]
+    return {"n": n, "F": X.shape[1], "A": A, "X": X,
+            "bit_A": oracle.val2bit(A, 1, False, False),
+            "bit_X": oracle.val2bit(X, bits, True, False),
+            "bit_X_rows": oracle.val2bit(X, bits, False, False)}
+
+
+def oracle_weights(oracle, feat, hidden, classes, bits):
+    one = lambda h, w: np.ones((h, w), dtype=np.float32)  # noqa: E731
+    return {"W1": oracle.val2bit(one(feat, hidden), bits, True, False),
+            "W2": oracle.val2bit(one(hidden, hidden), bits, True, False),
+            "W3": oracle.val2bit(one(hidden, classes), bits, True, True),
+            "W3h": oracle.val2bit(one(hidden, classes), bits, True, False),
+            "hidden": hidden, "classes": classes}
+
+
+def oracle_chain(oracle, bi, W, b, chain, gin):
+    """Returns the list of the six per-operator results (packed uint32 / float32)."""
+    n, F, H, C = bi["n"], bi["F"], W["hidden"], W["classes"]
+    mm, mmc, mi = oracle.bitmm2bit, (lambda *a: oracle.bitmm2bit(*a, col=True)), oracle.bitmm2int
+    A, Xc, Xr = bi["bit_A"], bi["bit_X"], bi["bit_X_rows"]
+    if chain == "reference" and not gin:      # main_qgtc.py:147-154
+        t0 = mm(Xc, W["W1"], n, F, H, b, b, b)
+        t1 = mm(A, t0, n, n, H, 1, b, b)
+        t2 = mm(t1, W["W2"], n, H, H, b, b, b)
+        t3 = mm(A, t2, n, n, H, 1, b, b)
+        t4 = mm(t3, W["W3"], n, H, C, b, b, b)
+        return [t0, t1, t2, t3, t4, mi(A, t4, n, n, H, 1, b, False)]
+    if chain == "reference":                  # main_qgtc.py:131-138
+        t0 = mm(A, Xc, n, n, F, 1, b, b)
+        t1 = mm(t0, W["W1"], n, F, H, b, b, b)
+        t2 = mm(A, t1, n, n, H, 1, b, b)
+        t3 = mm(t2, W["W2"], n, H, H, b, b, b)
+        t4 = mm(A, t3, n, n, H, 1, b, b)
+        return [t0, t1, t2, t3, t4, mi(t4, W["W3"], n, H, C, b, b, False)]
+    if not gin:
+        xw = mmc(Xr, W["W1"], n, F, H, b, b, b)
+        h1 = mm(A, xw, n, n, H, 1, b, b)
+        hw = mmc(h1, W["W2"], n, H, H, b, b, b)
+        h2 = mm(A, hw, n, n, H, 1, b, b)
+        hw3 = mmc(h2, W["W3h"], n, H, C, b, b, b)
+        return [xw, h1, hw, h2, hw3, mi(A, hw3, n, n, C, 1, b, True)]
+    ax = mm(A, Xc, n, n, F, 1, b, b)
+    h1 = mmc(ax, W["W1"], n, F, H, b, b, b)
+    a1 = mm(A, h1, n, n, H, 1, b, b)
+    h2 = mmc(a1, W["W2"], n, H, H, b, b, b)
+    a2 = mm(A, h2, n, n, H, 1, b, b)
+    return [ax, h1, a1, h2, a2, mi(a2, W["W3"], n, H, C, b, b, False)]
+
+
+def integer_gcn_reference(A, X, H, C, b, oracle):
+    """What the layout-correct GCN chain means in plain integer arithmetic:
+    clamp is kernel.h:31-37's rule, all-ones weights."""
+    from oracle.qgtc_oracle import np_quantize, np_requant
+
+    mask = (1 << b) - 1
+    qa = np_quantize(A, 1).astype(np.int64) & 1
+    qx = np_quantize(X, b).astype(np.int64) & mask
+    one = lambda h, w: np.ones((h, w), dtype=np.int64)  # noqa: E731
+    cl = lambda c: np_requant(c.astype(np.int32), b).astype(np.int64) & mask  # noqa: E731
+    h = cl(qa @ cl(qx @ one(X.shape[1], H)))
+    h = cl(qa @ cl(h @ one(H, H)))
+    return (qa @ cl(h @ one(H, C))).astype(np.float32)

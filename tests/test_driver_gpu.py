@@ -1,0 +1,94 @@
+"""Whole cluster batches through the driver (per-batch and grouped launches, both chains, GCN and
+GIN) against the oracle's restatement of the same six-operator chains."""
+import random
+
+import numpy as np
+import pytest
+
+from helpers import integer_gcn_reference, oracle_batch_inputs, oracle_chain, oracle_weights, to_np_u32
+
+pytestmark = pytest.mark.gpu
+
+PSIZE, BS = 40, 4   # 10 batches of ~200 nodes from the 2000-node 'tiny' graph
+
+
+def _args(extra):
+    from qgtc_ppopp22_amd import driver
+
+    return driver.build_parser().parse_args(
+        ["--dataset", "tiny", "--psize", str(PSIZE), "--batch-size", str(BS), "--n-hidden", "64",
+         "--n-classes", "10", "--n-epochs", "2", "--use_QGTC", "--quiet"] + extra)
+
+
+@pytest.mark.parametrize("chain", ["reference", "correct"])
+@pytest.mark.parametrize("gin", [False, True])
+@pytest.mark.parametrize("bits", [2, 4])
+@pytest.mark.parametrize("batched", [False, True])
+def test_epoch_outputs_match_oracle(qgtc, oracle, chain, gin, bits, batched):
+    from qgtc_ppopp22_amd import driver, graph as G
+
+    extra = ["--chain", chain, "--bit_width", str(bits)] + (["--run_GIN"] if gin else []) + (["--batched"] if batched else [])
+    res = driver.run(_args(extra), Q=qgtc)
+    graph = G.make_graph("tiny", PSIZE)
+    random.seed(2)                     # the driver's seed: same partition shuffle
+    par = G.partition_list(graph, PSIZE)
+    random.shuffle(par)
+    W = oracle_weights(oracle, graph.feat.shape[1], 64, 10, bits)
+    assert len(res["outs"]) == PSIZE // BS
+    for cid in range(PSIZE // BS):
+        bi = oracle_batch_inputs(oracle, graph, par, cid, PSIZE, BS, bits)
+        ct = res["iter"].cTensor_li[cid]
+        np.testing.assert_array_equal(to_np_u32(ct.bit_A), bi["bit_A"])
+        np.testing.assert_array_equal(to_np_u32(ct.bit_X), bi["bit_X"])
+        expect = oracle_chain(oracle, bi, W, bits, chain, gin)[-1]
+        np.testing.assert_array_equal(res["outs"][cid].cpu().numpy(), expect)
+        if chain == "correct" and not gin:
+            np.testing.assert_array_equal(expect, integer_gcn_reference(bi["A"], bi["X"], 64, 10, bits, oracle))
+
+
+def test_non_resident_matches_resident(qgtc):
+    import torch
+    from qgtc_ppopp22_amd import driver
+
+    a = driver.run(_args([]), Q=qgtc)
+    b = driver.run(_args(["--non-resident"]), Q=qgtc)
+    assert all(torch.equal(x, y) for x, y in zip(a["outs"], b["outs"]))
+    assert b["iter"].cTensor_li[0].bit_A.device.type == "cpu"
+
+
+def test_sharded_batches_cover_the_epoch(qgtc):
+    """Round-robin shards of the batch list reproduce the unsharded results batch by batch."""
+    import torch
+    from qgtc_ppopp22_amd import dist as D, driver
+
+    full = driver.run(_args(["--batched"]), Q=qgtc)["outs"]
+    nb = PSIZE // BS
+    for world in (2, 3):
+        seen = {}
+        for rank in range(world):
+            ids = D.shard_round_robin(nb, rank, world)
+            outs = driver.run(_args(["--batched"]), Q=qgtc, batch_ids=ids)["outs"]
+            seen.update(dict(zip(ids, outs)))
+        assert sorted(seen) == list(range(nb))
+        assert all(torch.equal(seen[i], full[i]) for i in range(nb))
+
+
+def test_zerotile_counters_mode(qgtc, capfd):
+    from qgtc_ppopp22_amd import driver
+
+    qgtc.reset_counters()
+    res = driver.run(_args(["--zerotile_jump"]), Q=qgtc)
+    out = capfd.readouterr().out
+    assert out.count("counter_global:") == PSIZE // BS and out.count("counter:") == PSIZE // BS
+    total, nz = res["counters"]
+    assert 0 < nz < total
+
+
+def test_avg_epoch_line_format(qgtc, capfd):
+    import re
+    from qgtc_ppopp22_amd import driver
+
+    driver.main(["--dataset", "tiny", "--psize", str(PSIZE), "--batch-size", str(BS), "--n-epochs", "1", "--use_QGTC"])
+    out = capfd.readouterr().out
+    assert "dataset='tiny'" in out                      # parse_time.py:9-14 greps this
+    assert re.search(r"Avg\. Epoch: \d+\.\d{3} ms", out)  # parse_time.py:15-17
