@@ -322,31 +322,44 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
         }
     };
 
-    // Per-thread slot table, computed once per tile: slot u of this thread is granule
-    // g = tid + u*NT of a (full) stage. X granules come first — (plane, row, k-quad) with the
-    // k-quad fastest, so consecutive lanes load consecutive 16 bytes of a packed row — then W.
-    // Only the stage origin (plane block, first k-quad) changes from stage to stage.
-    const int xg_full = sh.ab * TM * qc, total_full = xg_full + sh.wb * TN * qc;
-    const int nslots = (total_full + NT - 1) / NT;  // wave-uniform, <= GPT (plan_for)
-    uint32_t s_goff[GPT];  // word offset from the stage origin in X / W
-    uint32_t s_meta[GPT];  // bit0 X, bit1 W, bit2 row in range, bits 8..15 plane, bits 16.. k-quad
+    // Per-thread slot table, computed once per tile. A stage holds ab*TM*qc X granules and
+    // wb*TN*qc W granules; X granules use slots [0, nxs), W granules slots [nxs, nslots): slot u
+    // of this thread is granule g = tid + u*NT (resp. tid + (u-nxs)*NT) of its operand, decoded
+    // as (plane, row, k-quad) with the k-quad fastest, so consecutive lanes load consecutive 16
+    // bytes of a packed row. Only the stage origin (plane block, first k-quad) changes from
+    // stage to stage, and it is wave-uniform: loads are SGPR base + 32-bit VGPR offset.
+    const int xg_full = sh.ab * TM * qc, wg_full = sh.wb * TN * qc;
+    const int nxs = (xg_full + NT - 1) / NT;
+    const int nslots = nxs + (wg_full + NT - 1) / NT;  // wave-uniform, <= GPT (plan_for)
+    uint32_t s_boff[GPT];  // BYTE offset of the granule from the stage origin (< 4 GiB, host-checked)
+    int32_t s_lim[GPT];    // largest stage origin (in words) for which the granule is in bounds
+    uint32_t s_meta[GPT];  // bit0 valid slot, bit2 row in range, bits 8..15 plane, bits 16.. k-quad
+    {
+        // cheap decode: 24-bit multiplies (v_mul_u32_u24 is full rate, v_mul_lo_u32 is not) and
+        // no divergent branches. q and the row-within-slot are the same for every slot.
+        const uint32_t q = tid & (qc - 1), t0 = tid >> lqc, tstep = NT >> lqc;
+        const uint32_t xpl_lo = x_plane & 0xffffffu, xpl_hi = x_plane >> 24;
+        const uint32_t wpl_lo = w_plane & 0xffffffu, wpl_hi = w_plane >> 24;
 #pragma unroll
-    for (int u = 0; u < GPT; u++) {
-        s_goff[u] = 0u;
-        s_meta[u] = 0u;
-        if (u >= nslots) continue;
-        const int g = tid + u * NT;
-        if (g < xg_full) {
-            const uint32_t q = g & (qc - 1), t = g >> lqc;
-            const uint32_t row = t & (TM - 1), pl = t / TM;
-            s_goff[u] = pl * x_plane + static_cast<uint32_t>(m0 + row) * kw + q * 4u;
-            s_meta[u] = 1u | ((m0 + static_cast<int>(row) < M) ? 4u : 0u) | (pl << 8) | (q << 16);
-        } else if (g < total_full) {
-            const uint32_t g2 = g - xg_full;
-            const uint32_t q = g2 & (qc - 1), t = g2 >> lqc;
-            const uint32_t row = t & (TN - 1), pl = t / TN;
-            s_goff[u] = pl * w_plane + static_cast<uint32_t>(n0 + row) * kw + q * 4u;
-            s_meta[u] = 2u | ((n0 + static_cast<int>(row) < N) ? 4u : 0u) | (pl << 8) | (q << 16);
+        for (int u = 0; u < GPT; u++) {
+            s_boff[u] = 0u;
+            s_lim[u] = -8;
+            s_meta[u] = 0u;
+            if (u >= nslots) continue;
+            const bool is_x = u < nxs;
+            const uint32_t t = t0 + (is_x ? u : u - nxs) * tstep;    // flattened (plane,row) index
+            const uint32_t row = is_x ? (t & (TM - 1)) : (t & (TN - 1));
+            const uint32_t pl = is_x ? (t / TM) : (t / TN);
+            const bool in_stage = is_x ? (t < static_cast<uint32_t>(sh.ab * TM)) : (t < static_cast<uint32_t>(sh.wb * TN));
+            const uint32_t grow = (is_x ? m0 : n0) + row;
+            const uint32_t ploff = is_x ? (__umul24(pl, xpl_lo) + (__umul24(pl, xpl_hi) << 24))
+                                        : (__umul24(pl, wpl_lo) + (__umul24(pl, wpl_hi) << 24));
+            const uint32_t goff = ploff + __umul24(grow, kw) + q * 4u;  // kw < 2^24 (host-checked)
+            const int32_t words = static_cast<int32_t>(is_x ? pr.x_words : pr.w_words);
+            const bool row_ok = static_cast<int>(grow) < (is_x ? M : N);
+            s_boff[u] = goff * 4u;
+            s_lim[u] = in_stage ? words - 4 - static_cast<int32_t>(goff) : -8;
+            s_meta[u] = (in_stage ? 1u : 0u) | (row_ok ? 4u : 0u) | (pl << 8) | (q << 16);
         }
     }
 
@@ -355,19 +368,32 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
     uint4 pre[GPT];
     auto issue = [&](const MMCursor &c) {
         const int na = min(sh.ab, sh.a - c.pa0), nw = min(sh.wb, sh.w - c.pw0);
-        const unsigned long long xbase =
-            static_cast<unsigned long long>(c.pa0) * x_plane + static_cast<unsigned long long>(c.q0) * 4;
-        const unsigned long long wbase =
-            static_cast<unsigned long long>(c.pw0) * w_plane + static_cast<unsigned long long>(c.q0) * 4;
+        const bool full = na == sh.ab && nw == sh.wb && c.q0 + qc <= kq;  // wave-uniform
+        const int32_t xo = static_cast<int32_t>(c.pa0 * x_plane + c.q0 * 4u);
+        const int32_t wo = static_cast<int32_t>(c.pw0 * w_plane + c.q0 * 4u);
+        const char *xb = reinterpret_cast<const char *>(pr.X + xo);   // uniform stage origins
+        const char *wbp = reinterpret_cast<const char *>(pr.W + wo);
 #pragma unroll
         for (int u = 0; u < GPT; u++) {
             if (u >= nslots) break;
+            const bool is_x = u < nxs;
             const uint32_t meta = s_meta[u];
-            const int pl = (meta >> 8) & 0xff, q = meta >> 16;
+            bool ok = (meta & 5u) == 5u;
+            if (!full) {
+                const int pl = (meta >> 8) & 0xff, q = meta >> 16;
+                ok = ok && c.q0 + q < kq && pl < (is_x ? na : nw);
+            }
+            const int32_t org = is_x ? xo : wo, lim = s_lim[u];
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if ((meta & 4u) && c.q0 + q < kq) {
-                if ((meta & 1u) && pl < na) v = ldg4(pr.X, pr.x_words, xbase + s_goff[u]);
-                else if ((meta & 2u) && pl < nw) v = ldg4(pr.W, pr.w_words, wbase + s_goff[u]);
+            if (ok) {
+                if (org <= lim) {
+                    // SGPR base + zero-extended 32-bit VGPR byte offset (global_load saddr form)
+                    v = is_x ? *reinterpret_cast<const uint4 *>(xb + s_boff[u])
+                             : *reinterpret_cast<const uint4 *>(wbp + s_boff[u]);
+                } else if (org < lim + 4) {  // the buffer ends inside this granule
+                    v = ldg4(is_x ? pr.X : pr.W, is_x ? pr.x_words : pr.w_words,
+                             static_cast<unsigned long long>(org) + (s_boff[u] >> 2));
+                }
             }
             pre[u] = v;
         }
@@ -385,11 +411,10 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
     for (int u = 0; u < GPT; u++) {
         const uint32_t meta = s_meta[u];
         const uint32_t pl = (meta >> 8) & 0xff, q = meta >> 16;
-        const int g = tid + u * NT;
-        uint32_t loff = 0;
-        if (meta & 1u) loff = (pl * qc + q) * XR + ((g >> lqc) & (TM - 1));
-        else if (meta & 2u) loff = sh.ab * qc * XR + (pl * qc + q) * WR + (((g - xg_full) >> lqc) & (TN - 1));
-        s_loff[u] = loff;
+        const bool is_x = u < nxs;
+        const uint32_t t = (tid >> lqc) + (is_x ? u : u - nxs) * (NT >> lqc);
+        s_loff[u] = is_x ? (pl * qc + q) * XR + (t & (TM - 1))
+                         : sh.ab * qc * XR + (pl * qc + q) * WR + (t & (TN - 1));
     }
 
     uint32_t tot[R][C];  // unsigned: the reference's int32 accumulation wraps on overflow
@@ -405,7 +430,7 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
 #pragma unroll
             for (int u = 0; u < GPT; u++) {
                 if (u >= nslots) break;
-                if (s_meta[u] & 3u) dst[s_loff[u]] = pre[u];
+                if (s_meta[u] & 1u) dst[s_loff[u]] = pre[u];
             }
         }
         STAMP(2 + it * 4);
@@ -444,45 +469,62 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
             }
             for (int pw = 0; pw < nw; pw++) {
                 uint32_t part[R][C];
-#pragma unroll
-                for (int i = 0; i < R; i++)
-#pragma unroll
-                    for (int j = 0; j < C; j++) part[i][j] = 0u;
-                for (int q = qlo; q < qhi; q++) {
-                    if (prepass && !((occ >> (q - qlo)) & 1ull)) continue;  // zero X tile: skip
+                bool have = false;  // wave-uniform: part holds a value
+                // software pipeline over the wave's k-quads: the granules of k-quad q+1 are read
+                // from LDS while k-quad q is being multiplied
+                uint4 xg[R], wg[C], xn[R], wn[C];
+                auto lds_read = [&](int q, uint4 (&xr)[R], uint4 (&wr)[C]) {
                     const uint4 *xp = Xs + (pa * qc + q) * XR + lm;
                     const uint4 *wp = Ws + (pw * qc + q) * WR + ln;
-                    uint4 xg[R], wg[C];
 #pragma unroll
-                    for (int i = 0; i < R; i++) xg[i] = xp[i * Cfg::LM];
+                    for (int i = 0; i < R; i++) xr[i] = xp[i * Cfg::LM];
+#pragma unroll
+                    for (int j = 0; j < C; j++) wr[j] = wp[j * Cfg::LN];
+                };
+                if (qlo < qhi) lds_read(qlo, xg, wg);
+                for (int q = qlo; q < qhi; q++) {
+                    if (q + 1 < qhi) lds_read(q + 1, xn, wn);
+                    bool skip = prepass && !((occ >> (q - qlo)) & 1ull);
                     if (ZS && !prepass) {
                         uint32_t any = 0u;
 #pragma unroll
                         for (int i = 0; i < R; i++) any |= (xg[i].x | xg[i].y) | (xg[i].z | xg[i].w);
-                        if (__ballot(any != 0u) == 0ull) continue;  // zero X tile: skip
+                        skip = __ballot(any != 0u) == 0ull;  // zero X tile
+                    }
+                    if (!skip) {
+                        // word-major order: consecutive v_bcnt hit different accumulators
+                        if (!have) {
+#pragma unroll
+                            for (int i = 0; i < R; i++)
+#pragma unroll
+                                for (int j = 0; j < C; j++) part[i][j] = __popc(xg[i].x & wg[j].x);
+                            have = true;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < R; i++)
+#pragma unroll
+                                for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xg[i].x, wg[j].x);
+                        }
+#pragma unroll
+                        for (int i = 0; i < R; i++)
+#pragma unroll
+                            for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xg[i].y, wg[j].y);
+#pragma unroll
+                        for (int i = 0; i < R; i++)
+#pragma unroll
+                            for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xg[i].z, wg[j].z);
+#pragma unroll
+                        for (int i = 0; i < R; i++)
+#pragma unroll
+                            for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xg[i].w, wg[j].w);
                     }
 #pragma unroll
-                    for (int j = 0; j < C; j++) wg[j] = wp[j * Cfg::LN];
-                    // word-major order: consecutive v_bcnt hit different accumulators
+                    for (int i = 0; i < R; i++) xg[i] = xn[i];
 #pragma unroll
-                    for (int i = 0; i < R; i++)
-#pragma unroll
-                        for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xg[i].x, wg[j].x);
-#pragma unroll
-                    for (int i = 0; i < R; i++)
-#pragma unroll
-                        for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xg[i].y, wg[j].y);
-#pragma unroll
-                    for (int i = 0; i < R; i++)
-#pragma unroll
-                        for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xg[i].z, wg[j].z);
-#pragma unroll
-                    for (int i = 0; i < R; i++)
-#pragma unroll
-                        for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xg[i].w, wg[j].w);
+                    for (int j = 0; j < C; j++) wg[j] = wn[j];
                 }
                 const int s = cur.pa0 + pa + cur.pw0 + pw;  // reference kernel.h:295,340
-                if (s < 32) {
+                if (have && s < 32) {
 #pragma unroll
                     for (int i = 0; i < R; i++)
 #pragma unroll
@@ -539,10 +581,11 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
         }
         if (last_n) {  // zero the row words beyond the last column tile
             const int w0 = tiles_n * (TN / 32), nz = row_words - w0;
-            for (int e = tid; e < sh.ob * TM * nz; e += NT) {
-                const int wi = e % nz, row = (e / nz) % TM, p = e / (nz * TM);
+            for (int e = tid; e < sh.ob * TM; e += NT) {
+                const int row = e & (TM - 1), p = e / TM;
                 if (m0 + row < rows_pad)
-                    out[p * oplane + static_cast<size_t>(m0 + row) * row_words + w0 + wi] = 0u;
+                    for (int wi = 0; wi < nz; wi++)
+                        out[p * oplane + static_cast<size_t>(m0 + row) * row_words + w0 + wi] = 0u;
             }
         }
     } else {
@@ -646,8 +689,9 @@ bool plan_for(int K, int a, int w, int ob, int mode, Plan *pl) {
     while (qc > WK && qc / 2 >= kq) qc /= 2;
     int ab = a, wb = w;
     auto fits = [&](int ab_, int wb_, int qc_) {
-        return (ab_ * Cfg::TM + wb_ * Cfg::TN) * qc_ <= Cfg::GPT * Cfg::NT &&
-               mm_lds_bytes<R, C, WK>(ab_, wb_, qc_) <= kLdsBudget;
+        const int xs = (ab_ * Cfg::TM * qc_ + Cfg::NT - 1) / Cfg::NT;
+        const int ws = (wb_ * Cfg::TN * qc_ + Cfg::NT - 1) / Cfg::NT;
+        return xs + ws <= Cfg::GPT && mm_lds_bytes<R, C, WK>(ab_, wb_, qc_) <= kLdsBudget;
     };
     while (!fits(ab, wb, qc)) {
         if (wb >= ab && wb > 1) wb = (wb + 1) / 2;
@@ -756,12 +800,13 @@ int check_mm_args(const uint32_t *X, const uint32_t *W, const void *out, int M, 
     if (M <= 0 || K <= 0 || N <= 0) return QGTC_EINVAL;
     if (!bits_ok(a) || !bits_ok(w)) return QGTC_EINVAL;
     if (!aligned16(X) || !aligned16(W)) return QGTC_EALIGN;
+    if (step128(K) * 4 >= (1 << 24)) return QGTC_EINVAL;  // 24-bit row-stride multiplies in the kernel
     return QGTC_OK;
 }
 
-// in-kernel offsets inside one operand are 32-bit words
+// in-kernel byte offsets inside one operand are 32-bit
 inline bool words_ok(size_t x_words, size_t w_words) {
-    return x_words < (1ull << 32) && w_words < (1ull << 32);
+    return x_words < (1ull << 30) && w_words < (1ull << 30);  // < 4 GiB per packed operand
 }
 
 int grid_for(size_t work_items, int per_block) {

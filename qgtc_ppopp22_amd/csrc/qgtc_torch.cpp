@@ -273,6 +273,9 @@ struct BatchedGemm {
             TORCH_CHECK(X.device() == dev && W.device() == dev, "all operands must share a device");
             const int M = std::get<0>(dims[i]), K = std::get<1>(dims[i]), N = std::get<2>(dims[i]);
             TORCH_CHECK(M > 0 && K > 0 && N > 0, "bad dimensions");
+            TORCH_CHECK(X.numel() < (1LL << 30) && W.numel() < (1LL << 30), "packed operand too large (>= 4 GiB)");
+            TORCH_CHECK((reinterpret_cast<uintptr_t>(X.data_ptr()) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(W.data_ptr()) & 15) == 0, "packed operands must be 16-byte aligned");
             torch::Tensor out;
             if (mode == 2)
                 out = torch::empty({M, N}, torch::TensorOptions().dtype(torch::kFloat32).device(dev));
