@@ -291,6 +291,7 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
     using Cfg = MMCfg<R, C, WK>;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::NT, XR = Cfg::XR, WR = Cfg::WR,
                   TNP = Cfg::TNP, GPT = Cfg::GPT;
+    STAMP(26);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wk = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -302,6 +303,9 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
     const uint32_t x_plane = static_cast<uint32_t>(pad8(M)) * kw;  // < 2^32 (checked on the host)
     const uint32_t w_plane = static_cast<uint32_t>(pr.w_lines) * kw;
     const int m0 = tm * TM, n0 = tn * TN;
+#ifdef QGTC_STAMPS
+    if (M > 0) STAMP(27);  // after the first use of a kernel argument
+#endif
     const int qc = sh.qc, lqc = 31 - __clz(qc);
     const int qw = qc / WK;                      // k-quads per wave per chunk
 
@@ -373,6 +377,10 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
         const int32_t wo = static_cast<int32_t>(c.pw0 * w_plane + c.q0 * 4u);
         const char *xb = reinterpret_cast<const char *>(pr.X + xo);   // uniform stage origins
         const char *wbp = reinterpret_cast<const char *>(pr.W + wo);
+        // Fast path only inside the load loop (exec-masked loads, no merge with other values, so
+        // the compiler leaves all of them in flight); granules that straddle the end of a
+        // mis-sized buffer are fixed up afterwards in a wave-uniform, rarely taken branch.
+        uint32_t partial = 0u;
 #pragma unroll
         for (int u = 0; u < GPT; u++) {
             if (u >= nslots) break;
@@ -384,18 +392,23 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
                 ok = ok && c.q0 + q < kq && pl < (is_x ? na : nw);
             }
             const int32_t org = is_x ? xo : wo, lim = s_lim[u];
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (ok) {
-                if (org <= lim) {
-                    // SGPR base + zero-extended 32-bit VGPR byte offset (global_load saddr form)
-                    v = is_x ? *reinterpret_cast<const uint4 *>(xb + s_boff[u])
-                             : *reinterpret_cast<const uint4 *>(wbp + s_boff[u]);
-                } else if (org < lim + 4) {  // the buffer ends inside this granule
-                    v = ldg4(is_x ? pr.X : pr.W, is_x ? pr.x_words : pr.w_words,
-                             static_cast<unsigned long long>(org) + (s_boff[u] >> 2));
-                }
+            pre[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (ok && org <= lim) {
+                // SGPR base + zero-extended 32-bit VGPR byte offset (global_load saddr form)
+                pre[u] = is_x ? *reinterpret_cast<const uint4 *>(xb + s_boff[u])
+                              : *reinterpret_cast<const uint4 *>(wbp + s_boff[u]);
             }
-            pre[u] = v;
+            if (ok && org > lim && org < lim + 4) partial |= 1u << u;
+        }
+        if (__builtin_expect(__ballot(partial != 0u) != 0ull, 0)) {
+#pragma unroll
+            for (int u = 0; u < GPT; u++) {
+                if (u >= nslots) break;
+                const bool is_x = u < nxs;
+                if ((partial >> u) & 1u)  // the buffer ends inside this granule
+                    pre[u] = ldg4(is_x ? pr.X : pr.W, is_x ? pr.x_words : pr.w_words,
+                                  static_cast<unsigned long long>(is_x ? xo : wo) + (s_boff[u] >> 2));
+            }
         }
     };
 
@@ -469,7 +482,11 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
             }
             for (int pw = 0; pw < nw; pw++) {
                 uint32_t part[R][C];
-                bool have = false;  // wave-uniform: part holds a value
+#pragma unroll
+                for (int i = 0; i < R; i++)
+#pragma unroll
+                    for (int j = 0; j < C; j++) part[i][j] = 0u;
+                bool have = false;  // wave-uniform: at least one k-quad was multiplied
                 // software pipeline over the wave's k-quads: the granules of k-quad q+1 are read
                 // from LDS while k-quad q is being multiplied
                 uint4 xg[R], wg[C], xn[R], wn[C];
@@ -481,47 +498,43 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
 #pragma unroll
                     for (int j = 0; j < C; j++) wr[j] = wp[j * Cfg::LN];
                 };
-                if (qlo < qhi) lds_read(qlo, xg, wg);
-                for (int q = qlo; q < qhi; q++) {
-                    if (q + 1 < qhi) lds_read(q + 1, xn, wn);
+                // multiply one k-quad held in registers (or skip it when its X tile is zero)
+                auto mac = [&](int q, const uint4 (&xr)[R], const uint4 (&wr)[C]) {
                     bool skip = prepass && !((occ >> (q - qlo)) & 1ull);
                     if (ZS && !prepass) {
                         uint32_t any = 0u;
 #pragma unroll
-                        for (int i = 0; i < R; i++) any |= (xg[i].x | xg[i].y) | (xg[i].z | xg[i].w);
+                        for (int i = 0; i < R; i++) any |= (xr[i].x | xr[i].y) | (xr[i].z | xr[i].w);
                         skip = __ballot(any != 0u) == 0ull;  // zero X tile
                     }
-                    if (!skip) {
-                        // word-major order: consecutive v_bcnt hit different accumulators
-                        if (!have) {
+                    if (skip) return;
+                    // word-major order: consecutive v_bcnt hit different accumulators
+                    have = true;
 #pragma unroll
-                            for (int i = 0; i < R; i++)
+                    for (int i = 0; i < R; i++)
 #pragma unroll
-                                for (int j = 0; j < C; j++) part[i][j] = __popc(xg[i].x & wg[j].x);
-                            have = true;
-                        } else {
+                        for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xr[i].x, wr[j].x);
 #pragma unroll
-                            for (int i = 0; i < R; i++)
+                    for (int i = 0; i < R; i++)
 #pragma unroll
-                                for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xg[i].x, wg[j].x);
-                        }
+                        for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xr[i].y, wr[j].y);
 #pragma unroll
-                        for (int i = 0; i < R; i++)
+                    for (int i = 0; i < R; i++)
 #pragma unroll
-                            for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xg[i].y, wg[j].y);
+                        for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xr[i].z, wr[j].z);
 #pragma unroll
-                        for (int i = 0; i < R; i++)
+                    for (int i = 0; i < R; i++)
 #pragma unroll
-                            for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xg[i].z, wg[j].z);
-#pragma unroll
-                        for (int i = 0; i < R; i++)
-#pragma unroll
-                            for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xg[i].w, wg[j].w);
-                    }
-#pragma unroll
-                    for (int i = 0; i < R; i++) xg[i] = xn[i];
-#pragma unroll
-                    for (int j = 0; j < C; j++) wg[j] = wn[j];
+                        for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xr[i].w, wr[j].w);
+                };
+                // two register sets in ping-pong (no register copies)
+                if (qlo < qhi) lds_read(qlo, xg, wg);
+                for (int q = qlo; q < qhi; q += 2) {
+                    if (q + 1 < qhi) lds_read(q + 1, xn, wn);
+                    mac(q, xg, wg);
+                    if (q + 1 >= qhi) break;
+                    if (q + 2 < qhi) lds_read(q + 2, xg, wg);
+                    mac(q + 1, xn, wn);
                 }
                 const int s = cur.pa0 + pa + cur.pw0 + pw;  // reference kernel.h:295,340
                 if (have && s < 32) {

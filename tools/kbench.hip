@@ -40,8 +40,8 @@ int main(int argc, char **argv) {
     CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8));
     for (int b : {0, 1, 100, 255}) {
         printf("block %3d:", b);
-        unsigned long long t0 = st[b * 32];
-        for (int s = 1; s < 32; s++) {
+        unsigned long long t0 = st[b * 32 + 26];
+        for (int s = 0; s < 32; s++) {
             unsigned long long t = st[b * 32 + s];
             if (t >= t0 && t - t0 < 100000000ull) printf(" [%d]%llu", s, t - t0);
         }
