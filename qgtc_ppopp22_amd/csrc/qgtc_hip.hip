@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 
 #include "qgtc.h"
 
@@ -208,30 +209,108 @@ __global__ __launch_bounds__(256) void k_tile_counters(const uint32_t *__restric
 
 // ------------------------------------------------------------------------------------------
 // the bit-GEMM
+//
+// Decomposition. A workgroup owns a 32 x 32 output tile for the whole K range, so no reduction
+// ever crosses workgroups and the int32 sums are exact in any order. Its waves split K: wave v
+// owns the k-quads (128-bit steps of a packed row) [v*per, v*per + per). Everything a wave
+// multiplies is private to it: it loads its own slice of the X rows and W lines, stages it in
+// its own LDS region and reads it back in the micro-tile pattern, so the main loop has NO
+// workgroup barrier; the waves only meet once, to sum their 32 x 32 partial tiles through LDS.
+//
+// Per stage a wave holds QW k-quads of `ab` X planes and `wb` W planes:
+//   global -> registers   raw buffer loads (hardware range check: any dword outside the stated
+//                         extent reads as 0, so mis-sized / mis-laid operands can never fault),
+//                         lane = (line, k-quad) with the k-quads of one packed row in adjacent
+//                         lanes: every load instruction touches whole 16/32/64-byte runs;
+//   registers -> LDS      ds_write_b128 into [plane][k-quad][line] (pitch RS granules: the 8
+//                         lanes of one write group land in 8 different bank quads);
+//   LDS -> registers      ds_read_b128: the 8 distinct granules a wave reads per instruction are
+//                         contiguous, so reads are conflict-free and broadcast to 8 lanes each;
+//   the loads of stage s+1 are in flight while stage s is multiplied.
+// Each lane keeps a 4 x 4 register micro-tile (rows lm + 8i, columns ln + 8j) and spends, per
+// k-quad and plane pair, 8 granule reads on 64 v_and_b32 + 64 v_bcnt_u32_b32 (accumulate form).
+//
+// Zero-tile skipping. While a stage is still in registers the wave ORs each X granule and
+// ballots: one scalar bit per (X plane, k-quad) says whether the 32-row x 128-bit tile has any
+// bit set. All-zero tiles are skipped with a scalar branch (no divergence, no extra VALU work).
 // ------------------------------------------------------------------------------------------
 #ifdef QGTC_STAMPS  // diagnostic build only (tools/kbench.hip): per-phase s_memtime stamps
-__device__ unsigned long long g_stamps[1024 * 32];
-#define STAMP(slot)                                                                      \
-    do {                                                                                 \
-        if (threadIdx.x == 0 && (slot) < 32) g_stamps[blockIdx.x % 1024 * 32 + (slot)] = clock64(); \
+// The stamps stay in scalar registers while the kernel runs (a store per stamp would put memory
+// traffic and waits into the phases being timed); wave 0 of each workgroup writes them out at the end.
+__device__ unsigned long long g_stamps[1024 * 16];
+struct Stamps {
+    unsigned long long t[16];
+};
+#define STAMP_DECL Stamps stamps_; for (int i_ = 0; i_ < 16; i_++) stamps_.t[i_] = 0ull
+#define STAMP(slot) stamps_.t[slot] = __builtin_amdgcn_s_memtime()
+#define STAMP_FLUSH()                                                                          \
+    do {                                                                                       \
+        if (threadIdx.x == 0)                                                                  \
+            for (int i_ = 0; i_ < 16; i_++) g_stamps[blockIdx.x % 1024 * 16 + i_] = stamps_.t[i_]; \
     } while (0)
+#define STAMP_ARG , Stamps &stamps_
+#define STAMP_PASS , stamps_
 #else
+#define STAMP_DECL do { } while (0)
 #define STAMP(slot) do { } while (0)
+#define STAMP_FLUSH() do { } while (0)
+#define STAMP_ARG
+#define STAMP_PASS
 #endif
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct MMShape {           // per-launch constants
     int a, w, ob;          // planes of X, planes of W, output planes
     int mode;              // 0 rows-layout bits, 1 cols-layout bits, 2 float32
-    int qc;                // k-quads (128-bit steps) staged per chunk: power of two, WK..64
-    int ab, wb;            // plane blocking (planes staged at once)
+    int ab, wb;            // planes staged at once (generic kernel; the fixed kernels stage all)
+    int per;               // k-quads per wave (in-workgroup split-K slice)
     float maxv, maxm1;     // 2^ob and 2^ob - 1 as float (requant)
 };
+
+constexpr int TM = 32, TN = 32;      // workgroup tile
+constexpr int MR = 4, MC = 4;        // per-lane micro-tile
+constexpr int GPT = 8;               // granules (16 B) a lane may hold per stage
+constexpr int SLAB_PITCH = 72;       // ints between the (i,j) planes of the reduction tile
+constexpr int SLAB_BYTES = MR * MC * SLAB_PITCH * 4;
+constexpr int MAX_WAVES = 8;
+
+// granule pitch of one (plane, k-quad) line block in LDS
+__host__ __device__ constexpr int lds_pitch(int qw) { return qw == 4 ? 34 : (qw == 2 ? 36 : 32); }
+// slots (one 16-byte load per lane each) that `planes` plane tiles of QW k-quads need
+__host__ __device__ constexpr int slots_for(int planes, int qw) { return (planes * qw + 1) / 2; }
+// bytes of one wave's staging region
+__host__ __device__ constexpr size_t region_bytes(int planes, int qw) {
+    return static_cast<size_t>(planes) * qw * lds_pitch(qw) * 16;
+}
 
 // acc += popcount(x & w): v_and_b32 + v_bcnt_u32_b32 with the accumulator as the add operand
 // (hipcc otherwise emits v_bcnt(...,0) + v_add3_u32, 2.5 instructions per pair instead of 2).
 __device__ __forceinline__ void and_popc_acc(uint32_t &acc, uint32_t x, uint32_t w) {
     const uint32_t t = x & w;
     asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(t));
+}
+
+// one k-quad of the 4 x 4 micro-tile: 64 AND + 64 BCNT; word-major order so that consecutive
+// v_bcnt hit different accumulators
+__device__ __forceinline__ void mac_quad(uint32_t (&acc)[MR][MC], const u32x4 (&xg)[MR],
+                                         const u32x4 (&wg)[MC]) {
+#pragma unroll
+    for (int i = 0; i < MR; i++)
+#pragma unroll
+        for (int j = 0; j < MC; j++) and_popc_acc(acc[i][j], xg[i].x, wg[j].x);
+#pragma unroll
+    for (int i = 0; i < MR; i++)
+#pragma unroll
+        for (int j = 0; j < MC; j++) and_popc_acc(acc[i][j], xg[i].y, wg[j].y);
+#pragma unroll
+    for (int i = 0; i < MR; i++)
+#pragma unroll
+        for (int j = 0; j < MC; j++) and_popc_acc(acc[i][j], xg[i].z, wg[j].z);
+#pragma unroll
+    for (int i = 0; i < MR; i++)
+#pragma unroll
+        for (int j = 0; j < MC; j++) and_popc_acc(acc[i][j], xg[i].w, wg[j].w);
 }
 
 __device__ __forceinline__ int requant(int c, float maxv, float maxm1) {
@@ -243,396 +322,458 @@ __device__ __forceinline__ int requant(int c, float maxv, float maxm1) {
     return val >= 2147483648.0f ? 2147483647 : static_cast<int>(val);
 }
 
-template <int R, int C, int WK>
-struct MMCfg {
-    static constexpr int LM = 8, LN = 8;
-    static constexpr int TM = LM * R, TN = LN * C;
-    static constexpr int NT = 64 * WK;
-    static constexpr int XR = TM + 1, WR = TN + 1;  // odd row counts: conflict-free staging writes
-    static constexpr int TNP = TN + 8;              // reduction row pitch (words)
-    static constexpr int RED_BYTES = WK * TM * TNP * 4;
-    static constexpr int GPT = 8;                   // granules a thread may prefetch per stage
-};
-
-// bytes of one LDS staging buffer (there are two)
-template <int R, int C, int WK>
-__host__ __device__ constexpr size_t mm_stage_bytes(int ab, int wb, int qc) {
-    using Cfg = MMCfg<R, C, WK>;
-    return static_cast<size_t>(ab * Cfg::XR + wb * Cfg::WR) * qc * 16;
+// slot u of an operand, lane l  ->  (plane tile, line within the 32-line tile, k-quad of the chunk)
+template <int QW>
+__device__ __forceinline__ void slot_map(int u, int lane, int &pt, int &line, int &kk) {
+    if (QW == 4) {
+        pt = u >> 1;
+        line = ((u & 1) << 4) + (lane >> 2);
+        kk = lane & 3;
+    } else if (QW == 2) {
+        pt = u;
+        line = lane >> 1;
+        kk = lane & 1;
+    } else {
+        pt = 2 * u + (lane >> 5);
+        line = lane & 31;
+        kk = 0;
+    }
 }
 
-template <int R, int C, int WK>
-__host__ __device__ constexpr size_t mm_lds_bytes(int ab, int wb, int qc) {
-    using Cfg = MMCfg<R, C, WK>;
-    size_t stage2 = 2 * mm_stage_bytes<R, C, WK>(ab, wb, qc);
-    size_t body = stage2 > static_cast<size_t>(Cfg::RED_BYTES) ? stage2 : Cfg::RED_BYTES;
-    return body;
+// occupancy bits (bit kk = "k-quad kk of plane tile pt has a set bit") from the ballots of the
+// slots that hold the tile
+template <int QW>
+__device__ __forceinline__ uint32_t tile_occupancy(const unsigned long long (&nzm)[GPT], int pt) {
+    if (QW == 4) {
+        const unsigned long long m = nzm[2 * pt] | nzm[2 * pt + 1];
+        uint32_t o = 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) o |= (m & (0x1111111111111111ull << kk)) ? (1u << kk) : 0u;
+        return o;
+    } else if (QW == 2) {
+        const unsigned long long m = nzm[pt];
+        return ((m & 0x5555555555555555ull) ? 1u : 0u) | ((m & 0xaaaaaaaaaaaaaaaaull) ? 2u : 0u);
+    } else {
+        const unsigned long long m = nzm[pt >> 1];
+        return ((pt & 1) ? (m >> 32) : (m & 0xffffffffull)) ? 1u : 0u;
+    }
 }
 
-// Position in the (X plane block, W plane block, K chunk) iteration space.
-struct MMCursor {
-    int pa0, pw0, q0;
-    bool valid;
-};
+// OR over aligned groups of 8 lanes (every lane of the wave must be active)
+__device__ __forceinline__ uint32_t or_reduce8(uint32_t x) {
+    x |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0xB1, 0xf, 0xf, false));   // lane ^ 1
+    x |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x4E, 0xf, 0xf, false));   // lane ^ 2
+    x |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x141, 0xf, 0xf, false));  // 7 - lane
+    return x;
+}
+
+// In-workgroup split-K reduction and the fused epilogue.
+//
+// Reduction: the workgroup shares ONE 32 x 32 int32 tile in LDS, laid out [i*4+j][lane] (pitch 72
+// ints; the cols-layout epilogue uses the transposed lane index) and zeroed at kernel start.
+// Every wave adds its partial sums with no-return ds_add_u32 as soon as it has them, so after
+// the single barrier a thread gets a finished quad (four consecutive columns of a row, or rows
+// of a column) with one ds_read_b128. Integer adds commute: bit-exact in any arrival order.
+//
+// Epilogue (MODE 0 rows-layout bits, 1 cols-layout bits, 2 float32): a thread requantises its
+// quad and builds the quad's nibble of each output plane; eight adjacent lanes OR their nibbles
+// into the 32-bit word of one row (column) of the tile with DPP. Everything that does not
+// depend on the sums (addresses, masks) is computed BEFORE the barrier, while the wave would
+// otherwise idle waiting for its siblings.
+template <int MODE>
+__device__ __forceinline__ void tile_epilogue(const qgtc_problem &pr, const MMShape &sh,
+                                              const uint32_t (&tot)[MR][MC], int tm, int tn,
+                                              int tiles_m, int tiles_n, int *tile STAMP_ARG) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nwv = blockDim.x >> 6, NT = nwv * 64;
+    const int lm = lane >> 3, ln = lane & 7;
+    const int M = pr.M, N = pr.N;
+    const int m0 = tm * TM, n0 = tn * TN;
+    {
+        uint32_t *mine = reinterpret_cast<uint32_t *>(tile) + (MODE == 1 ? ln * 8 + lm : lane);
+#pragma unroll
+        for (int i = 0; i < MR; i++)
+#pragma unroll
+            for (int j = 0; j < MC; j++)
+                __hip_atomic_fetch_add(mine + (i * MC + j) * SLAB_PITCH, tot[i][j], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    STAMP(8);
+    const bool last_n = tn == tiles_n - 1, last_m = tm == tiles_m - 1;
+    const bool int_requant = sh.ob <= 23;  // float(c) > 2^ob  <=>  c > 2^ob for every int c >= 0
+    const int maxi = int_requant ? (1 << sh.ob) : 0;
+    // quad t = hi<<6 | a8<<3 | lo<<1 | h ; rows layout / float: (hi,lo) = (i,j), cols layout: (j,i).
+    // Up to 4 quads per thread (single-wave workgroups); their setup happens before the barrier.
+    constexpr int QMAX = 4;
+    const int nq = (256 + NT - 1) / NT;  // quads per thread: 1 (>= 4 waves), 2 (2-3 waves), 4 (1 wave)
+    int q_idx[QMAX];
+    size_t q_o0[QMAX];
+    uint32_t q_ok[QMAX];  // bits 0..3: element valid; bit 4: this lane stores the word / the quad row exists
+#pragma unroll
+    for (int r = 0; r < QMAX; r++) {
+        const int t = tid + r * NT;
+        const int hi = t >> 6, a8 = (t >> 3) & 7, lo = (t >> 1) & 3, h = t & 1;
+        const int i = MODE == 1 ? lo : hi, j = MODE == 1 ? hi : lo;
+        q_idx[r] = (i * MC + j) * SLAB_PITCH + a8 * 8 + h * 4;
+        const int m = MODE == 1 ? m0 + 8 * i + 4 * h : m0 + a8 + 8 * i;
+        const int n = MODE == 1 ? n0 + a8 + 8 * j : n0 + 8 * j + 4 * h;
+        uint32_t ok = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            ok |= (MODE == 1 ? (m + q < M && n < N) : (m < M && n + q < N)) ? (1u << q) : 0u;
+        if (MODE == 2) {
+            q_o0[r] = static_cast<size_t>(m) * N + n;
+            ok |= (m < M) ? 16u : 0u;
+        } else if (MODE == 0) {  // [ob][PAD8(M)][STEP128(N)*4] (reference kernel.h:357-389)
+            q_o0[r] = static_cast<size_t>(m) * (step128(N) * 4) + (n0 >> 5);
+            ok |= ((t & 7) == 0 && m < pad8(M)) ? 16u : 0u;
+        } else {                 // [ob][PAD128(N)][STEP128(M)*4] (intended semantics of kernel.h:651-810)
+            q_o0[r] = static_cast<size_t>(n) * (step128(M) * 4) + (m0 >> 5);
+            ok |= ((t & 7) == 0 && n < pad128(N)) ? 16u : 0u;
+        }
+        if (t >= 256) ok = 0u;
+        q_ok[r] = ok;
+    }
+    const int sh_n = 28 - 4 * (tid & 7);  // NT is a multiple of 8: the same for every quad of the thread
+    const size_t oplane = MODE == 0 ? static_cast<size_t>(pad8(M)) * (step128(N) * 4)
+                                    : static_cast<size_t>(pad128(N)) * (step128(M) * 4);
+    const int extra = (MODE == 0 && last_n) ? step128(N) * 4 - (n0 >> 5) - 1 : 0;  // row words past the last tile
+
+    __syncthreads();
+    STAMP(9);
+#pragma unroll
+    for (int r = 0; r < QMAX; r++) {
+        if (r >= nq) break;          // uniform
+        if (tid + r * NT >= 256) break;  // whole waves (NT and 256 are multiples of 64)
+        const int4 v4 = *reinterpret_cast<const int4 *>(tile + q_idx[r]);
+        const int v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const uint32_t ok = q_ok[r];
+        if (MODE == 2) {
+            // float32 [M,N] (reference kernel.h:915-930): row m, columns n .. n+3
+            float *dst = static_cast<float *>(pr.out) + q_o0[r];
+            if ((ok & 31u) == 31u && (N & 3) == 0) {
+                *reinterpret_cast<float4 *>(dst) = make_float4(static_cast<float>(v[0]), static_cast<float>(v[1]),
+                                                               static_cast<float>(v[2]), static_cast<float>(v[3]));
+            } else if (ok & 16u) {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if ((ok >> q) & 1u) dst[q] = static_cast<float>(v[q]);
+            }
+            continue;
+        }
+        uint32_t qv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int c;
+            if (int_requant) c = v[q] < 0 ? 1 : (v[q] > maxi ? maxi - 1 : v[q]);  // kernel.h:31-37
+            else c = requant(v[q], sh.maxv, sh.maxm1);
+            qv[q] = ((ok >> q) & 1u) ? static_cast<uint32_t>(c) : 0u;
+        }
+        uint32_t *out = static_cast<uint32_t *>(pr.out) + q_o0[r];
+        for (int p = 0; p < sh.ob; p++) {
+            // element e of the row's (column's) 32 sits at bit 31 - e; this quad is e = 4*(t&7) .. +3
+            const uint32_t nib = (((qv[0] >> p) & 1u) << 3) | (((qv[1] >> p) & 1u) << 2) |
+                                 (((qv[2] >> p) & 1u) << 1) | ((qv[3] >> p) & 1u);
+            const uint32_t word = or_reduce8(nib << sh_n);
+#ifndef QGTC_ABL_NOSTORE
+            if (ok & 16u) {
+                out[p * oplane] = word;
+                for (int x = 1; x <= extra; x++) out[p * oplane + x] = 0u;
+            }
+#else
+            asm volatile("" ::"v"(word));
+#endif
+        }
+    }
+    STAMP(14);
+    if (MODE == 1) {
+        // zero what no tile computes: words past the last row tile, lines past the last column tile
+        uint32_t *out = static_cast<uint32_t *>(pr.out);
+        const int lines = pad128(N), line_words = step128(M) * 4;
+        const int w_core0 = m0 >> 5, w_core1 = min(line_words, w_core0 + 1);
+        if (last_m && w_core1 < line_words) {
+            for (int e = tid; e < sh.ob * TN; e += NT) {
+                const int line = n0 + (e & (TN - 1)), p = e / TN;
+                if (line < lines)
+                    for (int wi = w_core1; wi < line_words; wi++)
+                        out[p * oplane + static_cast<size_t>(line) * line_words + wi] = 0u;
+            }
+        }
+        if (last_n && n0 + TN < lines) {
+            const int nl = lines - (n0 + TN), w_end = last_m ? line_words : w_core1;
+            for (int e = tid; e < sh.ob * nl; e += NT) {
+                const int line = n0 + TN + e % nl, p = e / nl;
+                for (int wi = w_core0; wi < w_end; wi++)
+                    out[p * oplane + static_cast<size_t>(line) * line_words + wi] = 0u;
+            }
+        }
+    }
+}
 
 // One output tile (tm, tn) of one problem. All threads of the workgroup call this.
-//
-// Software pipeline, one barrier per stage: while the waves compute stage s out of LDS buffer
-// s&1, the global loads of stage s+1 are in flight into registers (GPT granules per thread);
-// they are written to buffer (s+1)&1 at the top of the next iteration.
-//
-// Zero-tile skipping (ZS): before a wave spends R*C*4 AND+popcount pairs on a k-quad it ORs the
-// R granules each lane just read from LDS and ballots: if the whole TM x 128-bit X tile is zero
-// the wave skips the k-quad (wave-uniform scalar branch). For products with several W planes
-// the test is hoisted out of the plane loop (one pre-pass over the wave's k-quads per X plane).
-template <int R, int C, int WK, bool ZS>
+// NA, NW > 0: compile-time plane counts (== sh.a, sh.w), QW k-quads per stage;
+// NA == NW == 0: generic kernel, runtime plane blocks sh.ab x sh.wb, QW = 1.
+template <int QW, int NA, int NW, bool ZS>
 __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &sh, int tm, int tn,
                                         int tiles_m, int tiles_n, unsigned char *smem) {
-    using Cfg = MMCfg<R, C, WK>;
-    constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::NT, XR = Cfg::XR, WR = Cfg::WR,
-                  TNP = Cfg::TNP, GPT = Cfg::GPT;
-    STAMP(26);
+    constexpr bool GEN = NA == 0;
+    static_assert(!GEN || QW == 1, "the generic kernel stages one k-quad at a time");
+    constexpr int RS = lds_pitch(QW);
+    STAMP_DECL;
+    STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wk = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwv = blockDim.x >> 6;
     const int lm = lane >> 3, ln = lane & 7;
 
     const int M = pr.M, K = pr.K, N = pr.N;
     const int kq = step128(K);                   // k-quads per packed row
     const uint32_t kw = static_cast<uint32_t>(kq) * 4u;
-    const uint32_t x_plane = static_cast<uint32_t>(pad8(M)) * kw;  // < 2^32 (checked on the host)
+    const uint32_t x_plane = static_cast<uint32_t>(pad8(M)) * kw;  // < 2^30 words (host-checked)
     const uint32_t w_plane = static_cast<uint32_t>(pr.w_lines) * kw;
     const int m0 = tm * TM, n0 = tn * TN;
-#ifdef QGTC_STAMPS
-    if (M > 0) STAMP(27);  // after the first use of a kernel argument
-#endif
-    const int qc = sh.qc, lqc = 31 - __clz(qc);
-    const int qw = qc / WK;                      // k-quads per wave per chunk
+    const int ab = GEN ? sh.ab : NA, wb = GEN ? sh.wb : NW;
+    const int nsx = GEN ? slots_for(ab, 1) : slots_for(NA, QW);
+    const int nsw = GEN ? slots_for(wb, 1) : slots_for(NW, QW);
+    const int ks = wv * sh.per, ke = min(ks + sh.per, kq);  // this wave's k-quads
 
-    const uint32_t stage_granules = static_cast<uint32_t>(sh.ab * XR + sh.wb * WR) * qc;
-    uint4 *stage_base = reinterpret_cast<uint4 *>(smem);
-    int *red = reinterpret_cast<int *>(smem);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(pr.X), 0, static_cast<int>(static_cast<uint32_t>(pr.x_words) * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(pr.W), 0, static_cast<int>(static_cast<uint32_t>(pr.w_words) * 4u), 0x00020000);
 
-    auto advance = [&](MMCursor &c) {
-        c.q0 += qc;
-        if (c.q0 >= kq) {
-            c.q0 = 0;
-            c.pw0 += sh.wb;
+    // this wave's staging region: X plane tiles, then W plane tiles
+    u32x4 *region = reinterpret_cast<u32x4 *>(smem) + wv * ((ab + wb) * QW * RS);
+    const int wreg = ab * QW * RS;  // first granule of the W tiles
+
+    // Per-lane slot table (slot u < nsx: X, else W). Only the stage origin (plane block, first
+    // k-quad) changes from stage to stage and it is wave-uniform.
+    uint32_t s_off[GPT];   // byte offset of the granule from the stage origin
+    uint32_t s_lds[GPT];   // granule index inside the region
+    uint32_t v_in = 0u;    // bit u: the lane's granule of slot u lies inside the region
+    uint32_t v_ok = 0u;    // bit u: ... and its line exists (row < M / column < N)
+    int kkl = 0;           // the lane's k-quad within the chunk (same for every slot)
+#pragma unroll
+    for (int u = 0; u < GPT; u++) {
+        s_off[u] = 0u;
+        s_lds[u] = 0u;
+        if (u >= nsx + nsw) continue;
+        const bool is_x = u < nsx;
+        int pt, line, kk;
+        slot_map<QW>(is_x ? u : u - nsx, lane, pt, line, kk);
+        kkl = kk;
+        const bool in = pt < (is_x ? ab : wb);
+        const uint32_t gline = static_cast<uint32_t>((is_x ? m0 : n0) + line);
+        const bool ok = in && static_cast<int>(gline) < (is_x ? M : N);
+        s_off[u] = (static_cast<uint32_t>(pt) * (is_x ? x_plane : w_plane) + gline * kw +
+                    static_cast<uint32_t>(kk) * 4u) * 4u;
+        s_lds[u] = static_cast<uint32_t>((is_x ? 0 : wreg) + (pt * QW + kk) * RS + line);
+        v_in |= in ? (1u << u) : 0u;
+        v_ok |= ok ? (1u << u) : 0u;
+    }
+
+    // position in the (X plane block, W plane block, K chunk) iteration space of this wave
+    struct Cursor {
+        int pa0, pw0, q0;
+        bool valid;
+    };
+    auto advance = [&](Cursor &c) {
+        c.q0 += QW;
+        if (c.q0 >= ke) {
+            c.q0 = ks;
+            c.pw0 += wb;
             if (c.pw0 >= sh.w) {
                 c.pw0 = 0;
-                c.pa0 += sh.ab;
+                c.pa0 += ab;
                 if (c.pa0 >= sh.a) c.valid = false;
             }
         }
     };
 
-    // Per-thread slot table, computed once per tile. A stage holds ab*TM*qc X granules and
-    // wb*TN*qc W granules; X granules use slots [0, nxs), W granules slots [nxs, nslots): slot u
-    // of this thread is granule g = tid + u*NT (resp. tid + (u-nxs)*NT) of its operand, decoded
-    // as (plane, row, k-quad) with the k-quad fastest, so consecutive lanes load consecutive 16
-    // bytes of a packed row. Only the stage origin (plane block, first k-quad) changes from
-    // stage to stage, and it is wave-uniform: loads are SGPR base + 32-bit VGPR offset.
-    const int xg_full = sh.ab * TM * qc, wg_full = sh.wb * TN * qc;
-    const int nxs = (xg_full + NT - 1) / NT;
-    const int nslots = nxs + (wg_full + NT - 1) / NT;  // wave-uniform, <= GPT (plan_for)
-    uint32_t s_boff[GPT];  // BYTE offset of the granule from the stage origin (< 4 GiB, host-checked)
-    int32_t s_lim[GPT];    // largest stage origin (in words) for which the granule is in bounds
-    uint32_t s_meta[GPT];  // bit0 valid slot, bit2 row in range, bits 8..15 plane, bits 16.. k-quad
-    {
-        // cheap decode: 24-bit multiplies (v_mul_u32_u24 is full rate, v_mul_lo_u32 is not) and
-        // no divergent branches. q and the row-within-slot are the same for every slot.
-        const uint32_t q = tid & (qc - 1), t0 = tid >> lqc, tstep = NT >> lqc;
-        const uint32_t xpl_lo = x_plane & 0xffffffu, xpl_hi = x_plane >> 24;
-        const uint32_t wpl_lo = w_plane & 0xffffffu, wpl_hi = w_plane >> 24;
+    // issue the loads of one stage into registers; lanes whose granule does not exist (row or
+    // column out of range, plane or k-quad beyond this stage) load from offset 0xffffffff, which
+    // the range check turns into zeros
+    u32x4 pre[GPT];
+    auto issue = [&](const Cursor &c) {
+        const int nk = min(QW, ke - c.q0);
+        const int na = min(ab, sh.a - c.pa0), nw = min(wb, sh.w - c.pw0);
+        const uint32_t xo = (static_cast<uint32_t>(c.pa0) * x_plane + static_cast<uint32_t>(c.q0) * 4u) * 4u;
+        const uint32_t wo = (static_cast<uint32_t>(c.pw0) * w_plane + static_cast<uint32_t>(c.q0) * 4u) * 4u;
+        const bool kk_ok = kkl < nk;
 #pragma unroll
         for (int u = 0; u < GPT; u++) {
-            s_boff[u] = 0u;
-            s_lim[u] = -8;
-            s_meta[u] = 0u;
-            if (u >= nslots) continue;
-            const bool is_x = u < nxs;
-            const uint32_t t = t0 + (is_x ? u : u - nxs) * tstep;    // flattened (plane,row) index
-            const uint32_t row = is_x ? (t & (TM - 1)) : (t & (TN - 1));
-            const uint32_t pl = is_x ? (t / TM) : (t / TN);
-            const bool in_stage = is_x ? (t < static_cast<uint32_t>(sh.ab * TM)) : (t < static_cast<uint32_t>(sh.wb * TN));
-            const uint32_t grow = (is_x ? m0 : n0) + row;
-            const uint32_t ploff = is_x ? (__umul24(pl, xpl_lo) + (__umul24(pl, xpl_hi) << 24))
-                                        : (__umul24(pl, wpl_lo) + (__umul24(pl, wpl_hi) << 24));
-            const uint32_t goff = ploff + __umul24(grow, kw) + q * 4u;  // kw < 2^24 (host-checked)
-            const int32_t words = static_cast<int32_t>(is_x ? pr.x_words : pr.w_words);
-            const bool row_ok = static_cast<int>(grow) < (is_x ? M : N);
-            s_boff[u] = goff * 4u;
-            s_lim[u] = in_stage ? words - 4 - static_cast<int32_t>(goff) : -8;
-            s_meta[u] = (in_stage ? 1u : 0u) | (row_ok ? 4u : 0u) | (pl << 8) | (q << 16);
-        }
-    }
-
-    // issue the global loads of one stage into registers; out-of-range rows / planes / k-quads /
-    // words read as zero.
-    uint4 pre[GPT];
-    auto issue = [&](const MMCursor &c) {
-        const int na = min(sh.ab, sh.a - c.pa0), nw = min(sh.wb, sh.w - c.pw0);
-        const bool full = na == sh.ab && nw == sh.wb && c.q0 + qc <= kq;  // wave-uniform
-        const int32_t xo = static_cast<int32_t>(c.pa0 * x_plane + c.q0 * 4u);
-        const int32_t wo = static_cast<int32_t>(c.pw0 * w_plane + c.q0 * 4u);
-        const char *xb = reinterpret_cast<const char *>(pr.X + xo);   // uniform stage origins
-        const char *wbp = reinterpret_cast<const char *>(pr.W + wo);
-        // Fast path only inside the load loop (exec-masked loads, no merge with other values, so
-        // the compiler leaves all of them in flight); granules that straddle the end of a
-        // mis-sized buffer are fixed up afterwards in a wave-uniform, rarely taken branch.
-        uint32_t partial = 0u;
-#pragma unroll
-        for (int u = 0; u < GPT; u++) {
-            if (u >= nslots) break;
-            const bool is_x = u < nxs;
-            const uint32_t meta = s_meta[u];
-            bool ok = (meta & 5u) == 5u;
-            if (!full) {
-                const int pl = (meta >> 8) & 0xff, q = meta >> 16;
-                ok = ok && c.q0 + q < kq && pl < (is_x ? na : nw);
+            if (u >= nsx + nsw) break;
+            const bool is_x = u < nsx;
+            bool ok = ((v_ok >> u) & 1u) && kk_ok;
+            if (GEN) {
+                const int pt = 2 * (is_x ? u : u - nsx) + (lane >> 5);
+                ok = ok && pt < (is_x ? na : nw);
             }
-            const int32_t org = is_x ? xo : wo, lim = s_lim[u];
-            pre[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (ok && org <= lim) {
-                // SGPR base + zero-extended 32-bit VGPR byte offset (global_load saddr form)
-                pre[u] = is_x ? *reinterpret_cast<const uint4 *>(xb + s_boff[u])
-                              : *reinterpret_cast<const uint4 *>(wbp + s_boff[u]);
-            }
-            if (ok && org > lim && org < lim + 4) partial |= 1u << u;
-        }
-        if (__builtin_expect(__ballot(partial != 0u) != 0ull, 0)) {
-#pragma unroll
-            for (int u = 0; u < GPT; u++) {
-                if (u >= nslots) break;
-                const bool is_x = u < nxs;
-                if ((partial >> u) & 1u)  // the buffer ends inside this granule
-                    pre[u] = ldg4(is_x ? pr.X : pr.W, is_x ? pr.x_words : pr.w_words,
-                                  static_cast<unsigned long long>(is_x ? xo : wo) + (s_boff[u] >> 2));
-            }
+            const uint32_t off = ok ? s_off[u] + (is_x ? xo : wo) : 0xffffffffu;
+            pre[u] = __builtin_amdgcn_raw_buffer_load_b128(is_x ? rx : rw, off, 0, 0);
         }
     };
 
-    MMCursor cur{0, 0, 0, true};
-    STAMP(0);
-    issue(cur);
+    Cursor cur{0, 0, ks, ks < ke};
     STAMP(1);
+    if (cur.valid) issue(cur);
+    STAMP(2);
 
-    // LDS granule index of each slot ([plane][k-quad][row], X block then W block); computed
-    // while the first loads are in flight
-    uint32_t s_loff[GPT];
-#pragma unroll
-    for (int u = 0; u < GPT; u++) {
-        const uint32_t meta = s_meta[u];
-        const uint32_t pl = (meta >> 8) & 0xff, q = meta >> 16;
-        const bool is_x = u < nxs;
-        const uint32_t t = (tid >> lqc) + (is_x ? u : u - nxs) * (NT >> lqc);
-        s_loff[u] = is_x ? (pl * qc + q) * XR + (t & (TM - 1))
-                         : sh.ab * qc * XR + (pl * qc + q) * WR + (t & (TN - 1));
+    // zero the workgroup's reduction tile while the first loads are in flight
+    {
+        u32x4 *rt = reinterpret_cast<u32x4 *>(smem + nwv * ((ab + wb) * QW * RS * 16));
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int g = tid; g < SLAB_BYTES / 16; g += nwv * 64) rt[g] = z;
+        __syncthreads();
     }
 
-    uint32_t tot[R][C];  // unsigned: the reference's int32 accumulation wraps on overflow
+    uint32_t tot[MR][MC];  // unsigned: the reference's int32 accumulation wraps on overflow
 #pragma unroll
-    for (int i = 0; i < R; i++)
+    for (int i = 0; i < MR; i++)
 #pragma unroll
-        for (int j = 0; j < C; j++) tot[i][j] = 0u;
+        for (int j = 0; j < MC; j++) tot[i][j] = 0u;
+
+    // fixed kernels keep one accumulator set per shift (pa + pw) for the whole K slice
+    constexpr int NS = GEN ? 1 : NA + NW - 1;
+    uint32_t acc[NS][MR][MC];
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int i = 0; i < MR; i++)
+#pragma unroll
+            for (int j = 0; j < MC; j++) acc[s][i][j] = 0u;
+
+    const u32x4 *xrd = region + lm;         // + (pa*QW + kk)*RS + 8*i
+    const u32x4 *wrd = region + wreg + ln;  // + (pw*QW + kk)*RS + 8*j
+    auto read_x = [&](int tile_kk, u32x4 (&xr)[MR]) {
+#pragma unroll
+        for (int i = 0; i < MR; i++) xr[i] = xrd[tile_kk * RS + 8 * i];
+    };
+    auto read_w = [&](int tile_kk, u32x4 (&wr)[MC]) {
+#pragma unroll
+        for (int j = 0; j < MC; j++) wr[j] = wrd[tile_kk * RS + 8 * j];
+    };
 
     for (int it = 0; cur.valid; it++) {
-        const int buf = it & 1;
-        {   // write the prefetched granules into LDS buffer `buf`
-            uint4 *dst = stage_base + buf * stage_granules;
+        // ---- registers -> LDS, and the occupancy ballots of the X tiles ----
+        unsigned long long nzm[GPT];
 #pragma unroll
-            for (int u = 0; u < GPT; u++) {
-                if (u >= nslots) break;
-                if (s_meta[u] & 1u) dst[s_loff[u]] = pre[u];
-            }
+        for (int u = 0; u < GPT; u++) {
+            nzm[u] = 0ull;
+            if (u >= nsx + nsw) continue;
+            if ((v_in >> u) & 1u) region[s_lds[u]] = pre[u];
+            if (ZS && u < nsx) nzm[u] = __ballot(((pre[u].x | pre[u].y) | (pre[u].z | pre[u].w)) != 0u);
         }
-        STAMP(2 + it * 4);
-        __syncthreads();
-        STAMP(3 + it * 4);
+        if (it == 0) STAMP(3);
+        const Cursor now = cur;
+        advance(cur);
+        if (cur.valid) issue(cur);  // the next stage's loads fly while this one is multiplied
+        // the wave reads what its other lanes wrote: LDS is in order per wave, the fence only
+        // keeps the compiler from moving the reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (it == 0) STAMP(4);
 
-        MMCursor nxt = cur;
-        advance(nxt);
-        if (nxt.valid) issue(nxt);  // loads fly while this stage is computed
-        STAMP(4 + it * 4);
-
-        // ---- compute: this wave's k-quads [wk*qw, wk*qw+qw) of the stage ----
-        const int na = min(sh.ab, sh.a - cur.pa0), nw = min(sh.wb, sh.w - cur.pw0);
-        const uint4 *Xs = stage_base + buf * stage_granules;
-        const uint4 *Ws = Xs + sh.ab * qc * XR;
-        const int qlo = wk * qw;
-        const int qhi = min(qlo + qw, min(qc, kq - cur.q0));  // k-quads of this chunk that exist
-        for (int pa = 0; pa < na; pa++) {
-            // occupancy of this wave's k-quads of X plane pa (bit q - qlo); hoisted out of the
-            // W-plane loop when there are several W planes, tested inline otherwise
-            unsigned long long occ = ~0ull;
-            const bool prepass = ZS && nw > 2;
-            if (prepass) {
-                occ = 0ull;
-                for (int q = qlo; q < qhi; q++) {
-                    const uint4 *xp = Xs + (pa * qc + q) * XR + lm;
-                    uint32_t any = 0u;
+        const int nk = min(QW, ke - now.q0);
+        if constexpr (!GEN) {
+            uint32_t occ[NA];
 #pragma unroll
-                    for (int i = 0; i < R; i++) {
-                        const uint4 g = xp[i * Cfg::LM];
-                        any |= (g.x | g.y) | (g.z | g.w);
+            for (int pa = 0; pa < NA; pa++) occ[pa] = ZS ? tile_occupancy<QW>(nzm, pa) : ((1u << nk) - 1u);
+            constexpr int NOUT = QW * NA;  // (k-quad, X plane) pairs
+            if constexpr (NOUT * NW <= 8) {
+                // flat software pipeline over every (k-quad, X plane, W plane) step of the stage:
+                // the granules of step t+1 are read from LDS while step t is multiplied
+                constexpr int T = NOUT * NW;
+                u32x4 xg[2][MR], wg[2][MC];
+                read_x(0, xg[0]);
+                read_w(0, wg[0]);
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+                    const int o = t / NW, pw = t % NW, kk = o / NA, pa = o % NA;
+                    if (t + 1 < T) {
+                        const int o1 = (t + 1) / NW, pw1 = (t + 1) % NW, kk1 = o1 / NA, pa1 = o1 % NA;
+                        read_w(pw1 * QW + kk1, wg[(t + 1) & 1]);
+                        if (pw1 == 0) read_x(pa1 * QW + kk1, xg[o1 & 1]);
                     }
-                    if (__ballot(any != 0u)) occ |= 1ull << (q - qlo);
+#ifdef QGTC_ABL_NOMAC  // timing-only build: keep the LDS reads, skip the multiply
+                    asm volatile("" ::"v"(xg[o & 1][0].x), "v"(wg[t & 1][0].x), "v"(xg[o & 1][3].w), "v"(wg[t & 1][3].w));
+#else
+                    if ((occ[pa] >> kk) & 1u) mac_quad(acc[pa + pw], xg[o & 1], wg[t & 1]);
+#endif
                 }
-                if (occ == 0ull) continue;  // this wave's slice of the X plane is all zero
-            }
-            for (int pw = 0; pw < nw; pw++) {
-                uint32_t part[R][C];
+            } else {
+                // k-quads in a loop, the (X plane, W plane) steps of one k-quad unrolled
+#pragma unroll 1
+                for (int kk = 0; kk < nk; kk++) {
+                    u32x4 xg[MR], wg[2][MC];
 #pragma unroll
-                for (int i = 0; i < R; i++)
+                    for (int pa = 0; pa < NA; pa++) {
+                        if (!((occ[pa] >> kk) & 1u)) continue;
+                        read_x(pa * QW + kk, xg);
+                        read_w(kk, wg[0]);
 #pragma unroll
-                    for (int j = 0; j < C; j++) part[i][j] = 0u;
-                bool have = false;  // wave-uniform: at least one k-quad was multiplied
-                // software pipeline over the wave's k-quads: the granules of k-quad q+1 are read
-                // from LDS while k-quad q is being multiplied
-                uint4 xg[R], wg[C], xn[R], wn[C];
-                auto lds_read = [&](int q, uint4 (&xr)[R], uint4 (&wr)[C]) {
-                    const uint4 *xp = Xs + (pa * qc + q) * XR + lm;
-                    const uint4 *wp = Ws + (pw * qc + q) * WR + ln;
-#pragma unroll
-                    for (int i = 0; i < R; i++) xr[i] = xp[i * Cfg::LM];
-#pragma unroll
-                    for (int j = 0; j < C; j++) wr[j] = wp[j * Cfg::LN];
-                };
-                // multiply one k-quad held in registers (or skip it when its X tile is zero)
-                auto mac = [&](int q, const uint4 (&xr)[R], const uint4 (&wr)[C]) {
-                    bool skip = prepass && !((occ >> (q - qlo)) & 1ull);
-                    if (ZS && !prepass) {
-                        uint32_t any = 0u;
-#pragma unroll
-                        for (int i = 0; i < R; i++) any |= (xr[i].x | xr[i].y) | (xr[i].z | xr[i].w);
-                        skip = __ballot(any != 0u) == 0ull;  // zero X tile
+                        for (int pw = 0; pw < NW; pw++) {
+                            if (pw + 1 < NW) read_w((pw + 1) * QW + kk, wg[(pw + 1) & 1]);
+                            mac_quad(acc[pa + pw], xg, wg[pw & 1]);
+                        }
                     }
-                    if (skip) return;
-                    // word-major order: consecutive v_bcnt hit different accumulators
-                    have = true;
-#pragma unroll
-                    for (int i = 0; i < R; i++)
-#pragma unroll
-                        for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xr[i].x, wr[j].x);
-#pragma unroll
-                    for (int i = 0; i < R; i++)
-#pragma unroll
-                        for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xr[i].y, wr[j].y);
-#pragma unroll
-                    for (int i = 0; i < R; i++)
-#pragma unroll
-                        for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xr[i].z, wr[j].z);
-#pragma unroll
-                    for (int i = 0; i < R; i++)
-#pragma unroll
-                        for (int j = 0; j < C; j++) and_popc_acc(part[i][j], xr[i].w, wr[j].w);
-                };
-                // two register sets in ping-pong (no register copies)
-                if (qlo < qhi) lds_read(qlo, xg, wg);
-                for (int q = qlo; q < qhi; q += 2) {
-                    if (q + 1 < qhi) lds_read(q + 1, xn, wn);
-                    mac(q, xg, wg);
-                    if (q + 1 >= qhi) break;
-                    if (q + 2 < qhi) lds_read(q + 2, xg, wg);
-                    mac(q + 1, xn, wn);
                 }
-                const int s = cur.pa0 + pa + cur.pw0 + pw;  // reference kernel.h:295,340
-                if (have && s < 32) {
+            }
+        } else {
+            const int na = min(ab, sh.a - now.pa0), nw = min(wb, sh.w - now.pw0);
+            uint32_t occ = 0u;  // bit pa: X plane tile pa of the stage has a set bit
 #pragma unroll
-                    for (int i = 0; i < R; i++)
+            for (int u = 0; u < GPT / 2; u++)
+                occ |= ((nzm[u] & 0xffffffffull) ? (1u << (2 * u)) : 0u) | ((nzm[u] >> 32) ? (2u << (2 * u)) : 0u);
+            for (int pa = 0; pa < na; pa++) {
+                if (ZS && !((occ >> pa) & 1u)) continue;
+                u32x4 xg[MR];
+                read_x(pa, xg);
+                for (int pw = 0; pw < nw; pw++) {
+                    u32x4 wg[MC];
+                    read_w(pw, wg);
 #pragma unroll
-                        for (int j = 0; j < C; j++) tot[i][j] += part[i][j] << s;
+                    for (int i = 0; i < MR; i++)
+#pragma unroll
+                        for (int j = 0; j < MC; j++) acc[0][i][j] = 0u;
+                    mac_quad(acc[0], xg, wg);
+                    const int s = now.pa0 + pa + now.pw0 + pw;  // reference kernel.h:295,340
+                    if (s < 32) {
+#pragma unroll
+                        for (int i = 0; i < MR; i++)
+#pragma unroll
+                            for (int j = 0; j < MC; j++) tot[i][j] += acc[0][i][j] << s;
+                    }
                 }
             }
         }
-        STAMP(5 + it * 4);
-        cur = nxt;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (it == 0) STAMP(5);
     }
-    __syncthreads();  // every wave is done with the staging buffers: reuse them for the reduction
-    STAMP(28);
-
-    // ---- in-workgroup split-K reduction through LDS ----
+    if constexpr (!GEN) {
 #pragma unroll
-    for (int i = 0; i < R; i++)
+        for (int s = 0; s < NS; s++)
 #pragma unroll
-        for (int j = 0; j < C; j++)
-            red[(wk * TM + lm + i * Cfg::LM) * TNP + ln + j * Cfg::LN] = static_cast<int>(tot[i][j]);
-    __syncthreads();
-    STAMP(29);
-
-    const bool last_n = tn == tiles_n - 1, last_m = tm == tiles_m - 1;
-    if (sh.mode == 2) {
-        // float32 [M,N] (reference kernel.h:915-930)
-        float *out = static_cast<float *>(pr.out);
-        for (int e = tid; e < TM * TN; e += NT) {
-            const int row = e / TN, col = e % TN;
-            int v = 0;
+            for (int i = 0; i < MR; i++)
 #pragma unroll
-            for (int k = 0; k < WK; k++) v += red[(k * TM + row) * TNP + col];
-            const int m = m0 + row, n = n0 + col;
-            if (m < M && n < N) out[static_cast<size_t>(m) * N + n] = static_cast<float>(v);
-        }
-    } else if (sh.mode == 0) {
-        // rows layout [ob][PAD8(M)][STEP128(N)*4] (reference kernel.h:357-389)
-        uint32_t *out = static_cast<uint32_t *>(pr.out);
-        const int rows_pad = pad8(M), row_words = step128(N) * 4;
-        const size_t oplane = static_cast<size_t>(rows_pad) * row_words;
-        for (int e = tid; e < TM * TN; e += NT) {
-            const int row = e / TN, col = e % TN;  // each 32-lane half: 32 columns of one row
-            int v = 0;
-#pragma unroll
-            for (int k = 0; k < WK; k++) v += red[(k * TM + row) * TNP + col];
-            const int m = m0 + row, n = n0 + col;
-            const int qv = (m < M && n < N) ? requant(v, sh.maxv, sh.maxm1) : 0;
-            for (int p = 0; p < sh.ob; p++) {
-                const unsigned long long mk = __ballot((qv >> p) & 1);
-                if ((lane & 31) == 0 && m < rows_pad) {
-                    const uint32_t half = lane ? static_cast<uint32_t>(mk >> 32) : static_cast<uint32_t>(mk);
-                    out[p * oplane + static_cast<size_t>(m) * row_words + (n >> 5)] = __brev(half);
-                }
-            }
-        }
-        if (last_n) {  // zero the row words beyond the last column tile
-            const int w0 = tiles_n * (TN / 32), nz = row_words - w0;
-            for (int e = tid; e < sh.ob * TM; e += NT) {
-                const int row = e & (TM - 1), p = e / TM;
-                if (m0 + row < rows_pad)
-                    for (int wi = 0; wi < nz; wi++)
-                        out[p * oplane + static_cast<size_t>(m0 + row) * row_words + w0 + wi] = 0u;
-            }
-        }
-    } else {
-        // cols layout [ob][PAD128(N)][STEP128(M)*4] (intended semantics of kernel.h:651-810)
-        uint32_t *out = static_cast<uint32_t *>(pr.out);
-        const int lines = pad128(N), line_words = step128(M) * 4;
-        const size_t oplane = static_cast<size_t>(lines) * line_words;
-        for (int e = tid; e < TM * TN; e += NT) {
-            const int row = e % TM, col = e / TM;  // each 32-lane half: 32 rows of one column
-            int v = 0;
-#pragma unroll
-            for (int k = 0; k < WK; k++) v += red[(k * TM + row) * TNP + col];
-            const int m = m0 + row, n = n0 + col;
-            const int qv = (m < M && n < N) ? requant(v, sh.maxv, sh.maxm1) : 0;
-            for (int p = 0; p < sh.ob; p++) {
-                const unsigned long long mk = __ballot((qv >> p) & 1);
-                if ((lane & 31) == 0 && n < lines && (m >> 5) < line_words) {
-                    const uint32_t half = lane ? static_cast<uint32_t>(mk >> 32) : static_cast<uint32_t>(mk);
-                    out[p * oplane + static_cast<size_t>(n) * line_words + (m >> 5)] = __brev(half);
-                }
-            }
-        }
-        // zero what no tile computes: lines past the last column tile, words past the last row tile
-        const int l_end = last_n ? lines : min(lines, n0 + TN);
-        const int w_core0 = m0 >> 5, w_core1 = min(line_words, (m0 + TM) >> 5);
-        const int w_end = last_m ? line_words : w_core1;
-        const int nl = l_end - n0, nwd = w_end - w_core0;
-        for (int e = tid; e < sh.ob * nl * nwd; e += NT) {
-            const int wi = w_core0 + e % nwd, line = n0 + (e / nwd) % nl, p = e / (nwd * nl);
-            const bool core = line < n0 + TN && wi < w_core1;
-            if (!core) out[p * oplane + static_cast<size_t>(line) * line_words + wi] = 0u;
-        }
+                for (int j = 0; j < MC; j++) tot[i][j] += acc[s][i][j] << s;
     }
-    STAMP(30);
+    STAMP(7);
+#ifdef QGTC_ABL_NOEPI  // timing-only build: keep the sums alive, skip the reduction and epilogue
+#pragma unroll
+    for (int i = 0; i < MR; i++)
+#pragma unroll
+        for (int j = 0; j < MC; j++) asm volatile("" ::"v"(tot[i][j]));
+    return;
+#endif
+    int *rtile = reinterpret_cast<int *>(smem + nwv * ((ab + wb) * QW * RS * 16));
+    if (sh.mode == 0) tile_epilogue<0>(pr, sh, tot, tm, tn, tiles_m, tiles_n, rtile STAMP_PASS);
+    else if (sh.mode == 1) tile_epilogue<1>(pr, sh, tot, tm, tn, tiles_m, tiles_n, rtile STAMP_PASS);
+    else tile_epilogue<2>(pr, sh, tot, tm, tn, tiles_m, tiles_n, rtile STAMP_PASS);
+    STAMP(15);
+    STAMP_FLUSH();
 }
 
 // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so blocks b and b+8
@@ -646,165 +787,131 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     return xcd * q + min(xcd, r) + idx;
 }
 
-template <int R, int C, int WK, bool ZS>
-__global__ __launch_bounds__(64 * WK) void k_bitmm(qgtc_problem pr, MMShape sh, int tiles_m,
-                                                   int tiles_n) {
+template <int QW, int NA, int NW, bool ZS>
+__global__ __launch_bounds__(64 * MAX_WAVES) void k_bitmm(qgtc_problem pr, MMShape sh, int tiles_m,
+                                                          int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    mm_tile<R, C, WK, ZS>(pr, sh, tile / tiles_n, tile % tiles_n, tiles_m, tiles_n, smem);
+    mm_tile<QW, NA, NW, ZS>(pr, sh, tile / tiles_n, tile % tiles_n, tiles_m, tiles_n, smem);
 }
 
 // grouped launch: blockIdx.y = problem, blockIdx.x = tile (surplus tiles exit at once)
-template <int R, int C, int WK, bool ZS>
-__global__ __launch_bounds__(64 * WK) void k_bitmm_batched(const qgtc_problem *__restrict__ prs,
-                                                           MMShape sh) {
+template <int QW, int NA, int NW, bool ZS>
+__global__ __launch_bounds__(64 * MAX_WAVES) void k_bitmm_batched(const qgtc_problem *__restrict__ prs,
+                                                                  MMShape sh) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using Cfg = MMCfg<R, C, WK>;
     const qgtc_problem pr = prs[blockIdx.y];
-    const int tiles_m = (pr.M + Cfg::TM - 1) / Cfg::TM, tiles_n = (pr.N + Cfg::TN - 1) / Cfg::TN;
+    const int tiles_m = (pr.M + TM - 1) / TM, tiles_n = (pr.N + TN - 1) / TN;
     const int tile = blockIdx.x;
     if (tile >= tiles_m * tiles_n) return;
-    mm_tile<R, C, WK, ZS>(pr, sh, tile / tiles_n, tile % tiles_n, tiles_m, tiles_n, smem);
+    mm_tile<QW, NA, NW, ZS>(pr, sh, tile / tiles_n, tile % tiles_n, tiles_m, tiles_n, smem);
 }
 
 // ------------------------------------------------------------------------------------------
 // host-side launch plumbing
 // ------------------------------------------------------------------------------------------
-constexpr size_t kLdsBudget = 80 * 1024;  // keeps two workgroups per CU resident (160 KiB LDS)
-
 struct Plan {
-    int wk;  // waves per workgroup (split-K factor)
+    int waves;  // waves per workgroup (in-workgroup split-K factor)
     MMShape sh;
     size_t lds;
 };
 
-inline int pow2_floor(int x) {
-    int p = 1;
-    while (p * 2 <= x) p *= 2;
-    return p;
+// Split K over up to MAX_WAVES waves: `per` k-quads each, as few waves as cover the row.
+inline void plan_split(int K, int planes, int qw, Plan *pl) {
+    const int kq = step128(K);
+    const int per = (kq + MAX_WAVES - 1) / MAX_WAVES;
+    pl->sh.per = per;
+    pl->waves = (kq + per - 1) / per;
+    // every wave's staging region, then the workgroup's reduction tile
+    pl->lds = pl->waves * region_bytes(planes, qw) + SLAB_BYTES;
 }
 
-template <int R, int C, int WK>
-bool plan_for(int K, int a, int w, int ob, int mode, Plan *pl) {
-    using Cfg = MMCfg<R, C, WK>;
-    const int kq = step128(K);
+inline MMShape base_shape(int a, int w, int ob, int mode) {
     MMShape sh{};
     sh.a = a;
     sh.w = w;
     sh.ob = ob;
     sh.mode = mode;
+    sh.ab = a;
+    sh.wb = w;
     sh.maxv = std::ldexp(1.0f, ob);
     sh.maxm1 = sh.maxv - 1.0f;
-    // k-quads per stage: a power of two >= WK (every wave gets >= 1), as small as the pipeline
-    // allows (more stages = earlier first compute); planes are blocked until one stage fits the
-    // per-thread prefetch registers (GPT granules) and two stages fit the LDS budget.
-    int qc = WK > 8 ? WK : 8;
-    while (qc > WK && qc / 2 >= kq) qc /= 2;
-    int ab = a, wb = w;
-    auto fits = [&](int ab_, int wb_, int qc_) {
-        const int xs = (ab_ * Cfg::TM * qc_ + Cfg::NT - 1) / Cfg::NT;
-        const int ws = (wb_ * Cfg::TN * qc_ + Cfg::NT - 1) / Cfg::NT;
-        return xs + ws <= Cfg::GPT && mm_lds_bytes<R, C, WK>(ab_, wb_, qc_) <= kLdsBudget;
-    };
-    while (!fits(ab, wb, qc)) {
-        if (wb >= ab && wb > 1) wb = (wb + 1) / 2;
-        else if (ab > 1) ab = (ab + 1) / 2;
-        else if (qc > WK) qc /= 2;
-        else return false;
-    }
-    // with room to spare, stage more K per barrier (fewer barriers) up to 64 k-quads
-    while (qc < 64 && qc < kq && fits(ab, wb, qc * 2)) qc *= 2;
-    sh.qc = qc;
-    sh.ab = ab;
-    sh.wb = wb;
-    pl->wk = WK;
-    pl->sh = sh;
-    pl->lds = mm_lds_bytes<R, C, WK>(ab, wb, qc);
-    return true;
+    return sh;
 }
 
-template <int R, int C, int WK, bool ZS>
+template <int QW, int NA, int NW, bool ZS>
 int launch_single(const qgtc_problem &pr, const Plan &pl, hipStream_t st) {
-    using Cfg = MMCfg<R, C, WK>;
-    const int tiles_m = (pr.M + Cfg::TM - 1) / Cfg::TM, tiles_n = (pr.N + Cfg::TN - 1) / Cfg::TN;
+    const int tiles_m = (pr.M + TM - 1) / TM, tiles_n = (pr.N + TN - 1) / TN;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm<R, C, WK, ZS>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    static_cast<int>(kLdsBudget)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm<QW, NA, NW, ZS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_bitmm<R, C, WK, ZS>), dim3(tiles_m * tiles_n), dim3(Cfg::NT), pl.lds, st,
-                       pr, pl.sh, tiles_m, tiles_n);
+    hipLaunchKernelGGL((k_bitmm<QW, NA, NW, ZS>), dim3(tiles_m * tiles_n), dim3(64 * pl.waves), pl.lds,
+                       st, pr, pl.sh, tiles_m, tiles_n);
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
 }
 
-template <int R, int C, int WK, bool ZS>
+template <int QW, int NA, int NW, bool ZS>
 int launch_batched(const qgtc_problem *prs, int count, int max_M, int max_N, const Plan &pl,
                    hipStream_t st) {
-    using Cfg = MMCfg<R, C, WK>;
-    const int tiles = ((max_M + Cfg::TM - 1) / Cfg::TM) * ((max_N + Cfg::TN - 1) / Cfg::TN);
+    const int tiles = ((max_M + TM - 1) / TM) * ((max_N + TN - 1) / TN);
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_batched<R, C, WK, ZS>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    static_cast<int>(kLdsBudget)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_batched<QW, NA, NW, ZS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_bitmm_batched<R, C, WK, ZS>), dim3(tiles, count), dim3(Cfg::NT), pl.lds,
-                       st, prs, pl.sh);
+    hipLaunchKernelGGL((k_bitmm_batched<QW, NA, NW, ZS>), dim3(tiles, count), dim3(64 * pl.waves),
+                       pl.lds, st, prs, pl.sh);
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
 }
 
-// Pick the split-K factor from the K extent: short K (feature/weight products, K <= 512 bits)
-// has too few k-quads to feed 8 waves.
-inline int choose_wk(int K) {
-    const int kq = step128(K);
-    if (kq >= 8) return 8;
-    if (kq >= 4) return 4;
-    if (kq >= 2) return 2;
-    return 1;
+// Kernel selection: the plane combinations the reference's drivers and benchmarks use get a
+// kernel with compile-time plane loops and per-shift accumulators; everything else (any a, w in
+// 1..32) runs the generic kernel, which blocks the planes 8 x 8 at a time.
+template <bool ZS, typename F>
+int with_kernel(int a, int w, int K, int ob, int mode, Plan *pl, F &&go) {
+    pl->sh = base_shape(a, w, ob, mode);
+#define QGTC_FIXED(QW_, NA_, NW_)                              \
+    if (a == NA_ && w == NW_) {                                \
+        plan_split(K, NA_ + NW_, QW_, pl);                     \
+        return go(std::integral_constant<int, QW_>{}, std::integral_constant<int, NA_>{}, \
+                  std::integral_constant<int, NW_>{});         \
+    }
+    QGTC_FIXED(4, 1, 1)
+    QGTC_FIXED(4, 1, 2)
+    QGTC_FIXED(2, 1, 4)
+    QGTC_FIXED(1, 1, 8)
+    QGTC_FIXED(4, 2, 2)
+    QGTC_FIXED(2, 4, 4)
+#undef QGTC_FIXED
+    pl->sh.ab = a < 8 ? a : 8;
+    pl->sh.wb = w < 8 ? w : 8;
+    plan_split(K, pl->sh.ab + pl->sh.wb, 1, pl);
+    return go(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{},
+              std::integral_constant<int, 0>{});
 }
 
 template <bool ZS>
 int dispatch_single(const qgtc_problem &pr, int K, int a, int w, int ob, int mode, hipStream_t st) {
     Plan pl;
-    switch (choose_wk(K)) {
-        case 8:
-            if (!plan_for<4, 4, 8>(K, a, w, ob, mode, &pl)) return QGTC_EINVAL;
-            return launch_single<4, 4, 8, ZS>(pr, pl, st);
-        case 4:
-            if (!plan_for<4, 4, 4>(K, a, w, ob, mode, &pl)) return QGTC_EINVAL;
-            return launch_single<4, 4, 4, ZS>(pr, pl, st);
-        case 2:
-            if (!plan_for<4, 4, 2>(K, a, w, ob, mode, &pl)) return QGTC_EINVAL;
-            return launch_single<4, 4, 2, ZS>(pr, pl, st);
-        default:
-            if (!plan_for<4, 4, 1>(K, a, w, ob, mode, &pl)) return QGTC_EINVAL;
-            return launch_single<4, 4, 1, ZS>(pr, pl, st);
-    }
+    return with_kernel<ZS>(a, w, K, ob, mode, &pl, [&](auto qw, auto na, auto nw) {
+        return launch_single<decltype(qw)::value, decltype(na)::value, decltype(nw)::value, ZS>(pr, pl, st);
+    });
 }
 
 template <bool ZS>
 int dispatch_batched(const qgtc_problem *prs, int count, int max_M, int max_N, int K_hint, int a,
                      int w, int ob, int mode, hipStream_t st) {
     Plan pl;
-    switch (choose_wk(K_hint)) {
-        case 8:
-            if (!plan_for<4, 4, 8>(K_hint, a, w, ob, mode, &pl)) return QGTC_EINVAL;
-            return launch_batched<4, 4, 8, ZS>(prs, count, max_M, max_N, pl, st);
-        case 4:
-            if (!plan_for<4, 4, 4>(K_hint, a, w, ob, mode, &pl)) return QGTC_EINVAL;
-            return launch_batched<4, 4, 4, ZS>(prs, count, max_M, max_N, pl, st);
-        case 2:
-            if (!plan_for<4, 4, 2>(K_hint, a, w, ob, mode, &pl)) return QGTC_EINVAL;
-            return launch_batched<4, 4, 2, ZS>(prs, count, max_M, max_N, pl, st);
-        default:
-            if (!plan_for<4, 4, 1>(K_hint, a, w, ob, mode, &pl)) return QGTC_EINVAL;
-            return launch_batched<4, 4, 1, ZS>(prs, count, max_M, max_N, pl, st);
-    }
+    return with_kernel<ZS>(a, w, K_hint, ob, mode, &pl, [&](auto qw, auto na, auto nw) {
+        return launch_batched<decltype(qw)::value, decltype(na)::value, decltype(nw)::value, ZS>(
+            prs, count, max_M, max_N, pl, st);
+    });
 }
 
 int check_mm_args(const uint32_t *X, const uint32_t *W, const void *out, int M, int K, int N,

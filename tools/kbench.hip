@@ -36,13 +36,13 @@ int main(int argc, char **argv) {
     printf("%dx%dx%d a=%d w=%d: %.2f us/launch  eff %.1f TOPS  valu-frac %.3f\n", M, K, N, a, w, us,
            2.0 * M * K * N / us / 1e6, 2.0 * M * K * N * a * w / (us * 1e-6) / 2.516e15);
 #ifdef QGTC_STAMPS
-    std::vector<unsigned long long> st(1024 * 32);
+    std::vector<unsigned long long> st(1024 * 16);
     CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8));
     for (int b : {0, 1, 100, 255}) {
         printf("block %3d:", b);
-        unsigned long long t0 = st[b * 32 + 26];
-        for (int s = 0; s < 32; s++) {
-            unsigned long long t = st[b * 32 + s];
+        unsigned long long t0 = st[b * 16];
+        for (int s = 0; s < 16; s++) {
+            unsigned long long t = st[b * 16 + s];
             if (t >= t0 && t - t0 < 100000000ull) printf(" [%d]%llu", s, t - t0);
         }
         printf("\n");
