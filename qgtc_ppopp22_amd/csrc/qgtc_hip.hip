@@ -265,13 +265,14 @@ struct MMShape {           // per-launch constants
     int mode;              // 0 rows-layout bits, 1 cols-layout bits, 2 float32
     int ab, wb;            // planes staged at once (generic kernel; the fixed kernels stage all)
     int per;               // k-quads per wave (in-workgroup split-K slice)
+    uint32_t inv_tiles_n;  // floor(2^32 / tiles_n), single launches only (tiles_n >= 2; else 0xffffffff)
     float maxv, maxm1;     // 2^ob and 2^ob - 1 as float (requant)
 };
 
 constexpr int TM = 32, TN = 32;      // workgroup tile
 constexpr int MR = 4, MC = 4;        // per-lane micro-tile
 constexpr int GPT = 8;               // granules (16 B) a lane may hold per stage
-constexpr int SLAB_PITCH = 72;       // ints between the (i,j) planes of the reduction tile
+constexpr int SLAB_PITCH = 72;       // ints between the (i,j) planes of a wave's partial tile
 constexpr int SLAB_BYTES = MR * MC * SLAB_PITCH * 4;
 constexpr int MAX_WAVES = 8;
 
@@ -284,33 +285,38 @@ __host__ __device__ constexpr size_t region_bytes(int planes, int qw) {
     return static_cast<size_t>(planes) * qw * lds_pitch(qw) * 16;
 }
 
-// acc += popcount(x & w): v_and_b32 + v_bcnt_u32_b32 with the accumulator as the add operand
-// (hipcc otherwise emits v_bcnt(...,0) + v_add3_u32, 2.5 instructions per pair instead of 2).
-__device__ __forceinline__ void and_popc_acc(uint32_t &acc, uint32_t x, uint32_t w) {
-    const uint32_t t = x & w;
-    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(t));
+// acc[i][j] += popcount(x[i] & w[j]) for two X words and four W words: 8 v_and_b32 into
+// temporaries, then 8 v_bcnt_u32_b32 with the accumulator as the add operand. Written as one asm
+// block because hipcc (a) turns __popc(a & b) + c into v_bcnt(..., 0) + v_add3 (2.5 instructions
+// per pair instead of 2) and (b) likes to issue each v_bcnt right behind the v_and it depends on,
+// which costs a dependent-issue bubble per pair; here every v_bcnt is 8 instructions behind.
+__device__ __forceinline__ void and_popc_2x4(uint32_t &a00, uint32_t &a01, uint32_t &a02, uint32_t &a03,
+                                             uint32_t &a10, uint32_t &a11, uint32_t &a12, uint32_t &a13,
+                                             uint32_t x0, uint32_t x1, uint32_t w0, uint32_t w1,
+                                             uint32_t w2, uint32_t w3) {
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
+    asm("v_and_b32 %8, %16, %18\n\tv_and_b32 %9, %16, %19\n\tv_and_b32 %10, %16, %20\n\tv_and_b32 %11, %16, %21\n\t"
+        "v_and_b32 %12, %17, %18\n\tv_and_b32 %13, %17, %19\n\tv_and_b32 %14, %17, %20\n\tv_and_b32 %15, %17, %21\n\t"
+        "v_bcnt_u32_b32 %0, %8, %0\n\tv_bcnt_u32_b32 %1, %9, %1\n\tv_bcnt_u32_b32 %2, %10, %2\n\tv_bcnt_u32_b32 %3, %11, %3\n\t"
+        "v_bcnt_u32_b32 %4, %12, %4\n\tv_bcnt_u32_b32 %5, %13, %5\n\tv_bcnt_u32_b32 %6, %14, %6\n\tv_bcnt_u32_b32 %7, %15, %7"
+        : "+v"(a00), "+v"(a01), "+v"(a02), "+v"(a03), "+v"(a10), "+v"(a11), "+v"(a12), "+v"(a13),
+          "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(x0), "v"(x1), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
 }
 
-// one k-quad of the 4 x 4 micro-tile: 64 AND + 64 BCNT; word-major order so that consecutive
-// v_bcnt hit different accumulators
+// one k-quad of the 4 x 4 micro-tile: 64 AND + 64 BCNT
 __device__ __forceinline__ void mac_quad(uint32_t (&acc)[MR][MC], const u32x4 (&xg)[MR],
                                          const u32x4 (&wg)[MC]) {
-#pragma unroll
-    for (int i = 0; i < MR; i++)
-#pragma unroll
-        for (int j = 0; j < MC; j++) and_popc_acc(acc[i][j], xg[i].x, wg[j].x);
-#pragma unroll
-    for (int i = 0; i < MR; i++)
-#pragma unroll
-        for (int j = 0; j < MC; j++) and_popc_acc(acc[i][j], xg[i].y, wg[j].y);
-#pragma unroll
-    for (int i = 0; i < MR; i++)
-#pragma unroll
-        for (int j = 0; j < MC; j++) and_popc_acc(acc[i][j], xg[i].z, wg[j].z);
-#pragma unroll
-    for (int i = 0; i < MR; i++)
-#pragma unroll
-        for (int j = 0; j < MC; j++) and_popc_acc(acc[i][j], xg[i].w, wg[j].w);
+#define QGTC_MAC_WORD(c)                                                                            \
+    and_popc_2x4(acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3], \
+                 xg[0].c, xg[1].c, wg[0].c, wg[1].c, wg[2].c, wg[3].c);                             \
+    and_popc_2x4(acc[2][0], acc[2][1], acc[2][2], acc[2][3], acc[3][0], acc[3][1], acc[3][2], acc[3][3], \
+                 xg[2].c, xg[3].c, wg[0].c, wg[1].c, wg[2].c, wg[3].c);
+    QGTC_MAC_WORD(x)
+    QGTC_MAC_WORD(y)
+    QGTC_MAC_WORD(z)
+    QGTC_MAC_WORD(w)
+#undef QGTC_MAC_WORD
 }
 
 __device__ __forceinline__ int requant(int c, float maxv, float maxm1) {
@@ -369,121 +375,118 @@ __device__ __forceinline__ uint32_t or_reduce8(uint32_t x) {
 
 // In-workgroup split-K reduction and the fused epilogue.
 //
-// Reduction: the workgroup shares ONE 32 x 32 int32 tile in LDS, laid out [i*4+j][lane] (pitch 72
-// ints; the cols-layout epilogue uses the transposed lane index) and zeroed at kernel start.
-// Every wave adds its partial sums with no-return ds_add_u32 as soon as it has them, so after
-// the single barrier a thread gets a finished quad (four consecutive columns of a row, or rows
-// of a column) with one ds_read_b128. Integer adds commute: bit-exact in any arrival order.
+// Reduction: every wave stores its 32 x 32 partial tile as a slab [i*4+j][lane] (pitch 72 ints;
+// the cols-layout epilogue stores it with the lane index transposed), so that four consecutive
+// ints are four consecutive columns of a row (rows of a column). After the single barrier a
+// thread sums one quad over the slabs with ds_read_b128. (LDS atomics were measured: 16
+// ds_add_u32 per wave cost ~1300 cycles, four times the plain stores plus the wide reads.)
 //
 // Epilogue (MODE 0 rows-layout bits, 1 cols-layout bits, 2 float32): a thread requantises its
 // quad and builds the quad's nibble of each output plane; eight adjacent lanes OR their nibbles
-// into the 32-bit word of one row (column) of the tile with DPP. Everything that does not
-// depend on the sums (addresses, masks) is computed BEFORE the barrier, while the wave would
-// otherwise idle waiting for its siblings.
+// into the 32-bit word of one row (column) of the tile with DPP. 256 threads finish a tile, so
+// in workgroups of 4+ waves the upper waves leave right after the barrier. What runs here is
+// latency-bound (a few waves, dependent instructions), so the code is kept short: every
+// instruction behind the barrier costs the whole workgroup ~8 cycles.
+template <int MODE, bool INT_RQ, bool ALL8>
+__device__ __forceinline__ void epi_quad(const qgtc_problem &pr, const MMShape &sh, int t, int m0, int n0,
+                                         int extra, size_t oplane, const unsigned char *slabs, int nwv) {
+    // quad t = hi<<6 | a8<<3 | lo<<1 | h ; rows layout / float: (hi,lo) = (i,j), cols layout: (j,i)
+    const int M = pr.M, N = pr.N;
+    const int hi = t >> 6, a8 = (t >> 3) & 7, lo = (t >> 1) & 3, h = t & 1;
+    const int i = MODE == 1 ? lo : hi, j = MODE == 1 ? hi : lo;
+    const unsigned char *src = slabs + ((i * MC + j) * SLAB_PITCH + a8 * 8 + h * 4) * 4;
+    int4 part[MAX_WAVES];
+#pragma unroll
+    for (int k = 0; k < MAX_WAVES; k++)  // slabs that do not exist alias slab 0 and are masked
+        part[k] = *reinterpret_cast<const int4 *>(src + ((ALL8 || k < nwv) ? k : 0) * SLAB_BYTES);
+    const int m = MODE == 1 ? m0 + 8 * i + 4 * h : m0 + a8 + 8 * i;
+    const int n = MODE == 1 ? n0 + a8 + 8 * j : n0 + 8 * j + 4 * h;
+    // valid elements of the quad: rows layout / float (m, n+q), cols layout (m+q, n)
+    const int nvalid = MODE == 1 ? (n < N ? min(max(M - m, 0), 4) : 0) : (m < M ? min(max(N - n, 0), 4) : 0);
+    int v[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < MAX_WAVES; k++) {
+        const bool on = ALL8 || k < nwv;
+        v[0] += on ? part[k].x : 0;
+        v[1] += on ? part[k].y : 0;
+        v[2] += on ? part[k].z : 0;
+        v[3] += on ? part[k].w : 0;
+    }
+    if (MODE == 2) {
+        // float32 [M,N] (reference kernel.h:915-930): row m, columns n .. n+3
+        float *dst = static_cast<float *>(pr.out) + static_cast<size_t>(m) * N + n;
+        if (nvalid == 4 && (N & 3) == 0) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(static_cast<float>(v[0]), static_cast<float>(v[1]),
+                                                           static_cast<float>(v[2]), static_cast<float>(v[3]));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (q < nvalid) dst[q] = static_cast<float>(v[q]);
+        }
+        return;
+    }
+    const int maxi = 1 << (sh.ob & 31);
+    uint32_t qv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        int c;
+        if (INT_RQ) c = v[q] < 0 ? 1 : (v[q] > maxi ? maxi - 1 : v[q]);  // kernel.h:31-37
+        else c = requant(v[q], sh.maxv, sh.maxm1);
+        qv[q] = q < nvalid ? static_cast<uint32_t>(c) : 0u;
+    }
+    // rows layout [ob][PAD8(M)][STEP128(N)*4] (reference kernel.h:357-389): word (m, n0/32);
+    // cols layout [ob][PAD128(N)][STEP128(M)*4] (intended semantics of kernel.h:651-810): word (n, m0/32)
+    const bool store = (t & 7) == 0 && (MODE == 0 ? m < pad8(M) : n < pad128(N));
+    uint32_t *out = static_cast<uint32_t *>(pr.out) +
+                    (MODE == 0 ? static_cast<size_t>(m) * (step128(N) * 4) + (n0 >> 5)
+                               : static_cast<size_t>(n) * (step128(M) * 4) + (m0 >> 5));
+    const uint32_t sh_n = 28 - 4 * (t & 7);  // element e of the 32 sits at bit 31 - e; this quad is e = 4*(t&7) .. +3
+    for (int p = 0; p < sh.ob; p++, out += oplane) {
+        const uint32_t nib = (((qv[0] >> p) & 1u) << 3) | (((qv[1] >> p) & 1u) << 2) |
+                             (((qv[2] >> p) & 1u) << 1) | ((qv[3] >> p) & 1u);
+        const uint32_t word = or_reduce8(nib << sh_n);
+#ifndef QGTC_ABL_NOSTORE
+        if (store) {
+            out[0] = word;
+            for (int x = 1; x <= extra; x++) out[x] = 0u;  // row words past the last column tile
+        }
+#else
+        asm volatile("" ::"v"(word));
+#endif
+    }
+}
+
 template <int MODE>
-__device__ __forceinline__ void tile_epilogue(const qgtc_problem &pr, const MMShape &sh,
-                                              const uint32_t (&tot)[MR][MC], int tm, int tn,
-                                              int tiles_m, int tiles_n, int *tile STAMP_ARG) {
+__device__ __forceinline__ void epi_finish(const qgtc_problem &pr, const MMShape &sh,
+                                           const uint32_t (&tot)[MR][MC], int tm, int tn,
+                                           int tiles_m, int tiles_n, unsigned char *slabs STAMP_ARG) {
     const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwv = blockDim.x >> 6, NT = nwv * 64;
     const int lm = lane >> 3, ln = lane & 7;
-    const int M = pr.M, N = pr.N;
-    const int m0 = tm * TM, n0 = tn * TN;
+    const int M = pr.M, N = pr.N, m0 = tm * TM, n0 = tn * TN;
     {
-        uint32_t *mine = reinterpret_cast<uint32_t *>(tile) + (MODE == 1 ? ln * 8 + lm : lane);
+        int *mine = reinterpret_cast<int *>(slabs + wv * SLAB_BYTES) + (MODE == 1 ? ln * 8 + lm : lane);
 #pragma unroll
         for (int i = 0; i < MR; i++)
 #pragma unroll
-            for (int j = 0; j < MC; j++)
-                __hip_atomic_fetch_add(mine + (i * MC + j) * SLAB_PITCH, tot[i][j], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int j = 0; j < MC; j++) mine[(i * MC + j) * SLAB_PITCH] = static_cast<int>(tot[i][j]);
     }
     STAMP(8);
-    const bool last_n = tn == tiles_n - 1, last_m = tm == tiles_m - 1;
-    const bool int_requant = sh.ob <= 23;  // float(c) > 2^ob  <=>  c > 2^ob for every int c >= 0
-    const int maxi = int_requant ? (1 << sh.ob) : 0;
-    // quad t = hi<<6 | a8<<3 | lo<<1 | h ; rows layout / float: (hi,lo) = (i,j), cols layout: (j,i).
-    // Up to 4 quads per thread (single-wave workgroups); their setup happens before the barrier.
-    constexpr int QMAX = 4;
-    const int nq = (256 + NT - 1) / NT;  // quads per thread: 1 (>= 4 waves), 2 (2-3 waves), 4 (1 wave)
-    int q_idx[QMAX];
-    size_t q_o0[QMAX];
-    uint32_t q_ok[QMAX];  // bits 0..3: element valid; bit 4: this lane stores the word / the quad row exists
-#pragma unroll
-    for (int r = 0; r < QMAX; r++) {
-        const int t = tid + r * NT;
-        const int hi = t >> 6, a8 = (t >> 3) & 7, lo = (t >> 1) & 3, h = t & 1;
-        const int i = MODE == 1 ? lo : hi, j = MODE == 1 ? hi : lo;
-        q_idx[r] = (i * MC + j) * SLAB_PITCH + a8 * 8 + h * 4;
-        const int m = MODE == 1 ? m0 + 8 * i + 4 * h : m0 + a8 + 8 * i;
-        const int n = MODE == 1 ? n0 + a8 + 8 * j : n0 + 8 * j + 4 * h;
-        uint32_t ok = 0u;
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            ok |= (MODE == 1 ? (m + q < M && n < N) : (m < M && n + q < N)) ? (1u << q) : 0u;
-        if (MODE == 2) {
-            q_o0[r] = static_cast<size_t>(m) * N + n;
-            ok |= (m < M) ? 16u : 0u;
-        } else if (MODE == 0) {  // [ob][PAD8(M)][STEP128(N)*4] (reference kernel.h:357-389)
-            q_o0[r] = static_cast<size_t>(m) * (step128(N) * 4) + (n0 >> 5);
-            ok |= ((t & 7) == 0 && m < pad8(M)) ? 16u : 0u;
-        } else {                 // [ob][PAD128(N)][STEP128(M)*4] (intended semantics of kernel.h:651-810)
-            q_o0[r] = static_cast<size_t>(n) * (step128(M) * 4) + (m0 >> 5);
-            ok |= ((t & 7) == 0 && n < pad128(N)) ? 16u : 0u;
-        }
-        if (t >= 256) ok = 0u;
-        q_ok[r] = ok;
-    }
-    const int sh_n = 28 - 4 * (tid & 7);  // NT is a multiple of 8: the same for every quad of the thread
-    const size_t oplane = MODE == 0 ? static_cast<size_t>(pad8(M)) * (step128(N) * 4)
-                                    : static_cast<size_t>(pad128(N)) * (step128(M) * 4);
-    const int extra = (MODE == 0 && last_n) ? step128(N) * 4 - (n0 >> 5) - 1 : 0;  // row words past the last tile
-
     __syncthreads();
     STAMP(9);
-#pragma unroll
-    for (int r = 0; r < QMAX; r++) {
-        if (r >= nq) break;          // uniform
-        if (tid + r * NT >= 256) break;  // whole waves (NT and 256 are multiples of 64)
-        const int4 v4 = *reinterpret_cast<const int4 *>(tile + q_idx[r]);
-        const int v[4] = {v4.x, v4.y, v4.z, v4.w};
-        const uint32_t ok = q_ok[r];
-        if (MODE == 2) {
-            // float32 [M,N] (reference kernel.h:915-930): row m, columns n .. n+3
-            float *dst = static_cast<float *>(pr.out) + q_o0[r];
-            if ((ok & 31u) == 31u && (N & 3) == 0) {
-                *reinterpret_cast<float4 *>(dst) = make_float4(static_cast<float>(v[0]), static_cast<float>(v[1]),
-                                                               static_cast<float>(v[2]), static_cast<float>(v[3]));
-            } else if (ok & 16u) {
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if ((ok >> q) & 1u) dst[q] = static_cast<float>(v[q]);
-            }
-            continue;
+    const bool last_n = tn == tiles_n - 1, last_m = tm == tiles_m - 1;
+    const size_t oplane = MODE == 0 ? static_cast<size_t>(pad8(M)) * (step128(N) * 4)
+                                    : static_cast<size_t>(pad128(N)) * (step128(M) * 4);
+    const int extra = (MODE == 0 && last_n) ? step128(N) * 4 - (n0 >> 5) - 1 : 0;
+    if (sh.ob <= 23) {  // float(c) > 2^ob  <=>  c > 2^ob for every int c >= 0: integer requantisation
+        if (nwv == MAX_WAVES) {
+            if (tid < 256) epi_quad<MODE, true, true>(pr, sh, tid, m0, n0, extra, oplane, slabs, nwv);
+        } else {
+            for (int t = tid; t < 256; t += NT) epi_quad<MODE, true, false>(pr, sh, t, m0, n0, extra, oplane, slabs, nwv);
         }
-        uint32_t qv[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            int c;
-            if (int_requant) c = v[q] < 0 ? 1 : (v[q] > maxi ? maxi - 1 : v[q]);  // kernel.h:31-37
-            else c = requant(v[q], sh.maxv, sh.maxm1);
-            qv[q] = ((ok >> q) & 1u) ? static_cast<uint32_t>(c) : 0u;
-        }
-        uint32_t *out = static_cast<uint32_t *>(pr.out) + q_o0[r];
-        for (int p = 0; p < sh.ob; p++) {
-            // element e of the row's (column's) 32 sits at bit 31 - e; this quad is e = 4*(t&7) .. +3
-            const uint32_t nib = (((qv[0] >> p) & 1u) << 3) | (((qv[1] >> p) & 1u) << 2) |
-                                 (((qv[2] >> p) & 1u) << 1) | ((qv[3] >> p) & 1u);
-            const uint32_t word = or_reduce8(nib << sh_n);
-#ifndef QGTC_ABL_NOSTORE
-            if (ok & 16u) {
-                out[p * oplane] = word;
-                for (int x = 1; x <= extra; x++) out[p * oplane + x] = 0u;
-            }
-#else
-            asm volatile("" ::"v"(word));
-#endif
-        }
+    } else {
+        for (int t = tid; t < 256; t += NT) epi_quad<MODE, false, false>(pr, sh, t, m0, n0, extra, oplane, slabs, nwv);
     }
     STAMP(14);
     if (MODE == 1) {
@@ -619,14 +622,6 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
     STAMP(1);
     if (cur.valid) issue(cur);
     STAMP(2);
-
-    // zero the workgroup's reduction tile while the first loads are in flight
-    {
-        u32x4 *rt = reinterpret_cast<u32x4 *>(smem + nwv * ((ab + wb) * QW * RS * 16));
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        for (int g = tid; g < SLAB_BYTES / 16; g += nwv * 64) rt[g] = z;
-        __syncthreads();
-    }
 
     uint32_t tot[MR][MC];  // unsigned: the reference's int32 accumulation wraps on overflow
 #pragma unroll
@@ -768,10 +763,10 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
         for (int j = 0; j < MC; j++) asm volatile("" ::"v"(tot[i][j]));
     return;
 #endif
-    int *rtile = reinterpret_cast<int *>(smem + nwv * ((ab + wb) * QW * RS * 16));
-    if (sh.mode == 0) tile_epilogue<0>(pr, sh, tot, tm, tn, tiles_m, tiles_n, rtile STAMP_PASS);
-    else if (sh.mode == 1) tile_epilogue<1>(pr, sh, tot, tm, tn, tiles_m, tiles_n, rtile STAMP_PASS);
-    else tile_epilogue<2>(pr, sh, tot, tm, tn, tiles_m, tiles_n, rtile STAMP_PASS);
+    unsigned char *slabs = smem + nwv * ((ab + wb) * QW * RS * 16);
+    if (sh.mode == 0) epi_finish<0>(pr, sh, tot, tm, tn, tiles_m, tiles_n, slabs STAMP_PASS);
+    else if (sh.mode == 1) epi_finish<1>(pr, sh, tot, tm, tn, tiles_m, tiles_n, slabs STAMP_PASS);
+    else epi_finish<2>(pr, sh, tot, tm, tn, tiles_m, tiles_n, slabs STAMP_PASS);
     STAMP(15);
     STAMP_FLUSH();
 }
@@ -792,7 +787,14 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void k_bitmm(qgtc_problem pr, MMSha
                                                           int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    mm_tile<QW, NA, NW, ZS>(pr, sh, tile / tiles_n, tile % tiles_n, tiles_m, tiles_n, smem);
+    // tile / tiles_n by multiply-high with floor(2^32 / tiles_n) (from the host) + one correction
+    int tm = static_cast<int>(__umulhi(static_cast<uint32_t>(tile), sh.inv_tiles_n));
+    int tn = tile - tm * tiles_n;
+    if (tn >= tiles_n) {
+        tn -= tiles_n;
+        tm++;
+    }
+    mm_tile<QW, NA, NW, ZS>(pr, sh, tm, tn, tiles_m, tiles_n, smem);
 }
 
 // grouped launch: blockIdx.y = problem, blockIdx.x = tile (surplus tiles exit at once)
@@ -822,8 +824,9 @@ inline void plan_split(int K, int planes, int qw, Plan *pl) {
     const int per = (kq + MAX_WAVES - 1) / MAX_WAVES;
     pl->sh.per = per;
     pl->waves = (kq + per - 1) / per;
-    // every wave's staging region, then the workgroup's reduction tile
-    pl->lds = pl->waves * region_bytes(planes, qw) + SLAB_BYTES;
+    // every wave's staging region, then every wave's partial-sum slab (separate, so that a wave
+    // can store its slab while others are still multiplying)
+    pl->lds = pl->waves * (region_bytes(planes, qw) + SLAB_BYTES);
 }
 
 inline MMShape base_shape(int a, int w, int ob, int mode) {
@@ -848,8 +851,10 @@ int launch_single(const qgtc_problem &pr, const Plan &pl, hipStream_t st) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
+    MMShape sh = pl.sh;
+    sh.inv_tiles_n = tiles_n > 1 ? static_cast<uint32_t>((1ull << 32) / tiles_n) : 0xffffffffu;
     hipLaunchKernelGGL((k_bitmm<QW, NA, NW, ZS>), dim3(tiles_m * tiles_n), dim3(64 * pl.waves), pl.lds,
-                       st, pr, pl.sh, tiles_m, tiles_n);
+                       st, pr, sh, tiles_m, tiles_n);
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
 }

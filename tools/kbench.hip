@@ -38,7 +38,7 @@ int main(int argc, char **argv) {
 #ifdef QGTC_STAMPS
     std::vector<unsigned long long> st(1024 * 16);
     CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8));
-    for (int b : {0, 1, 100, 255}) {
+    for (int b : {0, 1, 100, 255, 600, 900, 1023}) {
         printf("block %3d:", b);
         unsigned long long t0 = st[b * 16];
         for (int s = 0; s < 16; s++) {
