@@ -157,7 +157,7 @@ def main():
     sums = D.gather_batch_summaries(csum, world, rank, world) if world > 1 else csum
 
     algo_bytes = 1 * M * K / 8 + w * K * N / 8 + w * M * N / 8      # a*M*K/8 + w*K*N/8 + ob*M*N/8
-    roofline = {"bound": "hbm", "kernel": "k_bitmm<4,4,8>", "achieved": round(algo_bytes / kern / 1e9, 2),
+    roofline = {"bound": "hbm", "kernel": "k_bitmm<%d,1,%d,ZS>" % ({1: 4, 2: 4, 4: 2, 8: 1}.get(w, 1), w), "achieved": round(algo_bytes / kern / 1e9, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo_bytes / kern / 1e9 / HBM_PEAK_GBS, 5),
                 "traffic": None, "algorithmic_bytes_per_launch": int(algo_bytes),
                 "avg_launch_us": round(kern * 1e6, 3),

@@ -78,6 +78,66 @@ __device__ __forceinline__ uint32_t quant1(float x, float ub, float ubm1) {
     return r >= 4294967296.0f ? 0u : static_cast<uint32_t>(r);  // low 32 bits (nbits >= 31 only)
 }
 
+// OR over aligned groups of 8 lanes (every lane of the wave must be active)
+__device__ __forceinline__ uint32_t or_reduce8(uint32_t x) {
+    x |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0xB1, 0xf, 0xf, false));   // lane ^ 1
+    x |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x4E, 0xf, 0xf, false));   // lane ^ 2
+    x |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x141, 0xf, 0xf, false));  // 7 - lane
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------
+// val2bit, rows layout, fast path (W % 4 == 0, 16-byte aligned input): HBM-streaming.
+// A wave packs 256 columns of one row per unit: every lane loads one float4 (16 B/lane, 1 KiB per
+// wave-instruction, fully coalesced), builds the nibble of its four columns per plane, and eight
+// adjacent lanes OR their nibbles into one output word with DPP (lane 8k stores word k of the
+// unit: 32 contiguous bytes per plane). UNROLL units are loaded before any is packed, so a wave
+// keeps UNROLL KiB in flight. Every word of the padded output is written.
+// ------------------------------------------------------------------------------------------
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_val2bit_rows_v4(const float *__restrict__ x, int H, int W,
+                                                         int nbits, float ub, float ubm1,
+                                                         uint32_t *__restrict__ out, int rows_pad,
+                                                         int row_words) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int chunks = (row_words + 7) >> 3;  // 256-column units per row
+    const uint32_t units = static_cast<uint32_t>(rows_pad) * chunks;  // < 2^31 (host-checked)
+    const size_t plane = static_cast<size_t>(rows_pad) * row_words;
+    const uint32_t sh_n = 28 - 4 * (lane & 7);
+    for (uint32_t u0 = wave * UNROLL; u0 < units; u0 += nwaves * UNROLL) {
+        float4 v[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; k++) {
+            const uint32_t u = u0 + k;
+            const int r = static_cast<int>(u / chunks), ch = static_cast<int>(u % chunks);
+            const int c = ch * 256 + lane * 4;
+            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < units && r < H && c < W)  // W % 4 == 0: the quad is entirely inside or outside
+                v[k] = *reinterpret_cast<const float4 *>(x + static_cast<size_t>(r) * W + c);
+        }
+#pragma unroll
+        for (int k = 0; k < UNROLL; k++) {
+            const uint32_t u = u0 + k;
+            if (u >= units) break;  // wave-uniform
+            const int r = static_cast<int>(u / chunks), ch = static_cast<int>(u % chunks);
+            const int c = ch * 256 + lane * 4;
+            const bool in = r < H && c < W;
+            const uint32_t q0 = in ? quant1(v[k].x, ub, ubm1) : 0u, q1 = in ? quant1(v[k].y, ub, ubm1) : 0u;
+            const uint32_t q2 = in ? quant1(v[k].z, ub, ubm1) : 0u, q3 = in ? quant1(v[k].w, ub, ubm1) : 0u;
+            const int wi = ch * 8 + (lane >> 3);
+            uint32_t *dst = out + static_cast<size_t>(r) * row_words + wi;
+            for (int p = 0; p < nbits; p++, dst += plane) {
+                const uint32_t nib = (((q0 >> p) & 1u) << 3) | (((q1 >> p) & 1u) << 2) |
+                                     (((q2 >> p) & 1u) << 1) | ((q3 >> p) & 1u);
+                const uint32_t word = or_reduce8(nib << sh_n);
+                if ((lane & 7) == 0 && wi < row_words) *dst = word;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // val2bit, rows layout: out[p][r][c>>5] bit(31-(c&31)) = bit p of quant(x[r][c])
 // One wave per (row, 256-column chunk): 4 coalesced loads per lane, one 64-bit ballot per
@@ -363,14 +423,6 @@ __device__ __forceinline__ uint32_t tile_occupancy(const unsigned long long (&nz
         const unsigned long long m = nzm[pt >> 1];
         return ((pt & 1) ? (m >> 32) : (m & 0xffffffffull)) ? 1u : 0u;
     }
-}
-
-// OR over aligned groups of 8 lanes (every lane of the wave must be active)
-__device__ __forceinline__ uint32_t or_reduce8(uint32_t x) {
-    x |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0xB1, 0xf, 0xf, false));   // lane ^ 1
-    x |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x4E, 0xf, 0xf, false));   // lane ^ 2
-    x |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x141, 0xf, 0xf, false));  // 7 - lane
-    return x;
 }
 
 // In-workgroup split-K reduction and the fused epilogue.
@@ -981,8 +1033,14 @@ int qgtc_val2bit(const float *x, int H, int W, int nbits, int col_major, int out
         if (out_words < qgtc_rows_words(H, W, nbits)) return QGTC_ESIZE;
         const int rows_pad = pad8(H), row_words = step128(W) * 4;
         const size_t units = static_cast<size_t>(rows_pad) * ((row_words + 7) / 8);
-        hipLaunchKernelGGL(k_val2bit_rows, dim3(grid_for(units, 4)), dim3(256), 0, st, x, H, W, nbits,
-                           ub, ubm1, out, rows_pad, row_words);
+        if ((W & 3) == 0 && aligned16(x) && units < (1ull << 30)) {
+            constexpr int UNR = 4;
+            hipLaunchKernelGGL(k_val2bit_rows_v4<UNR>, dim3(grid_for((units + UNR - 1) / UNR, 4)), dim3(256),
+                               0, st, x, H, W, nbits, ub, ubm1, out, rows_pad, row_words);
+        } else {
+            hipLaunchKernelGGL(k_val2bit_rows, dim3(grid_for(units, 4)), dim3(256), 0, st, x, H, W, nbits,
+                               ub, ubm1, out, rows_pad, row_words);
+        }
     } else {
         if (out_words < qgtc_cols_words(H, W, nbits, output_layer)) return QGTC_ESIZE;
         const int lines = output_layer ? pad8(W) : pad128(W), line_words = step128(H) * 4;
