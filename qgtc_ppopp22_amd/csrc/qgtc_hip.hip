@@ -508,6 +508,78 @@ __device__ __forceinline__ void epi_quad(const qgtc_problem &pr, const MMShape &
     }
 }
 
+// Epilogue of a single-wave workgroup (the wave owns the whole K range, nothing to reduce): straight
+// from the accumulators. Lane (lm, ln) holds rows lm + 8i and columns ln + 8j, so the 32 columns
+// of a row live in the 8 lanes of one aligned group (4 each): a DPP OR assembles the row word.
+// For the cols layout the 32 rows of a column live in the 8 lanes ln, ln+8, .., ln+56.
+template <int MODE>
+__device__ __forceinline__ void epi_direct(const qgtc_problem &pr, const MMShape &sh,
+                                           const uint32_t (&tot)[MR][MC], int tm, int tn, int tiles_n) {
+    const int lane = threadIdx.x & 63, lm = lane >> 3, ln = lane & 7;
+    const int M = pr.M, N = pr.N, m0 = tm * TM, n0 = tn * TN;
+    if (MODE == 2) {  // float32 [M,N] (reference kernel.h:915-930)
+        float *out = static_cast<float *>(pr.out);
+#pragma unroll
+        for (int i = 0; i < MR; i++)
+#pragma unroll
+            for (int j = 0; j < MC; j++) {
+                const int m = m0 + lm + 8 * i, n = n0 + ln + 8 * j;
+                if (m < M && n < N) out[static_cast<size_t>(m) * N + n] = static_cast<float>(static_cast<int>(tot[i][j]));
+            }
+        return;
+    }
+    const bool int_rq = sh.ob <= 23;
+    const int maxi = 1 << (sh.ob & 31);
+    uint32_t qv[MR][MC];
+#pragma unroll
+    for (int i = 0; i < MR; i++)
+#pragma unroll
+        for (int j = 0; j < MC; j++) {
+            const int c = static_cast<int>(tot[i][j]);
+            const int r = int_rq ? (c < 0 ? 1 : (c > maxi ? maxi - 1 : c)) : requant(c, sh.maxv, sh.maxm1);
+            qv[i][j] = (m0 + lm + 8 * i < M && n0 + ln + 8 * j < N) ? static_cast<uint32_t>(r) : 0u;
+        }
+    uint32_t *out = static_cast<uint32_t *>(pr.out);
+    if (MODE == 0) {  // rows layout [ob][PAD8(M)][STEP128(N)*4] (reference kernel.h:357-389)
+        const int rows_pad = pad8(M), row_words = step128(N) * 4;
+        const size_t oplane = static_cast<size_t>(rows_pad) * row_words;
+        const int extra = tn == tiles_n - 1 ? row_words - (n0 >> 5) - 1 : 0;
+#pragma unroll
+        for (int i = 0; i < MR; i++) {
+            const int m = m0 + lm + 8 * i;
+            uint32_t *dst = out + static_cast<size_t>(m) * row_words + (n0 >> 5);
+            for (int p = 0; p < sh.ob; p++, dst += oplane) {
+                // column ln + 8j sits at bit 31 - ln - 8j = (24 - 8j) + (7 - ln)
+                const uint32_t x = (((qv[i][0] >> p) & 1u) << 24) | (((qv[i][1] >> p) & 1u) << 16) |
+                                   (((qv[i][2] >> p) & 1u) << 8) | ((qv[i][3] >> p) & 1u);
+                const uint32_t word = or_reduce8(x << (7 - ln));
+                if (ln == 0 && m < rows_pad) {
+                    dst[0] = word;
+                    for (int e = 1; e <= extra; e++) dst[e] = 0u;
+                }
+            }
+        }
+    } else {  // cols layout [ob][PAD128(N)][STEP128(M)*4] (intended semantics of kernel.h:651-810)
+        const int lines = pad128(N), line_words = step128(M) * 4;
+        const size_t oplane = static_cast<size_t>(lines) * line_words;
+#pragma unroll
+        for (int j = 0; j < MC; j++) {
+            const int n = n0 + ln + 8 * j;
+            uint32_t *dst = out + static_cast<size_t>(n) * line_words + (m0 >> 5);
+            for (int p = 0; p < sh.ob; p++, dst += oplane) {
+                // row lm + 8i sits at bit 31 - lm - 8i
+                uint32_t x = (((qv[0][j] >> p) & 1u) << 24) | (((qv[1][j] >> p) & 1u) << 16) |
+                             (((qv[2][j] >> p) & 1u) << 8) | ((qv[3][j] >> p) & 1u);
+                x <<= (7 - lm);
+                x |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(x), 8));
+                x |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(x), 16));
+                x |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(x), 32));
+                if (lm == 0 && n < lines) dst[0] = x;
+            }
+        }
+    }
+}
+
 template <int MODE>
 __device__ __forceinline__ void epi_finish(const qgtc_problem &pr, const MMShape &sh,
                                            const uint32_t (&tot)[MR][MC], int tm, int tn,
@@ -517,7 +589,12 @@ __device__ __forceinline__ void epi_finish(const qgtc_problem &pr, const MMShape
     const int nwv = blockDim.x >> 6, NT = nwv * 64;
     const int lm = lane >> 3, ln = lane & 7;
     const int M = pr.M, N = pr.N, m0 = tm * TM, n0 = tn * TN;
-    {
+    const bool last_n = tn == tiles_n - 1, last_m = tm == tiles_m - 1;
+    const size_t oplane = MODE == 0 ? static_cast<size_t>(pad8(M)) * (step128(N) * 4)
+                                    : static_cast<size_t>(pad128(N)) * (step128(M) * 4);
+    if (nwv == 1) {
+        epi_direct<MODE>(pr, sh, tot, tm, tn, tiles_n);
+    } else {
         int *mine = reinterpret_cast<int *>(slabs + wv * SLAB_BYTES) + (MODE == 1 ? ln * 8 + lm : lane);
 #pragma unroll
         for (int i = 0; i < MR; i++)
@@ -525,13 +602,11 @@ __device__ __forceinline__ void epi_finish(const qgtc_problem &pr, const MMShape
             for (int j = 0; j < MC; j++) mine[(i * MC + j) * SLAB_PITCH] = static_cast<int>(tot[i][j]);
     }
     STAMP(8);
-    __syncthreads();
+    if (nwv > 1) __syncthreads();
     STAMP(9);
-    const bool last_n = tn == tiles_n - 1, last_m = tm == tiles_m - 1;
-    const size_t oplane = MODE == 0 ? static_cast<size_t>(pad8(M)) * (step128(N) * 4)
-                                    : static_cast<size_t>(pad128(N)) * (step128(M) * 4);
     const int extra = (MODE == 0 && last_n) ? step128(N) * 4 - (n0 >> 5) - 1 : 0;
-    if (sh.ob <= 23) {  // float(c) > 2^ob  <=>  c > 2^ob for every int c >= 0: integer requantisation
+    if (nwv == 1) {
+    } else if (sh.ob <= 23) {  // float(c) > 2^ob  <=>  c > 2^ob for every int c >= 0: integer requantisation
         if (nwv == MAX_WAVES) {
             if (tid < 256) epi_quad<MODE, true, true>(pr, sh, tid, m0, n0, extra, oplane, slabs, nwv);
         } else {
@@ -870,15 +945,22 @@ struct Plan {
     size_t lds;
 };
 
-// Split K over up to MAX_WAVES waves: `per` k-quads each, as few waves as cover the row.
-inline void plan_split(int K, int planes, int qw, Plan *pl) {
+// Split K over the waves of a workgroup: `per` k-quads each. Split-K only buys parallelism: every
+// extra wave repeats the prologue and adds a slab to the reduction, so a launch with many tiles
+// (grouped cluster batches, wide N) runs one or two waves per tile and a launch with few tiles
+// (the 4096 x 4096 x 64 micro-benchmark: 256 tiles) runs eight.
+constexpr long kTargetWaves = 256 * 4 * 4;  // 4 waves on every SIMD of the chip
+inline void plan_split(int K, int planes, int qw, long total_tiles, Plan *pl) {
     const int kq = step128(K);
-    const int per = (kq + MAX_WAVES - 1) / MAX_WAVES;
+    long want = (kTargetWaves + total_tiles - 1) / (total_tiles > 0 ? total_tiles : 1);
+    if (want < 1) want = 1;
+    if (want > MAX_WAVES) want = MAX_WAVES;
+    const int per = (kq + static_cast<int>(want) - 1) / static_cast<int>(want);
     pl->sh.per = per;
     pl->waves = (kq + per - 1) / per;
     // every wave's staging region, then every wave's partial-sum slab (separate, so that a wave
-    // can store its slab while others are still multiplying)
-    pl->lds = pl->waves * (region_bytes(planes, qw) + SLAB_BYTES);
+    // can store its slab while others are still multiplying); single-wave workgroups need no slab
+    pl->lds = pl->waves * (region_bytes(planes, qw) + (pl->waves > 1 ? SLAB_BYTES : 0));
 }
 
 inline MMShape base_shape(int a, int w, int ob, int mode) {
@@ -931,11 +1013,11 @@ int launch_batched(const qgtc_problem *prs, int count, int max_M, int max_N, con
 // kernel with compile-time plane loops and per-shift accumulators; everything else (any a, w in
 // 1..32) runs the generic kernel, which blocks the planes 8 x 8 at a time.
 template <bool ZS, typename F>
-int with_kernel(int a, int w, int K, int ob, int mode, Plan *pl, F &&go) {
+int with_kernel(int a, int w, int K, int ob, int mode, long total_tiles, Plan *pl, F &&go) {
     pl->sh = base_shape(a, w, ob, mode);
 #define QGTC_FIXED(QW_, NA_, NW_)                              \
     if (a == NA_ && w == NW_) {                                \
-        plan_split(K, NA_ + NW_, QW_, pl);                     \
+        plan_split(K, NA_ + NW_, QW_, total_tiles, pl);        \
         return go(std::integral_constant<int, QW_>{}, std::integral_constant<int, NA_>{}, \
                   std::integral_constant<int, NW_>{});         \
     }
@@ -948,7 +1030,7 @@ int with_kernel(int a, int w, int K, int ob, int mode, Plan *pl, F &&go) {
 #undef QGTC_FIXED
     pl->sh.ab = a < 8 ? a : 8;
     pl->sh.wb = w < 8 ? w : 8;
-    plan_split(K, pl->sh.ab + pl->sh.wb, 1, pl);
+    plan_split(K, pl->sh.ab + pl->sh.wb, 1, total_tiles, pl);
     return go(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{},
               std::integral_constant<int, 0>{});
 }
@@ -956,7 +1038,8 @@ int with_kernel(int a, int w, int K, int ob, int mode, Plan *pl, F &&go) {
 template <bool ZS>
 int dispatch_single(const qgtc_problem &pr, int K, int a, int w, int ob, int mode, hipStream_t st) {
     Plan pl;
-    return with_kernel<ZS>(a, w, K, ob, mode, &pl, [&](auto qw, auto na, auto nw) {
+    const long tiles = static_cast<long>((pr.M + TM - 1) / TM) * ((pr.N + TN - 1) / TN);
+    return with_kernel<ZS>(a, w, K, ob, mode, tiles, &pl, [&](auto qw, auto na, auto nw) {
         return launch_single<decltype(qw)::value, decltype(na)::value, decltype(nw)::value, ZS>(pr, pl, st);
     });
 }
@@ -965,7 +1048,8 @@ template <bool ZS>
 int dispatch_batched(const qgtc_problem *prs, int count, int max_M, int max_N, int K_hint, int a,
                      int w, int ob, int mode, hipStream_t st) {
     Plan pl;
-    return with_kernel<ZS>(a, w, K_hint, ob, mode, &pl, [&](auto qw, auto na, auto nw) {
+    const long tiles = static_cast<long>(count) * ((max_M + TM - 1) / TM) * ((max_N + TN - 1) / TN);
+    return with_kernel<ZS>(a, w, K_hint, ob, mode, tiles, &pl, [&](auto qw, auto na, auto nw) {
         return launch_batched<decltype(qw)::value, decltype(na)::value, decltype(nw)::value, ZS>(
             prs, count, max_M, max_N, pl, st);
     });

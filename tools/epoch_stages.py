@@ -1,0 +1,37 @@
+"""Per-stage timing of the grouped Cluster-GCN epoch (six launches): which operator dominates."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import QGTC as Q
+from qgtc_ppopp22_amd import driver, graph as G
+from qgtc_ppopp22_amd.sampler import ClusterIter
+
+chain = sys.argv[1] if len(sys.argv) > 1 else "correct"
+gin = len(sys.argv) > 2 and sys.argv[2] == "gin"
+dataset = "ppi" if gin else "ogbn-arxiv"
+b = 4 if gin else 2
+hidden = 64 if gin else 128
+graph = G.make_graph(dataset, 1500)
+dev = torch.device("cuda:0")
+it = ClusterIter(dataset, graph, 1500, 20, bit_width=b, run_GIN=gin, device=dev, qgtc=Q, with_rows_X=(chain == "correct"))
+W = driver.pack_weights(Q, graph.feat.shape[1], hidden, 10, b, dev)
+plan = driver.BatchedEpoch(Q, it.cTensor_li, it.cluster_param_li, W, b, chain, gin)
+for _ in range(3):
+    plan.run()
+torch.cuda.synchronize()
+names = ["g0", "g1", "g2", "g3", "g4", "g5"]
+for g, nme in zip(plan.stages, names):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        g.run()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{nme}: {e0.elapsed_time(e1) * 1e3 / 20:8.1f} us per grouped launch")
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    plan.run()
+e1.record()
+torch.cuda.synchronize()
+print(f"epoch ({chain}, {'GIN' if gin else 'GCN'}): {e0.elapsed_time(e1) * 1e3 / 20:8.1f} us")
