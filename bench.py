@@ -116,7 +116,8 @@ def epoch_leg(Q, rank, world, device_index):
     graph = G.make_graph("ogbn-arxiv", 1500)
     ids = D.shard_round_robin(1500 // 20, rank, world)
     res = {}
-    for name, extra in (("per_batch_reference_chain", []), ("batched_reference_chain", ["--batched"]),
+    for name, extra in (("per_batch_reference_chain", []), ("per_batch_graph_reference_chain", ["--graph"]),
+                        ("batched_reference_chain", ["--batched"]),
                         ("batched_correct_chain", ["--batched", "--chain", "correct"])):
         args = driver.build_parser().parse_args(base + extra)
         driver.run(args, Q=Q, batch_ids=ids, graph=graph)          # warm-up (allocator, attributes)
@@ -157,9 +158,18 @@ def main():
     sums = D.gather_batch_summaries(csum, world, rank, world) if world > 1 else csum
 
     algo_bytes = 1 * M * K / 8 + w * K * N / 8 + w * M * N / 8      # a*M*K/8 + w*K*N/8 + ob*M*N/8
+    # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected by
+    # tools/collect_profiles.sh in separate rocprofv3 --pmc runs; only valid for the 1-bit workload)
+    traffic = None
+    try:
+        if w == 1:
+            with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_bench_b.json")) as f:
+                traffic = int(json.load(f)["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        traffic = None
     roofline = {"bound": "hbm", "kernel": "k_bitmm<%d,1,%d,ZS>" % ({1: 4, 2: 4, 4: 2, 8: 1}.get(w, 1), w), "achieved": round(algo_bytes / kern / 1e9, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo_bytes / kern / 1e9 / HBM_PEAK_GBS, 5),
-                "traffic": None, "algorithmic_bytes_per_launch": int(algo_bytes),
+                "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes),
                 "avg_launch_us": round(kern * 1e6, 3),
                 "valu": {"achieved_bitops": round(eff_ops * w / kern, 1), "peak_bitops": VALU_PEAK_BITOPS,
                          "frac": round(eff_ops * w / kern / VALU_PEAK_BITOPS, 4),

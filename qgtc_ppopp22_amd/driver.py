@@ -13,6 +13,8 @@ Three ways to run the same math:
   the same as the reference's but the numbers are not A·X·W.
 * ``--chain correct``: the layout-correct chain (X·W re-packed in the cols layout by
   ``bitMM2Bit_col`` before A·(XW), as unitest.py:100-109 does).
+* ``--graph``: either chain with the reference's launch structure (6 calls per batch) captured in
+  one hipGraph per epoch.
 * ``--batched``: either chain, with each of the six operators issued ONCE for all cluster batches
   (grouped launch): 6 launches per epoch instead of 6 x 75 — on MI355X the ~1.5 us dependent-launch
   boundary, not the arithmetic, dominates these small products.
@@ -53,6 +55,8 @@ def build_parser() -> argparse.ArgumentParser:
     # additions
     p.add_argument("--chain", choices=["reference", "correct"], default="reference")
     p.add_argument("--batched", action="store_true", help="one grouped launch per operator per epoch")
+    p.add_argument("--graph", action="store_true",
+                   help="capture the epoch's per-batch launches (6 x batches) in one hipGraph and replay it")
     p.add_argument("--non-resident", action="store_true",
                    help="park packed batches on the CPU and upload them every iteration (main_qgtc.py:115)")
     p.add_argument("--quiet", action="store_true")
@@ -226,6 +230,21 @@ def run(args, Q=None, batch_ids=None, graph=None):
         plan = BatchedEpoch(Q, cts, it.cluster_param_li, W, b, args.chain, args.run_GIN)
         for _ in range(args.n_epochs):
             outs = plan.run()
+    elif args.graph:
+        # the reference's launch structure (six extension calls per batch), recorded once on a
+        # side stream and replayed per epoch: the host issues ONE graph launch per epoch
+        cts = [c.to(device) for c in it.cTensor_li]
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):      # warm-up outside capture (kernel attributes, allocator)
+            for ct, param in zip(cts, it.cluster_param_li):
+                chain(Q, ct, param, W, b)
+        torch.cuda.current_stream(device).wait_stream(side)
+        graph_obj = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph_obj):
+            outs = [chain(Q, ct, param, W, b) for ct, param in zip(cts, it.cluster_param_li)]
+        for _ in range(args.n_epochs):
+            graph_obj.replay()
     else:
         for _ in range(args.n_epochs):
             outs = []
