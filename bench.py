@@ -206,6 +206,44 @@ def main():
                                                "us_per_launch": round(ms * 1e3 / 200, 3),
                                                "ref_sm86_TFLOPs": REF_TFLOPS_4096_64[ww]}
             extras["width_sweep_4096x4096x64"] = sweep
+            # the reference's Fig. 8a comparison: INT8 GEMM on the matrix cores (its cuBLAS numbers
+            # are BASELINE.md §2) beside the 1-bit popcount path on the same nine shapes
+            cmp9 = {}
+            ref_cublas = {(1024, 16): 0.55, (2048, 16): 2.58, (4096, 16): 3.60, (1024, 32): 3.89, (2048, 32): 5.49,
+                          (4096, 32): 6.49, (1024, 64): 4.38, (2048, 64): 6.30, (4096, 64): 6.65}
+            ref_1bit = {(1024, 16): 5.847, (2048, 16): 16.605, (4096, 16): 40.627, (1024, 32): 11.724, (2048, 32): 32.666,
+                        (4096, 32): 35.032, (1024, 64): 23.219, (2048, 64): 37.438, (4096, 64): 46.768}
+            g = torch.Generator(device="cpu").manual_seed(5)
+            for nn in (16, 32, 64):
+                for mk in (1024, 2048, 4096):
+                    A8 = torch.randint(-128, 128, (mk, mk), generator=g, dtype=torch.int8).to(device)
+                    B8 = torch.randint(-128, 128, (nn, mk), generator=g, dtype=torch.int8).to(device)
+                    Q.i8gemm_profile(A8, B8, 20, False)
+                    ms8 = min(Q.i8gemm_profile(A8, B8, 200, False) for _ in range(3))
+                    lib8 = None   # the vendor-library GEMM the reference compares with (cuBLAS there, hipBLASLt here)
+                    try:
+                        B8kn = B8.t().contiguous()
+                        for _ in range(5):
+                            torch._int_mm(A8, B8kn)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(200):
+                            torch._int_mm(A8, B8kn)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        lib8 = round(2.0 * mk * mk * nn * 200 / (e0.elapsed_time(e1) * 1e-3) / 1e12, 2)
+                    except Exception:   # noqa: BLE001 - optional leg
+                        lib8 = None
+                    _, _, ba, bx = make_workload(Q, mk, mk, nn, 1, device, seed=3)
+                    Q.profile(ba, bx, mk, mk, nn, 1, 1, 1, 20)
+                    ms1 = min(Q.profile(ba, bx, mk, mk, nn, 1, 1, 1, 200) for _ in range(3))
+                    ops = 2.0 * mk * mk * nn * 200
+                    cmp9[f"{mk}x{mk}x{nn}"] = {"int8_mfma_TOPS": round(ops / (ms8 * 1e-3) / 1e12, 2),
+                                              "int8_hipblaslt_TOPS": lib8,
+                                              "bit1_popcount_TOPS": round(ops / (ms1 * 1e-3) / 1e12, 2),
+                                              "ref_sm86_cublas_int8_TFLOPS": ref_cublas[(mk, nn)],
+                                              "ref_sm86_qgtc_1bit_TFLOPs": ref_1bit[(mk, nn)]}
+            extras["int8_mfma_vs_1bit_popcount_9_shapes"] = cmp9
         ep, graph = epoch_leg(Q, rank, world, local)
         extras["cluster_gcn_epoch_ogbn_arxiv_shape"] = ep
         if rank == 0 and world == 1:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QGTC_ABI_VERSION 1
+#define QGTC_ABI_VERSION 2
 
 enum {
     QGTC_OK = 0,
@@ -123,6 +123,25 @@ typedef struct qgtc_problem {
 int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int max_K, int max_N,
                        int bit1, int bit2, int output_bit, int mode, unsigned flags,
                        void *stream);
+
+/* Adjacency bit planes from an edge list — replaces the dense detour of sampler.py:80-101
+ * (torch.sparse.FloatTensor(...).to_dense() then QGTC.val2bit(A, nbits, False, False)): the n x n
+ * float matrix (5.9 MB for a 1213-node batch) is never materialised. `cells[i]` = row * W + col of
+ * a DISTINCT non-zero cell (negative = skip), `counts[i]` its multiplicity (NULL = all 1); the
+ * value is quantised like Quantize_val (kernel.h:39-44,49-71) and packed in the rows layout.
+ * Result is word-for-word what qgtc_val2bit(dense A, rows layout) produces. */
+int qgtc_pack_edges(const int64_t *cells, const int32_t *counts, size_t n_cells, int H, int W,
+                    int nbits, uint32_t *out, size_t out_words, void *stream);
+
+/* int8 MFMA GEMM, the comparison path — MI355X analogue of the reference's cuBLAS INT8
+ * benchmark (cuBLASGemmEX/cublas_main.cu:123-172: cublasGemmEx, CUDA_R_8I in, CUDA_R_32F out).
+ * C[M,N] (float32, row-major) = A[M,K] x B[K,N]; A is int8 row-major, B is passed as Bt[N,K]
+ * (int8, K contiguous); int32 accumulation (v_mfma_i32_16x16x64_i8), exact. K % 16 == 0.
+ * qgtc_i8gemm_profile times `reps` launches between two events like cublas_main.cu:123-172. */
+int qgtc_i8gemm(const int8_t *A, const int8_t *Bt, int M, int K, int N, float *C, size_t c_elems,
+                void *stream);
+int qgtc_i8gemm_profile(const int8_t *A, const int8_t *Bt, int M, int K, int N, float *C,
+                        size_t c_elems, int reps, float *elapsed_ms, void *stream);
 
 #ifdef __cplusplus
 }

@@ -239,6 +239,71 @@ torch::Tensor bitMM2Int(torch::Tensor bit_X1, torch::Tensor bit_X2, const int X1
 }
 
 // ---------------------------------------------------------------------------------------------
+// Adjacency bit planes from an edge list (additive; the dense val2bit route stays). The
+// multiplicity of duplicate edges is what the reference's to_dense() would sum (sampler.py:87-89).
+torch::Tensor pack_edges(torch::Tensor src, torch::Tensor dst, const int height, const int width,
+                         const int nbits) {
+    CHECK_INPUT(src);
+    CHECK_INPUT(dst);
+    TORCH_CHECK(src.scalar_type() == torch::kInt64 && dst.scalar_type() == torch::kInt64,
+                "src and dst must be int64 index tensors");
+    TORCH_CHECK(src.dim() == 1 && src.sizes() == dst.sizes(), "src and dst must be 1-D and equally long");
+    TORCH_CHECK(height > 0 && width > 0, "height and width must be positive");
+    c10::DeviceGuard guard(src.device());
+    auto out = torch::empty({static_cast<int64_t>(nbits) * P8(height), S128(width) * 4},
+                            torch::TensorOptions().dtype(torch::kInt32).device(src.device()));
+    torch::Tensor cells, counts;
+    if (src.numel() > 0) {
+        TORCH_CHECK(src.min().item<int64_t>() >= 0 && src.max().item<int64_t>() < height &&
+                    dst.min().item<int64_t>() >= 0 && dst.max().item<int64_t>() < width, "edge index out of range");
+        auto uq = at::_unique2(src * width + dst, /*sorted=*/true, /*return_inverse=*/false, /*return_counts=*/true);
+        cells = std::get<0>(uq).contiguous();
+        counts = std::get<2>(uq).to(torch::kInt32).contiguous();
+    }
+    check_rc(qgtc_pack_edges(cells.defined() ? cells.data_ptr<int64_t>() : nullptr,
+                             counts.defined() ? counts.data_ptr<int32_t>() : nullptr,
+                             cells.defined() ? cells.numel() : 0, height, width, nbits, words_mut(out),
+                             out.numel(), current_stream(src)),
+             "pack_edges");
+    return out;
+}
+
+// int8 MFMA GEMM (comparison path, cuBLASGemmEX analogue): float32 [M,N] = A[M,K] x Bt[N,K]^T
+torch::Tensor i8gemm(torch::Tensor A, torch::Tensor Bt) {
+    CHECK_INPUT(A);
+    CHECK_INPUT(Bt);
+    TORCH_CHECK(A.scalar_type() == torch::kInt8 && Bt.scalar_type() == torch::kInt8, "A and Bt must be int8");
+    TORCH_CHECK(A.dim() == 2 && Bt.dim() == 2 && A.size(1) == Bt.size(1), "A is [M,K], Bt is [N,K]");
+    c10::DeviceGuard guard(A.device());
+    const int M = A.size(0), K = A.size(1), N = Bt.size(0);
+    auto out = torch::empty({M, N}, torch::TensorOptions().dtype(torch::kFloat32).device(A.device()));
+    check_rc(qgtc_i8gemm(A.data_ptr<int8_t>(), Bt.data_ptr<int8_t>(), M, K, N, out.data_ptr<float>(),
+                         out.numel(), current_stream(A)),
+             "i8gemm");
+    return out;
+}
+
+double i8gemm_profile(torch::Tensor A, torch::Tensor Bt, int reps, bool print) {
+    CHECK_INPUT(A);
+    CHECK_INPUT(Bt);
+    TORCH_CHECK(A.scalar_type() == torch::kInt8 && Bt.scalar_type() == torch::kInt8, "A and Bt must be int8");
+    TORCH_CHECK(A.dim() == 2 && Bt.dim() == 2 && A.size(1) == Bt.size(1), "A is [M,K], Bt is [N,K]");
+    c10::DeviceGuard guard(A.device());
+    const int M = A.size(0), K = A.size(1), N = Bt.size(0);
+    auto out = torch::empty({M, N}, torch::TensorOptions().dtype(torch::kFloat32).device(A.device()));
+    float ms = 0.0f;
+    check_rc(qgtc_i8gemm_profile(A.data_ptr<int8_t>(), Bt.data_ptr<int8_t>(), M, K, N,
+                                 out.data_ptr<float>(), out.numel(), reps, &ms, current_stream(A)),
+             "i8gemm_profile");
+    if (print) {  // line format of cublas_main.cu:170
+        printf("M: %d, K: %d, N: %d, TFLOPS: %.2f\n", M, K, N,
+               static_cast<double>(reps) * (static_cast<double>(M) * K * N * 2) / (ms / 1000.) / 1e12);
+        fflush(stdout);
+    }
+    return ms;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Grouped launch over many cluster batches (additive API; the per-batch calls above stay).
 // A BatchedGemm owns the device array of problem descriptors so that an epoch can re-launch it
 // without any host work besides the launch itself.
@@ -361,6 +426,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("set_zero_skip", [](bool on) { g_zero_skip = on; });
     m.def("get_zero_skip", [] { return g_zero_skip; });
     m.def("abi_version", [] { return qgtc_abi_version(); });
+
+    m.def("pack_edges", &pack_edges, "rows-layout bit planes of the [height, width] adjacency of an edge list "
+          "(= val2bit of the dense matrix, without materialising it)", py::arg("src"), py::arg("dst"),
+          py::arg("height"), py::arg("width"), py::arg("nbits") = 1);
+    m.def("i8gemm", &i8gemm, "int8 MFMA GEMM (comparison path): float32 [M,N] = A[M,K] x Bt[N,K]^T, exact");
+    m.def("i8gemm_profile", &i8gemm_profile, "time `reps` i8gemm launches; returns milliseconds",
+          py::arg("A"), py::arg("Bt"), py::arg("reps") = 200, py::arg("print") = true);
 
     py::class_<BatchedGemm>(m, "BatchedGemm")
         .def(py::init<std::vector<torch::Tensor>, std::vector<torch::Tensor>,

@@ -5,6 +5,9 @@ driver), `psize // batch_size` batches are built from `batch_size` consecutive p
 batch's dense float adjacency (row = src, col = dst, value = edge multiplicity) and features are
 packed ONCE with `QGTC.val2bit(A, 1, False, False)` and `QGTC.val2bit(X, bit_width, True, False)`,
 and the logical sizes `(A0, A1, X0, X1)` travel with the packed tensors.
+By default the adjacency planes are built straight from the batch's edge list
+(`QGTC.pack_edges`, word-for-word the same result); `dense_adjacency=True` takes the reference's
+dense float detour.
 
 What is MI355X-first: packed batches stay resident in HBM by default (a 1213-node 2-bit batch is
 230 KiB; all 75 batches of an ogbn-arxiv-sized graph are 17 MiB of 288 GB) instead of being parked
@@ -44,7 +47,7 @@ class ClusterTensor:
 class ClusterIter:
     def __init__(self, dn, g: G.Graph, psize: int, batch_size: int, bit_width: int = 2,
                  run_GIN: bool = False, device="cuda", resident: bool = True, qgtc=None,
-                 batch_ids=None, with_rows_X: bool = False):
+                 batch_ids=None, with_rows_X: bool = False, dense_adjacency: bool = False):
         if qgtc is None:
             import QGTC as qgtc  # the HIP extension; there is no fallback
         self.g = g
@@ -63,13 +66,20 @@ class ClusterIter:
             nodes = G.batch_nodes(self.par_li, cid, psize, batch_size)
             row, col = G.induced_edges(g, nodes)
             n = nodes.size
-            A = torch.zeros((n, n), dtype=torch.float32, device=self.device)
-            if row.size:
+            r_dev, c_dev = torch.from_numpy(row).to(self.device), torch.from_numpy(col).to(self.device)
+            if dense_adjacency:
+                # the reference's route: dense float n x n matrix, then val2bit (sampler.py:80-101);
                 # torch.sparse.FloatTensor(i, v).to_dense() sums duplicate edges (sampler.py:87-89)
-                A.index_put_((torch.from_numpy(row).to(self.device), torch.from_numpy(col).to(self.device)),
-                             torch.ones(row.size, dtype=torch.float32, device=self.device), accumulate=True)
+                A = torch.zeros((n, n), dtype=torch.float32, device=self.device)
+                if row.size:
+                    A.index_put_((r_dev, c_dev), torch.ones(row.size, dtype=torch.float32, device=self.device),
+                                 accumulate=True)
+                bit_A = qgtc.val2bit(A, 1, False, False)         # sampler.py:98/101
+            else:
+                # same words, straight from the edge list: the n x n floats (5.9 MB for n = 1213
+                # against 190 KiB packed) are never materialised
+                bit_A = qgtc.pack_edges(r_dev, c_dev, n, n, 1)
             X = torch.from_numpy(g.feat[nodes]).to(self.device)
-            bit_A = qgtc.val2bit(A, 1, False, False)             # sampler.py:98/101
             bit_X = qgtc.val2bit(X, bit_width, True, False)      # sampler.py:99/102
             bit_Xr = qgtc.val2bit(X, bit_width, False, False) if with_rows_X else None
             ct = ClusterTensor(bit_A, bit_X, bit_Xr)
