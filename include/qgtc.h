@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QGTC_ABI_VERSION 2
+#define QGTC_ABI_VERSION 3
 
 enum {
     QGTC_OK = 0,
@@ -118,7 +118,19 @@ typedef struct qgtc_problem {
     uint64_t x_words, w_words;
     int32_t M, K, N;
     int32_t w_lines; /* lines per W plane: PAD128(N), or PAD8(N) for bitMM2Int pad_128=0 */
+    int32_t occ_words; /* 64-bit words per row tile of `occ`: ceil(STEP128(K) / 64) */
+    const uint64_t *occ; /* optional (NULL = visit every k-quad): occupancy bitmap of X from
+                            qgtc_tile_occupancy; zero X tiles are then neither loaded nor multiplied */
 } qgtc_problem;
+
+/* Occupancy bitmap of a rows-layout left operand, for zero-tile JUMPING in qgtc_bitmm_batched (the
+ * reference only counts what jumping would save: QGTC_layer_hidden_zerojump_cnt, kernel.h:516-648).
+ * Bit q of word [row_tile][q / 64] is set when the 32-row x 128-bit tile (rows 32*row_tile..+31,
+ * k-quad q) has a set bit in any of the bit1 planes. qgtc_occupancy_words(M, K) 64-bit words.
+ * Products are bit-identical with and without the bitmap. */
+size_t qgtc_occupancy_words(int M, int K);
+int qgtc_tile_occupancy(const uint32_t *X, size_t x_words, int M, int K, int bit1, uint64_t *occ,
+                        size_t occ_words, void *stream);
 
 int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int max_K, int max_N,
                        int bit1, int bit2, int output_bit, int mode, unsigned flags,

@@ -32,6 +32,9 @@
 
 namespace {
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int TM = 32, TN = 32;  // workgroup tile of the bit-GEMM
+
 // ------------------------------------------------------------------------------------------
 // shape algebra (reference utility.h:33-45)
 // ------------------------------------------------------------------------------------------
@@ -352,6 +355,35 @@ __global__ __launch_bounds__(64 * I8_WAVES) void k_i8gemm(const int8_t *__restri
 }
 
 // ------------------------------------------------------------------------------------------
+// Occupancy bitmap of a rows-layout operand: bit q of word (tile, q/64) says whether the 32-row x
+// 128-bit tile (row tile, k-quad q) has a bit set in any plane. One wave per (row tile, word):
+// lane = k-quad, 32 x planes coalesced 16-byte loads per lane, one ballot.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_occupancy(const uint32_t *__restrict__ X, unsigned x_bytes,
+                                                        int M, int K, int a, unsigned long long *__restrict__ occ,
+                                                        int occ_words, int tiles_m) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wave >= tiles_m * occ_words) return;  // whole waves
+    const int tm = wave / occ_words, wi = wave % occ_words;
+    const int kq = step128(K), q = wi * 64 + lane;
+    const uint32_t kw = static_cast<uint32_t>(kq) * 4u, x_plane = static_cast<uint32_t>(pad8(M)) * kw;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(X), 0,
+                                                                       static_cast<int>(x_bytes), 0x00020000);
+    uint32_t any = 0u;
+    for (int p = 0; p < a; p++)
+#pragma unroll 8
+        for (int r = 0; r < TM; r++) {
+            const int m = tm * TM + r;
+            const uint32_t off = (q < kq && m < M) ? (p * x_plane + m * kw + q * 4u) * 4u : 0xffffffffu;
+            const u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+            any |= (g.x | g.y) | (g.z | g.w);
+        }
+    const unsigned long long m = __ballot(any != 0u);
+    if (lane == 0) occ[static_cast<size_t>(tm) * occ_words + wi] = m;
+}
+
+// ------------------------------------------------------------------------------------------
 // tile counters (reference kernel.h:452, :574-592): one thread per (plane, 8-row block, k-step)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tile_counters(const uint32_t *__restrict__ X,
@@ -431,7 +463,6 @@ struct Stamps {
 #define STAMP_PASS
 #endif
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct MMShape {           // per-launch constants
     int a, w, ob;          // planes of X, planes of W, output planes
@@ -442,7 +473,6 @@ struct MMShape {           // per-launch constants
     float maxv, maxm1;     // 2^ob and 2^ob - 1 as float (requant)
 };
 
-constexpr int TM = 32, TN = 32;      // workgroup tile
 constexpr int MR = 4, MC = 4;        // per-lane micro-tile
 constexpr int GPT = 8;               // granules (16 B) a lane may hold per stage
 constexpr int SLAB_PITCH = 72;       // ints between the (i,j) planes of a wave's partial tile
@@ -809,41 +839,120 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
         const bool in = pt < (is_x ? ab : wb);
         const uint32_t gline = static_cast<uint32_t>((is_x ? m0 : n0) + line);
         const bool ok = in && static_cast<int>(gline) < (is_x ? M : N);
-        s_off[u] = (static_cast<uint32_t>(pt) * (is_x ? x_plane : w_plane) + gline * kw +
-                    static_cast<uint32_t>(kk) * 4u) * 4u;
+        s_off[u] = (static_cast<uint32_t>(pt) * (is_x ? x_plane : w_plane) + gline * kw) * 4u;
         s_lds[u] = static_cast<uint32_t>((is_x ? 0 : wreg) + (pt * QW + kk) * RS + line);
         v_in |= in ? (1u << u) : 0u;
         v_ok |= ok ? (1u << u) : 0u;
     }
 
-    // position in the (X plane block, W plane block, K chunk) iteration space of this wave
-    struct Cursor {
-        int pa0, pw0, q0;
+    // One stage = up to QW k-quads of one (X plane block, W plane block). The k-quads a wave visits
+    // are either all of its slice [ks, ke) in order, or - when the caller supplies the occupancy
+    // bitmap of the left operand (pr.occ: one bit per 32-row tile and k-quad) - only those whose
+    // X tile has a bit set: zero tiles are then neither loaded nor multiplied ("zero-tile jumping").
+    struct Stage {
+        int pa0, pw0;
+        int i0, i1, i2, i3;  // k-quad of slot kk = 0..3 (named fields: an indexed array lands in scratch)
+        int nk;              // slots in use
         bool valid;
     };
-    auto advance = [&](Cursor &c) {
-        c.q0 += QW;
-        if (c.q0 >= ke) {
-            c.q0 = ks;
-            c.pw0 += wb;
-            if (c.pw0 >= sh.w) {
-                c.pw0 = 0;
-                c.pa0 += ab;
-                if (c.pa0 >= sh.a) c.valid = false;
-            }
+    const uint64_t *occ_row = pr.occ ? pr.occ + static_cast<size_t>(tm) * pr.occ_words : nullptr;
+    int k_next = ks;                // dense mode: next k-quad
+    int k_word = 0;                 // bitmap mode: current 64-k-quad word
+    unsigned long long k_mask = 0;  // bitmap mode: unvisited k-quads of the current word, inside [ks, ke)
+    auto k_word_mask = [&](int wi) -> unsigned long long {
+        unsigned long long m = occ_row[wi];
+        const int lo = ks - wi * 64, hi = ke - wi * 64;  // keep bits [lo, hi)
+        if (lo > 0) m &= ~0ull << lo;
+        if (hi < 64) m &= hi > 0 ? ~0ull >> (64 - hi) : 0ull;
+        return m;
+    };
+    auto k_reset = [&]() {
+        k_next = ks;
+        if (occ_row) {
+            k_word = ks >> 6;
+            k_mask = ks < ke ? k_word_mask(k_word) : 0ull;
         }
+    };
+    // the next k-quads of the slice as a stage (by value: a Stage passed by reference through
+    // the lambdas ends up in scratch); .valid = false when the wave's slice is exhausted
+    auto k_take = [&](int pa0, int pw0) -> Stage {
+        Stage st{pa0, pw0, 0, 0, 0, 0, 0, false};
+        if (!occ_row) {
+            if (k_next >= ke) return st;
+            st.i0 = k_next;
+            st.i1 = k_next + 1;
+            st.i2 = k_next + 2;
+            st.i3 = k_next + 3;
+            st.nk = min(QW, ke - k_next);
+            st.valid = true;
+            k_next += QW;
+            return st;
+        }
+        while (k_mask == 0ull) {
+            k_word++;
+            if (k_word * 64 >= ke) return st;
+            k_mask = k_word_mask(k_word);
+        }
+        st.valid = true;
+        // pop the lowest unvisited k-quads of the word (plain locals: a lambda capturing `st` by
+        // reference keeps the struct in scratch)
+        int nk = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+        unsigned long long m = k_mask;
+#define QGTC_POP(dst)                                \
+    if (m != 0ull) {                                 \
+        dst = k_word * 64 + __builtin_ctzll(m);      \
+        m &= m - 1ull;                               \
+        nk++;                                        \
+    }
+        QGTC_POP(q0)
+        if (QW > 1) { QGTC_POP(q1) }
+        if (QW > 2) { QGTC_POP(q2) QGTC_POP(q3) }
+#undef QGTC_POP
+        k_mask = m;
+        st.i0 = q0;
+        st.i1 = q1;
+        st.i2 = q2;
+        st.i3 = q3;
+        st.nk = nk;
+        return st;
+    };
+    auto first_stage = [&]() -> Stage {
+        k_reset();
+        return k_take(0, 0);  // an empty slice (or an all-zero row tile) has no stage at all
+    };
+    auto next_stage = [&](const Stage &prev) -> Stage {
+        Stage st = k_take(prev.pa0, prev.pw0);
+        if (st.valid) return st;
+        // the k range is exhausted: next plane block (generic kernel only), restart the k iteration
+        int pa0 = prev.pa0, pw0 = prev.pw0 + wb;
+        if (pw0 >= sh.w) {
+            pw0 = 0;
+            pa0 += ab;
+            if (pa0 >= sh.a) return st;  // invalid
+        }
+        k_reset();
+        return k_take(pa0, pw0);
     };
 
     // issue the loads of one stage into registers; lanes whose granule does not exist (row or
     // column out of range, plane or k-quad beyond this stage) load from offset 0xffffffff, which
     // the range check turns into zeros
     u32x4 pre[GPT];
-    auto issue = [&](const Cursor &c) {
-        const int nk = min(QW, ke - c.q0);
-        const int na = min(ab, sh.a - c.pa0), nw = min(wb, sh.w - c.pw0);
-        const uint32_t xo = (static_cast<uint32_t>(c.pa0) * x_plane + static_cast<uint32_t>(c.q0) * 4u) * 4u;
-        const uint32_t wo = (static_cast<uint32_t>(c.pw0) * w_plane + static_cast<uint32_t>(c.q0) * 4u) * 4u;
-        const bool kk_ok = kkl < nk;
+    auto issue = [&](const int pa0, const int pw0, const int i0, const int i1, const int i2, const int i3,
+                     const int nk_) {
+        // (scalars by value: selecting among the fields of a Stage passed by reference makes hipcc
+        // spill the struct and load the field through a computed scratch address)
+        const int na = min(ab, sh.a - pa0), nw = min(wb, sh.w - pw0);
+        const uint32_t xo = static_cast<uint32_t>(pa0) * x_plane * 4u;
+        const uint32_t wo = static_cast<uint32_t>(pw0) * w_plane * 4u;
+        // the lane's k-quad, as byte offset inside the packed row
+        uint32_t ko = static_cast<uint32_t>(i0) * 16u;
+        if (QW > 1) ko = kkl == 1 ? static_cast<uint32_t>(i1) * 16u : ko;
+        if (QW > 2) {
+            ko = kkl == 2 ? static_cast<uint32_t>(i2) * 16u : ko;
+            ko = kkl == 3 ? static_cast<uint32_t>(i3) * 16u : ko;
+        }
+        const bool kk_ok = kkl < nk_;
 #pragma unroll
         for (int u = 0; u < GPT; u++) {
             if (u >= nsx + nsw) break;
@@ -853,14 +962,14 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
                 const int pt = 2 * (is_x ? u : u - nsx) + (lane >> 5);
                 ok = ok && pt < (is_x ? na : nw);
             }
-            const uint32_t off = ok ? s_off[u] + (is_x ? xo : wo) : 0xffffffffu;
+            const uint32_t off = ok ? s_off[u] + (is_x ? xo : wo) + ko : 0xffffffffu;
             pre[u] = __builtin_amdgcn_raw_buffer_load_b128(is_x ? rx : rw, off, 0, 0);
         }
     };
 
-    Cursor cur{0, 0, ks, ks < ke};
+    Stage cur = first_stage();
     STAMP(1);
-    if (cur.valid) issue(cur);
+    if (cur.valid) issue(cur.pa0, cur.pw0, cur.i0, cur.i1, cur.i2, cur.i3, cur.nk);
     STAMP(2);
 
     uint32_t tot[MR][MC];  // unsigned: the reference's int32 accumulation wraps on overflow
@@ -901,16 +1010,17 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
             if (ZS && u < nsx) nzm[u] = __ballot(((pre[u].x | pre[u].y) | (pre[u].z | pre[u].w)) != 0u);
         }
         if (it == 0) STAMP(3);
-        const Cursor now = cur;
-        advance(cur);
-        if (cur.valid) issue(cur);  // the next stage's loads fly while this one is multiplied
+        const Stage now = cur;
+        cur = next_stage(now);
+        // the next stage's loads fly while this one is multiplied
+        if (cur.valid) issue(cur.pa0, cur.pw0, cur.i0, cur.i1, cur.i2, cur.i3, cur.nk);
         // the wave reads what its other lanes wrote: LDS is in order per wave, the fence only
         // keeps the compiler from moving the reads above the writes
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (it == 0) STAMP(4);
 
-        const int nk = min(QW, ke - now.q0);
+        const int nk = now.nk;
         if constexpr (!GEN) {
             uint32_t occ[NA];
 #pragma unroll
@@ -1288,7 +1398,7 @@ int qgtc_bitmm2bit(const uint32_t *X, size_t x_words, const uint32_t *W, size_t 
     const bool cols = flags & QGTC_OUT_COLS;
     const size_t need = cols ? qgtc_cols_words(M, N, output_bit, 0) : qgtc_rows_words(M, N, output_bit);
     if (out_words < need) return QGTC_ESIZE;
-    qgtc_problem pr{X, W, out, x_words, w_words, M, K, N, pad128(N)};
+    qgtc_problem pr{X, W, out, x_words, w_words, M, K, N, pad128(N), 0, nullptr};
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (flags & QGTC_NO_ZERO_SKIP)
         return dispatch_single<false>(pr, K, bit1, bit2, output_bit, cols ? 1 : 0, st);
@@ -1302,7 +1412,7 @@ int qgtc_bitmm2int(const uint32_t *X, size_t x_words, const uint32_t *W, size_t 
     if (rc != QGTC_OK) return rc;
     if (!words_ok(x_words, w_words)) return QGTC_EINVAL;
     if (out_elems < static_cast<size_t>(M) * N) return QGTC_ESIZE;
-    qgtc_problem pr{X, W, out, x_words, w_words, M, K, N, pad_128 ? pad128(N) : pad8(N)};
+    qgtc_problem pr{X, W, out, x_words, w_words, M, K, N, pad_128 ? pad128(N) : pad8(N), 0, nullptr};
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (flags & QGTC_NO_ZERO_SKIP) return dispatch_single<false>(pr, K, bit1, bit2, 1, 2, st);
     return dispatch_single<true>(pr, K, bit1, bit2, 1, 2, st);
@@ -1370,6 +1480,25 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
                                        mode == 2 ? 1 : output_bit, mode, st);
     return dispatch_batched<true>(problems, count, max_M, max_N, k_hint, bit1, bit2,
                                   mode == 2 ? 1 : output_bit, mode, st);
+}
+
+size_t qgtc_occupancy_words(int M, int K) {
+    return static_cast<size_t>((M + TM - 1) / TM) * ((step128(K) + 63) / 64);
+}
+
+int qgtc_tile_occupancy(const uint32_t *X, size_t x_words, int M, int K, int bit1, uint64_t *occ,
+                        size_t occ_words, void *stream) {
+    if (!X || !occ || M <= 0 || K <= 0 || !bits_ok(bit1)) return QGTC_EINVAL;
+    if (!aligned16(X)) return QGTC_EALIGN;
+    if (x_words >= (1ull << 30)) return QGTC_EINVAL;
+    if (occ_words < qgtc_occupancy_words(M, K)) return QGTC_ESIZE;
+    const int tiles_m = (M + TM - 1) / TM, ow = (step128(K) + 63) / 64;
+    const int waves = tiles_m * ow;
+    hipLaunchKernelGGL(k_tile_occupancy, dim3((waves + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       X, static_cast<unsigned>(x_words * 4), M, K, bit1,
+                       reinterpret_cast<unsigned long long *>(occ), ow, tiles_m);
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
 }
 
 int qgtc_pack_edges(const int64_t *cells, const int32_t *counts, size_t n_cells, int H, int W,

@@ -316,9 +316,13 @@ struct BatchedGemm {
 
     // Xs[i]: rows-layout left operand of problem i; Ws: one shared right operand (len 1) or one
     // per problem; dims[i] = (M, K, N). mode 0/1/2 as qgtc_bitmm_batched; pad_128 only for mode 2.
+    // zero_jump: build the occupancy bitmap of every left operand once (qgtc_tile_occupancy) so
+    // that run() neither loads nor multiplies all-zero 32-row x 128-bit X tiles. The bitmap
+    // describes Xs[i] as it is NOW: pass false when the left operands are outputs of an earlier
+    // stage that change between runs.
     BatchedGemm(std::vector<torch::Tensor> Xs, std::vector<torch::Tensor> Ws,
                 std::vector<std::tuple<int, int, int>> dims, int bit1_, int bit2_, int ob_,
-                int mode_, bool pad_128)
+                int mode_, bool pad_128, bool zero_jump)
         : bit1(bit1_), bit2(bit2_), ob(ob_), mode(mode_) {
         count = static_cast<int>(Xs.size());
         TORCH_CHECK(count > 0, "empty batch");
@@ -359,6 +363,19 @@ struct BatchedGemm {
             h[i].K = K;
             h[i].N = N;
             h[i].w_lines = (mode == 2 && !pad_128) ? P8(N) : P128(N);
+            h[i].occ = nullptr;
+            h[i].occ_words = 0;
+            if (zero_jump) {
+                const int64_t nw = static_cast<int64_t>(qgtc_occupancy_words(M, K));
+                auto occ = torch::empty({nw}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
+                check_rc(qgtc_tile_occupancy(words(X), X.numel(), M, K, bit1,
+                                             reinterpret_cast<uint64_t *>(occ.data_ptr<int64_t>()), nw,
+                                             current_stream(X)),
+                         "BatchedGemm (tile occupancy)");
+                h[i].occ = reinterpret_cast<const uint64_t *>(occ.data_ptr<int64_t>());
+                h[i].occ_words = (S128(K) + 63) / 64;
+                keep.push_back(occ);
+            }
             max_M = std::max(max_M, M);
             max_K = std::max(max_K, K);
             max_N = std::max(max_N, N);
@@ -421,6 +438,17 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         auto c = tile_counters(x, M, K, N, bit1, bit2);
         return py::make_tuple(c[0], c[1]);
     }, "per-call (total, non-zero) tile-step counts in the reference's 8x128-bit tile units");
+    m.def("tile_occupancy", [](torch::Tensor x, int M, int K, int bit1) {
+        CHECK_INPUT(x);
+        check_bits_tensor(x, "x");
+        c10::DeviceGuard guard(x.device());
+        const int64_t nw = static_cast<int64_t>(qgtc_occupancy_words(M, K));
+        auto occ = torch::empty({nw}, torch::TensorOptions().dtype(torch::kInt64).device(x.device()));
+        check_rc(qgtc_tile_occupancy(words(x), x.numel(), M, K, bit1,
+                                     reinterpret_cast<uint64_t *>(occ.data_ptr<int64_t>()), nw, current_stream(x)),
+                 "tile_occupancy");
+        return occ;
+    }, "occupancy bitmap (int64 words, [row tile][k-quad / 64]) of a rows-layout operand: 32-row x 128-bit tiles");
     m.def("get_counters", [] { return py::make_tuple(g_counter_global, g_counter); });
     m.def("reset_counters", [] { g_counter = 0; g_counter_global = 0; });
     m.def("set_zero_skip", [](bool on) { g_zero_skip = on; });
@@ -436,9 +464,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
 
     py::class_<BatchedGemm>(m, "BatchedGemm")
         .def(py::init<std::vector<torch::Tensor>, std::vector<torch::Tensor>,
-                      std::vector<std::tuple<int, int, int>>, int, int, int, int, bool>(),
+                      std::vector<std::tuple<int, int, int>>, int, int, int, int, bool, bool>(),
              py::arg("Xs"), py::arg("Ws"), py::arg("dims"), py::arg("bit1"), py::arg("bit2"),
-             py::arg("output_bit"), py::arg("mode") = 0, py::arg("pad_128") = false)
+             py::arg("output_bit"), py::arg("mode") = 0, py::arg("pad_128") = false,
+             py::arg("zero_jump") = false)
         .def("run", &BatchedGemm::run)
         .def_readonly("outs", &BatchedGemm::outs)
         .def_readonly("count", &BatchedGemm::count);

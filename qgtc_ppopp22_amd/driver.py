@@ -152,32 +152,32 @@ class BatchedEpoch:
         if chain == "reference" and not run_gin:
             x0x1 = [(p[2], p[3], H) for p in params]
             g0 = BG(bitX, [W["W1"]], x0x1, b, b, b, 0, False)
-            g1 = BG(bitA, g0.outs, dims(None, H), 1, b, b, 0, False)
+            g1 = BG(bitA, g0.outs, dims(None, H), 1, b, b, 0, False, True)
             g2 = BG(g1.outs, [W["W2"]], dims(H, H), b, b, b, 0, False)
-            g3 = BG(bitA, g2.outs, dims(None, H), 1, b, b, 0, False)
+            g3 = BG(bitA, g2.outs, dims(None, H), 1, b, b, 0, False, True)
             g4 = BG(g3.outs, [W["W3"]], dims(H, C), b, b, b, 0, False)
-            g5 = BG(bitA, g4.outs, dims(None, H), 1, b, 1, 2, False)
+            g5 = BG(bitA, g4.outs, dims(None, H), 1, b, 1, 2, False, True)
         elif chain == "reference":
-            g0 = BG(bitA, bitX, dims(None, F), 1, b, b, 0, False)
+            g0 = BG(bitA, bitX, dims(None, F), 1, b, b, 0, False, True)
             g1 = BG(g0.outs, [W["W1"]], dims(F, H), b, b, b, 0, False)
-            g2 = BG(bitA, g1.outs, dims(None, H), 1, b, b, 0, False)
+            g2 = BG(bitA, g1.outs, dims(None, H), 1, b, b, 0, False, True)
             g3 = BG(g2.outs, [W["W2"]], dims(H, H), b, b, b, 0, False)
-            g4 = BG(bitA, g3.outs, dims(None, H), 1, b, b, 0, False)
+            g4 = BG(bitA, g3.outs, dims(None, H), 1, b, b, 0, False, True)
             g5 = BG(g4.outs, [W["W3"]], dims(H, C), b, b, 1, 2, False)
         elif not run_gin:
             bitXr = [c.bit_X_rows for c in cts]
             g0 = BG(bitXr, [W["W1"]], dims(F, H), b, b, b, 1, False)
-            g1 = BG(bitA, g0.outs, dims(None, H), 1, b, b, 0, False)
+            g1 = BG(bitA, g0.outs, dims(None, H), 1, b, b, 0, False, True)
             g2 = BG(g1.outs, [W["W2"]], dims(H, H), b, b, b, 1, False)
-            g3 = BG(bitA, g2.outs, dims(None, H), 1, b, b, 0, False)
+            g3 = BG(bitA, g2.outs, dims(None, H), 1, b, b, 0, False, True)
             g4 = BG(g3.outs, [W["W3h"]], dims(H, C), b, b, b, 1, False)
-            g5 = BG(bitA, g4.outs, dims(None, C), 1, b, 1, 2, True)
+            g5 = BG(bitA, g4.outs, dims(None, C), 1, b, 1, 2, True, True)
         else:
-            g0 = BG(bitA, bitX, dims(None, F), 1, b, b, 0, False)
+            g0 = BG(bitA, bitX, dims(None, F), 1, b, b, 0, False, True)
             g1 = BG(g0.outs, [W["W1"]], dims(F, H), b, b, b, 1, False)
-            g2 = BG(bitA, g1.outs, dims(None, H), 1, b, b, 0, False)
+            g2 = BG(bitA, g1.outs, dims(None, H), 1, b, b, 0, False, True)
             g3 = BG(g2.outs, [W["W2"]], dims(H, H), b, b, b, 1, False)
-            g4 = BG(bitA, g3.outs, dims(None, H), 1, b, b, 0, False)
+            g4 = BG(bitA, g3.outs, dims(None, H), 1, b, b, 0, False, True)
             g5 = BG(g4.outs, [W["W3"]], dims(H, C), b, b, 1, 2, False)
         self.stages = [g0, g1, g2, g3, g4, g5]
         self.outs = g5.outs

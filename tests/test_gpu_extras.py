@@ -100,3 +100,67 @@ def test_sampler_edge_route_equals_dense_route(qgtc):
         outs.append([ct.bit_A for ct in it.cTensor_li])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def _np_occupancy(X_words, M, K, a):
+    """bit q of word [tile][q // 64]: any set bit in rows 32*tile..+31, words 4q..4q+3, any plane."""
+    kq = (K + 127) // 128
+    rows_pad = (M + 7) // 8 * 8
+    planes = X_words.reshape(a, rows_pad, kq * 4)
+    tiles = (M + 31) // 32
+    ow = (kq + 63) // 64
+    occ = np.zeros((tiles, ow), dtype=np.uint64)
+    for t in range(tiles):
+        blk = planes[:, 32 * t:min(32 * t + 32, M), :].reshape(a, -1, kq, 4)
+        nz = (blk != 0).any(axis=(0, 1, 3))
+        for q in np.nonzero(nz)[0]:
+            occ[t, q // 64] |= np.uint64(1) << np.uint64(q % 64)
+    return occ.reshape(-1)
+
+
+@pytest.mark.parametrize("M,K,a,density", [(100, 1000, 1, 0.002), (1213, 1213, 1, 0.0005), (70, 9000, 2, 0.0003),
+                                           (33, 130, 3, 0.5), (64, 128, 1, 0.0)])
+def test_tile_occupancy_bitmap(qgtc, oracle, M, K, a, density):
+    import torch
+    from helpers import rand_q, to_dev
+    rng = np.random.default_rng(M + K + a)
+    qx = rand_q(rng, M, K, a, density)
+    X = oracle.pack(qx, a, False)
+    dX = to_dev(torch, X, (a * ((M + 7) // 8 * 8), (K + 127) // 128 * 4))
+    got = qgtc.tile_occupancy(dX, M, K, a).cpu().numpy().view(np.uint64)
+    np.testing.assert_array_equal(got, _np_occupancy(X, M, K, a))
+
+
+@pytest.mark.parametrize("a,w,ob", [(1, 2, 2), (1, 1, 1), (2, 2, 3), (3, 5, 4)])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_zero_jump_products_are_identical(qgtc, oracle, a, w, ob, mode):
+    """Grouped launch with the occupancy bitmap (tiles neither loaded nor multiplied) against the
+    oracle: block-diagonal-dominant sparse left operands, including an all-zero one."""
+    import torch
+    from helpers import rand_q, to_dev
+    rng = np.random.default_rng(7 * a + w + mode)
+    dims = [(1213, 1213, 128), (300, 9000, 40), (37, 37, 10), (640, 640, 128), (64, 256, 32)]
+    Xs, Ws, refs = [], [], []
+    for i, (M, K, N) in enumerate(dims):
+        qx = rand_q(rng, M, K, a, 0.003)
+        for blk in range(0, min(M, K), 64):          # dense diagonal blocks, empty elsewhere
+            qx[blk:blk + 64, :] *= 0
+            qx[blk:blk + 64, blk:blk + 64] = rng.integers(0, 2 ** a, size=qx[blk:blk + 64, blk:blk + 64].shape)
+        if i == 4:
+            qx[:] = 0
+        qw = rand_q(rng, K, N, w)
+        X, Wt = oracle.pack(qx, a, False), oracle.pack(qw, w, True)
+        Xs.append(to_dev(torch, X, (a * ((M + 7) // 8 * 8), (K + 127) // 128 * 4)))
+        Ws.append(to_dev(torch, Wt, (w * ((K + 127) // 128 * 4), (N + 127) // 128 * 128)))
+        refs.append((X, Wt))
+    for zj in (True, False):
+        bg = qgtc.BatchedGemm(Xs, Ws, dims, a, w, ob, mode, True, zj)
+        bg.run()
+        torch.cuda.synchronize()
+        for i, (M, K, N) in enumerate(dims):
+            X, Wt = refs[i]
+            if mode == 2:
+                np.testing.assert_array_equal(bg.outs[i].cpu().numpy(), oracle.bitmm2int(X, Wt, M, K, N, a, w, True))
+            else:
+                np.testing.assert_array_equal(to_np_u32(bg.outs[i]),
+                                              oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob, col=(mode == 1)))
