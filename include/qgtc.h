@@ -48,6 +48,7 @@ enum {
 /* flags for qgtc_bitmm2bit */
 #define QGTC_OUT_COLS 0x1u     /* pack the result in the cols layout (bitMM2Bit_col)      */
 #define QGTC_NO_ZERO_SKIP 0x2u /* do not skip all-zero X tiles (result is identical)      */
+#define QGTC_ZERO_JUMP 0x4u    /* qgtc_bitmm_batched: the problems carry occupancy bitmaps */
 
 int qgtc_abi_version(void);
 const char *qgtc_strerror(int code);

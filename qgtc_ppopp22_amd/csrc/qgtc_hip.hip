@@ -469,6 +469,7 @@ struct MMShape {           // per-launch constants
     int mode;              // 0 rows-layout bits, 1 cols-layout bits, 2 float32
     int ab, wb;            // planes staged at once (generic kernel; the fixed kernels stage all)
     int per;               // k-quads per wave (in-workgroup split-K slice)
+    int waves;             // waves per workgroup (= blockDim.x / 64, passed so that no hidden argument is read)
     uint32_t inv_tiles_n;  // floor(2^32 / tiles_n), single launches only (tiles_n >= 2; else 0xffffffff)
     float maxv, maxm1;     // 2^ob and 2^ob - 1 as float (requant)
 };
@@ -582,22 +583,47 @@ __device__ __forceinline__ uint32_t tile_occupancy(const unsigned long long (&nz
 // in workgroups of 4+ waves the upper waves leave right after the barrier. What runs here is
 // latency-bound (a few waves, dependent instructions), so the code is kept short: every
 // instruction behind the barrier costs the whole workgroup ~8 cycles.
-template <int MODE, bool INT_RQ, bool ALL8>
-__device__ __forceinline__ void epi_quad(const qgtc_problem &pr, const MMShape &sh, int t, int m0, int n0,
-                                         int extra, size_t oplane, const unsigned char *slabs, int nwv) {
+// What a thread needs to finish its quad besides the sums. (Computing it at kernel start, under the
+// first loads' latency, was measured: it shortens the tail by ~300 cycles but costs as much in the
+// prologue and 5 VGPRs across the main loop.)
+struct QuadPlan {
+    uint32_t src;     // byte offset of the quad inside a slab
+    uint32_t *dst;    // first output word (or float) of the quad
+    int nvalid;       // leading elements of the quad that exist (rows layout / float: columns; cols layout: rows)
+    uint32_t sh_n;    // shift of the quad's nibble inside the 32-bit word; bit 31: this lane stores the word
+};
+
+template <int MODE>
+__device__ __forceinline__ QuadPlan quad_plan(const qgtc_problem &pr, int t, int m0, int n0) {
     // quad t = hi<<6 | a8<<3 | lo<<1 | h ; rows layout / float: (hi,lo) = (i,j), cols layout: (j,i)
     const int M = pr.M, N = pr.N;
-    const int hi = t >> 6, a8 = (t >> 3) & 7, lo = (t >> 1) & 3, h = t & 1;
+    const int hi = (t >> 6) & 3, a8 = (t >> 3) & 7, lo = (t >> 1) & 3, h = t & 1;
     const int i = MODE == 1 ? lo : hi, j = MODE == 1 ? hi : lo;
-    const unsigned char *src = slabs + ((i * MC + j) * SLAB_PITCH + a8 * 8 + h * 4) * 4;
-    int4 part[MAX_WAVES];
-#pragma unroll
-    for (int k = 0; k < MAX_WAVES; k++)  // slabs that do not exist alias slab 0 and are masked
-        part[k] = *reinterpret_cast<const int4 *>(src + ((ALL8 || k < nwv) ? k : 0) * SLAB_BYTES);
+    QuadPlan q;
+    q.src = static_cast<uint32_t>(((i * MC + j) * SLAB_PITCH + a8 * 8 + h * 4) * 4);
     const int m = MODE == 1 ? m0 + 8 * i + 4 * h : m0 + a8 + 8 * i;
     const int n = MODE == 1 ? n0 + a8 + 8 * j : n0 + 8 * j + 4 * h;
     // valid elements of the quad: rows layout / float (m, n+q), cols layout (m+q, n)
-    const int nvalid = MODE == 1 ? (n < N ? min(max(M - m, 0), 4) : 0) : (m < M ? min(max(N - n, 0), 4) : 0);
+    q.nvalid = MODE == 1 ? (n < N ? min(max(M - m, 0), 4) : 0) : (m < M ? min(max(N - n, 0), 4) : 0);
+    // rows layout [ob][PAD8(M)][STEP128(N)*4] (reference kernel.h:357-389): word (m, n0/32);
+    // cols layout [ob][PAD128(N)][STEP128(M)*4] (intended semantics of kernel.h:651-810): word (n, m0/32);
+    // float32 [M,N] (reference kernel.h:915-930): row m, columns n .. n+3
+    const size_t o0 = MODE == 2 ? static_cast<size_t>(m) * N + n
+                    : MODE == 0 ? static_cast<size_t>(m) * (step128(N) * 4) + (n0 >> 5)
+                                : static_cast<size_t>(n) * (step128(M) * 4) + (m0 >> 5);
+    q.dst = static_cast<uint32_t *>(pr.out) + o0;
+    const bool store = (t & 7) == 0 && (MODE == 0 ? m < pad8(M) : n < pad128(N));
+    q.sh_n = static_cast<uint32_t>(28 - 4 * (t & 7)) | (store ? 0x80000000u : 0u);
+    return q;
+}
+
+template <int MODE, bool INT_RQ, bool ALL8>
+__device__ __forceinline__ void quad_finish(const qgtc_problem &pr, const MMShape &sh, const QuadPlan &q,
+                                            int extra, size_t oplane, const unsigned char *slabs, int nwv) {
+    int4 part[MAX_WAVES];
+#pragma unroll
+    for (int k = 0; k < MAX_WAVES; k++)  // slabs that do not exist alias slab 0 and are masked
+        part[k] = *reinterpret_cast<const int4 *>(slabs + q.src + ((ALL8 || k < nwv) ? k : 0) * SLAB_BYTES);
     int v[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < MAX_WAVES; k++) {
@@ -608,34 +634,29 @@ __device__ __forceinline__ void epi_quad(const qgtc_problem &pr, const MMShape &
         v[3] += on ? part[k].w : 0;
     }
     if (MODE == 2) {
-        // float32 [M,N] (reference kernel.h:915-930): row m, columns n .. n+3
-        float *dst = static_cast<float *>(pr.out) + static_cast<size_t>(m) * N + n;
-        if (nvalid == 4 && (N & 3) == 0) {
+        float *dst = reinterpret_cast<float *>(q.dst);
+        if (q.nvalid == 4 && (pr.N & 3) == 0) {
             *reinterpret_cast<float4 *>(dst) = make_float4(static_cast<float>(v[0]), static_cast<float>(v[1]),
                                                            static_cast<float>(v[2]), static_cast<float>(v[3]));
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (q < nvalid) dst[q] = static_cast<float>(v[q]);
+            for (int e = 0; e < 4; e++)
+                if (e < q.nvalid) dst[e] = static_cast<float>(v[e]);
         }
         return;
     }
     const int maxi = 1 << (sh.ob & 31);
     uint32_t qv[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int e = 0; e < 4; e++) {
         int c;
-        if (INT_RQ) c = v[q] < 0 ? 1 : (v[q] > maxi ? maxi - 1 : v[q]);  // kernel.h:31-37
-        else c = requant(v[q], sh.maxv, sh.maxm1);
-        qv[q] = q < nvalid ? static_cast<uint32_t>(c) : 0u;
+        if (INT_RQ) c = v[e] < 0 ? 1 : (v[e] > maxi ? maxi - 1 : v[e]);  // kernel.h:31-37
+        else c = requant(v[e], sh.maxv, sh.maxm1);
+        qv[e] = e < q.nvalid ? static_cast<uint32_t>(c) : 0u;
     }
-    // rows layout [ob][PAD8(M)][STEP128(N)*4] (reference kernel.h:357-389): word (m, n0/32);
-    // cols layout [ob][PAD128(N)][STEP128(M)*4] (intended semantics of kernel.h:651-810): word (n, m0/32)
-    const bool store = (t & 7) == 0 && (MODE == 0 ? m < pad8(M) : n < pad128(N));
-    uint32_t *out = static_cast<uint32_t *>(pr.out) +
-                    (MODE == 0 ? static_cast<size_t>(m) * (step128(N) * 4) + (n0 >> 5)
-                               : static_cast<size_t>(n) * (step128(M) * 4) + (m0 >> 5));
-    const uint32_t sh_n = 28 - 4 * (t & 7);  // element e of the 32 sits at bit 31 - e; this quad is e = 4*(t&7) .. +3
+    const bool store = (q.sh_n >> 31) != 0u;
+    const uint32_t sh_n = q.sh_n & 31u;  // element e of the 32 sits at bit 31 - e; this quad is e = 4*(t&7) .. +3
+    uint32_t *out = q.dst;
     for (int p = 0; p < sh.ob; p++, out += oplane) {
         const uint32_t nib = (((qv[0] >> p) & 1u) << 3) | (((qv[1] >> p) & 1u) << 2) |
                              (((qv[2] >> p) & 1u) << 1) | ((qv[3] >> p) & 1u);
@@ -729,7 +750,7 @@ __device__ __forceinline__ void epi_finish(const qgtc_problem &pr, const MMShape
                                            int tiles_m, int tiles_n, unsigned char *slabs STAMP_ARG) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwv = blockDim.x >> 6, NT = nwv * 64;
+    const int nwv = sh.waves, NT = nwv * 64;
     const int lm = lane >> 3, ln = lane & 7;
     const int M = pr.M, N = pr.N, m0 = tm * TM, n0 = tn * TN;
     const bool last_n = tn == tiles_n - 1, last_m = tm == tiles_m - 1;
@@ -749,14 +770,15 @@ __device__ __forceinline__ void epi_finish(const qgtc_problem &pr, const MMShape
     STAMP(9);
     const int extra = (MODE == 0 && last_n) ? step128(N) * 4 - (n0 >> 5) - 1 : 0;
     if (nwv == 1) {
-    } else if (sh.ob <= 23) {  // float(c) > 2^ob  <=>  c > 2^ob for every int c >= 0: integer requantisation
-        if (nwv == MAX_WAVES) {
-            if (tid < 256) epi_quad<MODE, true, true>(pr, sh, tid, m0, n0, extra, oplane, slabs, nwv);
-        } else {
-            for (int t = tid; t < 256; t += NT) epi_quad<MODE, true, false>(pr, sh, t, m0, n0, extra, oplane, slabs, nwv);
-        }
+    } else if (nwv == MAX_WAVES && sh.ob <= 23) {  // one quad per thread, every slab exists
+        if (tid < 256) quad_finish<MODE, true, true>(pr, sh, quad_plan<MODE>(pr, tid, m0, n0), extra, oplane, slabs, nwv);
     } else {
-        for (int t = tid; t < 256; t += NT) epi_quad<MODE, false, false>(pr, sh, t, m0, n0, extra, oplane, slabs, nwv);
+        for (int t = tid; t < 256; t += NT) {
+            const QuadPlan q = quad_plan<MODE>(pr, t, m0, n0);
+            // float(c) > 2^ob  <=>  c > 2^ob for every int c >= 0: integer requantisation when ob <= 23
+            if (sh.ob > 23) quad_finish<MODE, false, false>(pr, sh, q, extra, oplane, slabs, nwv);
+            else quad_finish<MODE, true, false>(pr, sh, q, extra, oplane, slabs, nwv);
+        }
     }
     STAMP(14);
     if (MODE == 1) {
@@ -786,7 +808,7 @@ __device__ __forceinline__ void epi_finish(const qgtc_problem &pr, const MMShape
 // One output tile (tm, tn) of one problem. All threads of the workgroup call this.
 // NA, NW > 0: compile-time plane counts (== sh.a, sh.w), QW k-quads per stage;
 // NA == NW == 0: generic kernel, runtime plane blocks sh.ab x sh.wb, QW = 1.
-template <int QW, int NA, int NW, bool ZS>
+template <int QW, int NA, int NW, bool ZS, bool OCC>
 __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &sh, int tm, int tn,
                                         int tiles_m, int tiles_n, unsigned char *smem) {
     constexpr bool GEN = NA == 0;
@@ -797,7 +819,7 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwv = blockDim.x >> 6;
+    const int nwv = sh.waves;
     const int lm = lane >> 3, ln = lane & 7;
 
     const int M = pr.M, K = pr.K, N = pr.N;
@@ -855,7 +877,7 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
         int nk;              // slots in use
         bool valid;
     };
-    const uint64_t *occ_row = pr.occ ? pr.occ + static_cast<size_t>(tm) * pr.occ_words : nullptr;
+    const uint64_t *occ_row = (OCC && pr.occ) ? pr.occ + static_cast<size_t>(tm) * pr.occ_words : nullptr;
     int k_next = ks;                // dense mode: next k-quad
     int k_word = 0;                 // bitmap mode: current 64-k-quad word
     unsigned long long k_mask = 0;  // bitmap mode: unvisited k-quads of the current word, inside [ks, ke)
@@ -1136,7 +1158,12 @@ template <int QW, int NA, int NW, bool ZS>
 __global__ __launch_bounds__(64 * MAX_WAVES) void k_bitmm(qgtc_problem pr, MMShape sh, int tiles_m,
                                                           int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    // pull every kernel argument into SGPRs with ONE scalar-load round trip (hipcc otherwise loads
+    // them lazily in four dependent rounds, ~200 cycles each, ahead of the first global load)
+    asm volatile("" ::"s"(pr.X), "s"(pr.W), "s"(pr.out), "s"(pr.x_words), "s"(pr.w_words), "s"(pr.M), "s"(pr.K),
+                 "s"(pr.N), "s"(pr.w_lines), "s"(sh.a), "s"(sh.w), "s"(sh.ob), "s"(sh.mode), "s"(sh.per),
+                 "s"(sh.inv_tiles_n), "s"(sh.waves), "s"(tiles_m), "s"(tiles_n));
+    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     // tile / tiles_n by multiply-high with floor(2^32 / tiles_n) (from the host) + one correction
     int tm = static_cast<int>(__umulhi(static_cast<uint32_t>(tile), sh.inv_tiles_n));
     int tn = tile - tm * tiles_n;
@@ -1144,11 +1171,11 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void k_bitmm(qgtc_problem pr, MMSha
         tn -= tiles_n;
         tm++;
     }
-    mm_tile<QW, NA, NW, ZS>(pr, sh, tm, tn, tiles_m, tiles_n, smem);
+    mm_tile<QW, NA, NW, ZS, false>(pr, sh, tm, tn, tiles_m, tiles_n, smem);
 }
 
 // grouped launch: blockIdx.y = problem, blockIdx.x = tile (surplus tiles exit at once)
-template <int QW, int NA, int NW, bool ZS>
+template <int QW, int NA, int NW, bool ZS, bool OCC>
 __global__ __launch_bounds__(64 * MAX_WAVES) void k_bitmm_batched(const qgtc_problem *__restrict__ prs,
                                                                   MMShape sh) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1156,7 +1183,7 @@ __global__ __launch_bounds__(64 * MAX_WAVES) void k_bitmm_batched(const qgtc_pro
     const int tiles_m = (pr.M + TM - 1) / TM, tiles_n = (pr.N + TN - 1) / TN;
     const int tile = blockIdx.x;
     if (tile >= tiles_m * tiles_n) return;
-    mm_tile<QW, NA, NW, ZS>(pr, sh, tile / tiles_n, tile % tiles_n, tiles_m, tiles_n, smem);
+    mm_tile<QW, NA, NW, ZS, OCC>(pr, sh, tile / tiles_n, tile % tiles_n, tiles_m, tiles_n, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1181,6 +1208,7 @@ inline void plan_split(int K, int planes, int qw, long total_tiles, Plan *pl) {
     const int per = (kq + static_cast<int>(want) - 1) / static_cast<int>(want);
     pl->sh.per = per;
     pl->waves = (kq + per - 1) / per;
+    pl->sh.waves = pl->waves;
     // every wave's staging region, then every wave's partial-sum slab (separate, so that a wave
     // can store its slab while others are still multiplying); single-wave workgroups need no slab
     pl->lds = pl->waves * (region_bytes(planes, qw) + (pl->waves > 1 ? SLAB_BYTES : 0));
@@ -1216,17 +1244,17 @@ int launch_single(const qgtc_problem &pr, const Plan &pl, hipStream_t st) {
     return QGTC_OK;
 }
 
-template <int QW, int NA, int NW, bool ZS>
+template <int QW, int NA, int NW, bool ZS, bool OCC>
 int launch_batched(const qgtc_problem *prs, int count, int max_M, int max_N, const Plan &pl,
                    hipStream_t st) {
     const int tiles = ((max_M + TM - 1) / TM) * ((max_N + TN - 1) / TN);
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_batched<QW, NA, NW, ZS>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_batched<QW, NA, NW, ZS, OCC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_bitmm_batched<QW, NA, NW, ZS>), dim3(tiles, count), dim3(64 * pl.waves),
+    hipLaunchKernelGGL((k_bitmm_batched<QW, NA, NW, ZS, OCC>), dim3(tiles, count), dim3(64 * pl.waves),
                        pl.lds, st, prs, pl.sh);
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
@@ -1267,13 +1295,13 @@ int dispatch_single(const qgtc_problem &pr, int K, int a, int w, int ob, int mod
     });
 }
 
-template <bool ZS>
+template <bool ZS, bool OCC>
 int dispatch_batched(const qgtc_problem *prs, int count, int max_M, int max_N, int K_hint, int a,
                      int w, int ob, int mode, hipStream_t st) {
     Plan pl;
     const long tiles = static_cast<long>(count) * ((max_M + TM - 1) / TM) * ((max_N + TN - 1) / TN);
     return with_kernel<ZS>(a, w, K_hint, ob, mode, tiles, &pl, [&](auto qw, auto na, auto nw) {
-        return launch_batched<decltype(qw)::value, decltype(na)::value, decltype(nw)::value, ZS>(
+        return launch_batched<decltype(qw)::value, decltype(na)::value, decltype(nw)::value, ZS, OCC>(
             prs, count, max_M, max_N, pl, st);
     });
 }
@@ -1475,11 +1503,12 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
     // K is per problem; the split-K factor and chunk size are chosen for the longest K. Any
     // choice is correct; this only affects speed.
     const int k_hint = max_K;
+    const int ob_ = mode == 2 ? 1 : output_bit;
     if (flags & QGTC_NO_ZERO_SKIP)
-        return dispatch_batched<false>(problems, count, max_M, max_N, k_hint, bit1, bit2,
-                                       mode == 2 ? 1 : output_bit, mode, st);
-    return dispatch_batched<true>(problems, count, max_M, max_N, k_hint, bit1, bit2,
-                                  mode == 2 ? 1 : output_bit, mode, st);
+        return dispatch_batched<false, false>(problems, count, max_M, max_N, k_hint, bit1, bit2, ob_, mode, st);
+    if (flags & QGTC_ZERO_JUMP)  // the descriptors carry occupancy bitmaps (qgtc_tile_occupancy)
+        return dispatch_batched<true, true>(problems, count, max_M, max_N, k_hint, bit1, bit2, ob_, mode, st);
+    return dispatch_batched<true, false>(problems, count, max_M, max_N, k_hint, bit1, bit2, ob_, mode, st);
 }
 
 size_t qgtc_occupancy_words(int M, int K) {

@@ -313,6 +313,8 @@ struct BatchedGemm {
     std::vector<torch::Tensor> keep;  // operands + outputs kept alive
     std::vector<torch::Tensor> outs;
     int count = 0, max_M = 0, max_K = 0, max_N = 0, bit1 = 1, bit2 = 1, ob = 1, mode = 0;
+    bool jump = false;
+    double occupied_fraction = 1.0;  // of the left operands' 32-row x 128-bit tiles (when zero_jump was asked for)
 
     // Xs[i]: rows-layout left operand of problem i; Ws: one shared right operand (len 1) or one
     // per problem; dims[i] = (M, K, N). mode 0/1/2 as qgtc_bitmm_batched; pad_128 only for mode 2.
@@ -323,7 +325,7 @@ struct BatchedGemm {
     BatchedGemm(std::vector<torch::Tensor> Xs, std::vector<torch::Tensor> Ws,
                 std::vector<std::tuple<int, int, int>> dims, int bit1_, int bit2_, int ob_,
                 int mode_, bool pad_128, bool zero_jump)
-        : bit1(bit1_), bit2(bit2_), ob(ob_), mode(mode_) {
+        : bit1(bit1_), bit2(bit2_), ob(ob_), mode(mode_), jump(zero_jump) {
         count = static_cast<int>(Xs.size());
         TORCH_CHECK(count > 0, "empty batch");
         TORCH_CHECK(Ws.size() == 1 || static_cast<int>(Ws.size()) == count, "Ws must have 1 or len(Xs) tensors");
@@ -383,6 +385,31 @@ struct BatchedGemm {
             keep.push_back(W);
             outs.push_back(out);
         }
+        if (zero_jump) {
+            // Jumping pays when most X tiles are empty (block-diagonal cluster adjacency); on a dense
+            // operand the bitmap only adds a dependent scalar load ahead of every tile's first loads.
+            // Decide once, here: keep the bitmaps only if under a quarter of the tiles are occupied (measured: at 19 % jumping
+            // gains 10 %, at 43 % it loses 15 %).
+            double set = 0.0, all = 0.0;
+            for (size_t i = 0; i < keep.size(); i++) {
+                if (keep[i].scalar_type() != torch::kInt64) continue;
+                auto bytes = keep[i].view(torch::kUInt8).to(torch::kInt32);
+                // popcount of a byte via the 4-bit nibble counts
+                auto lo = bytes.bitwise_and(15), hi = bytes.div(16, "floor");
+                auto lut = torch::tensor({0, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4},
+                                         torch::TensorOptions().dtype(torch::kInt32).device(dev));
+                set += (lut.index({lo.to(torch::kInt64)}).sum() + lut.index({hi.to(torch::kInt64)}).sum()).item<double>();
+            }
+            for (int i = 0; i < count; i++) all += static_cast<double>(S128(h[i].K)) * ((h[i].M + 31) / 32);
+            occupied_fraction = all > 0.0 ? set / all : 1.0;
+            if (occupied_fraction > 0.25) {
+                jump = false;
+                for (int i = 0; i < count; i++) {
+                    h[i].occ = nullptr;
+                    h[i].occ_words = 0;
+                }
+            }
+        }
         auto host = torch::empty({static_cast<int64_t>(count * sizeof(qgtc_problem))},
                                  torch::TensorOptions().dtype(torch::kUInt8));
         std::memcpy(host.data_ptr(), h.data(), count * sizeof(qgtc_problem));
@@ -392,8 +419,8 @@ struct BatchedGemm {
     void run() {
         c10::DeviceGuard guard(descs.device());
         check_rc(qgtc_bitmm_batched(reinterpret_cast<const qgtc_problem *>(descs.data_ptr()), count,
-                                    max_M, max_K, max_N, bit1, bit2, ob, mode, mm_flags(),
-                                    current_stream(descs)),
+                                    max_M, max_K, max_N, bit1, bit2, ob, mode,
+                                    mm_flags() | (jump ? QGTC_ZERO_JUMP : 0u), current_stream(descs)),
                  "BatchedGemm.run");
     }
 };
@@ -470,5 +497,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
              py::arg("zero_jump") = false)
         .def("run", &BatchedGemm::run)
         .def_readonly("outs", &BatchedGemm::outs)
-        .def_readonly("count", &BatchedGemm::count);
+        .def_readonly("count", &BatchedGemm::count)
+        .def_readonly("zero_jump", &BatchedGemm::jump)
+        .def_readonly("occupied_fraction", &BatchedGemm::occupied_fraction);
 }

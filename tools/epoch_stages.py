@@ -35,3 +35,4 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 print(f"epoch ({chain}, {'GIN' if gin else 'GCN'}): {e0.elapsed_time(e1) * 1e3 / 20:8.1f} us")
+print("zero-jump per stage:", [(g.zero_jump, round(g.occupied_fraction, 3)) for g in plan.stages])
