@@ -265,3 +265,46 @@ def np_requant(c, ob):
     val = np.where(val > maxv, maxv - np.float32(1.0), val)
     val = np.where(val < 0, np.float32(1.0), val)
     return np.trunc(val.astype(np.float64)).astype(np.int64).clip(max=2 ** 31 - 1).astype(np.int32)
+
+
+# ======================================================================================
+# Restatements of the paths beside the bit-GEMM (test infrastructure, like everything here)
+# ======================================================================================
+def np_dense_adjacency(row, col, H, W):
+    """The dense float matrix the reference builds from a batch's edge list:
+    torch.sparse.FloatTensor(i, v, [n, n]).to_dense() with v = 1 sums duplicate edges
+    (sampler.py:80-89)."""
+    A = np.zeros((H, W), dtype=np.float32)
+    np.add.at(A, (np.asarray(row, dtype=np.int64), np.asarray(col, dtype=np.int64)), 1.0)
+    return A
+
+
+def np_pack_edges(row, col, H, W, nbits):
+    """What QGTC.val2bit(dense adjacency, nbits, False, False) yields (sampler.py:98/101), computed
+    from the edge list: cell value = multiplicity, quantised by Quantize_val (kernel.h:39-44,49-71),
+    packed in the rows layout (kernel.h:204-242)."""
+    return np_pack_rows(np_quantize(np_dense_adjacency(row, col, H, W), nbits), nbits).reshape(-1)
+
+
+def np_tile_occupancy(X_words, M, K, a, tile_rows=32):
+    """Occupancy bitmap of a rows-layout operand with `a` planes: bit q of word [tile][q // 64] is
+    set when rows tile_rows*tile .. +tile_rows-1, packed words 4q .. 4q+3 hold a set bit in any
+    plane. This is the build's own zero-tile unit (32 rows x 128 bits); the reference's counter
+    kernel tests 8 x 128-bit tiles (kernel.h:574-592) - same idea, same 128-bit k step."""
+    kq = S128(K)
+    planes = np.ascontiguousarray(X_words).view(np.uint32).reshape(a, P8(M), kq * 4)
+    tiles, ow = (M + tile_rows - 1) // tile_rows, (kq + 63) // 64
+    occ = np.zeros((tiles, ow), dtype=np.uint64)
+    for t in range(tiles):
+        blk = planes[:, tile_rows * t:min(tile_rows * (t + 1), M), :].reshape(a, -1, kq, 4)
+        for q in np.nonzero((blk != 0).any(axis=(0, 1, 3)))[0]:
+            occ[t, q // 64] |= np.uint64(1) << np.uint64(q % 64)
+    return occ.reshape(-1)
+
+
+def np_i8gemm(A, Bt):
+    """The INT8 comparison GEMM (cuBLASGemmEX/cublas_main.cu:123-172: CUDA_R_8I operands,
+    CUDA_R_32F result): C[M,N] = A[M,K] x B[K,N] with B given as Bt[N,K]; exact integer sum,
+    then the int32 -> float32 conversion the device epilogue performs."""
+    acc = np.asarray(A, dtype=np.int64) @ np.asarray(Bt, dtype=np.int64).T
+    return acc.astype(np.int32).astype(np.float32)

@@ -9,10 +9,7 @@ from helpers import to_np_u32
 pytestmark = pytest.mark.gpu
 
 
-def _dense_from_edges(row, col, H, W):
-    A = np.zeros((H, W), dtype=np.float32)
-    np.add.at(A, (row, col), 1.0)      # duplicates sum, like to_dense() in sampler.py:87-89
-    return A
+from oracle.qgtc_oracle import np_dense_adjacency, np_i8gemm, np_pack_edges, np_tile_occupancy
 
 
 @pytest.mark.parametrize("H,W,nbits,edges,dup", [
@@ -28,8 +25,9 @@ def test_pack_edges_equals_val2bit_of_the_dense_adjacency(qgtc, oracle, H, W, nb
         extra_r = np.concatenate([row[:20]] * 1 + [row[20:30]] * 2 + [row[30:35]] * 4)
         extra_c = np.concatenate([col[:20]] * 1 + [col[20:30]] * 2 + [col[30:35]] * 4)
         row, col = np.concatenate([row, extra_r]), np.concatenate([col, extra_c])
-    A = _dense_from_edges(row, col, H, W)
+    A = np_dense_adjacency(row, col, H, W)
     want = oracle.val2bit(A, nbits, False, False)
+    np.testing.assert_array_equal(want, np_pack_edges(row, col, H, W, nbits))
     got = qgtc.pack_edges(torch.from_numpy(row).cuda(), torch.from_numpy(col).cuda(), H, W, nbits)
     assert tuple(got.shape) == (nbits * ((H + 7) // 8 * 8), (W + 127) // 128 * 4)
     np.testing.assert_array_equal(to_np_u32(got), want)
@@ -53,8 +51,7 @@ def test_i8gemm_is_exact(qgtc, M, K, N):
     rng = np.random.default_rng(M + K + N)
     A = rng.integers(-128, 128, size=(M, K), dtype=np.int64).astype(np.int8)
     Bt = rng.integers(-128, 128, size=(N, K), dtype=np.int64).astype(np.int8)
-    # asymmetric, exact integer reference (int64 accumulate, then the int32 -> float32 conversion)
-    want = (A.astype(np.int64) @ Bt.astype(np.int64).T).astype(np.int32).astype(np.float32)
+    want = np_i8gemm(A, Bt)   # exact integer reference, then the int32 -> float32 conversion
     got = qgtc.i8gemm(torch.from_numpy(A).cuda(), torch.from_numpy(Bt).cuda())
     assert got.dtype == torch.float32 and tuple(got.shape) == (M, N)
     np.testing.assert_array_equal(got.cpu().numpy(), want)
@@ -102,22 +99,6 @@ def test_sampler_edge_route_equals_dense_route(qgtc):
         assert torch.equal(a, b)
 
 
-def _np_occupancy(X_words, M, K, a):
-    """bit q of word [tile][q // 64]: any set bit in rows 32*tile..+31, words 4q..4q+3, any plane."""
-    kq = (K + 127) // 128
-    rows_pad = (M + 7) // 8 * 8
-    planes = X_words.reshape(a, rows_pad, kq * 4)
-    tiles = (M + 31) // 32
-    ow = (kq + 63) // 64
-    occ = np.zeros((tiles, ow), dtype=np.uint64)
-    for t in range(tiles):
-        blk = planes[:, 32 * t:min(32 * t + 32, M), :].reshape(a, -1, kq, 4)
-        nz = (blk != 0).any(axis=(0, 1, 3))
-        for q in np.nonzero(nz)[0]:
-            occ[t, q // 64] |= np.uint64(1) << np.uint64(q % 64)
-    return occ.reshape(-1)
-
-
 @pytest.mark.parametrize("M,K,a,density", [(100, 1000, 1, 0.002), (1213, 1213, 1, 0.0005), (70, 9000, 2, 0.0003),
                                            (33, 130, 3, 0.5), (64, 128, 1, 0.0)])
 def test_tile_occupancy_bitmap(qgtc, oracle, M, K, a, density):
@@ -128,7 +109,7 @@ def test_tile_occupancy_bitmap(qgtc, oracle, M, K, a, density):
     X = oracle.pack(qx, a, False)
     dX = to_dev(torch, X, (a * ((M + 7) // 8 * 8), (K + 127) // 128 * 4))
     got = qgtc.tile_occupancy(dX, M, K, a).cpu().numpy().view(np.uint64)
-    np.testing.assert_array_equal(got, _np_occupancy(X, M, K, a))
+    np.testing.assert_array_equal(got, np_tile_occupancy(X, M, K, a))
 
 
 @pytest.mark.parametrize("a,w,ob", [(1, 2, 2), (1, 1, 1), (2, 2, 3), (3, 5, 4)])
