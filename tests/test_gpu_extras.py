@@ -145,3 +145,31 @@ def test_zero_jump_products_are_identical(qgtc, oracle, a, w, ob, mode):
             else:
                 np.testing.assert_array_equal(to_np_u32(bg.outs[i]),
                                               oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob, col=(mode == 1)))
+
+
+def test_gcnconv_qnt_module_matches_integer_reference(qgtc, oracle):
+    """qgtc_ppopp22_amd/conv.py (the working QGTC_conv.py): two quantised layers against integer
+    NumPy on the quantised values, with dense and edge-list adjacency."""
+    import torch
+    from oracle.qgtc_oracle import np_quantize, np_requant
+    from qgtc_ppopp22_amd.conv import GCNConv_Qnt
+
+    torch.manual_seed(3)
+    rng = np.random.default_rng(3)
+    n, F, H, C, wb, ab = 150, 40, 24, 7, 2, 3
+    row, col = rng.integers(0, n, size=900), rng.integers(0, n, size=900)
+    A = np_dense_adjacency(row, col, n, n)
+    X = (rng.standard_normal((n, F)) * 3).astype(np.float32)
+    model = GCNConv_Qnt(F, H, C, w_bit=wb, act_bit=ab).cuda()
+    out_dense = model(torch.from_numpy(A).cuda(), torch.from_numpy(X).cuda())
+    out_edges = model((torch.from_numpy(row).cuda(), torch.from_numpy(col).cuda(), n), torch.from_numpy(X).cuda())
+    assert torch.equal(out_dense, out_edges)
+
+    low = lambda q, b: (q.astype(np.int64) & ((1 << b) - 1))          # only bits 0..b-1 are packed
+    qA, qX = low(np_quantize(A, 1), 1), low(np_quantize(X, ab), ab)
+    qWi = low(np_quantize(model.W_in.detach().cpu().numpy(), wb), wb)
+    qWo = low(np_quantize(model.W_out.detach().cpu().numpy(), wb), wb)
+    rq = lambda c: low(np_requant(c.astype(np.int32), ab), ab)
+    h = rq(qA @ rq(qX @ qWi))
+    want = (qA @ rq(h @ qWo)).astype(np.float32)
+    np.testing.assert_array_equal(out_dense.cpu().numpy(), want)
