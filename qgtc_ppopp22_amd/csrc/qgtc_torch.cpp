@@ -312,6 +312,7 @@ struct BatchedGemm {
     torch::Tensor descs;  // uint8 device tensor holding qgtc_problem[count]
     std::vector<torch::Tensor> keep;  // operands + outputs kept alive
     std::vector<torch::Tensor> outs;
+    std::vector<torch::Tensor> occs;  // occupancy bitmaps of the left operands (zero_jump)
     int count = 0, max_M = 0, max_K = 0, max_N = 0, bit1 = 1, bit2 = 1, ob = 1, mode = 0;
     bool jump = false;
     double occupied_fraction = 1.0;  // of the left operands' 32-row x 128-bit tiles (when zero_jump was asked for)
@@ -324,7 +325,7 @@ struct BatchedGemm {
     // stage that change between runs.
     BatchedGemm(std::vector<torch::Tensor> Xs, std::vector<torch::Tensor> Ws,
                 std::vector<std::tuple<int, int, int>> dims, int bit1_, int bit2_, int ob_,
-                int mode_, bool pad_128, bool zero_jump)
+                int mode_, bool pad_128, bool zero_jump, std::vector<torch::Tensor> reuse_occs)
         : bit1(bit1_), bit2(bit2_), ob(ob_), mode(mode_), jump(zero_jump) {
         count = static_cast<int>(Xs.size());
         TORCH_CHECK(count > 0, "empty batch");
@@ -369,14 +370,22 @@ struct BatchedGemm {
             h[i].occ_words = 0;
             if (zero_jump) {
                 const int64_t nw = static_cast<int64_t>(qgtc_occupancy_words(M, K));
-                auto occ = torch::empty({nw}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
-                check_rc(qgtc_tile_occupancy(words(X), X.numel(), M, K, bit1,
-                                             reinterpret_cast<uint64_t *>(occ.data_ptr<int64_t>()), nw,
-                                             current_stream(X)),
-                         "BatchedGemm (tile occupancy)");
+                torch::Tensor occ;
+                if (!reuse_occs.empty()) {  // bitmaps of the same left operands from an earlier BatchedGemm
+                    TORCH_CHECK(static_cast<int>(reuse_occs.size()) == count, "occs must have len(Xs) tensors");
+                    occ = reuse_occs[i];
+                    TORCH_CHECK(occ.is_cuda() && occ.is_contiguous() && occ.scalar_type() == torch::kInt64 &&
+                                occ.numel() >= nw && occ.device() == dev, "bad occupancy bitmap");
+                } else {
+                    occ = torch::empty({nw}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
+                    check_rc(qgtc_tile_occupancy(words(X), X.numel(), M, K, bit1,
+                                                 reinterpret_cast<uint64_t *>(occ.data_ptr<int64_t>()), nw,
+                                                 current_stream(X)),
+                             "BatchedGemm (tile occupancy)");
+                }
                 h[i].occ = reinterpret_cast<const uint64_t *>(occ.data_ptr<int64_t>());
                 h[i].occ_words = (S128(K) + 63) / 64;
-                keep.push_back(occ);
+                occs.push_back(occ);
             }
             max_M = std::max(max_M, M);
             max_K = std::max(max_K, K);
@@ -390,15 +399,23 @@ struct BatchedGemm {
             // operand the bitmap only adds a dependent scalar load ahead of every tile's first loads.
             // Decide once, here: keep the bitmaps only if under a quarter of the tiles are occupied (measured: at 19 % jumping
             // gains 10 %, at 43 % it loses 15 %).
+            // one popcount over all bitmaps (a handful of elementwise kernels, one host sync)
             double set = 0.0, all = 0.0;
-            for (size_t i = 0; i < keep.size(); i++) {
-                if (keep[i].scalar_type() != torch::kInt64) continue;
-                auto bytes = keep[i].view(torch::kUInt8).to(torch::kInt32);
-                // popcount of a byte via the 4-bit nibble counts
-                auto lo = bytes.bitwise_and(15), hi = bytes.div(16, "floor");
-                auto lut = torch::tensor({0, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4},
-                                         torch::TensorOptions().dtype(torch::kInt32).device(dev));
-                set += (lut.index({lo.to(torch::kInt64)}).sum() + lut.index({hi.to(torch::kInt64)}).sum()).item<double>();
+            {
+                std::vector<torch::Tensor> flat;
+                for (auto &o : occs) flat.push_back(o.view({-1}));
+                auto x = torch::cat(flat);  // int64 words; SWAR popcount on the two's-complement bits
+                const int64_t m1 = 0x5555555555555555LL, m2 = 0x3333333333333333LL, m4 = 0x0f0f0f0f0f0f0f0fLL;
+                auto lsr = [](const torch::Tensor &t, int s) {  // logical shift right of int64
+                    return t.bitwise_right_shift(s).bitwise_and(static_cast<int64_t>((~0ULL) >> s));
+                };
+                x = x - lsr(x, 1).bitwise_and(m1);
+                x = x.bitwise_and(m2) + lsr(x, 2).bitwise_and(m2);
+                x = (x + lsr(x, 4)).bitwise_and(m4);
+                x = x + lsr(x, 8);
+                x = x + lsr(x, 16);
+                x = (x + lsr(x, 32)).bitwise_and(127);
+                set = x.sum().item<double>();
             }
             for (int i = 0; i < count; i++) all += static_cast<double>(S128(h[i].K)) * ((h[i].M + 31) / 32);
             occupied_fraction = all > 0.0 ? set / all : 1.0;
@@ -491,10 +508,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
 
     py::class_<BatchedGemm>(m, "BatchedGemm")
         .def(py::init<std::vector<torch::Tensor>, std::vector<torch::Tensor>,
-                      std::vector<std::tuple<int, int, int>>, int, int, int, int, bool, bool>(),
+                      std::vector<std::tuple<int, int, int>>, int, int, int, int, bool, bool,
+                      std::vector<torch::Tensor>>(),
              py::arg("Xs"), py::arg("Ws"), py::arg("dims"), py::arg("bit1"), py::arg("bit2"),
              py::arg("output_bit"), py::arg("mode") = 0, py::arg("pad_128") = false,
-             py::arg("zero_jump") = false)
+             py::arg("zero_jump") = false, py::arg("occs") = std::vector<torch::Tensor>())
+        .def_readonly("occs", &BatchedGemm::occs)
         .def("run", &BatchedGemm::run)
         .def_readonly("outs", &BatchedGemm::outs)
         .def_readonly("count", &BatchedGemm::count)

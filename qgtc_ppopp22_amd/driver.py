@@ -144,7 +144,17 @@ class BatchedEpoch:
         bitX = [c.bit_X for c in cts]
         n = [p[0] for p in params]
         F = params[0][3]
-        BG = Q.BatchedGemm
+        BGraw = Q.BatchedGemm
+        occ_cache = {}
+
+        def BG(Xs, Ws, dims_, b1, b2, ob_, mode, pad128, zero_jump=False):
+            # the adjacency's occupancy bitmaps are computed by the first A-stage and shared by the rest
+            if zero_jump and "A" in occ_cache:
+                return BGraw(Xs, Ws, dims_, b1, b2, ob_, mode, pad128, True, occ_cache["A"])
+            g = BGraw(Xs, Ws, dims_, b1, b2, ob_, mode, pad128, zero_jump)
+            if zero_jump:
+                occ_cache["A"] = g.occs
+            return g
 
         def dims(k, c):  # (M=n_i, K=k or n_i, N=c)
             return [(ni, ni if k is None else k, c) for ni in n]
