@@ -69,6 +69,10 @@ MM_CASES = [
     (129, 513, 100, 3, 2, 5), (40, 200, 10, 4, 4, 4), (300, 300, 128, 1, 8, 8), (70, 640, 33, 8, 8, 8),
     (1213, 1213, 128, 1, 2, 2), (1213, 128, 128, 2, 2, 2), (599, 599, 50, 1, 4, 4), (599, 64, 10, 4, 4, 4),
     (257, 9000, 40, 1, 1, 3), (31, 70, 200, 2, 1, 1), (16, 128, 130, 5, 7, 6),
+    # more planes than the generic kernel stages at once (8 x 8 plane blocks, k iteration restarts)
+    (20, 300, 40, 9, 12, 4), (33, 130, 20, 17, 3, 8), (8, 128, 8, 10, 10, 12),
+    # single-wave, 2-3 wave and 4-7 wave workgroups of the fixed kernels
+    (64, 256, 64, 1, 1, 1), (64, 384, 64, 1, 2, 2), (40, 700, 33, 2, 2, 2), (50, 900, 70, 4, 4, 3),
 ]
 
 
