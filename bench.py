@@ -41,8 +41,8 @@ VALU_PEAK_BITOPS = 4.2e13 * 32
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=200)
-    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--steps", type=int, default=1000)
+    p.add_argument("--warmup", type=int, default=50)
     p.add_argument("--bits", type=int, default=1, help="feature bit width w of the headline workload")
     p.add_argument("--no-extras", action="store_true", help="skip the width sweep / epoch / CPU legs")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget")
