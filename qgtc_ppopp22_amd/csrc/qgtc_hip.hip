@@ -587,80 +587,108 @@ __device__ __forceinline__ uint32_t tile_occupancy(const unsigned long long (&nz
 // first loads' latency, was measured: it shortens the tail by ~300 cycles but costs as much in the
 // prologue and 5 VGPRs across the main loop.)
 struct QuadPlan {
-    uint32_t src;     // byte offset of the quad inside a slab
-    uint32_t *dst;    // first output word (or float) of the quad
-    int nvalid;       // leading elements of the quad that exist (rows layout / float: columns; cols layout: rows)
-    uint32_t sh_n;    // shift of the quad's nibble inside the 32-bit word; bit 31: this lane stores the word
+    uint32_t src;     // byte offset of the thread's elements inside a slab
+    uint32_t *dst;    // first output word (or float) of the thread's elements
+    int nvalid;       // leading elements that exist (rows layout / float: columns; cols layout: rows)
+    uint32_t sh_n;    // shift of the thread's bits inside the 32-bit word; bit 31: this lane stores the word
 };
 
-template <int MODE>
+// OR over aligned groups of 32/E lanes (E = 4: 8 lanes, E = 2: 16 lanes = one DPP row)
+template <int E>
+__device__ __forceinline__ uint32_t or_reduce_group(uint32_t x) {
+    x = or_reduce8(x);
+    if (E == 2)  // 15 - lane within the row of 16: joins the two 8-lane halves
+        x |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x140, 0xf, 0xf, false));
+    return x;
+}
+
+// E consecutive elements per thread (E = 4: a quad, 256 threads finish a tile; E = 2: a pair, 512
+// threads - used by 8-wave workgroups so that every SIMD has two waves to interleave in the
+// latency-bound tail). Thread t = hi | a8 | lo | h with h the E-group inside the 8 columns (rows)
+// of micro-tile block (i, j); rows layout / float: (hi,lo) = (i,j), cols layout: (j,i).
+template <int MODE, int E>
 __device__ __forceinline__ QuadPlan quad_plan(const qgtc_problem &pr, int t, int m0, int n0) {
-    // quad t = hi<<6 | a8<<3 | lo<<1 | h ; rows layout / float: (hi,lo) = (i,j), cols layout: (j,i)
+    constexpr int HB = E == 4 ? 1 : 2;       // bits of h
+    constexpr int G = 32 / E;                // threads per output word
     const int M = pr.M, N = pr.N;
-    const int hi = (t >> 6) & 3, a8 = (t >> 3) & 7, lo = (t >> 1) & 3, h = t & 1;
+    const int h = t & ((1 << HB) - 1), lo = (t >> HB) & 3, a8 = (t >> (HB + 2)) & 7, hi = (t >> (HB + 5)) & 3;
     const int i = MODE == 1 ? lo : hi, j = MODE == 1 ? hi : lo;
     QuadPlan q;
-    q.src = static_cast<uint32_t>(((i * MC + j) * SLAB_PITCH + a8 * 8 + h * 4) * 4);
-    const int m = MODE == 1 ? m0 + 8 * i + 4 * h : m0 + a8 + 8 * i;
-    const int n = MODE == 1 ? n0 + a8 + 8 * j : n0 + 8 * j + 4 * h;
-    // valid elements of the quad: rows layout / float (m, n+q), cols layout (m+q, n)
-    q.nvalid = MODE == 1 ? (n < N ? min(max(M - m, 0), 4) : 0) : (m < M ? min(max(N - n, 0), 4) : 0);
+    q.src = static_cast<uint32_t>(((i * MC + j) * SLAB_PITCH + a8 * 8 + h * E) * 4);
+    const int m = MODE == 1 ? m0 + 8 * i + E * h : m0 + a8 + 8 * i;
+    const int n = MODE == 1 ? n0 + a8 + 8 * j : n0 + 8 * j + E * h;
+    // valid elements: rows layout / float (m, n+e), cols layout (m+e, n)
+    q.nvalid = MODE == 1 ? (n < N ? min(max(M - m, 0), E) : 0) : (m < M ? min(max(N - n, 0), E) : 0);
     // rows layout [ob][PAD8(M)][STEP128(N)*4] (reference kernel.h:357-389): word (m, n0/32);
     // cols layout [ob][PAD128(N)][STEP128(M)*4] (intended semantics of kernel.h:651-810): word (n, m0/32);
-    // float32 [M,N] (reference kernel.h:915-930): row m, columns n .. n+3
+    // float32 [M,N] (reference kernel.h:915-930): row m, columns n .. n+E-1
     const size_t o0 = MODE == 2 ? static_cast<size_t>(m) * N + n
                     : MODE == 0 ? static_cast<size_t>(m) * (step128(N) * 4) + (n0 >> 5)
                                 : static_cast<size_t>(n) * (step128(M) * 4) + (m0 >> 5);
     q.dst = static_cast<uint32_t *>(pr.out) + o0;
-    const bool store = (t & 7) == 0 && (MODE == 0 ? m < pad8(M) : n < pad128(N));
-    q.sh_n = static_cast<uint32_t>(28 - 4 * (t & 7)) | (store ? 0x80000000u : 0u);
+    const bool store = (t & (G - 1)) == 0 && (MODE == 0 ? m < pad8(M) : n < pad128(N));
+    // element e of the word's 32 sits at bit 31 - e; this thread holds e = E*(t % G) .. +E-1
+    q.sh_n = static_cast<uint32_t>(32 - E - E * (t & (G - 1))) | (store ? 0x80000000u : 0u);
     return q;
 }
 
-template <int MODE, bool INT_RQ, bool ALL8>
+template <int MODE, int E, bool INT_RQ, bool ALL8>
 __device__ __forceinline__ void quad_finish(const qgtc_problem &pr, const MMShape &sh, const QuadPlan &q,
-                                            int extra, size_t oplane, const unsigned char *slabs, int nwv) {
-    int4 part[MAX_WAVES];
+                                            int extra, size_t oplane, const unsigned char *slabs, int nwv STAMP_ARG) {
+    typedef int ivec __attribute__((ext_vector_type(E)));
+    ivec part[MAX_WAVES];
 #pragma unroll
     for (int k = 0; k < MAX_WAVES; k++)  // slabs that do not exist alias slab 0 and are masked
-        part[k] = *reinterpret_cast<const int4 *>(slabs + q.src + ((ALL8 || k < nwv) ? k : 0) * SLAB_BYTES);
-    int v[4] = {0, 0, 0, 0};
+        part[k] = *reinterpret_cast<const ivec *>(slabs + q.src + ((ALL8 || k < nwv) ? k : 0) * SLAB_BYTES);
+    int v[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) v[e] = 0;
 #pragma unroll
     for (int k = 0; k < MAX_WAVES; k++) {
         const bool on = ALL8 || k < nwv;
-        v[0] += on ? part[k].x : 0;
-        v[1] += on ? part[k].y : 0;
-        v[2] += on ? part[k].z : 0;
-        v[3] += on ? part[k].w : 0;
+#pragma unroll
+        for (int e = 0; e < E; e++) v[e] += on ? part[k][e] : 0;
     }
+#ifdef QGTC_STAMPS
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]));
+    STAMP(11);
+#endif
     if (MODE == 2) {
         float *dst = reinterpret_cast<float *>(q.dst);
-        if (q.nvalid == 4 && (pr.N & 3) == 0) {
-            *reinterpret_cast<float4 *>(dst) = make_float4(static_cast<float>(v[0]), static_cast<float>(v[1]),
-                                                           static_cast<float>(v[2]), static_cast<float>(v[3]));
+        if (q.nvalid == E && (pr.N & (E - 1)) == 0) {
+            typedef float fvec __attribute__((ext_vector_type(E)));
+            fvec f;
+#pragma unroll
+            for (int e = 0; e < E; e++) f[e] = static_cast<float>(v[e]);
+            *reinterpret_cast<fvec *>(dst) = f;
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; e++)
+            for (int e = 0; e < E; e++)
                 if (e < q.nvalid) dst[e] = static_cast<float>(v[e]);
         }
         return;
     }
     const int maxi = 1 << (sh.ob & 31);
-    uint32_t qv[4];
+    uint32_t qv[E];
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
+    for (int e = 0; e < E; e++) {
         int c;
         if (INT_RQ) c = v[e] < 0 ? 1 : (v[e] > maxi ? maxi - 1 : v[e]);  // kernel.h:31-37
         else c = requant(v[e], sh.maxv, sh.maxm1);
         qv[e] = e < q.nvalid ? static_cast<uint32_t>(c) : 0u;
     }
+#ifdef QGTC_STAMPS
+    asm volatile("" : "+v"(qv[0]), "+v"(qv[1]));
+    STAMP(12);
+#endif
     const bool store = (q.sh_n >> 31) != 0u;
-    const uint32_t sh_n = q.sh_n & 31u;  // element e of the 32 sits at bit 31 - e; this quad is e = 4*(t&7) .. +3
+    const uint32_t sh_n = q.sh_n & 31u;
     uint32_t *out = q.dst;
     for (int p = 0; p < sh.ob; p++, out += oplane) {
-        const uint32_t nib = (((qv[0] >> p) & 1u) << 3) | (((qv[1] >> p) & 1u) << 2) |
-                             (((qv[2] >> p) & 1u) << 1) | ((qv[3] >> p) & 1u);
-        const uint32_t word = or_reduce8(nib << sh_n);
+        uint32_t bits = 0u;
+#pragma unroll
+        for (int e = 0; e < E; e++) bits |= ((qv[e] >> p) & 1u) << (E - 1 - e);
+        const uint32_t word = or_reduce_group<E>(bits << sh_n);
 #ifndef QGTC_ABL_NOSTORE
         if (store) {
             out[0] = word;
@@ -770,14 +798,19 @@ __device__ __forceinline__ void epi_finish(const qgtc_problem &pr, const MMShape
     STAMP(9);
     const int extra = (MODE == 0 && last_n) ? step128(N) * 4 - (n0 >> 5) - 1 : 0;
     if (nwv == 1) {
-    } else if (nwv == MAX_WAVES && sh.ob <= 23) {  // one quad per thread, every slab exists
-        if (tid < 256) quad_finish<MODE, true, true>(pr, sh, quad_plan<MODE>(pr, tid, m0, n0), extra, oplane, slabs, nwv);
+    } else if (nwv == MAX_WAVES && sh.ob <= 23) {  // every slab exists: all 512 threads finish a pair each
+        const QuadPlan q = quad_plan<MODE, 2>(pr, tid, m0, n0);
+#ifdef QGTC_STAMPS
+        asm volatile("" ::"v"(q.src), "v"(q.dst), "v"(q.nvalid), "v"(q.sh_n));
+        STAMP(10);
+#endif
+        quad_finish<MODE, 2, true, true>(pr, sh, q, extra, oplane, slabs, nwv STAMP_PASS);
     } else {
         for (int t = tid; t < 256; t += NT) {
-            const QuadPlan q = quad_plan<MODE>(pr, t, m0, n0);
+            const QuadPlan q = quad_plan<MODE, 4>(pr, t, m0, n0);
             // float(c) > 2^ob  <=>  c > 2^ob for every int c >= 0: integer requantisation when ob <= 23
-            if (sh.ob > 23) quad_finish<MODE, false, false>(pr, sh, q, extra, oplane, slabs, nwv);
-            else quad_finish<MODE, true, false>(pr, sh, q, extra, oplane, slabs, nwv);
+            if (sh.ob > 23) quad_finish<MODE, 4, false, false>(pr, sh, q, extra, oplane, slabs, nwv STAMP_PASS);
+            else quad_finish<MODE, 4, true, false>(pr, sh, q, extra, oplane, slabs, nwv STAMP_PASS);
         }
     }
     STAMP(14);
@@ -1058,11 +1091,18 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
 #pragma unroll
                 for (int t = 0; t < T; t++) {
                     const int o = t / NW, pw = t % NW, kk = o / NA, pa = o % NA;
+#ifdef QGTC_ABL_NOLDS  // timing-only build: every step multiplies the first step's granules
+                    if (t == 0) {
+                        read_w(1, wg[1]);
+                        read_x(1, xg[1]);
+                    }
+#else
                     if (t + 1 < T) {
                         const int o1 = (t + 1) / NW, pw1 = (t + 1) % NW, kk1 = o1 / NA, pa1 = o1 % NA;
                         read_w(pw1 * QW + kk1, wg[(t + 1) & 1]);
                         if (pw1 == 0) read_x(pa1 * QW + kk1, xg[o1 & 1]);
                     }
+#endif
 #ifdef QGTC_ABL_NOMAC  // timing-only build: keep the LDS reads, skip the multiply
                     asm volatile("" ::"v"(xg[o & 1][0].x), "v"(wg[t & 1][0].x), "v"(xg[o & 1][3].w), "v"(wg[t & 1][3].w));
 #else
