@@ -7,7 +7,7 @@ TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-extras > $OUT/bench_under_trace.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-extras --steps 200 --warmup 20 > $OUT/bench_under_trace.json 2> $OUT/trace.err
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $GRAFT_REPO_ROOT/bench.py --no-extras --steps 50 --warmup 5 > $OUT/bench_under_$C.json 2> $OUT/pmc_$C.err
 done
