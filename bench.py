@@ -105,20 +105,25 @@ def cpu_baseline(M, K, N, w, A, X, budget_s):
             "sample": f"full {M}x{K}x{N} {w}-bit workload x {reps} reps ({dt:.1f} s, OpenMP C oracle)"}, ref
 
 
-def epoch_leg(Q, rank, world, device_index):
-    """Cluster-GCN epoch (BASELINE.json configs 3/5): ogbn-arxiv-sized synthetic graph, 75 batches,
-    2-bit, hidden 128; batches sharded round-robin over the ranks; per-batch launches (the
-    reference's structure) and grouped launches."""
+def epoch_leg(Q, rank, world, device_index, dataset="ogbn-arxiv", bits=2, hidden=128, gin=False, full=True):
+    """Epoch time (BASELINE.json configs 3/4/5): a synthetic graph of the dataset's size, 75 batches,
+    sharded round-robin over the ranks. Per-batch launches (the reference's structure: six extension
+    calls per batch), the same with the packed batches parked on the CPU and uploaded every iteration
+    (what main_qgtc.py:115 does), the same captured in a hipGraph, and grouped launches (one launch
+    per operator per epoch) of the reference's literal chain and of the layout-correct chain."""
     from qgtc_ppopp22_amd import dist as D, driver, graph as G
 
-    base = ["--dataset", "ogbn-arxiv", "--n-hidden", "128", "--n-classes", "10", "--bit_width", "2",
-            "--use_QGTC", "--gpu", str(device_index), "--quiet", "--n-epochs", "20"]
-    graph = G.make_graph("ogbn-arxiv", 1500)
+    base = ["--dataset", dataset, "--n-hidden", str(hidden), "--n-classes", "10", "--bit_width", str(bits),
+            "--use_QGTC", "--gpu", str(device_index), "--quiet", "--n-epochs", "20"] + (["--run_GIN"] if gin else [])
+    graph = G.make_graph(dataset, 1500)
     ids = D.shard_round_robin(1500 // 20, rank, world)
     res = {}
-    for name, extra in (("per_batch_reference_chain", []), ("per_batch_graph_reference_chain", ["--graph"]),
-                        ("batched_reference_chain", ["--batched"]),
-                        ("batched_correct_chain", ["--batched", "--chain", "correct"])):
+    legs = [("per_batch_reference_chain", []), ("batched_reference_chain", ["--batched"]),
+            ("batched_correct_chain", ["--batched", "--chain", "correct"])]
+    if full:
+        legs[1:1] = [("per_batch_nonresident_reference_chain", ["--non-resident"]),
+                     ("per_batch_graph_reference_chain", ["--graph"])]
+    for name, extra in legs:
         args = driver.build_parser().parse_args(base + extra)
         driver.run(args, Q=Q, batch_ids=ids, graph=graph)          # warm-up (allocator, attributes)
         D.barrier()
@@ -131,6 +136,29 @@ def epoch_leg(Q, rank, world, device_index):
         allsum = D.gather_batch_summaries(local, 1500 // 20, rank, world)
         res["gathered_batches"] = int(allsum.size(0))
     return res, graph
+
+
+# the reference's published effective TFLOPs (sm_86) for M=K, N, width
+REF_MICRO = {
+    (1024, 16): (5.847, 3.934, 2.488, 1.541), (2048, 16): (16.605, 10.086, 6.561, 3.483), (4096, 16): (40.627, 20.764, 12.409, 6.763),
+    (1024, 32): (11.724, 7.864, 4.456, 3.074), (2048, 32): (32.666, 19.762, 12.807, 6.816), (4096, 32): (35.032, 20.951, 13.929, 7.366),
+    (1024, 64): (23.219, 15.429, 10.683, 5.046), (2048, 64): (37.438, 25.055, 12.328, 6.165), (4096, 64): (46.768, 26.818, 14.196, 7.324),
+}
+
+
+def micro_bench_table(Q, device):
+    """The reference's whole micro-benchmark (2_7c_QGTC_GEMM_INT8.py: 9 shapes x widths 1/2/4/8, 200
+    launches per point between two events, all-ones inputs as there), best of 3."""
+    out = {}
+    for (mk, nn), ref in REF_MICRO.items():
+        row = {}
+        for wi, ww in enumerate((1, 2, 4, 8)):
+            _, _, ba, bx = make_workload(Q, mk, mk, nn, ww, device, seed=3, ones=True)
+            Q.profile(ba, bx, mk, mk, nn, 1, ww, ww, 20)
+            ms = min(Q.profile(ba, bx, mk, mk, nn, 1, ww, ww, 200) for _ in range(3))
+            row[f"w{ww}"] = {"TOPS": round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2), "ref_sm86": ref[wi]}
+        out[f"{mk}x{mk}x{nn}"] = row
+    return out
 
 
 def main():
@@ -244,8 +272,13 @@ def main():
                                               "ref_sm86_cublas_int8_TFLOPS": ref_cublas[(mk, nn)],
                                               "ref_sm86_qgtc_1bit_TFLOPs": ref_1bit[(mk, nn)]}
             extras["int8_mfma_vs_1bit_popcount_9_shapes"] = cmp9
+        if rank == 0 and world == 1:
+            extras["micro_bench_ones_9_shapes_x_4_widths"] = micro_bench_table(Q, device)
         ep, graph = epoch_leg(Q, rank, world, local)
         extras["cluster_gcn_epoch_ogbn_arxiv_shape"] = ep
+        # BASELINE.json configs[3]: Batched-GIN, ppi-sized graph, 4-bit weights/features, hidden 64 (0_7b's value)
+        ep_gin, _ = epoch_leg(Q, rank, world, local, dataset="ppi", bits=4, hidden=64, gin=True, full=False)
+        extras["batched_gin_epoch_ppi_shape_4bit"] = ep_gin
         if rank == 0 and world == 1:
             from oracle.dgl_cpu_baseline import graphsage_cpu_epoch
             from qgtc_ppopp22_amd import graph as G
