@@ -3,24 +3,17 @@
 // What is here (reference file:line each piece replaces is in include/qgtc.h):
 //   * fused quantise + bit-plane pack          (val2bit, rows and cols layouts)
 //   * bit-plane unpack                         (bit2val)
+//   * adjacency bit planes straight from an edge list (pack_edges), occupancy bitmaps
 //   * multi-plane 1-bit GEMM: AND + popcount (v_and_b32 / v_bcnt_u32_b32) with shift-accumulate
-//     into int32, in-workgroup split-K, zero-tile skipping, and a fused epilogue that either
-//     re-quantises and re-packs (rows / cols layout) or converts to float32
-//   * tile counters, the 200-rep profile loop, and a grouped (batched) launch.
+//     into int32, in-workgroup split-K, zero-tile skipping / jumping, and a fused epilogue that
+//     either re-quantises and re-packs (rows / cols layout) or converts to float32
+//   * tile counters, the 200-rep profile loop, a grouped (batched) launch
+//   * the int8 MFMA comparison GEMM.
 //
-// Design notes live in DESIGN.md; the short version of the GEMM kernel:
-//   - a workgroup owns a TM x TN output tile for the whole K range (no inter-workgroup
-//     reduction, so results are exact and order-independent); its WK waves split each staged
-//     K chunk among themselves and are summed through LDS at the end;
-//   - both operands are staged global -> LDS in 16-byte granules (= 128 bits of one packed
-//     row), laid out [plane][k-quad][row] so that the 8 distinct granules a wave reads per
-//     ds_read_b128 are contiguous (conflict-free) and the staging ds_write_b128 of 8
-//     consecutive k-quads hits 8 distinct 4-bank groups (row count padded to odd);
-//   - each lane keeps an R x C register micro-tile: per k-quad it reads R + C granules and
-//     issues R*C*4 v_and_b32 + v_bcnt_u32_b32 pairs;
-//   - while staging X the wave ballots "granule != 0" and ORs a per-k-quad occupancy bitmap
-//     into LDS; compute waves skip k-quads whose TM x 128-bit X tile is all zero (wave-uniform
-//     scalar branch, no divergence).
+// Design notes live in DESIGN.md; the short version of the bit-GEMM kernel is the comment block
+// above `mm_tile` ("the bit-GEMM"): 32 x 32 output tile per workgroup, waves split K and stream
+// their own operand slices (no barrier in the main loop), buffer loads with hardware range checks,
+// 4 x 4 register micro-tile per lane, one LDS reduction, DPP-packed epilogue.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
