@@ -1078,7 +1078,11 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
                 // flat software pipeline over every (k-quad, X plane, W plane) step of the stage:
                 // the granules of step t+1 are read from LDS while step t is multiplied
                 constexpr int T = NOUT * NW;
-                u32x4 xg[2][MR], wg[2][MC];
+                // X granules: double-buffered only when they change every step (NW == 1); with several W
+                // planes per X tile one set is enough (the next tile's X is read behind its last
+                // multiply) and 16 VGPRs fewer buy the (1,2) kernel a fourth wave per SIMD
+                constexpr int XB = NW == 1 ? 2 : 1;
+                u32x4 xg[XB][MR], wg[2][MC];
                 read_x(0, xg[0]);
                 read_w(0, wg[0]);
 #pragma unroll
@@ -1093,14 +1097,18 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
                     if (t + 1 < T) {
                         const int o1 = (t + 1) / NW, pw1 = (t + 1) % NW, kk1 = o1 / NA, pa1 = o1 % NA;
                         read_w(pw1 * QW + kk1, wg[(t + 1) & 1]);
-                        if (pw1 == 0) read_x(pa1 * QW + kk1, xg[o1 & 1]);
+                        if (XB == 2 && pw1 == 0) read_x(pa1 * QW + kk1, xg[o1 & 1]);
                     }
 #endif
 #ifdef QGTC_ABL_NOMAC  // timing-only build: keep the LDS reads, skip the multiply
-                    asm volatile("" ::"v"(xg[o & 1][0].x), "v"(wg[t & 1][0].x), "v"(xg[o & 1][3].w), "v"(wg[t & 1][3].w));
+                    asm volatile("" ::"v"(xg[o % XB][0].x), "v"(wg[t & 1][0].x), "v"(xg[o % XB][3].w), "v"(wg[t & 1][3].w));
 #else
-                    if ((occ[pa] >> kk) & 1u) mac_quad(acc[pa + pw], xg[o & 1], wg[t & 1]);
+                    if ((occ[pa] >> kk) & 1u) mac_quad(acc[pa + pw], xg[o % XB], wg[t & 1]);
 #endif
+                    if (XB == 1 && t + 1 < T && (t + 1) % NW == 0) {
+                        const int o1 = (t + 1) / NW;
+                        read_x((o1 % NA) * QW + o1 / NA, xg[0]);
+                    }
                 }
             } else {
                 // k-quads in a loop, the (X plane, W plane) steps of one k-quad unrolled
