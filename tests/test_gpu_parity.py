@@ -268,3 +268,40 @@ def test_batched_matches_single(qgtc, oracle):
             else:
                 np.testing.assert_array_equal(to_np_u32(bg.outs[i]),
                                               oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob, col=(mode == 1)))
+
+
+def test_random_shape_sweep(qgtc, oracle):
+    """Seeded random sweep over shapes, plane counts, output modes and both launch forms: catches
+    what the hand-picked cases miss (tile edges, wave counts, plane blocking, zero rows)."""
+    import torch
+    rng = np.random.default_rng(20260301)
+    singles = {0: lambda *a: qgtc.bitMM2Bit(*a), 1: lambda *a: qgtc.bitMM2Bit_col(*a)}
+    for case in range(70):
+        M = int(rng.integers(1, 180))
+        N = int(rng.integers(1, 150))
+        K = int(rng.choice([rng.integers(1, 130), rng.integers(130, 1100), rng.integers(1100, 5000)]))
+        a = int(rng.choice([1, 1, 1, 2, 2, 3, 4, 5, 8, 9]))
+        w = int(rng.choice([1, 2, 2, 3, 4, 4, 7, 8, 10]))
+        ob = int(rng.integers(1, 9))
+        mode = int(rng.integers(0, 3))
+        density = float(rng.choice([1.0, 0.3, 0.01]))
+        qx = rand_q(rng, M, K, a, density)
+        if case % 5 == 0:
+            qx[rng.integers(0, M)] = 0                       # an all-zero row
+        qw = rand_q(rng, K, N, w)
+        X, Wt = oracle.pack(qx, a, False), oracle.pack(qw, w, True)
+        dX, dW = to_dev(torch, X, rows_shape(M, K, a)), to_dev(torch, Wt, cols_shape(K, N, w))
+        tag = f"case {case}: M={M} K={K} N={N} a={a} w={w} ob={ob} mode={mode} density={density}"
+        if mode == 2:
+            want = oracle.bitmm2int(X, Wt, M, K, N, a, w, True)
+            got = qgtc.bitMM2Int(dX, dW, M, K, N, a, w, True).cpu().numpy()
+        else:
+            want = oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob, col=(mode == 1))
+            got = to_np_u32(singles[mode](dX, dW, M, K, N, a, w, ob))
+        np.testing.assert_array_equal(got, want, err_msg=tag)
+        # the grouped launch of the same product (with and without the occupancy bitmap)
+        for zj in (False, True):
+            bg = qgtc.BatchedGemm([dX], [dW], [(M, K, N)], a, w, ob, mode, True, zj)
+            bg.run()
+            got_b = bg.outs[0].cpu().numpy() if mode == 2 else to_np_u32(bg.outs[0])
+            np.testing.assert_array_equal(got_b, want, err_msg=tag + f" (grouped, zero_jump={zj})")
