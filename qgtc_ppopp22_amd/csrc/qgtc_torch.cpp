@@ -170,6 +170,44 @@ void bitMM2Bit_enqueue(torch::Tensor out, torch::Tensor bit_X1, torch::Tensor bi
                  "bitMM2Bit_enqueue");
 }
 
+// Enqueue `reps` INDEPENDENT bitMM2Bit launches round-robin on `outs.size()` HIP streams (launch i
+// writes outs[i % n]); the current stream waits for all of them. Cluster batches are independent,
+// so a serving loop may overlap their kernels: the head and tail of one launch run under the
+// multiply phase of another instead of being serialised by stream order.
+void bitMM2Bit_enqueue_streams(std::vector<torch::Tensor> outs, torch::Tensor bit_X1, torch::Tensor bit_X2,
+                               int M, int K, int N, int bit1, int bit2, int ob, int reps) {
+    CHECK_INPUT(bit_X1);
+    CHECK_INPUT(bit_X2);
+    check_bits_tensor(bit_X1, "bit_X1");
+    check_bits_tensor(bit_X2, "bit_X2");
+    TORCH_CHECK(!outs.empty() && reps > 0, "need at least one output buffer and one launch");
+    c10::DeviceGuard guard(bit_X1.device());
+    const int n = static_cast<int>(outs.size());
+    for (auto &o : outs) {
+        CHECK_INPUT(o);
+        check_bits_tensor(o, "out");
+    }
+    auto cur = c10::hip::getCurrentHIPStream(bit_X1.get_device());
+    static std::vector<c10::hip::HIPStream> pool;
+    while (static_cast<int>(pool.size()) < n) pool.push_back(c10::hip::getStreamFromPool(false, bit_X1.get_device()));
+    hipEvent_t ev;
+    TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+    TORCH_CHECK(hipEventRecord(ev, cur.stream()) == hipSuccess, "hipEventRecord failed");
+    for (int s = 0; s < n; s++) TORCH_CHECK(hipStreamWaitEvent(pool[s].stream(), ev, 0) == hipSuccess, "wait failed");
+    for (int i = 0; i < reps; i++) {
+        torch::Tensor &o = outs[i % n];
+        check_rc(qgtc_bitmm2bit(words(bit_X1), bit_X1.numel(), words(bit_X2), bit_X2.numel(), M, K, N, bit1,
+                                bit2, ob, words_mut(o), o.numel(), mm_flags(),
+                                static_cast<void *>(pool[i % n].stream())),
+                 "bitMM2Bit_enqueue_streams");
+    }
+    for (int s = 0; s < n; s++) {
+        TORCH_CHECK(hipEventRecord(ev, pool[s].stream()) == hipSuccess, "hipEventRecord failed");
+        TORCH_CHECK(hipStreamWaitEvent(cur.stream(), ev, 0) == hipSuccess, "wait failed");
+    }
+    (void)hipEventDestroy(ev);
+}
+
 torch::Tensor bitMM2Bit_profile(torch::Tensor bit_X1, torch::Tensor bit_X2, const int X1_height,
                                 const int X1_width, const int X2_width, const int bit1,
                                 const int bit2, const int output_bit) {
@@ -474,6 +512,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                         int ob, int reps) { return profile_impl(a, b, M, K, N, bit1, bit2, ob, reps).second; },
           "time `reps` bitMM2Bit launches; returns elapsed milliseconds (blocking)");
     m.def("last_profile_ms", [] { return g_last_profile_ms; });
+    m.def("bitMM2Bit_enqueue_streams", &bitMM2Bit_enqueue_streams,
+          "enqueue `reps` independent bitMM2Bit launches round-robin over len(outs) HIP streams (asynchronous)");
     m.def("bitMM2Bit_enqueue", &bitMM2Bit_enqueue,
           "enqueue `reps` bitMM2Bit launches into a preallocated output (asynchronous)");
     m.def("tile_counters", [](torch::Tensor x, int M, int K, int N, int bit1, int bit2) {
