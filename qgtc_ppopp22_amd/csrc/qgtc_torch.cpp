@@ -351,6 +351,7 @@ struct BatchedGemm {
     std::vector<torch::Tensor> keep;  // operands + outputs kept alive
     std::vector<torch::Tensor> outs;
     std::vector<torch::Tensor> occs;  // occupancy bitmaps of the left operands (zero_jump)
+    std::vector<qgtc_problem> host_descs;  // the same descriptors on the host, for run_per_problem()
     int count = 0, max_M = 0, max_K = 0, max_N = 0, bit1 = 1, bit2 = 1, ob = 1, mode = 0;
     bool jump = false;
     double occupied_fraction = 1.0;  // of the left operands' 32-row x 128-bit tiles (when zero_jump was asked for)
@@ -465,10 +466,47 @@ struct BatchedGemm {
                 }
             }
         }
+        host_descs = h;
         auto host = torch::empty({static_cast<int64_t>(count * sizeof(qgtc_problem))},
                                  torch::TensorOptions().dtype(torch::kUInt8));
         std::memcpy(host.data_ptr(), h.data(), count * sizeof(qgtc_problem));
         descs = host.to(dev);
+    }
+
+    // The reference's launch structure (one launch per cluster batch and operator) with the
+    // independent batches spread over `n_streams` HIP streams: batch i always runs on stream
+    // i % n_streams, so the stages of one batch stay ordered without any cross-stream dependency
+    // while kernels of different batches overlap. The current stream waits for all of them.
+    void run_per_problem(int n_streams) {
+        TORCH_CHECK(n_streams >= 1 && n_streams <= 32, "n_streams must be in 1..32");
+        c10::DeviceGuard guard(descs.device());
+        const int dev = descs.get_device();
+        auto cur = c10::hip::getCurrentHIPStream(dev);
+        static std::vector<c10::hip::HIPStream> pool;
+        while (static_cast<int>(pool.size()) < n_streams) pool.push_back(c10::hip::getStreamFromPool(false, dev));
+        hipEvent_t ev;
+        TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+        TORCH_CHECK(hipEventRecord(ev, cur.stream()) == hipSuccess, "hipEventRecord failed");
+        for (int s = 0; s < n_streams; s++)
+            TORCH_CHECK(hipStreamWaitEvent(pool[s].stream(), ev, 0) == hipSuccess, "wait failed");
+        for (int i = 0; i < count; i++) {
+            const qgtc_problem &p = host_descs[i];
+            void *st = static_cast<void *>(pool[i % n_streams].stream());
+            int rc;
+            if (mode == 2)
+                rc = qgtc_bitmm2int(p.X, p.x_words, p.W, p.w_words, p.M, p.K, p.N, bit1, bit2,
+                                    p.w_lines == P128(p.N), static_cast<float *>(p.out), outs[i].numel(), mm_flags(), st);
+            else
+                rc = qgtc_bitmm2bit(p.X, p.x_words, p.W, p.w_words, p.M, p.K, p.N, bit1, bit2, ob,
+                                    static_cast<uint32_t *>(p.out), outs[i].numel(),
+                                    mm_flags() | (mode == 1 ? QGTC_OUT_COLS : 0u), st);
+            check_rc(rc, "BatchedGemm.run_per_problem");
+        }
+        for (int s = 0; s < n_streams; s++) {
+            TORCH_CHECK(hipEventRecord(ev, pool[s].stream()) == hipSuccess, "hipEventRecord failed");
+            TORCH_CHECK(hipStreamWaitEvent(cur.stream(), ev, 0) == hipSuccess, "wait failed");
+        }
+        (void)hipEventDestroy(ev);
     }
 
     void run() {
@@ -555,6 +593,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
              py::arg("zero_jump") = false, py::arg("occs") = std::vector<torch::Tensor>())
         .def_readonly("occs", &BatchedGemm::occs)
         .def("run", &BatchedGemm::run)
+        .def("run_per_problem", &BatchedGemm::run_per_problem, py::arg("n_streams") = 1)
         .def_readonly("outs", &BatchedGemm::outs)
         .def_readonly("count", &BatchedGemm::count)
         .def_readonly("zero_jump", &BatchedGemm::jump)

@@ -13,6 +13,8 @@ Three ways to run the same math:
   the same as the reference's but the numbers are not A·X·W.
 * ``--chain correct``: the layout-correct chain (X·W re-packed in the cols layout by
   ``bitMM2Bit_col`` before A·(XW), as unitest.py:100-109 does).
+* ``--streams S``: the reference's launch structure (one launch per batch and operator), issued by the
+  extension with batch i on HIP stream i % S: independent batches overlap on the GPU.
 * ``--graph``: either chain with the reference's launch structure (6 calls per batch) captured in
   one hipGraph per epoch.
 * ``--batched``: either chain, with each of the six operators issued ONCE for all cluster batches
@@ -55,6 +57,9 @@ def build_parser() -> argparse.ArgumentParser:
     # additions
     p.add_argument("--chain", choices=["reference", "correct"], default="reference")
     p.add_argument("--batched", action="store_true", help="one grouped launch per operator per epoch")
+    p.add_argument("--streams", type=int, default=0,
+                   help="one launch per batch and operator (the reference's structure), batches spread over "
+                        "this many HIP streams by the extension (no Python in the loop)")
     p.add_argument("--graph", action="store_true",
                    help="capture the epoch's per-batch launches (6 x batches) in one hipGraph and replay it")
     p.add_argument("--non-resident", action="store_true",
@@ -197,6 +202,13 @@ class BatchedEpoch:
             g.run()
         return self.outs
 
+    def run_per_batch(self, n_streams: int):
+        """The same six operators, launched once per batch (450 launches for 75 batches), batch i on
+        stream i % n_streams."""
+        for g in self.stages:
+            g.run_per_problem(n_streams)
+        return self.outs
+
 
 # ---------------------------------------------------------------------------------------------
 def run(args, Q=None, batch_ids=None, graph=None):
@@ -235,11 +247,11 @@ def run(args, Q=None, batch_ids=None, graph=None):
             Q.bitMM2Bit_zerojump_cnt(ct.bit_A, t0, A0, A1, W["hidden"], 1, b, b)
         return {"avg_epoch_ms": float("nan"), "outs": [], "iter": it, "counters": Q.get_counters()}
 
-    if args.batched:
+    if args.batched or args.streams > 0:
         cts = [c.to(device) for c in it.cTensor_li]
         plan = BatchedEpoch(Q, cts, it.cluster_param_li, W, b, args.chain, args.run_GIN)
         for _ in range(args.n_epochs):
-            outs = plan.run()
+            outs = plan.run() if args.batched else plan.run_per_batch(args.streams)
     elif args.graph:
         # the reference's launch structure (six extension calls per batch), recorded once on a
         # side stream and replayed per epoch: the host issues ONE graph launch per epoch

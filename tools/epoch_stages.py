@@ -36,3 +36,16 @@ e1.record()
 torch.cuda.synchronize()
 print(f"epoch ({chain}, {'GIN' if gin else 'GCN'}): {e0.elapsed_time(e1) * 1e3 / 20:8.1f} us")
 print("zero-jump per stage:", [(g.zero_jump, round(g.occupied_fraction, 3)) for g in plan.stages])
+for S in (1, 2, 3, 4, 8):
+    for _ in range(2):
+        plan.run_per_batch(S)
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        plan.run_per_batch(S)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"per-batch launches on {S} stream(s): {e0.elapsed_time(e1) * 1e3 / 10:8.1f} us per epoch (host {1e6 * (time.perf_counter() - t0) / 10:8.1f} us)")
