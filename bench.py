@@ -45,6 +45,9 @@ def parse():
     p.add_argument("--warmup", type=int, default=50)
     p.add_argument("--bits", type=int, default=1, help="feature bit width w of the headline workload")
     p.add_argument("--no-extras", action="store_true", help="skip the width sweep / epoch / CPU legs")
+    p.add_argument("--streams", type=int, default=1,
+                   help="issue the steps round-robin on this many HIP streams (independent launches overlap); "
+                        "default 1 = the reference's metric, launches back to back on one stream")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget")
     return p.parse_args()
 
@@ -62,18 +65,23 @@ def make_workload(Q, M, K, N, w, device, seed, ones=False):
     return A, X, bit_A, bit_X
 
 
-def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier):
+def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams=1):
     """warmup untimed launches, then EXACTLY `steps` launches between barrier+synchronize pairs.
     Returns (wall seconds, mean kernel-stream time per launch in seconds from HIP events recorded
     on the stream the kernels are launched on)."""
-    Q.bitMM2Bit_enqueue(out, bit_A, bit_X, M, K, N, 1, w, w, max(warmup, 1))
+    if streams > 1:
+        outs = [out] + [torch.empty_like(out) for _ in range(streams - 1)]
+        enqueue = lambda n: Q.bitMM2Bit_enqueue_streams(outs, bit_A, bit_X, M, K, N, 1, w, w, n)  # noqa: E731
+    else:
+        enqueue = lambda n: Q.bitMM2Bit_enqueue(out, bit_A, bit_X, M, K, N, 1, w, w, n)  # noqa: E731
+    enqueue(max(warmup, 1))
     torch.cuda.synchronize()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record()
-    Q.bitMM2Bit_enqueue(out, bit_A, bit_X, M, K, N, 1, w, w, steps)
+    enqueue(steps)
     ev1.record()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -177,7 +185,7 @@ def main():
     N, w = 64, args.bits
     A, X, bit_A, bit_X = make_workload(Q, M, K, N, w, device, seed=3 + rank)
     out = Q.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w)
-    wall, kern = time_steps(Q, out, bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier)
+    wall, kern = time_steps(Q, out, bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams)
     wall_max = D.max_over_ranks(wall, device)
     eff_ops = 2.0 * M * K * N
     value = world * args.steps * eff_ops / wall_max / 1e12
@@ -213,7 +221,9 @@ def main():
         "dtype": "u32 bit-planes (AND+popcount into int32)", "data": "synthetic",
         "config": {"workload": f"bitMM2Bit {M}x{K}x{N}, a=1, w={w}, ob={w} (BASELINE.json configs[1], 2_7c shape)",
                    "inputs": "seeded Bernoulli(0.5) adjacency, uniform w-bit features, packed and resident in HBM",
-                   "parallelism": f"replica-per-GPU x{world}, no data-path collective"},
+                   "parallelism": f"replica-per-GPU x{world}, no data-path collective",
+                   "issue": "back-to-back launches on one stream (the reference's metric)" if args.streams <= 1
+                            else f"independent launches round-robin on {args.streams} HIP streams"},
         "roofline": roofline,
     }
 
