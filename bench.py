@@ -155,6 +155,26 @@ REF_MICRO = {
 }
 
 
+# adjacency-matrix-size study, 1-bit (5_9_adjmatrix_size.py), sm_86 effective TFLOPs
+REF_ADJ = {16: (5.831, 16.323, 34.425), 32: (11.717, 32.027, 40.175), 64: (23.158, 37.444, 46.759), 128: (28.417, 40.646, 52.517),
+           256: (32.089, 44.151, 59.508), 512: (41.743, 49.687, 64.172), 1024: (37.954, 52.970, 66.490)}
+
+
+def adj_size_table(Q, device):
+    """The reference's adjacency-size study (5_9_adjmatrix_size.py): 1-bit, M = K in 1024/2048/4096,
+    N = 16 .. 1024, all-ones inputs, 200 launches per point, best of 3."""
+    out = {}
+    for nn, ref in REF_ADJ.items():
+        row = {}
+        for mi, mk in enumerate((1024, 2048, 4096)):
+            _, _, ba, bx = make_workload(Q, mk, mk, nn, 1, device, seed=3, ones=True)
+            Q.profile(ba, bx, mk, mk, nn, 1, 1, 1, 20)
+            ms = min(Q.profile(ba, bx, mk, mk, nn, 1, 1, 1, 200) for _ in range(3))
+            row[f"M{mk}"] = {"TOPS": round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2), "ref_sm86": ref[mi]}
+        out[f"N{nn}"] = row
+    return out
+
+
 def micro_bench_table(Q, device):
     """The reference's whole micro-benchmark (2_7c_QGTC_GEMM_INT8.py: 9 shapes x widths 1/2/4/8, 200
     launches per point between two events, all-ones inputs as there), best of 3."""
@@ -309,6 +329,7 @@ def main():
             extras["int8_mfma_vs_1bit_popcount_9_shapes"] = cmp9
         if rank == 0 and world == 1:
             extras["micro_bench_ones_9_shapes_x_4_widths"] = micro_bench_table(Q, device)
+            extras["adjacency_size_study_1bit"] = adj_size_table(Q, device)
         ep, graph = epoch_leg(Q, rank, world, local)
         extras["cluster_gcn_epoch_ogbn_arxiv_shape"] = ep
         # BASELINE.json configs[3]: Batched-GIN, ppi-sized graph, 4-bit weights/features, hidden 64 (0_7b's value)
