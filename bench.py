@@ -330,6 +330,26 @@ def main():
         if rank == 0 and world == 1:
             extras["micro_bench_ones_9_shapes_x_4_widths"] = micro_bench_table(Q, device)
             extras["adjacency_size_study_1bit"] = adj_size_table(Q, device)
+            # the opt-in matrix-core engine (bit planes expanded to int8 on the fly, exact) beside the
+            # popcount engine on wide products, where an expanded operand byte feeds several MFMA tiles
+            eng = {}
+            for (mm, kk, nn, ww) in ((4096, 4096, 1024, 1), (4096, 4096, 1024, 2), (4096, 4096, 1024, 4),
+                                     (8192, 4096, 1024, 1), (8192, 4096, 1024, 2)):
+                _, _, ba, bx = make_workload(Q, mm, kk, nn, ww, device, seed=3)
+                row = {}
+                outs_e = {}
+                for name in ("popcount", "mfma"):
+                    Q.set_engine(name)
+                    try:
+                        Q.profile(ba, bx, mm, kk, nn, 1, ww, ww, 10)
+                        ms = min(Q.profile(ba, bx, mm, kk, nn, 1, ww, ww, 50) for _ in range(3))
+                        outs_e[name] = Q.bitMM2Bit(ba, bx, mm, kk, nn, 1, ww, ww)
+                    finally:
+                        Q.set_engine("popcount")
+                    row[name + "_TOPS"] = round(2.0 * mm * kk * nn * 50 / (ms * 1e-3) / 1e12, 1)
+                row["outputs_identical"] = bool(torch.equal(outs_e["popcount"], outs_e["mfma"]))
+                eng[f"{mm}x{kk}x{nn}_w{ww}"] = row
+            extras["mfma_engine_vs_popcount_wide_products"] = eng
         ep, graph = epoch_leg(Q, rank, world, local)
         extras["cluster_gcn_epoch_ogbn_arxiv_shape"] = ep
         # BASELINE.json configs[3]: Batched-GIN, ppi-sized graph, 4-bit weights/features, hidden 64 (0_7b's value)

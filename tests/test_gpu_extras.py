@@ -173,3 +173,58 @@ def test_gcnconv_qnt_module_matches_integer_reference(qgtc, oracle):
     h = rq(qA @ rq(qX @ qWi))
     want = (qA @ rq(h @ qWo)).astype(np.float32)
     np.testing.assert_array_equal(out_dense.cpu().numpy(), want)
+
+
+MFMA_CASES = [
+    # M, K, N, a, w, ob
+    (128, 128, 128, 1, 1, 1), (64, 256, 128, 1, 1, 1), (200, 1000, 150, 1, 2, 2), (129, 130, 257, 2, 2, 3),
+    (1213, 1213, 128, 1, 2, 2), (300, 4096, 300, 1, 4, 4), (77, 513, 40, 3, 5, 6), (512, 640, 256, 7, 7, 8),
+    (33, 33, 33, 1, 7, 2), (256, 9000, 128, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("M,K,N,a,w,ob", MFMA_CASES)
+def test_mfma_engine_matches_oracle_and_popcount(qgtc, oracle, M, K, N, a, w, ob):
+    """The opt-in matrix-core engine (bit planes expanded to int8, v_mfma_i32_32x32x32_i8) must give
+    the popcount engine's and the oracle's words, in all three output forms."""
+    import torch
+    from helpers import rand_q, to_dev
+    from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
+    rng = np.random.default_rng(M * 3 + K + N + a + w)
+    qx, qw = rand_q(rng, M, K, a), rand_q(rng, K, N, w)
+    X, Wt = oracle.pack(qx, a, False), oracle.pack(qw, w, True)
+    dX, dW = to_dev(torch, X, rows_shape(M, K, a)), to_dev(torch, Wt, cols_shape(K, N, w))
+    assert qgtc.get_engine() == "popcount"
+    pop = (qgtc.bitMM2Bit(dX, dW, M, K, N, a, w, ob), qgtc.bitMM2Bit_col(dX, dW, M, K, N, a, w, ob),
+           qgtc.bitMM2Int(dX, dW, M, K, N, a, w, True))
+    qgtc.set_engine("mfma")
+    try:
+        mf = (qgtc.bitMM2Bit(dX, dW, M, K, N, a, w, ob), qgtc.bitMM2Bit_col(dX, dW, M, K, N, a, w, ob),
+              qgtc.bitMM2Int(dX, dW, M, K, N, a, w, True))
+    finally:
+        qgtc.set_engine("popcount")
+    np.testing.assert_array_equal(to_np_u32(mf[0]), oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob))
+    np.testing.assert_array_equal(to_np_u32(mf[1]), oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob, col=True))
+    np.testing.assert_array_equal(mf[2].cpu().numpy(), oracle.bitmm2int(X, Wt, M, K, N, a, w, True))
+    np.testing.assert_array_equal(mf[2].cpu().numpy(), (qx.astype(np.int64) @ qw.astype(np.int64)).astype(np.float32))
+    for a_, b_ in zip(mf, pop):
+        assert torch.equal(a_, b_)
+
+
+def test_mfma_engine_falls_back_above_7_bits(qgtc, oracle):
+    import torch
+    from helpers import rand_q, to_dev
+    from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
+    rng = np.random.default_rng(8)
+    M, K, N, a, w, ob = 130, 300, 140, 1, 8, 8
+    qx, qw = rand_q(rng, M, K, a), rand_q(rng, K, N, w)
+    X, Wt = oracle.pack(qx, a, False), oracle.pack(qw, w, True)
+    dX, dW = to_dev(torch, X, rows_shape(M, K, a)), to_dev(torch, Wt, cols_shape(K, N, w))
+    qgtc.set_engine("mfma")
+    try:
+        got = qgtc.bitMM2Bit(dX, dW, M, K, N, a, w, ob)
+    finally:
+        qgtc.set_engine("popcount")
+    np.testing.assert_array_equal(to_np_u32(got), oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob))
+    with pytest.raises(RuntimeError):
+        qgtc.set_engine("tensor-core")

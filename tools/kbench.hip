@@ -25,7 +25,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&dx, xw * 4)); CK(hipMalloc(&dw, ww * 4)); CK(hipMalloc(&dout, ow * 4));
     CK(hipMemcpy(dx, hx.data(), xw * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dw, hw.data(), ww * 4, hipMemcpyHostToDevice));
-    const unsigned flags = getenv("NOZS") ? QGTC_NO_ZERO_SKIP : 0u;
+    const unsigned flags = (getenv("NOZS") ? QGTC_NO_ZERO_SKIP : 0u) | (getenv("MFMA") ? QGTC_ENGINE_MFMA : 0u);
     float ms = 0, best = 1e30f;
     for (int r = 0; r < 5; r++) {
         int rc = qgtc_bitmm2bit_profile(dx, xw, dw, ww, M, K, N, a, w, ob, dout, ow, flags, reps, &ms, nullptr);

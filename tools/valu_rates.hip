@@ -41,6 +41,28 @@ __global__ void k_rate(uint32_t *out, int iters) {
                               "v_pk_add_u16 %4, %8, %4\n v_pk_add_u16 %5, %9, %5\n v_pk_add_u16 %6, %8, %6\n v_pk_add_u16 %7, %9, %7\n")
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(w));
         }
+        if (MODE == 11) { BODY("v_mul_u32_u24") }
+        if (MODE == 12) {
+            asm volatile(REP8("v_bfe_u32 %0, %8, 4, 4\n v_bfe_u32 %1, %9, 8, 4\n v_bfe_u32 %2, %8, 12, 4\n v_bfe_u32 %3, %9, 16, 4\n"
+                              "v_bfe_u32 %4, %8, 20, 4\n v_bfe_u32 %5, %9, 24, 4\n v_bfe_u32 %6, %8, 28, 4\n v_bfe_u32 %7, %9, 0, 4\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(w));
+        }
+        if (MODE == 13) {
+            asm volatile(REP8("v_lshl_or_b32 %0, %8, 7, %0\n v_lshl_or_b32 %1, %9, 7, %1\n v_lshl_or_b32 %2, %8, 7, %2\n v_lshl_or_b32 %3, %9, 7, %3\n"
+                              "v_lshl_or_b32 %4, %8, 7, %4\n v_lshl_or_b32 %5, %9, 7, %5\n v_lshl_or_b32 %6, %8, 7, %6\n v_lshl_or_b32 %7, %9, 7, %7\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(w));
+        }
+        if (MODE == 14) {
+            asm volatile(REP8("v_perm_b32 %0, %8, %9, %0\n v_perm_b32 %1, %8, %9, %1\n v_perm_b32 %2, %8, %9, %2\n v_perm_b32 %3, %8, %9, %3\n"
+                              "v_perm_b32 %4, %8, %9, %4\n v_perm_b32 %5, %8, %9, %5\n v_perm_b32 %6, %8, %9, %6\n v_perm_b32 %7, %8, %9, %7\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(w));
+        }
+        if (MODE == 15) { BODY("v_lshrrev_b32") }
+        if (MODE == 16) {
+            asm volatile(REP8("v_mul_lo_u32 %0, %8, %0\n v_mul_lo_u32 %1, %9, %1\n v_mul_lo_u32 %2, %8, %2\n v_mul_lo_u32 %3, %9, %3\n"
+                              "v_mul_lo_u32 %4, %8, %4\n v_mul_lo_u32 %5, %9, %5\n v_mul_lo_u32 %6, %8, %6\n v_mul_lo_u32 %7, %9, %7\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(w));
+        }
         if (MODE == 10) {
             asm volatile(REP8("v_dot4_u32_u8 %0, %8, %9, %0\n v_dot4_u32_u8 %1, %8, %9, %1\n v_dot4_u32_u8 %2, %8, %9, %2\n v_dot4_u32_u8 %3, %8, %9, %3\n"
                               "v_dot4_u32_u8 %4, %8, %9, %4\n v_dot4_u32_u8 %5, %8, %9, %5\n v_dot4_u32_u8 %6, %8, %9, %6\n v_dot4_u32_u8 %7, %8, %9, %7\n")
@@ -87,5 +109,11 @@ int main() {
     run<8>("v_fma_f32", out);
     run<9>("v_pk_add_u16", out);
     run<10>("v_dot4_u32_u8", out);
+    run<11>("v_mul_u32_u24", out);
+    run<12>("v_bfe_u32", out);
+    run<13>("v_lshl_or_b32", out);
+    run<14>("v_perm_b32", out);
+    run<15>("v_lshrrev_b32", out);
+    run<16>("v_mul_lo_u32", out);
     return 0;
 }
