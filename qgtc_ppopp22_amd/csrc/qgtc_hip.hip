@@ -1271,8 +1271,11 @@ __device__ __forceinline__ void expand_word(const uint32_t (&wd)[MAXP], int plan
     }
 }
 
-template <int MAXP>
-__global__ __launch_bounds__(512) void k_bitmm_mfma(qgtc_problem pr, MMShape sh, int tiles_n) {
+// EXPW expander waves: 8 (two threads per line) when a CU holds one workgroup - a lone expander wave per
+// SIMD is latency-bound - or 4 (one thread per line, fewer registers per workgroup) when the grid is large
+// enough for two workgroups per CU to overlap each other.
+template <int MAXP, int EXPW>
+__global__ __launch_bounds__(64 * (4 + EXPW)) void k_bitmm_mfma(qgtc_problem pr, MMShape sh, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1280,10 +1283,17 @@ __global__ __launch_bounds__(512) void k_bitmm_mfma(qgtc_problem pr, MMShape sh,
     const int M = pr.M, K = pr.K, N = pr.N;
     const int m0 = tm * MF_T, n0 = tn * MF_T;
     const int kq = step128(K);
-    // Waves 0-3 multiply, waves 4-7 expand: wave v and wave v+4 share a SIMD, so the matrix pipe
+    // Waves 0-3 multiply, waves 4.. expand: waves v, v+4 (and v+8) share a SIMD, so the matrix pipe
     // (multiplying k-quad q) and the vector pipe (expanding k-quad q+1) of every SIMD run side by
     // side. Two staging buffers, one barrier per k-quad.
     const bool expander = wv >= 4;
+#ifdef QGTC_STAMPS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MF_STAMP(i) st_[i] = __builtin_amdgcn_s_memtime()
+#else
+#define MF_STAMP(i) do { } while (0)
+#endif
+    MF_STAMP(0);
 
     i32x16 acc[2][2];
     const int mw = wv & 3, wr = mw >> 1, wc = mw & 1;   // multiplier wave (wr, wc): a 64 x 64 quarter, 2 x 2 MFMA tiles
@@ -1304,8 +1314,11 @@ __global__ __launch_bounds__(512) void k_bitmm_mfma(qgtc_problem pr, MMShape sh,
             const_cast<uint32_t *>(pr.W), 0, static_cast<int>(static_cast<uint32_t>(pr.w_words) * 4u), 0x00020000);
         // this thread's expansion unit: one line (row of X / column of W) of the tile; the wave-level
         // split (waves 4,5: X rows, waves 6,7: W columns) keeps the descriptor choice wave-uniform
-        const int u = tid - 256;
-        const bool is_x = wv < 6;
+        // two threads per line (each expands two of the four words of a k-quad): eight expander waves, so
+        // that every SIMD has two of them to interleave - one expander wave per SIMD is latency-bound
+        constexpr int TPL = EXPW / 4;  // threads per line
+        const int u = (tid - 256) / TPL, hw = TPL == 2 ? (tid & 1) : 0;
+        const bool is_x = wv < 4 + EXPW / 2;
         const int line = is_x ? u : u - MF_T;
         const int gline = (is_x ? m0 : n0) + line;
         const bool line_ok = gline < (is_x ? M : N);
@@ -1334,10 +1347,11 @@ __global__ __launch_bounds__(512) void k_bitmm_mfma(qgtc_problem pr, MMShape sh,
         auto expand = [&](int q, const u32x4 (&src)[MAXP]) {  // packed words of k-quad q -> bytes in staging buffer q & 1
             unsigned char *stage = my_stage + (q & 1) * MF_STAGE;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
+            for (int cc = 0; cc < 4 / TPL; cc++) {
+                const int c = (4 / TPL) * hw + cc;  // this thread's words of the k-quad
                 uint32_t wd[MAXP], out[8];
 #pragma unroll
-                for (int p = 0; p < MAXP; p++) wd[p] = src[p][c];
+                for (int p = 0; p < MAXP; p++) wd[p] = (TPL == 2 && hw) ? src[p][2 + cc] : src[p][cc];
 #ifdef QGTC_MF_NOEXPAND  // timing-only build
 #pragma unroll
                 for (int d = 0; d < 8; d++) out[d] = wd[0];
@@ -1354,9 +1368,12 @@ __global__ __launch_bounds__(512) void k_bitmm_mfma(qgtc_problem pr, MMShape sh,
         };
         issue_group(0, grp[0]);
         issue_group(1, grp[1]);
+        MF_STAMP(1);
         expand(0, grp[0][0]);
         if (GQ == 1) issue_group(2, grp[0]);
+        MF_STAMP(2);
         __syncthreads();
+        MF_STAMP(3);
         // step J of a block of 2*GQ: k-quad q0+J is being multiplied; expand k-quad e = q0+J+1 (set (e/GQ)&1,
         // slot e%GQ); after the last slot of a set, refill the set with the group two ahead
 #define QGTC_MF_STEP(J)                                                                   \
@@ -1366,9 +1383,12 @@ __global__ __launch_bounds__(512) void k_bitmm_mfma(qgtc_problem pr, MMShape sh,
             expand(q0 + J + 1, grp[E / GQ][E % GQ]);                                      \
             if (E % GQ == GQ - 1) issue_group((q0 + J + 1) / GQ + 2, grp[E / GQ]);        \
         }                                                                                 \
+        if (q0 + J == 8) MF_STAMP(6);                                                     \
         __syncthreads();                                                                  \
+        if (q0 + J == 8) MF_STAMP(7);                                                     \
     }
         for (int q0 = 0; q0 < kq; q0 += 2 * GQ) {
+            if (q0 == 2 * GQ) MF_STAMP(4);
             QGTC_MF_STEP(0)
             QGTC_MF_STEP(1)
             QGTC_MF_STEP(2)
@@ -1379,9 +1399,12 @@ __global__ __launch_bounds__(512) void k_bitmm_mfma(qgtc_problem pr, MMShape sh,
             QGTC_MF_STEP(7)
         }
 #undef QGTC_MF_STEP
+        MF_STAMP(5);
     } else {
         __syncthreads();
+        MF_STAMP(3);
         for (int q = 0; q < kq; q++) {
+            if (q == 8) MF_STAMP(4);
             const unsigned char *xs = smem + (q & 1) * MF_STAGE + (64 * wr + fl) * MF_PITCH + 16 * fh;
             const unsigned char *ws = smem + (q & 1) * MF_STAGE + MF_T * MF_PITCH + (64 * wc + fl) * MF_PITCH + 16 * fh;
             // fragments of k sub-step s+1 are read from LDS while sub-step s is multiplied
@@ -1410,11 +1433,14 @@ __global__ __launch_bounds__(512) void k_bitmm_mfma(qgtc_problem pr, MMShape sh,
                         acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[sub & 1][i], bf[sub & 1][j], acc[i][j], 0, 0, 0);
 #endif
             }
+            if (q == 8) MF_STAMP(1);
             __syncthreads();
+            if (q == 8) MF_STAMP(2);
         }
         // ---- result tile to LDS (the staging buffers are free: the last barrier is behind every read):
         // MFMA C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5). The cols-layout
         // epilogue wants four consecutive ROWS of a column in one 16-byte read: it gets the tile transposed.
+        MF_STAMP(5);
         int *ctw = reinterpret_cast<int *>(smem);
         const bool transposed = sh.mode == 1;
 #pragma unroll
@@ -1430,6 +1456,7 @@ __global__ __launch_bounds__(512) void k_bitmm_mfma(qgtc_problem pr, MMShape sh,
     }
     __syncthreads();
 
+    if (!expander) MF_STAMP(6);
     // ---- epilogue: a thread takes four consecutive elements of a line of the tile (rows layout /
     // float: four columns of a row; cols layout: four rows of a column), 8 adjacent lanes make a word
     const int *ct = reinterpret_cast<const int *>(smem);
@@ -1438,7 +1465,7 @@ __global__ __launch_bounds__(512) void k_bitmm_mfma(qgtc_problem pr, MMShape sh,
     const int mode = sh.mode;
     const int rows_pad = pad8(M), row_words = step128(N) * 4, line_words = step128(M) * 4;
     const size_t oplane = mode == 0 ? static_cast<size_t>(rows_pad) * row_words : static_cast<size_t>(pad128(N)) * line_words;
-    for (int t = tid; t < MF_T * MF_T / 4; t += 512) {
+    for (int t = tid; t < MF_T * MF_T / 4; t += 64 * (4 + EXPW)) {
         const int ln = t >> 5, qd = t & 31;  // line of the tile, quad inside the line
         const int4 v4 = *reinterpret_cast<const int4 *>(ct + ln * MF_CPITCH + 4 * qd);
         const int v[4] = {v4.x, v4.y, v4.z, v4.w};
@@ -1477,6 +1504,12 @@ __global__ __launch_bounds__(512) void k_bitmm_mfma(qgtc_problem pr, MMShape sh,
             if (store) out[0] = word;
         }
     }
+#ifdef QGTC_STAMPS
+    if (!expander) MF_STAMP(7);
+    if ((tid == 0 || tid == 256) && blockIdx.x < 512)
+        for (int i = 0; i < 8; i++) g_stamps[blockIdx.x * 16 + (tid ? 8 : 0) + i] = st_[i];
+#endif
+#undef MF_STAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1608,17 +1641,24 @@ int launch_mfma(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStrea
     const int maxp = a > w ? a : w;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma<1>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma<2>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma<4>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma<7>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
+#define QGTC_MF_ATTR(P, E) \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma<P, E>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
+        QGTC_MF_ATTR(1, 4) QGTC_MF_ATTR(2, 4) QGTC_MF_ATTR(4, 4) QGTC_MF_ATTR(7, 4)
+        QGTC_MF_ATTR(1, 8) QGTC_MF_ATTR(2, 8) QGTC_MF_ATTR(4, 8) QGTC_MF_ATTR(7, 8)
+#undef QGTC_MF_ATTR
         attr_set = true;
     }
-    const dim3 grid(tiles_m * tiles_n), block(512);
-    if (maxp <= 1) hipLaunchKernelGGL(k_bitmm_mfma<1>, grid, block, MF_LDS, st, pr, sh, tiles_n);
-    else if (maxp <= 2) hipLaunchKernelGGL(k_bitmm_mfma<2>, grid, block, MF_LDS, st, pr, sh, tiles_n);
-    else if (maxp <= 4) hipLaunchKernelGGL(k_bitmm_mfma<4>, grid, block, MF_LDS, st, pr, sh, tiles_n);
-    else hipLaunchKernelGGL(k_bitmm_mfma<7>, grid, block, MF_LDS, st, pr, sh, tiles_n);
+    const dim3 grid(tiles_m * tiles_n);
+    // two workgroups per CU overlap each other from 512 tiles on; below that one 12-wave workgroup per CU
+    const bool wide = tiles_m * tiles_n < 512;
+#define QGTC_MF_LAUNCH(P)                                                                              \
+    if (wide) hipLaunchKernelGGL((k_bitmm_mfma<P, 8>), grid, dim3(768), MF_LDS, st, pr, sh, tiles_n);   \
+    else hipLaunchKernelGGL((k_bitmm_mfma<P, 4>), grid, dim3(512), MF_LDS, st, pr, sh, tiles_n);
+    if (maxp <= 1) { QGTC_MF_LAUNCH(1) }
+    else if (maxp <= 2) { QGTC_MF_LAUNCH(2) }
+    else if (maxp <= 4) { QGTC_MF_LAUNCH(4) }
+    else { QGTC_MF_LAUNCH(7) }
+#undef QGTC_MF_LAUNCH
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
 }

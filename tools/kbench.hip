@@ -44,6 +44,7 @@ int main(int argc, char **argv) {
         for (int s = 0; s < 16; s++) {
             unsigned long long t = st[b * 16 + s];
             if (t >= t0 && t - t0 < 100000000ull) printf(" [%d]%llu", s, t - t0);
+            else if (s >= 8 && t && st[b * 16 + 8]) printf(" [%d]%lld", s, (long long)(t - st[b * 16 + 8]));
         }
         printf("\n");
     }
