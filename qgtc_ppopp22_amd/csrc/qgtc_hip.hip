@@ -1441,69 +1441,87 @@ __global__ __launch_bounds__(64 * (4 + EXPW)) void k_bitmm_mfma(qgtc_problem pr,
         // MFMA C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5). The cols-layout
         // epilogue wants four consecutive ROWS of a column in one 16-byte read: it gets the tile transposed.
         MF_STAMP(5);
+        // (two loops, not a select per element: the addresses are then one lane base + immediates)
         int *ctw = reinterpret_cast<int *>(smem);
-        const bool transposed = sh.mode == 1;
+        if (sh.mode == 1) {
+            int *basep = ctw + (64 * wc + fl) * MF_CPITCH + 64 * wr + 4 * fh;
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+            for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+                for (int j = 0; j < 2; j++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int row = 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    const int col = 64 * wc + 32 * j + fl;
-                    ctw[transposed ? col * MF_CPITCH + row : row * MF_CPITCH + col] = acc[i][j][r];
-                }
+                    for (int r = 0; r < 16; r++) basep[32 * j * MF_CPITCH + 32 * i + (r & 3) + 8 * (r >> 2)] = acc[i][j][r];
+        } else {
+            int *basep = ctw + (64 * wr + 4 * fh) * MF_CPITCH + 64 * wc + fl;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) basep[(32 * i + (r & 3) + 8 * (r >> 2)) * MF_CPITCH + 32 * j] = acc[i][j][r];
+        }
     }
     __syncthreads();
 
     if (!expander) MF_STAMP(6);
     // ---- epilogue: a thread takes four consecutive elements of a line of the tile (rows layout /
-    // float: four columns of a row; cols layout: four rows of a column), 8 adjacent lanes make a word
+    // float: four columns of a row; cols layout: four rows of a column), 8 adjacent lanes make a word.
+    // Thread t handles quad (t & 31) of lines (t >> 5) + k * NT/32: everything but the line is invariant.
     const int *ct = reinterpret_cast<const int *>(smem);
     const bool int_rq = sh.ob <= 23;  // float(c) > 2^ob  <=>  c > 2^ob for every int c >= 0
     const int maxi = 1 << (sh.ob & 31);
-    const int mode = sh.mode;
-    const int rows_pad = pad8(M), row_words = step128(N) * 4, line_words = step128(M) * 4;
-    const size_t oplane = mode == 0 ? static_cast<size_t>(rows_pad) * row_words : static_cast<size_t>(pad128(N)) * line_words;
-    for (int t = tid; t < MF_T * MF_T / 4; t += 64 * (4 + EXPW)) {
-        const int ln = t >> 5, qd = t & 31;  // line of the tile, quad inside the line
-        const int4 v4 = *reinterpret_cast<const int4 *>(ct + ln * MF_CPITCH + 4 * qd);
-        const int v[4] = {v4.x, v4.y, v4.z, v4.w};
-        // global coordinates of element e of the quad
-        const int m = mode == 1 ? m0 + 4 * qd : m0 + ln;
-        const int n = mode == 1 ? n0 + ln : n0 + 4 * qd;
-        const int nvalid = mode == 1 ? (n < N ? min(max(M - m, 0), 4) : 0) : (m < M ? min(max(N - n, 0), 4) : 0);
-        if (mode == 2) {  // float32 [M,N] (reference kernel.h:915-930)
-            float *dst = static_cast<float *>(pr.out) + static_cast<size_t>(m) * N + n;
-            if (nvalid == 4 && (N & 3) == 0) {
-                *reinterpret_cast<float4 *>(dst) = make_float4(static_cast<float>(v[0]), static_cast<float>(v[1]),
-                                                               static_cast<float>(v[2]), static_cast<float>(v[3]));
-            } else {
+    constexpr int NT = 64 * (4 + EXPW), LSTEP = NT / 32;
+    const int qd = tid & 31, ln0 = tid >> 5;
+    auto finish = [&](auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;
+        // along-the-line coordinate of the quad (global), the line's coordinate limit
+        const int along = (MODE == 1 ? m0 : n0) + 4 * qd;
+        const int nvalid_line = min(max((MODE == 1 ? M : N) - along, 0), 4);  // leading elements inside the matrix
+        const int across0 = (MODE == 1 ? n0 : m0) + ln0, across_lim = MODE == 1 ? N : M;
+        const int rows_pad = pad8(M), row_words = step128(N) * 4, line_words = step128(M) * 4;
+        const size_t oplane = MODE == 0 ? static_cast<size_t>(rows_pad) * row_words : static_cast<size_t>(pad128(N)) * line_words;
+        const size_t pitch = MODE == 2 ? static_cast<size_t>(N) : (MODE == 0 ? row_words : line_words);  // output units per line
+        // rows layout [ob][PAD8(M)][STEP128(N)*4] (kernel.h:357-389): word (m, n / 32); cols layout
+        // [ob][PAD128(N)][STEP128(M)*4] (kernel.h:651-810 as intended): word (n, m / 32); float32 [M,N]: (m, n)
+        uint32_t *outp = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(across0) * pitch + (MODE == 2 ? along : (along >> 5));
+        const uint32_t sh_n = 28 - 4 * (tid & 7);
+        const bool lead = (tid & 7) == 0;
+        const int *src = ct + ln0 * MF_CPITCH + 4 * qd;
+        for (int ln = ln0, across = across0; ln < MF_T; ln += LSTEP, across += LSTEP, outp += LSTEP * pitch, src += LSTEP * MF_CPITCH) {
+            const int4 v4 = *reinterpret_cast<const int4 *>(src);
+            const int v[4] = {v4.x, v4.y, v4.z, v4.w};
+            const int nvalid = across < across_lim ? nvalid_line : 0;
+            if (MODE == 2) {  // float32 [M,N] (reference kernel.h:915-930)
+                float *dst = reinterpret_cast<float *>(outp);
+                if (nvalid == 4 && (N & 3) == 0) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(static_cast<float>(v[0]), static_cast<float>(v[1]),
+                                                                   static_cast<float>(v[2]), static_cast<float>(v[3]));
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if (e < nvalid) dst[e] = static_cast<float>(v[e]);
+                    for (int e = 0; e < 4; e++)
+                        if (e < nvalid) dst[e] = static_cast<float>(v[e]);
+                }
+                continue;
             }
-            continue;
-        }
-        uint32_t qv[4];
+            uint32_t qv[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int c = int_rq ? (v[e] < 0 ? 1 : (v[e] > maxi ? maxi - 1 : v[e])) : requant(v[e], sh.maxv, sh.maxm1);
-            qv[e] = e < nvalid ? static_cast<uint32_t>(c) : 0u;
+            for (int e = 0; e < 4; e++) {
+                const int c = int_rq ? (v[e] < 0 ? 1 : (v[e] > maxi ? maxi - 1 : v[e])) : requant(v[e], sh.maxv, sh.maxm1);
+                qv[e] = e < nvalid ? static_cast<uint32_t>(c) : 0u;
+            }
+            const bool store = lead && (MODE == 0 ? across < rows_pad : true);
+            uint32_t *out = outp;
+            for (int p = 0; p < sh.ob; p++, out += oplane) {
+                const uint32_t nib = (((qv[0] >> p) & 1u) << 3) | (((qv[1] >> p) & 1u) << 2) |
+                                     (((qv[2] >> p) & 1u) << 1) | ((qv[3] >> p) & 1u);
+                const uint32_t word = or_reduce8(nib << sh_n);
+                if (store) out[0] = word;
+            }
         }
-        // rows layout [ob][PAD8(M)][STEP128(N)*4] (kernel.h:357-389): word (m, (n0 + 4 qd) / 32);
-        // cols layout [ob][PAD128(N)][STEP128(M)*4] (kernel.h:651-810 as intended): word (n, (m0 + 4 qd) / 32)
-        uint32_t *out = static_cast<uint32_t *>(pr.out) +
-                        (mode == 0 ? static_cast<size_t>(m) * row_words + (n >> 5) : static_cast<size_t>(n) * line_words + (m >> 5));
-        const bool store = (t & 7) == 0 && (mode == 0 ? m < rows_pad : true);
-        const uint32_t sh_n = 28 - 4 * (t & 7);
-        for (int p = 0; p < sh.ob; p++, out += oplane) {
-            const uint32_t nib = (((qv[0] >> p) & 1u) << 3) | (((qv[1] >> p) & 1u) << 2) |
-                                 (((qv[2] >> p) & 1u) << 1) | ((qv[3] >> p) & 1u);
-            const uint32_t word = or_reduce8(nib << sh_n);
-            if (store) out[0] = word;
-        }
-    }
+    };
+    if (sh.mode == 0) finish(std::integral_constant<int, 0>{});
+    else if (sh.mode == 1) finish(std::integral_constant<int, 1>{});
+    else finish(std::integral_constant<int, 2>{});
 #ifdef QGTC_STAMPS
     if (!expander) MF_STAMP(7);
     if ((tid == 0 || tid == 256) && blockIdx.x < 512)
