@@ -52,6 +52,7 @@ enum {
 #define QGTC_ENGINE_MFMA 0x8u  /* qgtc_bitmm2bit / qgtc_bitmm2int: expand the bit planes to int8 values and
                                   multiply on the matrix cores (bit1, bit2 <= 7; otherwise ignored). Same
                                   results; pays for wide N and several planes, not for N = 64 */
+#define QGTC_ENGINE_AUTO 0x10u /* let a cost model fitted to MI355X measurements choose between the two engines */
 
 int qgtc_abi_version(void);
 const char *qgtc_strerror(int code);

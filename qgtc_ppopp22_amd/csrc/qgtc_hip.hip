@@ -1653,6 +1653,20 @@ int dispatch_batched(const qgtc_problem *prs, int count, int max_M, int max_N, i
 // the MFMA engine handles plane counts whose values fit a non-negative int8
 inline bool mfma_ok(int a, int w) { return a >= 1 && a <= 7 && w >= 1 && w <= 7; }
 
+// QGTC_ENGINE_AUTO: pick the engine by a two-line cost model fitted to the round-1 measurements
+// (DESIGN.md section 5.4b): popcount runs at ~0.95e15 bit-ops/s plus ~3 us of launch and tail; the
+// matrix-core engine pays ~6 us fixed and ~0.46 us per k-quad and 128 x 128 tile round (a quarter
+// more per extra plane to expand), rounds = tiles / 256 CUs. MFMA only when it wins by 10 %.
+inline bool auto_prefers_mfma(int M, int K, int N, int a, int w) {
+    if (!mfma_ok(a, w)) return false;
+    const double tiles = static_cast<double>((M + MF_T - 1) / MF_T) * ((N + MF_T - 1) / MF_T);
+    const double rounds = tiles <= 256.0 ? 1.0 : tiles / 256.0 * 0.9;
+    const int maxp = a > w ? a : w;
+    const double t_mfma = 6.0 + 0.46 * step128(K) * (1.0 + 0.25 * (maxp - 1)) * rounds;
+    const double t_pop = 3.0 + 2.0 * M * static_cast<double>(K) * N * a * w / 0.95e15 * 1e6;
+    return t_mfma < 0.9 * t_pop;
+}
+
 int launch_mfma(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, mode);
     const int tiles_m = (pr.M + MF_T - 1) / MF_T, tiles_n = (pr.N + MF_T - 1) / MF_T;
@@ -1803,7 +1817,8 @@ int qgtc_bitmm2bit(const uint32_t *X, size_t x_words, const uint32_t *W, size_t 
     if (out_words < need) return QGTC_ESIZE;
     qgtc_problem pr{X, W, out, x_words, w_words, M, K, N, pad128(N), 0, nullptr};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if ((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) return launch_mfma(pr, bit1, bit2, output_bit, cols ? 1 : 0, st);
+    if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma(M, K, N, bit1, bit2)))
+        return launch_mfma(pr, bit1, bit2, output_bit, cols ? 1 : 0, st);
     if (flags & QGTC_NO_ZERO_SKIP)
         return dispatch_single<false>(pr, K, bit1, bit2, output_bit, cols ? 1 : 0, st);
     return dispatch_single<true>(pr, K, bit1, bit2, output_bit, cols ? 1 : 0, st);
@@ -1818,7 +1833,8 @@ int qgtc_bitmm2int(const uint32_t *X, size_t x_words, const uint32_t *W, size_t 
     if (out_elems < static_cast<size_t>(M) * N) return QGTC_ESIZE;
     qgtc_problem pr{X, W, out, x_words, w_words, M, K, N, pad_128 ? pad128(N) : pad8(N), 0, nullptr};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if ((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) return launch_mfma(pr, bit1, bit2, 1, 2, st);
+    if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma(M, K, N, bit1, bit2)))
+        return launch_mfma(pr, bit1, bit2, 1, 2, st);
     if (flags & QGTC_NO_ZERO_SKIP) return dispatch_single<false>(pr, K, bit1, bit2, 1, 2, st);
     return dispatch_single<true>(pr, K, bit1, bit2, 1, 2, st);
 }

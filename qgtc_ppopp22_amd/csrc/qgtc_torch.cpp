@@ -56,8 +56,11 @@ void check_bits_tensor(const torch::Tensor &t, const char *name) {
 }
 
 bool g_zero_skip = true;
-bool g_engine_mfma = false;  // opt-in: multiply on the matrix cores where the plane counts allow it
-unsigned mm_flags() { return (g_zero_skip ? 0u : QGTC_NO_ZERO_SKIP) | (g_engine_mfma ? QGTC_ENGINE_MFMA : 0u); }
+int g_engine = 0;  // 0 popcount (default), 1 mfma (wherever the plane counts allow it), 2 auto (cost model)
+unsigned mm_flags() {
+    return (g_zero_skip ? 0u : QGTC_NO_ZERO_SKIP) | (g_engine == 1 ? QGTC_ENGINE_MFMA : 0u) |
+           (g_engine == 2 ? QGTC_ENGINE_AUTO : 0u);
+}
 
 // process-cumulative tile counters, like the reference's __device__ globals (kernel.h:13-14)
 unsigned long long g_counter = 0, g_counter_global = 0;
@@ -576,11 +579,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("reset_counters", [] { g_counter = 0; g_counter_global = 0; });
     m.def("set_zero_skip", [](bool on) { g_zero_skip = on; });
     m.def("set_engine", [](const std::string &name) {
-        TORCH_CHECK(name == "popcount" || name == "mfma", "engine must be 'popcount' or 'mfma'");
-        g_engine_mfma = name == "mfma";
-    }, "engine of bitMM2Bit / bitMM2Bit_col / bitMM2Int: 'popcount' (default, AND + v_bcnt) or 'mfma' (bit planes "
-       "expanded to int8 on the fly, v_mfma_i32_32x32x32_i8; bit widths <= 7, else popcount). Same results.");
-    m.def("get_engine", [] { return std::string(g_engine_mfma ? "mfma" : "popcount"); });
+        TORCH_CHECK(name == "popcount" || name == "mfma" || name == "auto", "engine must be 'popcount', 'mfma' or 'auto'");
+        g_engine = name == "mfma" ? 1 : (name == "auto" ? 2 : 0);
+    }, "engine of bitMM2Bit / bitMM2Bit_col / bitMM2Int: 'popcount' (default, AND + v_bcnt), 'mfma' (bit planes "
+       "expanded to int8 on the fly, v_mfma_i32_32x32x32_i8; bit widths <= 7, else popcount) or 'auto' (a cost "
+       "model picks per call). Same results.");
+    m.def("get_engine", [] { return std::string(g_engine == 1 ? "mfma" : (g_engine == 2 ? "auto" : "popcount")); });
     m.def("get_zero_skip", [] { return g_zero_skip; });
     m.def("abi_version", [] { return qgtc_abi_version(); });
 

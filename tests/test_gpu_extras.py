@@ -228,3 +228,25 @@ def test_mfma_engine_falls_back_above_7_bits(qgtc, oracle):
     np.testing.assert_array_equal(to_np_u32(got), oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob))
     with pytest.raises(RuntimeError):
         qgtc.set_engine("tensor-core")
+
+
+@pytest.mark.parametrize("M,K,N,a,w,ob", [(2048, 2048, 1024, 2, 2, 2), (2048, 2048, 64, 1, 1, 1)])
+def test_auto_engine_same_words_either_way(qgtc, M, K, N, a, w, ob):
+    """set_engine('auto') picks by a cost model (matrix cores for the wide product, popcount for the
+    64-column one); whichever it picks, the words are those of the parity-tested popcount engine."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
+    dX = torch.randint(-2**31, 2**31 - 1, rows_shape(M, K, a), dtype=torch.int32, generator=g).cuda()
+    dW = torch.randint(-2**31, 2**31 - 1, cols_shape(K, N, w), dtype=torch.int32, generator=g).cuda()
+    pop = (qgtc.bitMM2Bit(dX, dW, M, K, N, a, w, ob), qgtc.bitMM2Bit_col(dX, dW, M, K, N, a, w, ob),
+           qgtc.bitMM2Int(dX, dW, M, K, N, a, w, True))
+    qgtc.set_engine("auto")
+    try:
+        assert qgtc.get_engine() == "auto"
+        au = (qgtc.bitMM2Bit(dX, dW, M, K, N, a, w, ob), qgtc.bitMM2Bit_col(dX, dW, M, K, N, a, w, ob),
+              qgtc.bitMM2Int(dX, dW, M, K, N, a, w, True))
+    finally:
+        qgtc.set_engine("popcount")
+    for x, y in zip(au, pop):
+        assert torch.equal(x, y)
