@@ -1,6 +1,6 @@
 """In-tree build of the native pieces (called by __graft_entry__.build()).
 
-  libqgtc_hip.so                    hipcc --offload-arch=gfx950  csrc/qgtc_hip.hip   (C-ABI + kernels)
+  libqgtc_hip.so                    hipcc --offload-arch=gfx950  csrc/qgtc_hip.hip   (C-ABI; includes csrc/*.hip.h, the kernels)
   QGTC.cpython-*.so                 g++                          csrc/qgtc_torch.cpp (pybind11 binding)
 
 Both land next to this file so that they travel with the repo snapshot to the GPU box (they are
@@ -38,6 +38,7 @@ def _run(cmd: list[str]) -> None:
 
 def build_hip(force: bool = False) -> str:
     src = [os.path.join(CSRC, "qgtc_hip.hip"), os.path.join(INC, "qgtc.h")]
+    src += sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip.h"))
     if not force and _newer(HIP_LIB, src):
         return HIP_LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

@@ -1,0 +1,311 @@
+// bitmm_mfma.hip.h — part of libqgtc_hip.so (included by qgtc_hip.hip, one translation unit).
+// The bit-GEMM, matrix-core engine (opt-in): bit planes expanded to int8 on the fly,
+// v_mfma_i32_32x32x32_i8, same words as the popcount engine.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// The bit-GEMM on the matrix cores (opt-in engine, QGTC_ENGINE_MFMA): same operands, same
+// results, but the bit planes of both operands are expanded on the fly to int8 VALUES (plane p
+// contributes bit p of the byte, so a planes x w planes collapse into ONE product) and multiplied
+// with v_mfma_i32_32x32x32_i8, int32 accumulation, exact. gfx950 has no 1-bit MFMA; expanding
+// costs ~0.8 VALU operations per operand byte, which only pays when an expanded byte is reused by
+// several MFMA tiles: a workgroup owns a 128 x 128 output tile (four waves, 64 x 64 each), so this
+// engine is for wide N (>= 128) and/or several planes; the popcount kernels stay the default and
+// remain the faster path at N = 64. Needs a, w <= 7 (non-negative int8).
+//
+// Per k-quad (128 bits of K) one thread of the expander waves expands one row of X or one column of W:
+// every 32-bit word is bit-reversed (element i at bit i), each nibble is spread to four bytes with
+// one 24-bit multiply ((n * 0x204081) & 0x01010101) and planes are merged with shift-or; the 128
+// bytes go to LDS ([line][144-byte pitch]: the 16-byte MFMA fragment reads of 32 lines are
+// conflict-free). The packed words of the next k-quad are loaded (range-checked buffer loads)
+// while the current one is multiplied. The finished 128 x 128 int32 tile goes through LDS to the
+// same three epilogues (rows-layout bits, cols-layout bits, float32); with 128-wide tiles every
+// output word belongs to exactly one workgroup, so there is no padding to zero-fill separately.
+// ------------------------------------------------------------------------------------------
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+constexpr int MF_T = 128;          // tile edge
+constexpr int MF_PITCH = 144;      // bytes between the expanded lines of one operand
+constexpr int MF_CPITCH = 132;     // ints between the rows (cols layout: columns) of the result tile in LDS
+constexpr int MF_STAGE = 2 * MF_T * MF_PITCH;                 // one staging buffer: X lines, then W lines
+constexpr int MF_LDS = (MF_T * MF_CPITCH * 4 > 2 * MF_STAGE) ? MF_T * MF_CPITCH * 4 : 2 * MF_STAGE;
+
+// 32 packed elements (MSB-first) of `planes` planes -> 32 bytes (8 dwords), byte = sum_p bit_p << p
+template <int MAXP>
+__device__ __forceinline__ void expand_word(const uint32_t (&wd)[MAXP], int planes, uint32_t (&out)[8]) {
+#pragma unroll
+    for (int d = 0; d < 8; d++) out[d] = 0u;
+#pragma unroll
+    for (int p = 0; p < MAXP; p++) {
+        if (p >= planes) break;
+        const uint32_t r = __brev(wd[p]);  // element i of the word at bit i
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            const uint32_t nib = (r >> (4 * d)) & 15u;
+            const uint32_t bytes = __umul24(nib, 0x204081u) & 0x01010101u;  // bit e of the nibble -> byte e
+            out[d] |= bytes << p;
+        }
+    }
+}
+
+// EXPW expander waves: 8 (two threads per line) when a CU holds one workgroup - a lone expander wave per
+// SIMD is latency-bound - or 4 (one thread per line, fewer registers per workgroup) when the grid is large
+// enough for two workgroups per CU to overlap each other.
+template <int MAXP, int EXPW>
+__global__ __launch_bounds__(64 * (4 + EXPW)) void k_bitmm_mfma(qgtc_problem pr, MMShape sh, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int M = pr.M, K = pr.K, N = pr.N;
+    const int m0 = tm * MF_T, n0 = tn * MF_T;
+    const int kq = step128(K);
+    // Waves 0-3 multiply, waves 4.. expand: waves v, v+4 (and v+8) share a SIMD, so the matrix pipe
+    // (multiplying k-quad q) and the vector pipe (expanding k-quad q+1) of every SIMD run side by
+    // side. Two staging buffers, one barrier per k-quad.
+    const bool expander = wv >= 4;
+#ifdef QGTC_STAMPS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MF_STAMP(i) st_[i] = __builtin_amdgcn_s_memtime()
+#else
+#define MF_STAMP(i) do { } while (0)
+#endif
+    MF_STAMP(0);
+
+    i32x16 acc[2][2];
+    const int mw = wv & 3, wr = mw >> 1, wc = mw & 1;   // multiplier wave (wr, wc): a 64 x 64 quarter, 2 x 2 MFMA tiles
+    const int fl = lane & 31, fh = lane >> 5;           // fragment line, k half (16 bytes each)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
+
+    if (expander) {
+        const uint32_t kw = static_cast<uint32_t>(kq) * 4u;
+        const uint32_t x_plane = static_cast<uint32_t>(pad8(M)) * kw, w_plane = static_cast<uint32_t>(pr.w_lines) * kw;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint32_t *>(pr.X), 0, static_cast<int>(static_cast<uint32_t>(pr.x_words) * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint32_t *>(pr.W), 0, static_cast<int>(static_cast<uint32_t>(pr.w_words) * 4u), 0x00020000);
+        // this thread's expansion unit: one line (row of X / column of W) of the tile; the wave-level
+        // split (waves 4,5: X rows, waves 6,7: W columns) keeps the descriptor choice wave-uniform
+        // two threads per line (each expands two of the four words of a k-quad): eight expander waves, so
+        // that every SIMD has two of them to interleave - one expander wave per SIMD is latency-bound
+        constexpr int TPL = EXPW / 4;  // threads per line
+        const int u = (tid - 256) / TPL, hw = TPL == 2 ? (tid & 1) : 0;
+        const bool is_x = wv < 4 + EXPW / 2;
+        const int line = is_x ? u : u - MF_T;
+        const int gline = (is_x ? m0 : n0) + line;
+        const bool line_ok = gline < (is_x ? M : N);
+        const int planes = is_x ? sh.a : sh.w;
+        const uint32_t plane_words = is_x ? x_plane : w_plane;
+        const uint32_t base = static_cast<uint32_t>(gline) * kw * 4u;  // byte offset of the line inside a plane
+        unsigned char *my_stage = smem + (is_x ? 0 : MF_T * MF_PITCH) + line * MF_PITCH;
+        // Packed words are loaded GQ k-quads at a time per line (GQ * 16 contiguous bytes per lane): one
+        // k-quad per load instruction touches 64 different 128-byte lines for 16 bytes each and the L1
+        // (32 KB) does not keep them until the next k-quad - measured: 1300 cycles per k-quad, all of
+        // it L2 -> L1 traffic. Two register sets: group g+1 is in flight while group g is expanded.
+        constexpr int GQ = MAXP <= 2 ? 4 : (MAXP <= 4 ? 2 : 1);
+        u32x4 grp[2][GQ][MAXP];
+        auto issue_group = [&](int g, u32x4 (&dst)[GQ][MAXP]) {
+#pragma unroll
+            for (int p = 0; p < MAXP; p++)
+#pragma unroll
+                for (int j = 0; j < GQ; j++) {
+                    const int q = g * GQ + j;
+                    const bool ok = line_ok && p < planes && q < kq;
+                    const uint32_t off = ok ? static_cast<uint32_t>(p) * plane_words * 4u + base + static_cast<uint32_t>(q) * 16u : 0xffffffffu;
+                    dst[j][p] = is_x ? __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0)
+                                     : __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0);
+                }
+        };
+        auto expand = [&](int q, const u32x4 (&src)[MAXP]) {  // packed words of k-quad q -> bytes in staging buffer q & 1
+            unsigned char *stage = my_stage + (q & 1) * MF_STAGE;
+#pragma unroll
+            for (int cc = 0; cc < 4 / TPL; cc++) {
+                const int c = (4 / TPL) * hw + cc;  // this thread's words of the k-quad
+                uint32_t wd[MAXP], out[8];
+#pragma unroll
+                for (int p = 0; p < MAXP; p++) wd[p] = (TPL == 2 && hw) ? src[p][2 + cc] : src[p][cc];
+#ifdef QGTC_MF_NOEXPAND  // timing-only build
+#pragma unroll
+                for (int d = 0; d < 8; d++) out[d] = wd[0];
+#else
+                expand_word<MAXP>(wd, planes, out);
+#endif
+#ifdef QGTC_MF_NOWRITE  // timing-only build
+                asm volatile("" ::"v"(out[0]), "v"(out[1]), "v"(out[2]), "v"(out[3]), "v"(out[4]), "v"(out[5]), "v"(out[6]), "v"(out[7]));
+#else
+                *reinterpret_cast<u32x4 *>(stage + c * 32) = u32x4{out[0], out[1], out[2], out[3]};
+                *reinterpret_cast<u32x4 *>(stage + c * 32 + 16) = u32x4{out[4], out[5], out[6], out[7]};
+#endif
+            }
+        };
+        issue_group(0, grp[0]);
+        issue_group(1, grp[1]);
+        MF_STAMP(1);
+        expand(0, grp[0][0]);
+        if (GQ == 1) issue_group(2, grp[0]);
+        MF_STAMP(2);
+        __syncthreads();
+        MF_STAMP(3);
+        // step J of a block of 2*GQ: k-quad q0+J is being multiplied; expand k-quad e = q0+J+1 (set (e/GQ)&1,
+        // slot e%GQ); after the last slot of a set, refill the set with the group two ahead
+#define QGTC_MF_STEP(J)                                                                   \
+    if (J < 2 * GQ && q0 + J < kq) {                                                      \
+        constexpr int E = (J + 1) % (2 * GQ);                                             \
+        if (q0 + J + 1 < kq) {                                                            \
+            expand(q0 + J + 1, grp[E / GQ][E % GQ]);                                      \
+            if (E % GQ == GQ - 1) issue_group((q0 + J + 1) / GQ + 2, grp[E / GQ]);        \
+        }                                                                                 \
+        if (q0 + J == 8) MF_STAMP(6);                                                     \
+        __syncthreads();                                                                  \
+        if (q0 + J == 8) MF_STAMP(7);                                                     \
+    }
+        for (int q0 = 0; q0 < kq; q0 += 2 * GQ) {
+            if (q0 == 2 * GQ) MF_STAMP(4);
+            QGTC_MF_STEP(0)
+            QGTC_MF_STEP(1)
+            QGTC_MF_STEP(2)
+            QGTC_MF_STEP(3)
+            QGTC_MF_STEP(4)
+            QGTC_MF_STEP(5)
+            QGTC_MF_STEP(6)
+            QGTC_MF_STEP(7)
+        }
+#undef QGTC_MF_STEP
+        MF_STAMP(5);
+    } else {
+        __syncthreads();
+        MF_STAMP(3);
+        for (int q = 0; q < kq; q++) {
+            if (q == 8) MF_STAMP(4);
+            const unsigned char *xs = smem + (q & 1) * MF_STAGE + (64 * wr + fl) * MF_PITCH + 16 * fh;
+            const unsigned char *ws = smem + (q & 1) * MF_STAGE + MF_T * MF_PITCH + (64 * wc + fl) * MF_PITCH + 16 * fh;
+            // fragments of k sub-step s+1 are read from LDS while sub-step s is multiplied
+            i32x4 af[2][2], bf[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                af[0][i] = *reinterpret_cast<const i32x4 *>(xs + 32 * i * MF_PITCH);
+                bf[0][i] = *reinterpret_cast<const i32x4 *>(ws + 32 * i * MF_PITCH);
+            }
+#pragma unroll
+            for (int sub = 0; sub < 4; sub++) {
+                if (sub + 1 < 4) {
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        af[(sub + 1) & 1][i] = *reinterpret_cast<const i32x4 *>(xs + 32 * i * MF_PITCH + 32 * (sub + 1));
+                        bf[(sub + 1) & 1][i] = *reinterpret_cast<const i32x4 *>(ws + 32 * i * MF_PITCH + 32 * (sub + 1));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+#ifdef QGTC_MF_NOMFMA  // timing-only build
+                        asm volatile("" ::"v"(af[sub & 1][i]), "v"(bf[sub & 1][j]));
+#else
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[sub & 1][i], bf[sub & 1][j], acc[i][j], 0, 0, 0);
+#endif
+            }
+            if (q == 8) MF_STAMP(1);
+            __syncthreads();
+            if (q == 8) MF_STAMP(2);
+        }
+        // ---- result tile to LDS (the staging buffers are free: the last barrier is behind every read):
+        // MFMA C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5). The cols-layout
+        // epilogue wants four consecutive ROWS of a column in one 16-byte read: it gets the tile transposed.
+        MF_STAMP(5);
+        // (two loops, not a select per element: the addresses are then one lane base + immediates)
+        int *ctw = reinterpret_cast<int *>(smem);
+        if (sh.mode == 1) {
+            int *basep = ctw + (64 * wc + fl) * MF_CPITCH + 64 * wr + 4 * fh;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) basep[32 * j * MF_CPITCH + 32 * i + (r & 3) + 8 * (r >> 2)] = acc[i][j][r];
+        } else {
+            int *basep = ctw + (64 * wr + 4 * fh) * MF_CPITCH + 64 * wc + fl;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) basep[(32 * i + (r & 3) + 8 * (r >> 2)) * MF_CPITCH + 32 * j] = acc[i][j][r];
+        }
+    }
+    __syncthreads();
+
+    if (!expander) MF_STAMP(6);
+    // ---- epilogue: a thread takes four consecutive elements of a line of the tile (rows layout /
+    // float: four columns of a row; cols layout: four rows of a column), 8 adjacent lanes make a word.
+    // Thread t handles quad (t & 31) of lines (t >> 5) + k * NT/32: everything but the line is invariant.
+    const int *ct = reinterpret_cast<const int *>(smem);
+    const bool int_rq = sh.ob <= 23;  // float(c) > 2^ob  <=>  c > 2^ob for every int c >= 0
+    const int maxi = 1 << (sh.ob & 31);
+    constexpr int NT = 64 * (4 + EXPW), LSTEP = NT / 32;
+    const int qd = tid & 31, ln0 = tid >> 5;
+    auto finish = [&](auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;
+        // along-the-line coordinate of the quad (global), the line's coordinate limit
+        const int along = (MODE == 1 ? m0 : n0) + 4 * qd;
+        const int nvalid_line = min(max((MODE == 1 ? M : N) - along, 0), 4);  // leading elements inside the matrix
+        const int across0 = (MODE == 1 ? n0 : m0) + ln0, across_lim = MODE == 1 ? N : M;
+        const int rows_pad = pad8(M), row_words = step128(N) * 4, line_words = step128(M) * 4;
+        const size_t oplane = MODE == 0 ? static_cast<size_t>(rows_pad) * row_words : static_cast<size_t>(pad128(N)) * line_words;
+        const size_t pitch = MODE == 2 ? static_cast<size_t>(N) : (MODE == 0 ? row_words : line_words);  // output units per line
+        // rows layout [ob][PAD8(M)][STEP128(N)*4] (kernel.h:357-389): word (m, n / 32); cols layout
+        // [ob][PAD128(N)][STEP128(M)*4] (kernel.h:651-810 as intended): word (n, m / 32); float32 [M,N]: (m, n)
+        uint32_t *outp = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(across0) * pitch + (MODE == 2 ? along : (along >> 5));
+        const uint32_t sh_n = 28 - 4 * (tid & 7);
+        const bool lead = (tid & 7) == 0;
+        const int *src = ct + ln0 * MF_CPITCH + 4 * qd;
+        for (int ln = ln0, across = across0; ln < MF_T; ln += LSTEP, across += LSTEP, outp += LSTEP * pitch, src += LSTEP * MF_CPITCH) {
+            const int4 v4 = *reinterpret_cast<const int4 *>(src);
+            const int v[4] = {v4.x, v4.y, v4.z, v4.w};
+            const int nvalid = across < across_lim ? nvalid_line : 0;
+            if (MODE == 2) {  // float32 [M,N] (reference kernel.h:915-930)
+                float *dst = reinterpret_cast<float *>(outp);
+                if (nvalid == 4 && (N & 3) == 0) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(static_cast<float>(v[0]), static_cast<float>(v[1]),
+                                                                   static_cast<float>(v[2]), static_cast<float>(v[3]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (e < nvalid) dst[e] = static_cast<float>(v[e]);
+                }
+                continue;
+            }
+            uint32_t qv[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int c = int_rq ? (v[e] < 0 ? 1 : (v[e] > maxi ? maxi - 1 : v[e])) : requant(v[e], sh.maxv, sh.maxm1);
+                qv[e] = e < nvalid ? static_cast<uint32_t>(c) : 0u;
+            }
+            const bool store = lead && (MODE == 0 ? across < rows_pad : true);
+            uint32_t *out = outp;
+            for (int p = 0; p < sh.ob; p++, out += oplane) {
+                const uint32_t nib = (((qv[0] >> p) & 1u) << 3) | (((qv[1] >> p) & 1u) << 2) |
+                                     (((qv[2] >> p) & 1u) << 1) | ((qv[3] >> p) & 1u);
+                const uint32_t word = or_reduce8(nib << sh_n);
+                if (store) out[0] = word;
+            }
+        }
+    };
+    if (sh.mode == 0) finish(std::integral_constant<int, 0>{});
+    else if (sh.mode == 1) finish(std::integral_constant<int, 1>{});
+    else finish(std::integral_constant<int, 2>{});
+#ifdef QGTC_STAMPS
+    if (!expander) MF_STAMP(7);
+    if ((tid == 0 || tid == 256) && blockIdx.x < 512)
+        for (int i = 0; i < 8; i++) g_stamps[blockIdx.x * 16 + (tid ? 8 : 0) + i] = st_[i];
+#endif
+#undef MF_STAMP
+}
+
+}  // namespace

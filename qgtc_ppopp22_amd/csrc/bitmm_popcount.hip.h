@@ -1,0 +1,830 @@
+// bitmm_popcount.hip.h — part of libqgtc_hip.so (included by qgtc_hip.hip, one translation unit).
+// The bit-GEMM, popcount engine: v_and_b32 + v_bcnt_u32_b32 with shift-accumulate into int32,
+// in-workgroup split-K, zero-tile skipping / jumping, fused re-quantise + re-pack epilogue.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// the bit-GEMM
+//
+// Decomposition. A workgroup owns a 32 x 32 output tile for the whole K range, so no reduction
+// ever crosses workgroups and the int32 sums are exact in any order. Its waves split K: wave v
+// owns the k-quads (128-bit steps of a packed row) [v*per, v*per + per). Everything a wave
+// multiplies is private to it: it loads its own slice of the X rows and W lines, stages it in
+// its own LDS region and reads it back in the micro-tile pattern, so the main loop has NO
+// workgroup barrier; the waves only meet once, to sum their 32 x 32 partial tiles through LDS.
+//
+// Per stage a wave holds QW k-quads of `ab` X planes and `wb` W planes:
+//   global -> registers   raw buffer loads (hardware range check: any dword outside the stated
+//                         extent reads as 0, so mis-sized / mis-laid operands can never fault),
+//                         lane = (line, k-quad) with the k-quads of one packed row in adjacent
+//                         lanes: every load instruction touches whole 16/32/64-byte runs;
+//   registers -> LDS      ds_write_b128 into [plane][k-quad][line] (pitch RS granules: the 8
+//                         lanes of one write group land in 8 different bank quads);
+//   LDS -> registers      ds_read_b128: the 8 distinct granules a wave reads per instruction are
+//                         contiguous, so reads are conflict-free and broadcast to 8 lanes each;
+//   the loads of stage s+1 are in flight while stage s is multiplied.
+// Each lane keeps a 4 x 4 register micro-tile (rows lm + 8i, columns ln + 8j) and spends, per
+// k-quad and plane pair, 8 granule reads on 64 v_and_b32 + 64 v_bcnt_u32_b32 (accumulate form).
+//
+// Zero-tile skipping. While a stage is still in registers the wave ORs each X granule and
+// ballots: one scalar bit per (X plane, k-quad) says whether the 32-row x 128-bit tile has any
+// bit set. All-zero tiles are skipped with a scalar branch (no divergence, no extra VALU work).
+// ------------------------------------------------------------------------------------------
+#ifdef QGTC_STAMPS  // diagnostic build only (tools/kbench.hip): per-phase s_memtime stamps
+// The stamps stay in scalar registers while the kernel runs (a store per stamp would put memory
+// traffic and waits into the phases being timed); wave 0 of each workgroup writes them out at the end.
+__device__ unsigned long long g_stamps[1024 * 16];
+struct Stamps {
+    unsigned long long t[16];
+};
+#define STAMP_DECL Stamps stamps_; for (int i_ = 0; i_ < 16; i_++) stamps_.t[i_] = 0ull
+#define STAMP(slot) stamps_.t[slot] = __builtin_amdgcn_s_memtime()
+#define STAMP_FLUSH()                                                                          \
+    do {                                                                                       \
+        if (threadIdx.x == 0)                                                                  \
+            for (int i_ = 0; i_ < 16; i_++) g_stamps[blockIdx.x % 1024 * 16 + i_] = stamps_.t[i_]; \
+    } while (0)
+#define STAMP_ARG , Stamps &stamps_
+#define STAMP_PASS , stamps_
+#else
+#define STAMP_DECL do { } while (0)
+#define STAMP(slot) do { } while (0)
+#define STAMP_FLUSH() do { } while (0)
+#define STAMP_ARG
+#define STAMP_PASS
+#endif
+
+
+struct MMShape {           // per-launch constants
+    int a, w, ob;          // planes of X, planes of W, output planes
+    int mode;              // 0 rows-layout bits, 1 cols-layout bits, 2 float32
+    int ab, wb;            // planes staged at once (generic kernel; the fixed kernels stage all)
+    int per;               // k-quads per wave (in-workgroup split-K slice)
+    int waves;             // waves per workgroup (= blockDim.x / 64, passed so that no hidden argument is read)
+    uint32_t inv_tiles_n;  // floor(2^32 / tiles_n), single launches only (tiles_n >= 2; else 0xffffffff)
+    float maxv, maxm1;     // 2^ob and 2^ob - 1 as float (requant)
+};
+
+constexpr int MR = 4, MC = 4;        // per-lane micro-tile
+constexpr int GPT = 8;               // granules (16 B) a lane may hold per stage
+constexpr int SLAB_PITCH = 72;       // ints between the (i,j) planes of a wave's partial tile
+constexpr int SLAB_BYTES = MR * MC * SLAB_PITCH * 4;
+constexpr int MAX_WAVES = 8;
+
+// granule pitch of one (plane, k-quad) line block in LDS
+__host__ __device__ constexpr int lds_pitch(int qw) { return qw == 4 ? 34 : (qw == 2 ? 36 : 32); }
+// slots (one 16-byte load per lane each) that `planes` plane tiles of QW k-quads need
+__host__ __device__ constexpr int slots_for(int planes, int qw) { return (planes * qw + 1) / 2; }
+// bytes of one wave's staging region
+__host__ __device__ constexpr size_t region_bytes(int planes, int qw) {
+    return static_cast<size_t>(planes) * qw * lds_pitch(qw) * 16;
+}
+
+// acc[i][j] += popcount(x[i] & w[j]) for two X words and four W words: 8 v_and_b32 into
+// temporaries, then 8 v_bcnt_u32_b32 with the accumulator as the add operand. Written as one asm
+// block because hipcc (a) turns __popc(a & b) + c into v_bcnt(..., 0) + v_add3 (2.5 instructions
+// per pair instead of 2) and (b) likes to issue each v_bcnt right behind the v_and it depends on,
+// which costs a dependent-issue bubble per pair; here every v_bcnt is 8 instructions behind.
+__device__ __forceinline__ void and_popc_2x4(uint32_t &a00, uint32_t &a01, uint32_t &a02, uint32_t &a03,
+                                             uint32_t &a10, uint32_t &a11, uint32_t &a12, uint32_t &a13,
+                                             uint32_t x0, uint32_t x1, uint32_t w0, uint32_t w1,
+                                             uint32_t w2, uint32_t w3) {
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
+    asm("v_and_b32 %8, %16, %18\n\tv_and_b32 %9, %16, %19\n\tv_and_b32 %10, %16, %20\n\tv_and_b32 %11, %16, %21\n\t"
+        "v_and_b32 %12, %17, %18\n\tv_and_b32 %13, %17, %19\n\tv_and_b32 %14, %17, %20\n\tv_and_b32 %15, %17, %21\n\t"
+        "v_bcnt_u32_b32 %0, %8, %0\n\tv_bcnt_u32_b32 %1, %9, %1\n\tv_bcnt_u32_b32 %2, %10, %2\n\tv_bcnt_u32_b32 %3, %11, %3\n\t"
+        "v_bcnt_u32_b32 %4, %12, %4\n\tv_bcnt_u32_b32 %5, %13, %5\n\tv_bcnt_u32_b32 %6, %14, %6\n\tv_bcnt_u32_b32 %7, %15, %7"
+        : "+v"(a00), "+v"(a01), "+v"(a02), "+v"(a03), "+v"(a10), "+v"(a11), "+v"(a12), "+v"(a13),
+          "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(x0), "v"(x1), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+}
+
+// one k-quad of the 4 x 4 micro-tile: 64 AND + 64 BCNT
+__device__ __forceinline__ void mac_quad(uint32_t (&acc)[MR][MC], const u32x4 (&xg)[MR],
+                                         const u32x4 (&wg)[MC]) {
+#define QGTC_MAC_WORD(c)                                                                            \
+    and_popc_2x4(acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3], \
+                 xg[0].c, xg[1].c, wg[0].c, wg[1].c, wg[2].c, wg[3].c);                             \
+    and_popc_2x4(acc[2][0], acc[2][1], acc[2][2], acc[2][3], acc[3][0], acc[3][1], acc[3][2], acc[3][3], \
+                 xg[2].c, xg[3].c, wg[0].c, wg[1].c, wg[2].c, wg[3].c);
+    QGTC_MAC_WORD(x)
+    QGTC_MAC_WORD(y)
+    QGTC_MAC_WORD(z)
+    QGTC_MAC_WORD(w)
+#undef QGTC_MAC_WORD
+}
+
+__device__ __forceinline__ int requant(int c, float maxv, float maxm1) {
+    // reference kernel.h:31-37 called as quantize(c, ob, 1<<ob, 0): float compare, then the
+    // (val-min)*2^ob/(max-min) scaling, which is the identity for min=0, max=2^ob.
+    float val = static_cast<float>(c);
+    if (val > maxv) val = maxm1;
+    if (val < 0.0f) val = 1.0f;
+    return val >= 2147483648.0f ? 2147483647 : static_cast<int>(val);
+}
+
+// slot u of an operand, lane l  ->  (plane tile, line within the 32-line tile, k-quad of the chunk)
+template <int QW>
+__device__ __forceinline__ void slot_map(int u, int lane, int &pt, int &line, int &kk) {
+    if (QW == 4) {
+        pt = u >> 1;
+        line = ((u & 1) << 4) + (lane >> 2);
+        kk = lane & 3;
+    } else if (QW == 2) {
+        pt = u;
+        line = lane >> 1;
+        kk = lane & 1;
+    } else {
+        pt = 2 * u + (lane >> 5);
+        line = lane & 31;
+        kk = 0;
+    }
+}
+
+// occupancy bits (bit kk = "k-quad kk of plane tile pt has a set bit") from the ballots of the
+// slots that hold the tile
+template <int QW>
+__device__ __forceinline__ uint32_t tile_occupancy(const unsigned long long (&nzm)[GPT], int pt) {
+    if (QW == 4) {
+        const unsigned long long m = nzm[2 * pt] | nzm[2 * pt + 1];
+        uint32_t o = 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) o |= (m & (0x1111111111111111ull << kk)) ? (1u << kk) : 0u;
+        return o;
+    } else if (QW == 2) {
+        const unsigned long long m = nzm[pt];
+        return ((m & 0x5555555555555555ull) ? 1u : 0u) | ((m & 0xaaaaaaaaaaaaaaaaull) ? 2u : 0u);
+    } else {
+        const unsigned long long m = nzm[pt >> 1];
+        return ((pt & 1) ? (m >> 32) : (m & 0xffffffffull)) ? 1u : 0u;
+    }
+}
+
+// In-workgroup split-K reduction and the fused epilogue.
+//
+// Reduction: every wave stores its 32 x 32 partial tile as a slab [i*4+j][lane] (pitch 72 ints;
+// the cols-layout epilogue stores it with the lane index transposed), so that four consecutive
+// ints are four consecutive columns of a row (rows of a column). After the single barrier a
+// thread sums one quad over the slabs with ds_read_b128. (LDS atomics were measured: 16
+// ds_add_u32 per wave cost ~1300 cycles, four times the plain stores plus the wide reads.)
+//
+// Epilogue (MODE 0 rows-layout bits, 1 cols-layout bits, 2 float32): a thread requantises its
+// quad and builds the quad's nibble of each output plane; eight adjacent lanes OR their nibbles
+// into the 32-bit word of one row (column) of the tile with DPP. 256 threads finish a tile, so
+// in workgroups of 4+ waves the upper waves leave right after the barrier. What runs here is
+// latency-bound (a few waves, dependent instructions), so the code is kept short: every
+// instruction behind the barrier costs the whole workgroup ~8 cycles.
+// What a thread needs to finish its quad besides the sums. (Computing it at kernel start, under the
+// first loads' latency, was measured: it shortens the tail by ~300 cycles but costs as much in the
+// prologue and 5 VGPRs across the main loop.)
+struct QuadPlan {
+    uint32_t src;     // byte offset of the thread's elements inside a slab
+    uint32_t *dst;    // first output word (or float) of the thread's elements
+    int nvalid;       // leading elements that exist (rows layout / float: columns; cols layout: rows)
+    uint32_t sh_n;    // shift of the thread's bits inside the 32-bit word; bit 31: this lane stores the word
+};
+
+// OR over aligned groups of 32/E lanes (E = 4: 8 lanes, E = 2: 16 lanes = one DPP row)
+template <int E>
+__device__ __forceinline__ uint32_t or_reduce_group(uint32_t x) {
+    x = or_reduce8(x);
+    if (E == 2)  // 15 - lane within the row of 16: joins the two 8-lane halves
+        x |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x140, 0xf, 0xf, false));
+    return x;
+}
+
+// E consecutive elements per thread (E = 4: a quad, 256 threads finish a tile; E = 2: a pair, 512
+// threads - used by 8-wave workgroups so that every SIMD has two waves to interleave in the
+// latency-bound tail). Thread t = hi | a8 | lo | h with h the E-group inside the 8 columns (rows)
+// of micro-tile block (i, j); rows layout / float: (hi,lo) = (i,j), cols layout: (j,i).
+template <int MODE, int E>
+__device__ __forceinline__ QuadPlan quad_plan(const qgtc_problem &pr, int t, int m0, int n0) {
+    constexpr int HB = E == 4 ? 1 : 2;       // bits of h
+    constexpr int G = 32 / E;                // threads per output word
+    const int M = pr.M, N = pr.N;
+    const int h = t & ((1 << HB) - 1), lo = (t >> HB) & 3, a8 = (t >> (HB + 2)) & 7, hi = (t >> (HB + 5)) & 3;
+    const int i = MODE == 1 ? lo : hi, j = MODE == 1 ? hi : lo;
+    QuadPlan q;
+    q.src = static_cast<uint32_t>(((i * MC + j) * SLAB_PITCH + a8 * 8 + h * E) * 4);
+    const int m = MODE == 1 ? m0 + 8 * i + E * h : m0 + a8 + 8 * i;
+    const int n = MODE == 1 ? n0 + a8 + 8 * j : n0 + 8 * j + E * h;
+    // valid elements: rows layout / float (m, n+e), cols layout (m+e, n)
+    q.nvalid = MODE == 1 ? (n < N ? min(max(M - m, 0), E) : 0) : (m < M ? min(max(N - n, 0), E) : 0);
+    // rows layout [ob][PAD8(M)][STEP128(N)*4] (reference kernel.h:357-389): word (m, n0/32);
+    // cols layout [ob][PAD128(N)][STEP128(M)*4] (intended semantics of kernel.h:651-810): word (n, m0/32);
+    // float32 [M,N] (reference kernel.h:915-930): row m, columns n .. n+E-1
+    const size_t o0 = MODE == 2 ? static_cast<size_t>(m) * N + n
+                    : MODE == 0 ? static_cast<size_t>(m) * (step128(N) * 4) + (n0 >> 5)
+                                : static_cast<size_t>(n) * (step128(M) * 4) + (m0 >> 5);
+    q.dst = static_cast<uint32_t *>(pr.out) + o0;
+    const bool store = (t & (G - 1)) == 0 && (MODE == 0 ? m < pad8(M) : n < pad128(N));
+    // element e of the word's 32 sits at bit 31 - e; this thread holds e = E*(t % G) .. +E-1
+    q.sh_n = static_cast<uint32_t>(32 - E - E * (t & (G - 1))) | (store ? 0x80000000u : 0u);
+    return q;
+}
+
+template <int MODE, int E, bool INT_RQ, bool ALL8>
+__device__ __forceinline__ void quad_finish(const qgtc_problem &pr, const MMShape &sh, const QuadPlan &q,
+                                            int extra, size_t oplane, const unsigned char *slabs, int nwv STAMP_ARG) {
+    typedef int ivec __attribute__((ext_vector_type(E)));
+    ivec part[MAX_WAVES];
+#pragma unroll
+    for (int k = 0; k < MAX_WAVES; k++)  // slabs that do not exist alias slab 0 and are masked
+        part[k] = *reinterpret_cast<const ivec *>(slabs + q.src + ((ALL8 || k < nwv) ? k : 0) * SLAB_BYTES);
+    int v[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) v[e] = 0;
+#pragma unroll
+    for (int k = 0; k < MAX_WAVES; k++) {
+        const bool on = ALL8 || k < nwv;
+#pragma unroll
+        for (int e = 0; e < E; e++) v[e] += on ? part[k][e] : 0;
+    }
+#ifdef QGTC_STAMPS
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]));
+    STAMP(11);
+#endif
+    if (MODE == 2) {
+        float *dst = reinterpret_cast<float *>(q.dst);
+        if (q.nvalid == E && (pr.N & (E - 1)) == 0) {
+            typedef float fvec __attribute__((ext_vector_type(E)));
+            fvec f;
+#pragma unroll
+            for (int e = 0; e < E; e++) f[e] = static_cast<float>(v[e]);
+            *reinterpret_cast<fvec *>(dst) = f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; e++)
+                if (e < q.nvalid) dst[e] = static_cast<float>(v[e]);
+        }
+        return;
+    }
+    const int maxi = 1 << (sh.ob & 31);
+    uint32_t qv[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        int c;
+        if (INT_RQ) c = v[e] < 0 ? 1 : (v[e] > maxi ? maxi - 1 : v[e]);  // kernel.h:31-37
+        else c = requant(v[e], sh.maxv, sh.maxm1);
+        qv[e] = e < q.nvalid ? static_cast<uint32_t>(c) : 0u;
+    }
+#ifdef QGTC_STAMPS
+    asm volatile("" : "+v"(qv[0]), "+v"(qv[1]));
+    STAMP(12);
+#endif
+    const bool store = (q.sh_n >> 31) != 0u;
+    const uint32_t sh_n = q.sh_n & 31u;
+    uint32_t *out = q.dst;
+    for (int p = 0; p < sh.ob; p++, out += oplane) {
+        uint32_t bits = 0u;
+#pragma unroll
+        for (int e = 0; e < E; e++) bits |= ((qv[e] >> p) & 1u) << (E - 1 - e);
+        const uint32_t word = or_reduce_group<E>(bits << sh_n);
+#ifndef QGTC_ABL_NOSTORE
+        if (store) {
+            out[0] = word;
+            for (int x = 1; x <= extra; x++) out[x] = 0u;  // row words past the last column tile
+        }
+#else
+        asm volatile("" ::"v"(word));
+#endif
+    }
+}
+
+// Epilogue of a single-wave workgroup (the wave owns the whole K range, nothing to reduce): straight
+// from the accumulators. Lane (lm, ln) holds rows lm + 8i and columns ln + 8j, so the 32 columns
+// of a row live in the 8 lanes of one aligned group (4 each): a DPP OR assembles the row word.
+// For the cols layout the 32 rows of a column live in the 8 lanes ln, ln+8, .., ln+56.
+template <int MODE>
+__device__ __forceinline__ void epi_direct(const qgtc_problem &pr, const MMShape &sh,
+                                           const uint32_t (&tot)[MR][MC], int tm, int tn, int tiles_n) {
+    const int lane = threadIdx.x & 63, lm = lane >> 3, ln = lane & 7;
+    const int M = pr.M, N = pr.N, m0 = tm * TM, n0 = tn * TN;
+    if (MODE == 2) {  // float32 [M,N] (reference kernel.h:915-930)
+        float *out = static_cast<float *>(pr.out);
+#pragma unroll
+        for (int i = 0; i < MR; i++)
+#pragma unroll
+            for (int j = 0; j < MC; j++) {
+                const int m = m0 + lm + 8 * i, n = n0 + ln + 8 * j;
+                if (m < M && n < N) out[static_cast<size_t>(m) * N + n] = static_cast<float>(static_cast<int>(tot[i][j]));
+            }
+        return;
+    }
+    const bool int_rq = sh.ob <= 23;
+    const int maxi = 1 << (sh.ob & 31);
+    uint32_t qv[MR][MC];
+#pragma unroll
+    for (int i = 0; i < MR; i++)
+#pragma unroll
+        for (int j = 0; j < MC; j++) {
+            const int c = static_cast<int>(tot[i][j]);
+            const int r = int_rq ? (c < 0 ? 1 : (c > maxi ? maxi - 1 : c)) : requant(c, sh.maxv, sh.maxm1);
+            qv[i][j] = (m0 + lm + 8 * i < M && n0 + ln + 8 * j < N) ? static_cast<uint32_t>(r) : 0u;
+        }
+    uint32_t *out = static_cast<uint32_t *>(pr.out);
+    if (MODE == 0) {  // rows layout [ob][PAD8(M)][STEP128(N)*4] (reference kernel.h:357-389)
+        const int rows_pad = pad8(M), row_words = step128(N) * 4;
+        const size_t oplane = static_cast<size_t>(rows_pad) * row_words;
+        const int extra = tn == tiles_n - 1 ? row_words - (n0 >> 5) - 1 : 0;
+#pragma unroll
+        for (int i = 0; i < MR; i++) {
+            const int m = m0 + lm + 8 * i;
+            uint32_t *dst = out + static_cast<size_t>(m) * row_words + (n0 >> 5);
+            for (int p = 0; p < sh.ob; p++, dst += oplane) {
+                // column ln + 8j sits at bit 31 - ln - 8j = (24 - 8j) + (7 - ln)
+                const uint32_t x = (((qv[i][0] >> p) & 1u) << 24) | (((qv[i][1] >> p) & 1u) << 16) |
+                                   (((qv[i][2] >> p) & 1u) << 8) | ((qv[i][3] >> p) & 1u);
+                const uint32_t word = or_reduce8(x << (7 - ln));
+                if (ln == 0 && m < rows_pad) {
+                    dst[0] = word;
+                    for (int e = 1; e <= extra; e++) dst[e] = 0u;
+                }
+            }
+        }
+    } else {  // cols layout [ob][PAD128(N)][STEP128(M)*4] (intended semantics of kernel.h:651-810)
+        const int lines = pad128(N), line_words = step128(M) * 4;
+        const size_t oplane = static_cast<size_t>(lines) * line_words;
+#pragma unroll
+        for (int j = 0; j < MC; j++) {
+            const int n = n0 + ln + 8 * j;
+            uint32_t *dst = out + static_cast<size_t>(n) * line_words + (m0 >> 5);
+            for (int p = 0; p < sh.ob; p++, dst += oplane) {
+                // row lm + 8i sits at bit 31 - lm - 8i
+                uint32_t x = (((qv[0][j] >> p) & 1u) << 24) | (((qv[1][j] >> p) & 1u) << 16) |
+                             (((qv[2][j] >> p) & 1u) << 8) | ((qv[3][j] >> p) & 1u);
+                x <<= (7 - lm);
+                x |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(x), 8));
+                x |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(x), 16));
+                x |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(x), 32));
+                if (lm == 0 && n < lines) dst[0] = x;
+            }
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void epi_finish(const qgtc_problem &pr, const MMShape &sh,
+                                           const uint32_t (&tot)[MR][MC], int tm, int tn,
+                                           int tiles_m, int tiles_n, unsigned char *slabs STAMP_ARG) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwv = sh.waves, NT = nwv * 64;
+    const int lm = lane >> 3, ln = lane & 7;
+    const int M = pr.M, N = pr.N, m0 = tm * TM, n0 = tn * TN;
+    const bool last_n = tn == tiles_n - 1, last_m = tm == tiles_m - 1;
+    const size_t oplane = MODE == 0 ? static_cast<size_t>(pad8(M)) * (step128(N) * 4)
+                                    : static_cast<size_t>(pad128(N)) * (step128(M) * 4);
+    if (nwv == 1) {
+        epi_direct<MODE>(pr, sh, tot, tm, tn, tiles_n);
+    } else {
+        int *mine = reinterpret_cast<int *>(slabs + wv * SLAB_BYTES) + (MODE == 1 ? ln * 8 + lm : lane);
+#pragma unroll
+        for (int i = 0; i < MR; i++)
+#pragma unroll
+            for (int j = 0; j < MC; j++) mine[(i * MC + j) * SLAB_PITCH] = static_cast<int>(tot[i][j]);
+    }
+    STAMP(8);
+    if (nwv > 1) __syncthreads();
+    STAMP(9);
+    const int extra = (MODE == 0 && last_n) ? step128(N) * 4 - (n0 >> 5) - 1 : 0;
+    if (nwv == 1) {
+    } else if (nwv == MAX_WAVES && sh.ob <= 23) {  // every slab exists: all 512 threads finish a pair each
+        const QuadPlan q = quad_plan<MODE, 2>(pr, tid, m0, n0);
+#ifdef QGTC_STAMPS
+        asm volatile("" ::"v"(q.src), "v"(q.dst), "v"(q.nvalid), "v"(q.sh_n));
+        STAMP(10);
+#endif
+        quad_finish<MODE, 2, true, true>(pr, sh, q, extra, oplane, slabs, nwv STAMP_PASS);
+    } else {
+        for (int t = tid; t < 256; t += NT) {
+            const QuadPlan q = quad_plan<MODE, 4>(pr, t, m0, n0);
+            // float(c) > 2^ob  <=>  c > 2^ob for every int c >= 0: integer requantisation when ob <= 23
+            if (sh.ob > 23) quad_finish<MODE, 4, false, false>(pr, sh, q, extra, oplane, slabs, nwv STAMP_PASS);
+            else quad_finish<MODE, 4, true, false>(pr, sh, q, extra, oplane, slabs, nwv STAMP_PASS);
+        }
+    }
+    STAMP(14);
+    if (MODE == 1) {
+        // zero what no tile computes: words past the last row tile, lines past the last column tile
+        uint32_t *out = static_cast<uint32_t *>(pr.out);
+        const int lines = pad128(N), line_words = step128(M) * 4;
+        const int w_core0 = m0 >> 5, w_core1 = min(line_words, w_core0 + 1);
+        if (last_m && w_core1 < line_words) {
+            for (int e = tid; e < sh.ob * TN; e += NT) {
+                const int line = n0 + (e & (TN - 1)), p = e / TN;
+                if (line < lines)
+                    for (int wi = w_core1; wi < line_words; wi++)
+                        out[p * oplane + static_cast<size_t>(line) * line_words + wi] = 0u;
+            }
+        }
+        if (last_n && n0 + TN < lines) {
+            const int nl = lines - (n0 + TN), w_end = last_m ? line_words : w_core1;
+            for (int e = tid; e < sh.ob * nl; e += NT) {
+                const int line = n0 + TN + e % nl, p = e / nl;
+                for (int wi = w_core0; wi < w_end; wi++)
+                    out[p * oplane + static_cast<size_t>(line) * line_words + wi] = 0u;
+            }
+        }
+    }
+}
+
+// One output tile (tm, tn) of one problem. All threads of the workgroup call this.
+// NA, NW > 0: compile-time plane counts (== sh.a, sh.w), QW k-quads per stage;
+// NA == NW == 0: generic kernel, runtime plane blocks sh.ab x sh.wb, QW = 1.
+template <int QW, int NA, int NW, bool ZS, bool OCC>
+__device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &sh, int tm, int tn,
+                                        int tiles_m, int tiles_n, unsigned char *smem) {
+    constexpr bool GEN = NA == 0;
+    static_assert(!GEN || QW == 1, "the generic kernel stages one k-quad at a time");
+    constexpr int RS = lds_pitch(QW);
+    STAMP_DECL;
+    STAMP(0);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwv = sh.waves;
+    const int lm = lane >> 3, ln = lane & 7;
+
+    const int M = pr.M, K = pr.K, N = pr.N;
+    const int kq = step128(K);                   // k-quads per packed row
+    const uint32_t kw = static_cast<uint32_t>(kq) * 4u;
+    const uint32_t x_plane = static_cast<uint32_t>(pad8(M)) * kw;  // < 2^30 words (host-checked)
+    const uint32_t w_plane = static_cast<uint32_t>(pr.w_lines) * kw;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int ab = GEN ? sh.ab : NA, wb = GEN ? sh.wb : NW;
+    const int nsx = GEN ? slots_for(ab, 1) : slots_for(NA, QW);
+    const int nsw = GEN ? slots_for(wb, 1) : slots_for(NW, QW);
+    const int ks = wv * sh.per, ke = min(ks + sh.per, kq);  // this wave's k-quads
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(pr.X), 0, static_cast<int>(static_cast<uint32_t>(pr.x_words) * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(pr.W), 0, static_cast<int>(static_cast<uint32_t>(pr.w_words) * 4u), 0x00020000);
+
+    // this wave's staging region: X plane tiles, then W plane tiles
+    u32x4 *region = reinterpret_cast<u32x4 *>(smem) + wv * ((ab + wb) * QW * RS);
+    const int wreg = ab * QW * RS;  // first granule of the W tiles
+
+    // Per-lane slot table (slot u < nsx: X, else W). Only the stage origin (plane block, first
+    // k-quad) changes from stage to stage and it is wave-uniform.
+    uint32_t s_off[GPT];   // byte offset of the granule from the stage origin
+    uint32_t s_lds[GPT];   // granule index inside the region
+    uint32_t v_in = 0u;    // bit u: the lane's granule of slot u lies inside the region
+    uint32_t v_ok = 0u;    // bit u: ... and its line exists (row < M / column < N)
+    int kkl = 0;           // the lane's k-quad within the chunk (same for every slot)
+#pragma unroll
+    for (int u = 0; u < GPT; u++) {
+        s_off[u] = 0u;
+        s_lds[u] = 0u;
+        if (u >= nsx + nsw) continue;
+        const bool is_x = u < nsx;
+        int pt, line, kk;
+        slot_map<QW>(is_x ? u : u - nsx, lane, pt, line, kk);
+        kkl = kk;
+        const bool in = pt < (is_x ? ab : wb);
+        const uint32_t gline = static_cast<uint32_t>((is_x ? m0 : n0) + line);
+        const bool ok = in && static_cast<int>(gline) < (is_x ? M : N);
+        s_off[u] = (static_cast<uint32_t>(pt) * (is_x ? x_plane : w_plane) + gline * kw) * 4u;
+        s_lds[u] = static_cast<uint32_t>((is_x ? 0 : wreg) + (pt * QW + kk) * RS + line);
+        v_in |= in ? (1u << u) : 0u;
+        v_ok |= ok ? (1u << u) : 0u;
+    }
+
+    // One stage = up to QW k-quads of one (X plane block, W plane block). The k-quads a wave visits
+    // are either all of its slice [ks, ke) in order, or - when the caller supplies the occupancy
+    // bitmap of the left operand (pr.occ: one bit per 32-row tile and k-quad) - only those whose
+    // X tile has a bit set: zero tiles are then neither loaded nor multiplied ("zero-tile jumping").
+    struct Stage {
+        int pa0, pw0;
+        int i0, i1, i2, i3;  // k-quad of slot kk = 0..3 (named fields: an indexed array lands in scratch)
+        int nk;              // slots in use
+        bool valid;
+    };
+    const uint64_t *occ_row = (OCC && pr.occ) ? pr.occ + static_cast<size_t>(tm) * pr.occ_words : nullptr;
+    int k_next = ks;                // dense mode: next k-quad
+    int k_word = 0;                 // bitmap mode: current 64-k-quad word
+    unsigned long long k_mask = 0;  // bitmap mode: unvisited k-quads of the current word, inside [ks, ke)
+    auto k_word_mask = [&](int wi) -> unsigned long long {
+        unsigned long long m = occ_row[wi];
+        const int lo = ks - wi * 64, hi = ke - wi * 64;  // keep bits [lo, hi)
+        if (lo > 0) m &= ~0ull << lo;
+        if (hi < 64) m &= hi > 0 ? ~0ull >> (64 - hi) : 0ull;
+        return m;
+    };
+    auto k_reset = [&]() {
+        k_next = ks;
+        if (occ_row) {
+            k_word = ks >> 6;
+            k_mask = ks < ke ? k_word_mask(k_word) : 0ull;
+        }
+    };
+    // the next k-quads of the slice as a stage (by value: a Stage passed by reference through
+    // the lambdas ends up in scratch); .valid = false when the wave's slice is exhausted
+    auto k_take = [&](int pa0, int pw0) -> Stage {
+        Stage st{pa0, pw0, 0, 0, 0, 0, 0, false};
+        if (!occ_row) {
+            if (k_next >= ke) return st;
+            st.i0 = k_next;
+            st.i1 = k_next + 1;
+            st.i2 = k_next + 2;
+            st.i3 = k_next + 3;
+            st.nk = min(QW, ke - k_next);
+            st.valid = true;
+            k_next += QW;
+            return st;
+        }
+        while (k_mask == 0ull) {
+            k_word++;
+            if (k_word * 64 >= ke) return st;
+            k_mask = k_word_mask(k_word);
+        }
+        st.valid = true;
+        // pop the lowest unvisited k-quads of the word (plain locals: a lambda capturing `st` by
+        // reference keeps the struct in scratch)
+        int nk = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+        unsigned long long m = k_mask;
+#define QGTC_POP(dst)                                \
+    if (m != 0ull) {                                 \
+        dst = k_word * 64 + __builtin_ctzll(m);      \
+        m &= m - 1ull;                               \
+        nk++;                                        \
+    }
+        QGTC_POP(q0)
+        if (QW > 1) { QGTC_POP(q1) }
+        if (QW > 2) { QGTC_POP(q2) QGTC_POP(q3) }
+#undef QGTC_POP
+        k_mask = m;
+        st.i0 = q0;
+        st.i1 = q1;
+        st.i2 = q2;
+        st.i3 = q3;
+        st.nk = nk;
+        return st;
+    };
+    auto first_stage = [&]() -> Stage {
+        k_reset();
+        return k_take(0, 0);  // an empty slice (or an all-zero row tile) has no stage at all
+    };
+    auto next_stage = [&](const Stage &prev) -> Stage {
+        Stage st = k_take(prev.pa0, prev.pw0);
+        if (st.valid) return st;
+        // the k range is exhausted: next plane block (generic kernel only), restart the k iteration
+        int pa0 = prev.pa0, pw0 = prev.pw0 + wb;
+        if (pw0 >= sh.w) {
+            pw0 = 0;
+            pa0 += ab;
+            if (pa0 >= sh.a) return st;  // invalid
+        }
+        k_reset();
+        return k_take(pa0, pw0);
+    };
+
+    // issue the loads of one stage into registers; lanes whose granule does not exist (row or
+    // column out of range, plane or k-quad beyond this stage) load from offset 0xffffffff, which
+    // the range check turns into zeros
+    u32x4 pre[GPT];
+    auto issue = [&](const int pa0, const int pw0, const int i0, const int i1, const int i2, const int i3,
+                     const int nk_) {
+        // (scalars by value: selecting among the fields of a Stage passed by reference makes hipcc
+        // spill the struct and load the field through a computed scratch address)
+        const int na = min(ab, sh.a - pa0), nw = min(wb, sh.w - pw0);
+        const uint32_t xo = static_cast<uint32_t>(pa0) * x_plane * 4u;
+        const uint32_t wo = static_cast<uint32_t>(pw0) * w_plane * 4u;
+        // the lane's k-quad, as byte offset inside the packed row
+        uint32_t ko = static_cast<uint32_t>(i0) * 16u;
+        if (QW > 1) ko = kkl == 1 ? static_cast<uint32_t>(i1) * 16u : ko;
+        if (QW > 2) {
+            ko = kkl == 2 ? static_cast<uint32_t>(i2) * 16u : ko;
+            ko = kkl == 3 ? static_cast<uint32_t>(i3) * 16u : ko;
+        }
+        const bool kk_ok = kkl < nk_;
+#pragma unroll
+        for (int u = 0; u < GPT; u++) {
+            if (u >= nsx + nsw) break;
+            const bool is_x = u < nsx;
+            bool ok = ((v_ok >> u) & 1u) && kk_ok;
+            if (GEN) {
+                const int pt = 2 * (is_x ? u : u - nsx) + (lane >> 5);
+                ok = ok && pt < (is_x ? na : nw);
+            }
+            const uint32_t off = ok ? s_off[u] + (is_x ? xo : wo) + ko : 0xffffffffu;
+            pre[u] = __builtin_amdgcn_raw_buffer_load_b128(is_x ? rx : rw, off, 0, 0);
+        }
+    };
+
+    Stage cur = first_stage();
+    STAMP(1);
+    if (cur.valid) issue(cur.pa0, cur.pw0, cur.i0, cur.i1, cur.i2, cur.i3, cur.nk);
+    STAMP(2);
+
+    uint32_t tot[MR][MC];  // unsigned: the reference's int32 accumulation wraps on overflow
+#pragma unroll
+    for (int i = 0; i < MR; i++)
+#pragma unroll
+        for (int j = 0; j < MC; j++) tot[i][j] = 0u;
+
+    // fixed kernels keep one accumulator set per shift (pa + pw) for the whole K slice
+    constexpr int NS = GEN ? 1 : NA + NW - 1;
+    uint32_t acc[NS][MR][MC];
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int i = 0; i < MR; i++)
+#pragma unroll
+            for (int j = 0; j < MC; j++) acc[s][i][j] = 0u;
+
+    const u32x4 *xrd = region + lm;         // + (pa*QW + kk)*RS + 8*i
+    const u32x4 *wrd = region + wreg + ln;  // + (pw*QW + kk)*RS + 8*j
+    auto read_x = [&](int tile_kk, u32x4 (&xr)[MR]) {
+#pragma unroll
+        for (int i = 0; i < MR; i++) xr[i] = xrd[tile_kk * RS + 8 * i];
+    };
+    auto read_w = [&](int tile_kk, u32x4 (&wr)[MC]) {
+#pragma unroll
+        for (int j = 0; j < MC; j++) wr[j] = wrd[tile_kk * RS + 8 * j];
+    };
+
+    for (int it = 0; cur.valid; it++) {
+        // ---- registers -> LDS, and the occupancy ballots of the X tiles ----
+        unsigned long long nzm[GPT];
+#pragma unroll
+        for (int u = 0; u < GPT; u++) {
+            nzm[u] = 0ull;
+            if (u >= nsx + nsw) continue;
+            if ((v_in >> u) & 1u) region[s_lds[u]] = pre[u];
+            if (ZS && u < nsx) nzm[u] = __ballot(((pre[u].x | pre[u].y) | (pre[u].z | pre[u].w)) != 0u);
+        }
+        if (it == 0) STAMP(3);
+        const Stage now = cur;
+        cur = next_stage(now);
+        // the next stage's loads fly while this one is multiplied
+        if (cur.valid) issue(cur.pa0, cur.pw0, cur.i0, cur.i1, cur.i2, cur.i3, cur.nk);
+        // the wave reads what its other lanes wrote: LDS is in order per wave, the fence only
+        // keeps the compiler from moving the reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (it == 0) STAMP(4);
+
+        const int nk = now.nk;
+        if constexpr (!GEN) {
+            uint32_t occ[NA];
+#pragma unroll
+            for (int pa = 0; pa < NA; pa++) occ[pa] = ZS ? tile_occupancy<QW>(nzm, pa) : ((1u << nk) - 1u);
+            constexpr int NOUT = QW * NA;  // (k-quad, X plane) pairs
+            if constexpr (NOUT * NW <= 8) {
+                // flat software pipeline over every (k-quad, X plane, W plane) step of the stage:
+                // the granules of step t+1 are read from LDS while step t is multiplied
+                constexpr int T = NOUT * NW;
+                // X granules: double-buffered only when they change every step (NW == 1); with several W
+                // planes per X tile one set is enough (the next tile's X is read behind its last
+                // multiply) and 16 VGPRs fewer buy the (1,2) kernel a fourth wave per SIMD
+                constexpr int XB = NW == 1 ? 2 : 1;
+                u32x4 xg[XB][MR], wg[2][MC];
+                read_x(0, xg[0]);
+                read_w(0, wg[0]);
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+                    const int o = t / NW, pw = t % NW, kk = o / NA, pa = o % NA;
+#ifdef QGTC_ABL_NOLDS  // timing-only build: every step multiplies the first step's granules
+                    if (t == 0) {
+                        read_w(1, wg[1]);
+                        read_x(1, xg[1]);
+                    }
+#else
+                    if (t + 1 < T) {
+                        const int o1 = (t + 1) / NW, pw1 = (t + 1) % NW, kk1 = o1 / NA, pa1 = o1 % NA;
+                        read_w(pw1 * QW + kk1, wg[(t + 1) & 1]);
+                        if (XB == 2 && pw1 == 0) read_x(pa1 * QW + kk1, xg[o1 & 1]);
+                    }
+#endif
+#ifdef QGTC_ABL_NOMAC  // timing-only build: keep the LDS reads, skip the multiply
+                    asm volatile("" ::"v"(xg[o % XB][0].x), "v"(wg[t & 1][0].x), "v"(xg[o % XB][3].w), "v"(wg[t & 1][3].w));
+#else
+                    if ((occ[pa] >> kk) & 1u) mac_quad(acc[pa + pw], xg[o % XB], wg[t & 1]);
+#endif
+                    if (XB == 1 && t + 1 < T && (t + 1) % NW == 0) {
+                        const int o1 = (t + 1) / NW;
+                        read_x((o1 % NA) * QW + o1 / NA, xg[0]);
+                    }
+                }
+            } else {
+                // k-quads in a loop, the (X plane, W plane) steps of one k-quad unrolled
+#pragma unroll 1
+                for (int kk = 0; kk < nk; kk++) {
+                    u32x4 xg[MR], wg[2][MC];
+#pragma unroll
+                    for (int pa = 0; pa < NA; pa++) {
+                        if (!((occ[pa] >> kk) & 1u)) continue;
+                        read_x(pa * QW + kk, xg);
+                        read_w(kk, wg[0]);
+#pragma unroll
+                        for (int pw = 0; pw < NW; pw++) {
+                            if (pw + 1 < NW) read_w((pw + 1) * QW + kk, wg[(pw + 1) & 1]);
+                            mac_quad(acc[pa + pw], xg, wg[pw & 1]);
+                        }
+                    }
+                }
+            }
+        } else {
+            const int na = min(ab, sh.a - now.pa0), nw = min(wb, sh.w - now.pw0);
+            uint32_t occ = 0u;  // bit pa: X plane tile pa of the stage has a set bit
+#pragma unroll
+            for (int u = 0; u < GPT / 2; u++)
+                occ |= ((nzm[u] & 0xffffffffull) ? (1u << (2 * u)) : 0u) | ((nzm[u] >> 32) ? (2u << (2 * u)) : 0u);
+            for (int pa = 0; pa < na; pa++) {
+                if (ZS && !((occ >> pa) & 1u)) continue;
+                u32x4 xg[MR];
+                read_x(pa, xg);
+                for (int pw = 0; pw < nw; pw++) {
+                    u32x4 wg[MC];
+                    read_w(pw, wg);
+#pragma unroll
+                    for (int i = 0; i < MR; i++)
+#pragma unroll
+                        for (int j = 0; j < MC; j++) acc[0][i][j] = 0u;
+                    mac_quad(acc[0], xg, wg);
+                    const int s = now.pa0 + pa + now.pw0 + pw;  // reference kernel.h:295,340
+                    if (s < 32) {
+#pragma unroll
+                        for (int i = 0; i < MR; i++)
+#pragma unroll
+                            for (int j = 0; j < MC; j++) tot[i][j] += acc[0][i][j] << s;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (it == 0) STAMP(5);
+    }
+    if constexpr (!GEN) {
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+#pragma unroll
+            for (int i = 0; i < MR; i++)
+#pragma unroll
+                for (int j = 0; j < MC; j++) tot[i][j] += acc[s][i][j] << s;
+    }
+    STAMP(7);
+#ifdef QGTC_ABL_NOEPI  // timing-only build: keep the sums alive, skip the reduction and epilogue
+#pragma unroll
+    for (int i = 0; i < MR; i++)
+#pragma unroll
+        for (int j = 0; j < MC; j++) asm volatile("" ::"v"(tot[i][j]));
+    return;
+#endif
+    unsigned char *slabs = smem + nwv * ((ab + wb) * QW * RS * 16);
+    if (sh.mode == 0) epi_finish<0>(pr, sh, tot, tm, tn, tiles_m, tiles_n, slabs STAMP_PASS);
+    else if (sh.mode == 1) epi_finish<1>(pr, sh, tot, tm, tn, tiles_m, tiles_n, slabs STAMP_PASS);
+    else epi_finish<2>(pr, sh, tot, tm, tn, tiles_m, tiles_n, slabs STAMP_PASS);
+    STAMP(15);
+    STAMP_FLUSH();
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so blocks b and b+8
+// share an L2. Map block ids to tiles so that each XCD owns a contiguous range of tile ids: the
+// column tiles of one row tile (which read the same X rows) then hit the same L2. Bijective for
+// any grid size; placement only affects speed, never results.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    constexpr int NX = 8;
+    const int q = nblocks / NX, r = nblocks % NX;
+    const int xcd = bid % NX, idx = bid / NX;
+    return xcd * q + min(xcd, r) + idx;
+}
+
+template <int QW, int NA, int NW, bool ZS>
+__global__ __launch_bounds__(64 * MAX_WAVES) void k_bitmm(qgtc_problem pr, MMShape sh, int tiles_m,
+                                                          int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // pull every kernel argument into SGPRs with ONE scalar-load round trip (hipcc otherwise loads
+    // them lazily in four dependent rounds, ~200 cycles each, ahead of the first global load)
+    asm volatile("" ::"s"(pr.X), "s"(pr.W), "s"(pr.out), "s"(pr.x_words), "s"(pr.w_words), "s"(pr.M), "s"(pr.K),
+                 "s"(pr.N), "s"(pr.w_lines), "s"(sh.a), "s"(sh.w), "s"(sh.ob), "s"(sh.mode), "s"(sh.per),
+                 "s"(sh.inv_tiles_n), "s"(sh.waves), "s"(tiles_m), "s"(tiles_n));
+    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    // tile / tiles_n by multiply-high with floor(2^32 / tiles_n) (from the host) + one correction
+    int tm = static_cast<int>(__umulhi(static_cast<uint32_t>(tile), sh.inv_tiles_n));
+    int tn = tile - tm * tiles_n;
+    if (tn >= tiles_n) {
+        tn -= tiles_n;
+        tm++;
+    }
+    mm_tile<QW, NA, NW, ZS, false>(pr, sh, tm, tn, tiles_m, tiles_n, smem);
+}
+
+// grouped launch: blockIdx.y = problem, blockIdx.x = tile (surplus tiles exit at once)
+template <int QW, int NA, int NW, bool ZS, bool OCC>
+__global__ __launch_bounds__(64 * MAX_WAVES) void k_bitmm_batched(const qgtc_problem *__restrict__ prs,
+                                                                  MMShape sh) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const qgtc_problem pr = prs[blockIdx.y];
+    const int tiles_m = (pr.M + TM - 1) / TM, tiles_n = (pr.N + TN - 1) / TN;
+    const int tile = blockIdx.x;
+    if (tile >= tiles_m * tiles_n) return;
+    mm_tile<QW, NA, NW, ZS, OCC>(pr, sh, tile / tiles_n, tile % tiles_n, tiles_m, tiles_n, smem);
+}
+
+}  // namespace

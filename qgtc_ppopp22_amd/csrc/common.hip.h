@@ -1,0 +1,65 @@
+// common.hip.h — part of libqgtc_hip.so (included by qgtc_hip.hip, one translation unit).
+// Shared device helpers of the QGTC kernels: vector types, the reference's shape algebra, the
+// quantiser and the 8-lane DPP OR used by every packer.
+#pragma once
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int TM = 32, TN = 32;  // workgroup tile of the bit-GEMM
+
+// ------------------------------------------------------------------------------------------
+// shape algebra (reference utility.h:33-45)
+// ------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int step8(int x) { return (x + 7) >> 3; }
+__host__ __device__ constexpr int step128(int x) { return (x + 127) >> 7; }
+__host__ __device__ constexpr int pad8(int x) { return step8(x) << 3; }
+__host__ __device__ constexpr int pad128(int x) { return step128(x) << 7; }
+
+thread_local char g_hip_err[256] = "";
+
+int hip_fail(hipError_t e, const char *where) {
+    snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", where, hipGetErrorString(e));
+    return QGTC_EHIP;
+}
+#define HIP_TRY(expr)                                        \
+    do {                                                     \
+        hipError_t e_ = (expr);                              \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr);    \
+    } while (0)
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool bits_ok(int b) { return b >= 1 && b <= 32; }
+
+// bounds-safe word / granule loads: indices past the buffer read as zero
+__device__ __forceinline__ uint32_t ldw(const uint32_t *__restrict__ p, unsigned long long n,
+                                        unsigned long long i) {
+    return i < n ? p[i] : 0u;
+}
+__device__ __forceinline__ uint4 ldg4(const uint32_t *__restrict__ p, unsigned long long n,
+                                      unsigned long long i) {
+    if (i + 4 <= n) return *reinterpret_cast<const uint4 *>(p + i);
+    return make_uint4(ldw(p, n, i), ldw(p, n, i + 1), ldw(p, n, i + 2), ldw(p, n, i + 3));
+}
+
+// ------------------------------------------------------------------------------------------
+// quantisation (reference kernel.h:39-44 clip, :68 __float2int_rn)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t quant1(float x, float ub, float ubm1) {
+    float y = x;
+    if (x < 0.0f) y = 1.0f;       // negative -> lb + 1
+    else if (x > ub) y = ubm1;    // above 2^b -> 2^b - 1 (float arithmetic)
+    if (y != y) return 0u;        // NaN converts to 0
+    const float r = rintf(y);     // v_rndne_f32: round-half-to-even
+    return r >= 4294967296.0f ? 0u : static_cast<uint32_t>(r);  // low 32 bits (nbits >= 31 only)
+}
+
+// OR over aligned groups of 8 lanes (every lane of the wave must be active)
+__device__ __forceinline__ uint32_t or_reduce8(uint32_t x) {
+    x |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0xB1, 0xf, 0xf, false));   // lane ^ 1
+    x |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x4E, 0xf, 0xf, false));   // lane ^ 2
+    x |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x141, 0xf, 0xf, false));  // 7 - lane
+    return x;
+}
+
+}  // namespace
