@@ -52,15 +52,29 @@ __device__ __forceinline__ void expand_word(const uint32_t (&wd)[MAXP], int plan
 // EXPW expander waves: 8 (two threads per line) when a CU holds one workgroup - a lone expander wave per
 // SIMD is latency-bound - or 4 (one thread per line, fewer registers per workgroup) when the grid is large
 // enough for two workgroups per CU to overlap each other.
+//
+// Zero-tile jumping: when the problem carries the occupancy bitmap of its left operand (pr.occ, one
+// 64-bit word per 32-row tile, i.e. K <= 8192) the workgroup ORs the words of its four row tiles and
+// visits only the k-quads whose 128-row x 128-bit X tile has a bit set - every wave derives the same
+// sequence from the same scalar loads, so the expander / multiplier hand-over needs nothing extra.
 template <int MAXP, int EXPW>
-__global__ __launch_bounds__(64 * (4 + EXPW)) void k_bitmm_mfma(qgtc_problem pr, MMShape sh, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &sh, int tm, int tn,
+                                        unsigned char *smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
     const int M = pr.M, K = pr.K, N = pr.N;
     const int m0 = tm * MF_T, n0 = tn * MF_T;
     const int kq = step128(K);
+    // the k-quads this tile visits: all kq of them in order, or the set bits of `kmask`
+    const bool jump = pr.occ != nullptr && pr.occ_words == 1;
+    unsigned long long kmask = 0ull;
+    if (jump) {
+        const int rt0 = 4 * tm, rts = (M + 31) >> 5;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (rt0 + r < rts) kmask |= pr.occ[rt0 + r];
+    }
+    const int nq = jump ? __builtin_popcountll(kmask) : kq;   // steps of the main loop
     // Waves 0-3 multiply, waves 4.. expand: waves v, v+4 (and v+8) share a SIMD, so the matrix pipe
     // (multiplying k-quad q) and the vector pipe (expanding k-quad q+1) of every SIMD run side by
     // side. Two staging buffers, one barrier per k-quad.
@@ -110,19 +124,30 @@ __global__ __launch_bounds__(64 * (4 + EXPW)) void k_bitmm_mfma(qgtc_problem pr,
         // it L2 -> L1 traffic. Two register sets: group g+1 is in flight while group g is expanded.
         constexpr int GQ = MAXP <= 2 ? 4 : (MAXP <= 4 ? 2 : 1);
         u32x4 grp[2][GQ][MAXP];
-        auto issue_group = [&](int g, u32x4 (&dst)[GQ][MAXP]) {
+        // groups are requested strictly in order, so the k-quad stream is a running cursor
+        int k_seq = 0;
+        unsigned long long k_left = kmask;
+        auto next_k = [&]() -> int {  // next k-quad to load, kq when the stream is exhausted
+            if (!jump) return k_seq < kq ? k_seq++ : kq;
+            if (k_left == 0ull) return kq;
+            const int k = __builtin_ctzll(k_left);
+            k_left &= k_left - 1ull;
+            return k;
+        };
+        auto issue_group = [&](u32x4 (&dst)[GQ][MAXP]) {
 #pragma unroll
-            for (int p = 0; p < MAXP; p++)
+            for (int j = 0; j < GQ; j++) {
+                const int q = next_k();
 #pragma unroll
-                for (int j = 0; j < GQ; j++) {
-                    const int q = g * GQ + j;
+                for (int p = 0; p < MAXP; p++) {
                     const bool ok = line_ok && p < planes && q < kq;
                     const uint32_t off = ok ? static_cast<uint32_t>(p) * plane_words * 4u + base + static_cast<uint32_t>(q) * 16u : 0xffffffffu;
                     dst[j][p] = is_x ? __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0)
                                      : __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0);
                 }
+            }
         };
-        auto expand = [&](int q, const u32x4 (&src)[MAXP]) {  // packed words of k-quad q -> bytes in staging buffer q & 1
+        auto expand = [&](int q, const u32x4 (&src)[MAXP]) {  // packed words of step q -> bytes in staging buffer q & 1
             unsigned char *stage = my_stage + (q & 1) * MF_STAGE;
 #pragma unroll
             for (int cc = 0; cc < 4 / TPL; cc++) {
@@ -144,28 +169,28 @@ __global__ __launch_bounds__(64 * (4 + EXPW)) void k_bitmm_mfma(qgtc_problem pr,
 #endif
             }
         };
-        issue_group(0, grp[0]);
-        issue_group(1, grp[1]);
+        issue_group(grp[0]);
+        issue_group(grp[1]);
         MF_STAMP(1);
-        expand(0, grp[0][0]);
-        if (GQ == 1) issue_group(2, grp[0]);
+        if (nq > 0) expand(0, grp[0][0]);
+        if (GQ == 1) issue_group(grp[0]);
         MF_STAMP(2);
         __syncthreads();
         MF_STAMP(3);
-        // step J of a block of 2*GQ: k-quad q0+J is being multiplied; expand k-quad e = q0+J+1 (set (e/GQ)&1,
+        // step J of a block of 2*GQ: step q0+J is being multiplied; expand step e = q0+J+1 (set (e/GQ)&1,
         // slot e%GQ); after the last slot of a set, refill the set with the group two ahead
 #define QGTC_MF_STEP(J)                                                                   \
-    if (J < 2 * GQ && q0 + J < kq) {                                                      \
+    if (J < 2 * GQ && q0 + J < nq) {                                                      \
         constexpr int E = (J + 1) % (2 * GQ);                                             \
-        if (q0 + J + 1 < kq) {                                                            \
+        if (q0 + J + 1 < nq) {                                                            \
             expand(q0 + J + 1, grp[E / GQ][E % GQ]);                                      \
-            if (E % GQ == GQ - 1) issue_group((q0 + J + 1) / GQ + 2, grp[E / GQ]);        \
+            if (E % GQ == GQ - 1) issue_group(grp[E / GQ]);                               \
         }                                                                                 \
         if (q0 + J == 8) MF_STAMP(6);                                                     \
         __syncthreads();                                                                  \
         if (q0 + J == 8) MF_STAMP(7);                                                     \
     }
-        for (int q0 = 0; q0 < kq; q0 += 2 * GQ) {
+        for (int q0 = 0; q0 < nq; q0 += 2 * GQ) {
             if (q0 == 2 * GQ) MF_STAMP(4);
             QGTC_MF_STEP(0)
             QGTC_MF_STEP(1)
@@ -181,7 +206,7 @@ __global__ __launch_bounds__(64 * (4 + EXPW)) void k_bitmm_mfma(qgtc_problem pr,
     } else {
         __syncthreads();
         MF_STAMP(3);
-        for (int q = 0; q < kq; q++) {
+        for (int q = 0; q < nq; q++) {
             if (q == 8) MF_STAMP(4);
             const unsigned char *xs = smem + (q & 1) * MF_STAGE + (64 * wr + fl) * MF_PITCH + 16 * fh;
             const unsigned char *ws = smem + (q & 1) * MF_STAGE + MF_T * MF_PITCH + (64 * wc + fl) * MF_PITCH + 16 * fh;
@@ -219,17 +244,28 @@ __global__ __launch_bounds__(64 * (4 + EXPW)) void k_bitmm_mfma(qgtc_problem pr,
         // MFMA C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5). The cols-layout
         // epilogue wants four consecutive ROWS of a column in one 16-byte read: it gets the tile transposed.
         MF_STAMP(5);
-        // (two loops, not a select per element: the addresses are then one lane base + immediates)
+        // (one loop per mode, not a select per element: the addresses are then one lane base + immediates)
+        // Bit modes: inside every group of 32 elements along a line, element l + 8j is stored at 4l + j, so
+        // that the epilogue thread l of an 8-lane group reads its four elements {l, l+8, l+16, l+24} - one
+        // per byte of the output word - with one 16-byte read.
         int *ctw = reinterpret_cast<int *>(smem);
-        if (sh.mode == 1) {
-            int *basep = ctw + (64 * wc + fl) * MF_CPITCH + 64 * wr + 4 * fh;
+        if (sh.mode == 1) {         // lines = columns, along = rows; row = 64wr + 32i + (r&3) + 8(r>>2) + 4fh
+            int *basep = ctw + (64 * wc + fl) * MF_CPITCH + 64 * wr + 16 * fh;
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++) basep[32 * j * MF_CPITCH + 32 * i + (r & 3) + 8 * (r >> 2)] = acc[i][j][r];
-        } else {
+                    for (int r = 0; r < 16; r++) basep[32 * j * MF_CPITCH + 32 * i + 4 * (r & 3) + (r >> 2)] = acc[i][j][r];
+        } else if (sh.mode == 0) {  // lines = rows, along = columns; column = 64wc + 32j + fl
+            int *basep = ctw + (64 * wr + 4 * fh) * MF_CPITCH + 64 * wc + 4 * (fl & 7) + (fl >> 3);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) basep[(32 * i + (r & 3) + 8 * (r >> 2)) * MF_CPITCH + 32 * j] = acc[i][j][r];
+        } else {                    // float32: plain row-major tile
             int *basep = ctw + (64 * wr + 4 * fh) * MF_CPITCH + 64 * wc + fl;
 #pragma unroll
             for (int i = 0; i < 2; i++)
@@ -242,70 +278,126 @@ __global__ __launch_bounds__(64 * (4 + EXPW)) void k_bitmm_mfma(qgtc_problem pr,
     __syncthreads();
 
     if (!expander) MF_STAMP(6);
-    // ---- epilogue: a thread takes four consecutive elements of a line of the tile (rows layout /
-    // float: four columns of a row; cols layout: four rows of a column), 8 adjacent lanes make a word.
-    // Thread t handles quad (t & 31) of lines (t >> 5) + k * NT/32: everything but the line is invariant.
+    // ---- epilogue. Thread t handles the same quad (t & 31) of lines (t >> 5) + k * NT/32: everything but
+    // the line is invariant. float32: four consecutive columns of a row. Bit modes: the four elements
+    // {l, l+8, l+16, l+24} (l = t & 7) of a 32-element group of the line (rows layout: columns of a row;
+    // cols layout: rows of a column): element l + 8j belongs at bit (24 - 8j) + (7 - l) of the output
+    // word, so the re-quantised values are packed one per byte and plane p of all four is ONE shift + AND;
+    // the 8 lanes of a group OR their words with DPP.
     const int *ct = reinterpret_cast<const int *>(smem);
-    const bool int_rq = sh.ob <= 23;  // float(c) > 2^ob  <=>  c > 2^ob for every int c >= 0
-    const int maxi = 1 << (sh.ob & 31);
     constexpr int NT = 64 * (4 + EXPW), LSTEP = NT / 32;
     const int qd = tid & 31, ln0 = tid >> 5;
-    auto finish = [&](auto mode_c) {
-        constexpr int MODE = decltype(mode_c)::value;
-        // along-the-line coordinate of the quad (global), the line's coordinate limit
-        const int along = (MODE == 1 ? m0 : n0) + 4 * qd;
-        const int nvalid_line = min(max((MODE == 1 ? M : N) - along, 0), 4);  // leading elements inside the matrix
-        const int across0 = (MODE == 1 ? n0 : m0) + ln0, across_lim = MODE == 1 ? N : M;
-        const int rows_pad = pad8(M), row_words = step128(N) * 4, line_words = step128(M) * 4;
-        const size_t oplane = MODE == 0 ? static_cast<size_t>(rows_pad) * row_words : static_cast<size_t>(pad128(N)) * line_words;
-        const size_t pitch = MODE == 2 ? static_cast<size_t>(N) : (MODE == 0 ? row_words : line_words);  // output units per line
-        // rows layout [ob][PAD8(M)][STEP128(N)*4] (kernel.h:357-389): word (m, n / 32); cols layout
-        // [ob][PAD128(N)][STEP128(M)*4] (kernel.h:651-810 as intended): word (n, m / 32); float32 [M,N]: (m, n)
-        uint32_t *outp = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(across0) * pitch + (MODE == 2 ? along : (along >> 5));
-        const uint32_t sh_n = 28 - 4 * (tid & 7);
-        const bool lead = (tid & 7) == 0;
+    if (sh.mode == 2) {  // float32 [M,N] (reference kernel.h:915-930)
+        const int along = n0 + 4 * qd;
+        const int nvalid_line = min(max(N - along, 0), 4);
+        float *dst = static_cast<float *>(pr.out) + static_cast<size_t>(m0 + ln0) * N + along;
         const int *src = ct + ln0 * MF_CPITCH + 4 * qd;
-        for (int ln = ln0, across = across0; ln < MF_T; ln += LSTEP, across += LSTEP, outp += LSTEP * pitch, src += LSTEP * MF_CPITCH) {
+        const bool vec_ok = nvalid_line == 4 && (N & 3) == 0;
+        for (int ln = ln0; ln < MF_T && m0 + ln < M; ln += LSTEP, dst += static_cast<size_t>(LSTEP) * N, src += LSTEP * MF_CPITCH) {
             const int4 v4 = *reinterpret_cast<const int4 *>(src);
             const int v[4] = {v4.x, v4.y, v4.z, v4.w};
-            const int nvalid = across < across_lim ? nvalid_line : 0;
-            if (MODE == 2) {  // float32 [M,N] (reference kernel.h:915-930)
-                float *dst = reinterpret_cast<float *>(outp);
-                if (nvalid == 4 && (N & 3) == 0) {
-                    *reinterpret_cast<float4 *>(dst) = make_float4(static_cast<float>(v[0]), static_cast<float>(v[1]),
-                                                                   static_cast<float>(v[2]), static_cast<float>(v[3]));
-                } else {
+            if (vec_ok) {
+                *reinterpret_cast<float4 *>(dst) = make_float4(static_cast<float>(v[0]), static_cast<float>(v[1]),
+                                                               static_cast<float>(v[2]), static_cast<float>(v[3]));
+            } else {
 #pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        if (e < nvalid) dst[e] = static_cast<float>(v[e]);
-                }
-                continue;
-            }
-            uint32_t qv[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int c = int_rq ? (v[e] < 0 ? 1 : (v[e] > maxi ? maxi - 1 : v[e])) : requant(v[e], sh.maxv, sh.maxm1);
-                qv[e] = e < nvalid ? static_cast<uint32_t>(c) : 0u;
-            }
-            const bool store = lead && (MODE == 0 ? across < rows_pad : true);
-            uint32_t *out = outp;
-            for (int p = 0; p < sh.ob; p++, out += oplane) {
-                const uint32_t nib = (((qv[0] >> p) & 1u) << 3) | (((qv[1] >> p) & 1u) << 2) |
-                                     (((qv[2] >> p) & 1u) << 1) | ((qv[3] >> p) & 1u);
-                const uint32_t word = or_reduce8(nib << sh_n);
-                if (store) out[0] = word;
+                for (int e = 0; e < 4; e++)
+                    if (e < nvalid_line) dst[e] = static_cast<float>(v[e]);
             }
         }
-    };
-    if (sh.mode == 0) finish(std::integral_constant<int, 0>{});
-    else if (sh.mode == 1) finish(std::integral_constant<int, 1>{});
-    else finish(std::integral_constant<int, 2>{});
+    } else {
+        auto finish = [&](auto mode_c, auto ob_c) {
+            constexpr int MODE = decltype(mode_c)::value;
+            constexpr int OB = decltype(ob_c)::value;  // 0: any ob (runtime loop, per-plane bit extraction)
+            const int ell = tid & 7, grp = qd >> 3;
+            const int along0 = (MODE == 1 ? m0 : n0) + 32 * grp + ell;   // element j of the quad: along0 + 8j
+            const int along_lim = MODE == 1 ? M : N, across_lim = MODE == 1 ? N : M;
+            uint32_t vm = 0u;                                             // bit 24 - 8j: element j lies inside the matrix
+#pragma unroll
+            for (int j = 0; j < 4; j++) vm |= along0 + 8 * j < along_lim ? 1u << (24 - 8 * j) : 0u;
+            const int rows_pad = pad8(M), row_words = step128(N) * 4, line_words = step128(M) * 4;
+            const size_t oplane = MODE == 0 ? static_cast<size_t>(rows_pad) * row_words : static_cast<size_t>(pad128(N)) * line_words;
+            const int pitch = MODE == 0 ? row_words : line_words;        // output words per line
+            // rows layout [ob][PAD8(M)][STEP128(N)*4] (kernel.h:357-389): word (m, n / 32); cols layout
+            // [ob][PAD128(N)][STEP128(M)*4] (kernel.h:651-810 as intended): word (n, m / 32)
+            const int across0 = (MODE == 1 ? n0 : m0) + ln0;
+            uint32_t *outp = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(across0) * pitch + (((MODE == 1 ? m0 : n0) >> 5) + grp);
+            const uint32_t sh_l = 7 - ell;
+            const bool lead = ell == 0;
+            const int maxi = 1 << (sh.ob & 31);
+            const uint32_t ones = static_cast<uint32_t>(maxi - 1);
+            const int *src = ct + ln0 * MF_CPITCH + 32 * grp + 4 * ell;
+            const int across_store = MODE == 0 ? rows_pad : (1 << 30);   // lines that exist in the output
+            for (int ln = ln0, across = across0; ln < MF_T; ln += LSTEP, across += LSTEP, outp += LSTEP * pitch, src += LSTEP * MF_CPITCH) {
+                const int4 v4 = *reinterpret_cast<const int4 *>(src);
+                const int v[4] = {v4.x, v4.y, v4.z, v4.w};
+                const uint32_t vml = across < across_lim ? vm : 0u;
+                const bool store = lead && across < across_store;
+                if constexpr (OB > 0) {
+                    // the low OB bits of requant(c) = c < 0 ? 1 : (c > 2^ob ? all ones : c)  (kernel.h:31-37,350)
+                    uint32_t q[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        uint32_t t = v[e] > maxi ? ones : static_cast<uint32_t>(v[e]);
+                        if (!sh.nowrap) t = v[e] < 0 ? 1u : t;
+                        q[e] = OB < 8 ? t : (t & 255u);
+                    }
+                    // OB < 8: bits >= 8 of a value <= 2^OB cannot exist; bit OB (c == 2^OB) never reaches a mask bit
+                    const uint32_t P = (q[0] << 24) | (q[1] << 16) | (q[2] << 8) | q[3];
+                    uint32_t *out = outp;
+#pragma unroll
+                    for (int p = 0; p < OB; p++, out += oplane) {
+                        const uint32_t word = or_reduce8(((P >> p) & vml) << sh_l);
+                        if (store) out[0] = word;
+                    }
+                } else {
+                    const bool int_rq = sh.ob <= 23;  // float(c) > 2^ob  <=>  c > 2^ob for every int c >= 0
+                    uint32_t q[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        q[e] = static_cast<uint32_t>(int_rq ? (v[e] < 0 ? 1 : (v[e] > maxi ? maxi - 1 : v[e])) : requant(v[e], sh.maxv, sh.maxm1));
+                    uint32_t *out = outp;
+                    for (int p = 0; p < sh.ob; p++, out += oplane) {
+                        const uint32_t x = (((q[0] >> p) & 1u) << 24) | (((q[1] >> p) & 1u) << 16) | (((q[2] >> p) & 1u) << 8) | ((q[3] >> p) & 1u);
+                        const uint32_t word = or_reduce8((x & vml) << sh_l);
+                        if (store) out[0] = word;
+                    }
+                }
+            }
+        };
+        auto by_ob = [&](auto mode_c) {
+            if (sh.ob == 1) finish(mode_c, std::integral_constant<int, 1>{});
+            else if (sh.ob == 2) finish(mode_c, std::integral_constant<int, 2>{});
+            else if (sh.ob == 4) finish(mode_c, std::integral_constant<int, 4>{});
+            else if (sh.ob == 8) finish(mode_c, std::integral_constant<int, 8>{});
+            else finish(mode_c, std::integral_constant<int, 0>{});
+        };
+        if (sh.mode == 0) by_ob(std::integral_constant<int, 0>{});
+        else by_ob(std::integral_constant<int, 1>{});
+    }
 #ifdef QGTC_STAMPS
     if (!expander) MF_STAMP(7);
     if ((tid == 0 || tid == 256) && blockIdx.x < 512)
         for (int i = 0; i < 8; i++) g_stamps[blockIdx.x * 16 + (tid ? 8 : 0) + i] = st_[i];
 #endif
 #undef MF_STAMP
+}
+
+template <int MAXP, int EXPW>
+__global__ __launch_bounds__(64 * (4 + EXPW)) void k_bitmm_mfma(qgtc_problem pr, MMShape sh, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    mf_tile<MAXP, EXPW>(pr, sh, blockIdx.x / tiles_n, blockIdx.x % tiles_n, smem);
+}
+
+// grouped launch: blockIdx.y = problem, blockIdx.x = 128 x 128 tile (surplus tiles exit at once)
+template <int MAXP, int EXPW>
+__global__ __launch_bounds__(64 * (4 + EXPW)) void k_bitmm_mfma_batched(const qgtc_problem *__restrict__ prs, MMShape sh) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const qgtc_problem pr = prs[blockIdx.y];
+    const int tiles_m = (pr.M + MF_T - 1) / MF_T, tiles_n = (pr.N + MF_T - 1) / MF_T;
+    const int tile = blockIdx.x;
+    if (tile >= tiles_m * tiles_n) return;
+    mf_tile<MAXP, EXPW>(pr, sh, tile / tiles_n, tile % tiles_n, smem);
 }
 
 }  // namespace

@@ -65,6 +65,7 @@ struct MMShape {           // per-launch constants
     int waves;             // waves per workgroup (= blockDim.x / 64, passed so that no hidden argument is read)
     uint32_t inv_tiles_n;  // floor(2^32 / tiles_n), single launches only (tiles_n >= 2; else 0xffffffff)
     float maxv, maxm1;     // 2^ob and 2^ob - 1 as float (requant)
+    int nowrap;            // K (2^a - 1)(2^w - 1) < 2^31: no accumulator can wrap negative
 };
 
 constexpr int MR = 4, MC = 4;        // per-lane micro-tile

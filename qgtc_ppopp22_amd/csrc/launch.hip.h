@@ -42,7 +42,14 @@ inline MMShape base_shape(int a, int w, int ob, int mode) {
     sh.wb = w;
     sh.maxv = std::ldexp(1.0f, ob);
     sh.maxm1 = sh.maxv - 1.0f;
+    sh.nowrap = 0;
     return sh;
+}
+
+// no int32 accumulator of a product with this K can wrap (then requantisation needs no sign test)
+inline int no_wrap(int K, int a, int w) {
+    if (a > 16 || w > 16) return 0;
+    return static_cast<double>(K) * ((1u << a) - 1u) * ((1u << w) - 1u) < 2147483648.0;
 }
 
 template <int QW, int NA, int NW, bool ZS>
@@ -143,6 +150,7 @@ inline bool auto_prefers_mfma(int M, int K, int N, int a, int w) {
 
 int launch_mfma(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, mode);
+    sh.nowrap = no_wrap(pr.K, a, w);
     const int tiles_m = (pr.M + MF_T - 1) / MF_T, tiles_n = (pr.N + MF_T - 1) / MF_T;
     const int maxp = a > w ? a : w;
     static bool attr_set = false;
@@ -160,6 +168,36 @@ int launch_mfma(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStrea
 #define QGTC_MF_LAUNCH(P)                                                                              \
     if (wide) hipLaunchKernelGGL((k_bitmm_mfma<P, 8>), grid, dim3(768), MF_LDS, st, pr, sh, tiles_n);   \
     else hipLaunchKernelGGL((k_bitmm_mfma<P, 4>), grid, dim3(512), MF_LDS, st, pr, sh, tiles_n);
+    if (maxp <= 1) { QGTC_MF_LAUNCH(1) }
+    else if (maxp <= 2) { QGTC_MF_LAUNCH(2) }
+    else if (maxp <= 4) { QGTC_MF_LAUNCH(4) }
+    else { QGTC_MF_LAUNCH(7) }
+#undef QGTC_MF_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
+// grouped launch on the matrix cores: one workgroup per 128 x 128 tile of every problem
+int launch_mfma_batched(const qgtc_problem *prs, int count, int max_M, int max_K, int max_N, int a, int w,
+                        int ob, int mode, hipStream_t st) {
+    MMShape sh = base_shape(a, w, ob, mode);
+    sh.nowrap = no_wrap(max_K, a, w);
+    const int tiles = ((max_M + MF_T - 1) / MF_T) * ((max_N + MF_T - 1) / MF_T);
+    const int maxp = a > w ? a : w;
+    static bool attr_set = false;
+    if (!attr_set) {
+#define QGTC_MF_ATTR(P, E) \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma_batched<P, E>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
+        QGTC_MF_ATTR(1, 4) QGTC_MF_ATTR(2, 4) QGTC_MF_ATTR(4, 4) QGTC_MF_ATTR(7, 4)
+        QGTC_MF_ATTR(1, 8) QGTC_MF_ATTR(2, 8) QGTC_MF_ATTR(4, 8) QGTC_MF_ATTR(7, 8)
+#undef QGTC_MF_ATTR
+        attr_set = true;
+    }
+    const dim3 grid(tiles, count);
+    const bool wide = static_cast<long>(tiles) * count < 512;
+#define QGTC_MF_LAUNCH(P)                                                                          \
+    if (wide) hipLaunchKernelGGL((k_bitmm_mfma_batched<P, 8>), grid, dim3(768), MF_LDS, st, prs, sh); \
+    else hipLaunchKernelGGL((k_bitmm_mfma_batched<P, 4>), grid, dim3(512), MF_LDS, st, prs, sh);
     if (maxp <= 1) { QGTC_MF_LAUNCH(1) }
     else if (maxp <= 2) { QGTC_MF_LAUNCH(2) }
     else if (maxp <= 4) { QGTC_MF_LAUNCH(4) }

@@ -114,9 +114,12 @@ def test_tile_occupancy_bitmap(qgtc, oracle, M, K, a, density):
 
 @pytest.mark.parametrize("a,w,ob", [(1, 2, 2), (1, 1, 1), (2, 2, 3), (3, 5, 4)])
 @pytest.mark.parametrize("mode", [0, 1, 2])
-def test_zero_jump_products_are_identical(qgtc, oracle, a, w, ob, mode):
+@pytest.mark.parametrize("engine", ["popcount", "mfma"])
+def test_zero_jump_products_are_identical(qgtc, oracle, a, w, ob, mode, engine):
     """Grouped launch with the occupancy bitmap (tiles neither loaded nor multiplied) against the
-    oracle: block-diagonal-dominant sparse left operands, including an all-zero one."""
+    oracle: block-diagonal-dominant sparse left operands, including an all-zero one. Both engines;
+    the matrix-core one jumps 128-row tiles when the bitmap is one word per row tile (K <= 8192)
+    and visits every k-quad otherwise (the K = 9000 problem)."""
     import torch
     from helpers import rand_q, to_dev
     rng = np.random.default_rng(7 * a + w + mode)
@@ -136,7 +139,11 @@ def test_zero_jump_products_are_identical(qgtc, oracle, a, w, ob, mode):
         refs.append((X, Wt))
     for zj in (True, False):
         bg = qgtc.BatchedGemm(Xs, Ws, dims, a, w, ob, mode, True, zj)
-        bg.run()
+        qgtc.set_engine(engine)
+        try:
+            bg.run()
+        finally:
+            qgtc.set_engine("popcount")
         torch.cuda.synchronize()
         for i, (M, K, N) in enumerate(dims):
             X, Wt = refs[i]

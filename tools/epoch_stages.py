@@ -6,6 +6,7 @@ import QGTC as Q
 from qgtc_ppopp22_amd import driver, graph as G
 from qgtc_ppopp22_amd.sampler import ClusterIter
 
+Q.set_engine(os.environ.get("ENGINE", "popcount"))   # grouped launches follow the engine switch
 chain = sys.argv[1] if len(sys.argv) > 1 else "correct"
 gin = len(sys.argv) > 2 and sys.argv[2] == "gin"
 dataset = "ppi" if gin else "ogbn-arxiv"
