@@ -127,7 +127,8 @@ def epoch_leg(Q, rank, world, device_index, dataset="ogbn-arxiv", bits=2, hidden
     ids = D.shard_round_robin(1500 // 20, rank, world)
     res = {}
     legs = [("per_batch_reference_chain", []), ("batched_reference_chain", ["--batched"]),
-            ("batched_correct_chain", ["--batched", "--chain", "correct"])]
+            ("batched_correct_chain", ["--batched", "--chain", "correct"]),
+            ("batched_correct_chain_engine_auto", ["--batched", "--chain", "correct", "--engine", "auto"])]
     if full:
         legs[1:1] = [("per_batch_nonresident_reference_chain", ["--non-resident"]),
                      ("per_batch_graph_reference_chain", ["--graph"]),

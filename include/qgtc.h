@@ -49,10 +49,12 @@ enum {
 #define QGTC_OUT_COLS 0x1u     /* pack the result in the cols layout (bitMM2Bit_col)      */
 #define QGTC_NO_ZERO_SKIP 0x2u /* do not skip all-zero X tiles (result is identical)      */
 #define QGTC_ZERO_JUMP 0x4u    /* qgtc_bitmm_batched: the problems carry occupancy bitmaps */
-#define QGTC_ENGINE_MFMA 0x8u  /* qgtc_bitmm2bit / qgtc_bitmm2int: expand the bit planes to int8 values and
-                                  multiply on the matrix cores (bit1, bit2 <= 7; otherwise ignored). Same
-                                  results; pays for wide N and several planes, not for N = 64 */
-#define QGTC_ENGINE_AUTO 0x10u /* let a cost model fitted to MI355X measurements choose between the two engines */
+#define QGTC_ENGINE_MFMA 0x8u  /* qgtc_bitmm2bit / qgtc_bitmm2int / qgtc_bitmm_batched: expand the bit planes to
+                                  int8 values and multiply on the matrix cores (bit1, bit2 <= 7; otherwise
+                                  ignored). Same results; pays for wide N and several planes, not for N = 64.
+                                  Grouped launches whose problems carry a one-word occupancy bitmap
+                                  (K <= 8192) jump all-zero 128-row x 128-bit tiles */
+#define QGTC_ENGINE_AUTO 0x10u /* let rules fitted to MI355X measurements choose between the two engines */
 
 int qgtc_abi_version(void);
 const char *qgtc_strerror(int code);

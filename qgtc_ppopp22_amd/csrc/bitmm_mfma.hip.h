@@ -69,10 +69,11 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
     const bool jump = pr.occ != nullptr && pr.occ_words == 1;
     unsigned long long kmask = 0ull;
     if (jump) {
-        const int rt0 = 4 * tm, rts = (M + 31) >> 5;
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-            if (rt0 + r < rts) kmask |= pr.occ[rt0 + r];
+        // four independent scalar loads (a row tile past the end re-reads the last one: OR is idempotent)
+        const int rt0 = 4 * tm, rt_last = ((M + 31) >> 5) - 1;
+        const unsigned long long o0 = pr.occ[rt0], o1 = pr.occ[min(rt0 + 1, rt_last)];
+        const unsigned long long o2 = pr.occ[min(rt0 + 2, rt_last)], o3 = pr.occ[min(rt0 + 3, rt_last)];
+        kmask = (o0 | o1) | (o2 | o3);
     }
     const int nq = jump ? __builtin_popcountll(kmask) : kq;   // steps of the main loop
     // Waves 0-3 multiply, waves 4.. expand: waves v, v+4 (and v+8) share a SIMD, so the matrix pipe

@@ -215,7 +215,8 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
     // choice is correct; this only affects speed.
     const int k_hint = max_K;
     const int ob_ = mode == 2 ? 1 : output_bit;
-    if ((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2))  // problems with a one-word bitmap jump zero tiles
+    if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) ||  // problems with a one-word bitmap jump zero tiles
+        ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma_batched(max_M, max_N, bit1, bit2)))
         return launch_mfma_batched(problems, count, max_M, max_K, max_N, bit1, bit2, ob_, mode, st);
     if (flags & QGTC_NO_ZERO_SKIP)
         return dispatch_batched<false, false>(problems, count, max_M, max_N, k_hint, bit1, bit2, ob_, mode, st);

@@ -64,6 +64,9 @@ def build_parser() -> argparse.ArgumentParser:
                    help="capture the epoch's per-batch launches (6 x batches) in one hipGraph and replay it")
     p.add_argument("--non-resident", action="store_true",
                    help="park packed batches on the CPU and upload them every iteration (main_qgtc.py:115)")
+    p.add_argument("--engine", choices=["popcount", "mfma", "auto"], default="popcount",
+                   help="popcount: AND + v_bcnt kernels (default, the path BASELINE.json names); mfma: bit planes "
+                        "expanded to int8 on the matrix cores; auto: chosen per launch. Same results.")
     p.add_argument("--quiet", action="store_true")
     return p
 
@@ -234,6 +237,15 @@ def run(args, Q=None, batch_ids=None, graph=None):
                      batch_ids=batch_ids, with_rows_X=(args.chain == "correct"))
     torch.cuda.synchronize()
 
+    prev_engine = Q.get_engine()
+    Q.set_engine(args.engine)
+    try:
+        return _run_epochs(args, Q, it, feat_size, b, device)
+    finally:
+        Q.set_engine(prev_engine)
+
+
+def _run_epochs(args, Q, it, feat_size, b, device):
     start_time = time.time()  # main_qgtc.py:96 — the clock starts before the weights are packed
     W = pack_weights(Q, feat_size, args.n_hidden, args.n_classes, b, device)
     chain = CHAINS[(args.chain, args.run_GIN)]

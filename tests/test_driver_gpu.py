@@ -46,6 +46,23 @@ def test_epoch_outputs_match_oracle(qgtc, oracle, chain, gin, bits, batched):
             np.testing.assert_array_equal(expect, integer_gcn_reference(bi["A"], bi["X"], 64, 10, bits, oracle))
 
 
+@pytest.mark.parametrize("engine", ["mfma", "auto"])
+@pytest.mark.parametrize("gin", [False, True])
+@pytest.mark.parametrize("batched", [False, True])
+def test_engines_give_the_same_epoch(qgtc, engine, gin, batched):
+    """--engine mfma / auto (per-batch operators and grouped launches, reference and layout-correct
+    chains) reproduce the popcount engine's outputs - which the test above pins to the oracle."""
+    import torch
+    from qgtc_ppopp22_amd import driver
+
+    for chain in ("reference", "correct"):
+        extra = ["--chain", chain] + (["--run_GIN", "--bit_width", "4"] if gin else []) + (["--batched"] if batched else [])
+        base = driver.run(_args(extra), Q=qgtc)["outs"]
+        other = driver.run(_args(extra + ["--engine", engine]), Q=qgtc)["outs"]
+        assert qgtc.get_engine() == "popcount"          # the driver restores the switch
+        assert len(base) == len(other) and all(torch.equal(x, y) for x, y in zip(base, other))
+
+
 def test_non_resident_matches_resident(qgtc):
     import torch
     from qgtc_ppopp22_amd import driver

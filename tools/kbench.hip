@@ -1,6 +1,10 @@
 // tools/kbench.hip — standalone (no torch) kernel bench + phase-stamp dump for the bit-GEMM.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude [-DQGTC_STAMPS] -o /tmp/kbench tools/kbench.hip
 //   /tmp/kbench M K N a w ob reps [density]
+//   env: NOZS=1 (no zero-tile skipping), MFMA=1 (matrix-core engine),
+//        GROUPED=count (count copies of the problem in one grouped launch; X gets dense 64 x 64
+//        diagonal blocks + `density` elsewhere, like a cluster batch), JUMP=1 (with occupancy bitmaps),
+//        MODE=0|1|2 (grouped only: rows bits, cols bits, float)
 #include "../qgtc_ppopp22_amd/csrc/qgtc_hip.hip"
 
 #include <cstdlib>
@@ -27,12 +31,70 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(dw, hw.data(), ww * 4, hipMemcpyHostToDevice));
     const unsigned flags = (getenv("NOZS") ? QGTC_NO_ZERO_SKIP : 0u) | (getenv("MFMA") ? QGTC_ENGINE_MFMA : 0u);
     float ms = 0, best = 1e30f;
+    if (const char *g = getenv("GROUPED")) {
+        const int count = atoi(g), mode = getenv("MODE") ? atoi(getenv("MODE")) : 0;
+        const bool jump = getenv("JUMP") != nullptr;
+        // cluster-batch-like left operand: dense diagonal blocks, `density` elsewhere
+        std::fill(hx.begin(), hx.end(), 0u);
+        const int rw_ = (K + 127) / 128 * 4, rp = (M + 7) / 8 * 8;
+        for (int p = 0; p < a; p++)
+            for (int r = 0; r < M; r++)
+                for (int c = 0; c < K; c++) {
+                    const bool in_blk = r / 64 == c / 64;
+                    if (in_blk ? (rng() & 1) : bern(rng)) hx[(size_t)p * rp * rw_ + (size_t)r * rw_ + c / 32] |= 1u << (31 - c % 32);
+                }
+        CK(hipMemcpy(dx, hx.data(), xw * 4, hipMemcpyHostToDevice));
+        const size_t out_bytes = mode == 2 ? (size_t)M * N * 4 : (mode == 1 ? qgtc_cols_words(M, N, ob, 0) : ow) * 4;
+        std::vector<qgtc_problem> hp(count);
+        uint64_t *docc = nullptr;
+        const size_t occw = qgtc_occupancy_words(M, K);
+        CK(hipMalloc(&docc, occw * 8));
+        if (int rc = qgtc_tile_occupancy(dx, xw, M, K, a, docc, occw, nullptr)) { printf("occ rc=%d\n", rc); return 1; }
+        std::vector<uint64_t> hocc(occw);
+        CK(hipMemcpy(hocc.data(), docc, occw * 8, hipMemcpyDeviceToHost));
+        size_t set = 0;
+        for (auto v : hocc) set += __builtin_popcountll(v);
+        size_t set128 = 0, all128 = 0;
+        const int ow64 = ((K + 127) / 128 + 63) / 64, rts = (M + 31) / 32;
+        for (int t = 0; t < (M + 127) / 128; t++)
+            for (int wi = 0; wi < ow64; wi++) {
+                uint64_t m = 0;
+                for (int r = 0; r < 4; r++) if (4 * t + r < rts) m |= hocc[(size_t)(4 * t + r) * ow64 + wi];
+                set128 += __builtin_popcountll(m);
+            }
+        all128 = (size_t)((M + 127) / 128) * ((K + 127) / 128);
+        printf("occupied: %.3f of the 32-row tiles, %.3f of the 128-row tiles\n",
+               (double)set / ((double)rts * ((K + 127) / 128)), (double)set128 / all128);
+        for (int i = 0; i < count; i++) {
+            void *o;
+            CK(hipMalloc(&o, out_bytes));
+            hp[i] = qgtc_problem{dx, dw, o, xw, ww, M, K, N, (N + 127) / 128 * 128, jump ? ow64 : 0, jump ? docc : nullptr};
+        }
+        qgtc_problem *dp;
+        CK(hipMalloc(&dp, count * sizeof(qgtc_problem)));
+        CK(hipMemcpy(dp, hp.data(), count * sizeof(qgtc_problem), hipMemcpyHostToDevice));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        const unsigned gf = flags | (jump ? QGTC_ZERO_JUMP : 0u);
+        for (int r = 0; r < 5; r++) {
+            CK(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < reps; i++)
+                if (int rc = qgtc_bitmm_batched(dp, count, M, K, N, a, w, ob, mode, gf, nullptr)) { printf("rc=%d\n", rc); return 1; }
+            CK(hipEventRecord(e1, nullptr));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        printf("grouped x%d %dx%dx%d a=%d w=%d mode=%d%s%s: %.2f us per grouped launch\n", count, M, K, N, a, w, mode,
+               jump ? " jump" : "", (flags & QGTC_ENGINE_MFMA) ? " mfma" : "", best * 1e3 / reps);
+    } else
     for (int r = 0; r < 5; r++) {
         int rc = qgtc_bitmm2bit_profile(dx, xw, dw, ww, M, K, N, a, w, ob, dout, ow, flags, reps, &ms, nullptr);
         if (rc) { printf("rc=%d %s %s\n", rc, qgtc_strerror(rc), qgtc_last_hip_error()); return 1; }
         if (ms < best) best = ms;
     }
     const double us = best * 1e3 / reps;
+    if (!getenv("GROUPED"))
     printf("%dx%dx%d a=%d w=%d: %.2f us/launch  eff %.1f TOPS  valu-frac %.3f\n", M, K, N, a, w, us,
            2.0 * M * K * N / us / 1e6, 2.0 * M * K * N * a * w / (us * 1e-6) / 2.516e15);
 #ifdef QGTC_STAMPS
