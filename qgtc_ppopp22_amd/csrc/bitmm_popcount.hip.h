@@ -294,6 +294,79 @@ __device__ __forceinline__ void quad_finish(const qgtc_problem &pr, const MMShap
     }
 }
 
+// The same for OB = 1, 2, 4 or 8 output planes (the widths the reference publishes), bit modes only:
+// the four elements a lane contributes to one output word sit 8 bit positions apart, so their
+// re-quantised values (low OB bits of c < 0 ? 1 : c > 2^OB ? ones : c, kernel.h:31-37,350) are packed
+// one per byte and plane p of all four is ONE shift + AND with the lane's validity mask.
+template <int MODE, int OB>
+__device__ __forceinline__ void epi_direct_packed(const qgtc_problem &pr, const MMShape &sh,
+                                                  const uint32_t (&tot)[MR][MC], int tm, int tn, int tiles_n) {
+    const int lane = threadIdx.x & 63, lm = lane >> 3, ln = lane & 7;
+    const int M = pr.M, N = pr.N, m0 = tm * TM, n0 = tn * TN;
+    constexpr int maxi = 1 << OB;
+    constexpr uint32_t ones = maxi - 1;
+    uint32_t q[MR][MC];
+#pragma unroll
+    for (int i = 0; i < MR; i++)
+#pragma unroll
+        for (int j = 0; j < MC; j++) {
+            const int c = static_cast<int>(tot[i][j]);
+            uint32_t t = c > maxi ? ones : static_cast<uint32_t>(c);
+            if (!sh.nowrap) t = c < 0 ? 1u : t;
+            q[i][j] = OB < 8 ? t : (t & 255u);   // OB < 8: t <= 2^OB fits the byte; bit OB never meets a mask bit
+        }
+    // bit 24 - 8k of a mask: element k of the four along the word lies inside the matrix
+    uint32_t vrow = 0u, vcol = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        vrow |= m0 + lm + 8 * k < M ? 1u << (24 - 8 * k) : 0u;
+        vcol |= n0 + ln + 8 * k < N ? 1u << (24 - 8 * k) : 0u;
+    }
+    uint32_t *out = static_cast<uint32_t *>(pr.out);
+    if (MODE == 0) {  // rows layout [ob][PAD8(M)][STEP128(N)*4] (reference kernel.h:357-389)
+        const int rows_pad = pad8(M), row_words = step128(N) * 4;
+        const size_t oplane = static_cast<size_t>(rows_pad) * row_words;
+        const int extra = tn == tiles_n - 1 ? row_words - (n0 >> 5) - 1 : 0;
+#pragma unroll
+        for (int i = 0; i < MR; i++) {
+            const int m = m0 + lm + 8 * i;
+            uint32_t *dst = out + static_cast<size_t>(m) * row_words + (n0 >> 5);
+            // column ln + 8j sits at bit 31 - ln - 8j = (24 - 8j) + (7 - ln)
+            const uint32_t P = (q[i][0] << 24) | (q[i][1] << 16) | (q[i][2] << 8) | q[i][3];
+            const uint32_t vml = ((vrow >> (24 - 8 * i)) & 1u) ? vcol : 0u;
+            const bool store = ln == 0 && m < rows_pad;
+#pragma unroll
+            for (int p = 0; p < OB; p++, dst += oplane) {
+                const uint32_t word = or_reduce8(((P >> p) & vml) << (7 - ln));
+                if (store) {
+                    dst[0] = word;
+                    for (int e = 1; e <= extra; e++) dst[e] = 0u;
+                }
+            }
+        }
+    } else {  // cols layout [ob][PAD128(N)][STEP128(M)*4] (intended semantics of kernel.h:651-810)
+        const int lines = pad128(N), line_words = step128(M) * 4;
+        const size_t oplane = static_cast<size_t>(lines) * line_words;
+#pragma unroll
+        for (int j = 0; j < MC; j++) {
+            const int n = n0 + ln + 8 * j;
+            uint32_t *dst = out + static_cast<size_t>(n) * line_words + (m0 >> 5);
+            // row lm + 8i sits at bit 31 - lm - 8i
+            const uint32_t P = (q[0][j] << 24) | (q[1][j] << 16) | (q[2][j] << 8) | q[3][j];
+            const uint32_t vml = ((vcol >> (24 - 8 * j)) & 1u) ? vrow : 0u;
+            const bool store = lm == 0 && n < lines;
+#pragma unroll
+            for (int p = 0; p < OB; p++, dst += oplane) {
+                uint32_t x = ((P >> p) & vml) << (7 - lm);
+                x |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(x), 8));
+                x |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(x), 16));
+                x |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(x), 32));
+                if (store) dst[0] = x;
+            }
+        }
+    }
+}
+
 // Epilogue of a single-wave workgroup (the wave owns the whole K range, nothing to reduce): straight
 // from the accumulators. Lane (lm, ln) holds rows lm + 8i and columns ln + 8j, so the 32 columns
 // of a row live in the 8 lanes of one aligned group (4 each): a DPP OR assembles the row word.
@@ -312,6 +385,13 @@ __device__ __forceinline__ void epi_direct(const qgtc_problem &pr, const MMShape
                 const int m = m0 + lm + 8 * i, n = n0 + ln + 8 * j;
                 if (m < M && n < N) out[static_cast<size_t>(m) * N + n] = static_cast<float>(static_cast<int>(tot[i][j]));
             }
+        return;
+    }
+    if (sh.ob == 1 || sh.ob == 2 || sh.ob == 4 || sh.ob == 8) {
+        if (sh.ob == 1) epi_direct_packed<MODE, 1>(pr, sh, tot, tm, tn, tiles_n);
+        else if (sh.ob == 2) epi_direct_packed<MODE, 2>(pr, sh, tot, tm, tn, tiles_n);
+        else if (sh.ob == 4) epi_direct_packed<MODE, 4>(pr, sh, tot, tm, tn, tiles_n);
+        else epi_direct_packed<MODE, 8>(pr, sh, tot, tm, tn, tiles_n);
         return;
     }
     const bool int_rq = sh.ob <= 23;

@@ -91,6 +91,7 @@ int launch_batched(const qgtc_problem *prs, int count, int max_M, int max_N, con
 template <bool ZS, typename F>
 int with_kernel(int a, int w, int K, int ob, int mode, long total_tiles, Plan *pl, F &&go) {
     pl->sh = base_shape(a, w, ob, mode);
+    pl->sh.nowrap = no_wrap(K, a, w);
 #define QGTC_FIXED(QW_, NA_, NW_)                              \
     if (a == NA_ && w == NW_) {                                \
         plan_split(K, NA_ + NW_, QW_, total_tiles, pl);        \
