@@ -221,7 +221,7 @@ def main():
     traffic = None
     try:
         if w == 1:
-            with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_bench_b.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_bench_d.json")) as f:
                 traffic = int(json.load(f)["hbm_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         traffic = None
