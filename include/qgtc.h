@@ -50,7 +50,7 @@ enum {
 #define QGTC_NO_ZERO_SKIP 0x2u /* do not skip all-zero X tiles (result is identical)      */
 #define QGTC_ZERO_JUMP 0x4u    /* qgtc_bitmm_batched: the problems carry occupancy bitmaps */
 #define QGTC_ENGINE_MFMA 0x8u  /* qgtc_bitmm2bit / qgtc_bitmm2int / qgtc_bitmm_batched: expand the bit planes to
-                                  int8 values and multiply on the matrix cores (bit1, bit2 <= 7; otherwise
+                                  int8 values and multiply on the matrix cores (bit1, bit2 <= 8; otherwise
                                   ignored). Same results; pays for wide N and several planes, not for N = 64.
                                   Grouped launches whose problems carry a one-word occupancy bitmap
                                   (K <= 8192) jump all-zero 128-row x 128-bit tiles */

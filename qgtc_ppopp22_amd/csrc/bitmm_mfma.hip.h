@@ -13,7 +13,12 @@ namespace {
 // costs ~0.8 VALU operations per operand byte, which only pays when an expanded byte is reused by
 // several MFMA tiles: a workgroup owns a 128 x 128 output tile (four waves, 64 x 64 each), so this
 // engine is for wide N (>= 128) and/or several planes; the popcount kernels stay the default and
-// remain the faster path at N = 64. Needs a, w <= 7 (non-negative int8).
+// remain the faster path at N = 64. Needs a, w <= 8. An 8-plane operand does
+// not fit a non-negative int8: its plane 7 is inverted on the way in (byte = value - 128 as int8) and
+// the product is corrected in the epilogue with the line sums of the other operand,
+//   sum x w = sum x' w' + 128 [w has 8 planes] sum x + 128 [x has 8 planes] sum w - 16384 [both] K',
+// x', w' the bytes as multiplied, the sums over the K' = 128 * (visited k-quads) positions - exact in
+// int32 arithmetic mod 2^32, like everything else here. The sums are popcounts of the packed words.
 //
 // Per k-quad (128 bits of K) one thread of the expander waves expands one row of X or one column of W:
 // every 32-bit word is bit-reversed (element i at bit i), each nibble is spread to four bytes with
@@ -29,7 +34,8 @@ constexpr int MF_T = 128;          // tile edge
 constexpr int MF_PITCH = 144;      // bytes between the expanded lines of one operand
 constexpr int MF_CPITCH = 132;     // ints between the rows (cols layout: columns) of the result tile in LDS
 constexpr int MF_STAGE = 2 * MF_T * MF_PITCH;                 // one staging buffer: X lines, then W lines
-constexpr int MF_LDS = (MF_T * MF_CPITCH * 4 > 2 * MF_STAGE) ? MF_T * MF_CPITCH * 4 : 2 * MF_STAGE;
+constexpr int MF_SUMS = MF_T * MF_CPITCH * 4;  // line sums (8-plane operands): 128 X rows, 128 W columns, behind the result tile
+constexpr int MF_LDS = (MF_SUMS + 2 * MF_T * 4 > 2 * MF_STAGE) ? MF_SUMS + 2 * MF_T * 4 : 2 * MF_STAGE;
 
 // 32 packed elements (MSB-first) of `planes` planes -> 32 bytes (8 dwords), byte = sum_p bit_p << p
 template <int MAXP>
@@ -39,7 +45,7 @@ __device__ __forceinline__ void expand_word(const uint32_t (&wd)[MAXP], int plan
 #pragma unroll
     for (int p = 0; p < MAXP; p++) {
         if (p >= planes) break;
-        const uint32_t r = __brev(wd[p]);  // element i of the word at bit i
+        const uint32_t r = __brev(p == 7 ? ~wd[p] : wd[p]);  // element i of the word at bit i; plane 7: value - 128
 #pragma unroll
         for (int d = 0; d < 8; d++) {
             const uint32_t nib = (r >> (4 * d)) & 15u;
@@ -148,6 +154,11 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
                 }
             }
         };
+        // 8-plane operands: the epilogue needs this line's sum of values when the OTHER operand is the offset one
+        const bool need_sum = MAXP == 8 && (is_x ? sh.w == 8 : sh.a == 8);
+        uint32_t cnt[MAXP];  // set bits of the line, per plane
+#pragma unroll
+        for (int p = 0; p < MAXP; p++) cnt[p] = 0u;
         auto expand = [&](int q, const u32x4 (&src)[MAXP]) {  // packed words of step q -> bytes in staging buffer q & 1
             unsigned char *stage = my_stage + (q & 1) * MF_STAGE;
 #pragma unroll
@@ -156,6 +167,10 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
                 uint32_t wd[MAXP], out[8];
 #pragma unroll
                 for (int p = 0; p < MAXP; p++) wd[p] = (TPL == 2 && hw) ? src[p][2 + cc] : src[p][cc];
+                if (MAXP == 8 && need_sum) {
+#pragma unroll
+                    for (int p = 0; p < MAXP; p++) cnt[p] += __popc(wd[p]);
+                }
 #ifdef QGTC_MF_NOEXPAND  // timing-only build
 #pragma unroll
                 for (int d = 0; d < 8; d++) out[d] = wd[0];
@@ -204,6 +219,13 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
         }
 #undef QGTC_MF_STEP
         MF_STAMP(5);
+        if (MAXP == 8 && need_sum) {  // (the staging buffers are dead: the last barrier is behind every read)
+            uint32_t tot = 0u;
+#pragma unroll
+            for (int p = 0; p < MAXP; p++) tot += cnt[p] << p;
+            if (TPL == 2) tot += static_cast<uint32_t>(__shfl_xor(static_cast<int>(tot), 1));
+            if (hw == 0) reinterpret_cast<uint32_t *>(smem + MF_SUMS)[(is_x ? 0 : MF_T) + line] = tot;
+        }
     } else {
         __syncthreads();
         MF_STAMP(3);
@@ -288,6 +310,11 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
     const int *ct = reinterpret_cast<const int *>(smem);
     constexpr int NT = 64 * (4 + EXPW), LSTEP = NT / 32;
     const int qd = tid & 31, ln0 = tid >> 5;
+    // 8-plane operands (header): C += fix_x * (sum of X's row) + fix_w * (sum of W's column) + fix_k
+    const int *sums = reinterpret_cast<const int *>(smem + MF_SUMS);
+    const bool fix = MAXP == 8 && (sh.a == 8 || sh.w == 8);
+    const int fix_x = sh.w == 8 ? 128 : 0, fix_w = sh.a == 8 ? 128 : 0;
+    const int fix_k = (sh.a == 8 && sh.w == 8) ? static_cast<int>(0u - 2097152u * static_cast<uint32_t>(nq)) : 0;  // -16384 K' mod 2^32
     if (sh.mode == 2) {  // float32 [M,N] (reference kernel.h:915-930)
         const int along = n0 + 4 * qd;
         const int nvalid_line = min(max(N - along, 0), 4);
@@ -296,7 +323,11 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
         const bool vec_ok = nvalid_line == 4 && (N & 3) == 0;
         for (int ln = ln0; ln < MF_T && m0 + ln < M; ln += LSTEP, dst += static_cast<size_t>(LSTEP) * N, src += LSTEP * MF_CPITCH) {
             const int4 v4 = *reinterpret_cast<const int4 *>(src);
-            const int v[4] = {v4.x, v4.y, v4.z, v4.w};
+            int v[4] = {v4.x, v4.y, v4.z, v4.w};
+            if (MAXP == 8 && fix) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] += fix_x * sums[ln] + fix_w * sums[MF_T + 4 * qd + e] + fix_k;
+            }
             if (vec_ok) {
                 *reinterpret_cast<float4 *>(dst) = make_float4(static_cast<float>(v[0]), static_cast<float>(v[1]),
                                                                static_cast<float>(v[2]), static_cast<float>(v[3]));
@@ -331,7 +362,14 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
             const int across_store = MODE == 0 ? rows_pad : (1 << 30);   // lines that exist in the output
             for (int ln = ln0, across = across0; ln < MF_T; ln += LSTEP, across += LSTEP, outp += LSTEP * pitch, src += LSTEP * MF_CPITCH) {
                 const int4 v4 = *reinterpret_cast<const int4 *>(src);
-                const int v[4] = {v4.x, v4.y, v4.z, v4.w};
+                int v[4] = {v4.x, v4.y, v4.z, v4.w};
+                if (MAXP == 8 && fix) {  // element j of the quad: along index 32 grp + ell + 8j of line ln
+                    const int a0 = 32 * grp + ell;
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        v[e] += (MODE == 1 ? fix_w * sums[MF_T + ln] + fix_x * sums[a0 + 8 * e]
+                                           : fix_x * sums[ln] + fix_w * sums[MF_T + a0 + 8 * e]) + fix_k;
+                }
                 const uint32_t vml = across < across_lim ? vm : 0u;
                 const bool store = lead && across < across_store;
                 if constexpr (OB > 0) {

@@ -132,8 +132,8 @@ int dispatch_batched(const qgtc_problem *prs, int count, int max_M, int max_N, i
     });
 }
 
-// the MFMA engine handles plane counts whose values fit a non-negative int8
-inline bool mfma_ok(int a, int w) { return a >= 1 && a <= 7 && w >= 1 && w <= 7; }
+// the MFMA engine handles up to 8 planes per operand (8: offset by 128, corrected in the epilogue)
+inline bool mfma_ok(int a, int w) { return a >= 1 && a <= 8 && w >= 1 && w <= 8; }
 
 // QGTC_ENGINE_AUTO: pick the engine by a two-line cost model fitted to the round-1 measurements
 // (DESIGN.md section 5.4b): popcount runs at ~0.95e15 bit-ops/s plus ~3 us of launch and tail; the
@@ -158,8 +158,8 @@ int launch_mfma(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStrea
     if (!attr_set) {
 #define QGTC_MF_ATTR(P, E) \
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma<P, E>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
-        QGTC_MF_ATTR(1, 4) QGTC_MF_ATTR(2, 4) QGTC_MF_ATTR(4, 4) QGTC_MF_ATTR(7, 4)
-        QGTC_MF_ATTR(1, 8) QGTC_MF_ATTR(2, 8) QGTC_MF_ATTR(4, 8) QGTC_MF_ATTR(7, 8)
+        QGTC_MF_ATTR(1, 4) QGTC_MF_ATTR(2, 4) QGTC_MF_ATTR(4, 4) QGTC_MF_ATTR(8, 4)
+        QGTC_MF_ATTR(1, 8) QGTC_MF_ATTR(2, 8) QGTC_MF_ATTR(4, 8) QGTC_MF_ATTR(8, 8)
 #undef QGTC_MF_ATTR
         attr_set = true;
     }
@@ -172,7 +172,7 @@ int launch_mfma(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStrea
     if (maxp <= 1) { QGTC_MF_LAUNCH(1) }
     else if (maxp <= 2) { QGTC_MF_LAUNCH(2) }
     else if (maxp <= 4) { QGTC_MF_LAUNCH(4) }
-    else { QGTC_MF_LAUNCH(7) }
+    else { QGTC_MF_LAUNCH(8) }
 #undef QGTC_MF_LAUNCH
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
@@ -199,8 +199,8 @@ int launch_mfma_batched(const qgtc_problem *prs, int count, int max_M, int max_K
     if (!attr_set) {
 #define QGTC_MF_ATTR(P, E) \
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma_batched<P, E>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
-        QGTC_MF_ATTR(1, 4) QGTC_MF_ATTR(2, 4) QGTC_MF_ATTR(4, 4) QGTC_MF_ATTR(7, 4)
-        QGTC_MF_ATTR(1, 8) QGTC_MF_ATTR(2, 8) QGTC_MF_ATTR(4, 8) QGTC_MF_ATTR(7, 8)
+        QGTC_MF_ATTR(1, 4) QGTC_MF_ATTR(2, 4) QGTC_MF_ATTR(4, 4) QGTC_MF_ATTR(8, 4)
+        QGTC_MF_ATTR(1, 8) QGTC_MF_ATTR(2, 8) QGTC_MF_ATTR(4, 8) QGTC_MF_ATTR(8, 8)
 #undef QGTC_MF_ATTR
         attr_set = true;
     }
@@ -212,7 +212,7 @@ int launch_mfma_batched(const qgtc_problem *prs, int count, int max_M, int max_K
     if (maxp <= 1) { QGTC_MF_LAUNCH(1) }
     else if (maxp <= 2) { QGTC_MF_LAUNCH(2) }
     else if (maxp <= 4) { QGTC_MF_LAUNCH(4) }
-    else { QGTC_MF_LAUNCH(7) }
+    else { QGTC_MF_LAUNCH(8) }
 #undef QGTC_MF_LAUNCH
     HIP_TRY(hipGetLastError());
     return QGTC_OK;

@@ -582,7 +582,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         TORCH_CHECK(name == "popcount" || name == "mfma" || name == "auto", "engine must be 'popcount', 'mfma' or 'auto'");
         g_engine = name == "mfma" ? 1 : (name == "auto" ? 2 : 0);
     }, "engine of bitMM2Bit / bitMM2Bit_col / bitMM2Int: 'popcount' (default, AND + v_bcnt), 'mfma' (bit planes "
-       "expanded to int8 on the fly, v_mfma_i32_32x32x32_i8; bit widths <= 7, else popcount) or 'auto' (a cost "
+       "expanded to int8 on the fly, v_mfma_i32_32x32x32_i8; bit widths <= 8, else popcount) or 'auto' (a cost "
        "model picks per call). Same results.");
     m.def("get_engine", [] { return std::string(g_engine == 1 ? "mfma" : (g_engine == 2 ? "auto" : "popcount")); });
     m.def("get_zero_skip", [] { return g_zero_skip; });

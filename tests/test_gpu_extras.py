@@ -112,7 +112,7 @@ def test_tile_occupancy_bitmap(qgtc, oracle, M, K, a, density):
     np.testing.assert_array_equal(got, np_tile_occupancy(X, M, K, a))
 
 
-@pytest.mark.parametrize("a,w,ob", [(1, 2, 2), (1, 1, 1), (2, 2, 3), (3, 5, 4)])
+@pytest.mark.parametrize("a,w,ob", [(1, 2, 2), (1, 1, 1), (2, 2, 3), (3, 5, 4), (8, 8, 8)])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("engine", ["popcount", "mfma"])
 def test_zero_jump_products_are_identical(qgtc, oracle, a, w, ob, mode, engine):
@@ -187,6 +187,9 @@ MFMA_CASES = [
     (128, 128, 128, 1, 1, 1), (64, 256, 128, 1, 1, 1), (200, 1000, 150, 1, 2, 2), (129, 130, 257, 2, 2, 3),
     (1213, 1213, 128, 1, 2, 2), (300, 4096, 300, 1, 4, 4), (77, 513, 40, 3, 5, 6), (512, 640, 256, 7, 7, 8),
     (33, 33, 33, 1, 7, 2), (256, 9000, 128, 1, 1, 1),
+    # 8-plane operands: plane 7 inverted on the way in, corrected with line sums in the epilogue
+    (130, 300, 140, 1, 8, 8), (200, 520, 129, 8, 8, 8), (77, 129, 40, 8, 3, 4), (129, 1000, 257, 3, 8, 2),
+    (64, 128, 64, 8, 8, 1),
 ]
 
 
@@ -218,12 +221,12 @@ def test_mfma_engine_matches_oracle_and_popcount(qgtc, oracle, M, K, N, a, w, ob
         assert torch.equal(a_, b_)
 
 
-def test_mfma_engine_falls_back_above_7_bits(qgtc, oracle):
+def test_mfma_engine_falls_back_above_8_bits(qgtc, oracle):
     import torch
     from helpers import rand_q, to_dev
     from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
     rng = np.random.default_rng(8)
-    M, K, N, a, w, ob = 130, 300, 140, 1, 8, 8
+    M, K, N, a, w, ob = 130, 300, 140, 1, 9, 8
     qx, qw = rand_q(rng, M, K, a), rand_q(rng, K, N, w)
     X, Wt = oracle.pack(qx, a, False), oracle.pack(qw, w, True)
     dX, dW = to_dev(torch, X, rows_shape(M, K, a)), to_dev(torch, Wt, cols_shape(K, N, w))
