@@ -21,9 +21,9 @@ namespace {
 // int32 arithmetic mod 2^32, like everything else here. The sums are popcounts of the packed words.
 //
 // Per k-quad (128 bits of K) one thread of the expander waves expands one row of X or one column of W:
-// every 32-bit word is bit-reversed (element i at bit i), each nibble is spread to four bytes with
-// one 24-bit multiply ((n * 0x204081) & 0x01010101) and planes are merged with shift-or; the 128
-// bytes go to LDS ([line][144-byte pitch]: the 16-byte MFMA fragment reads of 32 lines are
+// dword d of a word's 32 bytes takes the word's bits d, d+8, d+16, d+24 (a shift and an AND per plane and
+// dword - the order of the elements inside a word is irrelevant to the product as long as both operands
+// share it); the 128 bytes go to LDS ([line][144-byte pitch]: the 16-byte MFMA fragment reads of 32 lines are
 // conflict-free). The packed words of the next k-quad are loaded (range-checked buffer loads)
 // while the current one is multiplied. The finished 128 x 128 int32 tile goes through LDS to the
 // same three epilogues (rows-layout bits, cols-layout bits, float32); with 128-wide tiles every
@@ -37,7 +37,11 @@ constexpr int MF_STAGE = 2 * MF_T * MF_PITCH;                 // one staging buf
 constexpr int MF_SUMS = MF_T * MF_CPITCH * 4;  // line sums (8-plane operands): 128 X rows, 128 W columns, behind the result tile
 constexpr int MF_LDS = (MF_SUMS + 2 * MF_T * 4 > 2 * MF_STAGE) ? MF_SUMS + 2 * MF_T * 4 : 2 * MF_STAGE;
 
-// 32 packed elements (MSB-first) of `planes` planes -> 32 bytes (8 dwords), byte = sum_p bit_p << p
+// 32 packed elements of `planes` planes -> 32 bytes (8 dwords), byte = sum_p bit_p << p.
+// The dot product over k does not care in which ORDER the 32 elements of a word become bytes as long as
+// X and W use the same order, so the cheapest bijection is taken: dword d holds the word's bits d, d+8,
+// d+16, d+24 (one per byte) - a shift and an AND with 0x01010101 << p per (plane, dword), no bit reversal,
+// no per-nibble multiply. (Plane 7 of an 8-plane operand arrives inverted: byte = value - 128.)
 template <int MAXP>
 __device__ __forceinline__ void expand_word(const uint32_t (&wd)[MAXP], int planes, uint32_t (&out)[8]) {
 #pragma unroll
@@ -45,12 +49,12 @@ __device__ __forceinline__ void expand_word(const uint32_t (&wd)[MAXP], int plan
 #pragma unroll
     for (int p = 0; p < MAXP; p++) {
         if (p >= planes) break;
-        const uint32_t r = __brev(p == 7 ? ~wd[p] : wd[p]);  // element i of the word at bit i; plane 7: value - 128
+        const uint32_t r = p == 7 ? ~wd[p] : wd[p];
 #pragma unroll
         for (int d = 0; d < 8; d++) {
-            const uint32_t nib = (r >> (4 * d)) & 15u;
-            const uint32_t bytes = __umul24(nib, 0x204081u) & 0x01010101u;  // bit e of the nibble -> byte e
-            out[d] |= bytes << p;
+            // bits d + 8i of r to bits p + 8i (p + 24 <= 31: a left shift loses nothing that is kept)
+            const uint32_t t = d > p ? r >> (d - p) : (d < p ? r << (p - d) : r);
+            out[d] |= t & (0x01010101u << p);
         }
     }
 }

@@ -180,12 +180,13 @@ int launch_mfma(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStrea
 
 // QGTC_ENGINE_AUTO for grouped launches (cluster batches: many small products, every workgroup short-
 // lived). Measured on the ogbn-arxiv- and ppi-sized epochs: the matrix-core
-// engine wins when its 128-wide tile is mostly full (N = 128: X.W 14 us against 27, A.(XW) 24
-// against 28) or when many plane pairs share one expansion (4 x 4 bits at N = 64: 17 against 24);
-// narrow outputs (N = 10 classes) and few-plane products at N <= 64 stay on the popcount kernels.
+// engine wins when its 128-wide tile is mostly full (N = 128: X.W 13 us against 24, A.(XW) 22
+// against 27) or when four or more plane pairs share one expansion at N >= 48 (ppi: 4 x 4 bits at
+// N = 64 14 against 22, 1 x 4 bits at N = 50 18.6 against 20.8); narrow outputs (N = 10 classes)
+// and one- or two-pair products at N <= 64 stay on the popcount kernels.
 inline bool auto_prefers_mfma_batched(int max_M, int max_N, int a, int w) {
     if (!mfma_ok(a, w) || max_M < MF_T) return false;
-    return max_N >= 96 || (a * w >= 8 && max_N >= 48);
+    return max_N >= 96 || (a * w >= 4 && max_N >= 48);
 }
 
 // grouped launch on the matrix cores: one workgroup per 128 x 128 tile of every problem
