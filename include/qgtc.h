@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QGTC_ABI_VERSION 3
+#define QGTC_ABI_VERSION 4
 
 enum {
     QGTC_OK = 0,
@@ -138,6 +138,20 @@ typedef struct qgtc_problem {
 size_t qgtc_occupancy_words(int M, int K);
 int qgtc_tile_occupancy(const uint32_t *X, size_t x_words, int M, int K, int bit1, uint64_t *occ,
                         size_t occ_words, void *stream);
+
+/* The bitmaps of all problems of a grouped launch in ONE launch: every problem with a non-NULL `occ`
+ * gets its bitmap written where `occ` points (occ_words must be ceil(STEP128(K) / 64)). With `stats`
+ * (device pointer to two uint64) a second, one-workgroup kernel counts stats[0] = occupied and
+ * stats[1] = all 32-row x 128-bit tiles and, when more than `max_fraction` of them are occupied, clears
+ * the `occ` fields of the DEVICE descriptors (jumping then only costs a dependent load): the decision
+ * needs no host round trip. Pass QGTC_ZERO_JUMP to qgtc_bitmm_batched either way. */
+int qgtc_tile_occupancy_batched(qgtc_problem *problems, int count, int max_M, int max_K, int bit1,
+                                float max_fraction, uint64_t *stats, void *stream);
+
+/* Only the counting / clearing step, for descriptors whose bitmaps already exist (the adjacency bitmaps of
+ * an epoch are shared by all its A.(...) stages). */
+int qgtc_tile_occupancy_decide(qgtc_problem *problems, int count, float max_fraction, uint64_t *stats,
+                               void *stream);
 
 int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int max_K, int max_N,
                        int bit1, int bit2, int output_bit, int mode, unsigned flags,

@@ -244,6 +244,30 @@ int qgtc_tile_occupancy(const uint32_t *X, size_t x_words, int M, int K, int bit
     return QGTC_OK;
 }
 
+int qgtc_tile_occupancy_batched(qgtc_problem *problems, int count, int max_M, int max_K, int bit1,
+                                float max_fraction, uint64_t *stats, void *stream) {
+    if (!problems || count <= 0 || count > 65535 || max_M <= 0 || max_K <= 0 || !bits_ok(bit1)) return QGTC_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int waves = ((max_M + TM - 1) / TM) * ((step128(max_K) + 63) / 64);
+    hipLaunchKernelGGL(k_tile_occupancy_batched, dim3((waves + 3) / 4, count), dim3(256), 0, st, problems, bit1);
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        hipLaunchKernelGGL(k_occupancy_decide, dim3(1), dim3(1024), 0, st, problems, count, max_fraction,
+                           reinterpret_cast<unsigned long long *>(stats));
+        HIP_TRY(hipGetLastError());
+    }
+    return QGTC_OK;
+}
+
+int qgtc_tile_occupancy_decide(qgtc_problem *problems, int count, float max_fraction, uint64_t *stats,
+                               void *stream) {
+    if (!problems || !stats || count <= 0 || count > 65535) return QGTC_EINVAL;
+    hipLaunchKernelGGL(k_occupancy_decide, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), problems,
+                       count, max_fraction, reinterpret_cast<unsigned long long *>(stats));
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
 int qgtc_pack_edges(const int64_t *cells, const int32_t *counts, size_t n_cells, int H, int W,
                     int nbits, uint32_t *out, size_t out_words, void *stream) {
     if (!out || H <= 0 || W <= 0 || !bits_ok(nbits) || (n_cells && !cells)) return QGTC_EINVAL;

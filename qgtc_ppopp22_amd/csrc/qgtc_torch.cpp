@@ -352,32 +352,54 @@ double i8gemm_profile(torch::Tensor A, torch::Tensor Bt, int reps, bool print) {
 // ---------------------------------------------------------------------------------------------
 struct BatchedGemm {
     torch::Tensor descs;  // uint8 device tensor holding qgtc_problem[count]
-    std::vector<torch::Tensor> keep;  // operands + outputs kept alive
-    std::vector<torch::Tensor> outs;
-    std::vector<torch::Tensor> occs;  // occupancy bitmaps of the left operands (zero_jump)
+    std::vector<torch::Tensor> keep;  // operands + pools kept alive
+    std::vector<torch::Tensor> outs;  // views into one pooled allocation per launch
+    std::vector<torch::Tensor> occs;  // occupancy bitmaps of the left operands (zero_jump), views into one pool
     std::vector<qgtc_problem> host_descs;  // the same descriptors on the host, for run_per_problem()
+    torch::Tensor stats;  // device: [occupied, all] 32-row x 128-bit tiles of the left operands (zero_jump)
     int count = 0, max_M = 0, max_K = 0, max_N = 0, bit1 = 1, bit2 = 1, ob = 1, mode = 0;
-    bool jump = false;
-    double occupied_fraction = 1.0;  // of the left operands' 32-row x 128-bit tiles (when zero_jump was asked for)
+    bool jump_asked = false;
+    static constexpr double kJumpBelow = 0.25;  // measured: at 19 % occupied tiles jumping gains 10 %, at 43 % it loses 15 %
 
     // Xs[i]: rows-layout left operand of problem i; Ws: one shared right operand (len 1) or one
     // per problem; dims[i] = (M, K, N). mode 0/1/2 as qgtc_bitmm_batched; pad_128 only for mode 2.
-    // zero_jump: build the occupancy bitmap of every left operand once (qgtc_tile_occupancy) so
-    // that run() neither loads nor multiplies all-zero 32-row x 128-bit X tiles. The bitmap
-    // describes Xs[i] as it is NOW: pass false when the left operands are outputs of an earlier
-    // stage that change between runs.
+    // zero_jump: build the occupancy bitmap of every left operand once (one grouped launch) so that
+    // run() neither loads nor multiplies all-zero 32-row x 128-bit X tiles. Jumping pays when most X
+    // tiles are empty (block-diagonal cluster adjacency); whether it does is decided on the device
+    // (qgtc_tile_occupancy_batched clears the descriptors' bitmaps above a quarter occupied), so building
+    // the plan never waits for the GPU; .zero_jump / .occupied_fraction read the outcome back lazily.
+    // The bitmap describes Xs[i] as it is NOW: pass false when the left operands are outputs of an
+    // earlier stage that change between runs.
     BatchedGemm(std::vector<torch::Tensor> Xs, std::vector<torch::Tensor> Ws,
                 std::vector<std::tuple<int, int, int>> dims, int bit1_, int bit2_, int ob_,
                 int mode_, bool pad_128, bool zero_jump, std::vector<torch::Tensor> reuse_occs)
-        : bit1(bit1_), bit2(bit2_), ob(ob_), mode(mode_), jump(zero_jump) {
+        : bit1(bit1_), bit2(bit2_), ob(ob_), mode(mode_), jump_asked(zero_jump) {
         count = static_cast<int>(Xs.size());
         TORCH_CHECK(count > 0, "empty batch");
         TORCH_CHECK(Ws.size() == 1 || static_cast<int>(Ws.size()) == count, "Ws must have 1 or len(Xs) tensors");
         TORCH_CHECK(static_cast<int>(dims.size()) == count, "dims must have len(Xs) entries");
         TORCH_CHECK(mode >= 0 && mode <= 2, "mode must be 0, 1 or 2");
+        TORCH_CHECK(reuse_occs.empty() || static_cast<int>(reuse_occs.size()) == count, "occs must have len(Xs) tensors");
         const auto dev = Xs[0].device();
         c10::DeviceGuard guard(dev);
         std::vector<qgtc_problem> h(count);
+        // one allocation for all outputs (and one for all bitmaps): every view starts 16-byte aligned
+        std::vector<int64_t> out_off(count + 1, 0), occ_off(count + 1, 0);
+        auto round4 = [](int64_t n) { return (n + 3) & ~int64_t(3); };
+        for (int i = 0; i < count; i++) {
+            const int M = std::get<0>(dims[i]), K = std::get<1>(dims[i]), N = std::get<2>(dims[i]);
+            TORCH_CHECK(M > 0 && K > 0 && N > 0, "bad dimensions");
+            const int64_t n_out = mode == 2 ? static_cast<int64_t>(M) * N
+                                : mode == 1 ? static_cast<int64_t>(ob) * S128(M) * 4 * P128(N)
+                                            : static_cast<int64_t>(ob) * P8(M) * S128(N) * 4;
+            out_off[i + 1] = out_off[i] + round4(n_out);
+            occ_off[i + 1] = occ_off[i] + static_cast<int64_t>(qgtc_occupancy_words(M, K));
+        }
+        torch::Tensor out_pool = torch::empty({out_off[count]}, torch::TensorOptions().dtype(mode == 2 ? torch::kFloat32 : torch::kInt32).device(dev));
+        torch::Tensor occ_pool;
+        if (zero_jump && reuse_occs.empty())
+            occ_pool = torch::empty({occ_off[count]}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
+        keep.push_back(out_pool);
         for (int i = 0; i < count; i++) {
             const torch::Tensor &X = Xs[i];
             const torch::Tensor &W = Ws.size() == 1 ? Ws[0] : Ws[i];
@@ -387,19 +409,15 @@ struct BatchedGemm {
             check_bits_tensor(W, "W");
             TORCH_CHECK(X.device() == dev && W.device() == dev, "all operands must share a device");
             const int M = std::get<0>(dims[i]), K = std::get<1>(dims[i]), N = std::get<2>(dims[i]);
-            TORCH_CHECK(M > 0 && K > 0 && N > 0, "bad dimensions");
             TORCH_CHECK(X.numel() < (1LL << 30) && W.numel() < (1LL << 30), "packed operand too large (>= 4 GiB)");
             TORCH_CHECK((reinterpret_cast<uintptr_t>(X.data_ptr()) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(W.data_ptr()) & 15) == 0, "packed operands must be 16-byte aligned");
-            torch::Tensor out;
-            if (mode == 2)
-                out = torch::empty({M, N}, torch::TensorOptions().dtype(torch::kFloat32).device(dev));
-            else if (mode == 1)
-                out = torch::empty({static_cast<int64_t>(ob) * S128(M) * 4, P128(N)},
-                                   torch::TensorOptions().dtype(torch::kInt32).device(dev));
-            else
-                out = torch::empty({static_cast<int64_t>(ob) * P8(M), S128(N) * 4},
-                                   torch::TensorOptions().dtype(torch::kInt32).device(dev));
+            torch::Tensor flat = out_pool.narrow(0, out_off[i], mode == 2 ? static_cast<int64_t>(M) * N
+                                                 : mode == 1 ? static_cast<int64_t>(ob) * S128(M) * 4 * P128(N)
+                                                             : static_cast<int64_t>(ob) * P8(M) * S128(N) * 4);
+            torch::Tensor out = mode == 2 ? flat.view({M, N})
+                              : mode == 1 ? flat.view({static_cast<int64_t>(ob) * S128(M) * 4, P128(N)})
+                                          : flat.view({static_cast<int64_t>(ob) * P8(M), S128(N) * 4});
             h[i].X = words(X);
             h[i].W = words(W);
             h[i].out = out.data_ptr();
@@ -412,19 +430,14 @@ struct BatchedGemm {
             h[i].occ = nullptr;
             h[i].occ_words = 0;
             if (zero_jump) {
-                const int64_t nw = static_cast<int64_t>(qgtc_occupancy_words(M, K));
+                const int64_t nw = occ_off[i + 1] - occ_off[i];
                 torch::Tensor occ;
                 if (!reuse_occs.empty()) {  // bitmaps of the same left operands from an earlier BatchedGemm
-                    TORCH_CHECK(static_cast<int>(reuse_occs.size()) == count, "occs must have len(Xs) tensors");
                     occ = reuse_occs[i];
                     TORCH_CHECK(occ.is_cuda() && occ.is_contiguous() && occ.scalar_type() == torch::kInt64 &&
                                 occ.numel() >= nw && occ.device() == dev, "bad occupancy bitmap");
                 } else {
-                    occ = torch::empty({nw}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
-                    check_rc(qgtc_tile_occupancy(words(X), X.numel(), M, K, bit1,
-                                                 reinterpret_cast<uint64_t *>(occ.data_ptr<int64_t>()), nw,
-                                                 current_stream(X)),
-                             "BatchedGemm (tile occupancy)");
+                    occ = occ_pool.narrow(0, occ_off[i], nw);
                 }
                 h[i].occ = reinterpret_cast<const uint64_t *>(occ.data_ptr<int64_t>());
                 h[i].occ_words = (S128(K) + 63) / 64;
@@ -437,45 +450,33 @@ struct BatchedGemm {
             keep.push_back(W);
             outs.push_back(out);
         }
-        if (zero_jump) {
-            // Jumping pays when most X tiles are empty (block-diagonal cluster adjacency); on a dense
-            // operand the bitmap only adds a dependent scalar load ahead of every tile's first loads.
-            // Decide once, here: keep the bitmaps only if under a quarter of the tiles are occupied (measured: at 19 % jumping
-            // gains 10 %, at 43 % it loses 15 %).
-            // one popcount over all bitmaps (a handful of elementwise kernels, one host sync)
-            double set = 0.0, all = 0.0;
-            {
-                std::vector<torch::Tensor> flat;
-                for (auto &o : occs) flat.push_back(o.view({-1}));
-                auto x = torch::cat(flat);  // int64 words; SWAR popcount on the two's-complement bits
-                const int64_t m1 = 0x5555555555555555LL, m2 = 0x3333333333333333LL, m4 = 0x0f0f0f0f0f0f0f0fLL;
-                auto lsr = [](const torch::Tensor &t, int s) {  // logical shift right of int64
-                    return t.bitwise_right_shift(s).bitwise_and(static_cast<int64_t>((~0ULL) >> s));
-                };
-                x = x - lsr(x, 1).bitwise_and(m1);
-                x = x.bitwise_and(m2) + lsr(x, 2).bitwise_and(m2);
-                x = (x + lsr(x, 4)).bitwise_and(m4);
-                x = x + lsr(x, 8);
-                x = x + lsr(x, 16);
-                x = (x + lsr(x, 32)).bitwise_and(127);
-                set = x.sum().item<double>();
-            }
-            for (int i = 0; i < count; i++) all += static_cast<double>(S128(h[i].K)) * ((h[i].M + 31) / 32);
-            occupied_fraction = all > 0.0 ? set / all : 1.0;
-            if (occupied_fraction > 0.25) {
-                jump = false;
-                for (int i = 0; i < count; i++) {
-                    h[i].occ = nullptr;
-                    h[i].occ_words = 0;
-                }
-            }
-        }
         host_descs = h;
         auto host = torch::empty({static_cast<int64_t>(count * sizeof(qgtc_problem))},
                                  torch::TensorOptions().dtype(torch::kUInt8));
         std::memcpy(host.data_ptr(), h.data(), count * sizeof(qgtc_problem));
         descs = host.to(dev);
+        if (zero_jump) {
+            stats = torch::empty({2}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
+            qgtc_problem *dp = reinterpret_cast<qgtc_problem *>(descs.data_ptr());
+            uint64_t *sp = reinterpret_cast<uint64_t *>(stats.data_ptr<int64_t>());
+            int rc;
+            if (reuse_occs.empty()) {
+                rc = qgtc_tile_occupancy_batched(dp, count, max_M, max_K, bit1, static_cast<float>(kJumpBelow), sp, current_stream(descs));
+            } else {  // the bitmaps exist: only count and decide
+                rc = qgtc_tile_occupancy_decide(dp, count, static_cast<float>(kJumpBelow), sp, current_stream(descs));
+            }
+            check_rc(rc, "BatchedGemm (tile occupancy)");
+        }
     }
+
+    // outcome of the on-device decision (waits for it)
+    double occupied_fraction() const {
+        if (!jump_asked) return 1.0;
+        auto s = stats.cpu();
+        const double set = static_cast<double>(s.data_ptr<int64_t>()[0]), all = static_cast<double>(s.data_ptr<int64_t>()[1]);
+        return all > 0.0 ? set / all : 1.0;
+    }
+    bool zero_jump() const { return jump_asked && occupied_fraction() <= kJumpBelow; }
 
     // The reference's launch structure (one launch per cluster batch and operator) with the
     // independent batches spread over `n_streams` HIP streams: batch i always runs on stream
@@ -517,7 +518,7 @@ struct BatchedGemm {
         c10::DeviceGuard guard(descs.device());
         check_rc(qgtc_bitmm_batched(reinterpret_cast<const qgtc_problem *>(descs.data_ptr()), count,
                                     max_M, max_K, max_N, bit1, bit2, ob, mode,
-                                    mm_flags() | (jump ? QGTC_ZERO_JUMP : 0u), current_stream(descs)),
+                                    mm_flags() | (jump_asked ? QGTC_ZERO_JUMP : 0u), current_stream(descs)),
                  "BatchedGemm.run");
     }
 };
@@ -607,6 +608,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def("run_per_problem", &BatchedGemm::run_per_problem, py::arg("n_streams") = 1)
         .def_readonly("outs", &BatchedGemm::outs)
         .def_readonly("count", &BatchedGemm::count)
-        .def_readonly("zero_jump", &BatchedGemm::jump)
-        .def_readonly("occupied_fraction", &BatchedGemm::occupied_fraction);
+        .def_property_readonly("zero_jump", &BatchedGemm::zero_jump)
+        .def_property_readonly("occupied_fraction", &BatchedGemm::occupied_fraction);
 }

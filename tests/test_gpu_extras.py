@@ -260,3 +260,39 @@ def test_auto_engine_same_words_either_way(qgtc, M, K, N, a, w, ob):
         qgtc.set_engine("popcount")
     for x, y in zip(au, pop):
         assert torch.equal(x, y)
+
+
+def test_jump_decision_is_made_on_the_device(qgtc, oracle):
+    """BatchedGemm(zero_jump=True) fills all bitmaps with one grouped launch and a one-workgroup kernel
+    keeps or clears them (a quarter of the tiles occupied is the threshold); the host only learns the
+    outcome when it asks. Counts equal the oracle's bitmaps; products are the same either way."""
+    import torch
+    from helpers import rand_q, to_dev
+    rng = np.random.default_rng(77)
+    a, w, ob = 1, 2, 2
+    dims = [(300, 1213, 64), (1213, 1213, 128), (90, 200, 10)]
+    for density, expect_jump in ((0.00003, True), (0.2, False)):
+        Xs, Ws, want, set_bits, all_tiles = [], [], [], 0, 0
+        for (M, K, N) in dims:
+            qx, qw = rand_q(rng, M, K, a, density), rand_q(rng, K, N, w)
+            X, Wt = oracle.pack(qx, a, False), oracle.pack(qw, w, True)
+            Xs.append(to_dev(torch, X, (a * ((M + 7) // 8 * 8), (K + 127) // 128 * 4)))
+            Ws.append(to_dev(torch, Wt, (w * ((K + 127) // 128 * 4), (N + 127) // 128 * 128)))
+            want.append(oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob))
+            occ = np_tile_occupancy(X, M, K, a)
+            set_bits += int(sum(bin(int(v)).count("1") for v in occ))
+            all_tiles += ((M + 31) // 32) * ((K + 127) // 128)
+        bg = qgtc.BatchedGemm(Xs, Ws, dims, a, w, ob, 0, True, True)
+        bg.run()
+        assert bg.zero_jump == expect_jump
+        assert abs(bg.occupied_fraction - set_bits / all_tiles) < 1e-12
+        for i in range(len(dims)):
+            np.testing.assert_array_equal(to_np_u32(bg.outs[i]), want[i])
+            np.testing.assert_array_equal(bg.occs[i].cpu().numpy().view(np.uint64),
+                                          np_tile_occupancy(to_np_u32(Xs[i]), dims[i][0], dims[i][1], a))
+        # a second stage reusing the bitmaps reaches the same decision
+        bg2 = qgtc.BatchedGemm(Xs, Ws, dims, a, w, ob, 0, True, True, bg.occs)
+        bg2.run()
+        assert bg2.zero_jump == expect_jump
+        for i in range(len(dims)):
+            np.testing.assert_array_equal(to_np_u32(bg2.outs[i]), want[i])
