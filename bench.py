@@ -172,6 +172,14 @@ def adj_size_table(Q, device):
             Q.profile(ba, bx, mk, mk, nn, 1, 1, 1, 20)
             ms = min(Q.profile(ba, bx, mk, mk, nn, 1, 1, 1, 200) for _ in range(3))
             row[f"M{mk}"] = {"TOPS": round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2), "ref_sm86": ref[mi]}
+            if nn >= 512:   # where the cost model of set_engine("auto") moves to the matrix cores
+                Q.set_engine("auto")
+                try:
+                    Q.profile(ba, bx, mk, mk, nn, 1, 1, 1, 20)
+                    ms = min(Q.profile(ba, bx, mk, mk, nn, 1, 1, 1, 200) for _ in range(3))
+                finally:
+                    Q.set_engine("popcount")
+                row[f"M{mk}"]["TOPS_engine_auto"] = round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2)
         out[f"N{nn}"] = row
     return out
 

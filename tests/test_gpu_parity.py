@@ -270,11 +270,22 @@ def test_batched_matches_single(qgtc, oracle):
                                               oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob, col=(mode == 1)))
 
 
-def test_random_shape_sweep(qgtc, oracle):
+@pytest.mark.parametrize("engine", ["popcount", "mfma"])
+def test_random_shape_sweep(qgtc, oracle, engine):
     """Seeded random sweep over shapes, plane counts, output modes and both launch forms: catches
-    what the hand-picked cases miss (tile edges, wave counts, plane blocking, zero rows)."""
+    what the hand-picked cases miss (tile edges, wave counts, plane blocking, zero rows). Run once per
+    engine (plane counts above 8 stay on the popcount kernels under 'mfma' too)."""
     import torch
-    rng = np.random.default_rng(20260301)
+    qgtc.set_engine(engine)
+    try:
+        _random_shape_sweep(qgtc, oracle, 20260301 if engine == "popcount" else 20260302)
+    finally:
+        qgtc.set_engine("popcount")
+
+
+def _random_shape_sweep(qgtc, oracle, seed):
+    import torch
+    rng = np.random.default_rng(seed)
     singles = {0: lambda *a: qgtc.bitMM2Bit(*a), 1: lambda *a: qgtc.bitMM2Bit_col(*a)}
     for case in range(70):
         M = int(rng.integers(1, 180))
