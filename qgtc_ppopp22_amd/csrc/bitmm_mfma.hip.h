@@ -29,7 +29,16 @@ namespace {
 // same three epilogues (rows-layout bits, cols-layout bits, float32); with 128-wide tiles every
 // output word belongs to exactly one workgroup, so there is no padding to zero-fill separately.
 // ------------------------------------------------------------------------------------------
+//
+// FP4 form (plane counts <= 2, sums below 2^24): E2M1 codes 0..3 are 0, 0.5, 1, 1.5, so a 2-bit value v
+// stored as the nibble v means v / 2 and v_mfma_scale_f32_32x32x64_f8f6f4 with the E8M0 scale 2 on both
+// operands returns the integer product exactly in float32 (tools/fp4_probe.hip). Half the expanded bytes
+// (64 per line and k-quad), half the expansion work (dword d of a word's 16 bytes takes bits d, d+4, ..),
+// half the fragment reads and twice the MFMA rate of the int8 form.
 typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MF_PITCH4 = 80;      // FP4 form: bytes between the expanded lines (64 + 16: conflict-free 16-byte reads)
 constexpr int MF_T = 128;          // tile edge
 constexpr int MF_PITCH = 144;      // bytes between the expanded lines of one operand
 constexpr int MF_CPITCH = 132;     // ints between the rows (cols layout: columns) of the result tile in LDS
@@ -59,6 +68,23 @@ __device__ __forceinline__ void expand_word(const uint32_t (&wd)[MAXP], int plan
     }
 }
 
+// FP4 form: 32 packed elements of 1 or 2 planes -> 32 nibbles (4 dwords), nibble = b0 + 2 b1 (= E2M1 v / 2)
+template <int MAXP>
+__device__ __forceinline__ void expand_word_fp4(const uint32_t (&wd)[MAXP], int planes, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int d = 0; d < 4; d++) out[d] = 0u;
+#pragma unroll
+    for (int p = 0; p < MAXP; p++) {
+        if (p >= planes || p >= 2) break;
+        const uint32_t r = wd[p];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t t = d > p ? r >> (d - p) : (d < p ? r << (p - d) : r);  // bits d + 4i to bits p + 4i
+            out[d] |= t & (0x11111111u << p);
+        }
+    }
+}
+
 // EXPW expander waves: 8 (two threads per line) when a CU holds one workgroup - a lone expander wave per
 // SIMD is latency-bound - or 4 (one thread per line, fewer registers per workgroup) when the grid is large
 // enough for two workgroups per CU to overlap each other.
@@ -67,9 +93,12 @@ __device__ __forceinline__ void expand_word(const uint32_t (&wd)[MAXP], int plan
 // 64-bit word per 32-row tile, i.e. K <= 8192) the workgroup ORs the words of its four row tiles and
 // visits only the k-quads whose 128-row x 128-bit X tile has a bit set - every wave derives the same
 // sequence from the same scalar loads, so the expander / multiplier hand-over needs nothing extra.
-template <int MAXP, int EXPW>
+template <int MAXP, int EXPW, bool FP4 = false>
 __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &sh, int tm, int tn,
                                         unsigned char *smem) {
+    static_assert(!FP4 || MAXP <= 2, "the FP4 form holds 2-bit values at most");
+    constexpr int PITCH = FP4 ? MF_PITCH4 : MF_PITCH;   // bytes between expanded lines
+    constexpr int STAGE = 2 * MF_T * PITCH;             // one staging buffer: X lines, then W lines
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = pr.M, K = pr.K, N = pr.N;
@@ -99,6 +128,7 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
     MF_STAMP(0);
 
     i32x16 acc[2][2];
+    f32x16 accf[2][2];  // FP4 form (the unused set is dead code)
     const int mw = wv & 3, wr = mw >> 1, wc = mw & 1;   // multiplier wave (wr, wc): a 64 x 64 quarter, 2 x 2 MFMA tiles
     const int fl = lane & 31, fh = lane >> 5;           // fragment line, k half (16 bytes each)
 #pragma unroll
@@ -106,7 +136,10 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
+            for (int r = 0; r < 16; r++) {
+                acc[i][j][r] = 0;
+                accf[i][j][r] = 0.0f;
+            }
 
     if (expander) {
         const uint32_t kw = static_cast<uint32_t>(kq) * 4u;
@@ -128,7 +161,7 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
         const int planes = is_x ? sh.a : sh.w;
         const uint32_t plane_words = is_x ? x_plane : w_plane;
         const uint32_t base = static_cast<uint32_t>(gline) * kw * 4u;  // byte offset of the line inside a plane
-        unsigned char *my_stage = smem + (is_x ? 0 : MF_T * MF_PITCH) + line * MF_PITCH;
+        unsigned char *my_stage = smem + (is_x ? 0 : MF_T * PITCH) + line * PITCH;
         // Packed words are loaded GQ k-quads at a time per line (GQ * 16 contiguous bytes per lane): one
         // k-quad per load instruction touches 64 different 128-byte lines for 16 bytes each and the L1
         // (32 KB) does not keep them until the next k-quad - measured: 1300 cycles per k-quad, all of
@@ -164,7 +197,7 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
 #pragma unroll
         for (int p = 0; p < MAXP; p++) cnt[p] = 0u;
         auto expand = [&](int q, const u32x4 (&src)[MAXP]) {  // packed words of step q -> bytes in staging buffer q & 1
-            unsigned char *stage = my_stage + (q & 1) * MF_STAGE;
+            unsigned char *stage = my_stage + (q & 1) * STAGE;
 #pragma unroll
             for (int cc = 0; cc < 4 / TPL; cc++) {
                 const int c = (4 / TPL) * hw + cc;  // this thread's words of the k-quad
@@ -174,6 +207,12 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
                 if (MAXP == 8 && need_sum) {
 #pragma unroll
                     for (int p = 0; p < MAXP; p++) cnt[p] += __popc(wd[p]);
+                }
+                if constexpr (FP4) {
+                    uint32_t o4[4];
+                    expand_word_fp4<MAXP>(wd, planes, o4);
+                    *reinterpret_cast<u32x4 *>(stage + c * 16) = u32x4{o4[0], o4[1], o4[2], o4[3]};
+                    continue;
                 }
 #ifdef QGTC_MF_NOEXPAND  // timing-only build
 #pragma unroll
@@ -235,33 +274,42 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
         MF_STAMP(3);
         for (int q = 0; q < nq; q++) {
             if (q == 8) MF_STAMP(4);
-            const unsigned char *xs = smem + (q & 1) * MF_STAGE + (64 * wr + fl) * MF_PITCH + 16 * fh;
-            const unsigned char *ws = smem + (q & 1) * MF_STAGE + MF_T * MF_PITCH + (64 * wc + fl) * MF_PITCH + 16 * fh;
+            const unsigned char *xs = smem + (q & 1) * STAGE + (64 * wr + fl) * PITCH + 16 * fh;
+            const unsigned char *ws = smem + (q & 1) * STAGE + MF_T * PITCH + (64 * wc + fl) * PITCH + 16 * fh;
             // fragments of k sub-step s+1 are read from LDS while sub-step s is multiplied
+            constexpr int NSUB = FP4 ? 2 : 4;   // FP4: 64 elements of K per MFMA, int8: 32; 16 bytes per lane either way
             i32x4 af[2][2], bf[2][2];
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                af[0][i] = *reinterpret_cast<const i32x4 *>(xs + 32 * i * MF_PITCH);
-                bf[0][i] = *reinterpret_cast<const i32x4 *>(ws + 32 * i * MF_PITCH);
+                af[0][i] = *reinterpret_cast<const i32x4 *>(xs + 32 * i * PITCH);
+                bf[0][i] = *reinterpret_cast<const i32x4 *>(ws + 32 * i * PITCH);
             }
 #pragma unroll
-            for (int sub = 0; sub < 4; sub++) {
-                if (sub + 1 < 4) {
+            for (int sub = 0; sub < NSUB; sub++) {
+                if (sub + 1 < NSUB) {
 #pragma unroll
                     for (int i = 0; i < 2; i++) {
-                        af[(sub + 1) & 1][i] = *reinterpret_cast<const i32x4 *>(xs + 32 * i * MF_PITCH + 32 * (sub + 1));
-                        bf[(sub + 1) & 1][i] = *reinterpret_cast<const i32x4 *>(ws + 32 * i * MF_PITCH + 32 * (sub + 1));
+                        af[(sub + 1) & 1][i] = *reinterpret_cast<const i32x4 *>(xs + 32 * i * PITCH + 32 * (sub + 1));
+                        bf[(sub + 1) & 1][i] = *reinterpret_cast<const i32x4 *>(ws + 32 * i * PITCH + 32 * (sub + 1));
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
-                    for (int j = 0; j < 2; j++)
+                    for (int j = 0; j < 2; j++) {
 #ifdef QGTC_MF_NOMFMA  // timing-only build
                         asm volatile("" ::"v"(af[sub & 1][i]), "v"(bf[sub & 1][j]));
 #else
-                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[sub & 1][i], bf[sub & 1][j], acc[i][j], 0, 0, 0);
+                        if constexpr (FP4) {
+                            const i32x4 fa = af[sub & 1][i], fb = bf[sub & 1][j];
+                            const i32x8 a8 = {fa.x, fa.y, fa.z, fa.w, 0, 0, 0, 0}, b8 = {fb.x, fb.y, fb.z, fb.w, 0, 0, 0, 0};
+                            // cbsz = blgp = 4: E2M1 operands; E8M0 scale 128 = x2 on each: nibble v counts as v
+                            accf[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, accf[i][j], 4, 4, 0, 128, 0, 128);
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[sub & 1][i], bf[sub & 1][j], acc[i][j], 0, 0, 0);
+                        }
 #endif
+                    }
             }
             if (q == 8) MF_STAMP(1);
             __syncthreads();
@@ -271,6 +319,14 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
         // MFMA C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5). The cols-layout
         // epilogue wants four consecutive ROWS of a column in one 16-byte read: it gets the tile transposed.
         MF_STAMP(5);
+        if constexpr (FP4) {  // the float32 sums are exact integers
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[i][j][r] = static_cast<int>(accf[i][j][r]);
+        }
         // (one loop per mode, not a select per element: the addresses are then one lane base + immediates)
         // Bit modes: inside every group of 32 elements along a line, element l + 8j is stored at 4l + j, so
         // that the epilogue thread l of an 8-lane group reads its four elements {l, l+8, l+16, l+24} - one
@@ -426,21 +482,21 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
 #undef MF_STAMP
 }
 
-template <int MAXP, int EXPW>
+template <int MAXP, int EXPW, bool FP4 = false>
 __global__ __launch_bounds__(64 * (4 + EXPW)) void k_bitmm_mfma(qgtc_problem pr, MMShape sh, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    mf_tile<MAXP, EXPW>(pr, sh, blockIdx.x / tiles_n, blockIdx.x % tiles_n, smem);
+    mf_tile<MAXP, EXPW, FP4>(pr, sh, blockIdx.x / tiles_n, blockIdx.x % tiles_n, smem);
 }
 
 // grouped launch: blockIdx.y = problem, blockIdx.x = 128 x 128 tile (surplus tiles exit at once)
-template <int MAXP, int EXPW>
+template <int MAXP, int EXPW, bool FP4 = false>
 __global__ __launch_bounds__(64 * (4 + EXPW)) void k_bitmm_mfma_batched(const qgtc_problem *__restrict__ prs, MMShape sh) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const qgtc_problem pr = prs[blockIdx.y];
     const int tiles_m = (pr.M + MF_T - 1) / MF_T, tiles_n = (pr.N + MF_T - 1) / MF_T;
     const int tile = blockIdx.x;
     if (tile >= tiles_m * tiles_n) return;
-    mf_tile<MAXP, EXPW>(pr, sh, tile / tiles_n, tile % tiles_n, smem);
+    mf_tile<MAXP, EXPW, FP4>(pr, sh, tile / tiles_n, tile % tiles_n, smem);
 }
 
 }  // namespace

@@ -135,6 +135,11 @@ int dispatch_batched(const qgtc_problem *prs, int count, int max_M, int max_N, i
 // the MFMA engine handles up to 8 planes per operand (8: offset by 128, corrected in the epilogue)
 inline bool mfma_ok(int a, int w) { return a >= 1 && a <= 8 && w >= 1 && w <= 8; }
 
+// the FP4 form of the matrix-core engine: 2-bit values at most and float32 sums that stay exact
+inline bool fp4_ok(int K, int a, int w) {
+    return a <= 2 && w <= 2 && static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
+}
+
 // QGTC_ENGINE_AUTO: pick the engine by a two-line cost model fitted to the round-1 measurements
 // (DESIGN.md section 5.4b): popcount runs at ~0.95e15 bit-ops/s plus ~3 us of launch and tail; the
 // matrix-core engine pays ~6 us fixed and ~0.46 us per k-quad and 128 x 128 tile round (a quarter
@@ -144,10 +149,16 @@ inline bool auto_prefers_mfma(int M, int K, int N, int a, int w) {
     const double tiles = static_cast<double>((M + MF_T - 1) / MF_T) * ((N + MF_T - 1) / MF_T);
     const double rounds = tiles <= 256.0 ? 1.0 : tiles / 256.0 * 0.9;
     const int maxp = a > w ? a : w;
-    const double t_mfma = 6.0 + 0.46 * step128(K) * (1.0 + 0.25 * (maxp - 1)) * rounds;
+    // per k-quad and round: 0.32 us in the FP4 form (2-bit values at most), else 0.46 us plus 15 % per extra plane
+    const double per_kq = fp4_ok(K, a, w) ? 0.32 * (1.0 + 0.25 * (maxp - 1)) : 0.46 * (1.0 + 0.15 * (maxp - 1));
+    const double t_mfma = 6.0 + per_kq * step128(K) * rounds;
     const double t_pop = 3.0 + 2.0 * M * static_cast<double>(K) * N * a * w / 0.95e15 * 1e6;
     return t_mfma < 0.9 * t_pop;
 }
+
+#define QGTC_MF_FOR_ALL(F)                                                                   \
+    F(1, 4, false) F(2, 4, false) F(4, 4, false) F(8, 4, false) F(1, 8, false) F(2, 8, false) \
+    F(4, 8, false) F(8, 8, false) F(1, 4, true) F(2, 4, true) F(1, 8, true) F(2, 8, true)
 
 int launch_mfma(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, mode);
@@ -156,23 +167,25 @@ int launch_mfma(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStrea
     const int maxp = a > w ? a : w;
     static bool attr_set = false;
     if (!attr_set) {
-#define QGTC_MF_ATTR(P, E) \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma<P, E>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
-        QGTC_MF_ATTR(1, 4) QGTC_MF_ATTR(2, 4) QGTC_MF_ATTR(4, 4) QGTC_MF_ATTR(8, 4)
-        QGTC_MF_ATTR(1, 8) QGTC_MF_ATTR(2, 8) QGTC_MF_ATTR(4, 8) QGTC_MF_ATTR(8, 8)
+#define QGTC_MF_ATTR(P, E, F4) \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma<P, E, F4>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
+        QGTC_MF_FOR_ALL(QGTC_MF_ATTR)
 #undef QGTC_MF_ATTR
         attr_set = true;
     }
     const dim3 grid(tiles_m * tiles_n);
     // two workgroups per CU overlap each other from 512 tiles on; below that one 12-wave workgroup per CU
     const bool wide = tiles_m * tiles_n < 512;
-#define QGTC_MF_LAUNCH(P)                                                                              \
-    if (wide) hipLaunchKernelGGL((k_bitmm_mfma<P, 8>), grid, dim3(768), MF_LDS, st, pr, sh, tiles_n);   \
-    else hipLaunchKernelGGL((k_bitmm_mfma<P, 4>), grid, dim3(512), MF_LDS, st, pr, sh, tiles_n);
-    if (maxp <= 1) { QGTC_MF_LAUNCH(1) }
-    else if (maxp <= 2) { QGTC_MF_LAUNCH(2) }
-    else if (maxp <= 4) { QGTC_MF_LAUNCH(4) }
-    else { QGTC_MF_LAUNCH(8) }
+    const bool fp4 = fp4_ok(pr.K, a, w);
+#define QGTC_MF_LAUNCH(P, F4)                                                                               \
+    if (wide) hipLaunchKernelGGL((k_bitmm_mfma<P, 8, F4>), grid, dim3(768), MF_LDS, st, pr, sh, tiles_n);    \
+    else hipLaunchKernelGGL((k_bitmm_mfma<P, 4, F4>), grid, dim3(512), MF_LDS, st, pr, sh, tiles_n);
+    if (fp4 && maxp <= 1) { QGTC_MF_LAUNCH(1, true) }
+    else if (fp4) { QGTC_MF_LAUNCH(2, true) }
+    else if (maxp <= 1) { QGTC_MF_LAUNCH(1, false) }
+    else if (maxp <= 2) { QGTC_MF_LAUNCH(2, false) }
+    else if (maxp <= 4) { QGTC_MF_LAUNCH(4, false) }
+    else { QGTC_MF_LAUNCH(8, false) }
 #undef QGTC_MF_LAUNCH
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
@@ -198,22 +211,24 @@ int launch_mfma_batched(const qgtc_problem *prs, int count, int max_M, int max_K
     const int maxp = a > w ? a : w;
     static bool attr_set = false;
     if (!attr_set) {
-#define QGTC_MF_ATTR(P, E) \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma_batched<P, E>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
-        QGTC_MF_ATTR(1, 4) QGTC_MF_ATTR(2, 4) QGTC_MF_ATTR(4, 4) QGTC_MF_ATTR(8, 4)
-        QGTC_MF_ATTR(1, 8) QGTC_MF_ATTR(2, 8) QGTC_MF_ATTR(4, 8) QGTC_MF_ATTR(8, 8)
+#define QGTC_MF_ATTR(P, E, F4) \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma_batched<P, E, F4>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
+        QGTC_MF_FOR_ALL(QGTC_MF_ATTR)
 #undef QGTC_MF_ATTR
         attr_set = true;
     }
     const dim3 grid(tiles, count);
     const bool wide = static_cast<long>(tiles) * count < 512;
-#define QGTC_MF_LAUNCH(P)                                                                          \
-    if (wide) hipLaunchKernelGGL((k_bitmm_mfma_batched<P, 8>), grid, dim3(768), MF_LDS, st, prs, sh); \
-    else hipLaunchKernelGGL((k_bitmm_mfma_batched<P, 4>), grid, dim3(512), MF_LDS, st, prs, sh);
-    if (maxp <= 1) { QGTC_MF_LAUNCH(1) }
-    else if (maxp <= 2) { QGTC_MF_LAUNCH(2) }
-    else if (maxp <= 4) { QGTC_MF_LAUNCH(4) }
-    else { QGTC_MF_LAUNCH(8) }
+    const bool fp4 = fp4_ok(max_K, a, w);
+#define QGTC_MF_LAUNCH(P, F4)                                                                              \
+    if (wide) hipLaunchKernelGGL((k_bitmm_mfma_batched<P, 8, F4>), grid, dim3(768), MF_LDS, st, prs, sh);   \
+    else hipLaunchKernelGGL((k_bitmm_mfma_batched<P, 4, F4>), grid, dim3(512), MF_LDS, st, prs, sh);
+    if (fp4 && maxp <= 1) { QGTC_MF_LAUNCH(1, true) }
+    else if (fp4) { QGTC_MF_LAUNCH(2, true) }
+    else if (maxp <= 1) { QGTC_MF_LAUNCH(1, false) }
+    else if (maxp <= 2) { QGTC_MF_LAUNCH(2, false) }
+    else if (maxp <= 4) { QGTC_MF_LAUNCH(4, false) }
+    else { QGTC_MF_LAUNCH(8, false) }
 #undef QGTC_MF_LAUNCH
     HIP_TRY(hipGetLastError());
     return QGTC_OK;

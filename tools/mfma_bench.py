@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, QGTC
 M = K = 4096
-for N, w, a in ((64, 1, 1), (128, 1, 1), (256, 1, 1), (1024, 1, 1), (128, 2, 1), (1024, 2, 1), (1024, 4, 1), (256, 7, 1),
+for N, w, a in ((64, 1, 1), (128, 1, 1), (256, 1, 1), (512, 1, 1), (1024, 1, 1), (256, 2, 1), (512, 2, 1), (256, 2, 2), (128, 2, 1), (1024, 2, 1), (1024, 4, 1), (256, 7, 1),
                 (256, 8, 1), (1024, 8, 1), (128, 8, 8), (1024, 8, 8)):
     A = torch.randint(0, 2 ** a, (M, K)).float().cuda()
     X = torch.randint(0, 2 ** w, (K, N)).float().cuda()
