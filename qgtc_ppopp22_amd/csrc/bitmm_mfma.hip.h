@@ -237,16 +237,26 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
         __syncthreads();
         MF_STAMP(3);
         // step J of a block of 2*GQ: step q0+J is being multiplied; expand step e = q0+J+1 (set (e/GQ)&1,
-        // slot e%GQ); after the last slot of a set, refill the set with the group two ahead
+        // slot e%GQ); after the last slot of a set, refill the set with the group two ahead.
+        // The refill is UNCONDITIONAL (an exhausted k stream loads zeros from offset 0xffffffff) and the
+        // block is left with `break`, not skipped step by step: with loads under a condition hipcc must
+        // assume at every later wait that they were not issued, and then waits for the just-issued group
+        // (a full memory latency every GQ-th step) instead of the one four steps old.
+#ifdef QGTC_STEP_TRACE  // the same for an X expander wave (256) and a W expander wave (last wave)
+#define MF_TRACE(Q, W) do { if (blockIdx.x == 0 && (Q) < 40 && (tid == 256 || tid == 64 * (4 + EXPW) - 64)) g_stamps[8192 + (tid == 256 ? 128 : 256) + 2 * (Q) + (W)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MF_TRACE(Q, W) do { } while (0)
+#endif
 #define QGTC_MF_STEP(J)                                                                   \
-    if (J < 2 * GQ && q0 + J < nq) {                                                      \
+    if (J < 2 * GQ) {                                                                     \
+        if (q0 + J >= nq) break;                                                          \
         constexpr int E = (J + 1) % (2 * GQ);                                             \
-        if (q0 + J + 1 < nq) {                                                            \
-            expand(q0 + J + 1, grp[E / GQ][E % GQ]);                                      \
-            if (E % GQ == GQ - 1) issue_group(grp[E / GQ]);                               \
-        }                                                                                 \
+        if (q0 + J + 1 < nq) expand(q0 + J + 1, grp[E / GQ][E % GQ]);                     \
+        if (E % GQ == GQ - 1) issue_group(grp[E / GQ]);                                   \
         if (q0 + J == 8) MF_STAMP(6);                                                     \
+        MF_TRACE(q0 + J, 0);                                                              \
         __syncthreads();                                                                  \
+        MF_TRACE(q0 + J, 1);                                                              \
         if (q0 + J == 8) MF_STAMP(7);                                                     \
     }
         for (int q0 = 0; q0 < nq; q0 += 2 * GQ) {
@@ -261,6 +271,7 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
             QGTC_MF_STEP(7)
         }
 #undef QGTC_MF_STEP
+#undef MF_TRACE
         MF_STAMP(5);
         if (MAXP == 8 && need_sum) {  // (the staging buffers are dead: the last barrier is behind every read)
             uint32_t tot = 0u;
@@ -312,7 +323,13 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
                     }
             }
             if (q == 8) MF_STAMP(1);
+#ifdef QGTC_STEP_TRACE  // diagnostic: when each step's MFMAs were issued / its barrier passed (workgroup 0, wave 0)
+            if (tid == 0 && blockIdx.x == 0 && q < 40) g_stamps[8192 + 2 * q] = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();
+#ifdef QGTC_STEP_TRACE
+            if (tid == 0 && blockIdx.x == 0 && q < 40) g_stamps[8192 + 2 * q + 1] = __builtin_amdgcn_s_memtime();
+#endif
             if (q == 8) MF_STAMP(2);
         }
         // ---- result tile to LDS (the staging buffers are free: the last barrier is behind every read):

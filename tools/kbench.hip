@@ -97,6 +97,18 @@ int main(int argc, char **argv) {
     if (!getenv("GROUPED"))
     printf("%dx%dx%d a=%d w=%d: %.2f us/launch  eff %.1f TOPS  valu-frac %.3f\n", M, K, N, a, w, us,
            2.0 * M * K * N / us / 1e6, 2.0 * M * K * N * a * w / (us * 1e-6) / 2.516e15);
+#ifdef QGTC_STEP_TRACE
+    {
+        std::vector<unsigned long long> tr(1024 * 16);
+        CK(hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(g_stamps), tr.size() * 8));
+        const unsigned long long t0 = tr[8192 + 1];
+        for (int q = 0; q < 40 && tr[8192 + 2 * q]; q++)
+            printf("step %2d  mult: mfma issued %6lld barrier passed %6lld | X exp: done %6lld passed %6lld | W exp: done %6lld passed %6lld\n", q,
+                   (long long)(tr[8192 + 2 * q] - t0), (long long)(tr[8192 + 2 * q + 1] - t0),
+                   (long long)(tr[8192 + 128 + 2 * q] - t0), (long long)(tr[8192 + 128 + 2 * q + 1] - t0),
+                   (long long)(tr[8192 + 256 + 2 * q] - t0), (long long)(tr[8192 + 256 + 2 * q + 1] - t0));
+    }
+#endif
 #ifdef QGTC_STAMPS
     std::vector<unsigned long long> st(1024 * 16);
     CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8));
