@@ -25,9 +25,10 @@ namespace {
 // dword - the order of the elements inside a word is irrelevant to the product as long as both operands
 // share it); the 128 bytes go to LDS ([line][144-byte pitch]: the 16-byte MFMA fragment reads of 32 lines are
 // conflict-free). The packed words of the next k-quad are loaded (range-checked buffer loads)
-// while the current one is multiplied. The finished 128 x 128 int32 tile goes through LDS to the
-// same three epilogues (rows-layout bits, cols-layout bits, float32); with 128-wide tiles every
-// output word belongs to exactly one workgroup, so there is no padding to zero-fill separately.
+// while the current one is multiplied. The three epilogues (rows-layout bits, cols-layout bits, float32)
+// work straight from the accumulators of the multiplier waves (the rows layout multiplies with the
+// operands swapped, so that a lane owns a row); with 128-wide tiles every output word belongs to
+// exactly one workgroup, so there is no padding to zero-fill separately.
 // ------------------------------------------------------------------------------------------
 //
 // FP4 form (plane counts <= 2, sums below 2^24): E2M1 codes 0..3 are 0, 0.5, 1, 1.5, so a 2-bit value v
@@ -41,10 +42,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MF_PITCH4 = 80;      // FP4 form: bytes between the expanded lines (64 + 16: conflict-free 16-byte reads)
 constexpr int MF_T = 128;          // tile edge
 constexpr int MF_PITCH = 144;      // bytes between the expanded lines of one operand
-constexpr int MF_CPITCH = 132;     // ints between the rows (cols layout: columns) of the result tile in LDS
-constexpr int MF_STAGE = 2 * MF_T * MF_PITCH;                 // one staging buffer: X lines, then W lines
-constexpr int MF_SUMS = MF_T * MF_CPITCH * 4;  // line sums (8-plane operands): 128 X rows, 128 W columns, behind the result tile
-constexpr int MF_LDS = (MF_SUMS + 2 * MF_T * 4 > 2 * MF_STAGE) ? MF_SUMS + 2 * MF_T * 4 : 2 * MF_STAGE;
+constexpr int MF_STAGE = 2 * MF_T * MF_PITCH;                 // one staging buffer (int8 form): X lines, then W lines
+constexpr int MF_SUMS = 0;  // line sums of 8-plane operands (128 X rows, 128 W columns): over the dead staging buffers
+__host__ __device__ constexpr int mf_lds_bytes(bool fp4) { return 2 * 2 * MF_T * (fp4 ? 80 : MF_PITCH); }  // two staging buffers
 
 // 32 packed elements of `planes` planes -> 32 bytes (8 dwords), byte = sum_p bit_p << p.
 // The dot product over k does not care in which ORDER the 32 elements of a word become bytes as long as
@@ -83,6 +83,12 @@ __device__ __forceinline__ void expand_word_fp4(const uint32_t (&wd)[MAXP], int 
             out[d] |= t & (0x11111111u << p);
         }
     }
+}
+
+// x | (x of lane ^ 32): v_permlane32_swap (gfx950) exchanges the wave's halves in the VALU, no LDS round trip
+__device__ __forceinline__ uint32_t or_with_partner_half(uint32_t x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // {lo, lo} and {hi, hi} of x
+    return r[0] | r[1];
 }
 
 // EXPW expander waves: 8 (two threads per line) when a CU holds one workgroup - a lone expander wave per
@@ -283,58 +289,63 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
     } else {
         __syncthreads();
         MF_STAMP(3);
+        // Rows-layout output (mode 0) multiplies with the operands SWAPPED: the accumulator tile is then the
+        // transpose (lane = row of C, registers = 16 of its columns), which is what a row word needs.
+        auto main_loop = [&](auto swap_c) {
+            constexpr bool SWAP = decltype(swap_c)::value;
         for (int q = 0; q < nq; q++) {
-            if (q == 8) MF_STAMP(4);
-            const unsigned char *xs = smem + (q & 1) * STAGE + (64 * wr + fl) * PITCH + 16 * fh;
-            const unsigned char *ws = smem + (q & 1) * STAGE + MF_T * PITCH + (64 * wc + fl) * PITCH + 16 * fh;
-            // fragments of k sub-step s+1 are read from LDS while sub-step s is multiplied
-            constexpr int NSUB = FP4 ? 2 : 4;   // FP4: 64 elements of K per MFMA, int8: 32; 16 bytes per lane either way
-            i32x4 af[2][2], bf[2][2];
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                af[0][i] = *reinterpret_cast<const i32x4 *>(xs + 32 * i * PITCH);
-                bf[0][i] = *reinterpret_cast<const i32x4 *>(ws + 32 * i * PITCH);
-            }
-#pragma unroll
-            for (int sub = 0; sub < NSUB; sub++) {
-                if (sub + 1 < NSUB) {
-#pragma unroll
-                    for (int i = 0; i < 2; i++) {
-                        af[(sub + 1) & 1][i] = *reinterpret_cast<const i32x4 *>(xs + 32 * i * PITCH + 32 * (sub + 1));
-                        bf[(sub + 1) & 1][i] = *reinterpret_cast<const i32x4 *>(ws + 32 * i * PITCH + 32 * (sub + 1));
-                    }
+                if (q == 8) MF_STAMP(4);
+                const unsigned char *xs = smem + (q & 1) * STAGE + (64 * wr + fl) * PITCH + 16 * fh;
+                const unsigned char *ws = smem + (q & 1) * STAGE + MF_T * PITCH + (64 * wc + fl) * PITCH + 16 * fh;
+                // fragments of k sub-step s+1 are read from LDS while sub-step s is multiplied
+                constexpr int NSUB = FP4 ? 2 : 4;   // FP4: 64 elements of K per MFMA, int8: 32; 16 bytes per lane either way
+                i32x4 af[2][2], bf[2][2];
+    #pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    af[0][i] = *reinterpret_cast<const i32x4 *>(xs + 32 * i * PITCH);
+                    bf[0][i] = *reinterpret_cast<const i32x4 *>(ws + 32 * i * PITCH);
                 }
-#pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int j = 0; j < 2; j++) {
-#ifdef QGTC_MF_NOMFMA  // timing-only build
-                        asm volatile("" ::"v"(af[sub & 1][i]), "v"(bf[sub & 1][j]));
-#else
-                        if constexpr (FP4) {
-                            const i32x4 fa = af[sub & 1][i], fb = bf[sub & 1][j];
-                            const i32x8 a8 = {fa.x, fa.y, fa.z, fa.w, 0, 0, 0, 0}, b8 = {fb.x, fb.y, fb.z, fb.w, 0, 0, 0, 0};
-                            // cbsz = blgp = 4: E2M1 operands; E8M0 scale 128 = x2 on each: nibble v counts as v
-                            accf[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, accf[i][j], 4, 4, 0, 128, 0, 128);
-                        } else {
-                            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[sub & 1][i], bf[sub & 1][j], acc[i][j], 0, 0, 0);
+    #pragma unroll
+                for (int sub = 0; sub < NSUB; sub++) {
+                    if (sub + 1 < NSUB) {
+    #pragma unroll
+                        for (int i = 0; i < 2; i++) {
+                            af[(sub + 1) & 1][i] = *reinterpret_cast<const i32x4 *>(xs + 32 * i * PITCH + 32 * (sub + 1));
+                            bf[(sub + 1) & 1][i] = *reinterpret_cast<const i32x4 *>(ws + 32 * i * PITCH + 32 * (sub + 1));
                         }
-#endif
                     }
+    #pragma unroll
+                    for (int i = 0; i < 2; i++)
+    #pragma unroll
+                        for (int j = 0; j < 2; j++) {
+    #ifdef QGTC_MF_NOMFMA  // timing-only build
+                            asm volatile("" ::"v"(af[sub & 1][i]), "v"(bf[sub & 1][j]));
+    #else
+                            if constexpr (FP4) {
+                                const i32x4 fa = SWAP ? bf[sub & 1][j] : af[sub & 1][i], fb = SWAP ? af[sub & 1][i] : bf[sub & 1][j];
+                                const i32x8 a8 = {fa.x, fa.y, fa.z, fa.w, 0, 0, 0, 0}, b8 = {fb.x, fb.y, fb.z, fb.w, 0, 0, 0, 0};
+                                // cbsz = blgp = 4: E2M1 operands; E8M0 scale 128 = x2 on each: nibble v counts as v
+                                accf[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, accf[i][j], 4, 4, 0, 128, 0, 128);
+                            } else {
+                                acc[i][j] = SWAP ? __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[sub & 1][j], af[sub & 1][i], acc[i][j], 0, 0, 0)
+                                                 : __builtin_amdgcn_mfma_i32_32x32x32_i8(af[sub & 1][i], bf[sub & 1][j], acc[i][j], 0, 0, 0);
+                            }
+    #endif
+                        }
+                }
+                if (q == 8) MF_STAMP(1);
+    #ifdef QGTC_STEP_TRACE  // diagnostic: when each step's MFMAs were issued / its barrier passed (workgroup 0, wave 0)
+                if (tid == 0 && blockIdx.x == 0 && q < 40) g_stamps[8192 + 2 * q] = __builtin_amdgcn_s_memtime();
+    #endif
+                __syncthreads();
+    #ifdef QGTC_STEP_TRACE
+                if (tid == 0 && blockIdx.x == 0 && q < 40) g_stamps[8192 + 2 * q + 1] = __builtin_amdgcn_s_memtime();
+    #endif
+                if (q == 8) MF_STAMP(2);
             }
-            if (q == 8) MF_STAMP(1);
-#ifdef QGTC_STEP_TRACE  // diagnostic: when each step's MFMAs were issued / its barrier passed (workgroup 0, wave 0)
-            if (tid == 0 && blockIdx.x == 0 && q < 40) g_stamps[8192 + 2 * q] = __builtin_amdgcn_s_memtime();
-#endif
-            __syncthreads();
-#ifdef QGTC_STEP_TRACE
-            if (tid == 0 && blockIdx.x == 0 && q < 40) g_stamps[8192 + 2 * q + 1] = __builtin_amdgcn_s_memtime();
-#endif
-            if (q == 8) MF_STAMP(2);
-        }
-        // ---- result tile to LDS (the staging buffers are free: the last barrier is behind every read):
-        // MFMA C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5). The cols-layout
-        // epilogue wants four consecutive ROWS of a column in one 16-byte read: it gets the tile transposed.
+        };
+        if (sh.mode == 0) main_loop(std::true_type{});
+        else main_loop(std::false_type{});
         MF_STAMP(5);
         if constexpr (FP4) {  // the float32 sums are exact integers
 #pragma unroll
@@ -344,152 +355,122 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
 #pragma unroll
                     for (int r = 0; r < 16; r++) acc[i][j][r] = static_cast<int>(accf[i][j][r]);
         }
-        // (one loop per mode, not a select per element: the addresses are then one lane base + immediates)
-        // Bit modes: inside every group of 32 elements along a line, element l + 8j is stored at 4l + j, so
-        // that the epilogue thread l of an 8-lane group reads its four elements {l, l+8, l+16, l+24} - one
-        // per byte of the output word - with one 16-byte read.
-        int *ctw = reinterpret_cast<int *>(smem);
-        if (sh.mode == 1) {         // lines = columns, along = rows; row = 64wr + 32i + (r&3) + 8(r>>2) + 4fh
-            int *basep = ctw + (64 * wc + fl) * MF_CPITCH + 64 * wr + 16 * fh;
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) basep[32 * j * MF_CPITCH + 32 * i + 4 * (r & 3) + (r >> 2)] = acc[i][j][r];
-        } else if (sh.mode == 0) {  // lines = rows, along = columns; column = 64wc + 32j + fl
-            int *basep = ctw + (64 * wr + 4 * fh) * MF_CPITCH + 64 * wc + 4 * (fl & 7) + (fl >> 3);
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) basep[(32 * i + (r & 3) + 8 * (r >> 2)) * MF_CPITCH + 32 * j] = acc[i][j][r];
-        } else {                    // float32: plain row-major tile
-            int *basep = ctw + (64 * wr + 4 * fh) * MF_CPITCH + 64 * wc + fl;
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) basep[(32 * i + (r & 3) + 8 * (r >> 2)) * MF_CPITCH + 32 * j] = acc[i][j][r];
-        }
     }
-    __syncthreads();
-
+    __syncthreads();  // (8-plane operands: the expanders' line sums are visible)
     if (!expander) MF_STAMP(6);
-    // ---- epilogue. Thread t handles the same quad (t & 31) of lines (t >> 5) + k * NT/32: everything but
-    // the line is invariant. float32: four consecutive columns of a row. Bit modes: the four elements
-    // {l, l+8, l+16, l+24} (l = t & 7) of a 32-element group of the line (rows layout: columns of a row;
-    // cols layout: rows of a column): element l + 8j belongs at bit (24 - 8j) + (7 - l) of the output
-    // word, so the re-quantised values are packed one per byte and plane p of all four is ONE shift + AND;
-    // the 8 lanes of a group OR their words with DPP.
-    const int *ct = reinterpret_cast<const int *>(smem);
-    constexpr int NT = 64 * (4 + EXPW), LSTEP = NT / 32;
-    const int qd = tid & 31, ln0 = tid >> 5;
-    // 8-plane operands (header): C += fix_x * (sum of X's row) + fix_w * (sum of W's column) + fix_k
-    const int *sums = reinterpret_cast<const int *>(smem + MF_SUMS);
-    const bool fix = MAXP == 8 && (sh.a == 8 || sh.w == 8);
-    const int fix_x = sh.w == 8 ? 128 : 0, fix_w = sh.a == 8 ? 128 : 0;
-    const int fix_k = (sh.a == 8 && sh.w == 8) ? static_cast<int>(0u - 2097152u * static_cast<uint32_t>(nq)) : 0;  // -16384 K' mod 2^32
-    if (sh.mode == 2) {  // float32 [M,N] (reference kernel.h:915-930)
-        const int along = n0 + 4 * qd;
-        const int nvalid_line = min(max(N - along, 0), 4);
-        float *dst = static_cast<float *>(pr.out) + static_cast<size_t>(m0 + ln0) * N + along;
-        const int *src = ct + ln0 * MF_CPITCH + 4 * qd;
-        const bool vec_ok = nvalid_line == 4 && (N & 3) == 0;
-        for (int ln = ln0; ln < MF_T && m0 + ln < M; ln += LSTEP, dst += static_cast<size_t>(LSTEP) * N, src += LSTEP * MF_CPITCH) {
-            const int4 v4 = *reinterpret_cast<const int4 *>(src);
-            int v[4] = {v4.x, v4.y, v4.z, v4.w};
-            if (MAXP == 8 && fix) {
+
+    // ---- epilogue, straight from the accumulators (multiplier waves; the expanders are done).
+    // MFMA C/D layout of a 32 x 32 tile: lane l owns "line" l & 31 and, in register r, "element"
+    // e(r) = (r & 3) + 8 (r >> 2) + 4 (l >> 5). Not swapped: line = column of C, element = row (what a
+    // cols-layout word - 32 rows of a column - and coalesced float rows need); swapped: line = row, element =
+    // column (a rows-layout word). A lane therefore holds 16 of the 32 bits of one output word per plane and
+    // its partner lane l ^ 32 the other 16. Bit of element e: 31 - e = 8 (3 - g) + (7 - t - 4 fh) with
+    // g = r >> 2, t = r & 3: the re-quantised values of one t are packed a byte each (byte 3 - g) and plane p of
+    // the four is ONE shift + AND; the four t are merged with constant shifts.
+    if (!expander) {
+        const int *sums = reinterpret_cast<const int *>(smem + MF_SUMS);
+        const bool fix = MAXP == 8 && (sh.a == 8 || sh.w == 8);   // 8-plane operands (header)
+        const int fix_x = sh.w == 8 ? 128 : 0, fix_w = sh.a == 8 ? 128 : 0;
+        const int fix_k = (sh.a == 8 && sh.w == 8) ? static_cast<int>(0u - 2097152u * static_cast<uint32_t>(nq)) : 0;  // -16384 K' mod 2^32
+        const bool swapped = sh.mode == 0;
+        if (MAXP == 8 && fix) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) v[e] += fix_x * sums[ln] + fix_w * sums[MF_T + 4 * qd + e] + fix_k;
-            }
-            if (vec_ok) {
-                *reinterpret_cast<float4 *>(dst) = make_float4(static_cast<float>(v[0]), static_cast<float>(v[1]),
-                                                               static_cast<float>(v[2]), static_cast<float>(v[3]));
-            } else {
+            for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if (e < nvalid_line) dst[e] = static_cast<float>(v[e]);
-            }
+                for (int j = 0; j < 2; j++) {
+                    // tile-local row / column of the lane's line and of element 0
+                    const int row_l = 64 * wr + 32 * i, col_l = 64 * wc + 32 * j;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int e = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        const int row = swapped ? row_l + fl : row_l + e, col = swapped ? col_l + e : col_l + fl;
+                        acc[i][j][r] += fix_x * sums[row] + fix_w * sums[MF_T + col] + fix_k;
+                    }
+                }
         }
-    } else {
-        auto finish = [&](auto mode_c, auto ob_c) {
-            constexpr int MODE = decltype(mode_c)::value;
-            constexpr int OB = decltype(ob_c)::value;  // 0: any ob (runtime loop, per-plane bit extraction)
-            const int ell = tid & 7, grp = qd >> 3;
-            const int along0 = (MODE == 1 ? m0 : n0) + 32 * grp + ell;   // element j of the quad: along0 + 8j
-            const int along_lim = MODE == 1 ? M : N, across_lim = MODE == 1 ? N : M;
-            uint32_t vm = 0u;                                             // bit 24 - 8j: element j lies inside the matrix
+        if (sh.mode == 2) {  // float32 [M,N] (reference kernel.h:915-930): 32 lanes = 32 consecutive columns of a row
+            float *outf = static_cast<float *>(pr.out);
 #pragma unroll
-            for (int j = 0; j < 4; j++) vm |= along0 + 8 * j < along_lim ? 1u << (24 - 8 * j) : 0u;
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int col = n0 + 64 * wc + 32 * j + fl;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int row = m0 + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        if (row < M && col < N) outf[static_cast<size_t>(row) * N + col] = static_cast<float>(acc[i][j][r]);
+                    }
+                }
+        } else {
+            // rows layout [ob][PAD8(M)][STEP128(N)*4] (kernel.h:357-389): word (m, n / 32), swapped tiles;
+            // cols layout [ob][PAD128(N)][STEP128(M)*4] (kernel.h:651-810 as intended): word (n, m / 32)
             const int rows_pad = pad8(M), row_words = step128(N) * 4, line_words = step128(M) * 4;
-            const size_t oplane = MODE == 0 ? static_cast<size_t>(rows_pad) * row_words : static_cast<size_t>(pad128(N)) * line_words;
-            const int pitch = MODE == 0 ? row_words : line_words;        // output words per line
-            // rows layout [ob][PAD8(M)][STEP128(N)*4] (kernel.h:357-389): word (m, n / 32); cols layout
-            // [ob][PAD128(N)][STEP128(M)*4] (kernel.h:651-810 as intended): word (n, m / 32)
-            const int across0 = (MODE == 1 ? n0 : m0) + ln0;
-            uint32_t *outp = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(across0) * pitch + (((MODE == 1 ? m0 : n0) >> 5) + grp);
-            const uint32_t sh_l = 7 - ell;
-            const bool lead = ell == 0;
-            const int maxi = 1 << (sh.ob & 31);
-            const uint32_t ones = static_cast<uint32_t>(maxi - 1);
-            const int *src = ct + ln0 * MF_CPITCH + 32 * grp + 4 * ell;
-            const int across_store = MODE == 0 ? rows_pad : (1 << 30);   // lines that exist in the output
-            for (int ln = ln0, across = across0; ln < MF_T; ln += LSTEP, across += LSTEP, outp += LSTEP * pitch, src += LSTEP * MF_CPITCH) {
-                const int4 v4 = *reinterpret_cast<const int4 *>(src);
-                int v[4] = {v4.x, v4.y, v4.z, v4.w};
-                if (MAXP == 8 && fix) {  // element j of the quad: along index 32 grp + ell + 8j of line ln
-                    const int a0 = 32 * grp + ell;
+            const size_t oplane = swapped ? static_cast<size_t>(rows_pad) * row_words : static_cast<size_t>(pad128(N)) * line_words;
+            const int pitch = swapped ? row_words : line_words;              // output words per line
+            const int line_lim = swapped ? M : N, elem_lim = swapped ? N : M; // lines / elements inside the matrix
+            const int line_store = swapped ? rows_pad : pad128(N);           // lines that exist in the output
+            uint32_t *out = static_cast<uint32_t *>(pr.out);
+            const uint32_t lane_sh = 4u - 4u * static_cast<uint32_t>(fh);
+            auto finish = [&](auto ob_c) {
+                constexpr int OB = decltype(ob_c)::value;   // 0: any ob (runtime loop, per-plane bit extraction)
+                const int maxi = 1 << (sh.ob & 31);
+                const uint32_t ones = static_cast<uint32_t>(maxi - 1);
+                const bool int_rq = sh.ob <= 23;  // float(c) > 2^ob  <=>  c > 2^ob for every int c >= 0
 #pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        v[e] += (MODE == 1 ? fix_w * sums[MF_T + ln] + fix_x * sums[a0 + 8 * e]
-                                           : fix_x * sums[ln] + fix_w * sums[MF_T + a0 + 8 * e]) + fix_k;
-                }
-                const uint32_t vml = across < across_lim ? vm : 0u;
-                const bool store = lead && across < across_store;
-                if constexpr (OB > 0) {
-                    // the low OB bits of requant(c) = c < 0 ? 1 : (c > 2^ob ? all ones : c)  (kernel.h:31-37,350)
-                    uint32_t q[4];
+                for (int i = 0; i < 2; i++)
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        uint32_t t = v[e] > maxi ? ones : static_cast<uint32_t>(v[e]);
-                        if (!sh.nowrap) t = v[e] < 0 ? 1u : t;
-                        q[e] = OB < 8 ? t : (t & 255u);
+                    for (int j = 0; j < 2; j++) {
+                        // tile coordinates along the lane dimension (lines) and the register dimension (elements)
+                        const int line0 = swapped ? m0 + 64 * wr + 32 * i : n0 + 64 * wc + 32 * j;
+                        const int elem0 = swapped ? n0 + 64 * wc + 32 * j : m0 + 64 * wr + 32 * i;
+                        const int line = line0 + fl;
+                        const int nvalid = min(max(elem_lim - elem0, 0), 32);       // leading elements inside the matrix
+                        uint32_t emask = nvalid == 32 ? 0xffffffffu : ~(0xffffffffu >> nvalid);  // element e at bit 31 - e
+                        if (line >= line_lim) emask = 0u;
+                        uint32_t q[16];
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int c = acc[i][j][r];
+                            if (OB > 0) {  // the low OB bits of requant(c) = c < 0 ? 1 : (c > 2^ob ? all ones : c)  (kernel.h:31-37,350)
+                                uint32_t t = c > maxi ? ones : static_cast<uint32_t>(c);
+                                if (!sh.nowrap) t = c < 0 ? 1u : t;
+                                q[r] = OB < 8 ? t : (t & 255u);
+                            } else {
+                                q[r] = static_cast<uint32_t>(int_rq ? (c < 0 ? 1 : (c > maxi ? maxi - 1 : c)) : requant(c, sh.maxv, sh.maxm1));
+                            }
+                        }
+                        uint32_t *dst = out + static_cast<size_t>(line) * pitch + (elem0 >> 5);
+                        const bool store = fh == 0 && line < line_store;
+                        if constexpr (OB > 0) {
+                            uint32_t P[4];  // values of t = r & 3, one per byte: g = r >> 2 in byte 3 - g
+#pragma unroll
+                            for (int t = 0; t < 4; t++) P[t] = (q[t] << 24) | (q[4 + t] << 16) | (q[8 + t] << 8) | q[12 + t];
+#pragma unroll
+                            for (int p = 0; p < OB; p++, dst += oplane) {
+                                uint32_t w = ((P[0] >> p) & 0x01010101u) << 3 | ((P[1] >> p) & 0x01010101u) << 2 |
+                                             ((P[2] >> p) & 0x01010101u) << 1 | ((P[3] >> p) & 0x01010101u);
+                                w <<= lane_sh;                       // bits 7 - t - 4 fh of every byte
+                                w = or_with_partner_half(w);
+                                if (store) dst[0] = w & emask;
+                            }
+                        } else {
+                            for (int p = 0; p < sh.ob; p++, dst += oplane) {
+                                uint32_t w = 0u;
+#pragma unroll
+                                for (int r = 0; r < 16; r++) w |= ((q[r] >> p) & 1u) << (31 - ((r & 3) + 8 * (r >> 2)));
+                                w >>= 4 * fh;
+                                w = or_with_partner_half(w);
+                                if (store) dst[0] = w & emask;
+                            }
+                        }
                     }
-                    // OB < 8: bits >= 8 of a value <= 2^OB cannot exist; bit OB (c == 2^OB) never reaches a mask bit
-                    const uint32_t P = (q[0] << 24) | (q[1] << 16) | (q[2] << 8) | q[3];
-                    uint32_t *out = outp;
-#pragma unroll
-                    for (int p = 0; p < OB; p++, out += oplane) {
-                        const uint32_t word = or_reduce8(((P >> p) & vml) << sh_l);
-                        if (store) out[0] = word;
-                    }
-                } else {
-                    const bool int_rq = sh.ob <= 23;  // float(c) > 2^ob  <=>  c > 2^ob for every int c >= 0
-                    uint32_t q[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        q[e] = static_cast<uint32_t>(int_rq ? (v[e] < 0 ? 1 : (v[e] > maxi ? maxi - 1 : v[e])) : requant(v[e], sh.maxv, sh.maxm1));
-                    uint32_t *out = outp;
-                    for (int p = 0; p < sh.ob; p++, out += oplane) {
-                        const uint32_t x = (((q[0] >> p) & 1u) << 24) | (((q[1] >> p) & 1u) << 16) | (((q[2] >> p) & 1u) << 8) | ((q[3] >> p) & 1u);
-                        const uint32_t word = or_reduce8((x & vml) << sh_l);
-                        if (store) out[0] = word;
-                    }
-                }
-            }
-        };
-        auto by_ob = [&](auto mode_c) {
-            if (sh.ob == 1) finish(mode_c, std::integral_constant<int, 1>{});
-            else if (sh.ob == 2) finish(mode_c, std::integral_constant<int, 2>{});
-            else if (sh.ob == 4) finish(mode_c, std::integral_constant<int, 4>{});
-            else if (sh.ob == 8) finish(mode_c, std::integral_constant<int, 8>{});
-            else finish(mode_c, std::integral_constant<int, 0>{});
-        };
-        if (sh.mode == 0) by_ob(std::integral_constant<int, 0>{});
-        else by_ob(std::integral_constant<int, 1>{});
+            };
+            if (sh.ob == 1) finish(std::integral_constant<int, 1>{});
+            else if (sh.ob == 2) finish(std::integral_constant<int, 2>{});
+            else if (sh.ob == 4) finish(std::integral_constant<int, 4>{});
+            else if (sh.ob == 8) finish(std::integral_constant<int, 8>{});
+            else finish(std::integral_constant<int, 0>{});
+        }
     }
 #ifdef QGTC_STAMPS
     if (!expander) MF_STAMP(7);

@@ -168,7 +168,7 @@ int launch_mfma(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStrea
     static bool attr_set = false;
     if (!attr_set) {
 #define QGTC_MF_ATTR(P, E, F4) \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma<P, E, F4>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma<P, E, F4>), hipFuncAttributeMaxDynamicSharedMemorySize, mf_lds_bytes(F4)));
         QGTC_MF_FOR_ALL(QGTC_MF_ATTR)
 #undef QGTC_MF_ATTR
         attr_set = true;
@@ -178,8 +178,8 @@ int launch_mfma(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStrea
     const bool wide = tiles_m * tiles_n < 512;
     const bool fp4 = fp4_ok(pr.K, a, w);
 #define QGTC_MF_LAUNCH(P, F4)                                                                               \
-    if (wide) hipLaunchKernelGGL((k_bitmm_mfma<P, 8, F4>), grid, dim3(768), MF_LDS, st, pr, sh, tiles_n);    \
-    else hipLaunchKernelGGL((k_bitmm_mfma<P, 4, F4>), grid, dim3(512), MF_LDS, st, pr, sh, tiles_n);
+    if (wide) hipLaunchKernelGGL((k_bitmm_mfma<P, 8, F4>), grid, dim3(768), mf_lds_bytes(F4), st, pr, sh, tiles_n);    \
+    else hipLaunchKernelGGL((k_bitmm_mfma<P, 4, F4>), grid, dim3(512), mf_lds_bytes(F4), st, pr, sh, tiles_n);
     if (fp4 && maxp <= 1) { QGTC_MF_LAUNCH(1, true) }
     else if (fp4) { QGTC_MF_LAUNCH(2, true) }
     else if (maxp <= 1) { QGTC_MF_LAUNCH(1, false) }
@@ -212,7 +212,7 @@ int launch_mfma_batched(const qgtc_problem *prs, int count, int max_M, int max_K
     static bool attr_set = false;
     if (!attr_set) {
 #define QGTC_MF_ATTR(P, E, F4) \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma_batched<P, E, F4>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma_batched<P, E, F4>), hipFuncAttributeMaxDynamicSharedMemorySize, mf_lds_bytes(F4)));
         QGTC_MF_FOR_ALL(QGTC_MF_ATTR)
 #undef QGTC_MF_ATTR
         attr_set = true;
@@ -221,8 +221,8 @@ int launch_mfma_batched(const qgtc_problem *prs, int count, int max_M, int max_K
     const bool wide = static_cast<long>(tiles) * count < 512;
     const bool fp4 = fp4_ok(max_K, a, w);
 #define QGTC_MF_LAUNCH(P, F4)                                                                              \
-    if (wide) hipLaunchKernelGGL((k_bitmm_mfma_batched<P, 8, F4>), grid, dim3(768), MF_LDS, st, prs, sh);   \
-    else hipLaunchKernelGGL((k_bitmm_mfma_batched<P, 4, F4>), grid, dim3(512), MF_LDS, st, prs, sh);
+    if (wide) hipLaunchKernelGGL((k_bitmm_mfma_batched<P, 8, F4>), grid, dim3(768), mf_lds_bytes(F4), st, prs, sh);   \
+    else hipLaunchKernelGGL((k_bitmm_mfma_batched<P, 4, F4>), grid, dim3(512), mf_lds_bytes(F4), st, prs, sh);
     if (fp4 && maxp <= 1) { QGTC_MF_LAUNCH(1, true) }
     else if (fp4) { QGTC_MF_LAUNCH(2, true) }
     else if (maxp <= 1) { QGTC_MF_LAUNCH(1, false) }
