@@ -111,7 +111,16 @@ def test_bitmm2bit_col(qgtc, oracle, M, K, N, a, w, ob):
 
 @pytest.mark.parametrize("M,K,N,a,w,ob", MM_CASES)
 @pytest.mark.parametrize("pad_128", [True, False])
-def test_bitmm2int(qgtc, oracle, M, K, N, a, w, ob, pad_128):
+@pytest.mark.parametrize("engine", ["popcount", "mfma"])
+def test_bitmm2int(qgtc, oracle, M, K, N, a, w, ob, pad_128, engine):
+    qgtc.set_engine(engine)   # (plane counts above 8 stay on the popcount kernels either way)
+    try:
+        _bitmm2int_case(qgtc, oracle, M, K, N, a, w, ob, pad_128)
+    finally:
+        qgtc.set_engine("popcount")
+
+
+def _bitmm2int_case(qgtc, oracle, M, K, N, a, w, ob, pad_128):
     import torch
     rng = np.random.default_rng(M + 7 * K + 13 * N + a + w + 2)
     qx = rand_q(rng, M, K, a)
