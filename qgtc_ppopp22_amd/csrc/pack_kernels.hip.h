@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_val2bit_rows(const float *__restrict__ 
 
 // ------------------------------------------------------------------------------------------
 // val2bit, cols layout: out[p][c][r>>5] bit(31-(r&31)) = bit p of quant(x[r][c])
-// One wave per (64-column chunk, 32-row group): lane = column, 32 coalesced row reads, each
+// One wave per (64-column chunk, 32-row group): lane = column, 32 coalesced row reads in flight, each
 // lane assembles its column's word per plane in registers. NB = compile-time bound on nbits.
 // ------------------------------------------------------------------------------------------
 template <int NB>
@@ -119,11 +119,16 @@ __global__ __launch_bounds__(256) void k_val2bit_cols(const float *__restrict__ 
         uint32_t wd[NB];
 #pragma unroll
         for (int p = 0; p < NB; p++) wd[p] = 0u;
-#pragma unroll 8
+        // all 32 row reads are issued before any is packed (one memory latency per unit, not four)
+        float v[32];
+#pragma unroll
         for (int rr = 0; rr < 32; rr++) {
             const int r = rw * 32 + rr;
-            const uint32_t q =
-                (r < H && c < W) ? quant1(x[static_cast<size_t>(r) * W + c], ub, ubm1) : 0u;
+            v[rr] = (r < H && c < W) ? x[static_cast<size_t>(r) * W + c] : 0.0f;   // quantises to 0
+        }
+#pragma unroll
+        for (int rr = 0; rr < 32; rr++) {
+            const uint32_t q = quant1(v[rr], ub, ubm1);
 #pragma unroll
             for (int p = 0; p < NB; p++) wd[p] |= ((q >> p) & 1u) << (31 - rr);
         }

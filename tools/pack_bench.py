@@ -1,7 +1,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, QGTC, time
-for (H,W,b,cm) in [(4096,4096,1,False),(4096,4096,2,False),(8192,8192,1,False),(1216,1213,1,False),(1216,1216,1,False),(4096,64,1,True),(4096,64,8,True),(1213,128,2,True)]:
+for (H,W,b,cm) in [(4096,4096,1,False),(4096,4096,2,False),(8192,8192,1,False),(1216,1213,1,False),(1216,1216,1,False),(4096,64,1,True),(4096,64,8,True),(1213,128,2,True),(4096,4096,1,True),(4096,4096,2,True),(8192,8192,1,True)]:
     x=torch.rand(H,W,device='cuda')*2**b
     for _ in range(3): o=QGTC.val2bit(x,b,cm,False)
     torch.cuda.synchronize()
