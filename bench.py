@@ -132,7 +132,8 @@ def epoch_leg(Q, rank, world, device_index, dataset="ogbn-arxiv", bits=2, hidden
     if full:
         legs[1:1] = [("per_batch_nonresident_reference_chain", ["--non-resident"]),
                      ("per_batch_graph_reference_chain", ["--graph"]),
-                     ("per_batch_2_streams_reference_chain", ["--streams", "2"])]
+                     ("per_batch_2_streams_reference_chain", ["--streams", "2"]),
+                     ("per_batch_pack_on_the_fly_reference_chain", ["--pack-on-the-fly"])]   # cluster_gcn.py's structure
     for name, extra in legs:
         args = driver.build_parser().parse_args(base + extra)
         driver.run(args, Q=Q, batch_ids=ids, graph=graph)          # warm-up (allocator, attributes)

@@ -166,6 +166,14 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
 int qgtc_pack_edges(const int64_t *cells, const int32_t *counts, size_t n_cells, int H, int W,
                     int nbits, uint32_t *out, size_t out_words, void *stream);
 
+/* The 1-bit case of the above from the RAW edge list: src[i], dst[i] may repeat, nothing is sorted or
+ * made unique first (three bitmaps count multiplicities 1, 2, >= 3 with atomic ORs; plane 0 = once or
+ * three-times-and-more, the 1-bit quantiser's image of the summed matrix). `scratch`: 2 x
+ * qgtc_rows_words(H, W, 1) words. Out-of-range indices are skipped and, if `bad_index` (device int) is
+ * given, reported there (1) - no host round trip unless the caller wants one. */
+int qgtc_pack_edge_list(const int64_t *src, const int64_t *dst, size_t n_edges, int H, int W, uint32_t *out,
+                        size_t out_words, uint32_t *scratch, size_t scratch_words, int *bad_index, void *stream);
+
 /* int8 MFMA GEMM, the comparison path — MI355X analogue of the reference's cuBLAS INT8
  * benchmark (cuBLASGemmEX/cublas_main.cu:123-172: cublasGemmEx, CUDA_R_8I in, CUDA_R_32F out).
  * C[M,N] (float32, row-major) = A[M,K] x B[K,N]; A is int8 row-major, B is passed as Bt[N,K]

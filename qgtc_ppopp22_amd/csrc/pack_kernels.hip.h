@@ -163,6 +163,39 @@ __global__ __launch_bounds__(256) void k_bit2val(const uint32_t *__restrict__ bi
 }
 
 // ------------------------------------------------------------------------------------------
+// 1-bit adjacency straight from the RAW edge list (duplicates allowed, no sort): three bitmaps count
+// every cell's multiplicity in unary - t1: seen once, t2: twice, t3: three times or more. atomicOr
+// returns the word as it was, so of the threads that hit the same cell exactly one finds its bit clear
+// in t1, exactly one of the others finds it clear in t2, the rest reach t3. The 1-bit quantiser maps the
+// multiplicities 1, 2, >= 3 to the bits 1, 0, 1 (kernel.h:39-44: 2.0 rounds to 2 = 2^1, whose plane 0 is 0;
+// anything above 2 clamps to 1), so plane 0 = t1 & (~t2 | t3). t1 is the output buffer itself.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_edge_list_count(const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                                                         size_t n_edges, int H, int W, uint32_t *__restrict__ t1,
+                                                         uint32_t *__restrict__ t2, uint32_t *__restrict__ t3,
+                                                         int row_words, int *__restrict__ bad) {
+    for (size_t e = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n_edges;
+         e += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const int64_t r = src[e], c = dst[e];
+        if (r < 0 || r >= H || c < 0 || c >= W) {
+            if (bad) *bad = 1;
+            continue;
+        }
+        const uint32_t bit = 1u << (31 - (c & 31));
+        const size_t wi = static_cast<size_t>(r) * row_words + (c >> 5);
+        if (atomicOr(t1 + wi, bit) & bit)
+            if (atomicOr(t2 + wi, bit) & bit) atomicOr(t3 + wi, bit);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_edge_list_finish(uint32_t *__restrict__ t1, const uint32_t *__restrict__ t2,
+                                                          const uint32_t *__restrict__ t3, size_t words) {
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < words;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x)
+        t1[i] &= ~t2[i] | t3[i];
+}
+
+// ------------------------------------------------------------------------------------------
 // Adjacency bit planes straight from an edge list (the packing sampler.py:80-101 does through a
 // dense float n x n matrix: A[src][dst] += 1 per edge, then val2bit(A, nbits, rows layout)).
 // One thread per DISTINCT (row, col) cell with its multiplicity: the cell's value is quantised

@@ -283,6 +283,25 @@ int qgtc_pack_edges(const int64_t *cells, const int32_t *counts, size_t n_cells,
     return QGTC_OK;
 }
 
+int qgtc_pack_edge_list(const int64_t *src, const int64_t *dst, size_t n_edges, int H, int W, uint32_t *out,
+                        size_t out_words, uint32_t *scratch, size_t scratch_words, int *bad_index, void *stream) {
+    if (!out || !scratch || H <= 0 || W <= 0 || (n_edges && (!src || !dst))) return QGTC_EINVAL;
+    const size_t words = qgtc_rows_words(H, W, 1);
+    if (out_words < words || scratch_words < 2 * words) return QGTC_ESIZE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(out, 0, words * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(scratch, 0, 2 * words * sizeof(uint32_t), st));
+    if (bad_index) HIP_TRY(hipMemsetAsync(bad_index, 0, sizeof(int), st));
+    if (n_edges) {
+        hipLaunchKernelGGL(k_edge_list_count, dim3(grid_for(n_edges, 256)), dim3(256), 0, st, src, dst, n_edges, H, W,
+                           out, scratch, scratch + words, step128(W) * 4, bad_index);
+        hipLaunchKernelGGL(k_edge_list_finish, dim3(grid_for(words, 256)), dim3(256), 0, st, out, scratch,
+                           scratch + words, words);
+        HIP_TRY(hipGetLastError());
+    }
+    return QGTC_OK;
+}
+
 int qgtc_i8gemm(const int8_t *A, const int8_t *Bt, int M, int K, int N, float *C, size_t c_elems,
                 void *stream) {
     if (!A || !Bt || !C || M <= 0 || K <= 0 || N <= 0) return QGTC_EINVAL;

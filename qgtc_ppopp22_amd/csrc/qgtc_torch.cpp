@@ -284,7 +284,7 @@ torch::Tensor bitMM2Int(torch::Tensor bit_X1, torch::Tensor bit_X2, const int X1
 // Adjacency bit planes from an edge list (additive; the dense val2bit route stays). The
 // multiplicity of duplicate edges is what the reference's to_dense() would sum (sampler.py:87-89).
 torch::Tensor pack_edges(torch::Tensor src, torch::Tensor dst, const int height, const int width,
-                         const int nbits) {
+                         const int nbits, const bool validate) {
     CHECK_INPUT(src);
     CHECK_INPUT(dst);
     TORCH_CHECK(src.scalar_type() == torch::kInt64 && dst.scalar_type() == torch::kInt64,
@@ -294,6 +294,18 @@ torch::Tensor pack_edges(torch::Tensor src, torch::Tensor dst, const int height,
     c10::DeviceGuard guard(src.device());
     auto out = torch::empty({static_cast<int64_t>(nbits) * P8(height), S128(width) * 4},
                             torch::TensorOptions().dtype(torch::kInt32).device(src.device()));
+    if (nbits == 1) {
+        // the adjacency case: raw edge list, no sort / unique, no host round trip unless validate asks for one
+        auto scratch = torch::empty({2 * out.numel()}, out.options());
+        torch::Tensor bad;
+        if (validate) bad = torch::empty({1}, out.options());
+        check_rc(qgtc_pack_edge_list(src.numel() ? src.data_ptr<int64_t>() : nullptr, src.numel() ? dst.data_ptr<int64_t>() : nullptr,
+                                     src.numel(), height, width, words_mut(out), out.numel(), words_mut(scratch),
+                                     scratch.numel(), validate ? bad.data_ptr<int>() : nullptr, current_stream(src)),
+                 "pack_edges");
+        if (validate) TORCH_CHECK(bad.item<int>() == 0, "edge index out of range");
+        return out;
+    }
     torch::Tensor cells, counts;
     if (src.numel() > 0) {
         TORCH_CHECK(src.min().item<int64_t>() >= 0 && src.max().item<int64_t>() < height &&
@@ -591,7 +603,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
 
     m.def("pack_edges", &pack_edges, "rows-layout bit planes of the [height, width] adjacency of an edge list "
           "(= val2bit of the dense matrix, without materialising it)", py::arg("src"), py::arg("dst"),
-          py::arg("height"), py::arg("width"), py::arg("nbits") = 1);
+          py::arg("height"), py::arg("width"), py::arg("nbits") = 1, py::arg("validate") = true);
     m.def("i8gemm", &i8gemm, "int8 MFMA GEMM (comparison path): float32 [M,N] = A[M,K] x Bt[N,K]^T, exact");
     m.def("i8gemm_profile", &i8gemm_profile, "time `reps` i8gemm launches; returns milliseconds",
           py::arg("A"), py::arg("Bt"), py::arg("reps") = 200, py::arg("print") = true);

@@ -64,6 +64,11 @@ def build_parser() -> argparse.ArgumentParser:
                    help="capture the epoch's per-batch launches (6 x batches) in one hipGraph and replay it")
     p.add_argument("--non-resident", action="store_true",
                    help="park packed batches on the CPU and upload them every iteration (main_qgtc.py:115)")
+    p.add_argument("--pack-on-the-fly", action="store_true",
+                   help="cluster_gcn.py's structure (:151-227): every iteration brings the batch's edge list and "
+                        "float features to the device (Trans), then packs them and runs the six operators "
+                        "(Compute), with synchronisation fences around both; prints its `Trans (ms): .., Compute "
+                        "(ms): ..` line too")
     p.add_argument("--engine", choices=["popcount", "mfma", "auto"], default="popcount",
                    help="popcount: AND + v_bcnt kernels (default, the path BASELINE.json names); mfma: bit planes "
                         "expanded to int8 on the matrix cores; auto: chosen per launch. Same results.")
@@ -234,7 +239,8 @@ def run(args, Q=None, batch_ids=None, graph=None):
     b = args.bit_width
     it = ClusterIter(args.dataset, graph, args.psize, args.batch_size, bit_width=b,
                      run_GIN=args.run_GIN, device=device, resident=not args.non_resident, qgtc=Q,
-                     batch_ids=batch_ids, with_rows_X=(args.chain == "correct"))
+                     batch_ids=batch_ids, with_rows_X=(args.chain == "correct"),
+                     keep_raw=getattr(args, "pack_on_the_fly", False))
     torch.cuda.synchronize()
 
     prev_engine = Q.get_engine()
@@ -258,6 +264,33 @@ def _run_epochs(args, Q, it, feat_size, b, device):
             Q.bitMM2Bit_base_cnt(ct.bit_A, t0, A0, A1, W["hidden"], 1, b, b)
             Q.bitMM2Bit_zerojump_cnt(ct.bit_A, t0, A0, A1, W["hidden"], 1, b, b)
         return {"avg_epoch_ms": float("nan"), "outs": [], "iter": it, "counters": Q.get_counters()}
+
+    if getattr(args, "pack_on_the_fly", False):
+        from .sampler import ClusterTensor
+        transfering = running_time = 0.0          # cluster_gcn.py:121-122
+        for _ in range(args.n_epochs):
+            outs = []
+            for (r_, c_, X_), param in zip(it.raw_li, it.cluster_param_li):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                r_d, c_d, X_d = r_.to(device), c_.to(device), X_.to(device)   # cluster_gcn.py:165-167 (no-op when resident)
+                torch.cuda.synchronize()
+                transfering += time.perf_counter() - t
+                t = time.perf_counter()
+                n = param[0]
+                ct = ClusterTensor(Q.pack_edges(r_d, c_d, n, n, 1, False), Q.val2bit(X_d, b, True, False),
+                                   Q.val2bit(X_d, b, False, False) if args.chain == "correct" else None)
+                outs.append(chain(Q, ct, param, W, b))
+                torch.cuda.synchronize()
+                running_time += time.perf_counter() - t
+        end_time = time.time()
+        avg = (end_time - start_time) * 1000 / args.n_epochs
+        if not args.quiet:
+            print("Trans (ms): {:.3f}, Compute (ms): {:.3f}".format(transfering / args.n_epochs * 1e3,
+                                                                      running_time / args.n_epochs * 1e3))   # cluster_gcn.py:245
+            print("Avg. Epoch: {:.3f} ms".format(avg))                                                       # cluster_gcn.py:246
+        return {"avg_epoch_ms": avg, "outs": outs, "iter": it, "trans_ms": transfering / args.n_epochs * 1e3,
+                "compute_ms": running_time / args.n_epochs * 1e3}
 
     if args.batched or args.streams > 0:
         cts = [c.to(device) for c in it.cTensor_li]

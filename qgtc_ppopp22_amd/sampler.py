@@ -47,7 +47,8 @@ class ClusterTensor:
 class ClusterIter:
     def __init__(self, dn, g: G.Graph, psize: int, batch_size: int, bit_width: int = 2,
                  run_GIN: bool = False, device="cuda", resident: bool = True, qgtc=None,
-                 batch_ids=None, with_rows_X: bool = False, dense_adjacency: bool = False):
+                 batch_ids=None, with_rows_X: bool = False, dense_adjacency: bool = False,
+                 keep_raw: bool = False):
         if qgtc is None:
             import QGTC as qgtc  # the HIP extension; there is no fallback
         self.g = g
@@ -62,6 +63,9 @@ class ClusterIter:
         # round-robin sharding hook: only these batch ids are materialised on this rank
         self.batch_ids = list(range(self.max)) if batch_ids is None else list(batch_ids)
         self.cTensor_li, self.cluster_param_li, self.n_edges = [], [], []
+        # keep_raw: the unpacked batch (edge list, float features) for drivers that pack inside the epoch
+        # loop as cluster_gcn.py:151-227 does
+        self.raw_li = []
         for cid in self.batch_ids:
             nodes = G.batch_nodes(self.par_li, cid, psize, batch_size)
             row, col = G.induced_edges(g, nodes)
@@ -88,6 +92,8 @@ class ClusterIter:
             self.cTensor_li.append(ct)
             self.cluster_param_li.append((n, n, X.size(0), X.size(1)))  # sampler.py:92-95,105
             self.n_edges.append(int(row.size))
+            if keep_raw:
+                self.raw_li.append((r_dev, c_dev, X) if resident else (r_dev.cpu(), c_dev.cpu(), X.cpu()))
 
     def __len__(self):
         return len(self.cTensor_li)

@@ -63,6 +63,25 @@ def test_engines_give_the_same_epoch(qgtc, engine, gin, batched):
         assert len(base) == len(other) and all(torch.equal(x, y) for x, y in zip(base, other))
 
 
+@pytest.mark.parametrize("extra", [[], ["--chain", "correct"], ["--run_GIN", "--bit_width", "4"], ["--non-resident"]])
+def test_pack_on_the_fly_matches_packed_once(qgtc, capfd, extra):
+    """cluster_gcn.py's structure - pack inside the epoch loop - gives the outputs of the packed-once runs and
+    prints the reference's `Trans (ms): .., Compute (ms): ..` line ahead of `Avg. Epoch`."""
+    import re
+    import torch
+    from qgtc_ppopp22_amd import driver
+
+    base = driver.run(_args(extra), Q=qgtc)["outs"]
+    a = _args(extra + ["--pack-on-the-fly"])
+    a.quiet = False
+    res = driver.run(a, Q=qgtc)
+    assert len(base) == len(res["outs"]) and all(torch.equal(x, y) for x, y in zip(base, res["outs"]))
+    out = capfd.readouterr().out
+    assert re.search(r"^Trans \(ms\): \d+\.\d{3}, Compute \(ms\): \d+\.\d{3}$", out, re.M)
+    assert re.search(r"^Avg\. Epoch: \d+\.\d{3} ms$", out, re.M)
+    assert res["compute_ms"] > 0.0
+
+
 def test_non_resident_matches_resident(qgtc):
     import torch
     from qgtc_ppopp22_amd import driver

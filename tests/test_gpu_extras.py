@@ -41,6 +41,12 @@ def test_pack_edges_rejects_bad_indices(qgtc):
     with pytest.raises(RuntimeError):
         qgtc.pack_edges(torch.tensor([0, 40]).cuda(), torch.tensor([1, 2]).cuda(), 37, 37, 1)
     with pytest.raises(RuntimeError):
+        qgtc.pack_edges(torch.tensor([0, 40]).cuda(), torch.tensor([1, 2]).cuda(), 37, 37, 2)
+    # validate=False (no host round trip): out-of-range edges are skipped, the rest is packed
+    got = qgtc.pack_edges(torch.tensor([0, 40, 3]).cuda(), torch.tensor([1, 2, -1]).cuda(), 37, 37, 1, False)
+    want = qgtc.pack_edges(torch.tensor([0]).cuda(), torch.tensor([1]).cuda(), 37, 37, 1)
+    assert torch.equal(got, want)
+    with pytest.raises(RuntimeError):
         qgtc.pack_edges(torch.tensor([0, 1], dtype=torch.int32).cuda(), torch.tensor([1, 2], dtype=torch.int32).cuda(), 37, 37, 1)
 
 
