@@ -82,7 +82,7 @@ class ClusterIter:
             else:
                 # same words, straight from the edge list: the n x n floats (5.9 MB for n = 1213
                 # against 190 KiB packed) are never materialised
-                bit_A = qgtc.pack_edges(r_dev, c_dev, n, n, 1)
+                bit_A = qgtc.pack_edges(r_dev, c_dev, n, n, 1, False)   # (our own induced edges: no index check, no sync)
             X = torch.from_numpy(g.feat[nodes]).to(self.device)
             bit_X = qgtc.val2bit(X, bit_width, True, False)      # sampler.py:99/102
             bit_Xr = qgtc.val2bit(X, bit_width, False, False) if with_rows_X else None
