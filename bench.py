@@ -36,6 +36,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 # VALU issue rate of the v_and_b32 + v_bcnt_u32_b32 pair measured on MI355X with
 # tools/valu_peak.hip (4.2e13 lane-instr/s at 8 waves/SIMD); one pair = 32 bit-MACs = 64 bit-ops.
 VALU_PEAK_BITOPS = 4.2e13 * 32
+FP4_PEAK_TFLOPS = 10000.0        # MI355X_MICROARCH.md: ~10 PF dense FP4 / FP6 MFMA
 
 
 def parse():
@@ -49,6 +50,10 @@ def parse():
                    help="issue the steps round-robin on this many HIP streams (independent launches overlap); "
                         "default 1 = the reference's metric, launches back to back on one stream")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget")
+    p.add_argument("--engine", choices=["popcount", "mfma", "auto"], default="auto",
+                   help="engine of the headline launches (same words either way): popcount = AND + v_bcnt kernels, "
+                        "auto = the library's choice per call (at this shape the FP4 matrix-core kernel for narrow "
+                        "right operands); the other engine's figure is reported in extras")
     return p.parse_args()
 
 
@@ -196,6 +201,14 @@ def micro_bench_table(Q, device):
             Q.profile(ba, bx, mk, mk, nn, 1, ww, ww, 20)
             ms = min(Q.profile(ba, bx, mk, mk, nn, 1, ww, ww, 200) for _ in range(3))
             row[f"w{ww}"] = {"TOPS": round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2), "ref_sm86": ref[wi]}
+            if ww <= 2:   # set_engine("auto"): the FP4 matrix-core kernel for narrow right operands
+                Q.set_engine("auto")
+                try:
+                    Q.profile(ba, bx, mk, mk, nn, 1, ww, ww, 20)
+                    ms = min(Q.profile(ba, bx, mk, mk, nn, 1, ww, ww, 200) for _ in range(3))
+                finally:
+                    Q.set_engine("popcount")
+                row[f"w{ww}"]["TOPS_engine_auto"] = round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2)
         out[f"{mk}x{mk}x{nn}"] = row
     return out
 
@@ -214,8 +227,16 @@ def main():
     M = K = 4096
     N, w = 64, args.bits
     A, X, bit_A, bit_X = make_workload(Q, M, K, N, w, device, seed=3 + rank)
-    out = Q.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w)
-    wall, kern = time_steps(Q, out, bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams)
+    out = Q.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w)   # popcount engine: the parity-pinned words
+    Q.set_engine(args.engine)
+    try:
+        out_e = Q.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w)
+        assert torch.equal(out_e, out), "engines disagree"
+        wall, kern = time_steps(Q, out_e, bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams)
+    finally:
+        Q.set_engine("popcount")
+    # what runs at this shape: the FP4 matrix-core kernel needs 1- / 2-bit planes (launch.hip.h: skinny_ok)
+    fp4_kernel = args.engine != "popcount" and w <= 2
     wall_max = D.max_over_ranks(wall, device)
     eff_ops = 2.0 * M * K * N
     value = world * args.steps * eff_ops / wall_max / 1e12
@@ -230,17 +251,28 @@ def main():
     traffic = None
     try:
         if w == 1:
-            with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_bench_d.json")) as f:
+            name = "pmc_traffic_bench_e.json" if fp4_kernel else "pmc_traffic_bench_d.json"
+            with open(os.path.join(ROOT, "profiles", "r01", name)) as f:
                 traffic = int(json.load(f)["hbm_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_bitmm<%d,1,%d,ZS>" % ({1: 4, 2: 4, 4: 2, 8: 1}.get(w, 1), w), "achieved": round(algo_bytes / kern / 1e9, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo_bytes / kern / 1e9 / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes),
-                "avg_launch_us": round(kern * 1e6, 3),
-                "valu": {"achieved_bitops": round(eff_ops * w / kern, 1), "peak_bitops": VALU_PEAK_BITOPS,
-                         "frac": round(eff_ops * w / kern / VALU_PEAK_BITOPS, 4),
-                         "note": "binding roofline of the popcount path: v_and_b32+v_bcnt_u32_b32 issue, peak measured by tools/valu_peak.hip"}}
+    hbm = {"achieved_GBs": round(algo_bytes / kern / 1e9, 2), "peak_GBs": HBM_PEAK_GBS,
+           "frac": round(algo_bytes / kern / 1e9 / HBM_PEAK_GBS, 5)}
+    if fp4_kernel:
+        # dominant kernel: k_bitmm_fp4_skinny (v_mfma_scale_f32_16x16x128_f8f6f4 on E2M1 codes of the bit planes)
+        roofline = {"bound": "mfma", "kernel": "k_bitmm_fp4_skinny<1,%d,0,ZS>" % w,
+                    "achieved": round(eff_ops / kern / 1e12, 2), "peak": FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(eff_ops / kern / 1e12 / FP4_PEAK_TFLOPS, 5), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_us": round(kern * 1e6, 3), "hbm": hbm,
+                    "note": "a 2.5 us kernel behind a 1.6 us dependent-launch gap: neither MFMA- nor HBM-bound, see DESIGN.md 5.4c"}
+    else:
+        roofline = {"bound": "hbm", "kernel": "k_bitmm<%d,1,%d,ZS>" % ({1: 4, 2: 4, 4: 2, 8: 1}.get(w, 1), w), "achieved": hbm["achieved_GBs"],
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"],
+                    "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes),
+                    "avg_launch_us": round(kern * 1e6, 3),
+                    "valu": {"achieved_bitops": round(eff_ops * w / kern, 1), "peak_bitops": VALU_PEAK_BITOPS,
+                             "frac": round(eff_ops * w / kern / VALU_PEAK_BITOPS, 4),
+                             "note": "binding roofline of the popcount path: v_and_b32+v_bcnt_u32_b32 issue, peak measured by tools/valu_peak.hip"}}
 
     line = {
         "metric": "effective bit-GEMM TOPS (2*M*K*N/t), 1-bit A x %d-bit X, M=K=4096, N=64" % w,
@@ -248,10 +280,12 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(wall_max * 1e3 / args.steps, 6),
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": round(value / REF_TFLOPS_4096_64[w], 3) if w in REF_TFLOPS_4096_64 else None,
-        "dtype": "u32 bit-planes (AND+popcount into int32)", "data": "synthetic",
+        "dtype": ("fp4 (E2M1 codes of the bit planes, MFMA, float32 sums of exact integers)" if fp4_kernel
+                  else "u32 bit-planes (AND+popcount into int32)"), "data": "synthetic",
         "config": {"workload": f"bitMM2Bit {M}x{K}x{N}, a=1, w={w}, ob={w} (BASELINE.json configs[1], 2_7c shape)",
                    "inputs": "seeded Bernoulli(0.5) adjacency, uniform w-bit features, packed and resident in HBM",
                    "parallelism": f"replica-per-GPU x{world}, no data-path collective",
+                   "engine": args.engine + (" -> FP4 matrix-core kernel for narrow right operands" if fp4_kernel else " -> AND + popcount kernels"),
                    "issue": "back-to-back launches on one stream (the reference's metric)" if args.streams <= 1
                             else f"independent launches round-robin on {args.streams} HIP streams"},
         "roofline": roofline,
@@ -265,6 +299,15 @@ def main():
     extras = {}
     if not args.no_extras:
         if rank == 0 and world == 1:
+            # the same headline launches on the other engine (identical words)
+            other = "popcount" if args.engine != "popcount" else "auto"
+            Q.set_engine(other)
+            try:
+                o_wall, o_kern = time_steps(Q, torch.empty_like(out), bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams)
+            finally:
+                Q.set_engine("popcount")
+            extras["headline_on_engine_" + other] = {"TOPS": round(args.steps * eff_ops / o_wall / 1e12, 3),
+                                                      "us_per_launch": round(o_kern * 1e6, 3)}
             sweep = {}
             for ww in (1, 2, 4, 8):
                 for label, ones in (("random", False), ("ones", True)):
@@ -274,6 +317,14 @@ def main():
                     sweep[f"w{ww}_{label}"] = {"TOPS": round(eff_ops * 200 / (ms * 1e-3) / 1e12, 2),
                                                "us_per_launch": round(ms * 1e3 / 200, 3),
                                                "ref_sm86_TFLOPs": REF_TFLOPS_4096_64[ww]}
+                    if ww <= 2:
+                        Q.set_engine("auto")
+                        try:
+                            Q.profile(ba, bx, M, K, N, 1, ww, ww, 20)
+                            ms = min(Q.profile(ba, bx, M, K, N, 1, ww, ww, 200) for _ in range(3))
+                        finally:
+                            Q.set_engine("popcount")
+                        sweep[f"w{ww}_{label}"]["TOPS_engine_auto"] = round(eff_ops * 200 / (ms * 1e-3) / 1e12, 2)
             extras["width_sweep_4096x4096x64"] = sweep
             # Independent launches (different cluster batches in a serving loop) need not be serialised
             # by stream order: the same products issued round-robin on two HIP streams, each launch

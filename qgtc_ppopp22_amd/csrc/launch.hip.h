@@ -234,6 +234,36 @@ int launch_mfma_batched(const qgtc_problem *prs, int count, int max_M, int max_K
     return QGTC_OK;
 }
 
+// narrow right operands (N <= 64) with 1- / 2-bit planes: the LDS-free FP4 kernel (bitmm_fp4_skinny.hip.h)
+inline bool skinny_ok(int K, int N, int a, int w) { return N <= SK_COLS && fp4_ok(K, a, w); }
+// QGTC_ENGINE_AUTO: measured against the popcount kernels on the reference's micro-benchmark shapes
+// (1024 / 2048 / 4096 square, N = 16 / 32 / 64, 1- and 2-bit): ahead on all of them (4096 x 4096 x 64:
+// 4.1 us against 4.8 at 1 bit, 5.8 against 7.0 at 2 bits); tiny problems stay where they were.
+inline bool auto_prefers_skinny(int M, int K, int N, int a, int w) {
+    (void)N; (void)a; (void)w;
+    return M >= 512 && K >= 512;
+}
+
+int launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, bool zero_skip, hipStream_t st) {
+    MMShape sh = base_shape(a, w, ob, mode);
+    sh.nowrap = 1;
+    const dim3 grid((pr.M + SK_ROWS - 1) / SK_ROWS, (pr.N + SK_COLS - 1) / SK_COLS);
+#define QGTC_SK_LAUNCH(NA_, NW_)                                                                              \
+    if (a == NA_ && w == NW_) {                                                                               \
+        if (mode == 2) {                                                                                      \
+            if (zero_skip) hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 2, true>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh);  \
+            else hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 2, false>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh);           \
+        } else {                                                                                              \
+            if (zero_skip) hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 0, true>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh);  \
+            else hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 0, false>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh);           \
+        }                                                                                                     \
+    }
+    QGTC_SK_LAUNCH(1, 1) QGTC_SK_LAUNCH(1, 2) QGTC_SK_LAUNCH(2, 1) QGTC_SK_LAUNCH(2, 2)
+#undef QGTC_SK_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
 int check_mm_args(const uint32_t *X, const uint32_t *W, const void *out, int M, int K, int N,
                   int a, int w) {
     if (!X || !W || !out) return QGTC_EINVAL;

@@ -16,7 +16,8 @@
 //   i8gemm_kernel.hip.h      int8 MFMA comparison GEMM
 //   tile_stats_kernels.hip.h occupancy bitmaps, tile counters
 //   bitmm_popcount.hip.h     the bit-GEMM (default engine) - start at the comment above `mm_tile`
-//   bitmm_mfma.hip.h         the bit-GEMM on the matrix cores (opt-in engine)
+//   bitmm_mfma.hip.h         the bit-GEMM on the matrix cores (opt-in engine), 128 x 128 tiles
+//   bitmm_fp4_skinny.hip.h   the same for narrow right operands (N <= 64, 1- / 2-bit): no LDS staging
 //   launch.hip.h             split-K plan, kernel selection, launchers
 //   qgtc_hip.hip             the C-ABI of include/qgtc.h (this file)
 // Design notes live in DESIGN.md.
@@ -35,6 +36,7 @@
 #include "tile_stats_kernels.hip.h"
 #include "bitmm_popcount.hip.h"
 #include "bitmm_mfma.hip.h"
+#include "bitmm_fp4_skinny.hip.h"
 #include "launch.hip.h"
 
 // ============================================================================================
@@ -135,6 +137,8 @@ int qgtc_bitmm2bit(const uint32_t *X, size_t x_words, const uint32_t *W, size_t 
     if (out_words < need) return QGTC_ESIZE;
     qgtc_problem pr{X, W, out, x_words, w_words, M, K, N, pad128(N), 0, nullptr};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!cols && skinny_ok(K, N, bit1, bit2) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_skinny(M, K, N, bit1, bit2))))
+        return launch_skinny(pr, bit1, bit2, output_bit, 0, !(flags & QGTC_NO_ZERO_SKIP), st);
     if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma(M, K, N, bit1, bit2)))
         return launch_mfma(pr, bit1, bit2, output_bit, cols ? 1 : 0, st);
     if (flags & QGTC_NO_ZERO_SKIP)
@@ -151,6 +155,8 @@ int qgtc_bitmm2int(const uint32_t *X, size_t x_words, const uint32_t *W, size_t 
     if (out_elems < static_cast<size_t>(M) * N) return QGTC_ESIZE;
     qgtc_problem pr{X, W, out, x_words, w_words, M, K, N, pad_128 ? pad128(N) : pad8(N), 0, nullptr};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (skinny_ok(K, N, bit1, bit2) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_skinny(M, K, N, bit1, bit2))))
+        return launch_skinny(pr, bit1, bit2, 1, 2, !(flags & QGTC_NO_ZERO_SKIP), st);
     if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma(M, K, N, bit1, bit2)))
         return launch_mfma(pr, bit1, bit2, 1, 2, st);
     if (flags & QGTC_NO_ZERO_SKIP) return dispatch_single<false>(pr, K, bit1, bit2, 1, 2, st);
