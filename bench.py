@@ -201,7 +201,7 @@ def micro_bench_table(Q, device):
             Q.profile(ba, bx, mk, mk, nn, 1, ww, ww, 20)
             ms = min(Q.profile(ba, bx, mk, mk, nn, 1, ww, ww, 200) for _ in range(3))
             row[f"w{ww}"] = {"TOPS": round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2), "ref_sm86": ref[wi]}
-            if ww <= 2:   # set_engine("auto"): the FP4 matrix-core kernel for narrow right operands
+            if True:      # set_engine("auto"): the FP4 matrix-core kernel for narrow right operands
                 Q.set_engine("auto")
                 try:
                     Q.profile(ba, bx, mk, mk, nn, 1, ww, ww, 20)
@@ -235,8 +235,9 @@ def main():
         wall, kern = time_steps(Q, out_e, bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams)
     finally:
         Q.set_engine("popcount")
-    # what runs at this shape: the FP4 matrix-core kernel needs 1- / 2-bit planes (launch.hip.h: skinny_ok)
-    fp4_kernel = args.engine != "popcount" and w <= 2
+    # what runs at this shape: the FP4 matrix-core kernel for narrow right operands (launch.hip.h: skinny_ok -
+    # N <= 64, at most 2 x 8 planes, float32 sums exact: K (2^a - 1)(2^w - 1) < 2^24)
+    fp4_kernel = args.engine != "popcount" and w <= 8 and K * (2 ** w - 1) < 2 ** 24
     wall_max = D.max_over_ranks(wall, device)
     eff_ops = 2.0 * M * K * N
     value = world * args.steps * eff_ops / wall_max / 1e12
@@ -260,7 +261,7 @@ def main():
            "frac": round(algo_bytes / kern / 1e9 / HBM_PEAK_GBS, 5)}
     if fp4_kernel:
         # dominant kernel: k_bitmm_fp4_skinny (v_mfma_scale_f32_16x16x128_f8f6f4 on E2M1 codes of the bit planes)
-        roofline = {"bound": "mfma", "kernel": "k_bitmm_fp4_skinny<1,%d,0,ZS>" % w,
+        roofline = {"bound": "mfma", "kernel": "k_bitmm_fp4_skinny<1,%d,0,2,2>" % ({1: 1, 2: 2}.get(w, 4 if w <= 4 else 8)),
                     "achieved": round(eff_ops / kern / 1e12, 2), "peak": FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(eff_ops / kern / 1e12 / FP4_PEAK_TFLOPS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_us": round(kern * 1e6, 3), "hbm": hbm,
@@ -317,7 +318,7 @@ def main():
                     sweep[f"w{ww}_{label}"] = {"TOPS": round(eff_ops * 200 / (ms * 1e-3) / 1e12, 2),
                                                "us_per_launch": round(ms * 1e3 / 200, 3),
                                                "ref_sm86_TFLOPs": REF_TFLOPS_4096_64[ww]}
-                    if ww <= 2:
+                    if True:
                         Q.set_engine("auto")
                         try:
                             Q.profile(ba, bx, M, K, N, 1, ww, ww, 20)

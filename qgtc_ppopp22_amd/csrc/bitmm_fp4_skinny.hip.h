@@ -16,22 +16,32 @@ namespace {
 // float32 sum the integer product, see bitmm_mfma.hip.h). Nothing is shared between lanes: no LDS staging and
 // no barrier until the end.
 //
-// A workgroup owns 16 rows x 64 columns for the whole K; its eight waves split K (wave v takes the super-steps
+// A workgroup owns a 32 x 32 (N > 32) or 16 x 32 tile for the whole K; its eight waves split K (wave v takes the super-steps
 // of 512 bits v, v+8, ..), keep two super-steps of packed words in flight and are summed through LDS once
 // (float32 adds of exact integers). 4096 x 4096 x 64: 256 workgroups, one super-step = 16 MFMAs per wave, two waves per SIMD.
-// All-zero 16-row x 512-bit X tiles are skipped with one ballot.
+// All-zero (tile rows) x 512-bit X tiles are skipped with one ballot.
 // Rows-layout bits (mode 0) and float32 (mode 2) only: a cols-layout word spans 32 rows, i.e. two workgroups.
-// Needs a, w <= 2 and K (2^a - 1)(2^w - 1) < 2^24 (fp4_ok).
+//
+// More than two planes: an operand is taken two planes at a time - base-4 "digits", each again the codes 0..3 -
+// and digit d is multiplied with the E8M0 scale 2 * 4^d, so sum_d 4^d (X . W_d) accumulates in the same float32
+// registers, exactly while K (2^a - 1)(2^w - 1) < 2^24 (skinny_ok). NA, NW are plane CAPACITIES (planes beyond
+// sh.a / sh.w are not loaded); one MFMA per pair of digits instead of one AND + popcount pass per pair of planes.
 // ------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int SK_ROWS = 16, SK_COLS = 64, SK_DEPTH = 2;   // tile, super-steps (4 k-quads) of packed words in flight per wave
-constexpr int SK_WAVES = 8;                                // waves per workgroup = in-workgroup split-K factor
-constexpr int SK_PITCH = 68;                              // floats between the rows of a wave's partial tile in LDS
+constexpr int SK_WAVES = 8;   // waves per workgroup = in-workgroup split-K factor
 
-template <int NA, int NW, int MODE, bool ZS>
-__global__ __launch_bounds__(64 * SK_WAVES) void k_bitmm_fp4_skinny(qgtc_problem pr, MMShape sh) {
-    static_assert(NA >= 1 && NA <= 2 && NW >= 1 && NW <= 2, "FP4 codes hold 2-bit values at most");
-    __shared__ __attribute__((aligned(16))) float part[SK_WAVES][SK_ROWS][SK_PITCH];
+// RF x CF fragments of 16 lines: the workgroup's tile is 16 RF rows x 16 CF columns. 2 x 2 (32 x 32) when N > 32:
+// every W line is then expanded (and fetched from L2) by M / 32 workgroups instead of M / 16, which is what
+// matters from four planes up; 1 x 2 (16 x 32) for N <= 32 keeps 256 workgroups at M = 4096.
+template <int NA, int NW, int MODE, int RF, int CF>
+__global__ __launch_bounds__(64 * SK_WAVES) void k_bitmm_fp4_skinny(qgtc_problem pr, MMShape sh, int zero_skip) {
+    static_assert(NA >= 1 && NA <= 8 && NW >= 1 && NW <= 8, "plane capacities");
+    constexpr int TR = 16 * RF, TC = 16 * CF, PITCH = TC + 4;   // tile; floats between the rows of a partial tile in LDS
+    constexpr int SK_DEPTH = RF * NA + CF * NW <= 10 ? 2 : 1;    // super-steps (4 k-quads) of packed words in flight per wave
+    constexpr int NDA = (NA + 1) / 2, NDW = (NW + 1) / 2;        // base-4 digits
+    constexpr int QPR = TC / 4, ETHREADS = TR * QPR;             // epilogue: quads per row, threads
+    static_assert(ETHREADS <= 64 * SK_WAVES && (TC == 32 || TC == 64), "tile");
+    __shared__ __attribute__((aligned(16))) float part[SK_WAVES][TR][PITCH];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef QGTC_STAMPS
@@ -41,9 +51,9 @@ __global__ __launch_bounds__(64 * SK_WAVES) void k_bitmm_fp4_skinny(qgtc_problem
 #define SK_STAMP(i) do { } while (0)
 #endif
     SK_STAMP(0);
-    const int li = lane & 15, g = lane >> 4;       // line within the 16-line fragment, word of the k-quad
+    const int li = lane & 15, g = lane >> 4;       // line within the 16-line fragment, k-quad of the super-step
     const int M = pr.M, K = pr.K, N = pr.N;
-    const int m0 = blockIdx.x * SK_ROWS, n0 = blockIdx.y * SK_COLS;
+    const int m0 = blockIdx.x * TR, n0 = blockIdx.y * TC;
     const int kq = step128(K);
     const uint32_t kw = static_cast<uint32_t>(kq) * 4u;
     const uint32_t x_plane = static_cast<uint32_t>(pad8(M)) * kw, w_plane = static_cast<uint32_t>(pr.w_lines) * kw;
@@ -52,66 +62,88 @@ __global__ __launch_bounds__(64 * SK_WAVES) void k_bitmm_fp4_skinny(qgtc_problem
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(pr.W), 0, static_cast<int>(static_cast<uint32_t>(pr.w_words) * 4u), 0x00020000);
     // byte offsets of the lane's lines; lines outside the matrix read as zero (offset 0xffffffff)
-    const bool x_ok = m0 + li < M;
-    const uint32_t x_off = static_cast<uint32_t>(m0 + li) * kw * 4u;
-    uint32_t w_off[4];
-    bool w_ok[4];
+    uint32_t x_off[RF], w_off[CF];
+    bool x_ok[RF], w_ok[CF];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int i = 0; i < RF; i++) {
+        x_ok[i] = m0 + 16 * i + li < M;
+        x_off[i] = static_cast<uint32_t>(m0 + 16 * i + li) * kw * 4u;
+    }
+#pragma unroll
+    for (int j = 0; j < CF; j++) {
         w_ok[j] = n0 + 16 * j + li < N;
         w_off[j] = static_cast<uint32_t>(n0 + 16 * j + li) * kw * 4u;
     }
-    const int nss = (kq + 3) / 4;                       // super-steps of four k-quads
-    const int ns = nss > wv ? (nss - wv + SK_WAVES - 1) / SK_WAVES : 0;   // this wave's: wv, wv + SK_WAVES, ..
+    const int nss = (kq + 3) / 4;                                        // super-steps of four k-quads
+    const int ns = nss > wv ? (nss - wv + SK_WAVES - 1) / SK_WAVES : 0;  // this wave's: wv, wv + SK_WAVES, ..
 
-    u32x4 xr[SK_DEPTH][NA], wr[SK_DEPTH][4][NW];
-    auto issue = [&](int s, u32x4 (&xd)[NA], u32x4 (&wd)[4][NW]) {  // unconditional: exact vmcnt waits
+    u32x4 xr[SK_DEPTH][RF][NA], wr[SK_DEPTH][CF][NW];
+    auto issue = [&](int s, u32x4 (&xd)[RF][NA], u32x4 (&wd)[CF][NW]) {  // unconditional: exact vmcnt waits
         const int q = 4 * (wv + SK_WAVES * s) + g;     // the lane's k-quad of the super-step
         const bool in = s < ns && q < kq;
         const uint32_t ko = static_cast<uint32_t>(q) * 16u;
 #pragma unroll
-        for (int p = 0; p < NA; p++)
-            xd[p] = __builtin_amdgcn_raw_buffer_load_b128(rx, (in && x_ok) ? static_cast<uint32_t>(p) * x_plane * 4u + x_off + ko : 0xffffffffu, 0, 0);
+        for (int i = 0; i < RF; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+            for (int p = 0; p < NA; p++)
+                xd[i][p] = __builtin_amdgcn_raw_buffer_load_b128(rx, (in && x_ok[i] && p < sh.a) ? static_cast<uint32_t>(p) * x_plane * 4u + x_off[i] + ko : 0xffffffffu, 0, 0);
+#pragma unroll
+        for (int j = 0; j < CF; j++)
 #pragma unroll
             for (int p = 0; p < NW; p++)
-                wd[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && w_ok[j]) ? static_cast<uint32_t>(p) * w_plane * 4u + w_off[j] + ko : 0xffffffffu, 0, 0);
+                wd[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && w_ok[j] && p < sh.w) ? static_cast<uint32_t>(p) * w_plane * 4u + w_off[j] + ko : 0xffffffffu, 0, 0);
     };
 #pragma unroll
     for (int d = 0; d < SK_DEPTH; d++) issue(d, xr[d], wr[d]);
     SK_STAMP(1);
 
-    f32x4 acc[4];
+    f32x4 acc[RF][CF];
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < RF; i++)
+#pragma unroll
+        for (int j = 0; j < CF; j++) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     for (int s0 = 0; s0 < ns; s0 += SK_DEPTH) {
 #pragma unroll
         for (int d = 0; d < SK_DEPTH; d++) {
             if (s0 + d >= ns) break;
-            uint32_t any = (xr[d][0].x | xr[d][0].y) | (xr[d][0].z | xr[d][0].w);
-            if (NA > 1) any |= (xr[d][1].x | xr[d][1].y) | (xr[d][1].z | xr[d][1].w);
-            const bool live = !ZS || __ballot(any != 0u) != 0ull;   // wave-uniform
+            uint32_t any = 0u;
+#pragma unroll
+            for (int i = 0; i < RF; i++)
+#pragma unroll
+                for (int p = 0; p < NA; p++) any |= (xr[d][i][p].x | xr[d][i][p].y) | (xr[d][i][p].z | xr[d][i][p].w);
+            const bool live = !zero_skip || __ballot(any != 0u) != 0ull;   // wave-uniform
             if (s0 + d == 0) SK_STAMP(2);
             if (live) {
 #pragma unroll
                 for (int t = 0; t < 4; t++) {   // word t of every lane's 16 bytes
-                    uint32_t xw[NA], xe[4];
+                    i32x8 a8[RF][NDA];
 #pragma unroll
-                    for (int p = 0; p < NA; p++) xw[p] = xr[d][p][t];
-                    expand_word_fp4<NA>(xw, NA, xe);
-                    const i32x8 a8 = {static_cast<int>(xe[0]), static_cast<int>(xe[1]), static_cast<int>(xe[2]), static_cast<int>(xe[3]), 0, 0, 0, 0};
+                    for (int i = 0; i < RF; i++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        uint32_t ww[NW], we[4];
+                        for (int da = 0; da < NDA; da++) {   // digit da of X: planes 2 da, 2 da + 1
+                            uint32_t xw[2], xe[4];
+                            xw[0] = xr[d][i][2 * da][t];
+                            xw[1] = 2 * da + 1 < NA ? xr[d][i][(2 * da + 1) % NA][t] : 0u;
+                            expand_word_fp4<2>(xw, 2, xe);
+                            a8[i][da] = i32x8{static_cast<int>(xe[0]), static_cast<int>(xe[1]), static_cast<int>(xe[2]), static_cast<int>(xe[3]), 0, 0, 0, 0};
+                        }
 #pragma unroll
-                        for (int p = 0; p < NW; p++) ww[p] = wr[d][j][p][t];
-                        expand_word_fp4<NW>(ww, NW, we);
-                        const i32x8 b8 = {static_cast<int>(we[0]), static_cast<int>(we[1]), static_cast<int>(we[2]), static_cast<int>(we[3]), 0, 0, 0, 0};
-                        // cbsz = blgp = 4: E2M1 operands; E8M0 scale 128 = x2 on each: the code v counts as v
-                        acc[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[j], 4, 4, 0, 128, 0, 128);
-                    }
+                    for (int j = 0; j < CF; j++)
+#pragma unroll
+                        for (int dw = 0; dw < NDW; dw++) {
+                            uint32_t ww[2], we[4];
+                            ww[0] = wr[d][j][2 * dw][t];
+                            ww[1] = 2 * dw + 1 < NW ? wr[d][j][(2 * dw + 1) % NW][t] : 0u;
+                            expand_word_fp4<2>(ww, 2, we);
+                            const i32x8 b8 = {static_cast<int>(we[0]), static_cast<int>(we[1]), static_cast<int>(we[2]), static_cast<int>(we[3]), 0, 0, 0, 0};
+#pragma unroll
+                            for (int i = 0; i < RF; i++)
+#pragma unroll
+                                for (int da = 0; da < NDA; da++)
+                                    // cbsz = blgp = 4: E2M1 operands; E8M0 scales 2 * 4^digit: the code v of digit d counts as v 4^d
+                                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8[i][da], b8, acc[i][j], 4, 4, 0, 128 + 2 * da, 0, 128 + 2 * dw);
+                        }
                 }
             }
             issue(s0 + d + SK_DEPTH, xr[d], wr[d]);
@@ -119,16 +151,18 @@ __global__ __launch_bounds__(64 * SK_WAVES) void k_bitmm_fp4_skinny(qgtc_problem
     }
 
     SK_STAMP(3);
-    // ---- reduce the four waves' partial tiles. MFMA 16 x 16 C/D layout: col = lane & 15, row = 4 (lane >> 4) + reg
+    // ---- reduce the waves' partial tiles. MFMA 16 x 16 C/D layout: col = lane & 15, row = 4 (lane >> 4) + reg
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+    for (int i = 0; i < RF; i++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) part[wv][4 * g + r][16 * j + li] = acc[j][r];
+        for (int j = 0; j < CF; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) part[wv][16 * i + 4 * g + r][16 * j + li] = acc[i][j][r];
     __syncthreads();
     SK_STAMP(4);
-    // thread t < 256: row t >> 4, four consecutive columns 4 (t & 15) ..; the upper waves are done
-    if (tid >= 256) return;
-    const int row = tid >> 4, quad = tid & 15;
+    // thread t < ETHREADS: row t / QPR, four consecutive columns 4 (t % QPR) ..; the other waves are done
+    if (tid >= ETHREADS) return;
+    const int row = tid / QPR, quad = tid % QPR;
     f32x4 sum = *reinterpret_cast<const f32x4 *>(&part[0][row][4 * quad]);
 #pragma unroll
     for (int v = 1; v < SK_WAVES; v++) {
@@ -165,7 +199,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void k_bitmm_fp4_skinny(qgtc_problem
     const uint32_t sh_n = 28u - 4u * static_cast<uint32_t>(quad & 7);
     const int word = (n0 >> 5) + (quad >> 3);
     // the last column tile also zeroes the row words past it (the kernels write every word of the output)
-    const int extra = (blockIdx.y == gridDim.y - 1 && quad == 8) ? row_words - word - 1 : 0;
+    const int extra = (blockIdx.y == gridDim.y - 1 && quad == QPR - 8) ? row_words - word - 1 : 0;
     uint32_t *dst = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(m) * row_words + word;
     for (int p = 0; p < sh.ob; p++, dst += oplane) {
         const uint32_t nib = (((q[0] >> p) & 1u) << 3) | (((q[1] >> p) & 1u) << 2) | (((q[2] >> p) & 1u) << 1) | ((q[3] >> p) & 1u);

@@ -235,7 +235,11 @@ int launch_mfma_batched(const qgtc_problem *prs, int count, int max_M, int max_K
 }
 
 // narrow right operands (N <= 64) with 1- / 2-bit planes: the LDS-free FP4 kernel (bitmm_fp4_skinny.hip.h)
-inline bool skinny_ok(int K, int N, int a, int w) { return N <= SK_COLS && fp4_ok(K, a, w); }
+// (plane capacities 1 / 2 for X and 1 / 2 / 4 / 8 for W are instantiated; float32 sums must stay exact)
+inline bool skinny_ok(int K, int N, int a, int w) {
+    return N <= 64 && a <= 2 && w <= 8 &&
+           static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
+}
 // QGTC_ENGINE_AUTO: measured against the popcount kernels on the reference's micro-benchmark shapes
 // (1024 / 2048 / 4096 square, N = 16 / 32 / 64, 1- and 2-bit): ahead on all of them (4096 x 4096 x 64:
 // 4.1 us against 4.8 at 1 bit, 5.8 against 7.0 at 2 bits); tiny problems stay where they were.
@@ -247,18 +251,23 @@ inline bool auto_prefers_skinny(int M, int K, int N, int a, int w) {
 int launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, bool zero_skip, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, mode);
     sh.nowrap = 1;
-    const dim3 grid((pr.M + SK_ROWS - 1) / SK_ROWS, (pr.N + SK_COLS - 1) / SK_COLS);
-#define QGTC_SK_LAUNCH(NA_, NW_)                                                                              \
-    if (a == NA_ && w == NW_) {                                                                               \
-        if (mode == 2) {                                                                                      \
-            if (zero_skip) hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 2, true>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh);  \
-            else hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 2, false>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh);           \
-        } else {                                                                                              \
-            if (zero_skip) hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 0, true>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh);  \
-            else hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 0, false>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh);           \
-        }                                                                                                     \
+    const int zs = zero_skip ? 1 : 0;
+    const bool wide = pr.N > 32;   // 32 x 32 tiles (two column tiles at N = 64), else 16 x 32
+    const dim3 grid(wide ? (pr.M + 31) / 32 : (pr.M + 15) / 16, (pr.N + 31) / 32);
+#define QGTC_SK_LAUNCH(NA_, NW_)                                                                                   \
+    if (!done && a <= NA_ && w <= NW_) {                                                                           \
+        done = true;                                                                                               \
+        if (mode == 2) {                                                                                           \
+            if (wide) hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 2, 2, 2>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh, zs);  \
+            else hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 2, 1, 2>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh, zs);       \
+        } else {                                                                                                   \
+            if (wide) hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 0, 2, 2>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh, zs);  \
+            else hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 0, 1, 2>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh, zs);       \
+        }                                                                                                          \
     }
-    QGTC_SK_LAUNCH(1, 1) QGTC_SK_LAUNCH(1, 2) QGTC_SK_LAUNCH(2, 1) QGTC_SK_LAUNCH(2, 2)
+    bool done = false;
+    QGTC_SK_LAUNCH(1, 1) QGTC_SK_LAUNCH(1, 2) QGTC_SK_LAUNCH(1, 4) QGTC_SK_LAUNCH(1, 8)
+    QGTC_SK_LAUNCH(2, 1) QGTC_SK_LAUNCH(2, 2) QGTC_SK_LAUNCH(2, 4) QGTC_SK_LAUNCH(2, 8)
 #undef QGTC_SK_LAUNCH
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
