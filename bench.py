@@ -180,7 +180,7 @@ def adj_size_table(Q, device):
             Q.profile(ba, bx, mk, mk, nn, 1, 1, 1, 20)
             ms = min(Q.profile(ba, bx, mk, mk, nn, 1, 1, 1, 200) for _ in range(3))
             row[f"M{mk}"] = {"TOPS": round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2), "ref_sm86": ref[mi]}
-            if nn >= 512:   # where the cost model of set_engine("auto") moves to the matrix cores
+            if True:        # set_engine("auto"): the matrix cores (FP4 kernels: no LDS staging up to N = 256, 128 x 128 tiles above)
                 Q.set_engine("auto")
                 try:
                     Q.profile(ba, bx, mk, mk, nn, 1, 1, 1, 20)

@@ -1,6 +1,6 @@
 // bitmm_fp4_skinny.hip.h — part of libqgtc_hip.so (included by qgtc_hip.hip, one translation unit).
-// The bit-GEMM on the matrix cores for NARROW right operands (the reference's benchmark shapes: N <= 64)
-// with 1- or 2-bit operands: no LDS staging, no barrier in the main loop.
+// The bit-GEMM on the matrix cores for NARROW right operands (the reference's benchmark shapes: N <= 64;
+// used up to N = 256): no LDS staging, no barrier in the main loop.
 #pragma once
 
 namespace {
