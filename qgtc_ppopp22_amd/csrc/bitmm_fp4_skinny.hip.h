@@ -9,18 +9,19 @@ namespace {
 // v_mfma_scale_f32_16x16x128_f8f6f4 multiplies 16 lines x 128 elements of K per instruction and lane l
 // supplies, for both operands, 32 elements (16 bytes of E2M1 codes) of line l & 15: exactly the expansion of
 // ONE packed 32-bit word. Which 128 elements of K an instruction covers is irrelevant as long as X and W agree
-// (the sum over k commutes), so lane (line, g = l >> 4) simply loads the 16 bytes of k-quad 4S + g of its X row
-// and of its four W lines - 64 contiguous bytes per line and load instruction - and instruction t = 0..3 of
+// (the sum over k commutes), so lane (line, g = l >> 4) simply loads the 16 bytes of k-quad 4S + g of its X rows
+// and of its W lines - 64 contiguous bytes per line and load instruction - and instruction t = 0..3 of
 // the super-step takes word t of every lane's 16 bytes, expanded in registers (expand_word_fp4: a shift and an
 // AND per plane and dword; the codes 0..3 mean 0, 0.5, 1, 1.5 and the E8M0 scale 2 on both operands makes the
 // float32 sum the integer product, see bitmm_mfma.hip.h). Nothing is shared between lanes: no LDS staging and
 // no barrier until the end.
 //
-// A workgroup owns a 32 x 32 (N > 32) or 16 x 32 tile for the whole K; its eight waves split K (wave v takes the super-steps
-// of 512 bits v, v+8, ..), keep two super-steps of packed words in flight and are summed through LDS once
-// (float32 adds of exact integers). 4096 x 4096 x 64: 256 workgroups, one super-step = 16 MFMAs per wave, two waves per SIMD.
+// A workgroup owns a 32 x 32 (N > 32) or 16 x 32 tile for the whole K; its eight waves split K (wave v takes
+// the super-steps of 512 bits v, v+8, ..), keep up to two super-steps of packed words in flight and are summed
+// through LDS once (float32 adds of exact integers). 4096 x 4096 x 64: 256 workgroups, one super-step = 16 MFMAs
+// per wave, two waves per SIMD.
 // All-zero (tile rows) x 512-bit X tiles are skipped with one ballot.
-// Rows-layout bits (mode 0) and float32 (mode 2) only: a cols-layout word spans 32 rows, i.e. two workgroups.
+// Rows-layout bits (mode 0) and float32 (mode 2) only (the cols layout keeps the other kernels).
 //
 // More than two planes: an operand is taken two planes at a time - base-4 "digits", each again the codes 0..3 -
 // and digit d is multiplied with the E8M0 scale 2 * 4^d, so sum_d 4^d (X . W_d) accumulates in the same float32
