@@ -275,6 +275,36 @@ int launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, bool z
     return QGTC_OK;
 }
 
+// grouped launches on the matrix cores, one wave per 32 x 32 tile (bitmm_fp4_wave.hip.h): for NARROW outputs.
+// Measured on the epochs (tools/epoch_stages.py): the class-count stages (N = 10) 7.1 / 10.9 us against 13.8 / 12.6
+// for the popcount kernels, ppi's 1 x 4-bit A-stages at N = 50 14.3 against 16.3 for the 128-tile kernel; at
+// N = 128 the 128-tile kernel is ahead (12 / 18.5 us against 18 / 25), and 64 x 64 outputs per wave are worse
+// still (24 / 41 us: 2850 waves do not fill the chip).
+inline bool fp4_wave_ok(int K, int N, int a, int w) {
+    return N <= 64 && a <= 2 && w <= 8 && static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
+}
+
+int launch_fp4_wave(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode,
+                    bool zero_skip, hipStream_t st) {
+    MMShape sh = base_shape(a, w, ob, mode);
+    sh.nowrap = 1;
+    const int zs = zero_skip ? 1 : 0;
+    const dim3 grid(((max_M + 31) / 32) * ((max_N + 31) / 32), count);   // 32 x 32 outputs per wave
+#define QGTC_FW_LAUNCH(NA_, NW_)                                                                                 \
+    if (!done && a <= NA_ && w <= NW_) {                                                                         \
+        done = true;                                                                                             \
+        if (mode == 2) hipLaunchKernelGGL((k_bitmm_fp4_wave<NA_, NW_, 2, 2, 2>), grid, dim3(64), 0, st, prs, sh, zs);      \
+        else if (mode == 1) hipLaunchKernelGGL((k_bitmm_fp4_wave<NA_, NW_, 1, 2, 2>), grid, dim3(64), 0, st, prs, sh, zs); \
+        else hipLaunchKernelGGL((k_bitmm_fp4_wave<NA_, NW_, 0, 2, 2>), grid, dim3(64), 0, st, prs, sh, zs);                \
+    }
+    bool done = false;
+    QGTC_FW_LAUNCH(1, 1) QGTC_FW_LAUNCH(1, 2) QGTC_FW_LAUNCH(1, 4) QGTC_FW_LAUNCH(1, 8)
+    QGTC_FW_LAUNCH(2, 1) QGTC_FW_LAUNCH(2, 2) QGTC_FW_LAUNCH(2, 4) QGTC_FW_LAUNCH(2, 8)
+#undef QGTC_FW_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
 int check_mm_args(const uint32_t *X, const uint32_t *W, const void *out, int M, int K, int N,
                   int a, int w) {
     if (!X || !W || !out) return QGTC_EINVAL;

@@ -17,7 +17,8 @@
 //   tile_stats_kernels.hip.h occupancy bitmaps, tile counters
 //   bitmm_popcount.hip.h     the bit-GEMM (default engine) - start at the comment above `mm_tile`
 //   bitmm_mfma.hip.h         the bit-GEMM on the matrix cores (opt-in engine), 128 x 128 tiles
-//   bitmm_fp4_skinny.hip.h   the same for narrow right operands (N <= 64, 1- / 2-bit): no LDS staging
+//   bitmm_fp4_skinny.hip.h   the same for narrow right operands (N <= 256): no LDS staging
+//   bitmm_fp4_wave.hip.h     the same for grouped launches over cluster batches: one wave per 32 x 32 tile
 //   launch.hip.h             split-K plan, kernel selection, launchers
 //   qgtc_hip.hip             the C-ABI of include/qgtc.h (this file)
 // Design notes live in DESIGN.md.
@@ -38,6 +39,7 @@
 #include "bitmm_popcount.hip.h"
 #include "bitmm_mfma.hip.h"
 #include "bitmm_fp4_skinny.hip.h"
+#include "bitmm_fp4_wave.hip.h"
 #include "launch.hip.h"
 
 // ============================================================================================
@@ -222,6 +224,8 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
     // choice is correct; this only affects speed.
     const int k_hint = max_K;
     const int ob_ = mode == 2 ? 1 : output_bit;
+    if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && fp4_wave_ok(max_K, max_N, bit1, bit2))   // narrow outputs: one wave per 32 x 32 tile
+        return launch_fp4_wave(problems, count, max_M, max_N, bit1, bit2, ob_, mode, !(flags & QGTC_NO_ZERO_SKIP), st);
     if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) ||  // problems with a one-word bitmap jump zero tiles
         ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma_batched(max_M, max_N, bit1, bit2)))
         return launch_mfma_batched(problems, count, max_M, max_K, max_N, bit1, bit2, ob_, mode, st);
