@@ -110,7 +110,7 @@ def cpu_baseline(M, K, N, w, A, X, budget_s):
     for _ in range(5):
         O.bitmm2bit(bx, bw, M, K, N, 1, w, w)
     one = (time.perf_counter() - t0) / 5
-    reps = max(1, min(2000, int(budget_s / max(one, 1e-6))))
+    reps = max(1, min(1000, int(budget_s / max(one, 1e-6))))
     t0 = time.perf_counter()
     for _ in range(reps):
         ref = O.bitmm2bit(bx, bw, M, K, N, 1, w, w)
