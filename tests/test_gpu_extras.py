@@ -302,3 +302,50 @@ def test_jump_decision_is_made_on_the_device(qgtc, oracle):
         assert bg2.zero_jump == expect_jump
         for i in range(len(dims)):
             np.testing.assert_array_equal(to_np_u32(bg2.outs[i]), want[i])
+
+
+def test_fp4_narrow_kernels_sweep(qgtc, oracle):
+    """The FP4 matrix-core kernels for narrow right operands (k_bitmm_fp4_skinny: single launches, N <= 256;
+    k_bitmm_fp4_wave: grouped launches, N <= 64) on shapes picked for their corners: K long enough for several
+    super-steps per wave and ragged at every granularity (32 bits, 128 bits, 512 bits), 1..8 planes in base-4
+    digits, all-zero row blocks (zero-tile skipping on and off), the float32-exactness bound (above it the
+    other kernels must take over) - against the oracle, rows-layout bits and float32."""
+    import torch
+    from helpers import rand_q, to_dev
+    from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
+    rng = np.random.default_rng(424242)
+    cases = [  # M, K, N, a, w, ob
+        (100, 9000, 64, 1, 1, 1), (70, 20000, 33, 1, 2, 2), (33, 40000, 10, 2, 2, 3), (300, 4100, 200, 1, 3, 2),
+        (50, 5000, 256, 1, 8, 8), (64, 2048, 17, 2, 8, 4), (129, 700, 129, 2, 5, 6), (40, 70000, 40, 1, 7, 8),
+        (16, 512, 32, 1, 4, 4), (31, 130, 31, 2, 1, 1),
+        (20, 70000, 20, 1, 8, 8),     # 70000 * 255 > 2^24: not exact in float32 -> the other kernels
+    ]
+    qgtc.set_engine("mfma")
+    try:
+        for (M, K, N, a, w, ob) in cases:
+            qx, qw = rand_q(rng, M, K, a), rand_q(rng, K, N, w)
+            qx[M // 3: M // 3 + 17] = 0                       # a block of all-zero rows
+            X, Wt = oracle.pack(qx, a, False), oracle.pack(qw, w, True)
+            dX, dW = to_dev(torch, X, rows_shape(M, K, a)), to_dev(torch, Wt, cols_shape(K, N, w))
+            tag = f"M={M} K={K} N={N} a={a} w={w} ob={ob}"
+            want_b = oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob)
+            want_f = oracle.bitmm2int(X, Wt, M, K, N, a, w, True)
+            for zs in (True, False):
+                qgtc.set_zero_skip(zs)
+                try:
+                    np.testing.assert_array_equal(to_np_u32(qgtc.bitMM2Bit(dX, dW, M, K, N, a, w, ob)), want_b, err_msg=tag)
+                    np.testing.assert_array_equal(qgtc.bitMM2Int(dX, dW, M, K, N, a, w, True).cpu().numpy(), want_f, err_msg=tag)
+                finally:
+                    qgtc.set_zero_skip(True)
+            for mode in (0, 1, 2):                            # grouped: two copies of the problem
+                for zj in (False, True):
+                    bg = qgtc.BatchedGemm([dX, dX], [dW, dW], [(M, K, N)] * 2, a, w, ob, mode, True, zj)
+                    bg.run()
+                    for o in bg.outs:
+                        if mode == 2:
+                            np.testing.assert_array_equal(o.cpu().numpy(), want_f, err_msg=tag + f" grouped mode {mode}")
+                        else:
+                            np.testing.assert_array_equal(to_np_u32(o), oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob, col=(mode == 1)),
+                                                          err_msg=tag + f" grouped mode {mode} jump {zj}")
+    finally:
+        qgtc.set_engine("popcount")
