@@ -1,6 +1,7 @@
 """In-tree build of the native pieces (called by __graft_entry__.build()).
 
-  libqgtc_hip.so                    hipcc --offload-arch=gfx950  csrc/qgtc_hip.hip   (C-ABI; includes csrc/*.hip.h, the kernels)
+  libqgtc_hip.so                    hipcc --offload-arch=gfx950  csrc/qgtc_hip.hip + qgtc_mfma.hip + qgtc_fp4.hip (three translation
+                                    units compiled in parallel; they include csrc/*.hip.h, the kernels)
   QGTC.cpython-*.so                 g++                          csrc/qgtc_torch.cpp (pybind11 binding)
 
 Both land next to this file so that they travel with the repo snapshot to the GPU box (they are
@@ -36,14 +37,29 @@ def _run(cmd: list[str]) -> None:
     subprocess.run(cmd, check=True)
 
 
+HIP_UNITS = ("qgtc_hip.hip", "qgtc_mfma.hip", "qgtc_fp4.hip")   # translation units of libqgtc_hip.so, compiled in parallel
+
+
 def build_hip(force: bool = False) -> str:
-    src = [os.path.join(CSRC, "qgtc_hip.hip"), os.path.join(INC, "qgtc.h")]
+    units = [os.path.join(CSRC, u) for u in HIP_UNITS]
+    src = units + [os.path.join(INC, "qgtc.h")]
     src += sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip.h"))
     if not force and _newer(HIP_LIB, src):
         return HIP_LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-          "-Wno-unused-value", f"-I{INC}", "-o", HIP_LIB, src[0]])
+    objs, procs = [], []
+    for u in units:
+        obj = os.path.join(PKG, os.path.basename(u) + ".o")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Wno-unused-value", f"-I{INC}", "-o", obj, u]
+        print("[qgtc build]", " ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    _run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", HIP_LIB] + objs)
+    for o in objs:
+        os.remove(o)
     return HIP_LIB
 
 

@@ -3,9 +3,12 @@
 // quantiser and the 8-lane DPP OR used by every packer.
 #pragma once
 
+extern thread_local char qgtc_g_hip_err[256];   // text of the last HIP error of this thread (qgtc_last_hip_error)
+
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int TM = 32, TN = 32;  // workgroup tile of the bit-GEMM
 
 // ------------------------------------------------------------------------------------------
@@ -16,10 +19,10 @@ __host__ __device__ constexpr int step128(int x) { return (x + 127) >> 7; }
 __host__ __device__ constexpr int pad8(int x) { return step8(x) << 3; }
 __host__ __device__ constexpr int pad128(int x) { return step128(x) << 7; }
 
-thread_local char g_hip_err[256] = "";
+// (one buffer for the whole library: defined in qgtc_hip.hip, declared before this namespace opens)
 
 int hip_fail(hipError_t e, const char *where) {
-    snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", where, hipGetErrorString(e));
+    snprintf(qgtc_g_hip_err, sizeof(qgtc_g_hip_err), "%s: %s", where, hipGetErrorString(e));
     return QGTC_EHIP;
 }
 #define HIP_TRY(expr)                                        \

@@ -12,7 +12,6 @@ namespace {
 // the A rows and B lines straight into MFMA fragments, 16 B per lane per load) and are summed
 // through LDS. Out-of-range rows / columns read as zero through buffer range checks.
 // ------------------------------------------------------------------------------------------
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int I8_TM = 16, I8_TN = 64, I8_WAVES = 8;
 
 __global__ __launch_bounds__(64 * I8_WAVES) void k_i8gemm(const int8_t *__restrict__ A,

@@ -1,0 +1,97 @@
+// launch_common.hip.h — part of libqgtc_hip.so: what the translation units (qgtc_hip.hip, qgtc_mfma.hip, qgtc_fp4.hip) need on the
+// host side: launch-constant helpers, the predicates that choose a kernel family, and the launchers of the
+// matrix-core kernels, which live in their own translation units (all compiled in parallel).
+#pragma once
+
+// defined in qgtc_mfma.hip
+int qgtc_launch_mfma(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st);
+int qgtc_launch_mfma_batched(const qgtc_problem *prs, int count, int max_M, int max_K, int max_N, int a, int w,
+                             int ob, int mode, hipStream_t st);
+// defined in qgtc_fp4.hip
+int qgtc_launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, bool zero_skip, hipStream_t st);
+int qgtc_launch_fp4_wave(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode,
+                         bool zero_skip, hipStream_t st);
+
+namespace {
+
+inline MMShape base_shape(int a, int w, int ob, int mode) {
+    MMShape sh{};
+    sh.a = a;
+    sh.w = w;
+    sh.ob = ob;
+    sh.mode = mode;
+    sh.ab = a;
+    sh.wb = w;
+    sh.maxv = std::ldexp(1.0f, ob);
+    sh.maxm1 = sh.maxv - 1.0f;
+    sh.nowrap = 0;
+    return sh;
+}
+
+// no int32 accumulator of a product with this K can wrap (then requantisation needs no sign test)
+inline int no_wrap(int K, int a, int w) {
+    if (a > 16 || w > 16) return 0;
+    return static_cast<double>(K) * ((1u << a) - 1u) * ((1u << w) - 1u) < 2147483648.0;
+}
+
+// the FP4 form of the matrix-core engine: 2-bit values at most and float32 sums that stay exact
+inline bool fp4_ok(int K, int a, int w) {
+    return a <= 2 && w <= 2 && static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
+}
+
+// narrow right operands: the LDS-free FP4 kernel (bitmm_fp4_skinny.hip.h). Measured at 4096 x 4096 x N: ahead of
+// both other kernels up to N = 256 (N = 128: 5.4 us against 7.0 popcount / 15.5 128-tile MFMA at 1 bit, 16.6 against
+// 40 / 46 at 8 bits), level with the 128-tile kernel at N = 512, behind it at N = 1024
+// (plane capacities 1 / 2 for X and 1 / 2 / 4 / 8 for W are instantiated; float32 sums must stay exact)
+inline bool skinny_ok(int K, int N, int a, int w) {
+    return N <= 256 && a <= 2 && w <= 8 &&
+           static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
+}
+// QGTC_ENGINE_AUTO: measured against the popcount kernels on the reference's micro-benchmark shapes
+// (1024 / 2048 / 4096 square, N = 16 / 32 / 64, 1- and 2-bit): ahead on all of them (4096 x 4096 x 64:
+// 4.1 us against 4.8 at 1 bit, 5.8 against 7.0 at 2 bits); tiny problems stay where they were.
+inline bool auto_prefers_skinny(int M, int K, int N, int a, int w) {
+    (void)N; (void)a; (void)w;
+    return M >= 512 && K >= 512;
+}
+
+// grouped launches on the matrix cores, one wave per 32 x 32 tile (bitmm_fp4_wave.hip.h): for NARROW outputs.
+// Measured on the epochs (tools/epoch_stages.py): the class-count stages (N = 10) 7.1 / 10.9 us against 13.8 / 12.6
+// for the popcount kernels, ppi's 1 x 4-bit A-stages at N = 50 14.3 against 16.3 for the 128-tile kernel; at
+// N = 128 the 128-tile kernel is ahead (12 / 18.5 us against 18 / 25), and 64 x 64 outputs per wave are worse
+// still (24 / 41 us: 2850 waves do not fill the chip).
+inline bool fp4_wave_ok(int K, int N, int a, int w) {
+    return N <= 64 && a <= 2 && w <= 8 && static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
+}
+
+// the MFMA engine handles up to 8 planes per operand (8: offset by 128, corrected in the epilogue)
+inline bool mfma_ok(int a, int w) { return a >= 1 && a <= 8 && w >= 1 && w <= 8; }
+
+// QGTC_ENGINE_AUTO: pick the engine by a two-line cost model fitted to the round-1 measurements
+// (DESIGN.md section 5.4b): popcount runs at ~0.95e15 bit-ops/s plus ~3 us of launch and tail; the
+// matrix-core engine pays ~6 us fixed and ~0.46 us per k-quad and 128 x 128 tile round (a quarter
+// more per extra plane to expand), rounds = tiles / 256 CUs. MFMA only when it wins by 10 %.
+inline bool auto_prefers_mfma(int M, int K, int N, int a, int w) {
+    if (!mfma_ok(a, w)) return false;
+    const double tiles = static_cast<double>((M + 128 - 1) / 128) * ((N + 128 - 1) / 128);
+    const double rounds = tiles <= 256.0 ? 1.0 : tiles / 256.0 * 0.9;
+    const int maxp = a > w ? a : w;
+    // per k-quad and round: 0.32 us in the FP4 form (2-bit values at most), else 0.46 us plus 15 % per extra plane
+    const double per_kq = fp4_ok(K, a, w) ? 0.32 * (1.0 + 0.25 * (maxp - 1)) : 0.46 * (1.0 + 0.15 * (maxp - 1));
+    const double t_mfma = 6.0 + per_kq * step128(K) * rounds;
+    const double t_pop = 3.0 + 2.0 * M * static_cast<double>(K) * N * a * w / 0.95e15 * 1e6;
+    return t_mfma < 0.9 * t_pop;
+}
+
+// QGTC_ENGINE_AUTO for grouped launches (cluster batches: many small products, every workgroup short-
+// lived). Measured on the ogbn-arxiv- and ppi-sized epochs: the matrix-core
+// engine wins when its 128-wide tile is mostly full (N = 128: X.W 13 us against 24, A.(XW) 22
+// against 27) or when four or more plane pairs share one expansion at N >= 48 (ppi: 4 x 4 bits at
+// N = 64 14 against 22, 1 x 4 bits at N = 50 18.6 against 20.8); narrow outputs (N = 10 classes)
+// and one- or two-pair products at N <= 64 stay on the popcount kernels.
+inline bool auto_prefers_mfma_batched(int max_M, int max_N, int a, int w) {
+    if (!mfma_ok(a, w) || max_M < 128) return false;
+    return max_N >= 96 || (a * w >= 4 && max_N >= 48);
+}
+
+}  // namespace

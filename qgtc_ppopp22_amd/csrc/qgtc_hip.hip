@@ -19,7 +19,10 @@
 //   bitmm_mfma.hip.h         the bit-GEMM on the matrix cores (opt-in engine), 128 x 128 tiles
 //   bitmm_fp4_skinny.hip.h   the same for narrow right operands (N <= 256): no LDS staging
 //   bitmm_fp4_wave.hip.h     the same for grouped launches over cluster batches: one wave per 32 x 32 tile
+//   launch_common.hip.h      launch constants, kernel-family predicates (shared with qgtc_fp4.hip)
 //   launch.hip.h             split-K plan, kernel selection, launchers
+//   qgtc_mfma.hip            second translation unit: the 128 x 128-tile matrix-core engine and its launchers
+//   qgtc_fp4.hip             third translation unit: the FP4 narrow-operand kernels and their launchers
 //   qgtc_hip.hip             the C-ABI of include/qgtc.h (this file)
 // Design notes live in DESIGN.md.
 #include <hip/hip_runtime.h>
@@ -38,9 +41,16 @@
 #include "tile_stats_kernels.hip.h"
 #include "bitmm_popcount.hip.h"
 #include "bitmm_mfma.hip.h"
+#include "launch_common.hip.h"
+#ifdef QGTC_SINGLE_TU   // tools/kbench.hip: everything in one translation unit
 #include "bitmm_fp4_skinny.hip.h"
 #include "bitmm_fp4_wave.hip.h"
+#include "launch_fp4.hip.h"
+#include "launch_mfma.hip.h"
+#endif
 #include "launch.hip.h"
+
+thread_local char qgtc_g_hip_err[256] = "";
 
 // ============================================================================================
 // C-ABI
@@ -61,7 +71,7 @@ const char *qgtc_strerror(int code) {
     }
 }
 
-const char *qgtc_last_hip_error(void) { return g_hip_err; }
+const char *qgtc_last_hip_error(void) { return qgtc_g_hip_err; }
 
 size_t qgtc_rows_words(int H, int W, int nbits) {
     return static_cast<size_t>(nbits) * pad8(H) * step128(W) * 4u;
@@ -141,9 +151,9 @@ int qgtc_bitmm2bit(const uint32_t *X, size_t x_words, const uint32_t *W, size_t 
     qgtc_problem pr{X, W, out, x_words, w_words, M, K, N, pad128(N), 0, nullptr};
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!cols && skinny_ok(K, N, bit1, bit2) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_skinny(M, K, N, bit1, bit2))))
-        return launch_skinny(pr, bit1, bit2, output_bit, 0, !(flags & QGTC_NO_ZERO_SKIP), st);
+        return qgtc_launch_skinny(pr, bit1, bit2, output_bit, 0, !(flags & QGTC_NO_ZERO_SKIP), st);
     if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma(M, K, N, bit1, bit2)))
-        return launch_mfma(pr, bit1, bit2, output_bit, cols ? 1 : 0, st);
+        return qgtc_launch_mfma(pr, bit1, bit2, output_bit, cols ? 1 : 0, st);
     if (flags & QGTC_NO_ZERO_SKIP)
         return dispatch_single<false>(pr, K, bit1, bit2, output_bit, cols ? 1 : 0, st);
     return dispatch_single<true>(pr, K, bit1, bit2, output_bit, cols ? 1 : 0, st);
@@ -159,9 +169,9 @@ int qgtc_bitmm2int(const uint32_t *X, size_t x_words, const uint32_t *W, size_t 
     qgtc_problem pr{X, W, out, x_words, w_words, M, K, N, pad_128 ? pad128(N) : pad8(N), 0, nullptr};
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (skinny_ok(K, N, bit1, bit2) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_skinny(M, K, N, bit1, bit2))))
-        return launch_skinny(pr, bit1, bit2, 1, 2, !(flags & QGTC_NO_ZERO_SKIP), st);
+        return qgtc_launch_skinny(pr, bit1, bit2, 1, 2, !(flags & QGTC_NO_ZERO_SKIP), st);
     if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma(M, K, N, bit1, bit2)))
-        return launch_mfma(pr, bit1, bit2, 1, 2, st);
+        return qgtc_launch_mfma(pr, bit1, bit2, 1, 2, st);
     if (flags & QGTC_NO_ZERO_SKIP) return dispatch_single<false>(pr, K, bit1, bit2, 1, 2, st);
     return dispatch_single<true>(pr, K, bit1, bit2, 1, 2, st);
 }
@@ -225,10 +235,10 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
     const int k_hint = max_K;
     const int ob_ = mode == 2 ? 1 : output_bit;
     if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && fp4_wave_ok(max_K, max_N, bit1, bit2))   // narrow outputs: one wave per 32 x 32 tile
-        return launch_fp4_wave(problems, count, max_M, max_N, bit1, bit2, ob_, mode, !(flags & QGTC_NO_ZERO_SKIP), st);
+        return qgtc_launch_fp4_wave(problems, count, max_M, max_N, bit1, bit2, ob_, mode, !(flags & QGTC_NO_ZERO_SKIP), st);
     if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) ||  // problems with a one-word bitmap jump zero tiles
         ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma_batched(max_M, max_N, bit1, bit2)))
-        return launch_mfma_batched(problems, count, max_M, max_K, max_N, bit1, bit2, ob_, mode, st);
+        return qgtc_launch_mfma_batched(problems, count, max_M, max_K, max_N, bit1, bit2, ob_, mode, st);
     if (flags & QGTC_NO_ZERO_SKIP)
         return dispatch_batched<false, false>(problems, count, max_M, max_N, k_hint, bit1, bit2, ob_, mode, st);
     if (flags & QGTC_ZERO_JUMP)  // the descriptors carry occupancy bitmaps (qgtc_tile_occupancy)

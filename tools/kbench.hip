@@ -5,6 +5,7 @@
 //        GROUPED=count (count copies of the problem in one grouped launch; X gets dense 64 x 64
 //        diagonal blocks + `density` elsewhere, like a cluster batch), JUMP=1 (with occupancy bitmaps),
 //        MODE=0|1|2 (grouped only: rows bits, cols bits, float)
+#define QGTC_SINGLE_TU 1   // pull the second translation unit (FP4 narrow-operand kernels) into this one
 #include "../qgtc_ppopp22_amd/csrc/qgtc_hip.hip"
 
 #include <cstdlib>
