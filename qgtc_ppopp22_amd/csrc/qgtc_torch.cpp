@@ -540,6 +540,12 @@ struct BatchedGemm {
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "QGTC bit-GEMM operators for AMD Instinct MI355X (gfx950); drop-in for the reference's QGTC extension";
     namespace py = pybind11;
+    // QGTC_ENGINE=popcount|mfma|auto picks the engine unmodified callers start with (set_engine() still overrides)
+    if (const char *e = std::getenv("QGTC_ENGINE")) {
+        const std::string name(e);
+        TORCH_CHECK(name == "popcount" || name == "mfma" || name == "auto", "QGTC_ENGINE must be 'popcount', 'mfma' or 'auto'");
+        g_engine = name == "mfma" ? 1 : (name == "auto" ? 2 : 0);
+    }
     // The eight reference entry points (QGTC_host.cpp:259-271). Positional call forms are
     // unchanged; the trailing bools get the C++ defaults of QGTC_host.cpp:6-7,15-16,60 so that
     // unitest.py's 7-argument bitMM2Int calls (unitest.py:72,79,143,146) also work.

@@ -74,3 +74,19 @@ def test_extension_imports_and_keeps_the_reference_surface():
     import QGTC  # the reference's module name
 
     assert QGTC.bitMM2Bit is ext.bitMM2Bit
+
+
+def test_engine_env_default():
+    """QGTC_ENGINE sets the engine unmodified callers start with (the extension imports without a GPU)."""
+    import subprocess
+    import sys
+
+    code = "import QGTC; print(QGTC.get_engine())"
+    for env_val, want in ((None, "popcount"), ("auto", "auto"), ("mfma", "mfma")):
+        env = dict(os.environ)
+        env.pop("QGTC_ENGINE", None)
+        if env_val:
+            env["QGTC_ENGINE"] = env_val
+        out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-500:]
+        assert out.stdout.strip().splitlines()[-1] == want
