@@ -21,7 +21,7 @@ namespace {
 // through LDS once (float32 adds of exact integers). 4096 x 4096 x 64: 256 workgroups, one super-step = 16 MFMAs
 // per wave, two waves per SIMD.
 // All-zero (tile rows) x 512-bit X tiles are skipped with one ballot.
-// Rows-layout bits (mode 0) and float32 (mode 2) only (the cols layout keeps the other kernels).
+// All three output forms; cols-layout bits (mode 1) always on 32 x 32 tiles (a word is 32 rows of a column).
 //
 // More than two planes: an operand is taken two planes at a time - base-4 "digits", each again the codes 0..3 -
 // and digit d is multiplied with the E8M0 scale 2 * 4^d, so sum_d 4^d (X . W_d) accumulates in the same float32
@@ -153,6 +153,62 @@ __global__ __launch_bounds__(64 * SK_WAVES) void k_bitmm_fp4_skinny(qgtc_problem
 
     SK_STAMP(3);
     // ---- reduce the waves' partial tiles. MFMA 16 x 16 C/D layout: col = lane & 15, row = 4 (lane >> 4) + reg
+    if (MODE == 1) {
+        // cols layout: a word is 32 ROWS of a column - the tile (32 x 32, always) is kept transposed in LDS, so that
+        // an epilogue thread reads four consecutive rows of its column with one 16-byte read
+        static_assert(MODE != 1 || (RF == 2 && CF == 2), "cols-layout words need whole 32-row tiles");
+#pragma unroll
+        for (int i = 0; i < RF; i++)
+#pragma unroll
+            for (int j = 0; j < CF; j++) *reinterpret_cast<f32x4 *>(&part[wv][16 * j + li][16 * i + 4 * g]) = acc[i][j];
+        __syncthreads();
+        if (tid >= 256) return;
+        const int col = tid >> 3, rq = tid & 7;   // column of the tile, rows 4 rq .. 4 rq + 3
+        f32x4 sum1 = *reinterpret_cast<const f32x4 *>(&part[0][col][4 * rq]);
+#pragma unroll
+        for (int v = 1; v < SK_WAVES; v++) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(&part[v][col][4 * rq]);
+            sum1 += t;
+        }
+        const int maxi1 = 1 << (sh.ob & 31);
+        const bool int_rq1 = sh.ob <= 23;
+        uint32_t q1[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int c = static_cast<int>(sum1[e]);   // exact: the sums are integers below 2^24
+            const int r = int_rq1 ? (c > maxi1 ? maxi1 - 1 : c) : requant(c, sh.maxv, sh.maxm1);
+            q1[e] = (m0 + 4 * rq + e < M && n0 + col < N) ? static_cast<uint32_t>(r) : 0u;
+        }
+        // cols layout [ob][PAD128(N)][STEP128(M)*4] (intended semantics of kernel.h:651-810): word (n, m / 32)
+        const int lines = pad128(N), line_words = step128(M) * 4;
+        const size_t oplane1 = static_cast<size_t>(lines) * line_words;
+        const int word1 = m0 >> 5, n1 = n0 + col;
+        uint32_t *out1 = static_cast<uint32_t *>(pr.out);
+        uint32_t *dst1 = out1 + static_cast<size_t>(n1) * line_words + word1;
+        for (int p = 0; p < sh.ob; p++, dst1 += oplane1) {
+            const uint32_t nib = (((q1[0] >> p) & 1u) << 3) | (((q1[1] >> p) & 1u) << 2) | (((q1[2] >> p) & 1u) << 1) | ((q1[3] >> p) & 1u);
+            const uint32_t wrd = or_reduce8(nib << (28u - 4u * static_cast<uint32_t>(rq)));   // row 4 rq + e at bit 31 - 4 rq - e
+            if (rq == 0 && n1 < lines && word1 < line_words) dst1[0] = wrd;
+        }
+        // zero what no tile computes: words past the last row tile, lines past the last column tile
+        const bool last_m = blockIdx.x == gridDim.x - 1, last_n = blockIdx.y == gridDim.y - 1;
+        const int w_core1 = min(line_words, word1 + 1);
+        if (last_m && w_core1 < line_words) {
+            for (int e = tid; e < sh.ob * 32; e += 256) {
+                const int line = n0 + (e & 31), p = e >> 5;
+                if (line < lines)
+                    for (int wi = w_core1; wi < line_words; wi++) out1[p * oplane1 + static_cast<size_t>(line) * line_words + wi] = 0u;
+            }
+        }
+        if (last_n && n0 + 32 < lines) {
+            const int nl = lines - (n0 + 32), w_end = last_m ? line_words : w_core1;
+            for (int e = tid; e < sh.ob * nl; e += 256) {
+                const int line = n0 + 32 + e % nl, p = e / nl;
+                for (int wi = word1; wi < w_end; wi++) out1[p * oplane1 + static_cast<size_t>(line) * line_words + wi] = 0u;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < RF; i++)
 #pragma unroll

@@ -5,12 +5,14 @@ int qgtc_launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, b
     MMShape sh = base_shape(a, w, ob, mode);
     sh.nowrap = 1;
     const int zs = zero_skip ? 1 : 0;
-    const bool wide = pr.N > 32;   // 32 x 32 tiles (two column tiles at N = 64), else 16 x 32
+    const bool wide = pr.N > 32 || mode == 1;   // 32 x 32 tiles (two column tiles at N = 64), else 16 x 32
     const dim3 grid(wide ? (pr.M + 31) / 32 : (pr.M + 15) / 16, (pr.N + 31) / 32);
 #define QGTC_SK_LAUNCH(NA_, NW_)                                                                                   \
     if (!done && a <= NA_ && w <= NW_) {                                                                           \
         done = true;                                                                                               \
-        if (mode == 2) {                                                                                           \
+        if (mode == 1) {                                                                                           \
+            hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 1, 2, 2>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh, zs);            \
+        } else if (mode == 2) {                                                                                    \
             if (wide) hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 2, 2, 2>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh, zs);  \
             else hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 2, 1, 2>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh, zs);       \
         } else {                                                                                                   \

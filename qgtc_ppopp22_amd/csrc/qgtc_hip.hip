@@ -150,8 +150,8 @@ int qgtc_bitmm2bit(const uint32_t *X, size_t x_words, const uint32_t *W, size_t 
     if (out_words < need) return QGTC_ESIZE;
     qgtc_problem pr{X, W, out, x_words, w_words, M, K, N, pad128(N), 0, nullptr};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!cols && skinny_ok(K, N, bit1, bit2) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_skinny(M, K, N, bit1, bit2))))
-        return qgtc_launch_skinny(pr, bit1, bit2, output_bit, 0, !(flags & QGTC_NO_ZERO_SKIP), st);
+    if (skinny_ok(K, N, bit1, bit2) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_skinny(M, K, N, bit1, bit2))))
+        return qgtc_launch_skinny(pr, bit1, bit2, output_bit, cols ? 1 : 0, !(flags & QGTC_NO_ZERO_SKIP), st);
     if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma(M, K, N, bit1, bit2)))
         return qgtc_launch_mfma(pr, bit1, bit2, output_bit, cols ? 1 : 0, st);
     if (flags & QGTC_NO_ZERO_SKIP)

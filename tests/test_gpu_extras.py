@@ -334,6 +334,8 @@ def test_fp4_narrow_kernels_sweep(qgtc, oracle):
                 qgtc.set_zero_skip(zs)
                 try:
                     np.testing.assert_array_equal(to_np_u32(qgtc.bitMM2Bit(dX, dW, M, K, N, a, w, ob)), want_b, err_msg=tag)
+                    np.testing.assert_array_equal(to_np_u32(qgtc.bitMM2Bit_col(dX, dW, M, K, N, a, w, ob)),
+                                                  oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob, col=True), err_msg=tag + " cols")
                     np.testing.assert_array_equal(qgtc.bitMM2Int(dX, dW, M, K, N, a, w, True).cpu().numpy(), want_f, err_msg=tag)
                 finally:
                     qgtc.set_zero_skip(True)
