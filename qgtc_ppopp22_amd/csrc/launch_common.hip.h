@@ -49,10 +49,12 @@ inline bool skinny_ok(int K, int N, int a, int w) {
 }
 // QGTC_ENGINE_AUTO: measured against the popcount kernels on the reference's micro-benchmark shapes
 // (1024 / 2048 / 4096 square, N = 16 / 32 / 64, 1- and 2-bit): ahead on all of them (4096 x 4096 x 64:
-// 4.1 us against 4.8 at 1 bit, 5.8 against 7.0 at 2 bits); tiny problems stay where they were.
+// 4.0 us against 4.8 at 1 bit, 4.8 against 7.1 at 2 bits)
 inline bool auto_prefers_skinny(int M, int K, int N, int a, int w) {
-    (void)N; (void)a; (void)w;
-    return M >= 512 && K >= 512;
+    // ... and on every smaller single launch tried since (1213 x 128 x 128 2-bit 3.5 against 4.2 us, 300 x 300 x 64
+    // 3.3 against 4.4, 256 x 4096 x 64 3.9 against 4.6): whenever skinny_ok holds
+    (void)M; (void)K; (void)N; (void)a; (void)w;
+    return true;
 }
 
 // grouped launches on the matrix cores, one wave per 32 x 32 tile (bitmm_fp4_wave.hip.h): for NARROW outputs.
