@@ -164,3 +164,28 @@ def test_wide_product_both_engines_and_checksum(qgtc, a, w, ob):
     assert torch.equal(pop[0], mf[0]) and torch.equal(pop[1], mf[1])
     row = (qa.to(torch.float64) @ qx.to(torch.float64).sum(1)).to(torch.int64)
     assert torch.equal(mf[1].to(torch.int64).sum(1), row)
+
+
+@pytest.mark.parametrize("NW_,w", [(128, 1), (256, 2), (200, 8)])
+def test_mid_width_products_all_engines_and_checksum(qgtc, NW_, w):
+    """4096 x 4096 x {128, 256, 200}: the width range where `auto` uses the narrow-operand FP4 kernel with several
+    column tiles per row tile. Engines agree word for word (rows bits, cols bits, float32) and the integer product
+    satisfies the row checksum C 1 = A (X 1), computed with torch reductions that share no code with the kernels."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(90 + NW_ + w)
+    qa = (torch.rand((M, K), generator=g) < 0.3).to(torch.float32).cuda()
+    qx = torch.randint(0, 2 ** w, (K, NW_), generator=g).to(torch.float32).cuda()
+    bit_A, bit_X = qgtc.val2bit(qa, 1, False, False), qgtc.val2bit(qx, w, True, False)
+    ref = (qgtc.bitMM2Bit(bit_A, bit_X, M, K, NW_, 1, w, w), qgtc.bitMM2Bit_col(bit_A, bit_X, M, K, NW_, 1, w, w),
+           qgtc.bitMM2Int(bit_A, bit_X, M, K, NW_, 1, w, True))
+    for eng in ("mfma", "auto"):
+        qgtc.set_engine(eng)
+        try:
+            got = (qgtc.bitMM2Bit(bit_A, bit_X, M, K, NW_, 1, w, w), qgtc.bitMM2Bit_col(bit_A, bit_X, M, K, NW_, 1, w, w),
+                   qgtc.bitMM2Int(bit_A, bit_X, M, K, NW_, 1, w, True))
+        finally:
+            qgtc.set_engine("popcount")
+        for x, y in zip(got, ref):
+            assert torch.equal(x, y), eng
+    row = (qa.to(torch.float64) @ qx.to(torch.float64).sum(1)).to(torch.int64)
+    assert torch.equal(ref[2].to(torch.int64).sum(1), row)
