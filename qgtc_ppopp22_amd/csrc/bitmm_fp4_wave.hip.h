@@ -17,7 +17,7 @@ namespace {
 //                 half-wave swaps (v_permlane16_swap, v_permlane32_swap);
 //   float32     : 16 consecutive columns per store.
 // With an occupancy bitmap (qgtc_tile_occupancy: one bit per 32-row tile and k-quad) super-steps whose four
-// k-quads are all empty are neither loaded nor multiplied. Needs a <= 2, w <= 8, float32 sums exact
+// k-quads are all empty are neither loaded nor multiplied. Needs a <= 4, w <= 8, float32 sums exact
 // (K (2^a - 1)(2^w - 1) < 2^24).
 // ------------------------------------------------------------------------------------------
 // RF x CF fragments of 16 lines per wave (2 x 2 = 32 x 32 outputs is what is launched; 4 x 4 was measured: with

@@ -63,7 +63,7 @@ inline bool auto_prefers_skinny(int M, int K, int N, int a, int w) {
 // N = 128 the 128-tile kernel is ahead (12 / 18.5 us against 18 / 25), and 64 x 64 outputs per wave are worse
 // still (24 / 41 us: 2850 waves do not fill the chip).
 inline bool fp4_wave_ok(int K, int N, int a, int w) {
-    return N <= 64 && a <= 2 && w <= 8 && static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
+    return N <= 64 && a <= 4 && w <= 8 && static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
 }
 
 // the MFMA engine handles up to 8 planes per operand (8: offset by 128, corrected in the epilogue)

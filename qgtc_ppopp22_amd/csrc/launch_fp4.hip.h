@@ -44,6 +44,7 @@ int qgtc_launch_fp4_wave(const qgtc_problem *prs, int count, int max_M, int max_
     bool done = false;
     QGTC_FW_LAUNCH(1, 1) QGTC_FW_LAUNCH(1, 2) QGTC_FW_LAUNCH(1, 4) QGTC_FW_LAUNCH(1, 8)
     QGTC_FW_LAUNCH(2, 1) QGTC_FW_LAUNCH(2, 2) QGTC_FW_LAUNCH(2, 4) QGTC_FW_LAUNCH(2, 8)
+    QGTC_FW_LAUNCH(4, 4) QGTC_FW_LAUNCH(4, 8)   // ppi's 4 x 4-bit X.W stages
 #undef QGTC_FW_LAUNCH
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
