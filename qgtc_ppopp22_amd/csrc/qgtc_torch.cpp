@@ -16,6 +16,7 @@
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 
+#include <atomic>
 #include <cstdio>
 #include <vector>
 
@@ -55,8 +56,11 @@ void check_bits_tensor(const torch::Tensor &t, const char *name) {
     TORCH_CHECK(t.scalar_type() == torch::kInt32, name, " must be an int32 bit tensor");
 }
 
-bool g_zero_skip = true;
-int g_engine = 0;  // 0 popcount (default), 1 mfma (wherever the plane counts allow it), 2 auto (cost model)
+// Process-wide switches of the binding (the reference's callers are single-threaded and hold the GIL for the whole
+// call, QGTC_host.cpp; the C-ABI itself is stateless - every call carries its flags). std::atomic: a second Python
+// thread may flip them, a launch then simply sees the old or the new value.
+std::atomic<bool> g_zero_skip{true};
+std::atomic<int> g_engine{0};  // 0 popcount (default), 1 mfma (wherever the plane counts allow it), 2 auto (measured rules)
 unsigned mm_flags() {
     return (g_zero_skip ? 0u : QGTC_NO_ZERO_SKIP) | (g_engine == 1 ? QGTC_ENGINE_MFMA : 0u) |
            (g_engine == 2 ? QGTC_ENGINE_AUTO : 0u);
@@ -604,7 +608,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
        "expanded to int8 on the fly, v_mfma_i32_32x32x32_i8; bit widths <= 8, else popcount) or 'auto' (a cost "
        "model picks per call). Same results.");
     m.def("get_engine", [] { return std::string(g_engine == 1 ? "mfma" : (g_engine == 2 ? "auto" : "popcount")); });
-    m.def("get_zero_skip", [] { return g_zero_skip; });
+    m.def("get_zero_skip", [] { return g_zero_skip.load(); });
     m.def("abi_version", [] { return qgtc_abi_version(); });
 
     m.def("pack_edges", &pack_edges, "rows-layout bit planes of the [height, width] adjacency of an edge list "
