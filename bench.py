@@ -50,11 +50,33 @@ def parse():
                    help="issue the steps round-robin on this many HIP streams (independent launches overlap); "
                         "default 1 = the reference's metric, launches back to back on one stream")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget")
+    p.add_argument("--backend", choices=["nccl", "gloo"], default=None, help="torch.distributed backend (default: nccl = RCCL)")
+    p.add_argument("--dry-run", action="store_true", help="exercise the rank launcher and the collectives only (no GPU)")
     p.add_argument("--engine", choices=["popcount", "mfma", "auto"], default="auto",
                    help="engine of the headline launches (same words either way): popcount = AND + v_bcnt kernels, "
                         "auto = the library's choice per call (at this shape the FP4 matrix-core kernel for narrow "
                         "right operands); the other engine's figure is reported in extras")
     return p.parse_args()
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def engine(Q, name):
+    """Run a block on one engine of the library ("auto" is the shipped default) and put the previous one back."""
+    prev = Q.get_engine()
+    Q.set_engine(name)
+    try:
+        yield
+    finally:
+        Q.set_engine(prev)
+
+
+def best_of_3(Q, ba, bx, M, K, N, w, reps=200):
+    """The reference's measurement (QGTC_device.cu:403-422): `reps` launches between two events; best of three."""
+    Q.profile(ba, bx, M, K, N, 1, w, w, max(reps // 10, 1))
+    return min(Q.profile(ba, bx, M, K, N, 1, w, w, reps) for _ in range(3))
 
 
 def make_workload(Q, M, K, N, w, device, seed, ones=False):
@@ -135,7 +157,7 @@ def epoch_leg(Q, rank, world, device_index, dataset="ogbn-arxiv", bits=2, hidden
     res = {}
     legs = [("per_batch_reference_chain", []), ("batched_reference_chain", ["--batched"]),
             ("batched_correct_chain", ["--batched", "--chain", "correct"]),
-            ("batched_correct_chain_engine_auto", ["--batched", "--chain", "correct", "--engine", "auto"])]
+            ("batched_correct_chain_engine_popcount", ["--batched", "--chain", "correct", "--engine", "popcount"])]
     if full:
         legs[1:1] = [("per_batch_nonresident_reference_chain", ["--non-resident"]),
                      ("per_batch_graph_reference_chain", ["--graph"]),
@@ -177,17 +199,11 @@ def adj_size_table(Q, device):
         row = {}
         for mi, mk in enumerate((1024, 2048, 4096)):
             _, _, ba, bx = make_workload(Q, mk, mk, nn, 1, device, seed=3, ones=True)
-            Q.profile(ba, bx, mk, mk, nn, 1, 1, 1, 20)
-            ms = min(Q.profile(ba, bx, mk, mk, nn, 1, 1, 1, 200) for _ in range(3))
-            row[f"M{mk}"] = {"TOPS": round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2), "ref_sm86": ref[mi]}
-            if True:        # set_engine("auto"): the matrix cores (FP4 kernels: no LDS staging up to N = 256, 128 x 128 tiles above)
-                Q.set_engine("auto")
-                try:
-                    Q.profile(ba, bx, mk, mk, nn, 1, 1, 1, 20)
-                    ms = min(Q.profile(ba, bx, mk, mk, nn, 1, 1, 1, 200) for _ in range(3))
-                finally:
-                    Q.set_engine("popcount")
-                row[f"M{mk}"]["TOPS_engine_auto"] = round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2)
+            row[f"M{mk}"] = {"ref_sm86": ref[mi]}
+            for eng, key in (("auto", "TOPS"), ("popcount", "TOPS_engine_popcount")):
+                with engine(Q, eng):
+                    ms = best_of_3(Q, ba, bx, mk, mk, nn, 1)
+                row[f"M{mk}"][key] = round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2)
         out[f"N{nn}"] = row
     return out
 
@@ -200,28 +216,94 @@ def micro_bench_table(Q, device):
         row = {}
         for wi, ww in enumerate((1, 2, 4, 8)):
             _, _, ba, bx = make_workload(Q, mk, mk, nn, ww, device, seed=3, ones=True)
-            Q.profile(ba, bx, mk, mk, nn, 1, ww, ww, 20)
-            ms = min(Q.profile(ba, bx, mk, mk, nn, 1, ww, ww, 200) for _ in range(3))
-            row[f"w{ww}"] = {"TOPS": round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2), "ref_sm86": ref[wi]}
-            if True:      # set_engine("auto"): the FP4 matrix-core kernel for narrow right operands
-                Q.set_engine("auto")
-                try:
-                    Q.profile(ba, bx, mk, mk, nn, 1, ww, ww, 20)
-                    ms = min(Q.profile(ba, bx, mk, mk, nn, 1, ww, ww, 200) for _ in range(3))
-                finally:
-                    Q.set_engine("popcount")
-                row[f"w{ww}"]["TOPS_engine_auto"] = round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2)
+            row[f"w{ww}"] = {"ref_sm86": ref[wi]}
+            for eng, key in (("auto", "TOPS"), ("popcount", "TOPS_engine_popcount")):
+                with engine(Q, eng):
+                    ms = best_of_3(Q, ba, bx, mk, mk, nn, ww)
+                row[f"w{ww}"][key] = round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2)
         out[f"{mk}x{mk}x{nn}"] = row
     return out
 
 
-def main():
-    args = parse()
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, the layout
+    torch.distributed.run would give them: all devices visible, LOCAL_RANK picks one) BEFORE this process makes any
+    GPU call, wait for them, and fail if any of them fails. Rank 0 prints the JSON line straight to our stdout."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    if not args.dry_run:
+        have = torch.cuda.device_count()       # counting devices does not initialise the GPU
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+            return 2
+    with socket.socket() as s:                 # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:      # one rank failed: the others would wait in a collective forever
+                    rc = code
+                    for q in pending:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def dry_run(args):
+    """Launcher / collective plumbing without a GPU (CPU tests: `--dry-run --backend gloo`): every rank takes part in
+    the same barrier, max-over-ranks and checksum gather as the real run and rank 0 prints the line's skeleton."""
     from qgtc_ppopp22_amd import dist as D
 
-    rank, world, local = D.init_from_env()
+    rank, world, local = D.init_from_env(backend=args.backend or "gloo")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("QGTC_BENCH_FAIL_RANK") == str(rank):   # test hook: a rank that dies before the collectives
+        sys.exit(3)
+    dev = torch.device("cpu")
+    D.barrier()
+    wall = D.max_over_ranks(0.001 * (rank + 1), dev)
+    csum = torch.tensor([[float(1000 + rank)]], dtype=torch.float64)
+    sums = D.gather_batch_summaries(csum, world, rank, world)
+    ids = D.shard_round_robin(75, rank, world)
+    counts = D.gather_batch_summaries(torch.tensor([[float(len(ids))]], dtype=torch.float64), world, rank, world)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "max_wall_s": wall, "extras": {"rank_checksums": [float(v) for v in sums.view(-1).tolist()],
+                                                         "batches_per_rank": [int(v) for v in counts.view(-1).tolist()]}}), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))           # (nothing above this line touches the GPU)
+    if args.dry_run:
+        return dry_run(args)
+    from qgtc_ppopp22_amd import dist as D
+
+    rank, world, local = D.init_from_env(backend=args.backend)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU (run `python bench.py --gpus N` " \
+                               "or torch.distributed.run with --nproc-per-node N)"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     import QGTC as Q
@@ -229,23 +311,18 @@ def main():
     M = K = 4096
     N, w = 64, args.bits
     A, X, bit_A, bit_X = make_workload(Q, M, K, N, w, device, seed=3 + rank)
-    out = Q.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w)   # popcount engine: the parity-pinned words
-    Q.set_engine(args.engine)
-    try:
+    with engine(Q, "popcount"):
+        out = Q.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w)   # AND + popcount kernels: the words every engine must produce
+    with engine(Q, args.engine):
         out_e = Q.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w)
         assert torch.equal(out_e, out), "engines disagree"
         wall, kern = time_steps(Q, out_e, bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams)
-    finally:
-        Q.set_engine("popcount")
     # the same headline launches on the other engine (identical words), measured back to back with the headline
     # (before the CPU baseline occupies every host core)
     other_engine, other_headline = ("popcount" if args.engine != "popcount" else "auto"), None
     if rank == 0 and world == 1 and not args.no_extras:
-        Q.set_engine(other_engine)
-        try:
+        with engine(Q, other_engine):
             o_wall, o_kern = time_steps(Q, torch.empty_like(out), bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams)
-        finally:
-            Q.set_engine("popcount")
         other_headline = {"TOPS": round(args.steps * 2.0 * M * K * N / o_wall / 1e12, 3), "us_per_launch": round(o_kern * 1e6, 3)}
     # what runs at this shape: the FP4 matrix-core kernel for narrow right operands (launch.hip.h: skinny_ok -
     # N <= 64, at most 2 x 8 planes, float32 sums exact: K (2^a - 1)(2^w - 1) < 2^24)
@@ -317,19 +394,13 @@ def main():
             for ww in (1, 2, 4, 8):
                 for label, ones in (("random", False), ("ones", True)):
                     _, _, ba, bx = make_workload(Q, M, K, N, ww, device, seed=3, ones=ones)
-                    Q.profile(ba, bx, M, K, N, 1, ww, ww, 20)
-                    ms = min(Q.profile(ba, bx, M, K, N, 1, ww, ww, 200) for _ in range(3))
-                    sweep[f"w{ww}_{label}"] = {"TOPS": round(eff_ops * 200 / (ms * 1e-3) / 1e12, 2),
-                                               "us_per_launch": round(ms * 1e3 / 200, 3),
-                                               "ref_sm86_TFLOPs": REF_TFLOPS_4096_64[ww]}
-                    if True:
-                        Q.set_engine("auto")
-                        try:
-                            Q.profile(ba, bx, M, K, N, 1, ww, ww, 20)
-                            ms = min(Q.profile(ba, bx, M, K, N, 1, ww, ww, 200) for _ in range(3))
-                        finally:
-                            Q.set_engine("popcount")
-                        sweep[f"w{ww}_{label}"]["TOPS_engine_auto"] = round(eff_ops * 200 / (ms * 1e-3) / 1e12, 2)
+                    sweep[f"w{ww}_{label}"] = {"ref_sm86_TFLOPs": REF_TFLOPS_4096_64[ww]}
+                    for eng, key in (("auto", "TOPS"), ("popcount", "TOPS_engine_popcount")):
+                        with engine(Q, eng):
+                            ms = best_of_3(Q, ba, bx, M, K, N, ww)
+                        sweep[f"w{ww}_{label}"][key] = round(eff_ops * 200 / (ms * 1e-3) / 1e12, 2)
+                        if eng == "auto":
+                            sweep[f"w{ww}_{label}"]["us_per_launch"] = round(ms * 1e3 / 200, 3)
             extras["width_sweep_4096x4096x64"] = sweep
             # Independent launches (different cluster batches in a serving loop) need not be serialised
             # by stream order: the same products issued round-robin on two HIP streams, each launch
@@ -338,7 +409,8 @@ def main():
             ovl = {}
             for ww in (1, 2, 4, 8):
                 _, _, ba, bx = make_workload(Q, M, K, N, ww, device, seed=3)
-                ref_out = Q.bitMM2Bit(ba, bx, M, K, N, 1, ww, ww)
+                with engine(Q, "popcount"):
+                    ref_out = Q.bitMM2Bit(ba, bx, M, K, N, 1, ww, ww)
                 outs2 = [torch.empty_like(ref_out) for _ in range(2)]
                 Q.bitMM2Bit_enqueue_streams(outs2, ba, bx, M, K, N, 1, ww, ww, 50)
                 torch.cuda.synchronize()
@@ -384,12 +456,14 @@ def main():
                     except Exception:   # noqa: BLE001 - optional leg
                         lib8 = None
                     _, _, ba, bx = make_workload(Q, mk, mk, nn, 1, device, seed=3)
-                    Q.profile(ba, bx, mk, mk, nn, 1, 1, 1, 20)
-                    ms1 = min(Q.profile(ba, bx, mk, mk, nn, 1, 1, 1, 200) for _ in range(3))
+                    with engine(Q, "popcount"):
+                        ms1 = best_of_3(Q, ba, bx, mk, mk, nn, 1)
+                    ms1a = best_of_3(Q, ba, bx, mk, mk, nn, 1)
                     ops = 2.0 * mk * mk * nn * 200
                     cmp9[f"{mk}x{mk}x{nn}"] = {"int8_mfma_TOPS": round(ops / (ms8 * 1e-3) / 1e12, 2),
                                               "int8_hipblaslt_TOPS": lib8,
                                               "bit1_popcount_TOPS": round(ops / (ms1 * 1e-3) / 1e12, 2),
+                                              "bit1_default_engine_TOPS": round(ops / (ms1a * 1e-3) / 1e12, 2),
                                               "ref_sm86_cublas_int8_TFLOPS": ref_cublas[(mk, nn)],
                                               "ref_sm86_qgtc_1bit_TFLOPs": ref_1bit[(mk, nn)]}
             extras["int8_mfma_vs_1bit_popcount_9_shapes"] = cmp9
@@ -404,16 +478,12 @@ def main():
                 _, _, ba, bx = make_workload(Q, mm, kk, nn, ww, device, seed=3)
                 row = {}
                 outs_e = {}
-                for name in ("popcount", "mfma"):
-                    Q.set_engine(name)
-                    try:
-                        Q.profile(ba, bx, mm, kk, nn, 1, ww, ww, 10)
-                        ms = min(Q.profile(ba, bx, mm, kk, nn, 1, ww, ww, 50) for _ in range(3))
+                for name in ("popcount", "mfma", "auto"):
+                    with engine(Q, name):
+                        ms = best_of_3(Q, ba, bx, mm, kk, nn, ww, reps=50)
                         outs_e[name] = Q.bitMM2Bit(ba, bx, mm, kk, nn, 1, ww, ww)
-                    finally:
-                        Q.set_engine("popcount")
                     row[name + "_TOPS"] = round(2.0 * mm * kk * nn * 50 / (ms * 1e-3) / 1e12, 1)
-                row["outputs_identical"] = bool(torch.equal(outs_e["popcount"], outs_e["mfma"]))
+                row["outputs_identical"] = bool(torch.equal(outs_e["popcount"], outs_e["mfma"]) and torch.equal(outs_e["popcount"], outs_e["auto"]))
                 eng[f"{mm}x{kk}x{nn}_w{ww}"] = row
             extras["mfma_engine_vs_popcount_wide_products"] = eng
         ep, graph = epoch_leg(Q, rank, world, local)

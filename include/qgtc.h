@@ -153,6 +153,11 @@ int qgtc_tile_occupancy_batched(qgtc_problem *problems, int count, int max_M, in
 int qgtc_tile_occupancy_decide(qgtc_problem *problems, int count, float max_fraction, uint64_t *stats,
                                void *stream);
 
+/* PRECONDITIONS the library cannot check (the descriptors live in device memory): max_M / max_K / max_N are at
+ * least every problem's M / K / N - the grid, the split-K plan and the choice between the float32 (FP4) and int32
+ * kernels are derived from them, so a larger problem than stated gets unwritten tiles or inexact sums; `occ` is
+ * NULL or a valid bitmap from qgtc_tile_occupancy* for the SAME X (the matrix-core kernels follow a non-NULL `occ`
+ * with or without QGTC_ZERO_JUMP). The PyTorch binding computes the maxima itself (BatchedGemm). */
 int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int max_K, int max_N,
                        int bit1, int bit2, int output_bit, int mode, unsigned flags,
                        void *stream);

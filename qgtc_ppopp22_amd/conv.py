@@ -45,19 +45,28 @@ class GCNConv_Qnt(torch.nn.Module):
         self.W_out = torch.nn.Parameter(torch.randn(hidden_dim, output_dim))
         self.w_bit = w_bit
         self.act_bit = act_bit
+        # edge-list adjacencies: True checks the indices on the device and reads the flag back (one host sync per
+        # forward); callers that build their own induced edge lists (sampler.ClusterIter) can switch it off
+        self.validate_edges = True
         self.bit_W_in = None
         self.bit_W_out = None
+        self._packed_from = None   # (device, version of W_in, version of W_out) the packed weights were made from
+
+    def _weights_key(self):
+        return (self.W_in.device, self.W_in._version, self.W_out._version, self.w_bit)
 
     def weight_Qnt(self):
-        """Pack the weights once (cols layout: they are right operands)."""
+        """Pack the weights (cols layout: they are right operands). forward() calls this again whenever the
+        parameters moved to another device or were modified in place (optimizer step, load_state_dict)."""
         self.bit_W_in = QGTC.val2bit(self.W_in.detach().contiguous(), self.w_bit, True, False)
         self.bit_W_out = QGTC.val2bit(self.W_out.detach().contiguous(), self.w_bit, True, False)
+        self._packed_from = self._weights_key()
 
     def A_Qnt(self, A):
         """A: dense float [n, n], or a (src, dst, n) edge list (packed without the dense detour)."""
         if isinstance(A, (tuple, list)):
             src, dst, n = A
-            return QGTC.pack_edges(src, dst, n, n, 1)
+            return QGTC.pack_edges(src, dst, n, n, 1, self.validate_edges)
         return QGTC.val2bit(A.contiguous(), 1, False, False)
 
     def X_Qnt(self, X):
@@ -65,8 +74,9 @@ class GCNConv_Qnt(torch.nn.Module):
 
     def forward(self, A, X):
         """X: node embeddings [n_nodes, n_dim]; A: the subgraph's adjacency (dense or edge list)."""
-        if self.bit_W_in is None:
+        if self.bit_W_in is None or self._packed_from != self._weights_key():
             self.weight_Qnt()
+        assert X.device == self.W_in.device, "inputs and weights must be on the same device"
         n = X.size(0)
         bit_A = self.A_Qnt(A)
         bit_X = self.X_Qnt(X)

@@ -35,12 +35,13 @@ inline void plan_split(int K, int planes, int qw, long total_tiles, Plan *pl) {
 template <int QW, int NA, int NW, bool ZS>
 int launch_single(const qgtc_problem &pr, const Plan &pl, hipStream_t st) {
     const int tiles_m = (pr.M + TM - 1) / TM, tiles_n = (pr.N + TN - 1) / TN;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr;
+    const int arc = attr.run([]() -> int {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm<QW, NA, NW, ZS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
-    }
+        return QGTC_OK;
+    });
+    if (arc != QGTC_OK) return arc;
     MMShape sh = pl.sh;
     sh.inv_tiles_n = tiles_n > 1 ? static_cast<uint32_t>((1ull << 32) / tiles_n) : 0xffffffffu;
     hipLaunchKernelGGL((k_bitmm<QW, NA, NW, ZS>), dim3(tiles_m * tiles_n), dim3(64 * pl.waves), pl.lds,
@@ -53,12 +54,13 @@ template <int QW, int NA, int NW, bool ZS, bool OCC>
 int launch_batched(const qgtc_problem *prs, int count, int max_M, int max_N, const Plan &pl,
                    hipStream_t st) {
     const int tiles = ((max_M + TM - 1) / TM) * ((max_N + TN - 1) / TN);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr;
+    const int arc = attr.run([]() -> int {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_batched<QW, NA, NW, ZS, OCC>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
-    }
+        return QGTC_OK;
+    });
+    if (arc != QGTC_OK) return arc;
     hipLaunchKernelGGL((k_bitmm_batched<QW, NA, NW, ZS, OCC>), dim3(tiles, count), dim3(64 * pl.waves),
                        pl.lds, st, prs, pl.sh);
     HIP_TRY(hipGetLastError());

@@ -3,6 +3,8 @@
 // matrix-core kernels, which live in their own translation units (all compiled in parallel).
 #pragma once
 
+#include <atomic>
+
 // defined in qgtc_mfma.hip
 int qgtc_launch_mfma(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st);
 int qgtc_launch_mfma_batched(const qgtc_problem *prs, int count, int max_M, int max_K, int max_N, int a, int w,
@@ -13,6 +15,24 @@ int qgtc_launch_fp4_wave(const qgtc_problem *prs, int count, int max_M, int max_
                          bool zero_skip, hipStream_t st);
 
 namespace {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE property of a kernel: one flag per device
+// index (not one per process), so that a second GPU used from the same process gets its opt-in too.
+// Racing threads may both set the attribute; that is harmless.
+constexpr int kMaxDevices = 64;
+struct PerDeviceOnce {
+    std::atomic<bool> done[kMaxDevices];   // static storage: zero-initialised
+    template <typename F>
+    int run(F &&f) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        if (dev < 0 || dev >= kMaxDevices) return f();   // beyond the table: set it every time
+        if (done[dev].load(std::memory_order_acquire)) return QGTC_OK;
+        const int rc = f();
+        if (rc == QGTC_OK) done[dev].store(true, std::memory_order_release);
+        return rc;
+    }
+};
 
 inline MMShape base_shape(int a, int w, int ob, int mode) {
     MMShape sh{};

@@ -10,14 +10,15 @@ int qgtc_launch_mfma(const qgtc_problem &pr, int a, int w, int ob, int mode, hip
     sh.nowrap = no_wrap(pr.K, a, w);
     const int tiles_m = (pr.M + MF_T - 1) / MF_T, tiles_n = (pr.N + MF_T - 1) / MF_T;
     const int maxp = a > w ? a : w;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr;
+    const int arc = attr.run([]() -> int {
 #define QGTC_MF_ATTR(P, E, F4) \
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma<P, E, F4>), hipFuncAttributeMaxDynamicSharedMemorySize, mf_lds_bytes(F4)));
         QGTC_MF_FOR_ALL(QGTC_MF_ATTR)
 #undef QGTC_MF_ATTR
-        attr_set = true;
-    }
+        return QGTC_OK;
+    });
+    if (arc != QGTC_OK) return arc;
     const dim3 grid(tiles_m * tiles_n);
     // two workgroups per CU overlap each other from 512 tiles on; below that one 12-wave workgroup per CU
     const bool wide = tiles_m * tiles_n < 512;
@@ -43,14 +44,15 @@ int qgtc_launch_mfma_batched(const qgtc_problem *prs, int count, int max_M, int 
     sh.nowrap = no_wrap(max_K, a, w);
     const int tiles = ((max_M + MF_T - 1) / MF_T) * ((max_N + MF_T - 1) / MF_T);
     const int maxp = a > w ? a : w;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr;
+    const int arc = attr.run([]() -> int {
 #define QGTC_MF_ATTR(P, E, F4) \
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_mfma_batched<P, E, F4>), hipFuncAttributeMaxDynamicSharedMemorySize, mf_lds_bytes(F4)));
         QGTC_MF_FOR_ALL(QGTC_MF_ATTR)
 #undef QGTC_MF_ATTR
-        attr_set = true;
-    }
+        return QGTC_OK;
+    });
+    if (arc != QGTC_OK) return arc;
     const dim3 grid(tiles, count);
     const bool wide = static_cast<long>(tiles) * count < 512;
     const bool fp4 = fp4_ok(max_K, a, w);

@@ -52,6 +52,21 @@
 
 thread_local char qgtc_g_hip_err[256] = "";
 
+namespace {
+// the two timing events of a profile loop; destroyed on every path out of the scope
+struct EventPair {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t create() {
+        hipError_t e = hipEventCreate(&e0);
+        return e == hipSuccess ? hipEventCreate(&e1) : e;
+    }
+    ~EventPair() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+}  // namespace
+
 // ============================================================================================
 // C-ABI
 // ============================================================================================
@@ -186,19 +201,16 @@ int qgtc_bitmm2bit_profile(const uint32_t *X, size_t x_words, const uint32_t *W,
     int rc = qgtc_bitmm2bit(X, x_words, W, w_words, M, K, N, bit1, bit2, output_bit, out, out_words,
                             flags, stream);
     if (rc != QGTC_OK) return rc;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, st));
+    EventPair ev;   // destroyed on every path out
+    HIP_TRY(ev.create());
+    HIP_TRY(hipEventRecord(ev.e0, st));
     for (int i = 0; i < reps && rc == QGTC_OK; i++)
         rc = qgtc_bitmm2bit(X, x_words, W, w_words, M, K, N, bit1, bit2, output_bit, out, out_words,
                             flags, stream);
-    hipError_t e = hipEventRecord(e1, st);
-    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    hipError_t e = hipEventRecord(ev.e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(ev.e1);
     float ms = 0.0f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev.e0, ev.e1);
     if (rc != QGTC_OK) return rc;
     if (e != hipSuccess) return hip_fail(e, "profile events");
     *elapsed_ms = ms;
@@ -343,17 +355,14 @@ int qgtc_i8gemm_profile(const int8_t *A, const int8_t *Bt, int M, int K, int N, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc = qgtc_i8gemm(A, Bt, M, K, N, C, c_elems, stream);
     if (rc != QGTC_OK) return rc;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, st));
+    EventPair ev;
+    HIP_TRY(ev.create());
+    HIP_TRY(hipEventRecord(ev.e0, st));
     for (int i = 0; i < reps && rc == QGTC_OK; i++) rc = qgtc_i8gemm(A, Bt, M, K, N, C, c_elems, stream);
-    hipError_t e = hipEventRecord(e1, st);
-    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    hipError_t e = hipEventRecord(ev.e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(ev.e1);
     float ms = 0.0f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev.e0, ev.e1);
     if (rc != QGTC_OK) return rc;
     if (e != hipSuccess) return hip_fail(e, "profile events");
     *elapsed_ms = ms;

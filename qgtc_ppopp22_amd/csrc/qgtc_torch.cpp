@@ -16,8 +16,10 @@
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 
+#include <array>
 #include <atomic>
 #include <cstdio>
+#include <mutex>
 #include <vector>
 
 #include "qgtc.h"
@@ -60,15 +62,40 @@ void check_bits_tensor(const torch::Tensor &t, const char *name) {
 // call, QGTC_host.cpp; the C-ABI itself is stateless - every call carries its flags). std::atomic: a second Python
 // thread may flip them, a launch then simply sees the old or the new value.
 std::atomic<bool> g_zero_skip{true};
-std::atomic<int> g_engine{0};  // 0 popcount (default), 1 mfma (wherever the plane counts allow it), 2 auto (measured rules)
+// 0 popcount (AND + v_bcnt kernels), 1 mfma (matrix cores wherever the plane counts allow it), 2 auto: per call the
+// kernel family that measured fastest on MI355X (launch_common.hip.h) - the DEFAULT, and what bench.py's headline runs.
+// QGTC_ENGINE=popcount|mfma|auto or set_engine() choose another; every engine returns the same words.
+std::atomic<int> g_engine{2};
 unsigned mm_flags() {
     return (g_zero_skip ? 0u : QGTC_NO_ZERO_SKIP) | (g_engine == 1 ? QGTC_ENGINE_MFMA : 0u) |
            (g_engine == 2 ? QGTC_ENGINE_AUTO : 0u);
 }
 
 // process-cumulative tile counters, like the reference's __device__ globals (kernel.h:13-14)
-unsigned long long g_counter = 0, g_counter_global = 0;
-double g_last_profile_ms = 0.0;
+std::atomic<unsigned long long> g_counter{0}, g_counter_global{0};
+std::atomic<double> g_last_profile_ms{0.0};
+
+// Side streams for the multi-stream launchers, one pool PER DEVICE (a pool filled on device 0 must never be used
+// under device 1's guard).
+constexpr int kMaxDevices = 64;
+std::mutex g_pool_mutex;
+std::array<std::vector<c10::hip::HIPStream>, kMaxDevices> g_stream_pools;
+std::vector<c10::hip::HIPStream> side_streams(int device, int n) {
+    TORCH_CHECK(device >= 0 && device < kMaxDevices, "device index out of range");
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    auto &pool = g_stream_pools[device];
+    while (static_cast<int>(pool.size()) < n) pool.push_back(c10::hip::getStreamFromPool(false, device));
+    return std::vector<c10::hip::HIPStream>(pool.begin(), pool.begin() + n);
+}
+
+// hipEvent that is destroyed on every path out of the scope (TORCH_CHECK throws)
+struct ScopedEvent {
+    hipEvent_t ev = nullptr;
+    ScopedEvent() { TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed"); }
+    ~ScopedEvent() { if (ev) (void)hipEventDestroy(ev); }
+    ScopedEvent(const ScopedEvent &) = delete;
+    ScopedEvent &operator=(const ScopedEvent &) = delete;
+};
 
 // ---------------------------------------------------------------------------------------------
 torch::Tensor val2bit(torch::Tensor input, const int nbits, const bool col_major,
@@ -170,6 +197,7 @@ void bitMM2Bit_enqueue(torch::Tensor out, torch::Tensor bit_X1, torch::Tensor bi
     check_bits_tensor(bit_X1, "bit_X1");
     check_bits_tensor(bit_X2, "bit_X2");
     TORCH_CHECK(reps > 0, "reps must be positive");
+    TORCH_CHECK(out.device() == bit_X1.device() && bit_X2.device() == bit_X1.device(), "out, bit_X1 and bit_X2 must be on the same device");
     c10::DeviceGuard guard(bit_X1.device());
     void *st = current_stream(bit_X1);
     for (int i = 0; i < reps; i++)
@@ -191,15 +219,16 @@ void bitMM2Bit_enqueue_streams(std::vector<torch::Tensor> outs, torch::Tensor bi
     TORCH_CHECK(!outs.empty() && reps > 0, "need at least one output buffer and one launch");
     c10::DeviceGuard guard(bit_X1.device());
     const int n = static_cast<int>(outs.size());
+    TORCH_CHECK(bit_X2.device() == bit_X1.device(), "bit_X1 and bit_X2 must be on the same device");
     for (auto &o : outs) {
         CHECK_INPUT(o);
         check_bits_tensor(o, "out");
+        TORCH_CHECK(o.device() == bit_X1.device(), "every output must be on the operands' device");
     }
     auto cur = c10::hip::getCurrentHIPStream(bit_X1.get_device());
-    static std::vector<c10::hip::HIPStream> pool;
-    while (static_cast<int>(pool.size()) < n) pool.push_back(c10::hip::getStreamFromPool(false, bit_X1.get_device()));
-    hipEvent_t ev;
-    TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+    const auto pool = side_streams(bit_X1.get_device(), n);
+    ScopedEvent sev;
+    hipEvent_t ev = sev.ev;
     TORCH_CHECK(hipEventRecord(ev, cur.stream()) == hipSuccess, "hipEventRecord failed");
     for (int s = 0; s < n; s++) TORCH_CHECK(hipStreamWaitEvent(pool[s].stream(), ev, 0) == hipSuccess, "wait failed");
     for (int i = 0; i < reps; i++) {
@@ -213,7 +242,6 @@ void bitMM2Bit_enqueue_streams(std::vector<torch::Tensor> outs, torch::Tensor bi
         TORCH_CHECK(hipEventRecord(ev, pool[s].stream()) == hipSuccess, "hipEventRecord failed");
         TORCH_CHECK(hipStreamWaitEvent(cur.stream(), ev, 0) == hipSuccess, "wait failed");
     }
-    (void)hipEventDestroy(ev);
 }
 
 torch::Tensor bitMM2Bit_profile(torch::Tensor bit_X1, torch::Tensor bit_X2, const int X1_height,
@@ -231,6 +259,7 @@ torch::Tensor bitMM2Bit_profile(torch::Tensor bit_X1, torch::Tensor bit_X2, cons
 
 std::vector<unsigned long long> tile_counters(const torch::Tensor &bit_X1, int M, int K, int N,
                                               int bit1, int bit2) {
+    c10::DeviceGuard guard(bit_X1.device());
     auto buf = torch::empty({2}, torch::TensorOptions().dtype(torch::kInt64).device(bit_X1.device()));
     check_rc(qgtc_tile_counters(words(bit_X1), bit_X1.numel(), M, K, N, bit1, bit2,
                                 reinterpret_cast<uint64_t *>(buf.data_ptr<int64_t>()),
@@ -247,8 +276,8 @@ torch::Tensor bitMM2Bit_base_cnt(torch::Tensor bit_X1, torch::Tensor bit_X2, con
     auto out = mm2bit_impl(bit_X1, bit_X2, X1_height, X1_width, X2_width, bit1, bit2, output_bit,
                            false, "bitMM2Bit_base_cnt");
     auto c = tile_counters(bit_X1, X1_height, X1_width, X2_width, bit1, bit2);
-    g_counter_global += c[0];
-    printf("counter_global: %d\n", static_cast<int>(g_counter_global));  // kernel.h:27 (%d of a 64-bit)
+    const unsigned long long total = g_counter_global.fetch_add(c[0]) + c[0];
+    printf("counter_global: %d\n", static_cast<int>(total));  // kernel.h:27 (%d of a 64-bit)
     fflush(stdout);
     return out;
 }
@@ -259,8 +288,8 @@ torch::Tensor bitMM2Bit_zerojump_cnt(torch::Tensor bit_X1, torch::Tensor bit_X2,
     auto out = mm2bit_impl(bit_X1, bit_X2, X1_height, X1_width, X2_width, bit1, bit2, output_bit,
                            false, "bitMM2Bit_zerojump_cnt");
     auto c = tile_counters(bit_X1, X1_height, X1_width, X2_width, bit1, bit2);
-    g_counter += c[1];
-    printf("counter: %d\n", static_cast<int>(g_counter));  // kernel.h:19
+    const unsigned long long total = g_counter.fetch_add(c[1]) + c[1];
+    printf("counter: %d\n", static_cast<int>(total));  // kernel.h:19
     fflush(stdout);
     return out;
 }
@@ -503,10 +532,9 @@ struct BatchedGemm {
         c10::DeviceGuard guard(descs.device());
         const int dev = descs.get_device();
         auto cur = c10::hip::getCurrentHIPStream(dev);
-        static std::vector<c10::hip::HIPStream> pool;
-        while (static_cast<int>(pool.size()) < n_streams) pool.push_back(c10::hip::getStreamFromPool(false, dev));
-        hipEvent_t ev;
-        TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+        const auto pool = side_streams(dev, n_streams);
+        ScopedEvent sev;
+        hipEvent_t ev = sev.ev;
         TORCH_CHECK(hipEventRecord(ev, cur.stream()) == hipSuccess, "hipEventRecord failed");
         for (int s = 0; s < n_streams; s++)
             TORCH_CHECK(hipStreamWaitEvent(pool[s].stream(), ev, 0) == hipSuccess, "wait failed");
@@ -527,7 +555,6 @@ struct BatchedGemm {
             TORCH_CHECK(hipEventRecord(ev, pool[s].stream()) == hipSuccess, "hipEventRecord failed");
             TORCH_CHECK(hipStreamWaitEvent(cur.stream(), ev, 0) == hipSuccess, "wait failed");
         }
-        (void)hipEventDestroy(ev);
     }
 
     void run() {
@@ -544,7 +571,7 @@ struct BatchedGemm {
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "QGTC bit-GEMM operators for AMD Instinct MI355X (gfx950); drop-in for the reference's QGTC extension";
     namespace py = pybind11;
-    // QGTC_ENGINE=popcount|mfma|auto picks the engine unmodified callers start with (set_engine() still overrides)
+    // QGTC_ENGINE=popcount|mfma|auto picks the engine unmodified callers start with (default auto; set_engine() overrides)
     if (const char *e = std::getenv("QGTC_ENGINE")) {
         const std::string name(e);
         TORCH_CHECK(name == "popcount" || name == "mfma" || name == "auto", "QGTC_ENGINE must be 'popcount', 'mfma' or 'auto'");
@@ -576,7 +603,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("profile", [](torch::Tensor a, torch::Tensor b, int M, int K, int N, int bit1, int bit2,
                         int ob, int reps) { return profile_impl(a, b, M, K, N, bit1, bit2, ob, reps).second; },
           "time `reps` bitMM2Bit launches; returns elapsed milliseconds (blocking)");
-    m.def("last_profile_ms", [] { return g_last_profile_ms; });
+    m.def("last_profile_ms", [] { return g_last_profile_ms.load(); });
     m.def("bitMM2Bit_enqueue_streams", &bitMM2Bit_enqueue_streams,
           "enqueue `reps` independent bitMM2Bit launches round-robin over len(outs) HIP streams (asynchronous)");
     m.def("bitMM2Bit_enqueue", &bitMM2Bit_enqueue,
@@ -598,15 +625,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                  "tile_occupancy");
         return occ;
     }, "occupancy bitmap (int64 words, [row tile][k-quad / 64]) of a rows-layout operand: 32-row x 128-bit tiles");
-    m.def("get_counters", [] { return py::make_tuple(g_counter_global, g_counter); });
+    m.def("get_counters", [] { return py::make_tuple(g_counter_global.load(), g_counter.load()); });
     m.def("reset_counters", [] { g_counter = 0; g_counter_global = 0; });
     m.def("set_zero_skip", [](bool on) { g_zero_skip = on; });
     m.def("set_engine", [](const std::string &name) {
         TORCH_CHECK(name == "popcount" || name == "mfma" || name == "auto", "engine must be 'popcount', 'mfma' or 'auto'");
         g_engine = name == "mfma" ? 1 : (name == "auto" ? 2 : 0);
-    }, "engine of bitMM2Bit / bitMM2Bit_col / bitMM2Int: 'popcount' (default, AND + v_bcnt), 'mfma' (bit planes "
-       "expanded to int8 on the fly, v_mfma_i32_32x32x32_i8; bit widths <= 8, else popcount) or 'auto' (a cost "
-       "model picks per call). Same results.");
+    }, "engine of bitMM2Bit / bitMM2Bit_col / bitMM2Int: 'auto' (default: per call the kernel family that measured "
+       "fastest on MI355X), 'popcount' (AND + v_bcnt kernels only) or 'mfma' (matrix cores wherever the plane counts "
+       "allow: FP4 / int8 expansions of the bit planes). Same results.");
     m.def("get_engine", [] { return std::string(g_engine == 1 ? "mfma" : (g_engine == 2 ? "auto" : "popcount")); });
     m.def("get_zero_skip", [] { return g_zero_skip.load(); });
     m.def("abi_version", [] { return qgtc_abi_version(); });

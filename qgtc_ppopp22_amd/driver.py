@@ -69,9 +69,10 @@ def build_parser() -> argparse.ArgumentParser:
                         "float features to the device (Trans), then packs them and runs the six operators "
                         "(Compute), with synchronisation fences around both; prints its `Trans (ms): .., Compute "
                         "(ms): ..` line too")
-    p.add_argument("--engine", choices=["popcount", "mfma", "auto"], default="popcount",
-                   help="popcount: AND + v_bcnt kernels (default, the path BASELINE.json names); mfma: bit planes "
-                        "expanded to int8 on the matrix cores; auto: chosen per launch. Same results.")
+    p.add_argument("--engine", choices=["popcount", "mfma", "auto"], default="auto",
+                   help="auto (default): per launch the kernel family that measured fastest on MI355X; popcount: AND + "
+                        "v_bcnt kernels only (the path BASELINE.json names); mfma: bit planes expanded on the matrix "
+                        "cores wherever the plane counts allow. Same results.")
     p.add_argument("--quiet", action="store_true")
     return p
 
@@ -138,6 +139,26 @@ def gin_correct(Q, ct, param, W, b):
     h2 = Q.bitMM2Bit_col(a1, W["W2"], n, H, H, b, b, b)
     a2 = Q.bitMM2Bit(ct.bit_A, h2, n, n, H, 1, b, b)
     return Q.bitMM2Int(a2, W["W3"], n, H, C, b, b, False)
+
+
+# parse_counter.py:31-33 - the columns of the reference's zerotile_jumping.csv
+ZEROTILE_HEADER = "dataset , non-jumping , jumping , ratio(jumping/non-jumping)"
+
+
+def zerotile_row(dataset, printed_global, printed_counter):
+    """The row parse_counter.py:10-34 computes from a `--zerotile_jump` log: it SUMS the printed lines, and the
+    printed values are cumulative (kernel.h:13-28 never resets the device counters), so the sums are of running
+    totals; `ratio` = jumping / non-jumping as there. `per_epoch_*` are the plain totals of one pass (the last
+    cumulative value when the counters started from zero), whose ratio is the fraction of 8-row x 128-bit tile steps
+    that survive zero-tile jumping."""
+    gc, c = int(sum(printed_global)), int(sum(printed_counter))
+    ratio = c / gc if gc else float("nan")
+    last_g = int(printed_global[-1]) if printed_global else 0
+    last_c = int(printed_counter[-1]) if printed_counter else 0
+    return {"dataset": dataset, "non_jumping": gc, "jumping": c, "ratio": ratio,
+            "per_epoch_non_jumping": last_g, "per_epoch_jumping": last_c,
+            "per_epoch_ratio": (last_c / last_g) if last_g else float("nan"),
+            "line": "{} , {} , {} , {:.3f}".format(dataset, gc, c, ratio)}
 
 
 CHAINS = {("reference", False): gcn_reference, ("reference", True): gin_reference,
@@ -257,13 +278,20 @@ def _run_epochs(args, Q, it, feat_size, b, device):
     chain = CHAINS[(args.chain, args.run_GIN)]
     outs = []
     if args.zerotile_jump:    # main_qgtc.py:142-145 / cluster_gcn.py:208-211
+        printed_global, printed_counter = [], []      # the cumulative values of the `counter_global:` / `counter:` lines
         for ct, param in it:
             ct = ct.to(device)
             A0, A1 = param[0], param[1]
             t0 = Q.bitMM2Bit(ct.bit_X, W["W1"], param[2], param[3], W["hidden"], b, b, b)
             Q.bitMM2Bit_base_cnt(ct.bit_A, t0, A0, A1, W["hidden"], 1, b, b)
+            printed_global.append(Q.get_counters()[0])
             Q.bitMM2Bit_zerojump_cnt(ct.bit_A, t0, A0, A1, W["hidden"], 1, b, b)
-        return {"avg_epoch_ms": float("nan"), "outs": [], "iter": it, "counters": Q.get_counters()}
+            printed_counter.append(Q.get_counters()[1])
+        row = zerotile_row(args.dataset, printed_global, printed_counter)
+        if not args.quiet:
+            print(ZEROTILE_HEADER)
+            print(row["line"])
+        return {"avg_epoch_ms": float("nan"), "outs": [], "iter": it, "counters": Q.get_counters(), "zerotile": row}
 
     if getattr(args, "pack_on_the_fly", False):
         from .sampler import ClusterTensor

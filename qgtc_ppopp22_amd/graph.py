@@ -63,17 +63,87 @@ def make_graph(name: str, psize: int = 1500, dim: int | None = None, seed: int =
     return make_sbm_graph(name, n, psize, deg, dim or f, seed=seed)
 
 
-def load_npz_graph(path: str, dim: int, psize: int, seed: int = 2) -> Graph:
-    """The reference's `.npz` format: arrays `src_li`, `dst_li` (dataset.py:48-53); features are
-    random as in dataset.py:64. Partitions are contiguous node ranges (no METIS here)."""
+def locality_partition(src: np.ndarray, dst: np.ndarray, n_nodes: int, psize: int, sweeps: int = 12) -> np.ndarray:
+    """METIS-free stand-in for get_partition_list's partitioner (partition_utils.py:11-18, dgl metis_partition):
+    returns int32 [n_nodes] part ids in [0, psize), parts of (almost) equal size, neighbours mostly together - so
+    that a cluster batch's adjacency is block-structured (which is what zero-tile skipping feeds on) instead of the
+    uniform scatter that contiguous id ranges give on an arbitrary node numbering.
+
+    1. reverse Cuthill-McKee ordering of the symmetrised graph (bandwidth reduction: neighbours get close ranks),
+       cut into psize equal runs;
+    2. sweeps of size-capped label propagation: a node moves to the part holding most of its neighbours when that
+       part has room (cap = 1.05 x the mean size) and its own part is above half the mean size, most-gaining nodes
+       first; stops early when fewer than 0.1 % of the nodes still want to move.
+    On the ogbn-arxiv-sized SBM graph with shuffled node ids: 45 % of the edges inside their partition after 12
+    sweeps (planted blocks: 89 %, contiguous id ranges: 0.07 %), ~7 s.
+    Deterministic; O(E) per sweep with scipy.sparse."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+
+    psize = max(1, min(int(psize), n_nodes))
+    keep = src != dst
+    s_, d_ = src[keep], dst[keep]
+    A = sp.coo_matrix((np.ones(s_.size, dtype=np.float32), (s_, d_)), shape=(n_nodes, n_nodes)).tocsr()
+    A = ((A + A.T) > 0).astype(np.float32).tocsr()
+    order = reverse_cuthill_mckee(A, symmetric_mode=True)
+    rank = np.empty(n_nodes, dtype=np.int64)
+    rank[order] = np.arange(n_nodes)
+    part = (rank * psize // n_nodes).astype(np.int32)
+    cap = int(np.ceil(1.05 * n_nodes / psize))
+    for _ in range(sweeps):
+        onehot = sp.csr_matrix((np.ones(n_nodes, dtype=np.float32), (np.arange(n_nodes), part)), shape=(n_nodes, psize))
+        votes = (A @ onehot).tocsr()                       # votes[v, p] = neighbours of v in part p
+        best = np.asarray(votes.argmax(axis=1)).reshape(-1).astype(np.int32)
+        best_cnt = np.asarray(votes.max(axis=1).todense()).reshape(-1)
+        here = np.asarray(votes[np.arange(n_nodes), part]).reshape(-1)
+        gain = best_cnt - here
+        size = np.bincount(part, minlength=psize).astype(np.int64)
+        floor = max(1, n_nodes // (2 * psize))            # parts at half the mean size keep their nodes
+        movers = np.nonzero((gain > 0) & (best != part) & (size[part] > floor))[0]
+        if movers.size < max(1, n_nodes // 1000):
+            break
+        movers = movers[np.argsort(-gain[movers], kind="stable")]
+        # admit movers per target part while it has room (arrival order = gain order); departures are not credited
+        # back within the sweep, which only makes the cap conservative
+        tgt = best[movers]
+        o = np.argsort(tgt, kind="stable")
+        tgt_sorted = tgt[o]
+        first = np.searchsorted(tgt_sorted, tgt_sorted, side="left")
+        arrival = np.arange(tgt_sorted.size) - first      # 0, 1, 2.. within each target part
+        ok = arrival < (cap - size[tgt_sorted])
+        chosen = movers[o[ok]]
+        part[chosen] = best[chosen]
+    return part
+
+
+def load_npz_graph(path: str, dim: int, psize: int, seed: int = 2, partitioner: str = "locality") -> Graph:
+    """The reference's `.npz` format: arrays `src_li`, `dst_li` (dataset.py:48-53; the node count is the largest id
+    + 1 as DGL's add_edges makes it, dataset.py:52-56); features are random as in dataset.py:64. Partitions come from
+    `locality_partition` (no METIS here); partitioner="contiguous" keeps plain id ranges."""
     obj = np.load(path)
-    src = np.asarray(obj["src_li"], dtype=np.int64)
-    dst = np.asarray(obj["dst_li"], dtype=np.int64)
-    n = int(max(src.max(), dst.max())) + 1
+    src = np.asarray(obj["src_li"], dtype=np.int64).reshape(-1)
+    dst = np.asarray(obj["dst_li"], dtype=np.int64).reshape(-1)
+    if src.size != dst.size:
+        raise ValueError(f"{path}: src_li and dst_li differ in length ({src.size} vs {dst.size})")
+    if src.size and (min(src.min(), dst.min()) < 0):
+        raise ValueError(f"{path}: negative node id")
+    n = int(max(src.max(), dst.max())) + 1 if src.size else 0
+    if n == 0:
+        raise ValueError(f"{path}: empty edge list")
     rng = np.random.default_rng(seed)
     feat = rng.standard_normal((n, dim), dtype=np.float32)
-    block_of = (np.arange(n, dtype=np.int64) * psize // n).astype(np.int32)
+    if partitioner == "contiguous":
+        block_of = (np.arange(n, dtype=np.int64) * psize // n).astype(np.int32)
+    elif partitioner == "locality":
+        block_of = locality_partition(src, dst, n, psize)
+    else:
+        raise ValueError(f"unknown partitioner {partitioner!r}")
     return Graph(path, n, src, dst, feat, block_of)
+
+
+def edge_locality(g: Graph) -> float:
+    """Fraction of edges whose endpoints share a partition (1 - edge cut)."""
+    return float(np.mean(g.block_of[g.src] == g.block_of[g.dst])) if g.src.size else 1.0
 
 
 def partition_list(g: Graph, psize: int):

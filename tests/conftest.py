@@ -30,3 +30,16 @@ def qgtc():
     import QGTC
 
     return QGTC
+
+
+@pytest.fixture(autouse=True)
+def _library_switches_back_to_default(request):
+    """Process-wide switches of the binding (engine, zero-tile skipping) never leak from one GPU test into the
+    next: every test starts on the shipped defaults."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    mod = sys.modules.get("QGTC")
+    if mod is not None:
+        mod.set_engine("auto")
+        mod.set_zero_skip(True)

@@ -1,5 +1,22 @@
 """Shared input generators for the parity tests."""
+import contextlib
+
 import numpy as np
+
+# every engine of the library; "auto" is what an unmodified caller gets (qgtc_torch.cpp: g_engine)
+ENGINES = ("popcount", "mfma", "auto")
+DEFAULT_ENGINE = "auto"
+
+
+@contextlib.contextmanager
+def use_engine(qgtc, name):
+    """Run a block on one engine and put the previous one back."""
+    prev = qgtc.get_engine()
+    qgtc.set_engine(name)
+    try:
+        yield
+    finally:
+        qgtc.set_engine(prev)
 
 
 def edge_floats(rng, H, W, nbits):

@@ -1,0 +1,76 @@
+"""The C-ABI of libqgtc_hip.so driven WITHOUT the PyTorch extension: ctypes + raw device pointers, the way
+INTEGRATION.md section 3 shows a non-torch host (cgo / JNI / plain C) would call it. torch is used only as the
+device allocator here; every compute call goes through `extern "C"` entry points with plain pointers and sizes, and
+the results are compared with the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from helpers import rand_q
+
+pytestmark = pytest.mark.gpu
+
+u32p, f32p, vp = ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_float), ctypes.c_void_p
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    import qgtc_ppopp22_amd
+
+    L = ctypes.CDLL(qgtc_ppopp22_amd.lib_path())
+    L.qgtc_rows_words.restype = ctypes.c_size_t
+    L.qgtc_rows_words.argtypes = [ctypes.c_int] * 3
+    L.qgtc_cols_words.restype = ctypes.c_size_t
+    L.qgtc_cols_words.argtypes = [ctypes.c_int] * 4
+    L.qgtc_val2bit.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+    L.qgtc_bitmm2bit.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t] + [ctypes.c_int] * 6 + [vp, ctypes.c_size_t, ctypes.c_uint, vp]
+    L.qgtc_bitmm2int.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t] + [ctypes.c_int] * 6 + [vp, ctypes.c_size_t, ctypes.c_uint, vp]
+    L.qgtc_bit2val.argtypes = [vp, ctypes.c_size_t] + [ctypes.c_int] * 5 + [vp, vp]
+    L.qgtc_strerror.restype = ctypes.c_char_p
+    return L
+
+
+def _dev(torch, n, dtype):
+    return torch.empty(int(n), dtype=dtype, device="cuda")
+
+
+@pytest.mark.parametrize("M,K,N,a,w,ob", [(300, 300, 64, 1, 2, 2), (129, 1000, 40, 2, 2, 3), (64, 4096, 64, 1, 1, 1),
+                                          (77, 500, 130, 3, 5, 4)])
+@pytest.mark.parametrize("flags", [0x0, 0x10, 0x8, 0x2], ids=["popcount", "auto", "mfma", "no-zero-skip"])
+def test_c_abi_with_raw_device_pointers(lib, oracle, M, K, N, a, w, ob, flags):
+    import torch
+    rng = np.random.default_rng(M + K + N + flags)
+    qx, qw = rand_q(rng, M, K, a).astype(np.float32), rand_q(rng, K, N, w).astype(np.float32)
+    dx, dw = torch.from_numpy(qx).cuda(), torch.from_numpy(qw).cuda()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # val2bit: float -> packed planes, straight into caller-owned buffers
+    xw_, ww_ = lib.qgtc_rows_words(M, K, a), lib.qgtc_cols_words(K, N, w, 0)
+    bx, bw = _dev(torch, xw_, torch.int32), _dev(torch, ww_, torch.int32)
+    assert lib.qgtc_val2bit(dx.data_ptr(), M, K, a, 0, 0, bx.data_ptr(), xw_, st) == 0
+    assert lib.qgtc_val2bit(dw.data_ptr(), K, N, w, 1, 0, bw.data_ptr(), ww_, st) == 0
+    X_o, W_o = oracle.val2bit(qx, a, False, False), oracle.val2bit(qw, w, True, False)
+    np.testing.assert_array_equal(bx.cpu().numpy().view(np.uint32), X_o)
+    np.testing.assert_array_equal(bw.cpu().numpy().view(np.uint32), W_o)
+    # bitMM2Bit (rows layout), bitMM2Bit_col (QGTC_OUT_COLS = 0x1), bitMM2Int
+    ow = lib.qgtc_rows_words(M, N, ob)
+    out = _dev(torch, ow, torch.int32)
+    rc = lib.qgtc_bitmm2bit(bx.data_ptr(), xw_, bw.data_ptr(), ww_, M, K, N, a, w, ob, out.data_ptr(), ow, flags, st)
+    assert rc == 0, lib.qgtc_strerror(rc)
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), oracle.bitmm2bit(X_o, W_o, M, K, N, a, w, ob))
+    oc = lib.qgtc_cols_words(M, N, ob, 0)
+    outc = _dev(torch, oc, torch.int32)
+    assert lib.qgtc_bitmm2bit(bx.data_ptr(), xw_, bw.data_ptr(), ww_, M, K, N, a, w, ob, outc.data_ptr(), oc, flags | 0x1, st) == 0
+    np.testing.assert_array_equal(outc.cpu().numpy().view(np.uint32), oracle.bitmm2bit(X_o, W_o, M, K, N, a, w, ob, col=True))
+    outf = _dev(torch, M * N, torch.float32)
+    assert lib.qgtc_bitmm2int(bx.data_ptr(), xw_, bw.data_ptr(), ww_, M, K, N, a, w, 1, outf.data_ptr(), M * N, flags, st) == 0
+    np.testing.assert_array_equal(outf.cpu().numpy().reshape(M, N), oracle.bitmm2int(X_o, W_o, M, K, N, a, w, True))
+    # bit2val of the packed result closes the loop
+    dec = _dev(torch, M * N, torch.int32)
+    assert lib.qgtc_bit2val(out.data_ptr(), ow, ob, M, N, 0, 0, dec.data_ptr(), st) == 0
+    np.testing.assert_array_equal(dec.cpu().numpy().reshape(M, N), oracle.bit2val(oracle.bitmm2bit(X_o, W_o, M, K, N, a, w, ob), ob, M, N, False, False))
+    # an undersized output buffer is an error code, not a fault
+    assert lib.qgtc_bitmm2bit(bx.data_ptr(), xw_, bw.data_ptr(), ww_, M, K, N, a, w, ob, out.data_ptr(), ow - 1, flags, st) == 2

@@ -82,7 +82,7 @@ def test_engine_env_default():
     import sys
 
     code = "import QGTC; print(QGTC.get_engine())"
-    for env_val, want in ((None, "popcount"), ("auto", "auto"), ("mfma", "mfma")):
+    for env_val, want in ((None, "auto"), ("popcount", "popcount"), ("mfma", "mfma")):
         env = dict(os.environ)
         env.pop("QGTC_ENGINE", None)
         if env_val:

@@ -46,12 +46,12 @@ def test_epoch_outputs_match_oracle(qgtc, oracle, chain, gin, bits, batched):
             np.testing.assert_array_equal(expect, integer_gcn_reference(bi["A"], bi["X"], 64, 10, bits, oracle))
 
 
-@pytest.mark.parametrize("engine", ["mfma", "auto"])
+@pytest.mark.parametrize("engine", ["mfma", "popcount"])
 @pytest.mark.parametrize("gin", [False, True])
 @pytest.mark.parametrize("batched", [False, True])
 def test_engines_give_the_same_epoch(qgtc, engine, gin, batched):
-    """--engine mfma / auto (per-batch operators and grouped launches, reference and layout-correct
-    chains) reproduce the popcount engine's outputs - which the test above pins to the oracle."""
+    """--engine mfma / popcount (per-batch operators and grouped launches, reference and layout-correct
+    chains) reproduce the default engine's outputs - which the test above pins to the oracle."""
     import torch
     from qgtc_ppopp22_amd import driver
 
@@ -59,7 +59,7 @@ def test_engines_give_the_same_epoch(qgtc, engine, gin, batched):
         extra = ["--chain", chain] + (["--run_GIN", "--bit_width", "4"] if gin else []) + (["--batched"] if batched else [])
         base = driver.run(_args(extra), Q=qgtc)["outs"]
         other = driver.run(_args(extra + ["--engine", engine]), Q=qgtc)["outs"]
-        assert qgtc.get_engine() == "popcount"          # the driver restores the switch
+        assert qgtc.get_engine() == "auto"              # the driver restores the switch
         assert len(base) == len(other) and all(torch.equal(x, y) for x, y in zip(base, other))
 
 
@@ -128,3 +128,61 @@ def test_avg_epoch_line_format(qgtc, capfd):
     out = capfd.readouterr().out
     assert "dataset='tiny'" in out                      # parse_time.py:9-14 greps this
     assert re.search(r"Avg\. Epoch: \d+\.\d{3} ms", out)  # parse_time.py:15-17
+
+
+def test_zerotile_row_from_the_driver_log(qgtc, capfd):
+    """`--zerotile_jump` without --quiet: the counter lines plus the `dataset , non-jumping , jumping , ratio` row of
+    parse_counter.py:31-33 computed from them."""
+    from qgtc_ppopp22_amd import driver
+
+    qgtc.reset_counters()
+    args = driver.build_parser().parse_args(["--dataset", "tiny", "--psize", str(PSIZE), "--batch-size", str(BS),
+                                             "--n-hidden", "64", "--use_QGTC", "--zerotile_jump"])
+    res = driver.run(args, Q=qgtc)
+    out = capfd.readouterr().out.splitlines()
+    gl = [int(l.split(":")[1]) for l in out if l.startswith("counter_global:")]
+    cn = [int(l.split(":")[1]) for l in out if l.startswith("counter:")]
+    assert len(gl) == len(cn) == PSIZE // BS
+    row = res["zerotile"]
+    assert driver.ZEROTILE_HEADER in out and row["line"] in out
+    assert row["non_jumping"] == sum(gl) and row["jumping"] == sum(cn)
+    assert row["line"] == "tiny , {} , {} , {:.3f}".format(sum(gl), sum(cn), sum(cn) / sum(gl))
+    assert (row["per_epoch_non_jumping"], row["per_epoch_jumping"]) == (gl[-1], cn[-1]) == tuple(res["counters"])
+    assert 0.0 < row["per_epoch_ratio"] < 1.0
+
+
+@pytest.mark.parametrize("dataset,bits,hidden,gin", [("ogbn-arxiv", 2, 128, False), ("ppi", 4, 64, True)])
+def test_full_size_epoch_matches_oracle_and_per_batch_launches(qgtc, oracle, dataset, bits, hidden, gin):
+    """BASELINE.json configs 3 / 4 at the size bench.py times: the ogbn-arxiv-sized graph (75 cluster batches of ~1213
+    nodes, F = H = 128, 2-bit, Cluster-GCN) and the ppi-sized one (75 x ~599, F = 50, H = 64, 4-bit, Batched-GIN),
+    layout-correct chain, grouped launches on the default engine. Three batches are checked against the oracle's
+    chain (every one of the six operators' final float output), all 75 against the per-batch launches."""
+    import torch
+    from qgtc_ppopp22_amd import driver, graph as G
+
+    psize, bs = 1500, 20
+    base = ["--dataset", dataset, "--psize", str(psize), "--batch-size", str(bs), "--n-hidden", str(hidden),
+            "--n-classes", "10", "--bit_width", str(bits), "--n-epochs", "1", "--use_QGTC", "--quiet", "--chain", "correct"]
+    if gin:
+        base.append("--run_GIN")
+    graph = G.make_graph(dataset, psize)
+    grouped = driver.run(driver.build_parser().parse_args(base + ["--batched"]), Q=qgtc, graph=graph)
+    assert qgtc.get_engine() == "auto"
+    per_batch = driver.run(driver.build_parser().parse_args(base), Q=qgtc, graph=graph)
+    assert len(grouped["outs"]) == len(per_batch["outs"]) == psize // bs == 75
+    for i, (x, y) in enumerate(zip(grouped["outs"], per_batch["outs"])):
+        assert torch.equal(x, y), f"batch {i}"
+    random.seed(2)
+    par = G.partition_list(graph, psize)
+    random.shuffle(par)
+    W = oracle_weights(oracle, graph.feat.shape[1], hidden, 10, bits)
+    sizes = []
+    for cid in (0, 37, 74):
+        bi = oracle_batch_inputs(oracle, graph, par, cid, psize, bs, bits)
+        sizes.append(bi["n"])
+        ct = grouped["iter"].cTensor_li[cid]
+        np.testing.assert_array_equal(to_np_u32(ct.bit_A), bi["bit_A"])
+        expect = oracle_chain(oracle, bi, W, bits, "correct", gin)[-1]
+        np.testing.assert_array_equal(grouped["outs"][cid].cpu().numpy(), expect, err_msg=f"batch {cid}")
+        assert grouped["outs"][cid].abs().sum().item() > 0
+    assert min(sizes) > (1100 if dataset == "ogbn-arxiv" else 500)

@@ -4,7 +4,7 @@
 import numpy as np
 import pytest
 
-from helpers import to_np_u32
+from helpers import to_np_u32, use_engine
 
 pytestmark = pytest.mark.gpu
 
@@ -120,7 +120,7 @@ def test_tile_occupancy_bitmap(qgtc, oracle, M, K, a, density):
 
 @pytest.mark.parametrize("a,w,ob", [(1, 2, 2), (1, 1, 1), (2, 2, 3), (3, 5, 4), (8, 8, 8)])
 @pytest.mark.parametrize("mode", [0, 1, 2])
-@pytest.mark.parametrize("engine", ["popcount", "mfma"])
+@pytest.mark.parametrize("engine", ["popcount", "mfma", "auto"])
 def test_zero_jump_products_are_identical(qgtc, oracle, a, w, ob, mode, engine):
     """Grouped launch with the occupancy bitmap (tiles neither loaded nor multiplied) against the
     oracle: block-diagonal-dominant sparse left operands, including an all-zero one. Both engines;
@@ -149,7 +149,7 @@ def test_zero_jump_products_are_identical(qgtc, oracle, a, w, ob, mode, engine):
         try:
             bg.run()
         finally:
-            qgtc.set_engine("popcount")
+            qgtc.set_engine("auto")
         torch.cuda.synchronize()
         for i, (M, K, N) in enumerate(dims):
             X, Wt = refs[i]
@@ -186,6 +186,11 @@ def test_gcnconv_qnt_module_matches_integer_reference(qgtc, oracle):
     h = rq(qA @ rq(qX @ qWi))
     want = (qA @ rq(h @ qWo)).astype(np.float32)
     np.testing.assert_array_equal(out_dense.cpu().numpy(), want)
+    # an in-place parameter update must not leave stale packed weights behind
+    with torch.no_grad():
+        model.W_out.mul_(0.0).add_(1.0)
+    want1 = (qA @ rq(h @ np.ones_like(qWo))).astype(np.float32)
+    np.testing.assert_array_equal(model(torch.from_numpy(A).cuda(), torch.from_numpy(X).cuda()).cpu().numpy(), want1)
 
 
 MFMA_CASES = [
@@ -210,7 +215,8 @@ def test_mfma_engine_matches_oracle_and_popcount(qgtc, oracle, M, K, N, a, w, ob
     qx, qw = rand_q(rng, M, K, a), rand_q(rng, K, N, w)
     X, Wt = oracle.pack(qx, a, False), oracle.pack(qw, w, True)
     dX, dW = to_dev(torch, X, rows_shape(M, K, a)), to_dev(torch, Wt, cols_shape(K, N, w))
-    assert qgtc.get_engine() == "popcount"
+    assert qgtc.get_engine() == "auto"      # the shipped default
+    qgtc.set_engine("popcount")
     pop = (qgtc.bitMM2Bit(dX, dW, M, K, N, a, w, ob), qgtc.bitMM2Bit_col(dX, dW, M, K, N, a, w, ob),
            qgtc.bitMM2Int(dX, dW, M, K, N, a, w, True))
     qgtc.set_engine("mfma")
@@ -218,7 +224,7 @@ def test_mfma_engine_matches_oracle_and_popcount(qgtc, oracle, M, K, N, a, w, ob
         mf = (qgtc.bitMM2Bit(dX, dW, M, K, N, a, w, ob), qgtc.bitMM2Bit_col(dX, dW, M, K, N, a, w, ob),
               qgtc.bitMM2Int(dX, dW, M, K, N, a, w, True))
     finally:
-        qgtc.set_engine("popcount")
+        qgtc.set_engine("auto")
     np.testing.assert_array_equal(to_np_u32(mf[0]), oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob))
     np.testing.assert_array_equal(to_np_u32(mf[1]), oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob, col=True))
     np.testing.assert_array_equal(mf[2].cpu().numpy(), oracle.bitmm2int(X, Wt, M, K, N, a, w, True))
@@ -240,7 +246,7 @@ def test_mfma_engine_falls_back_above_8_bits(qgtc, oracle):
     try:
         got = qgtc.bitMM2Bit(dX, dW, M, K, N, a, w, ob)
     finally:
-        qgtc.set_engine("popcount")
+        qgtc.set_engine("auto")
     np.testing.assert_array_equal(to_np_u32(got), oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob))
     with pytest.raises(RuntimeError):
         qgtc.set_engine("tensor-core")
@@ -255,6 +261,7 @@ def test_auto_engine_same_words_either_way(qgtc, M, K, N, a, w, ob):
     from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
     dX = torch.randint(-2**31, 2**31 - 1, rows_shape(M, K, a), dtype=torch.int32, generator=g).cuda()
     dW = torch.randint(-2**31, 2**31 - 1, cols_shape(K, N, w), dtype=torch.int32, generator=g).cuda()
+    qgtc.set_engine("popcount")
     pop = (qgtc.bitMM2Bit(dX, dW, M, K, N, a, w, ob), qgtc.bitMM2Bit_col(dX, dW, M, K, N, a, w, ob),
            qgtc.bitMM2Int(dX, dW, M, K, N, a, w, True))
     qgtc.set_engine("auto")
@@ -263,7 +270,7 @@ def test_auto_engine_same_words_either_way(qgtc, M, K, N, a, w, ob):
         au = (qgtc.bitMM2Bit(dX, dW, M, K, N, a, w, ob), qgtc.bitMM2Bit_col(dX, dW, M, K, N, a, w, ob),
               qgtc.bitMM2Int(dX, dW, M, K, N, a, w, True))
     finally:
-        qgtc.set_engine("popcount")
+        qgtc.set_engine("auto")
     for x, y in zip(au, pop):
         assert torch.equal(x, y)
 
@@ -350,4 +357,111 @@ def test_fp4_narrow_kernels_sweep(qgtc, oracle):
                             np.testing.assert_array_equal(to_np_u32(o), oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob, col=(mode == 1)),
                                                           err_msg=tag + f" grouped mode {mode} jump {zj}")
     finally:
-        qgtc.set_engine("popcount")
+        qgtc.set_engine("auto")
+
+
+# ---------------------------------------------------------------------------------------------
+# The FP4 matrix-core kernels accumulate in float32; the library only routes a product to them while
+# K (2^a - 1)(2^w - 1) < 2^24 (launch_common.hip.h: skinny_ok / fp4_wave_ok / fp4_ok), i.e. while every partial sum
+# is an exactly representable integer. That predicate is the whole safety case of those kernels (the reference
+# accumulates in int32, kernel.h:292-341), so it is tested at its edge with worst-case operands.
+# ---------------------------------------------------------------------------------------------
+def _kmax(a, w):
+    return (2 ** 24 - 1) // ((2 ** a - 1) * (2 ** w - 1))
+
+
+def _packed_pair(torch, oracle, qx, qw, a, w):
+    from helpers import to_dev
+    from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
+    M, K = qx.shape
+    N = qw.shape[1]
+    X, Wt = oracle.pack(qx, a, False), oracle.pack(qw, w, True)
+    return X, Wt, to_dev(torch, X, rows_shape(M, K, a)), to_dev(torch, Wt, cols_shape(K, N, w))
+
+
+@pytest.mark.parametrize("a,w", [(1, 8), (2, 8), (2, 2), (1, 1), (2, 4)])
+@pytest.mark.parametrize("engine", ["auto", "mfma"])
+def test_float32_exactness_bound_all_max_operands(qgtc, oracle, a, w, engine):
+    """All-max X times all-max W at the LARGEST K the FP4 kernels are admitted for (every output = K (2^a-1)(2^w-1)
+    <= 2^24 - 1, the largest float32 sum that can occur) and at K + 1 (the int32 kernels must take over): exact
+    float32 output, exact packed output, and equal to the oracle."""
+    import torch
+    M, N = 20, 24
+    for K in (_kmax(a, w), _kmax(a, w) + 1):
+        if a == 1 and w == 1:
+            K = min(K, 3000000)     # 2^24 - 1 bits of K per row is only a size issue, not an exactness one
+        qx = np.full((M, K), 2 ** a - 1, dtype=np.int32)
+        qw = np.full((K, N), 2 ** w - 1, dtype=np.int32)
+        X, Wt, dX, dW = _packed_pair(torch, oracle, qx, qw, a, w)
+        want = K * (2 ** a - 1) * (2 ** w - 1)
+        with use_engine(qgtc, engine):
+            f = qgtc.bitMM2Int(dX, dW, M, K, N, a, w, True).cpu().numpy()
+            b = qgtc.bitMM2Bit(dX, dW, M, K, N, a, w, 8)
+        assert want < 2 ** 31
+        np.testing.assert_array_equal(f, np.full((M, N), np.float32(want)), err_msg=f"K={K}")
+        if float(np.float32(want)) == want:
+            assert (f.astype(np.int64) == want).all()
+        np.testing.assert_array_equal(f, oracle.bitmm2int(X, Wt, M, K, N, a, w, True))
+        np.testing.assert_array_equal(to_np_u32(b), oracle.bitmm2bit(X, Wt, M, K, N, a, w, 8))
+
+
+@pytest.mark.parametrize("a,w", [(1, 8), (2, 8), (2, 2)])
+def test_float32_sums_do_not_truncate_small_addends(qgtc, oracle, a, w):
+    """A pattern aimed at the INSIDE of the block-scaled MFMA: most of K drives every accumulator close to 2^24 with
+    all-max operands, then the remaining k-quads contribute products of every magnitude down to single 1 x 1 pairs
+    (lowest base-4 digits, scale 2 x 2) interleaved with all-max ones (highest digits, scale up to 2 x 128) in the
+    SAME 128-element instruction. A datapath that aligned the addends of its 128-term sum to the largest one and
+    dropped low bits would lose them; int32 accumulation (the reference, kernel.h:292-341) does not."""
+    import torch
+    rng = np.random.default_rng(1000 * a + w)
+    M, N = 33, 40
+    K = _kmax(a, w)
+    ma, mw = 2 ** a - 1, 2 ** w - 1
+    for tail in (512, 4096 + 77):              # ragged tails, several super-steps
+        qx = np.full((M, K), ma, dtype=np.int32)
+        qw = np.full((K, N), mw, dtype=np.int32)
+        t0 = K - tail
+        # the tail: alternating all-max and tiny values element by element, then pure 1 x 1 pairs, then zeros
+        alt = (np.arange(tail) % 2 == 0)
+        qx[:, t0:] = np.where(alt[None, :], ma, rng.integers(0, 2, size=(M, tail)))
+        qw[t0:, :] = np.where(alt[:, None], mw, rng.integers(0, 2, size=(tail, N)))
+        third = tail // 3
+        qx[:, K - third:] = rng.integers(0, 2, size=(M, third))
+        qw[K - third:, :] = (rng.random((third, N)) < 0.05).astype(np.int32)
+        # keep every sum below 2^24: the head alone stays under the bound since the tail replaced all-max entries
+        exact = (qx.astype(np.float64) @ qw.astype(np.float64)).astype(np.int64)     # BLAS; exact far below 2^53
+        assert exact.max() < 2 ** 24 and exact.max() > 2 ** 23
+        X, Wt, dX, dW = _packed_pair(torch, oracle, qx, qw, a, w)
+        for engine in ("auto", "mfma"):
+            with use_engine(qgtc, engine):
+                f = qgtc.bitMM2Int(dX, dW, M, K, N, a, w, True).cpu().numpy()
+                c = qgtc.bitMM2Bit_col(dX, dW, M, K, N, a, w, 3)
+            np.testing.assert_array_equal(f.astype(np.int64), exact, err_msg=f"{engine} tail={tail}")
+            np.testing.assert_array_equal(to_np_u32(c), oracle.bitmm2bit(X, Wt, M, K, N, a, w, 3, col=True))
+
+
+@pytest.mark.parametrize("a,w", [(4, 8), (2, 8), (4, 4)])
+def test_float32_exactness_bound_grouped(qgtc, oracle, a, w):
+    """The same edge for the grouped FP4 kernel (k_bitmm_fp4_wave: a <= 4, w <= 8, N <= 64): all-max operands at the
+    largest admitted K and one above (decided from max_K of the launch), all three output modes."""
+    import torch
+    M, N = 40, 33
+    for K in (_kmax(a, w), _kmax(a, w) + 1):
+        rng = np.random.default_rng(K)
+        qx = np.full((M, K), 2 ** a - 1, dtype=np.int32)
+        qw = np.full((K, N), 2 ** w - 1, dtype=np.int32)
+        qx2 = qx.copy()
+        qx2[:, K // 2:] = rng.integers(0, 2, size=(M, K - K // 2))       # a second problem with small late addends
+        X, Wt, dX, dW = _packed_pair(torch, oracle, qx, qw, a, w)
+        X2, _, dX2, _ = _packed_pair(torch, oracle, qx2, qw, a, w)
+        for engine in ("auto", "mfma"):
+            for mode in (0, 1, 2):
+                with use_engine(qgtc, engine):
+                    bg = qgtc.BatchedGemm([dX, dX2], [dW], [(M, K, N)] * 2, a, w, 8, mode, True, False)
+                    bg.run()
+                for o, Xo in zip(bg.outs, (X, X2)):
+                    if mode == 2:
+                        np.testing.assert_array_equal(o.cpu().numpy(), oracle.bitmm2int(Xo, Wt, M, K, N, a, w, True), err_msg=f"K={K} {engine}")
+                    else:
+                        np.testing.assert_array_equal(to_np_u32(o), oracle.bitmm2bit(Xo, Wt, M, K, N, a, w, 8, col=(mode == 1)),
+                                                      err_msg=f"K={K} {engine} mode {mode}")

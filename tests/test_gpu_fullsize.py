@@ -14,7 +14,7 @@ others are size-independent properties of the path that do not involve the oracl
 import numpy as np
 import pytest
 
-from helpers import to_np_u32
+from helpers import ENGINES, to_np_u32, use_engine
 
 pytestmark = pytest.mark.gpu
 
@@ -32,8 +32,13 @@ def _operands(torch, w, seed, density=0.5):
 
 
 @pytest.mark.parametrize("w", [1, 2, 4, 8])
-def test_headline_shape_equals_the_oracle(qgtc, oracle, w):
+@pytest.mark.parametrize("engine", ENGINES)
+def test_headline_shape_equals_the_oracle(qgtc, oracle, w, engine):
+    """Dense random operands at BASELINE.json's headline shape, every engine DIRECTLY against the oracle ("auto" -
+    the default, what bench.py times - runs the FP4 narrow-operand kernel here, "mfma" the same, "popcount" the AND +
+    v_bcnt kernels)."""
     import torch
+    qgtc.set_engine(engine)     # (the autouse fixture puts the default back)
     qa, qx = _operands(torch, w, 10 + w)
     bit_A = qgtc.val2bit(qa, 1, False, False)
     bit_X = qgtc.val2bit(qx, w, True, False)
@@ -127,22 +132,25 @@ def test_every_route_gives_the_same_words(qgtc, w):
     qa, qx = _operands(torch, w, 60 + w, density=0.002)
     qa[:, 1024:3072] = 0                                   # whole k-quads of zeros
     bit_A, bit_X = qgtc.val2bit(qa, 1, False, False), qgtc.val2bit(qx, w, True, False)
-    ref = qgtc.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w)
-    qgtc.set_zero_skip(False)
-    try:
-        assert torch.equal(qgtc.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w), ref)
-    finally:
-        qgtc.set_zero_skip(True)
+    with use_engine(qgtc, "popcount"):
+        ref = qgtc.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w)
+        qgtc.set_zero_skip(False)
+        try:
+            assert torch.equal(qgtc.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w), ref)
+        finally:
+            qgtc.set_zero_skip(True)
     for eng in ("mfma", "auto"):
         qgtc.set_engine(eng)
         try:
             assert torch.equal(qgtc.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w), ref)
         finally:
-            qgtc.set_engine("popcount")
-    for zj in (False, True):
-        bg = qgtc.BatchedGemm([bit_A, bit_A], [bit_X, bit_X], [(M, K, N), (M, K, N)], 1, w, w, 0, True, zj)
-        bg.run()
-        assert torch.equal(bg.outs[0].view(-1), ref.view(-1)) and torch.equal(bg.outs[1].view(-1), ref.view(-1))
+            qgtc.set_engine("auto")
+    for eng in ENGINES:
+        for zj in (False, True):
+            with use_engine(qgtc, eng):
+                bg = qgtc.BatchedGemm([bit_A, bit_A], [bit_X, bit_X], [(M, K, N), (M, K, N)], 1, w, w, 0, True, zj)
+                bg.run()
+            assert torch.equal(bg.outs[0].view(-1), ref.view(-1)) and torch.equal(bg.outs[1].view(-1), ref.view(-1))
 
 
 @pytest.mark.parametrize("a,w,ob", [(1, 1, 1), (2, 2, 2), (1, 4, 4)])
@@ -155,13 +163,12 @@ def test_wide_product_both_engines_and_checksum(qgtc, a, w, ob):
     qa = torch.randint(0, 2 ** a, (M, K), generator=g).to(torch.float32).cuda()
     qx = torch.randint(0, 2 ** w, (K, NW), generator=g).to(torch.float32).cuda()
     bit_A, bit_X = qgtc.val2bit(qa, a, False, False), qgtc.val2bit(qx, w, True, False)
-    pop = (qgtc.bitMM2Bit(bit_A, bit_X, M, K, NW, a, w, ob), qgtc.bitMM2Int(bit_A, bit_X, M, K, NW, a, w, True))
-    qgtc.set_engine("mfma")
-    try:
-        mf = (qgtc.bitMM2Bit(bit_A, bit_X, M, K, NW, a, w, ob), qgtc.bitMM2Int(bit_A, bit_X, M, K, NW, a, w, True))
-    finally:
-        qgtc.set_engine("popcount")
-    assert torch.equal(pop[0], mf[0]) and torch.equal(pop[1], mf[1])
+    with use_engine(qgtc, "popcount"):
+        pop = (qgtc.bitMM2Bit(bit_A, bit_X, M, K, NW, a, w, ob), qgtc.bitMM2Int(bit_A, bit_X, M, K, NW, a, w, True))
+    for eng in ("mfma", "auto"):
+        with use_engine(qgtc, eng):
+            mf = (qgtc.bitMM2Bit(bit_A, bit_X, M, K, NW, a, w, ob), qgtc.bitMM2Int(bit_A, bit_X, M, K, NW, a, w, True))
+        assert torch.equal(pop[0], mf[0]) and torch.equal(pop[1], mf[1]), eng
     row = (qa.to(torch.float64) @ qx.to(torch.float64).sum(1)).to(torch.int64)
     assert torch.equal(mf[1].to(torch.int64).sum(1), row)
 
@@ -176,15 +183,16 @@ def test_mid_width_products_all_engines_and_checksum(qgtc, NW_, w):
     qa = (torch.rand((M, K), generator=g) < 0.3).to(torch.float32).cuda()
     qx = torch.randint(0, 2 ** w, (K, NW_), generator=g).to(torch.float32).cuda()
     bit_A, bit_X = qgtc.val2bit(qa, 1, False, False), qgtc.val2bit(qx, w, True, False)
-    ref = (qgtc.bitMM2Bit(bit_A, bit_X, M, K, NW_, 1, w, w), qgtc.bitMM2Bit_col(bit_A, bit_X, M, K, NW_, 1, w, w),
-           qgtc.bitMM2Int(bit_A, bit_X, M, K, NW_, 1, w, True))
+    with use_engine(qgtc, "popcount"):
+        ref = (qgtc.bitMM2Bit(bit_A, bit_X, M, K, NW_, 1, w, w), qgtc.bitMM2Bit_col(bit_A, bit_X, M, K, NW_, 1, w, w),
+               qgtc.bitMM2Int(bit_A, bit_X, M, K, NW_, 1, w, True))
     for eng in ("mfma", "auto"):
         qgtc.set_engine(eng)
         try:
             got = (qgtc.bitMM2Bit(bit_A, bit_X, M, K, NW_, 1, w, w), qgtc.bitMM2Bit_col(bit_A, bit_X, M, K, NW_, 1, w, w),
                    qgtc.bitMM2Int(bit_A, bit_X, M, K, NW_, 1, w, True))
         finally:
-            qgtc.set_engine("popcount")
+            qgtc.set_engine("auto")
         for x, y in zip(got, ref):
             assert torch.equal(x, y), eng
     row = (qa.to(torch.float64) @ qx.to(torch.float64).sum(1)).to(torch.int64)

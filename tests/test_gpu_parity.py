@@ -4,7 +4,7 @@ bitMM2Int is an exact int->float conversion, so it is compared exactly too."""
 import numpy as np
 import pytest
 
-from helpers import edge_floats, rand_q, to_dev, to_np_u32
+from helpers import ENGINES, edge_floats, rand_q, to_dev, to_np_u32, use_engine
 from qgtc_ppopp22_amd.shapes import P8, P128, S128, cols_shape, rows_shape
 
 pytestmark = pytest.mark.gpu
@@ -86,13 +86,17 @@ def _operands(torch, oracle, rng, M, K, N, a, w, density=None):
 
 @pytest.mark.parametrize("M,K,N,a,w,ob", MM_CASES)
 @pytest.mark.parametrize("zero_skip", [True, False])
-def test_bitmm2bit(qgtc, oracle, M, K, N, a, w, ob, zero_skip):
+@pytest.mark.parametrize("engine", ENGINES)
+def test_bitmm2bit(qgtc, oracle, M, K, N, a, w, ob, zero_skip, engine):
+    """Every engine against the oracle directly ("auto" is the shipped default; plane counts an engine does not
+    cover run on the AND + popcount kernels under any setting)."""
     import torch
     rng = np.random.default_rng(M + 7 * K + 13 * N + a + w)
     qx, qw, X, Wt, dX, dW = _operands(torch, oracle, rng, M, K, N, a, w)
     qgtc.set_zero_skip(zero_skip)
     try:
-        got = qgtc.bitMM2Bit(dX, dW, M, K, N, a, w, ob)
+        with use_engine(qgtc, engine):
+            got = qgtc.bitMM2Bit(dX, dW, M, K, N, a, w, ob)
     finally:
         qgtc.set_zero_skip(True)
     assert tuple(got.shape) == rows_shape(M, N, ob)
@@ -100,24 +104,26 @@ def test_bitmm2bit(qgtc, oracle, M, K, N, a, w, ob, zero_skip):
 
 
 @pytest.mark.parametrize("M,K,N,a,w,ob", MM_CASES)
-def test_bitmm2bit_col(qgtc, oracle, M, K, N, a, w, ob):
+@pytest.mark.parametrize("engine", ENGINES)
+def test_bitmm2bit_col(qgtc, oracle, M, K, N, a, w, ob, engine):
     import torch
     rng = np.random.default_rng(M + 7 * K + 13 * N + a + w + 1)
     qx, qw, X, Wt, dX, dW = _operands(torch, oracle, rng, M, K, N, a, w)
-    got = qgtc.bitMM2Bit_col(dX, dW, M, K, N, a, w, ob)
+    with use_engine(qgtc, engine):
+        got = qgtc.bitMM2Bit_col(dX, dW, M, K, N, a, w, ob)
     assert tuple(got.shape) == cols_shape(M, N, ob)
     np.testing.assert_array_equal(to_np_u32(got), oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob, col=True))
 
 
 @pytest.mark.parametrize("M,K,N,a,w,ob", MM_CASES)
 @pytest.mark.parametrize("pad_128", [True, False])
-@pytest.mark.parametrize("engine", ["popcount", "mfma"])
+@pytest.mark.parametrize("engine", ENGINES)
 def test_bitmm2int(qgtc, oracle, M, K, N, a, w, ob, pad_128, engine):
     qgtc.set_engine(engine)   # (plane counts above 8 stay on the popcount kernels either way)
     try:
         _bitmm2int_case(qgtc, oracle, M, K, N, a, w, ob, pad_128)
     finally:
-        qgtc.set_engine("popcount")
+        qgtc.set_engine("auto")
 
 
 def _bitmm2int_case(qgtc, oracle, M, K, N, a, w, ob, pad_128):
@@ -279,7 +285,7 @@ def test_batched_matches_single(qgtc, oracle):
                                               oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob, col=(mode == 1)))
 
 
-@pytest.mark.parametrize("engine", ["popcount", "mfma"])
+@pytest.mark.parametrize("engine", ENGINES)
 def test_random_shape_sweep(qgtc, oracle, engine):
     """Seeded random sweep over shapes, plane counts, output modes and both launch forms: catches
     what the hand-picked cases miss (tile edges, wave counts, plane blocking, zero rows). Run once per
@@ -287,9 +293,9 @@ def test_random_shape_sweep(qgtc, oracle, engine):
     import torch
     qgtc.set_engine(engine)
     try:
-        _random_shape_sweep(qgtc, oracle, 20260301 if engine == "popcount" else 20260302)
+        _random_shape_sweep(qgtc, oracle, 20260301 + ENGINES.index(engine))
     finally:
-        qgtc.set_engine("popcount")
+        qgtc.set_engine("auto")
 
 
 def _random_shape_sweep(qgtc, oracle, seed):

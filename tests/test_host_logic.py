@@ -106,3 +106,113 @@ def test_gather_over_gloo_world2(n_batches):
     for r, rows, tmax in results:
         assert rows == expect      # every rank sees every batch's row, in global batch order
         assert tmax == 11.0        # max over ranks
+
+
+def test_npz_loader_and_locality_partitioner(tmp_path):
+    """The reference's .npz edge-list format (dataset.py:48-53: arrays src_li / dst_li, node count = largest id + 1)
+    and the METIS-free partitioner standing in for partition_utils.py:11-18: on a planted-block graph whose node
+    ids were shuffled, contiguous id ranges keep almost no edge inside a partition, the locality partitioner keeps
+    a large share - so the cluster batches get their block structure back."""
+    from qgtc_ppopp22_amd import graph as G
+
+    g = G.make_sbm_graph("t", 6000, 100, 8.0, 16, seed=5)
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(g.n_nodes)
+    path = str(tmp_path / "g.npz")
+    np.savez(path, src_li=perm[g.src], dst_li=perm[g.dst])
+    loc = G.load_npz_graph(path, dim=12, psize=100)
+    con = G.load_npz_graph(path, dim=12, psize=100, partitioner="contiguous")
+    for h in (loc, con):
+        assert h.n_nodes == int(max(perm[g.src].max(), perm[g.dst].max())) + 1
+        assert h.feat.shape == (h.n_nodes, 12) and h.feat.dtype == np.float32
+        np.testing.assert_array_equal(h.src, perm[g.src])
+        np.testing.assert_array_equal(h.dst, perm[g.dst])
+        assert h.block_of.shape == (h.n_nodes,) and h.block_of.min() >= 0 and h.block_of.max() < 100
+        parts = G.partition_list(h, 100)
+        assert sorted(np.concatenate(parts).tolist()) == list(range(h.n_nodes))     # a partition of the node set
+    assert np.bincount(loc.block_of, minlength=100).max() <= int(np.ceil(1.05 * loc.n_nodes / 100))
+    assert G.edge_locality(con) < 0.05
+    assert G.edge_locality(loc) > 0.4 and G.edge_locality(loc) > 10 * G.edge_locality(con)
+    # deterministic
+    np.testing.assert_array_equal(G.load_npz_graph(path, dim=12, psize=100).block_of, loc.block_of)
+    # malformed files are rejected
+    bad = str(tmp_path / "bad.npz")
+    np.savez(bad, src_li=np.array([0, 1, 2]), dst_li=np.array([1, 2]))
+    with pytest.raises(ValueError):
+        G.load_npz_graph(bad, 4, 2)
+    np.savez(bad, src_li=np.array([0, -1]), dst_li=np.array([1, 2]))
+    with pytest.raises(ValueError):
+        G.load_npz_graph(bad, 4, 2)
+
+
+def test_zerotile_row_is_what_parse_counter_computes():
+    """driver.zerotile_row against a restatement of parse_counter.py:10-34 run over the log lines the extension
+    prints (`counter_global: %d` / `counter: %d`, cumulative)."""
+    from qgtc_ppopp22_amd import driver
+
+    per_call_total, per_call_nz = [100, 80, 120], [10, 40, 0]
+    cum_g = np.cumsum(per_call_total).tolist()
+    cum_c = np.cumsum(per_call_nz).tolist()
+    log = ["Namespace(batch_size=20, dataset='ppi', dim=10)"]
+    for g_, c_ in zip(cum_g, cum_c):
+        log += [f"counter_global: {g_}", f"counter: {c_}"]
+    log += ["Namespace(batch_size=20, dataset='next', dim=10)"]
+    # parse_counter.py's loop: a line with 'dataset' closes the previous block
+    rows, gcs, cs, name = [], [], [], None
+    for line in log:
+        if "dataset" in line:
+            if name is not None:
+                rows.append((name, sum(gcs), sum(cs), sum(cs) / sum(gcs)))
+            name = line.split(",")[1].split("=")[1].strip("'")
+            gcs, cs = [], []
+        if "counter_global:" in line:
+            gcs.append(int(line.split(":")[1]))
+            continue
+        if "counter:" in line:
+            cs.append(int(line.split(":")[1]))
+    row = driver.zerotile_row("ppi", cum_g, cum_c)
+    assert (row["dataset"], row["non_jumping"], row["jumping"]) == rows[0][:3]
+    assert row["line"] == "{} , {} , {} , {:.3f}".format(*rows[0])
+    assert row["per_epoch_non_jumping"] == 300 and row["per_epoch_jumping"] == 50
+    assert driver.ZEROTILE_HEADER.split(" , ")[0] == "dataset" and "ratio" in driver.ZEROTILE_HEADER
+
+
+def _run_bench(extra, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, cwd=root, env=env,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment must run TWO ranks (the parent spawns them
+    before touching a GPU) and report n_gpus = 2 with one checksum per rank - here in dry mode over gloo."""
+    import json
+
+    out = _run_bench(["--gpus", "2", "--dry-run", "--backend", "gloo", "--steps", "3", "--warmup", "1"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3
+    assert line["extras"]["rank_checksums"] == [1000.0, 1001.0]
+    assert line["extras"]["batches_per_rank"] == [38, 37]    # 75 cluster batches round-robin
+    assert line["max_wall_s"] == pytest.approx(0.002)        # the MAX over ranks
+
+
+def test_bench_fails_loudly_on_a_rank_count_mismatch():
+    """A launcher that started a different number of ranks than --gpus says is an error, never a silent 1-GPU run."""
+    out = _run_bench(["--gpus", "4", "--dry-run", "--backend", "gloo"],
+                     env_extra={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
+
+
+def test_bench_parent_fails_when_a_rank_fails():
+    out = _run_bench(["--gpus", "2", "--dry-run", "--backend", "gloo"], env_extra={"QGTC_BENCH_FAIL_RANK": "1"})
+    assert out.returncode != 0
