@@ -50,7 +50,9 @@ def build_hip(force: bool = False) -> str:
     objs, procs = [], []
     for u in units:
         obj = os.path.join(PKG, os.path.basename(u) + ".o")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Wno-unused-value", f"-I{INC}", "-o", obj, u]
+        # kernels with scalar arguments get them preloaded into SGPRs (no s_load round trip at the head of the kernel)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Wno-unused-value",
+               "-mllvm", "-amdgpu-kernarg-preload-count=16", f"-I{INC}", "-o", obj, u]
         print("[qgtc build]", " ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(obj)

@@ -34,6 +34,12 @@ struct PerDeviceOnce {
     }
 };
 
+// diagnostic switches read once per process (tools/ only; the product never sets them)
+inline bool getenv_flag(const char *name) {
+    const char *v = std::getenv(name);
+    return v && v[0] && v[0] != '0';
+}
+
 inline MMShape base_shape(int a, int w, int ob, int mode) {
     MMShape sh{};
     sh.a = a;

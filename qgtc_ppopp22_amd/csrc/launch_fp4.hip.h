@@ -1,7 +1,49 @@
 // launch_fp4.hip.h — part of libqgtc_hip.so (qgtc_fp4.hip): launchers of the FP4 narrow-operand kernels.
 #pragma once
 
+// bytes of the result (32-bit offsets inside the kernel)
+static size_t one_out_bytes(const qgtc_problem &pr, int ob, int mode) {
+    if (mode == 2) return static_cast<size_t>(pr.M) * pr.N * 4u;
+    if (mode == 1) return static_cast<size_t>(ob) * step128(pr.M) * 4u * pad128(pr.N) * 4u;
+    return static_cast<size_t>(ob) * pad8(pr.M) * step128(pr.N) * 4u * 4u;
+}
+static bool one_ok(const qgtc_problem &pr, int ob, int mode) {
+    return pr.K <= ONE_MAX_K && (mode == 2 || ob <= 23) && pr.M < (1 << 24) && one_out_bytes(pr, ob, mode) < (1ull << 32);
+}
+
+// K <= 4096: one super-step per wave, the latency-trimmed kernel (bitmm_fp4_one.hip.h)
+static int launch_one(const qgtc_problem &pr, int a, int w, int ob, int mode, bool zero_skip, hipStream_t st) {
+    const bool wide = pr.N > 32 || mode == 1;   // 32 x 32 tiles (two column tiles at N = 64), else 16 x 32
+    const dim3 grid(wide ? (pr.M + 31) / 32 : (pr.M + 15) / 16, (pr.N + 31) / 32), block(64 * ONE_WAVES);
+    const uint32_t cfg = static_cast<uint32_t>(a) | static_cast<uint32_t>(w) << 8 | static_cast<uint32_t>(mode == 2 ? 1 : ob) << 16 |
+                         (zero_skip ? 1u : 0u) << 24
+#ifdef QGTC_ABL
+                         | (getenv_flag("ABL_X") ? 1u << 28 : 0u) | (getenv_flag("ABL_W") ? 1u << 29 : 0u)
+#endif
+        ;
+    const uint32_t xb = static_cast<uint32_t>(pr.x_words * 4u), wb = static_cast<uint32_t>(pr.w_words * 4u);
+    const uint32_t ob_ = static_cast<uint32_t>(one_out_bytes(pr, ob, mode));
+#define QGTC_ONE_GO(NA_, NW_, MODE_, RF_)                                                                          \
+    hipLaunchKernelGGL((k_bitmm_fp4_one<NA_, NW_, MODE_, RF_, 2>), grid, block, 0, st, pr.X, pr.W, pr.out, xb, wb, ob_, pr.M, \
+                       pr.K, pr.N, pr.w_lines, cfg)
+#define QGTC_ONE_LAUNCH(NA_, NW_)                                       \
+    if (!done && a <= NA_ && w <= NW_) {                                \
+        done = true;                                                    \
+        if (mode == 1) { QGTC_ONE_GO(NA_, NW_, 1, 2); }                 \
+        else if (mode == 2) { if (wide) { QGTC_ONE_GO(NA_, NW_, 2, 2); } else { QGTC_ONE_GO(NA_, NW_, 2, 1); } } \
+        else { if (wide) { QGTC_ONE_GO(NA_, NW_, 0, 2); } else { QGTC_ONE_GO(NA_, NW_, 0, 1); } }                \
+    }
+    bool done = false;
+    QGTC_ONE_LAUNCH(1, 1) QGTC_ONE_LAUNCH(1, 2) QGTC_ONE_LAUNCH(1, 4) QGTC_ONE_LAUNCH(1, 8)
+    QGTC_ONE_LAUNCH(2, 1) QGTC_ONE_LAUNCH(2, 2) QGTC_ONE_LAUNCH(2, 4) QGTC_ONE_LAUNCH(2, 8)
+#undef QGTC_ONE_LAUNCH
+#undef QGTC_ONE_GO
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
 int qgtc_launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, bool zero_skip, hipStream_t st) {
+    if (one_ok(pr, ob, mode) && !getenv_flag("QGTC_NO_ONE")) return launch_one(pr, a, w, ob, mode, zero_skip, st);
     MMShape sh = base_shape(a, w, ob, mode);
     sh.nowrap = 1;
     const int zs = zero_skip ? 1 : 0;

@@ -15,5 +15,6 @@
 #include "bitmm_mfma.hip.h"       // expand_word_fp4, or_with_partner_half, vector types
 #include "bitmm_fp4_skinny.hip.h"
 #include "bitmm_fp4_wave.hip.h"
+#include "bitmm_fp4_one.hip.h"
 #include "launch_common.hip.h"
 #include "launch_fp4.hip.h"

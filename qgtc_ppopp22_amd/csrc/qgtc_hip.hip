@@ -45,6 +45,7 @@
 #ifdef QGTC_SINGLE_TU   // tools/kbench.hip: everything in one translation unit
 #include "bitmm_fp4_skinny.hip.h"
 #include "bitmm_fp4_wave.hip.h"
+#include "bitmm_fp4_one.hip.h"
 #include "launch_fp4.hip.h"
 #include "launch_mfma.hip.h"
 #endif
