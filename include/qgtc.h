@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QGTC_ABI_VERSION 4
+#define QGTC_ABI_VERSION 5
 
 enum {
     QGTC_OK = 0,
@@ -55,6 +55,8 @@ enum {
                                   Grouped launches whose problems carry a one-word occupancy bitmap
                                   (K <= 8192) jump all-zero 128-row x 128-bit tiles */
 #define QGTC_ENGINE_AUTO 0x10u /* let rules fitted to MI355X measurements choose between the two engines */
+#define QGTC_LAYER_ONE_LAUNCH 0x20u /* qgtc_gcn_layer_batched: both products of the layer in ONE launch (in-launch
+                                  hand-off through per-batch arrival counters) instead of two grouped launches */
 
 int qgtc_abi_version(void);
 const char *qgtc_strerror(int code);
@@ -161,6 +163,26 @@ int qgtc_tile_occupancy_decide(qgtc_problem *problems, int count, float max_frac
 int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int max_K, int max_N,
                        int bit1, int bit2, int output_bit, int mode, unsigned flags,
                        void *stream);
+
+/* One quantised GNN layer for `count` cluster batches in ONE launch - the fused form of the reference's per-layer
+ * pair (QGTC_conv.py:14-22: X.W, then A.(XW); main_qgtc.py:147-154 issues it as two extension calls per batch):
+ *   stage 1   T_b   = bitMM2Bit_col(X_b, W, x_bits, w_bits, t_bits)        (cols-layout bits, written to stage1[b].out)
+ *   stage 2   out_b = bitMM2Bit(A_b, T_b, a_bits, t_bits, output_bit)      mode 0: rows-layout bits
+ *                   = bitMM2Int(A_b, T_b, a_bits, t_bits, pad_128 = 1)     mode 2: float32
+ * stage1[b] = {X_b, W, T_b, .., M = n_b, K = f_in, N = f_out}, stage2[b] = {A_b, T_b, out_b, .., M = n_b, K = n_b,
+ * N = f_out} (stage2[b].W must be stage1[b].out; w_lines = PAD128(N) in both). Results are word for word those of the
+ * two grouped launches - which is also how the call runs by default: measured on MI355X the two launches are the
+ * faster form (30 us against 35 us for a 75-batch 128-wide layer). With QGTC_LAYER_ONE_LAUNCH (and
+ * QGTC_ENGINE_AUTO / _MFMA) both stages share one launch: stage 2 of a batch starts as soon as the stage-1 tiles of THAT
+ * batch have arrived (one arrival counter per batch, `arrival`: `count` x QGTC_ARRIVAL_STRIDE words - batch b's counter is word
+ * b * QGTC_ARRIVAL_STRIDE - zeroed ONCE when the plan is made and never reset; `epoch` =
+ * 1, 2, 3.. counts the launches made with these counters). max_* are hard preconditions as for qgtc_bitmm_batched.
+ * `arrival` may be NULL when QGTC_LAYER_ONE_LAUNCH is not set. Plane counts the one-launch kernels do not cover run as
+ * the two grouped launches - same results, same call. */
+#define QGTC_ARRIVAL_STRIDE 64   /* 32-bit words between the arrival counters of two batches (one 256-byte line each) */
+int qgtc_gcn_layer_batched(const qgtc_problem *stage1, const qgtc_problem *stage2, int count, int max_M, int max_K1,
+                           int max_K2, int max_N, int x_bits, int w_bits, int t_bits, int a_bits, int output_bit,
+                           int mode, uint32_t *arrival, uint32_t epoch, unsigned flags, void *stream);
 
 /* Adjacency bit planes from an edge list — replaces the dense detour of sampler.py:80-101
  * (torch.sparse.FloatTensor(...).to_dense() then QGTC.val2bit(A, nbits, False, False)): the n x n

@@ -25,10 +25,9 @@ class Aggregation_Qnt(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, bit_A, bit_X, bit_W, n, f_in, f_out, act_bit, w_bit, output=False):
-        xw = QGTC.bitMM2Bit_col(bit_X, bit_W, n, f_in, f_out, act_bit, w_bit, act_bit)
-        if output:
-            return QGTC.bitMM2Int(bit_A, xw, n, n, f_out, 1, act_bit, True)
-        return QGTC.bitMM2Bit(bit_A, xw, n, n, f_out, 1, act_bit, act_bit)
+        # one extension call per layer (the library's fused-layer entry, qgtc_gcn_layer_batched): X.W re-packed in the
+        # cols layout, then A.(XW); word for word what bitMM2Bit_col followed by bitMM2Bit / bitMM2Int returns
+        return QGTC.gcn_layer(bit_A, bit_X, bit_W, n, f_in, f_out, 1, act_bit, w_bit, output)
 
     @staticmethod
     def backward(ctx, d_output):  # the reference has no training path (QGTC_conv.py:24-27)

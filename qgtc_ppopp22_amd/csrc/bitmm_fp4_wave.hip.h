@@ -22,17 +22,16 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // RF x CF fragments of 16 lines per wave (2 x 2 = 32 x 32 outputs is what is launched; 4 x 4 was measured: with
 // 2850 waves for an epoch stage the chip is not filled and every wave's long serial chain is exposed).
-template <int NA, int NW, int MODE, int RF, int CF>
-__global__ __launch_bounds__(64) void k_bitmm_fp4_wave(const qgtc_problem *__restrict__ prs, MMShape sh, int zero_skip) {
+template <int NA, int NW, int MODE, int RF, int CF, bool PUB = false, bool WCOH = false>
+__device__ __forceinline__ void fw_tile(const qgtc_problem &pr, const MMShape &sh, int zero_skip, int tile) {
     static_assert(RF % 2 == 0 && CF % 2 == 0, "whole 32-bit output words");
     constexpr int TR = 16 * RF, TC = 16 * CF;
     constexpr int DEPTH = (RF * NA + CF * NW) <= 12 ? 2 : 1;
     constexpr int NDA = (NA + 1) / 2, NDW = (NW + 1) / 2;  // base-4 digits
-    const qgtc_problem pr = prs[blockIdx.y];
     const int M = pr.M, K = pr.K, N = pr.N;
     const int tiles_m = (M + TR - 1) / TR, tiles_n = (N + TC - 1) / TC;
-    if (static_cast<int>(blockIdx.x) >= tiles_m * tiles_n) return;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    if (tile >= tiles_m * tiles_n) return;
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
     const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
     const int m0 = tm * TR, n0 = tn * TC;
     const int kq = step128(K);
@@ -87,7 +86,7 @@ __global__ __launch_bounds__(64) void k_bitmm_fp4_wave(const qgtc_problem *__res
         for (int j = 0; j < CF; j++)
 #pragma unroll
             for (int p = 0; p < NW; p++)
-                wd[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && w_ok[j] && p < sh.w) ? static_cast<uint32_t>(p) * w_plane * 4u + w_off[j] + ko : 0xffffffffu, 0, 0);
+                wd[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rw, (in && w_ok[j] && p < sh.w) ? static_cast<uint32_t>(p) * w_plane * 4u + w_off[j] + ko : 0xffffffffu, 0, WCOH ? AUX_SC1 : 0);
         return S < nss;
     };
     bool have[DEPTH];
@@ -192,10 +191,10 @@ __global__ __launch_bounds__(64) void k_bitmm_fp4_wave(const qgtc_problem *__res
                         // column 32 jw + 16 jj + li at bit 31 - 16 jj - li of word jw
                         const uint32_t x = (((q[i][2 * jw][r] >> p) & 1u) << 16 | ((q[i][2 * jw + 1][r] >> p) & 1u)) << (15 - li);
                         const uint32_t wrd = or_reduce_group<2>(x);   // the 16 lanes of the DPP row
-                        if (li == 0 && m < rows_pad && word0 + jw < row_words) dst[jw] = wrd;
+                        if (li == 0 && m < rows_pad && word0 + jw < row_words) st_word<PUB>(dst + jw, wrd);
                     }
                     if (li == 0 && m < rows_pad)
-                        for (int e = 0; e < extra; e++) dst[CF / 2 + e] = 0u;
+                        for (int e = 0; e < extra; e++) st_word<PUB>(dst + CF / 2 + e, 0u);
                 }
             }
     } else {  // cols layout [ob][PAD128(N)][STEP128(M)*4] (intended semantics of kernel.h:651-810): word (n, m / 32)
@@ -219,7 +218,7 @@ __global__ __launch_bounds__(64) void k_bitmm_fp4_wave(const qgtc_problem *__res
                     const auto s16 = __builtin_amdgcn_permlane16_swap(x, x, false, false);   // rows of 16 lanes: (0,1), (2,3)
                     x = s16[0] | s16[1];
                     x = or_with_partner_half(x);                                            // halves of the wave
-                    if (g == 0 && n < lines && word0 + iw < line_words) dst[iw] = x;
+                    if (g == 0 && n < lines && word0 + iw < line_words) st_word<PUB>(dst + iw, x);
                 }
             }
         }
@@ -230,17 +229,23 @@ __global__ __launch_bounds__(64) void k_bitmm_fp4_wave(const qgtc_problem *__res
             for (int e = lane; e < sh.ob * TC; e += 64) {
                 const int line = n0 + e % TC, p = e / TC;
                 if (line < lines)
-                    for (int wi = w_core1; wi < line_words; wi++) out[p * oplane + static_cast<size_t>(line) * line_words + wi] = 0u;
+                    for (int wi = w_core1; wi < line_words; wi++) st_word<PUB>(out + p * oplane + static_cast<size_t>(line) * line_words + wi, 0u);
             }
         }
         if (last_n && n0 + TC < lines) {
             const int nl = lines - (n0 + TC), w_end = last_m ? line_words : w_core1;
             for (int e = lane; e < sh.ob * nl; e += 64) {
                 const int line = n0 + TC + e % nl, p = e / nl;
-                for (int wi = word0; wi < w_end; wi++) out[p * oplane + static_cast<size_t>(line) * line_words + wi] = 0u;
+                for (int wi = word0; wi < w_end; wi++) st_word<PUB>(out + p * oplane + static_cast<size_t>(line) * line_words + wi, 0u);
             }
         }
     }
+}
+
+template <int NA, int NW, int MODE, int RF, int CF>
+__global__ __launch_bounds__(64) void k_bitmm_fp4_wave(const qgtc_problem *__restrict__ prs, MMShape sh, int zero_skip) {
+    const qgtc_problem pr = prs[blockIdx.y];
+    fw_tile<NA, NW, MODE, RF, CF>(pr, sh, zero_skip, static_cast<int>(blockIdx.x));
 }
 
 }  // namespace

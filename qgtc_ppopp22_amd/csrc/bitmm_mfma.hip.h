@@ -99,7 +99,9 @@ __device__ __forceinline__ uint32_t or_with_partner_half(uint32_t x) {
 // 64-bit word per 32-row tile, i.e. K <= 8192) the workgroup ORs the words of its four row tiles and
 // visits only the k-quads whose 128-row x 128-bit X tile has a bit set - every wave derives the same
 // sequence from the same scalar loads, so the expander / multiplier hand-over needs nothing extra.
-template <int MAXP, int EXPW, bool FP4 = false>
+// WCOH: the right operand was written by other workgroups of THIS launch (fused layer, stage 2): its loads carry
+// agent scope (sc1: served from the memory side, never from a line this XCD's L2 filled before the writer was done).
+template <int MAXP, int EXPW, bool FP4 = false, bool PUB = false, bool WCOH = false>
 __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &sh, int tm, int tn,
                                         unsigned char *smem) {
     static_assert(!FP4 || MAXP <= 2, "the FP4 form holds 2-bit values at most");
@@ -193,7 +195,7 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
                     const bool ok = line_ok && p < planes && q < kq;
                     const uint32_t off = ok ? static_cast<uint32_t>(p) * plane_words * 4u + base + static_cast<uint32_t>(q) * 16u : 0xffffffffu;
                     dst[j][p] = is_x ? __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0)
-                                     : __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0);
+                                     : __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, WCOH ? AUX_SC1 : 0);
                 }
             }
         };
@@ -451,7 +453,7 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
                                              ((P[2] >> p) & 0x01010101u) << 1 | ((P[3] >> p) & 0x01010101u);
                                 w <<= lane_sh;                       // bits 7 - t - 4 fh of every byte
                                 w = or_with_partner_half(w);
-                                if (store) dst[0] = w & emask;
+                                if (store) st_word<PUB>(dst, w & emask);
                             }
                         } else {
                             for (int p = 0; p < sh.ob; p++, dst += oplane) {
@@ -460,7 +462,7 @@ __device__ __forceinline__ void mf_tile(const qgtc_problem &pr, const MMShape &s
                                 for (int r = 0; r < 16; r++) w |= ((q[r] >> p) & 1u) << (31 - ((r & 3) + 8 * (r >> 2)));
                                 w >>= 4 * fh;
                                 w = or_with_partner_half(w);
-                                if (store) dst[0] = w & emask;
+                                if (store) st_word<PUB>(dst, w & emask);
                             }
                         }
                     }

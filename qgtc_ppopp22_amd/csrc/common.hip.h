@@ -57,6 +57,18 @@ __device__ __forceinline__ uint32_t quant1(float x, float ub, float ubm1) {
     return r >= 4294967296.0f ? 0u : static_cast<uint32_t>(r);  // low 32 bits (nbits >= 31 only)
 }
 
+constexpr int AUX_SC1 = 16;   // cache-policy operand of the raw buffer builtins on gfx940+: bit 4 = sc1 (agent scope)
+
+// A packed output word. PUB = the fused layer's first stage: the word is read by OTHER workgroups (possibly on another
+// XCD, whose L2 is not coherent with ours) later in the same launch, so it is stored with agent scope (write-through,
+// `sc1`) instead of being left dirty in this XCD's L2 (MI355X_MICROARCH.md: publish with write-through stores, then a
+// drained flag).
+template <bool PUB>
+__device__ __forceinline__ void st_word(uint32_t *p, uint32_t v) {
+    if (PUB) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 // OR over aligned groups of 8 lanes (every lane of the wave must be active)
 __device__ __forceinline__ uint32_t or_reduce8(uint32_t x) {
     x |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0xB1, 0xf, 0xf, false));   // lane ^ 1

@@ -3,6 +3,7 @@
 // matrix-core kernels, which live in their own translation units (all compiled in parallel).
 #pragma once
 
+#include <algorithm>
 #include <atomic>
 
 // defined in qgtc_mfma.hip
@@ -13,6 +14,19 @@ int qgtc_launch_mfma_batched(const qgtc_problem *prs, int count, int max_M, int 
 int qgtc_launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, bool zero_skip, hipStream_t st);
 int qgtc_launch_fp4_wave(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode,
                          bool zero_skip, hipStream_t st);
+
+// fused GNN layer (bitmm_layer.hip.h): defined in qgtc_mfma.hip (wide layers) and qgtc_fp4.hip (narrow layers)
+struct LayerArgs {
+    const qgtc_problem *p1, *p2;
+    uint32_t *arrival;
+    int count, max_M, max_K1, max_K2, max_N;
+    int a1, w1, ob1;       // stage 1: planes of X, planes of W, bits of T
+    int a2, ob2, mode2;    // stage 2: planes of A, output bits, 0 rows-layout bits / 2 float32
+    uint32_t epoch;
+    bool zero_skip;
+};
+int qgtc_launch_layer_mfma(const LayerArgs &la, hipStream_t st);
+int qgtc_launch_layer_wave(const LayerArgs &la, hipStream_t st);
 
 namespace {
 
@@ -90,6 +104,12 @@ inline bool auto_prefers_skinny(int M, int K, int N, int a, int w) {
 // still (24 / 41 us: 2850 waves do not fill the chip).
 inline bool fp4_wave_ok(int K, int N, int a, int w) {
     return N <= 64 && a <= 4 && w <= 8 && static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
+}
+
+// slots between a batch's two stages in the fused layer launch: about half a chip of resident workgroups
+inline int layer_delay(int per_slot, int resident) {
+    if (const char *e = std::getenv("QGTC_LAYER_DELAY")) return std::max(0, std::atoi(e));   // (tuning only)
+    return std::max(1, resident / (2 * std::max(per_slot, 1)));
 }
 
 // the MFMA engine handles up to 8 planes per operand (8: offset by 128, corrected in the epilogue)

@@ -92,3 +92,32 @@ int qgtc_launch_fp4_wave(const qgtc_problem *prs, int count, int max_M, int max_
     return QGTC_OK;
 }
 
+
+// fused GNN layer, narrow form: both stages with one wave per 32 x 32 tile in one launch (bitmm_layer.hip.h)
+int qgtc_launch_layer_wave(const LayerArgs &la, hipStream_t st) {
+    LayerShape ls{};
+    ls.sh1 = base_shape(la.a1, la.w1, la.ob1, 1);
+    ls.sh1.nowrap = 1;
+    ls.sh2 = base_shape(la.a2, la.ob1, la.mode2 == 2 ? 1 : la.ob2, la.mode2);
+    ls.sh2.nowrap = 1;
+    const int tiles = ((la.max_M + 31) / 32) * ((la.max_N + 31) / 32);
+    ls.t1 = ls.t2 = tiles;
+    ls.count = la.count;
+    ls.delay = layer_delay(16 * tiles, 4096);     // in octets of batches
+    ls.epoch = la.epoch;
+    ls.zero_skip = la.zero_skip;
+    const dim3 grid(static_cast<unsigned>(((la.count + 7) / 8 + ls.delay) * 16 * tiles));
+    const int na = std::max(la.a1, la.a2), nw = std::max(la.w1, la.ob1);   // plane capacities covering both stages
+#define QGTC_LW_LAUNCH(NA_, NW_)                                                                                   \
+    if (!done && na <= NA_ && nw <= NW_) {                                                                         \
+        done = true;                                                                                               \
+        if (la.mode2 == 2) hipLaunchKernelGGL((k_layer_wave<NA_, NW_, 2>), grid, dim3(64), 0, st, la.p1, la.p2, la.arrival, ls); \
+        else hipLaunchKernelGGL((k_layer_wave<NA_, NW_, 0>), grid, dim3(64), 0, st, la.p1, la.p2, la.arrival, ls);               \
+    }
+    bool done = false;
+    QGTC_LW_LAUNCH(1, 1) QGTC_LW_LAUNCH(1, 2) QGTC_LW_LAUNCH(2, 2) QGTC_LW_LAUNCH(2, 4) QGTC_LW_LAUNCH(4, 4) QGTC_LW_LAUNCH(4, 8)
+#undef QGTC_LW_LAUNCH
+    if (!done) return QGTC_EINVAL;
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}

@@ -46,6 +46,9 @@
 #include "bitmm_fp4_skinny.hip.h"
 #include "bitmm_fp4_wave.hip.h"
 #include "bitmm_fp4_one.hip.h"
+#define QGTC_LAYER_MFMA 1
+#define QGTC_LAYER_WAVE 1
+#include "bitmm_layer.hip.h"
 #include "launch_fp4.hip.h"
 #include "launch_mfma.hip.h"
 #endif
@@ -257,6 +260,33 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
     if (flags & QGTC_ZERO_JUMP)  // the descriptors carry occupancy bitmaps (qgtc_tile_occupancy)
         return dispatch_batched<true, true>(problems, count, max_M, max_N, k_hint, bit1, bit2, ob_, mode, st);
     return dispatch_batched<true, false>(problems, count, max_M, max_N, k_hint, bit1, bit2, ob_, mode, st);
+}
+
+int qgtc_gcn_layer_batched(const qgtc_problem *stage1, const qgtc_problem *stage2, int count, int max_M, int max_K1,
+                           int max_K2, int max_N, int x_bits, int w_bits, int t_bits, int a_bits, int output_bit,
+                           int mode, uint32_t *arrival, uint32_t epoch, unsigned flags, void *stream) {
+    if (!stage1 || !stage2 || count <= 0 || count > 65535) return QGTC_EINVAL;
+    if (max_M <= 0 || max_K1 <= 0 || max_K2 <= 0 || max_N <= 0) return QGTC_EINVAL;
+    const bool one_launch = (flags & QGTC_LAYER_ONE_LAUNCH) != 0u;
+    if (one_launch && (!arrival || epoch == 0u)) return QGTC_EINVAL;
+    if (!bits_ok(x_bits) || !bits_ok(w_bits) || !bits_ok(t_bits) || !bits_ok(a_bits)) return QGTC_EINVAL;
+    if (mode != 0 && mode != 2) return QGTC_EINVAL;
+    if (mode == 0 && !bits_ok(output_bit)) return QGTC_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const LayerArgs la{stage1, stage2, arrival, count, max_M, max_K1, max_K2, max_N, x_bits, w_bits, t_bits,
+                       a_bits, output_bit, mode, epoch, !(flags & QGTC_NO_ZERO_SKIP)};
+    // Default: the two grouped launches (measured faster, bitmm_layer.hip.h). The one-launch forms run on the matrix
+    // cores: they need QGTC_LAYER_ONE_LAUNCH and QGTC_ENGINE_AUTO / _MFMA and plane counts inside their range.
+    const bool want = one_launch && (flags & (QGTC_ENGINE_AUTO | QGTC_ENGINE_MFMA)) != 0u;
+    if (want && max_N <= 64 && fp4_wave_ok(max_K1, max_N, x_bits, w_bits) && fp4_wave_ok(max_K2, max_N, a_bits, t_bits) &&
+        std::max(x_bits, a_bits) <= 4 && std::max(w_bits, t_bits) <= 8)
+        return qgtc_launch_layer_wave(la, st);
+    if (want && max_N > 64 && max_M >= 128 && mfma_ok(x_bits, w_bits) && mfma_ok(a_bits, t_bits))
+        return qgtc_launch_layer_mfma(la, st);
+    const unsigned f2 = flags & ~QGTC_LAYER_ONE_LAUNCH;
+    int rc = qgtc_bitmm_batched(stage1, count, max_M, max_K1, max_N, x_bits, w_bits, t_bits, 1, f2 & ~QGTC_ZERO_JUMP, stream);
+    if (rc != QGTC_OK) return rc;
+    return qgtc_bitmm_batched(stage2, count, max_M, max_K2, max_N, a_bits, t_bits, mode == 2 ? 1 : output_bit, mode, f2, stream);
 }
 
 size_t qgtc_occupancy_words(int M, int K) {

@@ -19,6 +19,7 @@
 #include <array>
 #include <atomic>
 #include <cstdio>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -566,6 +567,88 @@ struct BatchedGemm {
     }
 };
 
+// One quantised GNN layer for all cluster batches in ONE launch (qgtc_gcn_layer_batched): stage1 = the grouped
+// bitMM2Bit_col X.W (mode 1), stage2 = the grouped A.(XW) whose right operands ARE stage1's outputs. Owns the
+// per-batch arrival counters (zeroed once; monotonic) and counts its own launches.
+struct FusedLayer {
+    std::shared_ptr<BatchedGemm> s1, s2;
+    torch::Tensor arrival;   // int32 [count x QGTC_ARRIVAL_STRIDE], device
+    uint32_t epoch = 0;
+    bool one_launch = false;  // both stages in one launch (in-launch hand-off); default: two grouped launches (faster)
+
+    FusedLayer(std::shared_ptr<BatchedGemm> stage1, std::shared_ptr<BatchedGemm> stage2, bool one_launch_)
+        : s1(std::move(stage1)), s2(std::move(stage2)), one_launch(one_launch_) {
+        TORCH_CHECK(s1 && s2, "FusedLayer needs two BatchedGemm plans");
+        TORCH_CHECK(s1->count == s2->count, "both stages must cover the same cluster batches");
+        TORCH_CHECK(s1->mode == 1, "stage 1 must produce cols-layout bits (mode 1: it is stage 2's right operand)");
+        TORCH_CHECK(s2->mode == 0 || s2->mode == 2, "stage 2 must produce rows-layout bits (mode 0) or float32 (mode 2)");
+        TORCH_CHECK(s1->ob == s2->bit2, "stage 1's output bits must be stage 2's right-operand planes");
+        TORCH_CHECK(s1->descs.device() == s2->descs.device(), "both stages must live on one device");
+        for (int i = 0; i < s1->count; i++) {
+            const qgtc_problem &a = s1->host_descs[i], &b = s2->host_descs[i];
+            TORCH_CHECK(b.W == static_cast<const uint32_t *>(a.out), "stage 2's right operand ", i, " must be stage 1's output ", i);
+            TORCH_CHECK(a.M == b.M && a.M == b.K && a.N == b.N, "batch ", i, ": stage shapes do not chain (n x f_in x f_out, then n x n x f_out)");
+            TORCH_CHECK(b.w_lines == P128(b.N), "stage 2 reads a cols-layout operand with PAD128 lines");
+        }
+        c10::DeviceGuard guard(s1->descs.device());
+        arrival = torch::zeros({static_cast<int64_t>(s1->count) * QGTC_ARRIVAL_STRIDE}, torch::TensorOptions().dtype(torch::kInt32).device(s1->descs.device()));
+    }
+
+    void run() {
+        c10::DeviceGuard guard(s1->descs.device());
+        epoch++;
+        if (epoch == 0u) {   // 2^32 launches: start the counters over
+            arrival.zero_();
+            epoch = 1;
+        }
+        check_rc(qgtc_gcn_layer_batched(reinterpret_cast<const qgtc_problem *>(s1->descs.data_ptr()),
+                                        reinterpret_cast<const qgtc_problem *>(s2->descs.data_ptr()), s1->count,
+                                        std::max(s1->max_M, s2->max_M), s1->max_K, s2->max_K, std::max(s1->max_N, s2->max_N),
+                                        s1->bit1, s1->bit2, s1->ob, s2->bit1, s2->ob, s2->mode,
+                                        reinterpret_cast<uint32_t *>(arrival.data_ptr<int32_t>()), epoch,
+                                        mm_flags() | (s2->jump_asked ? QGTC_ZERO_JUMP : 0u) | (one_launch ? QGTC_LAYER_ONE_LAUNCH : 0u),
+                                        current_stream(arrival)),
+                 "FusedLayer.run");
+    }
+};
+
+// One quantised GNN layer on ONE subgraph in one launch: requant(A . requant(X . W)) (QGTC_conv.py:14-22). bit_A: rows
+// layout, 1.. planes, [n, n]; bit_X: rows layout [n, f_in]; bit_W: cols layout [f_in, f_out]. Returns the packed
+// activations (rows layout, act_bit planes) or, with output = true, float32 [n, f_out].
+torch::Tensor gcn_layer(torch::Tensor bit_A, torch::Tensor bit_X, torch::Tensor bit_W, int n, int f_in, int f_out,
+                        int a_bit, int act_bit, int w_bit, bool output, bool one_launch) {
+    CHECK_INPUT(bit_A);
+    CHECK_INPUT(bit_X);
+    CHECK_INPUT(bit_W);
+    check_bits_tensor(bit_A, "bit_A");
+    check_bits_tensor(bit_X, "bit_X");
+    check_bits_tensor(bit_W, "bit_W");
+    TORCH_CHECK(bit_A.device() == bit_X.device() && bit_A.device() == bit_W.device(), "all operands must share a device");
+    TORCH_CHECK(n > 0 && f_in > 0 && f_out > 0, "bad dimensions");
+    TORCH_CHECK(bit_A.numel() < (1LL << 30) && bit_X.numel() < (1LL << 30) && bit_W.numel() < (1LL << 30), "packed operand too large (>= 4 GiB)");
+    const auto dev = bit_A.device();
+    c10::DeviceGuard guard(dev);
+    const auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(dev);
+    torch::Tensor T = torch::empty({static_cast<int64_t>(act_bit) * S128(n) * 4, P128(f_out)}, i32);   // QGTC_device.cu:456
+    torch::Tensor out = output ? torch::empty({n, f_out}, torch::TensorOptions().dtype(torch::kFloat32).device(dev))
+                               : torch::empty({static_cast<int64_t>(act_bit) * P8(n), S128(f_out) * 4}, i32);   // QGTC_device.cu:223
+    qgtc_problem h[2];
+    h[0] = qgtc_problem{words(bit_X), words(bit_W), T.data_ptr(), static_cast<uint64_t>(bit_X.numel()), static_cast<uint64_t>(bit_W.numel()),
+                        n, f_in, f_out, P128(f_out), 0, nullptr};
+    h[1] = qgtc_problem{words(bit_A), words(T), out.data_ptr(), static_cast<uint64_t>(bit_A.numel()), static_cast<uint64_t>(T.numel()),
+                        n, n, f_out, P128(f_out), 0, nullptr};
+    auto host = torch::empty({static_cast<int64_t>(2 * sizeof(qgtc_problem))}, torch::TensorOptions().dtype(torch::kUInt8));
+    std::memcpy(host.data_ptr(), h, sizeof(h));
+    torch::Tensor descs = host.to(dev);
+    torch::Tensor arrival = torch::zeros({QGTC_ARRIVAL_STRIDE}, i32);
+    const qgtc_problem *dp = reinterpret_cast<const qgtc_problem *>(descs.data_ptr());
+    check_rc(qgtc_gcn_layer_batched(dp, dp + 1, 1, n, f_in, n, f_out, act_bit, w_bit, act_bit, a_bit, act_bit, output ? 2 : 0,
+                                    reinterpret_cast<uint32_t *>(arrival.data_ptr<int32_t>()), 1u,
+                                    mm_flags() | (one_launch ? QGTC_LAYER_ONE_LAUNCH : 0u), current_stream(bit_A)),
+             "gcn_layer");
+    return out;   // (T, descs and arrival go back to the stream-ordered allocator: reuse happens behind this launch)
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -645,7 +728,21 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("i8gemm_profile", &i8gemm_profile, "time `reps` i8gemm launches; returns milliseconds",
           py::arg("A"), py::arg("Bt"), py::arg("reps") = 200, py::arg("print") = true);
 
-    py::class_<BatchedGemm>(m, "BatchedGemm")
+    m.def("gcn_layer", &gcn_layer, "one quantised GNN layer on a subgraph in one call: requant(A . requant(X . W)) "
+          "(QGTC_conv.py:14-22); packed activations, or float32 with output=True",
+          py::arg("bit_A"), py::arg("bit_X"), py::arg("bit_W"), py::arg("n"), py::arg("f_in"), py::arg("f_out"),
+          py::arg("a_bit") = 1, py::arg("act_bit") = 2, py::arg("w_bit") = 2, py::arg("output") = false,
+          py::arg("one_launch") = false);
+
+    py::class_<FusedLayer>(m, "FusedLayer")
+        .def(py::init<std::shared_ptr<BatchedGemm>, std::shared_ptr<BatchedGemm>, bool>(), py::arg("stage1"), py::arg("stage2"),
+             py::arg("one_launch") = false)
+        .def("run", &FusedLayer::run, "one call per layer: X.W (cols-layout re-pack) then A.(XW) for every cluster batch")
+        .def_readonly("one_launch", &FusedLayer::one_launch)
+        .def_readonly("arrival", &FusedLayer::arrival)
+        .def_property_readonly("outs", [](const FusedLayer &f) { return f.s2->outs; });
+
+    py::class_<BatchedGemm, std::shared_ptr<BatchedGemm>>(m, "BatchedGemm")
         .def(py::init<std::vector<torch::Tensor>, std::vector<torch::Tensor>,
                       std::vector<std::tuple<int, int, int>>, int, int, int, int, bool, bool,
                       std::vector<torch::Tensor>>(),

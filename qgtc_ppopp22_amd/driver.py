@@ -57,6 +57,12 @@ def build_parser() -> argparse.ArgumentParser:
     # additions
     p.add_argument("--chain", choices=["reference", "correct"], default="reference")
     p.add_argument("--batched", action="store_true", help="one grouped launch per operator per epoch")
+    p.add_argument("--no-fuse", action="store_true",
+                   help="with --batched --chain correct: issue the two products of a layer as two separate calls "
+                        "(default: one call of the library's layer entry per layer)")
+    p.add_argument("--one-launch", action="store_true",
+                   help="with --batched --chain correct: both products of a layer in ONE launch (in-launch hand-off; "
+                        "measured slower than the two grouped launches the library uses by default)")
     p.add_argument("--streams", type=int, default=0,
                    help="one launch per batch and operator (the reference's structure), batches spread over "
                         "this many HIP streams by the extension (no Python in the loop)")
@@ -172,7 +178,7 @@ class BatchedEpoch:
     """Builds the six grouped GEMMs of an epoch once (outputs preallocated and chained); run()
     issues six launches."""
 
-    def __init__(self, Q, cts, params, W, b, chain: str, run_gin: bool):
+    def __init__(self, Q, cts, params, W, b, chain: str, run_gin: bool, fuse: bool = True, one_launch: bool = False):
         H, C = W["hidden"], W["classes"]
         bitA = [c.bit_A for c in cts]
         bitX = [c.bit_X for c in cts]
@@ -225,9 +231,19 @@ class BatchedEpoch:
             g5 = BG(g4.outs, [W["W3"]], dims(H, C), b, b, 1, 2, False)
         self.stages = [g0, g1, g2, g3, g4, g5]
         self.outs = g5.outs
+        # The layout-correct chains are pairs "X.W re-packed in the cols layout, then A.(XW)": each pair is one call of
+        # the library's layer entry (Q.FusedLayer -> qgtc_gcn_layer_batched): 3 calls per GCN epoch (4 for GIN). The
+        # library runs a pair as two grouped launches (measured faster) unless one_launch asks for the in-launch
+        # hand-off form.
+        self.launches = list(self.stages)
+        if fuse and chain == "correct":
+            pairs = [(0, 1), (2, 3), (4, 5)] if not run_gin else [(1, 2), (3, 4)]
+            first = {i: Q.FusedLayer(self.stages[i], self.stages[j], one_launch) for i, j in pairs}
+            second = {j for _, j in pairs}
+            self.launches = [first.get(i, g) for i, g in enumerate(self.stages) if i not in second]
 
     def run(self):
-        for g in self.stages:
+        for g in self.launches:
             g.run()
         return self.outs
 
@@ -322,7 +338,8 @@ def _run_epochs(args, Q, it, feat_size, b, device):
 
     if args.batched or args.streams > 0:
         cts = [c.to(device) for c in it.cTensor_li]
-        plan = BatchedEpoch(Q, cts, it.cluster_param_li, W, b, args.chain, args.run_GIN)
+        plan = BatchedEpoch(Q, cts, it.cluster_param_li, W, b, args.chain, args.run_GIN, fuse=not getattr(args, "no_fuse", False),
+                            one_launch=getattr(args, "one_launch", False))
         for _ in range(args.n_epochs):
             outs = plan.run() if args.batched else plan.run_per_batch(args.streams)
     elif args.graph:

@@ -186,3 +186,17 @@ def test_full_size_epoch_matches_oracle_and_per_batch_launches(qgtc, oracle, dat
         np.testing.assert_array_equal(grouped["outs"][cid].cpu().numpy(), expect, err_msg=f"batch {cid}")
         assert grouped["outs"][cid].abs().sum().item() > 0
     assert min(sizes) > (1100 if dataset == "ogbn-arxiv" else 500)
+
+
+@pytest.mark.parametrize("gin", [False, True])
+def test_layer_entry_routes_give_the_same_epoch(qgtc, gin):
+    """--batched --chain correct: one call of the library's layer entry per layer (default), the same as ONE launch per
+    layer (--one-launch, in-launch hand-off), and the six separate grouped launches (--no-fuse): identical outputs."""
+    import torch
+    from qgtc_ppopp22_amd import driver
+
+    base = ["--batched", "--chain", "correct"] + (["--run_GIN", "--bit_width", "4"] if gin else [])
+    ref = driver.run(_args(base + ["--no-fuse"]), Q=qgtc)["outs"]
+    for extra in ([], ["--one-launch"]):
+        got = driver.run(_args(base + extra), Q=qgtc)["outs"]
+        assert len(got) == len(ref) and all(torch.equal(x, y) for x, y in zip(got, ref)), extra

@@ -465,3 +465,93 @@ def test_float32_exactness_bound_grouped(qgtc, oracle, a, w):
                     else:
                         np.testing.assert_array_equal(to_np_u32(o), oracle.bitmm2bit(Xo, Wt, M, K, N, a, w, 8, col=(mode == 1)),
                                                       err_msg=f"K={K} {engine} mode {mode}")
+
+
+# ---------------------------------------------------------------------------------------------
+# the fused GNN layer (qgtc_gcn_layer_batched): X.W re-packed in the cols layout, then A.(XW), ONE launch
+# ---------------------------------------------------------------------------------------------
+def _layer_batches(torch, oracle, rng, dims_nf, f_out, act, wb, a_bits=1):
+    from helpers import rand_q, to_dev
+    from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
+    qw = rand_q(rng, dims_nf[0][1], f_out, wb)
+    Wt = oracle.pack(qw, wb, True)
+    dW = to_dev(torch, Wt, cols_shape(dims_nf[0][1], f_out, wb))
+    As, Xs, want = [], [], []
+    for (n, f_in) in dims_nf:
+        qa = rand_q(rng, n, n, a_bits, 0.01)
+        for blk in range(0, n, 64):                       # block-diagonal-dominant, like a cluster batch
+            qa[blk:blk + 64, blk:blk + 64] = rng.integers(0, 2 ** a_bits, size=qa[blk:blk + 64, blk:blk + 64].shape)
+        qx = rand_q(rng, n, f_in, act)
+        A, X = oracle.pack(qa, a_bits, False), oracle.pack(qx, act, False)
+        As.append(to_dev(torch, A, rows_shape(n, n, a_bits)))
+        Xs.append(to_dev(torch, X, rows_shape(n, f_in, act)))
+        T = oracle.bitmm2bit(X, Wt, n, f_in, f_out, act, wb, act, col=True)
+        want.append((T, oracle.bitmm2bit(A, T, n, n, f_out, a_bits, act, act), oracle.bitmm2int(A, T, n, n, f_out, a_bits, act, True)))
+    return As, Xs, dW, want
+
+
+@pytest.mark.parametrize("f_in,f_out,act,wb", [(128, 128, 2, 2), (50, 64, 4, 4), (128, 10, 2, 2), (64, 200, 1, 1), (40, 33, 3, 5),
+                                               (128, 128, 8, 8), (64, 10, 9, 2)])
+@pytest.mark.parametrize("engine", ["auto", "mfma", "popcount"])
+@pytest.mark.parametrize("zero_jump", [False, True])
+@pytest.mark.parametrize("one_launch", [False, True])
+def test_fused_layer_matches_oracle(qgtc, oracle, f_in, f_out, act, wb, engine, zero_jump, one_launch):
+    """FusedLayer (one call per GNN layer for a group of cluster batches; as two grouped launches - the default - and
+    as ONE launch with the in-launch hand-off) against the oracle's two products, both output forms, batches of ragged
+    sizes (incl. fewer rows than a tile), run several times (the arrival counters are monotonic), on every engine (the
+    popcount engine and plane counts outside the one-launch kernels' range take the two grouped launches either way)."""
+    import torch
+    rng = np.random.default_rng(f_in * 7 + f_out + act + wb)
+    dims_nf = [(1213, f_in), (640, f_in), (37, f_in), (129, f_in), (300, f_in)]
+    As, Xs, dW, want = _layer_batches(torch, oracle, rng, dims_nf, f_out, act, wb)
+    d1 = [(n, f, f_out) for n, f in dims_nf]
+    d2 = [(n, n, f_out) for n, _ in dims_nf]
+    with use_engine(qgtc, engine):
+        for mode2 in (0, 2):
+            s1 = qgtc.BatchedGemm(Xs, [dW], d1, act, wb, act, 1, True)
+            s2 = qgtc.BatchedGemm(As, s1.outs, d2, 1, act, act, mode2, True, zero_jump)
+            layer = qgtc.FusedLayer(s1, s2, one_launch)
+            for rep in range(3):
+                layer.run()
+                torch.cuda.synchronize()
+                for i in range(len(dims_nf)):
+                    np.testing.assert_array_equal(to_np_u32(s1.outs[i]), want[i][0], err_msg=f"T of batch {i}, run {rep}")
+                    if mode2 == 2:
+                        np.testing.assert_array_equal(layer.outs[i].cpu().numpy(), want[i][2], err_msg=f"float out of batch {i}, run {rep}")
+                    else:
+                        np.testing.assert_array_equal(to_np_u32(layer.outs[i]), want[i][1], err_msg=f"bits out of batch {i}, run {rep}")
+                if rep == 0:
+                    for o in list(s1.outs) + list(layer.outs):      # the next run must rewrite everything
+                        o.fill_(-1 if o.dtype == torch.int32 else 7.0)
+
+
+def test_fused_layer_rejects_plans_that_do_not_chain(qgtc, oracle):
+    import torch
+    rng = np.random.default_rng(5)
+    As, Xs, dW, _ = _layer_batches(torch, oracle, rng, [(100, 64), (70, 64)], 32, 2, 2)
+    s1 = qgtc.BatchedGemm(Xs, [dW], [(100, 64, 32), (70, 64, 32)], 2, 2, 2, 1, True)
+    s1_rows = qgtc.BatchedGemm(Xs, [dW], [(100, 64, 32), (70, 64, 32)], 2, 2, 2, 0, True)
+    s2 = qgtc.BatchedGemm(As, s1.outs, [(100, 100, 32), (70, 70, 32)], 1, 2, 2, 0, True)
+    with pytest.raises(RuntimeError, match="cols-layout"):
+        qgtc.FusedLayer(s1_rows, s2)
+    s2_other = qgtc.BatchedGemm(As, s1_rows.outs, [(100, 100, 32), (70, 70, 32)], 1, 2, 2, 0, True)
+    with pytest.raises(RuntimeError, match="must be stage 1's output"):
+        qgtc.FusedLayer(s1, s2_other)
+    s2_bits = qgtc.BatchedGemm(As, s1.outs, [(100, 100, 32), (70, 70, 32)], 1, 3, 2, 0, True)
+    with pytest.raises(RuntimeError, match="output bits"):
+        qgtc.FusedLayer(s1, s2_bits)
+
+
+@pytest.mark.parametrize("n,f_in,f_out,act,wb", [(300, 64, 64, 2, 2), (1213, 128, 128, 2, 2), (599, 50, 10, 4, 4), (40, 33, 200, 3, 3)])
+def test_gcn_layer_single_subgraph(qgtc, oracle, n, f_in, f_out, act, wb):
+    """QGTC.gcn_layer (what conv.py's Aggregation_Qnt calls): one subgraph, one launch, both output forms."""
+    import torch
+    rng = np.random.default_rng(n + f_in + f_out)
+    As, Xs, dW, want = _layer_batches(torch, oracle, rng, [(n, f_in)], f_out, act, wb)
+    for engine in ("auto", "popcount"):
+        with use_engine(qgtc, engine):
+            for one in (False, True):
+                bits = qgtc.gcn_layer(As[0], Xs[0], dW, n, f_in, f_out, 1, act, wb, False, one)
+                flt = qgtc.gcn_layer(As[0], Xs[0], dW, n, f_in, f_out, 1, act, wb, True, one)
+                np.testing.assert_array_equal(to_np_u32(bits), want[0][1])
+                np.testing.assert_array_equal(flt.cpu().numpy(), want[0][2])

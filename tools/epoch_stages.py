@@ -6,7 +6,7 @@ import QGTC as Q
 from qgtc_ppopp22_amd import driver, graph as G
 from qgtc_ppopp22_amd.sampler import ClusterIter
 
-Q.set_engine(os.environ.get("ENGINE", "popcount"))   # grouped launches follow the engine switch
+Q.set_engine(os.environ.get("ENGINE", "auto"))   # grouped launches follow the engine switch
 chain = sys.argv[1] if len(sys.argv) > 1 else "correct"
 gin = len(sys.argv) > 2 and sys.argv[2] == "gin"
 dataset = "ppi" if gin else "ogbn-arxiv"
@@ -16,10 +16,32 @@ graph = G.make_graph(dataset, 1500)
 dev = torch.device("cuda:0")
 it = ClusterIter(dataset, graph, 1500, 20, bit_width=b, run_GIN=gin, device=dev, qgtc=Q, with_rows_X=(chain == "correct"))
 W = driver.pack_weights(Q, graph.feat.shape[1], hidden, 10, b, dev)
-plan = driver.BatchedEpoch(Q, it.cTensor_li, it.cluster_param_li, W, b, chain, gin)
+plan = driver.BatchedEpoch(Q, it.cTensor_li, it.cluster_param_li, W, b, chain, gin, fuse=False)
 for _ in range(3):
     plan.run()
 torch.cuda.synchronize()
+ref_outs = [o.clone() for o in plan.outs]
+
+
+def timed(fn, reps=20):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+if chain == "correct":     # one fused launch per layer (qgtc_gcn_layer_batched) against the two grouped launches
+    fused = driver.BatchedEpoch(Q, it.cTensor_li, it.cluster_param_li, W, b, chain, gin, fuse=True, one_launch=True)
+    for _ in range(3):
+        fused.run()
+    torch.cuda.synchronize()
+    same = all(torch.equal(x, y) for x, y in zip(fused.outs, ref_outs))
+    for i, g in enumerate(fused.launches):
+        print(f"fused launch {i} ({type(g).__name__}): {timed(g.run):8.1f} us")
+    print(f"epoch ({chain}, {'GIN' if gin else 'GCN'}) fused, {len(fused.launches)} launches: {timed(fused.run):8.1f} us   outputs identical: {same}")
 names = ["g0", "g1", "g2", "g3", "g4", "g5"]
 for g, nme in zip(plan.stages, names):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
