@@ -178,6 +178,86 @@ def epoch_leg(Q, rank, world, device_index, dataset="ogbn-arxiv", bits=2, hidden
     return res, graph
 
 
+def epoch_roofline(Q, graph, device_index, dataset, bits, hidden, gin):
+    """The second BASELINE metric against ITS floors: the grouped, layout-correct epoch (six grouped launches, the
+    default engine) timed with HIP events around the launches only - plan building and weight packing, which
+    main_qgtc.py:96 puts inside its epoch clock, are timed separately on the host. Algorithmic work is summed over
+    the six operators and 75 batches from the logical shapes: bytes = a M K / 8 + w K N / 8 + output,
+    FP4 MFMA ops = 2 M K N x (base-4 digit pairs)."""
+    from qgtc_ppopp22_amd import driver
+    from qgtc_ppopp22_amd.sampler import ClusterIter
+
+    dev = torch.device("cuda", device_index)
+    it = ClusterIter(dataset, graph, 1500, 20, bit_width=bits, run_GIN=gin, device=dev, qgtc=Q, with_rows_X=True)
+    t0 = time.perf_counter()
+    W = driver.pack_weights(Q, graph.feat.shape[1], hidden, 10, bits, dev)
+    plan = driver.BatchedEpoch(Q, it.cTensor_li, it.cluster_param_li, W, bits, "correct", gin)
+    torch.cuda.synchronize()
+    host_ms = (time.perf_counter() - t0) * 1e3
+
+    def ev(fn, reps=20):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
+
+    epoch_us = ev(plan.run)
+    stage_us = [round(ev(g.run), 2) for g in plan.stages]
+    F, H, C, b = graph.feat.shape[1], hidden, 10, bits
+    digits = lambda p: (p + 1) // 2       # noqa: E731
+    ops = [  # (K_is_n, K, N, a, w, out: "bits"|"f32") per operator of the layout-correct chain
+        [(False, F, H, b, b, "bits"), (True, 0, H, 1, b, "bits"), (False, H, H, b, b, "bits"), (True, 0, H, 1, b, "bits"),
+         (False, H, C, b, b, "bits"), (True, 0, C, 1, b, "f32")],
+        [(True, 0, F, 1, b, "bits"), (False, F, H, b, b, "bits"), (True, 0, H, 1, b, "bits"), (False, H, H, b, b, "bits"),
+         (True, 0, H, 1, b, "bits"), (False, H, C, b, b, "f32")]][1 if gin else 0]
+    algo_bytes = mfma_ops = eff_ops = 0.0
+    for (n, _, _, _) in it.cluster_param_li:
+        for (k_is_n, K, N, a, w, out) in ops:
+            K = n if k_is_n else K
+            algo_bytes += a * n * K / 8 + w * K * N / 8 + (4 * n * N if out == "f32" else b * n * N / 8)
+            mfma_ops += 2.0 * n * K * N * digits(a) * digits(w)
+            eff_ops += 2.0 * n * K * N
+    occ = [round(g.occupied_fraction, 4) for g in plan.stages if g.zero_jump or g.occupied_fraction < 1.0]
+    floors = {"hbm_us": round(algo_bytes / (HBM_PEAK_GBS * 1e9) * 1e6, 2), "mfma_fp4_us": round(mfma_ops / (FP4_PEAK_TFLOPS * 1e12) * 1e6, 2),
+              "launch_gaps_us": round(1.5 * (len(plan.launches) - 1), 1)}
+    return {"kernel_us_per_epoch": round(epoch_us, 2), "kernel_us_per_stage": stage_us, "calls_per_epoch": len(plan.launches),
+            "launches_per_epoch": len(plan.stages), "host_plan_build_and_weight_pack_ms": round(host_ms, 3),
+            "algorithmic_bytes_per_epoch": int(algo_bytes), "effective_ops_per_epoch": eff_ops,
+            "eff_TOPS": round(eff_ops / epoch_us / 1e6, 1), "floors": floors,
+            "roofline": {"bound": "hbm", "achieved": round(algo_bytes / epoch_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(algo_bytes / epoch_us / 1e3 / HBM_PEAK_GBS, 4),
+                         "frac_mfma": round(mfma_ops / epoch_us / 1e6 / FP4_PEAK_TFLOPS, 4),
+                         "note": "75 x 10 workgroups of fixed cost per stage: latency- and occupancy-bound, see DESIGN.md section 6"},
+            "adjacency_tiles_occupied": occ[:1], "rocprof": "profiles/r02/summary_epoch%s.json" % ("_gin" if gin else "")}
+
+
+def zero_tile_rows(Q, graph_arxiv, device_index):
+    """`--zerotile_jump` (main_qgtc.py:142-145) on both synthetic graphs: the row parse_counter.py:31-33 would print
+    (dataset, non-jumping, jumping, ratio over the CUMULATIVE counter lines) and the plain per-epoch ratio of 8-row x
+    128-bit tile steps that survive zero-tile jumping."""
+    import contextlib
+    import io
+    from qgtc_ppopp22_amd import driver, graph as G
+
+    out = {}
+    for dataset, bits, hidden, g in (("ogbn-arxiv", 2, 128, graph_arxiv), ("ppi", 4, 64, None)):
+        args = driver.build_parser().parse_args(["--dataset", dataset, "--n-hidden", str(hidden), "--bit_width", str(bits), "--use_QGTC",
+                                                 "--gpu", str(device_index), "--quiet", "--zerotile_jump"])
+        Q.reset_counters()
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = driver.run(args, Q=Q, graph=g if g is not None else G.make_graph(dataset, 1500))
+        z = r["zerotile"]
+        out[dataset] = {"parse_counter_row": z["line"], "per_epoch_non_jumping": z["per_epoch_non_jumping"],
+                        "per_epoch_jumping": z["per_epoch_jumping"], "per_epoch_ratio": round(z["per_epoch_ratio"], 4)}
+    Q.reset_counters()
+    return out
+
+
 # BASELINE.md §1: the reference's published effective TFLOPs (sm_86) for M=K, N, width
 REF_MICRO = {
     (1024, 16): (5.847, 3.934, 2.488, 1.541), (2048, 16): (16.605, 10.086, 6.561, 3.483), (4096, 16): (40.627, 20.764, 12.409, 6.763),
@@ -336,30 +416,46 @@ def main():
     sums = D.gather_batch_summaries(csum, world, rank, world) if world > 1 else csum
 
     algo_bytes = 1 * M * K / 8 + w * K * N / 8 + w * M * N / 8      # a*M*K/8 + w*K*N/8 + ob*M*N/8
-    # HBM traffic per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected by
-    # tools/collect_profiles.sh in separate rocprofv3 --pmc runs; only valid for the 1-bit workload)
-    traffic = None
+    # Evidence kept under profiles/ (tools/collect_profiles.sh, rocprofv3 on the SAME workload through
+    # tools/profile_targets.py headline): the kernel's per-dispatch duration under --kernel-trace and, from separate
+    # --pmc passes, FETCH_SIZE / WRITE_SIZE in KiB per launch (HBM-side bytes = 2 x FETCH_SIZE + WRITE_SIZE: the gfx950
+    # correction for 16-byte-per-lane reads, MI355X_MICROARCH.md). Only the 1-bit workload on the default engine has one.
+    traffic, rocprof = None, None
     try:
-        if w == 1:
-            name = "pmc_traffic_bench_e.json" if fp4_kernel else "pmc_traffic_bench_d.json"
-            with open(os.path.join(ROOT, "profiles", "r01", name)) as f:
-                traffic = int(json.load(f)["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        traffic = None
-    hbm = {"achieved_GBs": round(algo_bytes / kern / 1e9, 2), "peak_GBs": HBM_PEAK_GBS,
-           "frac": round(algo_bytes / kern / 1e9 / HBM_PEAK_GBS, 5)}
+        if w == 1 and fp4_kernel:
+            with open(os.path.join(ROOT, "profiles", "r02", "summary_headline.json")) as f:
+                prof = json.load(f)
+            ks = [k for k in prof["kernel_stats"] if "k_bitmm_fp4_one" in k["name"]][0]
+            rocprof = {"file": "profiles/r02/kernel_stats_headline.csv", "calls": ks["calls"], "avg_us": round(ks["avg_ns"] / 1e3, 3),
+                       "min_us": round(ks["min_ns"] / 1e3, 3),
+                       "hbm_frac_at_avg": round(algo_bytes / (ks["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBS, 5),
+                       "note": "kernel span per dispatch under the tracer (no launch gap; the tracer's completion signals "
+                               "stretch a dispatch this short, see profiles/r02/README.md)"}
+            pm = [v for k, v in prof["pmc_per_dispatch_mean"].items() if "k_bitmm_fp4_one" in k][0]
+            traffic = int(2 * 1024 * pm["FETCH_SIZE"]["mean"] + 1024 * pm["WRITE_SIZE"]["mean"])
+    except (OSError, KeyError, ValueError, IndexError):
+        traffic, rocprof = None, None
+    hbm_floor_us, mfma_floor_us = algo_bytes / (HBM_PEAK_GBS * 1e9) * 1e6, eff_ops / (FP4_PEAK_TFLOPS * 1e12) * 1e6
+    frac_hbm = round(algo_bytes / kern / 1e9 / HBM_PEAK_GBS, 5)
     if fp4_kernel:
-        # dominant kernel: k_bitmm_fp4_skinny (v_mfma_scale_f32_16x16x128_f8f6f4 on E2M1 codes of the bit planes)
-        roofline = {"bound": "mfma", "kernel": "k_bitmm_fp4_skinny<1,%d,0,2,2>" % ({1: 1, 2: 2}.get(w, 4 if w <= 4 else 8)),
-                    "achieved": round(eff_ops / kern / 1e12, 2), "peak": FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(eff_ops / kern / 1e12 / FP4_PEAK_TFLOPS, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_us": round(kern * 1e6, 3), "hbm": hbm,
-                    "note": "a 2.5 us kernel behind a 1.6 us dependent-launch gap: neither MFMA- nor HBM-bound, see DESIGN.md 5.4c"}
-    else:
-        roofline = {"bound": "hbm", "kernel": "k_bitmm<%d,1,%d,ZS>" % ({1: 4, 2: 4, 4: 2, 8: 1}.get(w, 1), w), "achieved": hbm["achieved_GBs"],
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"],
+        # dominant kernel: k_bitmm_fp4_one (v_mfma_scale_f32_16x16x128_f8f6f4 on E2M1 codes of the bit planes). Its larger
+        # floor is the HBM one (2.16 MB / 8 TB/s = 0.27 us against 2.1 Gop / 10 PF = 0.21 us), so that is the bound named.
+        roofline = {"bound": "hbm", "kernel": "k_bitmm_fp4_one<1,%d,0,2,2>" % ({1: 1, 2: 2}.get(w, 4 if w <= 4 else 8)),
+                    "achieved": round(algo_bytes / kern / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac_hbm,
                     "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes),
                     "avg_launch_us": round(kern * 1e6, 3),
+                    "avg_launch_source": "HIP events on the launch stream around the timed steps, divided by the steps: kernel + "
+                                         "dependent-launch gap (~1.5 us), i.e. what a caller gets per launch",
+                    "frac_hbm": frac_hbm, "frac_mfma": round(eff_ops / kern / 1e12 / FP4_PEAK_TFLOPS, 5),
+                    "floors_us": {"hbm": round(hbm_floor_us, 3), "mfma_fp4": round(mfma_floor_us, 3)},
+                    "rocprof": rocprof,
+                    "note": "latency-bound: one memory round trip, 16 MFMAs per wave, one LDS reduction and the epilogue behind a "
+                            "dependent-launch gap; DESIGN.md 5.4e"}
+    else:
+        roofline = {"bound": "hbm", "kernel": "k_bitmm<%d,1,%d,ZS>" % ({1: 4, 2: 4, 4: 2, 8: 1}.get(w, 1), w), "achieved": round(algo_bytes / kern / 1e9, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac_hbm,
+                    "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes),
+                    "avg_launch_us": round(kern * 1e6, 3), "frac_hbm": frac_hbm,
                     "valu": {"achieved_bitops": round(eff_ops * w / kern, 1), "peak_bitops": VALU_PEAK_BITOPS,
                              "frac": round(eff_ops * w / kern / VALU_PEAK_BITOPS, 4),
                              "note": "binding roofline of the popcount path: v_and_b32+v_bcnt_u32_b32 issue, peak measured by tools/valu_peak.hip"}}
@@ -375,7 +471,7 @@ def main():
         "config": {"workload": f"bitMM2Bit {M}x{K}x{N}, a=1, w={w}, ob={w} (BASELINE.json configs[1], 2_7c shape)",
                    "inputs": "seeded Bernoulli(0.5) adjacency, uniform w-bit features, packed and resident in HBM",
                    "parallelism": f"replica-per-GPU x{world}, no data-path collective",
-                   "engine": args.engine + (" -> FP4 matrix-core kernel for narrow right operands" if fp4_kernel else " -> AND + popcount kernels"),
+                   "engine": args.engine + (" (library default) -> FP4 matrix-core kernel for narrow right operands" if fp4_kernel else " -> AND + popcount kernels"),
                    "issue": "back-to-back launches on one stream (the reference's metric)" if args.streams <= 1
                             else f"independent launches round-robin on {args.streams} HIP streams"},
         "roofline": roofline,
@@ -466,6 +562,8 @@ def main():
                                               "bit1_default_engine_TOPS": round(ops / (ms1a * 1e-3) / 1e12, 2),
                                               "ref_sm86_cublas_int8_TFLOPS": ref_cublas[(mk, nn)],
                                               "ref_sm86_qgtc_1bit_TFLOPs": ref_1bit[(mk, nn)]}
+            cmp9["note"] = ("comparison path only (the reference's Fig. 8a: INT8 tensor-core GEMM beside the 1-bit path); at N <= 64 "
+                            "the int8 GEMMs are bound by operand replication, a few percent of the int8 MFMA peak - DESIGN.md 5.4")
             extras["int8_mfma_vs_1bit_popcount_9_shapes"] = cmp9
         if rank == 0 and world == 1:
             extras["micro_bench_ones_9_shapes_x_4_widths"] = micro_bench_table(Q, device)
@@ -488,9 +586,15 @@ def main():
             extras["mfma_engine_vs_popcount_wide_products"] = eng
         ep, graph = epoch_leg(Q, rank, world, local)
         extras["cluster_gcn_epoch_ogbn_arxiv_shape"] = ep
+        if rank == 0 and world == 1:
+            ep["roofline_of_the_grouped_correct_chain"] = epoch_roofline(Q, graph, local, "ogbn-arxiv", 2, 128, False)
+            extras["zero_tile_jumping"] = zero_tile_rows(Q, graph, local)
         # BASELINE.json configs[3]: Batched-GIN, ppi-sized graph, 4-bit weights/features, hidden 64 (0_7b's value)
         ep_gin, _ = epoch_leg(Q, rank, world, local, dataset="ppi", bits=4, hidden=64, gin=True, full=False)
         extras["batched_gin_epoch_ppi_shape_4bit"] = ep_gin
+        if rank == 0 and world == 1:
+            from qgtc_ppopp22_amd import graph as G2
+            ep_gin["roofline_of_the_grouped_correct_chain"] = epoch_roofline(Q, G2.make_graph("ppi", 1500), local, "ppi", 4, 64, True)
         if rank == 0 and world == 1:
             from oracle.dgl_cpu_baseline import graphsage_cpu_epoch
             from qgtc_ppopp22_amd import graph as G

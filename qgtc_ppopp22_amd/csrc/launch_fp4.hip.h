@@ -121,3 +121,4 @@ int qgtc_launch_layer_wave(const LayerArgs &la, hipStream_t st) {
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
 }
+

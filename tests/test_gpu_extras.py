@@ -555,3 +555,4 @@ def test_gcn_layer_single_subgraph(qgtc, oracle, n, f_in, f_out, act, wb):
                 flt = qgtc.gcn_layer(As[0], Xs[0], dW, n, f_in, f_out, 1, act, wb, True, one)
                 np.testing.assert_array_equal(to_np_u32(bits), want[0][1])
                 np.testing.assert_array_equal(flt.cpu().numpy(), want[0][2])
+
