@@ -122,3 +122,35 @@ int qgtc_launch_layer_wave(const LayerArgs &la, hipStream_t st) {
     return QGTC_OK;
 }
 
+
+// grouped "X . W" stages with one k-quad of K and cols-layout output: one workgroup per 32-column strip (bitmm_fp4_strip.hip.h)
+int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, hipStream_t st) {
+    MMShape sh = base_shape(a, w, ob, 1);
+    sh.nowrap = 1;
+    // a strip's rows can be split over several workgroups (gridDim.z). Measured on the ogbn-arxiv-sized epoch (75 batches
+    // x 4 strips): 1 part 10.8-12.0 us, 2 parts 11.3, 4 parts 14.2, 8 parts 22.6 - every extra workgroup repeats the W
+    // loads and their latency, so launches that already have a few hundred workgroups keep whole strips
+    const int strips = pad128(max_N) / 32;
+    int parts = 1;
+    if (const char *e = std::getenv("QGTC_STRIP_PARTS")) parts = std::max(1, std::atoi(e));   // (tuning only)
+    else while (parts < 4 && static_cast<long>(strips) * count * parts < 128) parts *= 2;
+    const dim3 grid(strips, count, parts), block(64 * ST_WAVES);
+    const size_t lds = strip_lds_bytes(max_M, ob);
+#define QGTC_ST_GO(NA_, NW_, OB_) hipLaunchKernelGGL((k_bitmm_fp4_strip<NA_, NW_, OB_>), grid, block, lds, st, prs, sh)
+#define QGTC_ST_LAUNCH(NA_, NW_)                                         \
+    if (!done && a <= NA_ && w <= NW_) {                                 \
+        done = true;                                                     \
+        if (ob == 1) QGTC_ST_GO(NA_, NW_, 1);                            \
+        else if (ob == 2) QGTC_ST_GO(NA_, NW_, 2);                       \
+        else if (ob == 4) QGTC_ST_GO(NA_, NW_, 4);                       \
+        else if (ob == 8) QGTC_ST_GO(NA_, NW_, 8);                       \
+        else QGTC_ST_GO(NA_, NW_, 0);                                    \
+    }
+    bool done = false;
+    QGTC_ST_LAUNCH(1, 1) QGTC_ST_LAUNCH(1, 2) QGTC_ST_LAUNCH(2, 2) QGTC_ST_LAUNCH(2, 4) QGTC_ST_LAUNCH(4, 4) QGTC_ST_LAUNCH(4, 8)
+#undef QGTC_ST_LAUNCH
+#undef QGTC_ST_GO
+    if (!done) return QGTC_EINVAL;
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}

@@ -556,3 +556,33 @@ def test_gcn_layer_single_subgraph(qgtc, oracle, n, f_in, f_out, act, wb):
                 np.testing.assert_array_equal(to_np_u32(bits), want[0][1])
                 np.testing.assert_array_equal(flt.cpu().numpy(), want[0][2])
 
+
+
+def test_small_k_column_strip_kernel(qgtc, oracle):
+    """k_bitmm_fp4_strip (grouped launches, K <= 128, cols-layout output: the X . W stages of the epochs) against the
+    oracle: ragged rows (not a multiple of 32 / 128), K from 1 to 128, N from 1 column to several 128-line groups,
+    1..8 planes in base-4 digits, 1..10 output planes, all-zero row blocks, problems of different sizes in one launch
+    (the strips past a smaller problem's last column write its padding lines)."""
+    import torch
+    from helpers import rand_q, to_dev
+    from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
+    rng = np.random.default_rng(31337)
+    for (a, w, ob, K, N) in [(2, 2, 2, 128, 128), (4, 4, 4, 50, 64), (2, 2, 2, 128, 10), (1, 1, 1, 1, 1), (3, 5, 10, 77, 130),
+                             (4, 8, 8, 128, 33), (1, 8, 3, 100, 300), (2, 1, 9, 64, 96)]:
+        dims = [(1213, K, N), (37, K, N), (640, K, max(1, N // 2)), (129, K, N), (32, K, N)]
+        Xs, Ws, want = [], [], []
+        for (M, K_, N_) in dims:
+            qx, qw = rand_q(rng, M, K_, a), rand_q(rng, K_, N_, w)
+            qx[M // 2: M // 2 + 40] = 0
+            X, Wt = oracle.pack(qx, a, False), oracle.pack(qw, w, True)
+            Xs.append(to_dev(torch, X, rows_shape(M, K_, a)))
+            Ws.append(to_dev(torch, Wt, cols_shape(K_, N_, w)))
+            want.append(oracle.bitmm2bit(X, Wt, M, K_, N_, a, w, ob, col=True))
+        for engine in ("auto", "mfma"):
+            with use_engine(qgtc, engine):
+                bg = qgtc.BatchedGemm(Xs, Ws, dims, a, w, ob, 1, True)
+                for o in bg.outs:
+                    o.fill_(-1)
+                bg.run()
+            for i, o in enumerate(bg.outs):
+                np.testing.assert_array_equal(to_np_u32(o), want[i], err_msg=f"{engine} a={a} w={w} ob={ob} problem {dims[i]}")
