@@ -1,0 +1,188 @@
+// bitmm_fp4_rows.hip.h — part of libqgtc_hip.so (qgtc_fp4.hip).
+// Grouped launches of the "A . (XW)" stages of a GNN epoch: sparse, block-structured left operands (cluster-batch
+// adjacencies), right operands of at most 256 columns, rows-layout bits or float32 out.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// On 128 x 128 tiles (bitmm_mfma.hip.h) a workgroup of these stages visits every k-quad in which ANY of its 128 rows
+// has a bit: 54 % of them on the ogbn-arxiv-sized cluster batches, where only 19 % of the 32-row x 128-bit tiles are
+// occupied. Here the unit is a 32-row block of one batch:
+//   * a workgroup = one row block, wave j = its columns 32 j .. 32 j + 31 (N <= 128: four waves, N <= 256: eight); the
+//     waves never synchronise and use no LDS;
+//   * the k-quads to visit come from the occupancy bitmap (qgtc_tile_occupancy: one bit per 32-row tile and k-quad;
+//     without a bitmap: all of them), in pairs: the lanes of half fh load the 16 bytes of the pair's k-quad fh of
+//     their A row and T line, two pairs in flight before the first is used;
+//   * per pair four v_mfma_scale_f32_32x32x64_f8f6f4 (word t of both k-quads), operands SWAPPED so that a lane owns one row and
+//     16 of its 32 columns: half an output word per plane (byte-packed re-quantised values, one shift + AND per plane
+//     and four values, one half-wave swap), stored straight from the registers - the four waves' words of a row are 16
+//     contiguous bytes; float32 rows for the output layer.
+// Rows past M and columns past N need no masks: their operand lines are read as zeros and requant(0) = 0.
+// float32 sums: exact while K (2^a - 1)(2^w - 1) < 2^24 (the host checks it, a <= 4, w <= 8, K <= 8192).
+// ------------------------------------------------------------------------------------------
+constexpr int RS_CHUNK = 2;   // PAIRS of k-quads whose packed words a wave has in flight at once
+
+template <int NA, int NW, int MODE, int OB>   // MODE 0 rows-layout bits / 2 float32; OB output planes (0 = any)
+__global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *__restrict__ prs, MMShape sh) {
+    constexpr int NDA = (NA + 1) / 2, NDW = (NW + 1) / 2;   // base-4 digits
+#ifdef QGTC_STAMPS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RW_STAMP(i) st_[i] = __builtin_amdgcn_s_memtime()
+#else
+#define RW_STAMP(i) do { } while (0)
+#endif
+    RW_STAMP(0);
+    const qgtc_problem pr = prs[blockIdx.y];
+    const int M = pr.M, K = pr.K, N = pr.N;
+    const int rb = static_cast<int>(blockIdx.x);
+    if (32 * rb >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fl = lane & 31, fh = lane >> 5;
+    const int n0 = 32 * wv;
+    const int row_words = step128(N) * 4;
+    if (MODE == 0 ? wv >= row_words : n0 >= N) return;       // nothing of this wave's word / columns exists
+    const int kq = step128(K);
+    const uint32_t row_bytes = static_cast<uint32_t>(kq) * 16u;
+    // k-quads to visit (K <= 8192: one 64-bit word per 32-row tile)
+    unsigned long long todo = kq >= 64 ? ~0ull : ((1ull << kq) - 1ull);
+    if (pr.occ) todo &= pr.occ[static_cast<size_t>(rb) * pr.occ_words];
+    const bool cols_live = n0 < N;                           // (a padding word of the row: zeros, no arithmetic)
+    if (!cols_live) todo = 0ull;
+#ifdef QGTC_STAMPS
+    asm volatile("" ::"s"(todo));
+    st_[6] = __builtin_popcountll(todo);
+#endif
+    RW_STAMP(1);
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(pr.X), 0, static_cast<int>(static_cast<uint32_t>(pr.x_words) * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(pr.W), 0, static_cast<int>(static_cast<uint32_t>(pr.w_words) * 4u), 0x00020000);
+    const int m = 32 * rb + fl, n = n0 + fl;
+    const uint32_t x_plane = static_cast<uint32_t>(pad8(M)) * row_bytes, w_plane = static_cast<uint32_t>(pr.w_lines) * row_bytes;
+    const uint32_t x_base = m < M ? static_cast<uint32_t>(m) * row_bytes : 0xffffffffu;
+    const uint32_t w_base = n < N ? static_cast<uint32_t>(n) * row_bytes : 0xffffffffu;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    // The visited k-quads are taken in PAIRS: the lanes of half fh load the 16 bytes of the pair's k-quad fh of their
+    // A row and T line (one 16-byte load per lane, operand and plane - every byte used; 4-byte loads at a 160-byte row
+    // stride cost the address unit 16 cycles each for a quarter of the data), and MFMA t = 0..3 of the pair multiplies
+    // word t of both k-quads: which 64 elements of K an instruction covers is free as long as A and T agree.
+    while (todo != 0ull) {   // wave-uniform
+        int q[RS_CHUNK];     // this lane's k-quad of pair c (-1: none)
+#pragma unroll
+        for (int c = 0; c < RS_CHUNK; c++) {
+            const int qa = todo != 0ull ? __builtin_ctzll(todo) : -1;
+            todo &= todo - 1ull;
+            const int qb = todo != 0ull ? __builtin_ctzll(todo) : -1;
+            todo &= todo - 1ull;
+            q[c] = fh ? qb : qa;
+            if (qa < 0) q[c] = -1;
+        }
+        u32x4 xl[RS_CHUNK][NA], wl[RS_CHUNK][NW];
+#pragma unroll
+        for (int c = 0; c < RS_CHUNK; c++) {   // unconditional loads (a missing k-quad reads zeros): exact vmcnt waits
+            const uint32_t ko = static_cast<uint32_t>(q[c]) * 16u;
+#pragma unroll
+            for (int p = 0; p < NA; p++)
+                xl[c][p] = __builtin_amdgcn_raw_buffer_load_b128(rx, (q[c] >= 0 && x_base != 0xffffffffu && p < sh.a) ? x_base + static_cast<uint32_t>(p) * x_plane + ko : 0xffffffffu, 0, 0);
+#pragma unroll
+            for (int p = 0; p < NW; p++)
+                wl[c][p] = __builtin_amdgcn_raw_buffer_load_b128(rw, (q[c] >= 0 && w_base != 0xffffffffu && p < sh.w) ? w_base + static_cast<uint32_t>(p) * w_plane + ko : 0xffffffffu, 0, 0);
+        }
+#ifdef QGTC_STAMPS
+        asm volatile("" ::"v"(xl[0][0]), "v"(wl[0][0]));
+        if (st_[2] == 0) RW_STAMP(2);
+#endif
+#pragma unroll
+        for (int c = 0; c < RS_CHUNK; c++) {
+            if (__builtin_amdgcn_readfirstlane(q[c]) < 0) break;   // (lanes of half 0 hold the pair's first k-quad)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                uint32_t xw[NA], ww[NW];
+#pragma unroll
+                for (int p = 0; p < NA; p++) xw[p] = xl[c][p][t];
+#pragma unroll
+                for (int p = 0; p < NW; p++) ww[p] = wl[c][p][t];
+#pragma unroll
+                for (int da = 0; da < NDA; da++) {
+                    const i32x8 xa = strip_operand<NA>(xw, da);
+#pragma unroll
+                    for (int dw = 0; dw < NDW; dw++) {
+                        const i32x8 wb = strip_operand<NW>(ww, dw);
+                        // swapped: lane (fl, fh) register r holds C[row fl][column (r & 3) + 8 (r >> 2) + 4 fh]
+                        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb, xa, acc, 4, 4, 0, 128 + 2 * dw, 0, 128 + 2 * da);
+                    }
+                }
+            }
+        }
+    }
+
+#ifdef QGTC_STAMPS
+    asm volatile("" ::"v"(acc[0]));
+#endif
+    RW_STAMP(3);
+    if (MODE == 2) {   // float32 [M,N] (reference kernel.h:915-930)
+        if (m < M) {
+            float *dst = static_cast<float *>(pr.out) + static_cast<size_t>(m) * N + n0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int e = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const float v = acc[r];
+                if (n0 + e < N) dst[e] = v;
+            }
+        }
+        return;
+    }
+    // rows layout [ob][PAD8(M)][STEP128(N)*4] (reference kernel.h:357-389): word (row, wv); column e of the block at bit
+    // 31 - e = 8 (3 - gq) + (7 - t - 4 fh) with t = r & 3, gq = r >> 2: the values of one t a byte each (byte 3 - gq),
+    // plane p of the four = one shift + AND; the partner lane (fl, fh ^ 1) holds the other 16 bits of the word
+    const int ob = OB > 0 ? OB : sh.ob;
+    const int maxi = 1 << ob;   // (host: ob <= 23, so the reference's float compare c > 2^ob is this integer compare)
+    const uint32_t ones = static_cast<uint32_t>(maxi - 1);
+    uint32_t qv[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int c = static_cast<int>(acc[r]);   // exact: the sums are integers below 2^24
+        qv[r] = c > maxi ? ones : static_cast<uint32_t>(c);
+    }
+    uint32_t P[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        if (OB > 0 && OB < 8) P[t] = (qv[t] << 24) | (qv[4 + t] << 16) | (qv[8 + t] << 8) | qv[12 + t];   // values <= 2^OB fit a byte
+        else P[t] = ((qv[t] & 255u) << 24) | ((qv[4 + t] & 255u) << 16) | ((qv[8 + t] & 255u) << 8) | (qv[12 + t] & 255u);
+    }
+    const int rows_pad = pad8(M);
+    const size_t oplane = static_cast<size_t>(rows_pad) * row_words;
+    uint32_t *dst = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(m) * row_words + wv;
+    const bool store = fh == 0 && m < rows_pad;
+#pragma unroll
+    for (int p = 0; p < (OB > 0 ? OB : 32); p++) {
+        if (OB == 0 && p >= ob) break;
+        uint32_t x;
+        if (OB > 0 || p < 8) {
+            x = ((P[0] >> p) & 0x01010101u) << 3 | ((P[1] >> p) & 0x01010101u) << 2 | ((P[2] >> p) & 0x01010101u) << 1 | ((P[3] >> p) & 0x01010101u);
+        } else {   // more than 8 output planes: from the full values
+            x = 0u;
+#pragma unroll
+            for (int r = 0; r < 16; r++) x |= ((qv[r] >> p) & 1u) << (8 * (3 - (r >> 2)) + 3 - (r & 3));
+        }
+        x <<= 4u - 4u * static_cast<uint32_t>(fh);   // bits 7 - t - 4 fh of every byte
+        x = or_with_partner_half(x);
+        if (store) dst[p * oplane] = x;
+    }
+#ifdef QGTC_STAMPS
+    RW_STAMP(4);
+    if (tid == 0) {
+        const int slot = (blockIdx.y * gridDim.x + blockIdx.x) % 1024;
+        for (int i = 0; i < 8; i++) g_stamps[slot * 16 + i] = st_[i];
+    }
+#endif
+#undef RW_STAMP
+}
+
+}  // namespace

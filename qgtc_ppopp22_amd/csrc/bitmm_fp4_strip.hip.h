@@ -72,26 +72,30 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_strip(const qgtc_pr
             const_cast<uint32_t *>(pr.X), 0, static_cast<int>(static_cast<uint32_t>(pr.x_words) * 4u), 0x00020000);
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<uint32_t *>(pr.W), 0, static_cast<int>(static_cast<uint32_t>(pr.w_words) * 4u), 0x00020000);
-        // one k-quad: a packed line is 16 bytes = words 0..3; MFMA h (v_mfma_scale_f32_32x32x64_f8f6f4, h = 0, 1) covers
-        // words 2 h and 2 h + 1, lane (fl, fh) supplying word 2 h + fh of line fl (words past K are zero padding)
+        // one k-quad: a packed line is 16 bytes = words 0..3; lane (fl, fh) loads words 2 fh and 2 fh + 1 of line fl (ONE
+        // 8-byte load; 4-byte loads cost the address unit the same 16 cycles for half the data) and supplies word 2 fh + h
+        // to MFMA h (v_mfma_scale_f32_32x32x64_f8f6f4, h = 0, 1): which 64 elements of K an instruction covers is free as
+        // long as X and W agree (words past K are zero padding)
         const uint32_t x_plane = static_cast<uint32_t>(pad8(M)) * 16u, w_plane = static_cast<uint32_t>(pr.w_lines) * 16u;
         uint32_t wl[2][NW];   // [k half][plane]
         {
             const int n = n0 + fl;
 #pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int p = 0; p < NW; p++)
-                    wl[h][p] = __builtin_amdgcn_raw_buffer_load_b32(rw, (n < N && p < sh.w) ? static_cast<uint32_t>(p) * w_plane + static_cast<uint32_t>(n) * 16u + 8u * h + 4u * fh : 0xffffffffu, 0, 0);
+            for (int p = 0; p < NW; p++) {
+                const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rw, (n < N && p < sh.w) ? static_cast<uint32_t>(p) * w_plane + static_cast<uint32_t>(n) * 16u + 8u * fh : 0xffffffffu, 0, 0));
+                wl[0][p] = v.x;
+                wl[1][p] = v.y;
+            }
         }
         uint32_t xl[ST_CHUNK][2][NA];   // [row block of the pass][k half][plane]
         auto issue = [&](int rb, uint32_t (&xd)[2][NA]) {   // unconditional: exact vmcnt waits
             const int m = 32 * rb + fl;
 #pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int p = 0; p < NA; p++)
-                    xd[h][p] = __builtin_amdgcn_raw_buffer_load_b32(rx, (rb < rb1 && m < M && p < sh.a) ? static_cast<uint32_t>(p) * x_plane + static_cast<uint32_t>(m) * 16u + 8u * h + 4u * fh : 0xffffffffu, 0, 0);
+            for (int p = 0; p < NA; p++) {
+                const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, (rb < rb1 && m < M && p < sh.a) ? static_cast<uint32_t>(p) * x_plane + static_cast<uint32_t>(m) * 16u + 8u * fh : 0xffffffffu, 0, 0));
+                xd[0][p] = v.x;
+                xd[1][p] = v.y;
+            }
         };
         // the first pass's X words are requested before anything waits for W: one memory round trip for both
 #pragma unroll

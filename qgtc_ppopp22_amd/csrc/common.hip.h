@@ -8,6 +8,7 @@ extern thread_local char qgtc_g_hip_err[256];   // text of the last HIP error of
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int TM = 32, TN = 32;  // workgroup tile of the bit-GEMM
 

@@ -15,6 +15,7 @@ int qgtc_launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, b
 int qgtc_launch_fp4_wave(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode,
                          bool zero_skip, hipStream_t st);
 int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, hipStream_t st);
+int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode, hipStream_t st);
 
 // fused GNN layer (bitmm_layer.hip.h): defined in qgtc_mfma.hip (wide layers) and qgtc_fp4.hip (narrow layers)
 struct LayerArgs {
@@ -105,6 +106,13 @@ inline size_t strip_lds_bytes(int max_M, int ob) { return static_cast<size_t>(ob
 inline bool strip_ok(int max_M, int max_K, int a, int w, int ob) {
     return max_K <= 128 && a <= 4 && w <= 8 && ob >= 1 && ob <= 23 && strip_lds_bytes(max_M, ob) <= 64u * 1024u &&
            !getenv_flag("QGTC_NO_STRIP");
+}
+
+// grouped "A . (XW)" stages (rows-layout bits or float32 out, at most 256 columns): one workgroup per 32-row block of a
+// batch, visiting only the k-quads its occupancy word names (bitmm_fp4_rows.hip.h)
+inline bool rows_ok(int max_K, int max_N, int a, int w, int ob, int mode) {
+    return (mode == 0 || mode == 2) && max_K <= 8192 && max_N <= 256 && a <= 4 && w <= 8 && (mode == 2 || (ob >= 1 && ob <= 23)) &&
+           static_cast<double>(max_K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0 && !getenv_flag("QGTC_NO_ROWS");
 }
 
 // grouped launches on the matrix cores, one wave per 32 x 32 tile (bitmm_fp4_wave.hip.h): for NARROW outputs.

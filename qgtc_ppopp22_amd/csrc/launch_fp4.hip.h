@@ -154,3 +154,29 @@ int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, 
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
 }
+
+// grouped "A . (XW)" stages: one workgroup per 32-row block of a batch, only the occupied k-quads (bitmm_fp4_rows.hip.h)
+int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode, hipStream_t st) {
+    MMShape sh = base_shape(a, w, ob, mode);
+    sh.nowrap = 1;
+    const int waves = mode == 2 ? (max_N + 31) / 32 : step128(max_N) * 4;   // a wave per 32 columns / per word of a packed row
+    const dim3 grid((max_M + 31) / 32, count), block(64 * waves);
+#define QGTC_RW_GO(NA_, NW_, MODE_, OB_) hipLaunchKernelGGL((k_bitmm_fp4_rows<NA_, NW_, MODE_, OB_>), grid, block, 0, st, prs, sh)
+#define QGTC_RW_LAUNCH(NA_, NW_)                                         \
+    if (!done && a <= NA_ && w <= NW_) {                                 \
+        done = true;                                                     \
+        if (mode == 2) QGTC_RW_GO(NA_, NW_, 2, 0);                       \
+        else if (ob == 1) QGTC_RW_GO(NA_, NW_, 0, 1);                    \
+        else if (ob == 2) QGTC_RW_GO(NA_, NW_, 0, 2);                    \
+        else if (ob == 4) QGTC_RW_GO(NA_, NW_, 0, 4);                    \
+        else if (ob == 8) QGTC_RW_GO(NA_, NW_, 0, 8);                    \
+        else QGTC_RW_GO(NA_, NW_, 0, 0);                                 \
+    }
+    bool done = false;
+    QGTC_RW_LAUNCH(1, 1) QGTC_RW_LAUNCH(1, 2) QGTC_RW_LAUNCH(1, 4) QGTC_RW_LAUNCH(1, 8) QGTC_RW_LAUNCH(2, 2) QGTC_RW_LAUNCH(4, 4) QGTC_RW_LAUNCH(4, 8)
+#undef QGTC_RW_LAUNCH
+#undef QGTC_RW_GO
+    if (!done) return QGTC_EINVAL;
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
