@@ -41,7 +41,7 @@ __device__ __forceinline__ i32x8 strip_operand(const uint32_t (&pl)[NP], int dig
 template <int NA, int NW, int OB>
 __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_strip(const qgtc_problem *__restrict__ prs, MMShape sh) {
     constexpr int NDA = (NA + 1) / 2, NDW = (NW + 1) / 2;   // base-4 digits
-    extern __shared__ __attribute__((aligned(16))) uint32_t strip_words[];   // [ob][32 columns][line_words]
+    extern __shared__ __attribute__((aligned(16))) uint32_t strip_words[];   // [ob][32 columns][line_words | 1]
     const qgtc_problem pr = prs[blockIdx.y];
     const int M = pr.M, N = pr.N;
     const int n0 = static_cast<int>(blockIdx.x) * 32;
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_strip(const qgtc_pr
     const int per = (line_words + static_cast<int>(gridDim.z) - 1) / static_cast<int>(gridDim.z);
     const int rb0 = static_cast<int>(blockIdx.z) * per, w1 = min(line_words, rb0 + per), rb1 = min(nrb, w1);
     if (rb0 >= line_words) return;
+    const int ps = per | 1;   // odd LDS pitch between a plane's columns: 32 lanes write one word each, 32 different banks
 #ifdef QGTC_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define ST_STAMP(i) st_[i] = __builtin_amdgcn_s_memtime()
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_strip(const qgtc_pr
                 }
                 x <<= 4u - 4u * static_cast<uint32_t>(fh);   // bits 7 - t - 4 fh of every byte
                 x = or_with_partner_half(x);
-                if (fh == 0) strip_words[(p * 32 + fl) * per + (rb - rb0)] = x;
+                if (fh == 0) strip_words[(p * 32 + fl) * ps + (rb - rb0)] = x;
             }
         };
         // a pass = ST_WAVES x ST_CHUNK row blocks: every packed X word of the pass is requested before the first is used
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_strip(const qgtc_pr
         const int line = nw == 1 ? idx : static_cast<int>(__umulhi(static_cast<uint32_t>(idx), inv_nw));   // (2^32 / 1 does not fit)
         const int wi = idx - line * nw, p = line >> 5;
         dst0[p * oplane + static_cast<size_t>(line & 31) * line_words + wi] =
-            (live && rb0 + wi < rb1) ? strip_words[line * per + wi] : 0u;
+            (live && rb0 + wi < rb1) ? strip_words[line * ps + wi] : 0u;
     }
 #ifdef QGTC_STAMPS
     ST_STAMP(5);

@@ -102,7 +102,7 @@ inline bool auto_prefers_skinny(int M, int K, int N, int a, int w) {
 // grouped "X . W" stages of an epoch (one k-quad of K, cols-layout output): one workgroup per 32-column strip of a
 // batch, whole output lines written at once (bitmm_fp4_strip.hip.h). Measured on the ogbn-arxiv-sized epoch: 12 -> 5 us
 // per stage against the 128 x 128-tile kernel, and 11 -> 4 us for the 10-class stage against one wave per 32 x 32 tile.
-inline size_t strip_lds_bytes(int max_M, int ob) { return static_cast<size_t>(ob) * 32u * step128(max_M) * 4u * 4u; }
+inline size_t strip_lds_bytes(int max_M, int ob) { return static_cast<size_t>(ob) * 32u * (step128(max_M) * 4u + 1u) * 4u; }
 inline bool strip_ok(int max_M, int max_K, int a, int w, int ob) {
     return max_K <= 128 && a <= 4 && w <= 8 && ob >= 1 && ob <= 23 && strip_lds_bytes(max_M, ob) <= 64u * 1024u &&
            !getenv_flag("QGTC_NO_STRIP");

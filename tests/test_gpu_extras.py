@@ -586,3 +586,46 @@ def test_small_k_column_strip_kernel(qgtc, oracle):
                 bg.run()
             for i, o in enumerate(bg.outs):
                 np.testing.assert_array_equal(to_np_u32(o), want[i], err_msg=f"{engine} a={a} w={w} ob={ob} problem {dims[i]}")
+
+
+@pytest.mark.parametrize("a,w,ob", [(1, 2, 2), (1, 4, 4), (4, 8, 8), (2, 2, 10), (1, 1, 1), (3, 5, 3)])
+def test_row_block_kernel_for_sparse_left_operands(qgtc, oracle, a, w, ob):
+    """k_bitmm_fp4_rows (grouped launches with occupancy bitmaps or narrow outputs: the A . (XW) stages) against the
+    oracle: K up to 64 k-quads (8192: the bitmap is one word per 32-row tile), odd and even numbers of occupied k-quads
+    per row block (k-quads are multiplied in pairs), an all-zero problem, N from 1 to 256 columns, rows-layout bits and
+    float32, with and without the bitmap, problems of different sizes in one launch."""
+    import torch
+    from helpers import rand_q, to_dev
+    from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
+    rng = np.random.default_rng(1000 * a + 10 * w + ob)
+    for N in (10, 64, 128, 200, 256):
+        dims = [(1213, 1213, N), (70, 8192, N), (333, 5000, max(1, N - 7)), (40, 300, N), (129, 129, N)]
+        if 8192 * (2 ** a - 1) * (2 ** w - 1) >= 2 ** 24:
+            dims[1], dims[2] = (70, 900, N), (333, 1000, max(1, N - 7))     # keep inside the float32 exactness bound
+        Xs, Ws, refs = [], [], []
+        for i, (M, K, N_) in enumerate(dims):
+            qx = rand_q(rng, M, K, a, 0.0004)
+            for blk in range(0, min(M, K), 64):          # dense diagonal blocks, a few stray bits elsewhere
+                qx[blk:blk + 64, blk:blk + 64] = rng.integers(0, 2 ** a, size=qx[blk:blk + 64, blk:blk + 64].shape)
+            if i == 3:
+                qx[:] = 0
+            qw = rand_q(rng, K, N_, w)
+            X, Wt = oracle.pack(qx, a, False), oracle.pack(qw, w, True)
+            Xs.append(to_dev(torch, X, rows_shape(M, K, a)))
+            Ws.append(to_dev(torch, Wt, cols_shape(K, N_, w)))
+            refs.append((X, Wt))
+        for mode in (0, 2):
+            for zj in (True, False):
+                with use_engine(qgtc, "auto"):
+                    bg = qgtc.BatchedGemm(Xs, Ws, dims, a, w, ob, mode, True, zj)
+                    for o in bg.outs:
+                        o.fill_(-1 if mode == 0 else 7.0)
+                    bg.run()
+                for i, (M, K, N_) in enumerate(dims):
+                    X, Wt = refs[i]
+                    if mode == 2:
+                        np.testing.assert_array_equal(bg.outs[i].cpu().numpy(), oracle.bitmm2int(X, Wt, M, K, N_, a, w, True),
+                                                      err_msg=f"N={N} problem {i} float, bitmap {zj}")
+                    else:
+                        np.testing.assert_array_equal(to_np_u32(bg.outs[i]), oracle.bitmm2bit(X, Wt, M, K, N_, a, w, ob),
+                                                      err_msg=f"N={N} problem {i} bits, bitmap {zj}")
