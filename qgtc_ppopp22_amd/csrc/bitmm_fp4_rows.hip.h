@@ -23,7 +23,9 @@ namespace {
 // ------------------------------------------------------------------------------------------
 constexpr int RS_CHUNK = 2;   // PAIRS of k-quads whose packed words a wave has in flight at once
 
-template <int NA, int NW, int MODE, int OB>   // MODE 0 rows-layout bits / 2 float32; OB output planes (0 = any)
+// MODE 0 rows-layout bits / 2 float32; OB output planes (0 = any); CB column blocks of 32 per wave (2: half the waves per
+// launch - a stage of the ogbn-arxiv-sized epoch then fits the chip in ONE round of waves instead of 1.4)
+template <int NA, int NW, int MODE, int OB, int CB>
 __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *__restrict__ prs, MMShape sh) {
     constexpr int NDA = (NA + 1) / 2, NDW = (NW + 1) / 2;   // base-4 digits
 #ifdef QGTC_STAMPS
@@ -40,9 +42,9 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 31, fh = lane >> 5;
-    const int n0 = 32 * wv;
+    const int n0 = 32 * CB * wv;
     const int row_words = step128(N) * 4;
-    if (MODE == 0 ? wv >= row_words : n0 >= N) return;       // nothing of this wave's word / columns exists
+    if (MODE == 0 ? CB * wv >= row_words : n0 >= N) return;  // nothing of this wave's words / columns exists
     const int kq = step128(K);
     const uint32_t row_bytes = static_cast<uint32_t>(kq) * 16u;
     // k-quads to visit (K <= 8192: one 64-bit word per 32-row tile)
@@ -60,14 +62,18 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
         const_cast<uint32_t *>(pr.X), 0, static_cast<int>(static_cast<uint32_t>(pr.x_words) * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(pr.W), 0, static_cast<int>(static_cast<uint32_t>(pr.w_words) * 4u), 0x00020000);
-    const int m = 32 * rb + fl, n = n0 + fl;
+    const int m = 32 * rb + fl;
     const uint32_t x_plane = static_cast<uint32_t>(pad8(M)) * row_bytes, w_plane = static_cast<uint32_t>(pr.w_lines) * row_bytes;
     const uint32_t x_base = m < M ? static_cast<uint32_t>(m) * row_bytes : 0xffffffffu;
-    const uint32_t w_base = n < N ? static_cast<uint32_t>(n) * row_bytes : 0xffffffffu;
-
-    f32x16 acc;
+    uint32_t w_base[CB];
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    for (int j = 0; j < CB; j++) w_base[j] = n0 + 32 * j + fl < N ? static_cast<uint32_t>(n0 + 32 * j + fl) * row_bytes : 0xffffffffu;
+
+    f32x16 acc[CB];
+#pragma unroll
+    for (int j = 0; j < CB; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.0f;
     // The visited k-quads are taken in PAIRS: the lanes of half fh load the 16 bytes of the pair's k-quad fh of their
     // A row and T line (one 16-byte load per lane, operand and plane - every byte used; 4-byte loads at a 160-byte row
     // stride cost the address unit 16 cycles each for a quarter of the data), and MFMA t = 0..3 of the pair multiplies
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
             q[c] = fh ? qb : qa;
             if (qa < 0) q[c] = -1;
         }
-        u32x4 xl[RS_CHUNK][NA], wl[RS_CHUNK][NW];
+        u32x4 xl[RS_CHUNK][NA], wl[RS_CHUNK][CB][NW];
 #pragma unroll
         for (int c = 0; c < RS_CHUNK; c++) {   // unconditional loads (a missing k-quad reads zeros): exact vmcnt waits
             const uint32_t ko = static_cast<uint32_t>(q[c]) * 16u;
@@ -91,11 +97,13 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
             for (int p = 0; p < NA; p++)
                 xl[c][p] = __builtin_amdgcn_raw_buffer_load_b128(rx, (q[c] >= 0 && x_base != 0xffffffffu && p < sh.a) ? x_base + static_cast<uint32_t>(p) * x_plane + ko : 0xffffffffu, 0, 0);
 #pragma unroll
-            for (int p = 0; p < NW; p++)
-                wl[c][p] = __builtin_amdgcn_raw_buffer_load_b128(rw, (q[c] >= 0 && w_base != 0xffffffffu && p < sh.w) ? w_base + static_cast<uint32_t>(p) * w_plane + ko : 0xffffffffu, 0, 0);
+            for (int j = 0; j < CB; j++)
+#pragma unroll
+                for (int p = 0; p < NW; p++)
+                    wl[c][j][p] = __builtin_amdgcn_raw_buffer_load_b128(rw, (q[c] >= 0 && w_base[j] != 0xffffffffu && p < sh.w) ? w_base[j] + static_cast<uint32_t>(p) * w_plane + ko : 0xffffffffu, 0, 0);
         }
 #ifdef QGTC_STAMPS
-        asm volatile("" ::"v"(xl[0][0]), "v"(wl[0][0]));
+        asm volatile("" ::"v"(xl[0][0]), "v"(wl[0][0][0]));
         if (st_[2] == 0) RW_STAMP(2);
 #endif
 #pragma unroll
@@ -103,19 +111,23 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
             if (__builtin_amdgcn_readfirstlane(q[c]) < 0) break;   // (lanes of half 0 hold the pair's first k-quad)
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                uint32_t xw[NA], ww[NW];
+                uint32_t xw[NA];
 #pragma unroll
                 for (int p = 0; p < NA; p++) xw[p] = xl[c][p][t];
+                i32x8 xa[NDA];
 #pragma unroll
-                for (int p = 0; p < NW; p++) ww[p] = wl[c][p][t];
+                for (int da = 0; da < NDA; da++) xa[da] = strip_operand<NA>(xw, da);
 #pragma unroll
-                for (int da = 0; da < NDA; da++) {
-                    const i32x8 xa = strip_operand<NA>(xw, da);
+                for (int j = 0; j < CB; j++) {
+                    uint32_t ww[NW];
+#pragma unroll
+                    for (int p = 0; p < NW; p++) ww[p] = wl[c][j][p][t];
 #pragma unroll
                     for (int dw = 0; dw < NDW; dw++) {
                         const i32x8 wb = strip_operand<NW>(ww, dw);
-                        // swapped: lane (fl, fh) register r holds C[row fl][column (r & 3) + 8 (r >> 2) + 4 fh]
-                        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb, xa, acc, 4, 4, 0, 128 + 2 * dw, 0, 128 + 2 * da);
+#pragma unroll
+                        for (int da = 0; da < NDA; da++)   // swapped: lane (fl, fh) register r holds C[row fl][column (r & 3) + 8 (r >> 2) + 4 fh]
+                            acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb, xa[da], acc[j], 4, 4, 0, 128 + 2 * dw, 0, 128 + 2 * da);
                     }
                 }
             }
@@ -123,17 +135,20 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
     }
 
 #ifdef QGTC_STAMPS
-    asm volatile("" ::"v"(acc[0]));
+    asm volatile("" ::"v"(acc[0][0]));
 #endif
     RW_STAMP(3);
     if (MODE == 2) {   // float32 [M,N] (reference kernel.h:915-930)
         if (m < M) {
-            float *dst = static_cast<float *>(pr.out) + static_cast<size_t>(m) * N + n0;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int e = (r & 3) + 8 * (r >> 2) + 4 * fh;
-                const float v = acc[r];
-                if (n0 + e < N) dst[e] = v;
+            for (int j = 0; j < CB; j++) {
+                float *dst = static_cast<float *>(pr.out) + static_cast<size_t>(m) * N + n0 + 32 * j;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int e = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const float v = acc[j][r];
+                    if (n0 + 32 * j + e < N) dst[e] = v;
+                }
             }
         }
         return;
@@ -144,36 +159,40 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
     const int ob = OB > 0 ? OB : sh.ob;
     const int maxi = 1 << ob;   // (host: ob <= 23, so the reference's float compare c > 2^ob is this integer compare)
     const uint32_t ones = static_cast<uint32_t>(maxi - 1);
-    uint32_t qv[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int c = static_cast<int>(acc[r]);   // exact: the sums are integers below 2^24
-        qv[r] = c > maxi ? ones : static_cast<uint32_t>(c);
-    }
-    uint32_t P[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        if (OB > 0 && OB < 8) P[t] = (qv[t] << 24) | (qv[4 + t] << 16) | (qv[8 + t] << 8) | qv[12 + t];   // values <= 2^OB fit a byte
-        else P[t] = ((qv[t] & 255u) << 24) | ((qv[4 + t] & 255u) << 16) | ((qv[8 + t] & 255u) << 8) | (qv[12 + t] & 255u);
-    }
     const int rows_pad = pad8(M);
     const size_t oplane = static_cast<size_t>(rows_pad) * row_words;
-    uint32_t *dst = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(m) * row_words + wv;
     const bool store = fh == 0 && m < rows_pad;
 #pragma unroll
-    for (int p = 0; p < (OB > 0 ? OB : 32); p++) {
-        if (OB == 0 && p >= ob) break;
-        uint32_t x;
-        if (OB > 0 || p < 8) {
-            x = ((P[0] >> p) & 0x01010101u) << 3 | ((P[1] >> p) & 0x01010101u) << 2 | ((P[2] >> p) & 0x01010101u) << 1 | ((P[3] >> p) & 0x01010101u);
-        } else {   // more than 8 output planes: from the full values
-            x = 0u;
+    for (int j = 0; j < CB; j++) {
+        if (CB * wv + j >= row_words) break;   // (wave-uniform: the row has no such word)
+        uint32_t qv[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) x |= ((qv[r] >> p) & 1u) << (8 * (3 - (r >> 2)) + 3 - (r & 3));
+        for (int r = 0; r < 16; r++) {
+            const int c = static_cast<int>(acc[j][r]);   // exact: the sums are integers below 2^24
+            qv[r] = c > maxi ? ones : static_cast<uint32_t>(c);
         }
-        x <<= 4u - 4u * static_cast<uint32_t>(fh);   // bits 7 - t - 4 fh of every byte
-        x = or_with_partner_half(x);
-        if (store) dst[p * oplane] = x;
+        uint32_t P[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if (OB > 0 && OB < 8) P[t] = (qv[t] << 24) | (qv[4 + t] << 16) | (qv[8 + t] << 8) | qv[12 + t];   // values <= 2^OB fit a byte
+            else P[t] = ((qv[t] & 255u) << 24) | ((qv[4 + t] & 255u) << 16) | ((qv[8 + t] & 255u) << 8) | (qv[12 + t] & 255u);
+        }
+        uint32_t *dst = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(m) * row_words + CB * wv + j;
+#pragma unroll
+        for (int p = 0; p < (OB > 0 ? OB : 32); p++) {
+            if (OB == 0 && p >= ob) break;
+            uint32_t x;
+            if (OB > 0 || p < 8) {
+                x = ((P[0] >> p) & 0x01010101u) << 3 | ((P[1] >> p) & 0x01010101u) << 2 | ((P[2] >> p) & 0x01010101u) << 1 | ((P[3] >> p) & 0x01010101u);
+            } else {   // more than 8 output planes: from the full values
+                x = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; r++) x |= ((qv[r] >> p) & 1u) << (8 * (3 - (r >> 2)) + 3 - (r & 3));
+            }
+            x <<= 4u - 4u * static_cast<uint32_t>(fh);   // bits 7 - t - 4 fh of every byte
+            x = or_with_partner_half(x);
+            if (store) dst[p * oplane] = x;
+        }
     }
 #ifdef QGTC_STAMPS
     RW_STAMP(4);

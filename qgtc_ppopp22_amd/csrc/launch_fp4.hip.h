@@ -127,13 +127,14 @@ int qgtc_launch_layer_wave(const LayerArgs &la, hipStream_t st) {
 int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, 1);
     sh.nowrap = 1;
-    // a strip's rows can be split over several workgroups (gridDim.z). Measured on the ogbn-arxiv-sized epoch (75 batches
-    // x 4 strips): 1 part 10.8-12.0 us, 2 parts 11.3, 4 parts 14.2, 8 parts 22.6 - every extra workgroup repeats the W
-    // loads and their latency, so launches that already have a few hundred workgroups keep whole strips
+    // a strip's rows can be split over several workgroups (gridDim.z): 300 whole strips on 256 CUs leave 44 CUs with two
+    // (the stage is bound by the epilogue's VALU work per CU), halves balance better. Measured on the ogbn-arxiv-sized
+    // epoch (75 batches x 4 strips): 1 / 2 / 3 / 4 parts 9.7 / 8.6 / 9.0 / 9.6 us per stage - every extra workgroup
+    // repeats the W loads and their latency
     const int strips = pad128(max_N) / 32;
     int parts = 1;
     if (const char *e = std::getenv("QGTC_STRIP_PARTS")) parts = std::max(1, std::atoi(e));   // (tuning only)
-    else while (parts < 4 && static_cast<long>(strips) * count * parts < 128) parts *= 2;
+    else if (a <= 2 && w <= 2 && static_cast<long>(strips) * count < 512) parts = 2;   // (4-bit stages: 9.3 us whole, 10.5 split)
     const dim3 grid(strips, count, parts), block(64 * ST_WAVES);
     const size_t lds = strip_lds_bytes(max_M, ob);
 #define QGTC_ST_GO(NA_, NW_, OB_) hipLaunchKernelGGL((k_bitmm_fp4_strip<NA_, NW_, OB_>), grid, block, lds, st, prs, sh)
@@ -159,9 +160,17 @@ int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, 
 int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, mode);
     sh.nowrap = 1;
-    const int waves = mode == 2 ? (max_N + 31) / 32 : step128(max_N) * 4;   // a wave per 32 columns / per word of a packed row
+    const int blocks = mode == 2 ? (max_N + 31) / 32 : step128(max_N) * 4;   // 32-column blocks: per 32 columns / per word of a packed row
+    // (two column blocks per wave - half the waves, one round of them on the chip instead of 1.4 - measured no faster:
+    // 11.1 against 10.6 us on the ogbn-arxiv-sized A-stages; kept as a tuning switch)
+    const bool two = blocks >= 2 && getenv_flag("QGTC_ROWS_CB2");
+    const int waves = two ? (blocks + 1) / 2 : blocks;
     const dim3 grid((max_M + 31) / 32, count), block(64 * waves);
-#define QGTC_RW_GO(NA_, NW_, MODE_, OB_) hipLaunchKernelGGL((k_bitmm_fp4_rows<NA_, NW_, MODE_, OB_>), grid, block, 0, st, prs, sh)
+#define QGTC_RW_GO(NA_, NW_, MODE_, OB_)                                                                                   \
+    do {                                                                                                                    \
+        if (two) hipLaunchKernelGGL((k_bitmm_fp4_rows<NA_, NW_, MODE_, OB_, 2>), grid, block, 0, st, prs, sh);               \
+        else hipLaunchKernelGGL((k_bitmm_fp4_rows<NA_, NW_, MODE_, OB_, 1>), grid, block, 0, st, prs, sh);                   \
+    } while (0)
 #define QGTC_RW_LAUNCH(NA_, NW_)                                         \
     if (!done && a <= NA_ && w <= NW_) {                                 \
         done = true;                                                     \
