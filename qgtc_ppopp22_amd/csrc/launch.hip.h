@@ -129,10 +129,10 @@ inline bool words_ok(size_t x_words, size_t w_words) {
     return x_words < (1ull << 30) && w_words < (1ull << 30);  // < 4 GiB per packed operand
 }
 
-int grid_for(size_t work_items, int per_block) {
+int grid_for(size_t work_items, int per_block, size_t cap = 2048) {
     size_t blocks = (work_items + per_block - 1) / per_block;
     if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 resident blocks, grid-stride the rest
+    if (blocks > cap) blocks = cap;  // default: 256 CUs x 8 resident blocks, grid-stride the rest
     return static_cast<int>(blocks);
 }
 

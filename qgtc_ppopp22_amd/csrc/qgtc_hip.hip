@@ -112,9 +112,15 @@ int qgtc_val2bit(const float *x, int H, int W, int nbits, int col_major, int out
         const int rows_pad = pad8(H), row_words = step128(W) * 4;
         const size_t units = static_cast<size_t>(rows_pad) * ((row_words + 7) / 8);
         if ((W & 3) == 0 && aligned16(x) && units < (1ull << 30)) {
-            constexpr int UNR = 4;
-            hipLaunchKernelGGL(k_val2bit_rows_v4<UNR>, dim3(grid_for((units + UNR - 1) / UNR, 4)), dim3(256),
-                               0, st, x, H, W, nbits, ub, ubm1, out, rows_pad, row_words);
+            // Grid: one block per 4 x UNROLL units up to 8192 blocks, two units in flight per wave while that covers the
+            // matrix, four beyond. Measured (tools/pack_exp.py): 4096^2 15.1 us (cap 2048, 4 units) -> 13.2 us = 5.2 TB/s,
+            // 8192^2 50.4 -> 45.6 us = 6.1 TB/s: more, shorter waves hide the HBM latency better than deeper unrolling
+            if (units <= 8192u * 8u)
+                hipLaunchKernelGGL(k_val2bit_rows_v4<2>, dim3(grid_for((units + 1) / 2, 4, 8192)), dim3(256), 0, st, x, H, W,
+                                   nbits, ub, ubm1, out, rows_pad, row_words);
+            else
+                hipLaunchKernelGGL(k_val2bit_rows_v4<4>, dim3(grid_for((units + 3) / 4, 4, 8192)), dim3(256), 0, st, x, H, W,
+                                   nbits, ub, ubm1, out, rows_pad, row_words);
         } else {
             hipLaunchKernelGGL(k_val2bit_rows, dim3(grid_for(units, 4)), dim3(256), 0, st, x, H, W, nbits,
                                ub, ubm1, out, rows_pad, row_words);
@@ -123,7 +129,7 @@ int qgtc_val2bit(const float *x, int H, int W, int nbits, int col_major, int out
         if (out_words < qgtc_cols_words(H, W, nbits, output_layer)) return QGTC_ESIZE;
         const int lines = output_layer ? pad8(W) : pad128(W), line_words = step128(H) * 4;
         const size_t units = static_cast<size_t>((lines + 63) / 64) * line_words;
-        const dim3 g(grid_for(units, 4)), b(256);
+        const dim3 g(grid_for(units, 4, 8192)), b(256);   // (cap 2048 -> 8192: 8192^2 49.1 -> 41.4 us = 6.7 TB/s)
         if (nbits <= 1)
             hipLaunchKernelGGL(k_val2bit_cols<1>, g, b, 0, st, x, H, W, nbits, ub, ubm1, out, lines, line_words);
         else if (nbits <= 2)
