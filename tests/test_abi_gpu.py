@@ -74,3 +74,56 @@ def test_c_abi_with_raw_device_pointers(lib, oracle, M, K, N, a, w, ob, flags):
     np.testing.assert_array_equal(dec.cpu().numpy().reshape(M, N), oracle.bit2val(oracle.bitmm2bit(X_o, W_o, M, K, N, a, w, ob), ob, M, N, False, False))
     # an undersized output buffer is an error code, not a fault
     assert lib.qgtc_bitmm2bit(bx.data_ptr(), xw_, bw.data_ptr(), ww_, M, K, N, a, w, ob, out.data_ptr(), ow - 1, flags, st) == 2
+
+
+class QgtcProblem(ctypes.Structure):
+    """include/qgtc.h: struct qgtc_problem (the layout a cgo / JNI / plain-C host would declare)."""
+    _fields_ = [("X", ctypes.c_void_p), ("W", ctypes.c_void_p), ("out", ctypes.c_void_p), ("x_words", ctypes.c_uint64),
+                ("w_words", ctypes.c_uint64), ("M", ctypes.c_int32), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
+                ("w_lines", ctypes.c_int32), ("occ_words", ctypes.c_int32), ("occ", ctypes.c_void_p)]
+
+
+@pytest.mark.parametrize("flags", [0x0, 0x10, 0x10 | 0x20], ids=["popcount", "auto", "auto-one-launch"])
+def test_layer_entry_with_raw_descriptors(lib, oracle, flags):
+    """qgtc_gcn_layer_batched through ctypes: descriptors written by the HOST into a device buffer (struct layout of
+    include/qgtc.h), raw device pointers, arrival counters with QGTC_ARRIVAL_STRIDE - against the oracle's two products."""
+    import torch
+    assert ctypes.sizeof(QgtcProblem) == 72   # three pointers, two u64, five i32 (+4 padding), one pointer
+    lib.qgtc_gcn_layer_batched.argtypes = [vp, vp, ctypes.c_int] + [ctypes.c_int] * 4 + [ctypes.c_int] * 6 + [vp, ctypes.c_uint32, ctypes.c_uint, vp]
+    rng = np.random.default_rng(17 + flags)
+    act, wb, f_in, f_out = 2, 2, 64, 96
+    batches = [(150, f_in), (333, f_in), (40, f_in)]
+    qw = rand_q(rng, f_in, f_out, wb)
+    Wt = oracle.pack(qw, wb, True)
+    dW = torch.from_numpy(Wt.view(np.int32)).cuda()
+    keep, s1, s2, want = [dW], [], [], []
+    P128 = lambda x: (x + 127) // 128 * 128   # noqa: E731
+    for (n, f) in batches:
+        qa = (rng.random((n, n)) < 0.02).astype(np.int32)
+        qx = rand_q(rng, n, f, act)
+        A, X = oracle.pack(qa, 1, False), oracle.pack(qx, act, False)
+        dA, dX = torch.from_numpy(A.view(np.int32)).cuda(), torch.from_numpy(X.view(np.int32)).cuda()
+        T = torch.empty(int(lib.qgtc_cols_words(n, f_out, act, 0)), dtype=torch.int32, device="cuda")
+        out = torch.empty(n * f_out, dtype=torch.float32, device="cuda")
+        keep += [dA, dX, T, out]
+        s1.append(QgtcProblem(dX.data_ptr(), dW.data_ptr(), T.data_ptr(), dX.numel(), dW.numel(), n, f, f_out, P128(f_out), 0, None))
+        s2.append(QgtcProblem(dA.data_ptr(), T.data_ptr(), out.data_ptr(), dA.numel(), T.numel(), n, n, f_out, P128(f_out), 0, None))
+        T_o = oracle.bitmm2bit(X, Wt, n, f, f_out, act, wb, act, col=True)
+        want.append((T, T_o, out, oracle.bitmm2int(A, T_o, n, n, f_out, 1, act, True)))
+    count = len(batches)
+    host = (QgtcProblem * (2 * count))(*(s1 + s2))
+    descs = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
+    arrival = torch.zeros(count * 64, dtype=torch.int32, device="cuda")       # QGTC_ARRIVAL_STRIDE = 64
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for epoch in (1, 2):
+        rc = lib.qgtc_gcn_layer_batched(descs.data_ptr(), descs.data_ptr() + 72 * count, count, max(n for n, _ in batches), f_in,
+                                        max(n for n, _ in batches), f_out, act, wb, act, 1, 1, 2, arrival.data_ptr(), epoch, flags, st)
+        assert rc == 0, lib.qgtc_strerror(rc)
+        torch.cuda.synchronize()
+        for (T, T_o, out, out_o) in want:
+            np.testing.assert_array_equal(T.cpu().numpy().view(np.uint32), T_o)
+            np.testing.assert_array_equal(out.cpu().numpy().reshape(out_o.shape), out_o)
+            out.fill_(-3.0)
+    # bad arguments are error codes
+    assert lib.qgtc_gcn_layer_batched(None, descs.data_ptr(), count, 10, 10, 10, 10, 2, 2, 2, 1, 1, 2, arrival.data_ptr(), 1, flags, st) == 1
+    assert lib.qgtc_gcn_layer_batched(descs.data_ptr(), descs.data_ptr(), count, 10, 10, 10, 10, 2, 2, 2, 1, 1, 1, arrival.data_ptr(), 1, flags, st) == 1
