@@ -5,8 +5,9 @@
 //   * bit-plane unpack                         (bit2val)
 //   * adjacency bit planes straight from an edge list (pack_edges), occupancy bitmaps
 //   * multi-plane 1-bit GEMM: AND + popcount (v_and_b32 / v_bcnt_u32_b32) with shift-accumulate
-//     into int32, in-workgroup split-K, zero-tile skipping / jumping, and a fused epilogue that
-//     either re-quantises and re-packs (rows / cols layout) or converts to float32
+//     into int32, and the same product on the matrix cores (bit planes expanded to FP4 / int8 codes, exact);
+//     in-workgroup split-K, zero-tile skipping / jumping, and a fused epilogue that either re-quantises and
+//     re-packs (rows / cols layout) or converts to float32; one entry per GNN layer
 //   * tile counters, the 200-rep profile loop, a grouped (batched) launch
 //   * the int8 MFMA comparison GEMM.
 //
@@ -15,14 +16,19 @@
 //   pack_kernels.hip.h       val2bit (rows / cols), bit2val, pack_edges
 //   i8gemm_kernel.hip.h      int8 MFMA comparison GEMM
 //   tile_stats_kernels.hip.h occupancy bitmaps, tile counters
-//   bitmm_popcount.hip.h     the bit-GEMM (default engine) - start at the comment above `mm_tile`
-//   bitmm_mfma.hip.h         the bit-GEMM on the matrix cores (opt-in engine), 128 x 128 tiles
-//   bitmm_fp4_skinny.hip.h   the same for narrow right operands (N <= 256): no LDS staging
-//   bitmm_fp4_wave.hip.h     the same for grouped launches over cluster batches: one wave per 32 x 32 tile
-//   launch_common.hip.h      launch constants, kernel-family predicates (shared with qgtc_fp4.hip)
+//   bitmm_popcount.hip.h     the bit-GEMM on AND + popcount (engine "popcount", and every plane count the matrix-core
+//                            kernels do not cover) - start at the comment above `mm_tile`
+//   bitmm_mfma.hip.h         the bit-GEMM on the matrix cores, 128 x 128 tiles (wide right operands)
+//   bitmm_fp4_one.hip.h      the same for narrow right operands (N <= 256) and K <= 4096: the headline kernel
+//   bitmm_fp4_skinny.hip.h   the same for longer K: no LDS staging
+//   bitmm_fp4_wave.hip.h     grouped launches over cluster batches: one wave per 32 x 32 tile
+//   bitmm_fp4_strip.hip.h    grouped X . W stages (K <= 128, cols-layout output): one workgroup per 32-column strip
+//   bitmm_fp4_rows.hip.h     grouped A . (XW) stages (sparse left operand): one workgroup per 32-row block
+//   bitmm_layer.hip.h        both stages of a GNN layer in one launch (qgtc_gcn_layer_batched, on request)
+//   launch_common.hip.h      launch constants, kernel-family predicates (shared with qgtc_mfma.hip / qgtc_fp4.hip)
 //   launch.hip.h             split-K plan, kernel selection, launchers
 //   qgtc_mfma.hip            second translation unit: the 128 x 128-tile matrix-core engine and its launchers
-//   qgtc_fp4.hip             third translation unit: the FP4 narrow-operand kernels and their launchers
+//   qgtc_fp4.hip             third translation unit: the FP4 narrow-operand / grouped kernels and their launchers
 //   qgtc_hip.hip             the C-ABI of include/qgtc.h (this file)
 // Design notes live in DESIGN.md.
 #include <hip/hip_runtime.h>
