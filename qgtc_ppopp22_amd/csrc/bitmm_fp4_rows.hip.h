@@ -157,26 +157,14 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
     // 31 - e = 8 (3 - gq) + (7 - t - 4 fh) with t = r & 3, gq = r >> 2: the values of one t a byte each (byte 3 - gq),
     // plane p of the four = one shift + AND; the partner lane (fl, fh ^ 1) holds the other 16 bits of the word
     const int ob = OB > 0 ? OB : sh.ob;
-    const int maxi = 1 << ob;   // (host: ob <= 23, so the reference's float compare c > 2^ob is this integer compare)
-    const uint32_t ones = static_cast<uint32_t>(maxi - 1);
     const int rows_pad = pad8(M);
     const size_t oplane = static_cast<size_t>(rows_pad) * row_words;
     const bool store = fh == 0 && m < rows_pad;
 #pragma unroll
     for (int j = 0; j < CB; j++) {
         if (CB * wv + j >= row_words) break;   // (wave-uniform: the row has no such word)
-        uint32_t qv[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int c = static_cast<int>(acc[j][r]);   // exact: the sums are integers below 2^24
-            qv[r] = c > maxi ? ones : static_cast<uint32_t>(c);
-        }
-        uint32_t P[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            if (OB > 0 && OB < 8) P[t] = (qv[t] << 24) | (qv[4 + t] << 16) | (qv[8 + t] << 8) | qv[12 + t];   // values <= 2^OB fit a byte
-            else P[t] = ((qv[t] & 255u) << 24) | ((qv[4 + t] & 255u) << 16) | ((qv[8 + t] & 255u) << 8) | (qv[12 + t] & 255u);
-        }
+        uint32_t qv[16], P[4];
+        requant_pack16<OB>(acc[j], ob, P, qv);
         uint32_t *dst = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(m) * row_words + CB * wv + j;
 #pragma unroll
         for (int p = 0; p < (OB > 0 ? OB : 32); p++) {

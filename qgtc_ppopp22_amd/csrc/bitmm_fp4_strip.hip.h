@@ -38,6 +38,39 @@ __device__ __forceinline__ i32x8 strip_operand(const uint32_t (&pl)[NP], int dig
 }
 
 // OB: output planes at compile time (1, 2, 4, 8: the widths the reference publishes; 0 = any, runtime loop)
+// Re-quantise the 16 sums a lane holds of a 32 x 32 tile (kernel.h:31-37,350: c > 2^ob ? 2^ob - 1 : c) and pack them a
+// byte each: P[t] byte 3 - gq = value of register 4 gq + t. For OB = 1, 2, 4 the compare and select happen on the
+// float (an exact integer) and v_cvt_pk_u8_f32 converts AND inserts the byte: 3 operations per value where convert +
+// compare + select + shift/mask/or took 4.5 (these kernels are bound by exactly this VALU work). Other widths keep the
+// integer route (OB = 8 must map the sum 256 to the byte 0, which a saturating conversion cannot).
+template <int OB>
+__device__ __forceinline__ void requant_pack16(const f32x16 &acc, int ob, uint32_t (&P)[4], uint32_t (&qv)[16]) {
+    const int maxi = 1 << ob;   // (host: ob <= 23, so the reference's float compare c > 2^ob is this integer compare)
+    const uint32_t ones = static_cast<uint32_t>(maxi - 1);
+    if constexpr (OB == 1 || OB == 2 || OB == 4) {
+        const float lim = static_cast<float>(maxi), onesf = static_cast<float>(ones);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            uint32_t pk = 0u;
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                float f = acc[4 * gq + t];
+                f = f > lim ? onesf : f;
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(f, 3 - gq, pk);
+            }
+            P[t] = pk;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int c = static_cast<int>(acc[r]);   // exact: the sums are integers below 2^24
+            qv[r] = c > maxi ? ones : static_cast<uint32_t>(c);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) P[t] = ((qv[t] & 255u) << 24) | ((qv[4 + t] & 255u) << 16) | ((qv[8 + t] & 255u) << 8) | (qv[12 + t] & 255u);
+    }
+}
+
 template <int NA, int NW, int OB>
 __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_strip(const qgtc_problem *__restrict__ prs, MMShape sh) {
     constexpr int NDA = (NA + 1) / 2, NDW = (NW + 1) / 2;   // base-4 digits
@@ -110,8 +143,6 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_strip(const qgtc_pr
         asm volatile("" ::"v"(wb[0][0][0]), "v"(wb[1][0][3]));
 #endif
         ST_STAMP(1);
-        const int maxi = 1 << ob;   // (host: ob <= 23, so the reference's float compare c > 2^ob is this integer compare)
-        const uint32_t ones = static_cast<uint32_t>(maxi - 1);
         // one row block = one 32 x 32 tile: two MFMAs (the halves of K) per pair of base-4 digits. Not swapped: lane
         // (fl, fh) register r holds C[row (r & 3) + 8 (r >> 2) + 4 fh][column fl]: 16 of the 32 bits of ONE output word
         auto mma = [&](const uint32_t (&xd)[2][NA], f32x16 &acc) {
@@ -132,15 +163,8 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_strip(const qgtc_pr
         // of the column's word: the values of one t are packed a byte each (byte 3 - gq) and plane p of the four is
         // ONE shift + AND (the scheme of bitmm_mfma.hip.h's epilogue); the partner lane (fl, fh ^ 1) holds the other 16 bits
         auto finish = [&](int rb, const f32x16 &acc) {
-            uint32_t q[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int c = static_cast<int>(acc[r]);   // exact: the sums are integers below 2^24
-                q[r] = c > maxi ? ones : static_cast<uint32_t>(c);
-            }
-            uint32_t P[4];
-#pragma unroll
-            for (int t = 0; t < 4; t++) P[t] = ((q[t] & 255u) << 24) | ((q[4 + t] & 255u) << 16) | ((q[8 + t] & 255u) << 8) | (q[12 + t] & 255u);
+            uint32_t q[16], P[4];
+            requant_pack16<OB>(acc, ob, P, q);
 #pragma unroll
             for (int p = 0; p < (OB > 0 ? OB : 32); p++) {
                 if (OB == 0 && p >= ob) break;
