@@ -37,7 +37,7 @@ def _run(cmd: list[str]) -> None:
     subprocess.run(cmd, check=True)
 
 
-HIP_UNITS = ("qgtc_hip.hip", "qgtc_mfma.hip", "qgtc_fp4.hip")   # translation units of libqgtc_hip.so, compiled in parallel
+HIP_UNITS = ("qgtc_hip.hip", "qgtc_mfma.hip", "qgtc_fp4.hip", "qgtc_wide.hip")   # translation units of libqgtc_hip.so, compiled in parallel
 
 
 def build_hip(force: bool = False) -> str:

@@ -28,7 +28,6 @@ namespace {
 // registers, exactly while K (2^a - 1)(2^w - 1) < 2^24 (skinny_ok). NA, NW are plane CAPACITIES (planes beyond
 // sh.a / sh.w are not loaded); one MFMA per pair of digits instead of one AND + popcount pass per pair of planes.
 // ------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int SK_WAVES = 8;   // waves per workgroup = in-workgroup split-K factor
 
 // RF x CF fragments of 16 lines: the workgroup's tile is 16 RF rows x 16 CF columns. 2 x 2 (32 x 32) when N > 32:

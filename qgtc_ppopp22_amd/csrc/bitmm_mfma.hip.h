@@ -39,6 +39,7 @@ namespace {
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int MF_PITCH4 = 80;      // FP4 form: bytes between the expanded lines (64 + 16: conflict-free 16-byte reads)
 constexpr int MF_T = 128;          // tile edge
 constexpr int MF_PITCH = 144;      // bytes between the expanded lines of one operand

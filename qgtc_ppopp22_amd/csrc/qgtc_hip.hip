@@ -57,8 +57,10 @@
 #define QGTC_LAYER_MFMA 1
 #define QGTC_LAYER_WAVE 1
 #include "bitmm_layer.hip.h"
+#include "bitmm_fp4_wide.hip.h"
 #include "launch_fp4.hip.h"
 #include "launch_mfma.hip.h"
+#include "launch_wide.hip.h"
 #endif
 #include "launch.hip.h"
 
@@ -185,6 +187,8 @@ int qgtc_bitmm2bit(const uint32_t *X, size_t x_words, const uint32_t *W, size_t 
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (skinny_ok(K, N, bit1, bit2) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_skinny(M, K, N, bit1, bit2))))
         return qgtc_launch_skinny(pr, bit1, bit2, output_bit, cols ? 1 : 0, !(flags & QGTC_NO_ZERO_SKIP), st);
+    if (wide_ok(pr, bit1, bit2, output_bit, cols ? 1 : 0) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_wide(M, K, N, cols ? 1 : 0))))
+        return qgtc_launch_wide(pr, bit1, bit2, output_bit, cols ? 1 : 0, st);
     if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma(M, K, N, bit1, bit2)))
         return qgtc_launch_mfma(pr, bit1, bit2, output_bit, cols ? 1 : 0, st);
     if (flags & QGTC_NO_ZERO_SKIP)
@@ -203,6 +207,8 @@ int qgtc_bitmm2int(const uint32_t *X, size_t x_words, const uint32_t *W, size_t 
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (skinny_ok(K, N, bit1, bit2) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_skinny(M, K, N, bit1, bit2))))
         return qgtc_launch_skinny(pr, bit1, bit2, 1, 2, !(flags & QGTC_NO_ZERO_SKIP), st);
+    if (wide_ok(pr, bit1, bit2, 1, 2) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_wide(M, K, N, 2))))
+        return qgtc_launch_wide(pr, bit1, bit2, 1, 2, st);
     if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma(M, K, N, bit1, bit2)))
         return qgtc_launch_mfma(pr, bit1, bit2, 1, 2, st);
     if (flags & QGTC_NO_ZERO_SKIP) return dispatch_single<false>(pr, K, bit1, bit2, 1, 2, st);

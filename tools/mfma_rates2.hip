@@ -44,15 +44,21 @@ template <int FORM, int V>
 int run(const char *name, int waves, unsigned long long *d, int *sink) {
     unsigned long long h[16];
     const int iters = 1000;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float ms = 0;
     for (int rep = 0; rep < 2; rep++) {
+        CK(hipEventRecord(e0, nullptr));
         hipLaunchKernelGGL((k<FORM, V>), dim3(256), dim3(64 * waves), 0, 0, iters, d, sink, 1u);
+        CK(hipEventRecord(e1, nullptr));
         CK(hipDeviceSynchronize());
+        CK(hipEventElapsedTime(&ms, e0, e1));
     }
     CK(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
     const double per = (double)h[0] / (8.0 * iters);
     const double flops = FORM == 0 ? 2.0 * 16 * 16 * 128 : 2.0 * 32 * 32 * 64;
-    printf("%-28s %d wave(s)/SIMD, %2d VALU per MFMA: %6.1f ticks per MFMA  (%.0f flop/tick/SIMD)\n", name, waves / 4, V, per,
-           flops * (waves / 4) / per);
+    printf("%-28s %d wave(s)/SIMD, %2d VALU per MFMA: %6.1f ticks per MFMA  (%.0f flop/tick/SIMD)  %.1f us = %.2f ticks/ns, %.2f PFLOP/s chip\n", name, waves / 4, V, per,
+           flops * (waves / 4) / per, ms * 1e3, (double)h[0] / (ms * 1e6), flops * 8.0 * iters * waves * 256 / (ms * 1e-3) / 1e15);
     return 0;
 }
 
