@@ -35,8 +35,12 @@ constexpr int WD_PIECE = 1024;            // bytes one LDS-DMA wave-instruction 
 
 constexpr int wd_tl(int rf) { return 2 * 16 * rf; }   // lines of the left / right operand per workgroup
 constexpr int wd_tr(int cf) { return 4 * 16 * cf; }
-constexpr int wd_stage_bytes(int nl, int nr, int rf, int cf) { return (nl * (wd_tl(rf) / 8) + nr * (wd_tr(cf) / 8)) * WD_PIECE; }
-constexpr int wd_lds_bytes(int nl, int nr, int rf, int cf) { return WD_STAGES * wd_stage_bytes(nl, nr, rf, cf); }
+// gb = bytes of a line per group of K: 128 (one-plane operands: full cache lines, pieces of 8 lines) or 64 (more planes
+// per stage: pieces of 16 lines = one fragment)
+constexpr int wd_pieces(int nl, int nr, int rf, int cf, int gb) { return (nl * wd_tl(rf) + nr * wd_tr(cf)) * gb / WD_PIECE; }
+constexpr int wd_lds_bytes(int nl, int nr, int rf, int cf, int gb) {
+    return (WD_STAGES * wd_pieces(nl, nr, rf, cf, gb) + (wd_pieces(nl, nr, rf, cf, gb) % WD_WAVES ? 1 : 0)) * WD_PIECE;
+}
 
 // one LDS-DMA instruction: lane i's 16 bytes at (voff + soff) of the buffer land at LDS byte lds_dst + 16 i.
 // hipcc does not count this load: the kernel waits for it with its own s_waitcnt vmcnt.
@@ -87,17 +91,21 @@ __device__ __forceinline__ constexpr int wd_scale(int s) { return NP == 1 ? (s <
 // MODE 2: float32 [Lc][Rc] (kernel.h:915-930).
 // RF x CF fragments per wave (CF a multiple of 4: whole output words): 4 x 4 when the grid fills the chip, 2 x 4
 // (64 x 256 workgroup tiles, 3.75 instead of 2.5 VALU operations per MFMA) when it would leave half the CUs idle.
-template <int NL, int NR, int MODE, int RF, int CF>
+// GB bytes of every line per group of K (128 for one-plane operands, 64 when the stage has to hold more planes).
+template <int NL, int NR, int MODE, int RF, int CF, int GB>
 __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
     const uint32_t *__restrict__ Lp, const uint32_t *__restrict__ Rp, void *__restrict__ outp, uint32_t l_bytes,
     uint32_t r_bytes, uint32_t out_bytes, int Lc, int Rc, int K, int l_lines, int r_lines, int out_lines,
     uint32_t cfg /* ob | tiles along R << 8; host: ob <= 23, every byte count < 2^32 */) {
-    static_assert(CF % 4 == 0 && (RF == 2 || RF == 4), "fragment grid of a wave");
+    static_assert(CF % 4 == 0 && (RF == 2 || RF == 4) && (GB == 64 || GB == 128), "fragment grid of a wave, group of K");
     constexpr int TL = wd_tl(RF), TR = wd_tr(CF);
-    constexpr int LPP = TL / 8, RPP = TR / 8;                       // pieces per plane
-    constexpr int LPC = NL * LPP, RPC = NR * RPP;                   // pieces per stage
-    constexpr int STAGE = (LPC + RPC) * WD_PIECE;
-    constexpr int LJ = LPP / WD_WAVES, RJ = RPP / WD_WAVES;         // pieces per wave, plane and group
+    constexpr int PL = GB == 128 ? 8 : 16;                          // lines per piece
+    constexpr int GQ = GB / 16;                                     // k-quads per group
+    constexpr int LPP = TL / PL, RPP = TR / PL;                     // pieces per plane
+    constexpr int LPC = NL * LPP, RPC = NR * RPP, TOT = LPC + RPC;  // pieces per stage
+    constexpr int STAGE = TOT * WD_PIECE;
+    constexpr int DMAS = (TOT + WD_WAVES - 1) / WD_WAVES;           // per wave and group
+    static_assert(DMAS >= 1 && DMAS <= 15, "vmcnt immediate");
     extern __shared__ __attribute__((aligned(1024))) unsigned char wd_lds[];
 #ifdef QGTC_STAMPS
     unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -123,36 +131,45 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
     const uint32_t row_bytes = static_cast<uint32_t>(kq) * 16u;
     const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(wd_lds));
 
-    // ---- the DMA plan of this wave: pieces wv, wv + 8, .. of either operand; lane (rr, cc) fetches chunk cc ^ (rr & 6)
-    // of line rr of the piece (the swizzle lives on the source side: the LDS image of a piece is lane-linear). Lines
-    // past the operand read whatever follows them (finite E2M1 codes) or are dropped by the range check: the epilogue
-    // keeps nothing of them.
+    // ---- the DMA plan of this wave: pieces wv, wv + 8, .. of the stage's list [left planes][right planes]. The 16-byte
+    // chunks of a line are XOR-swizzled on the SOURCE side (the LDS image of a piece is lane-linear) so that a fragment
+    // read touches every bank once. GB = 128: a piece = 8 consecutive lines x 8 chunks, lane (rr, cc) fetches chunk
+    // cc ^ (rr & 6). GB = 64: a piece = the 16 lines of one fragment x 4 chunks, lane (rr, cc) fetches chunk
+    // cc ^ G(rr >> 2), G = (0, 2, 3, 1). Lines past the operand read whatever follows them (finite E2M1 codes) or are
+    // dropped by the range check: the epilogue keeps nothing of them.
     const i32x4 rs_l = {static_cast<int>(reinterpret_cast<uintptr_t>(Lp)), static_cast<int>((reinterpret_cast<uintptr_t>(Lp) >> 32) & 0xffffu), static_cast<int>(l_bytes), 0x00020000};
     const i32x4 rs_r = {static_cast<int>(reinterpret_cast<uintptr_t>(Rp)), static_cast<int>((reinterpret_cast<uintptr_t>(Rp) >> 32) & 0xffffu), static_cast<int>(r_bytes), 0x00020000};
     uint32_t voff_l, voff_r;
-    {
+    if constexpr (GB == 128) {
         const int rr = lane >> 3, cc = lane & 7;
         const uint32_t swz = static_cast<uint32_t>(cc ^ (rr & 6)) * 16u;
-        voff_l = static_cast<uint32_t>(tl * TL + 8 * wv + rr) * row_bytes + swz;
-        voff_r = static_cast<uint32_t>(tr * TR + 8 * wv + rr) * row_bytes + swz;
+        voff_l = static_cast<uint32_t>(tl * TL + rr) * row_bytes + swz;
+        voff_r = static_cast<uint32_t>(tr * TR + rr) * row_bytes + swz;
+    } else {
+        const int rr = lane >> 2, cc = lane & 3;
+        const uint32_t swz = static_cast<uint32_t>(cc ^ ((0x78 >> (2 * (rr >> 2))) & 3)) * 16u;
+        voff_l = static_cast<uint32_t>(tl * TL + rr) * row_bytes + swz;
+        voff_r = static_cast<uint32_t>(tr * TR + (rr & 7) + 32 * (rr >> 3)) * row_bytes + swz;   // (a right-hand fragment: two runs of 8 lines)
     }
     const uint32_t l_plane = static_cast<uint32_t>(l_lines) * row_bytes, r_plane = static_cast<uint32_t>(r_lines) * row_bytes;
     auto issue = [&](int g) {   // group g -> stage g % 3 (groups past the last: garbage into a stage nobody reads)
-        const uint32_t base = lds0 + static_cast<uint32_t>(g % WD_STAGES) * STAGE + static_cast<uint32_t>(wv) * WD_PIECE;
-        const uint32_t ko = static_cast<uint32_t>(g) * 128u;
+        const uint32_t base = lds0 + static_cast<uint32_t>(g % WD_STAGES) * STAGE;
+        const uint32_t ko = static_cast<uint32_t>(g) * GB;
 #pragma unroll
-        for (int p = 0; p < NL; p++)
-#pragma unroll
-            for (int j = 0; j < LJ; j++)
-                wd_dma(base + static_cast<uint32_t>(p * LPP + 8 * j) * WD_PIECE, voff_l, rs_l, ko + static_cast<uint32_t>(p) * l_plane + static_cast<uint32_t>(64 * j) * row_bytes);
-#pragma unroll
-        for (int p = 0; p < NR; p++)
-#pragma unroll
-            for (int j = 0; j < RJ; j++)
-                wd_dma(base + static_cast<uint32_t>(LPC + p * RPP + 8 * j) * WD_PIECE, voff_r, rs_r, ko + static_cast<uint32_t>(p) * r_plane + static_cast<uint32_t>(64 * j) * row_bytes);
+        for (int j = 0; j < DMAS; j++) {
+            const int t = wv + WD_WAVES * j;   // (scalar)
+            if (t < LPC) {
+                const int p = t / LPP, q = t % LPP;
+                wd_dma(base + static_cast<uint32_t>(t) * WD_PIECE, voff_l, rs_l, ko + static_cast<uint32_t>(p) * l_plane + static_cast<uint32_t>(PL * q) * row_bytes);
+            } else if (TOT % WD_WAVES == 0 || t < TOT) {
+                const int p = (t - LPC) / RPP, q = (t - LPC) % RPP;
+                const int line = GB == 128 ? 8 * q : 64 * (q >> 2) + 8 * (q & 3);
+                wd_dma(base + static_cast<uint32_t>(t) * WD_PIECE, voff_r, rs_r, ko + static_cast<uint32_t>(p) * r_plane + static_cast<uint32_t>(line) * row_bytes);
+            } else {   // (keeps the count of outstanding loads the same for every wave: lands in a spare piece)
+                wd_dma(lds0 + static_cast<uint32_t>(WD_STAGES) * STAGE, voff_l, rs_l, 0xfffffff0u);
+            }
+        }
     };
-    constexpr int DMAS = NL * LJ + NR * RJ;   // per wave and group
-    static_assert(DMAS >= 1 && DMAS <= 15, "vmcnt immediate");
     issue(0);
     issue(1);
     WD_STAMP(1);
@@ -160,9 +177,18 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
     // ---- the fragment reads of this wave: lane (li, kg) takes chunk 4 u + kg of line li of the fragment. Left-hand
     // fragment fr = lines 16 fr .. 16 fr + 15 of the wave's 16 RF; right-hand fragment fc = lines 8 (fc & 3) .. + 7 and
     // 32 + 8 (fc & 3) .. + 7 of block fc >> 2 of 64 lines (a lane's 16 values of a line and block = half of every byte of one word)
-    const uint32_t frag_off = static_cast<uint32_t>(li & 7) * 128u + static_cast<uint32_t>(kg ^ (li & 6)) * 16u;
-    const uint32_t la0 = static_cast<uint32_t>(2 * RF * wr + (li >> 3)) * WD_PIECE + frag_off;
-    const uint32_t ra0 = static_cast<uint32_t>(LPC + 2 * CF * wc + 4 * (li >> 3)) * WD_PIECE + frag_off;
+    uint32_t la0, ra0;   // + the fragment's and the plane's pieces
+    if constexpr (GB == 128) {
+        const uint32_t frag_off = static_cast<uint32_t>(li & 7) * 128u + static_cast<uint32_t>(kg ^ (li & 6)) * 16u;
+        la0 = static_cast<uint32_t>(2 * RF * wr + (li >> 3)) * WD_PIECE + frag_off;
+        ra0 = static_cast<uint32_t>(LPC + 2 * CF * wc + 4 * (li >> 3)) * WD_PIECE + frag_off;
+    } else {
+        const uint32_t frag_off = static_cast<uint32_t>(li) * 64u + static_cast<uint32_t>(kg ^ ((0x78 >> (2 * (li >> 2))) & 3)) * 16u;
+        la0 = static_cast<uint32_t>(RF * wr) * WD_PIECE + frag_off;
+        ra0 = static_cast<uint32_t>(LPC + CF * wc) * WD_PIECE + frag_off;
+    }
+    auto l_piece = [](int f, int p) { return GB == 128 ? 2 * f + p * LPP : f + p * LPP; };
+    auto r_piece = [](int f, int p) { return GB == 128 ? 8 * (f >> 2) + (f & 3) + p * RPP : f + p * RPP; };
 
     f32x4 acc[RF][CF];
 #pragma unroll
@@ -180,12 +206,12 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
 #endif
         issue(g + 2);
     };
-    // the 8 (or rem < 8) k-quads of group g: two rounds of (fragment reads, 4 x RF x CF MFMAs)
+    // the GQ (or rem < GQ) k-quads of group g: GB / 64 rounds of (fragment reads, 4 x RF x CF MFMAs)
     auto body = [&](int g, int rem, auto tail_c) {
         constexpr bool TAIL = decltype(tail_c)::value;
         const unsigned char *stage = wd_lds + (g % WD_STAGES) * STAGE;
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < GB / 64; u++) {
             if (TAIL && 4 * u >= rem) break;   // (workgroup-uniform)
             WdPrep<NL> lp[RF];
             WdPrep<NR> rp[CF];
@@ -195,7 +221,7 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
                 u32x4 raw[NL];
 #pragma unroll
                 for (int p = 0; p < NL; p++) {
-                    raw[p] = *reinterpret_cast<const u32x4 *>(stage + ((la0 + static_cast<uint32_t>(f * 2 + p * LPP) * WD_PIECE) ^ (64u * u)));
+                    raw[p] = *reinterpret_cast<const u32x4 *>(stage + ((la0 + static_cast<uint32_t>(l_piece(f, p)) * WD_PIECE) ^ (64u * u)));
                     if (TAIL && !live) raw[p] = u32x4{0u, 0u, 0u, 0u};
                 }
                 wd_prep<NL>(raw, lp[f]);
@@ -205,7 +231,7 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
                 u32x4 raw[NR];
 #pragma unroll
                 for (int p = 0; p < NR; p++)
-                    raw[p] = *reinterpret_cast<const u32x4 *>(stage + ((ra0 + static_cast<uint32_t>(8 * (f >> 2) + (f & 3) + p * RPP) * WD_PIECE) ^ (64u * u)));
+                    raw[p] = *reinterpret_cast<const u32x4 *>(stage + ((ra0 + static_cast<uint32_t>(r_piece(f, p)) * WD_PIECE) ^ (64u * u)));
                 wd_prep<NR>(raw, rp[f]);
             }
 #pragma unroll
@@ -223,14 +249,14 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
             }
         }
     };
-    const int ng_full = kq >> 3;
+    const int ng_full = kq / GQ;
     for (int g = 0; g < ng_full; g++) {
         publish(g);
-        body(g, 8, std::false_type{});
+        body(g, GQ, std::false_type{});
     }
-    if (kq & 7) {   // the last, shorter group
+    if (kq % GQ) {   // the last, shorter group
         publish(ng_full);
-        body(ng_full, kq & 7, std::true_type{});
+        body(ng_full, kq % GQ, std::true_type{});
     }
 #ifdef QGTC_STAMPS
     asm volatile("" : "+v"(acc[0][0]));

@@ -84,23 +84,26 @@ inline bool fp4_ok(int K, int a, int w) {
     return a <= 2 && w <= 2 && static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
 }
 
-// wide right operands, one plane each: packed words staged by LDS-DMA, expanded in the multiplying waves' registers
+// wide right operands, one or two planes each: packed words staged by LDS-DMA, expanded in the multiplying waves' registers
 // (bitmm_fp4_wide.hip.h)
 inline bool wide_ok(const qgtc_problem &pr, int a, int w, int ob, int mode) {
     const size_t out_bytes = mode == 2 ? static_cast<size_t>(pr.M) * pr.N * 4u
                                        : static_cast<size_t>(ob) * (mode == 1 ? pad128(pr.N) : pad8(pr.M)) * step128(mode == 1 ? pr.M : pr.N) * 16u;
-    return a == 1 && w == 1 && fp4_ok(pr.K, a, w) && (mode == 2 || (ob >= 1 && ob <= 23)) && pr.x_words < (1ull << 30) &&
+    return a >= 1 && a <= 2 && w >= 1 && w <= 2 && fp4_ok(pr.K, a, w) && (mode == 2 || (ob >= 1 && ob <= 23)) && pr.x_words < (1ull << 30) &&
            pr.w_words < (1ull << 30) && out_bytes < (1ull << 32) && !getenv_flag("QGTC_NO_WIDE");
 }
-// QGTC_ENGINE_AUTO, measured (tools/wide_check.py): ~3.5 us of launch, first DMA and epilogue, then 1.5 us per group of
-// 1024 bits of K and round of 128 x 256 tiles (0.85 us on the 64 x 256 tiles used while those fill less than 3/4 of the chip)
-inline bool auto_prefers_wide(int M, int K, int N, int mode) {
+// QGTC_ENGINE_AUTO, measured (tools/wide_check.py): ~3.5 us of launch, first DMA and epilogue, then per 1024 bits of K and
+// round of 128 x 256 tiles 3.1 us at 1 x 1 planes, 4.6 at 1 x 2, 5.8 at 2 x 2 (1.9 / 3.4 / 3.9 on the 64 x 256 tiles used
+// while the larger ones would fill less than 3/4 of the chip)
+inline bool auto_prefers_wide(int M, int K, int N, int a, int w, int mode) {
     const int L = mode == 1 ? N : M, R = mode == 1 ? M : N;
     const double tr = (R + 255) / 256;
     const bool big = ((L + 127) / 128) * tr >= 192.0;
     const double tiles = big ? ((L + 127) / 128) * tr : ((L + 63) / 64) * tr;
-    const double t_wide = 3.5 + std::ceil(tiles / 256.0) * ((step128(K) + 7) / 8) * (big ? 1.5 : 0.85);
-    const double t_pop = 3.0 + 2.0 * M * static_cast<double>(K) * N / 0.95e15 * 1e6;
+    const int pl = a + w;
+    const double per = big ? (pl == 2 ? 3.1 : pl == 3 ? 4.6 : 5.8) : (pl == 2 ? 1.9 : pl == 3 ? 3.4 : 3.9);
+    const double t_wide = 3.5 + std::ceil(tiles / 256.0) * (step128(K) / 8.0) * per;
+    const double t_pop = 3.0 + 2.0 * M * static_cast<double>(K) * N * a * w / 0.95e15 * 1e6;
     return t_wide < 0.9 * t_pop;
 }
 

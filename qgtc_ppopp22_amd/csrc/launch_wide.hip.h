@@ -1,7 +1,8 @@
 // launch_wide.hip.h — part of libqgtc_hip.so (qgtc_wide.hip): launcher of the wide-operand FP4 kernel.
 #pragma once
 
-#define QGTC_WD_FOR_ALL(F) F(1, 1, 0, 4, 4) F(1, 1, 2, 4, 4) F(1, 1, 0, 2, 4) F(1, 1, 2, 2, 4)
+#define QGTC_WD_FOR_PLANES(F, NL, NR, GB) F(NL, NR, 0, 4, 4, GB) F(NL, NR, 2, 4, 4, GB) F(NL, NR, 0, 2, 4, GB) F(NL, NR, 2, 2, 4, GB)
+#define QGTC_WD_FOR_ALL(F) QGTC_WD_FOR_PLANES(F, 1, 1, 128) QGTC_WD_FOR_PLANES(F, 1, 2, 64) QGTC_WD_FOR_PLANES(F, 2, 1, 64) QGTC_WD_FOR_PLANES(F, 2, 2, 64)
 
 // mode 0 rows-layout bits, 1 cols-layout bits (the operands change places: a cols-layout word runs along M), 2 float32
 int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st) {
@@ -15,14 +16,14 @@ int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hip
     const size_t out_bytes = mode == 2 ? static_cast<size_t>(pr.M) * pr.N * 4u : static_cast<size_t>(ob) * out_lines * step128(Rc) * 16u;
     static PerDeviceOnce attr;
     const int arc = attr.run([]() -> int {
-#define QGTC_WD_ATTR(NL, NR, MD, RF, CF) \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_fp4_wide<NL, NR, MD, RF, CF>), hipFuncAttributeMaxDynamicSharedMemorySize, wd_lds_bytes(NL, NR, RF, CF)));
+#define QGTC_WD_ATTR(NL, NR, MD, RF, CF, GB) \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_fp4_wide<NL, NR, MD, RF, CF, GB>), hipFuncAttributeMaxDynamicSharedMemorySize, wd_lds_bytes(NL, NR, RF, CF, GB)));
         QGTC_WD_FOR_ALL(QGTC_WD_ATTR)
 #undef QGTC_WD_ATTR
         return QGTC_OK;
     });
     if (arc != QGTC_OK) return arc;
-    (void)a; (void)w;
+    const int nl = swap ? w : a, nr = swap ? a : w;   // planes of the left / right operand (1 or 2 each: wide_ok)
     // 128 x 256 tiles (2.5 VALU operations per MFMA) when they fill the chip, else 64 x 256 (3.75, twice the workgroups)
     const int cover = mode == 2 ? Lc : out_lines;   // (the padding lines of the bit layouts are written as zeros)
     const int nt_r = (Rc + wd_tr(4) - 1) / wd_tr(4);
@@ -31,12 +32,17 @@ int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hip
     const int nt_l = (cover + wd_tl(rf) - 1) / wd_tl(rf);
     const uint32_t cfg = static_cast<uint32_t>(ob) | static_cast<uint32_t>(nt_r) << 8;
     const dim3 grid(static_cast<unsigned>(nt_l * nt_r)), block(64 * WD_WAVES);
-#define QGTC_WD_LAUNCH(MD, RF)                                                                                               \
-    hipLaunchKernelGGL((k_bitmm_fp4_wide<1, 1, MD, RF, 4>), grid, block, wd_lds_bytes(1, 1, RF, 4), st, Lp, Rp, pr.out, l_bytes, r_bytes, \
-                       static_cast<uint32_t>(out_bytes), Lc, Rc, pr.K, l_lines, r_lines, out_lines, cfg)
-    if (mode == 2) { if (rf == 4) QGTC_WD_LAUNCH(2, 4); else QGTC_WD_LAUNCH(2, 2); }
-    else { if (rf == 4) QGTC_WD_LAUNCH(0, 4); else QGTC_WD_LAUNCH(0, 2); }
+    const int md = mode == 2 ? 2 : 0;
+    bool launched = false;
+#define QGTC_WD_LAUNCH(NL, NR, MD, RF, CF, GB)                                                                                              \
+    if (!launched && nl == NL && nr == NR && md == MD && rf == RF) {                                                                        \
+        hipLaunchKernelGGL((k_bitmm_fp4_wide<NL, NR, MD, RF, CF, GB>), grid, block, wd_lds_bytes(NL, NR, RF, CF, GB), st, Lp, Rp, pr.out, l_bytes, \
+                           r_bytes, static_cast<uint32_t>(out_bytes), Lc, Rc, pr.K, l_lines, r_lines, out_lines, cfg);                      \
+        launched = true;                                                                                                                    \
+    }
+    QGTC_WD_FOR_ALL(QGTC_WD_LAUNCH)
 #undef QGTC_WD_LAUNCH
+    if (!launched) return QGTC_EINVAL;
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
 }

@@ -187,7 +187,7 @@ int qgtc_bitmm2bit(const uint32_t *X, size_t x_words, const uint32_t *W, size_t 
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (skinny_ok(K, N, bit1, bit2) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_skinny(M, K, N, bit1, bit2))))
         return qgtc_launch_skinny(pr, bit1, bit2, output_bit, cols ? 1 : 0, !(flags & QGTC_NO_ZERO_SKIP), st);
-    if (wide_ok(pr, bit1, bit2, output_bit, cols ? 1 : 0) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_wide(M, K, N, cols ? 1 : 0))))
+    if (wide_ok(pr, bit1, bit2, output_bit, cols ? 1 : 0) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_wide(M, K, N, bit1, bit2, cols ? 1 : 0))))
         return qgtc_launch_wide(pr, bit1, bit2, output_bit, cols ? 1 : 0, st);
     if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma(M, K, N, bit1, bit2)))
         return qgtc_launch_mfma(pr, bit1, bit2, output_bit, cols ? 1 : 0, st);
@@ -207,7 +207,7 @@ int qgtc_bitmm2int(const uint32_t *X, size_t x_words, const uint32_t *W, size_t 
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (skinny_ok(K, N, bit1, bit2) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_skinny(M, K, N, bit1, bit2))))
         return qgtc_launch_skinny(pr, bit1, bit2, 1, 2, !(flags & QGTC_NO_ZERO_SKIP), st);
-    if (wide_ok(pr, bit1, bit2, 1, 2) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_wide(M, K, N, 2))))
+    if (wide_ok(pr, bit1, bit2, 1, 2) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_wide(M, K, N, bit1, bit2, 2))))
         return qgtc_launch_wide(pr, bit1, bit2, 1, 2, st);
     if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma(M, K, N, bit1, bit2)))
         return qgtc_launch_mfma(pr, bit1, bit2, 1, 2, st);

@@ -633,26 +633,27 @@ def test_row_block_kernel_for_sparse_left_operands(qgtc, oracle, a, w, ob):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rf", ["", "2", "4"])
-def test_wide_operand_kernel_equals_the_oracle(qgtc, oracle, monkeypatch, rf):
-    """k_bitmm_fp4_wide (one-plane operands, N > 256: packed words staged by LDS-DMA, expanded in registers) against the
-    oracle in all three output forms: ragged M and N, K with 1..8 k-quads in the last group of 1024 bits, fewer lines
-    than a tile, several output widths (one / two planes have their own epilogue), both tile shapes forced in turn."""
+@pytest.mark.parametrize("a,w", [(1, 1), (1, 2), (2, 1), (2, 2)])
+def test_wide_operand_kernel_equals_the_oracle(qgtc, oracle, monkeypatch, rf, a, w):
+    """k_bitmm_fp4_wide (one- and two-plane operands, N > 256: packed words staged by LDS-DMA, expanded in registers)
+    against the oracle in all three output forms: ragged M and N, K with 1..8 k-quads in the last group, fewer lines than
+    a tile, several output widths (one / two planes have their own epilogue), both tile shapes forced in turn."""
     import torch
     from helpers import rand_q, to_dev
     from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
     if rf:
         monkeypatch.setenv("QGTC_WIDE_RF", rf)
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + 10 * a + w)
     for (M, K, N) in ((129, 1024, 257), (300, 896, 513), (8, 3968, 264), (77, 128, 1000), (513, 2176, 1030), (1000, 1152, 300), (64, 8320, 520)):
-        qx, qw = rand_q(rng, M, K, 1), rand_q(rng, K, N, 1)
-        X, Wt = oracle.pack(qx, 1, False), oracle.pack(qw, 1, True)
-        bX, bW = to_dev(torch, X, rows_shape(M, K, 1)), to_dev(torch, Wt, cols_shape(K, N, 1))
+        qx, qw = rand_q(rng, M, K, a), rand_q(rng, K, N, w)
+        X, Wt = oracle.pack(qx, a, False), oracle.pack(qw, w, True)
+        bX, bW = to_dev(torch, X, rows_shape(M, K, a)), to_dev(torch, Wt, cols_shape(K, N, w))
         for eng in ("mfma", "auto"):
             with use_engine(qgtc, eng):
                 for ob in (1, 2, 3, 10):
-                    np.testing.assert_array_equal(to_np_u32(qgtc.bitMM2Bit(bX, bW, M, K, N, 1, 1, ob)), oracle.bitmm2bit(X, Wt, M, K, N, 1, 1, ob),
+                    np.testing.assert_array_equal(to_np_u32(qgtc.bitMM2Bit(bX, bW, M, K, N, a, w, ob)), oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob),
                                                   err_msg=f"{M}x{K}x{N} rows ob={ob} {eng}")
-                    np.testing.assert_array_equal(to_np_u32(qgtc.bitMM2Bit_col(bX, bW, M, K, N, 1, 1, ob)), oracle.bitmm2bit(X, Wt, M, K, N, 1, 1, ob, True),
+                    np.testing.assert_array_equal(to_np_u32(qgtc.bitMM2Bit_col(bX, bW, M, K, N, a, w, ob)), oracle.bitmm2bit(X, Wt, M, K, N, a, w, ob, col=True),
                                                   err_msg=f"{M}x{K}x{N} cols ob={ob} {eng}")
-                np.testing.assert_array_equal(qgtc.bitMM2Int(bX, bW, M, K, N, 1, 1).cpu().numpy(), oracle.bitmm2int(X, Wt, M, K, N, 1, 1, True),
+                np.testing.assert_array_equal(qgtc.bitMM2Int(bX, bW, M, K, N, a, w, True).cpu().numpy(), oracle.bitmm2int(X, Wt, M, K, N, a, w, True),
                                               err_msg=f"{M}x{K}x{N} float {eng}")
