@@ -92,17 +92,21 @@ inline bool wide_ok(const qgtc_problem &pr, int a, int w, int ob, int mode) {
     return a >= 1 && a <= 2 && w >= 1 && w <= 2 && fp4_ok(pr.K, a, w) && (mode == 2 || (ob >= 1 && ob <= 23)) && pr.x_words < (1ull << 30) &&
            pr.w_words < (1ull << 30) && out_bytes < (1ull << 32) && !getenv_flag("QGTC_NO_WIDE");
 }
-// QGTC_ENGINE_AUTO, measured (tools/wide_check.py): ~3.5 us of launch, first DMA and epilogue, then per 1024 bits of K and
-// round of 128 x 256 tiles 3.1 us at 1 x 1 planes, 4.6 at 1 x 2, 5.8 at 2 x 2 (1.9 / 3.4 / 3.9 on the 64 x 256 tiles used
-// while the larger ones would fill less than 3/4 of the chip)
-inline bool auto_prefers_wide(int M, int K, int N, int a, int w, int mode) {
-    const int L = mode == 1 ? N : M, R = mode == 1 ? M : N;
-    const double tr = (R + 255) / 256;
-    const bool big = ((L + 127) / 128) * tr >= 192.0;
-    const double tiles = big ? ((L + 127) / 128) * tr : ((L + 63) / 64) * tr;
+// Measured (tools/wide_check.py): ~3.5 us of launch, first DMA and epilogue, then per 1024 bits of K and round of
+// 128 x 256 tiles 3.1 us at 1 x 1 planes, 4.6 at 1 x 2, 5.8 at 2 x 2; 1.9 / 3.4 / 3.9 on 64 x 256 tiles (twice the
+// workgroups, 3.75 instead of 2.5 VALU operations per MFMA). rf = the left-hand fragments per wave (4 or 2) that give
+// the shorter launch; returns its estimated time in us.
+inline double wide_plan(int lines, int R, int K, int a, int w, int *rf) {
     const int pl = a + w;
-    const double per = big ? (pl == 2 ? 3.1 : pl == 3 ? 4.6 : 5.8) : (pl == 2 ? 1.9 : pl == 3 ? 3.4 : 3.9);
-    const double t_wide = 3.5 + std::ceil(tiles / 256.0) * (step128(K) / 8.0) * per;
+    const double tr = (R + 255) / 256;
+    const double g4 = std::ceil(((lines + 127) / 128) * tr / 256.0) * (pl == 2 ? 3.1 : pl == 3 ? 4.6 : 5.8);
+    const double g2 = std::ceil(((lines + 63) / 64) * tr / 256.0) * (pl == 2 ? 1.9 : pl == 3 ? 3.4 : 3.9);
+    if (rf) *rf = g2 < g4 ? 2 : 4;
+    return 3.5 + (step128(K) / 8.0) * std::min(g2, g4);
+}
+// QGTC_ENGINE_AUTO
+inline bool auto_prefers_wide(int M, int K, int N, int a, int w, int mode) {
+    const double t_wide = wide_plan(mode == 1 ? N : M, mode == 1 ? M : N, K, a, w, nullptr);
     const double t_pop = 3.0 + 2.0 * M * static_cast<double>(K) * N * a * w / 0.95e15 * 1e6;
     return t_wide < 0.9 * t_pop;
 }

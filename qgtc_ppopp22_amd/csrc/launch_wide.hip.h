@@ -24,10 +24,10 @@ int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hip
     });
     if (arc != QGTC_OK) return arc;
     const int nl = swap ? w : a, nr = swap ? a : w;   // planes of the left / right operand (1 or 2 each: wide_ok)
-    // 128 x 256 tiles (2.5 VALU operations per MFMA) when they fill the chip, else 64 x 256 (3.75, twice the workgroups)
     const int cover = mode == 2 ? Lc : out_lines;   // (the padding lines of the bit layouts are written as zeros)
     const int nt_r = (Rc + wd_tr(4) - 1) / wd_tr(4);
-    int rf = ((cover + wd_tl(4) - 1) / wd_tl(4)) * nt_r >= 192 ? 4 : 2;
+    int rf = 4;
+    wide_plan(cover, Rc, pr.K, a, w, &rf);
     if (const char *e = std::getenv("QGTC_WIDE_RF")) rf = std::atoi(e) == 2 ? 2 : 4;   // (tuning only)
     const int nt_l = (cover + wd_tl(rf) - 1) / wd_tl(rf);
     const uint32_t cfg = static_cast<uint32_t>(ob) | static_cast<uint32_t>(nt_r) << 8;

@@ -7,12 +7,12 @@
 set -u
 TAG=${1:-r02}
 shift
-TARGETS=${@:-headline wide1 wide4 epoch epoch_gin pack}
+TARGETS=${@:-headline wide1 wide8k wide2 wide4 epoch epoch_gin pack}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for T in $TARGETS; do
-  REPS=200; [ "$T" = "epoch" -o "$T" = "epoch_gin" ] && REPS=20; [ "$T" = "wide1" -o "$T" = "wide4" ] && REPS=50
+  REPS=200; [ "$T" = "epoch" -o "$T" = "epoch_gin" ] && REPS=20; case "$T" in wide*) REPS=50;; esac
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$T -- python3 $GRAFT_REPO_ROOT/tools/profile_targets.py $T $REPS > $OUT/run_trace_$T.json 2> $OUT/trace_$T.err
   for C in FETCH_SIZE WRITE_SIZE "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
     N=$(echo $C | tr ' ' '_')

@@ -1,6 +1,6 @@
 """One kernel family per invocation, for rocprofv3 (tools/collect_profiles.sh):
 
-    python3 tools/profile_targets.py headline|wide1|wide4|epoch|epoch_gin|pack [reps]
+    python3 tools/profile_targets.py headline|wide1|wide8k|wide2|wide4|epoch|epoch_gin|pack [reps]
 
 Runs the named workload `reps` times after a warm-up and prints one JSON line with the HIP-event time per launch
 (events recorded on the launch stream), so that the trace's per-kernel averages can be put beside it."""
@@ -69,6 +69,10 @@ def main():
         r = gemm_target(4096, 4096, 64, 1, reps)
     elif t == "wide1":
         r = gemm_target(4096, 4096, 1024, 1, reps)
+    elif t == "wide8k":
+        r = gemm_target(8192, 4096, 1024, 1, reps)
+    elif t == "wide2":
+        r = gemm_target(8192, 4096, 1024, 2, reps)
     elif t == "wide4":
         r = gemm_target(4096, 4096, 1024, 4, reps)
     elif t == "epoch":
