@@ -657,3 +657,37 @@ def test_wide_operand_kernel_equals_the_oracle(qgtc, oracle, monkeypatch, rf, a,
                                                   err_msg=f"{M}x{K}x{N} cols ob={ob} {eng}")
                 np.testing.assert_array_equal(qgtc.bitMM2Int(bX, bW, M, K, N, a, w, True).cpu().numpy(), oracle.bitmm2int(X, Wt, M, K, N, a, w, True),
                                               err_msg=f"{M}x{K}x{N} float {eng}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["auto", "mfma"])
+def test_wide_kernel_at_the_float32_exactness_bound(qgtc, engine):
+    """The wide-operand kernel at the edge of its admission predicate (K (2^a-1)(2^w-1) < 2^24): all-max 2 x 2-bit
+    operands at K = 1 864 135, where every sum is 2^24 - 1, and at K + 1, where the int32 kernels must take over
+    (sum 2^24 + 8). The packed operands are built word by word (the dense K x N array would be 2 GB) and the expected
+    values are known in closed form."""
+    import torch
+    from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
+    M, N, a, w = 8, 257, 2, 2
+    for K in (_kmax(a, w), _kmax(a, w) + 1):
+        line = torch.zeros(rows_shape(M, K, a)[-1], dtype=torch.int64)
+        line[:K // 32] = 0xFFFFFFFF
+        if K % 32:
+            line[K // 32] = 0xFFFFFFFF ^ (0xFFFFFFFF >> (K % 32))      # element i at bit 31 - (i & 31)
+        line = line.to(torch.uint32).view(torch.int32)
+        bX = torch.zeros(rows_shape(M, K, a), dtype=torch.int32)
+        bW = torch.zeros(cols_shape(K, N, w), dtype=torch.int32)
+        bX.view(a, -1, line.numel())[:, :M] = line
+        bW.view(w, -1, line.numel())[:, :N] = line
+        bX, bW = bX.cuda(), bW.cuda()
+        want = K * 9
+        with use_engine(qgtc, engine):
+            f = qgtc.bitMM2Int(bX, bW, M, K, N, a, w, True)
+            b = qgtc.bitMM2Bit(bX, bW, M, K, N, a, w, 8)
+        assert float(np.float32(want)) == want
+        assert bool((f == float(want)).all()), f"K={K}: {f.unique()[:4].tolist()} instead of {want}"
+        words = to_np_u32(b).reshape(8, -1, 12)                        # [ob][PAD8(M)][STEP128(N) * 4]; requantised to 255
+        expect = np.zeros_like(words)
+        expect[:, :M, :8] = 0xFFFFFFFF
+        expect[:, :M, 8] = 0x80000000                                  # column 256
+        np.testing.assert_array_equal(words, expect, err_msg=f"K={K}")
