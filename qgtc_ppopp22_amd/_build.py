@@ -1,6 +1,6 @@
 """In-tree build of the native pieces (called by __graft_entry__.build()).
 
-  libqgtc_hip.so                    hipcc --offload-arch=gfx950  csrc/qgtc_hip.hip + qgtc_mfma.hip + qgtc_fp4.hip (three translation
+  libqgtc_hip.so                    hipcc --offload-arch=gfx950  csrc/qgtc_hip.hip + qgtc_mfma.hip + qgtc_fp4.hip + qgtc_wide.hip (four translation
                                     units compiled in parallel; they include csrc/*.hip.h, the kernels)
   QGTC.cpython-*.so                 g++                          csrc/qgtc_torch.cpp (pybind11 binding)
 

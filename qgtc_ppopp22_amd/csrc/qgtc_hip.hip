@@ -29,6 +29,7 @@
 //   launch.hip.h             split-K plan, kernel selection, launchers
 //   qgtc_mfma.hip            second translation unit: the 128 x 128-tile matrix-core engine and its launchers
 //   qgtc_fp4.hip             third translation unit: the FP4 narrow-operand / grouped kernels and their launchers
+//   qgtc_wide.hip            fourth translation unit: bitmm_fp4_wide.hip.h (wide right operands: LDS-DMA staging) + launch_wide.hip.h
 //   qgtc_hip.hip             the C-ABI of include/qgtc.h (this file)
 // Design notes live in DESIGN.md.
 #include <hip/hip_runtime.h>
