@@ -20,7 +20,7 @@ namespace {
 //     takes bits s, s + 4, .. of all four IN PLACE: nibble code 1 << s = 0.5, 1, 2 with the E8M0 scale 2^(1 - s)
 //     (the fourth with one shift: code 8 is -0). Which 128 elements of K an instruction covers is free as long as both
 //     operands agree. 2.5 VALU operations per MFMA for one-plane operands; two planes become the 2-bit code of one
-//     nibble (6.5 per MFMA);
+//     nibble (6.5 per MFMA), four planes two such base-4 digits (an MFMA per pair of digits);
 //   * operands swapped (D = R-fragment x L-fragment^T): a lane owns ONE output line and four consecutive elements of it
 //     per fragment; fragment fc of a wave is made of the right-hand lines 8 fc .. 8 fc + 7 and 32 + 8 fc .. 32 + 8 fc + 7
 //     of the wave's 64, so that the 16 values a lane holds of a line are half of every byte of one output word: byte-
@@ -30,7 +30,7 @@ namespace {
 // float32 sums: exact while K (2^a - 1)(2^w - 1) < 2^24 (host).
 // ------------------------------------------------------------------------------------------
 constexpr int WD_WAVES = 8;               // 2 (left) x 4 (right) waves of RF x CF fragments each
-constexpr int WD_STAGES = 3;
+constexpr int WD_LDS_MAX = 160 * 1024;
 constexpr int WD_PIECE = 1024;            // bytes one LDS-DMA wave-instruction lands: 8 lines x 128 bytes
 
 constexpr int wd_tl(int rf) { return 2 * 16 * rf; }   // lines of the left / right operand per workgroup
@@ -38,8 +38,13 @@ constexpr int wd_tr(int cf) { return 4 * 16 * cf; }
 // gb = bytes of a line per group of K: 128 (one-plane operands: full cache lines, pieces of 8 lines) or 64 (more planes
 // per stage: pieces of 16 lines = one fragment)
 constexpr int wd_pieces(int nl, int nr, int rf, int cf, int gb) { return (nl * wd_tl(rf) + nr * wd_tr(cf)) * gb / WD_PIECE; }
+constexpr int wd_spare(int nl, int nr, int rf, int cf, int gb) { return wd_pieces(nl, nr, rf, cf, gb) % WD_WAVES ? 1 : 0; }
+// three stages (two groups in flight) where they fit the 160 KB of a CU, else two (four-plane operands)
+constexpr int wd_stages(int nl, int nr, int rf, int cf, int gb) {
+    return (3 * wd_pieces(nl, nr, rf, cf, gb) + wd_spare(nl, nr, rf, cf, gb)) * WD_PIECE <= WD_LDS_MAX ? 3 : 2;
+}
 constexpr int wd_lds_bytes(int nl, int nr, int rf, int cf, int gb) {
-    return (WD_STAGES * wd_pieces(nl, nr, rf, cf, gb) + (wd_pieces(nl, nr, rf, cf, gb) % WD_WAVES ? 1 : 0)) * WD_PIECE;
+    return (wd_stages(nl, nr, rf, cf, gb) * wd_pieces(nl, nr, rf, cf, gb) + wd_spare(nl, nr, rf, cf, gb)) * WD_PIECE;
 }
 
 // one LDS-DMA instruction: lane i's 16 bytes at (voff + soff) of the buffer land at LDS byte lds_dst + 16 i.
@@ -52,20 +57,24 @@ __device__ __forceinline__ void wd_dma(uint32_t lds_dst, uint32_t voff, i32x4 rs
                  : "memory");
 }
 
-// what a lane keeps of one fragment chunk (four packed words per plane) between the four MFMAs that use it
+// Operands of more than two planes are split into base-4 DIGITS (planes 2d, 2d + 1): one MFMA per pair of digits, the
+// E8M0 scales carry 4^(dl + dr).
+constexpr int wd_digits(int np) { return np == 1 ? 1 : np / 2; }
+
+// what a lane keeps of one fragment chunk (four packed words per plane) and digit between the four MFMAs that use it
 template <int NP>
 struct WdPrep {
     uint32_t a[4], b[4];
 };
 template <int NP>
-__device__ __forceinline__ void wd_prep(const u32x4 (&pl)[NP], WdPrep<NP> &pp) {
+__device__ __forceinline__ void wd_prep(const u32x4 (&pl)[NP], int digit, WdPrep<NP> &pp) {
     if constexpr (NP == 1) {
 #pragma unroll
         for (int t = 0; t < 4; t++) pp.a[t] = pl[0][t];
-    } else {   // the 2-bit code v of (plane 0, plane 1) at the even (a) and the odd (b) bit positions
+    } else {   // the 2-bit code v of (plane 2d, plane 2d + 1) at the even (a) and the odd (b) bit positions
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const uint32_t w0 = pl[0][t], w1 = pl[1][t];
+            const uint32_t w0 = pl[2 * digit][t], w1 = pl[2 * digit + 1][t];
             pp.a[t] = (w0 & 0x55555555u) | ((w1 & 0x55555555u) << 1);
             pp.b[t] = ((w0 >> 1) & 0x55555555u) | (w1 & 0xaaaaaaaau);
         }
@@ -84,7 +93,7 @@ __device__ __forceinline__ i32x8 wd_operand(const WdPrep<NP> &pp, int s) {
     return i32x8{static_cast<int>(o[0]), static_cast<int>(o[1]), static_cast<int>(o[2]), static_cast<int>(o[3]), 0, 0, 0, 0};
 }
 template <int NP>
-__device__ __forceinline__ constexpr int wd_scale(int s) { return NP == 1 ? (s < 3 ? 128 - s : 128) : 128; }
+__device__ __forceinline__ constexpr int wd_scale(int s, int digit) { return NP == 1 ? (s < 3 ? 128 - s : 128) : 128 + 2 * digit; }
 
 // MODE 0: packed bits [ob][out_lines][STEP128(Rc) * 4], a word = 32 consecutive right-hand lines of one left-hand line
 // (rows layout, kernel.h:357-389, or - operands exchanged by the host - the cols layout, kernel.h:651-810);
@@ -98,6 +107,9 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
     uint32_t r_bytes, uint32_t out_bytes, int Lc, int Rc, int K, int l_lines, int r_lines, int out_lines,
     uint32_t cfg /* ob | tiles along R << 8; host: ob <= 23, every byte count < 2^32 */) {
     static_assert(CF % 4 == 0 && (RF == 2 || RF == 4) && (GB == 64 || GB == 128), "fragment grid of a wave, group of K");
+    static_assert((NL == 1 || NL == 2 || NL == 4) && (NR == 1 || NR == 2 || NR == 4), "planes: one, or whole base-4 digits");
+    constexpr int NDL = wd_digits(NL), NDR = wd_digits(NR);
+    constexpr int WD_STAGES = wd_stages(NL, NR, RF, CF, GB);
     constexpr int TL = wd_tl(RF), TR = wd_tr(CF);
     constexpr int PL = GB == 128 ? 8 : 16;                          // lines per piece
     constexpr int GQ = GB / 16;                                     // k-quads per group
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
         }
     };
     issue(0);
-    issue(1);
+    if constexpr (WD_STAGES == 3) issue(1);
     WD_STAMP(1);
 
     // ---- the fragment reads of this wave: lane (li, kg) takes chunk 4 u + kg of line li of the fragment. Left-hand
@@ -196,15 +208,15 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
 #pragma unroll
         for (int j = 0; j < CF; j++) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // group g has landed for every wave that passes the barrier; stage (g + 2) % 3 = (g - 1) % 3 is free again
+    // group g has landed for every wave that passes the barrier; the stage of group g - 1 is free again
     auto publish = [&](int g) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMAS) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WD_STAGES - 2) * DMAS) : "memory");
         __builtin_amdgcn_s_barrier();
 #ifdef QGTC_STAMPS
         if (g == 0) WD_STAMP(2); else if (g == 1) WD_STAMP(3); else if (g == 2) WD_STAMP(4); else if (g == 3) WD_STAMP(5);
         else if (g == 4) WD_STAMP(6); else if (g == 5) WD_STAMP(7); else if (g == 6) WD_STAMP(8); else if (g == 7) WD_STAMP(9);
 #endif
-        issue(g + 2);
+        issue(g + WD_STAGES - 1);
     };
     // the GQ (or rem < GQ) k-quads of group g: GB / 64 rounds of (fragment reads, 4 x RF x CF MFMAs)
     auto body = [&](int g, int rem, auto tail_c) {
@@ -213,8 +225,8 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
 #pragma unroll
         for (int u = 0; u < GB / 64; u++) {
             if (TAIL && 4 * u >= rem) break;   // (workgroup-uniform)
-            WdPrep<NL> lp[RF];
-            WdPrep<NR> rp[CF];
+            WdPrep<NL> lp[RF][NDL];
+            WdPrep<NR> rp[CF][NDR];
             const bool live = 4 * u + kg < rem;   // a chunk past K: whatever the DMA found there must not count
 #pragma unroll
             for (int f = 0; f < RF; f++) {
@@ -224,7 +236,8 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
                     raw[p] = *reinterpret_cast<const u32x4 *>(stage + ((la0 + static_cast<uint32_t>(l_piece(f, p)) * WD_PIECE) ^ (64u * u)));
                     if (TAIL && !live) raw[p] = u32x4{0u, 0u, 0u, 0u};
                 }
-                wd_prep<NL>(raw, lp[f]);
+#pragma unroll
+                for (int d = 0; d < NDL; d++) wd_prep<NL>(raw, d, lp[f][d]);
             }
 #pragma unroll
             for (int f = 0; f < CF; f++) {
@@ -232,20 +245,27 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
 #pragma unroll
                 for (int p = 0; p < NR; p++)
                     raw[p] = *reinterpret_cast<const u32x4 *>(stage + ((ra0 + static_cast<uint32_t>(r_piece(f, p)) * WD_PIECE) ^ (64u * u)));
-                wd_prep<NR>(raw, rp[f]);
+#pragma unroll
+                for (int d = 0; d < NDR; d++) wd_prep<NR>(raw, d, rp[f][d]);
             }
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                i32x8 lo[RF];
+                i32x8 lo[RF][NDL];
 #pragma unroll
-                for (int f = 0; f < RF; f++) lo[f] = wd_operand<NL>(lp[f], s);
+                for (int f = 0; f < RF; f++)
 #pragma unroll
-                for (int fc = 0; fc < CF; fc++) {
-                    const i32x8 ro = wd_operand<NR>(rp[fc], s);
+                    for (int d = 0; d < NDL; d++) lo[f][d] = wd_operand<NL>(lp[f][d], s);
 #pragma unroll
-                    for (int fr = 0; fr < RF; fr++)   // lane (li, kg) register j: line 16 fr + li of the wave's lines, right-hand element 4 kg + j of fragment fc
-                        acc[fr][fc] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ro, lo[fr], acc[fr][fc], 4, 4, 0, wd_scale<NR>(s), 0, wd_scale<NL>(s));
-                }
+                for (int fc = 0; fc < CF; fc++)
+#pragma unroll
+                    for (int dr = 0; dr < NDR; dr++) {
+                        const i32x8 ro = wd_operand<NR>(rp[fc][dr], s);
+#pragma unroll
+                        for (int fr = 0; fr < RF; fr++)   // lane (li, kg) register j: line 16 fr + li of the wave's lines, right-hand element 4 kg + j of fragment fc
+#pragma unroll
+                            for (int dl = 0; dl < NDL; dl++)
+                                acc[fr][fc] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ro, lo[fr][dl], acc[fr][fc], 4, 4, 0, wd_scale<NR>(s, dr), 0, wd_scale<NL>(s, dl));
+                    }
             }
         }
     };

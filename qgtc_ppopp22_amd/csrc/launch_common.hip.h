@@ -84,29 +84,39 @@ inline bool fp4_ok(int K, int a, int w) {
     return a <= 2 && w <= 2 && static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
 }
 
-// wide right operands, one or two planes each: packed words staged by LDS-DMA, expanded in the multiplying waves' registers
-// (bitmm_fp4_wide.hip.h)
+// wide right operands; one, two or four planes per operand (not 4 x 4: its stage does not fit the LDS): packed words
+// staged by LDS-DMA, expanded in the multiplying waves' registers (bitmm_fp4_wide.hip.h)
 inline bool wide_ok(const qgtc_problem &pr, int a, int w, int ob, int mode) {
     const size_t out_bytes = mode == 2 ? static_cast<size_t>(pr.M) * pr.N * 4u
                                        : static_cast<size_t>(ob) * (mode == 1 ? pad128(pr.N) : pad8(pr.M)) * step128(mode == 1 ? pr.M : pr.N) * 16u;
-    return a >= 1 && a <= 2 && w >= 1 && w <= 2 && fp4_ok(pr.K, a, w) && (mode == 2 || (ob >= 1 && ob <= 23)) && pr.x_words < (1ull << 30) &&
-           pr.w_words < (1ull << 30) && out_bytes < (1ull << 32) && !getenv_flag("QGTC_NO_WIDE");
+    const bool planes = (a == 1 || a == 2 || a == 4) && (w == 1 || w == 2 || w == 4) && a * w < 16;
+    return planes && static_cast<double>(pr.K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0 && (mode == 2 || (ob >= 1 && ob <= 23)) &&
+           pr.x_words < (1ull << 30) && pr.w_words < (1ull << 30) && out_bytes < (1ull << 32) && !getenv_flag("QGTC_NO_WIDE");
 }
-// Measured (tools/wide_check.py): ~3.5 us of launch, first DMA and epilogue, then per 1024 bits of K and round of
-// 128 x 256 tiles 3.1 us at 1 x 1 planes, 4.6 at 1 x 2, 5.8 at 2 x 2; 1.9 / 3.4 / 3.9 on 64 x 256 tiles (twice the
-// workgroups, 3.75 instead of 2.5 VALU operations per MFMA). rf = the left-hand fragments per wave (4 or 2) that give
-// the shorter launch; returns its estimated time in us.
+// The kernel is bound by VALU issue: per MFMA and SIMD 7.8 ns + 1.55 ns per VALU operation, two waves
+// per SIMD; expanding a fragment for one MFMA position costs 5 operations per one-plane operand, 12 per base-4 digit.
+// Measured against that model (tools/wide_check.py): +3 % with 128-byte groups of K (1 x 1 planes), +27 % with 64-byte
+// groups, plus ~3.5 us of launch, first DMA and epilogue. rf = the left-hand fragments per wave (4: 128 x 256 tiles,
+// 2: 64 x 256, twice the workgroups) that give the shorter launch; returns its estimated time in us.
 inline double wide_plan(int lines, int R, int K, int a, int w, int *rf) {
-    const int pl = a + w;
-    const double tr = (R + 255) / 256;
-    const double g4 = std::ceil(((lines + 127) / 128) * tr / 256.0) * (pl == 2 ? 3.1 : pl == 3 ? 4.6 : 5.8);
-    const double g2 = std::ceil(((lines + 63) / 64) * tr / 256.0) * (pl == 2 ? 1.9 : pl == 3 ? 3.4 : 3.9);
-    if (rf) *rf = g2 < g4 ? 2 : 4;
-    return 3.5 + (step128(K) / 8.0) * std::min(g2, g4);
+    auto digits = [](int p) { return p == 1 ? 1 : p / 2; };
+    auto expand = [&](int p) { return p == 1 ? 5.0 : 12.0 * digits(p); };
+    const double tr = (R + 255) / 256, nd = digits(a) * digits(w);
+    double best = 0.0;
+    for (int f = a == 4 ? 2 : 4; f >= 2; f -= 2) {   // (four left-hand planes: 2 x 4 fragments only)
+        const double v = (f * expand(a) + 4 * expand(w)) / (f * 4 * nd);
+        const double per_group = 2.0 * f * 4 * 8 * nd * (7.8 + 1.55 * v) * 1e-3 * (a + w == 2 ? 1.03 : 1.27);   // us per 1024 bits of K and round
+        const double t = std::ceil(((lines + 32 * f - 1) / (32 * f)) * tr / 256.0) * per_group;
+        if (best == 0.0 || t < best) {
+            best = t;
+            if (rf) *rf = f;
+        }
+    }
+    return 3.5 + (step128(K) / 8.0) * best;
 }
 // QGTC_ENGINE_AUTO
 inline bool auto_prefers_wide(int M, int K, int N, int a, int w, int mode) {
-    const double t_wide = wide_plan(mode == 1 ? N : M, mode == 1 ? M : N, K, a, w, nullptr);
+    const double t_wide = wide_plan(mode == 1 ? N : M, mode == 1 ? M : N, K, mode == 1 ? w : a, mode == 1 ? a : w, nullptr);
     const double t_pop = 3.0 + 2.0 * M * static_cast<double>(K) * N * a * w / 0.95e15 * 1e6;
     return t_wide < 0.9 * t_pop;
 }

@@ -2,7 +2,9 @@
 #pragma once
 
 #define QGTC_WD_FOR_PLANES(F, NL, NR, GB) F(NL, NR, 0, 4, 4, GB) F(NL, NR, 2, 4, 4, GB) F(NL, NR, 0, 2, 4, GB) F(NL, NR, 2, 2, 4, GB)
-#define QGTC_WD_FOR_ALL(F) QGTC_WD_FOR_PLANES(F, 1, 1, 128) QGTC_WD_FOR_PLANES(F, 1, 2, 64) QGTC_WD_FOR_PLANES(F, 2, 1, 64) QGTC_WD_FOR_PLANES(F, 2, 2, 64)
+#define QGTC_WD_FOR_ALL(F)                                                                                                   \
+    QGTC_WD_FOR_PLANES(F, 1, 1, 128) QGTC_WD_FOR_PLANES(F, 1, 2, 64) QGTC_WD_FOR_PLANES(F, 2, 1, 64) QGTC_WD_FOR_PLANES(F, 2, 2, 64) \
+    QGTC_WD_FOR_PLANES(F, 1, 4, 64) QGTC_WD_FOR_PLANES(F, 2, 4, 64) F(4, 1, 0, 2, 4, 64) F(4, 1, 2, 2, 4, 64) F(4, 2, 0, 2, 4, 64) F(4, 2, 2, 2, 4, 64)
 
 // mode 0 rows-layout bits, 1 cols-layout bits (the operands change places: a cols-layout word runs along M), 2 float32
 int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st) {
@@ -23,12 +25,13 @@ int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hip
         return QGTC_OK;
     });
     if (arc != QGTC_OK) return arc;
-    const int nl = swap ? w : a, nr = swap ? a : w;   // planes of the left / right operand (1 or 2 each: wide_ok)
+    const int nl = swap ? w : a, nr = swap ? a : w;   // planes of the left / right operand (1, 2 or 4 each, not 4 x 4: wide_ok)
     const int cover = mode == 2 ? Lc : out_lines;   // (the padding lines of the bit layouts are written as zeros)
     const int nt_r = (Rc + wd_tr(4) - 1) / wd_tr(4);
     int rf = 4;
-    wide_plan(cover, Rc, pr.K, a, w, &rf);
+    wide_plan(cover, Rc, pr.K, nl, nr, &rf);
     if (const char *e = std::getenv("QGTC_WIDE_RF")) rf = std::atoi(e) == 2 ? 2 : 4;   // (tuning only)
+    if (nl == 4) rf = 2;   // (four left-hand planes on 4 x 4 fragments spill registers: not instantiated)
     const int nt_l = (cover + wd_tl(rf) - 1) / wd_tl(rf);
     const uint32_t cfg = static_cast<uint32_t>(ob) | static_cast<uint32_t>(nt_r) << 8;
     const dim3 grid(static_cast<unsigned>(nt_l * nt_r)), block(64 * WD_WAVES);

@@ -633,10 +633,10 @@ def test_row_block_kernel_for_sparse_left_operands(qgtc, oracle, a, w, ob):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rf", ["", "2", "4"])
-@pytest.mark.parametrize("a,w", [(1, 1), (1, 2), (2, 1), (2, 2)])
+@pytest.mark.parametrize("a,w", [(1, 1), (1, 2), (2, 1), (2, 2), (1, 4), (4, 1), (2, 4), (4, 2)])
 def test_wide_operand_kernel_equals_the_oracle(qgtc, oracle, monkeypatch, rf, a, w):
-    """k_bitmm_fp4_wide (one- and two-plane operands, N > 256: packed words staged by LDS-DMA, expanded in registers)
-    against the oracle in all three output forms: ragged M and N, K with 1..8 k-quads in the last group, fewer lines than
+    """k_bitmm_fp4_wide (one-, two- and four-plane operands, N > 256: packed words staged by LDS-DMA, expanded in
+    registers, base-4 digits for four planes) against the oracle in all three output forms: ragged M and N, K with 1..8 k-quads in the last group, fewer lines than
     a tile, several output widths (one / two planes have their own epilogue), both tile shapes forced in turn."""
     import torch
     from helpers import rand_q, to_dev
@@ -644,7 +644,8 @@ def test_wide_operand_kernel_equals_the_oracle(qgtc, oracle, monkeypatch, rf, a,
     if rf:
         monkeypatch.setenv("QGTC_WIDE_RF", rf)
     rng = np.random.default_rng(77 + 10 * a + w)
-    for (M, K, N) in ((129, 1024, 257), (300, 896, 513), (8, 3968, 264), (77, 128, 1000), (513, 2176, 1030), (1000, 1152, 300), (64, 8320, 520)):
+    shapes = ((129, 1024, 257), (300, 896, 513), (8, 3968, 264), (77, 128, 1000), (513, 2176, 1030), (1000, 1152, 300), (64, 8320, 520))
+    for (M, K, N) in (shapes if not rf else shapes[1:4]):
         qx, qw = rand_q(rng, M, K, a), rand_q(rng, K, N, w)
         X, Wt = oracle.pack(qx, a, False), oracle.pack(qw, w, True)
         bX, bW = to_dev(torch, X, rows_shape(M, K, a)), to_dev(torch, Wt, cols_shape(K, N, w))
