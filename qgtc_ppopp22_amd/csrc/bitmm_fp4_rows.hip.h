@@ -78,59 +78,73 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
     // A row and T line (one 16-byte load per lane, operand and plane - every byte used; 4-byte loads at a 160-byte row
     // stride cost the address unit 16 cycles each for a quarter of the data), and MFMA t = 0..3 of the pair multiplies
     // word t of both k-quads: which 64 elements of K an instruction covers is free as long as A and T agree.
-    while (todo != 0ull) {   // wave-uniform
-        int q[RS_CHUNK];     // this lane's k-quad of pair c (-1: none)
+    // Two register sets in turn: the loads of the NEXT pair are issued before the current one is multiplied. (Written
+    // as a loop over chunks of pairs with a `break` for the missing ones, hipcc sank the loads of the second pair below
+    // the multiplication of the first - one more exposed memory latency for every row block with three k-quads or more.)
+    unsigned todo_lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(todo)), todo_hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(todo >> 32));
+    unsigned long long left = (static_cast<unsigned long long>(todo_hi) << 32) | todo_lo;   // (wave-uniform: scalar registers)
+    struct Pair {
+        int first;      // this lane's k-quad of the pair (-1: none)
+        bool second;    // the pair exists (wave-uniform)
+    };
+    auto take = [&]() {
+        const int qa = left != 0ull ? __builtin_ctzll(left) : -1;
+        left &= left - 1ull;
+        const int qb = left != 0ull ? __builtin_ctzll(left) : -1;
+        left &= left - 1ull;
+        return Pair{qa < 0 ? -1 : (fh ? qb : qa), qa >= 0};
+    };
+    auto load = [&](int q, u32x4 (&xl)[NA], u32x4 (&wl)[CB][NW]) {   // unconditional (a missing k-quad reads zeros): exact vmcnt waits
+        const uint32_t ko = static_cast<uint32_t>(q) * 16u;
 #pragma unroll
-        for (int c = 0; c < RS_CHUNK; c++) {
-            const int qa = todo != 0ull ? __builtin_ctzll(todo) : -1;
-            todo &= todo - 1ull;
-            const int qb = todo != 0ull ? __builtin_ctzll(todo) : -1;
-            todo &= todo - 1ull;
-            q[c] = fh ? qb : qa;
-            if (qa < 0) q[c] = -1;
-        }
-        u32x4 xl[RS_CHUNK][NA], wl[RS_CHUNK][CB][NW];
+        for (int p = 0; p < NA; p++)
+            xl[p] = __builtin_amdgcn_raw_buffer_load_b128(rx, (q >= 0 && x_base != 0xffffffffu && p < sh.a) ? x_base + static_cast<uint32_t>(p) * x_plane + ko : 0xffffffffu, 0, 0);
 #pragma unroll
-        for (int c = 0; c < RS_CHUNK; c++) {   // unconditional loads (a missing k-quad reads zeros): exact vmcnt waits
-            const uint32_t ko = static_cast<uint32_t>(q[c]) * 16u;
+        for (int j = 0; j < CB; j++)
 #pragma unroll
-            for (int p = 0; p < NA; p++)
-                xl[c][p] = __builtin_amdgcn_raw_buffer_load_b128(rx, (q[c] >= 0 && x_base != 0xffffffffu && p < sh.a) ? x_base + static_cast<uint32_t>(p) * x_plane + ko : 0xffffffffu, 0, 0);
+            for (int p = 0; p < NW; p++)
+                wl[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rw, (q >= 0 && w_base[j] != 0xffffffffu && p < sh.w) ? w_base[j] + static_cast<uint32_t>(p) * w_plane + ko : 0xffffffffu, 0, 0);
+    };
+    auto multiply = [&](const u32x4 (&xl)[NA], const u32x4 (&wl)[CB][NW]) {
 #pragma unroll
-            for (int j = 0; j < CB; j++)
+        for (int t = 0; t < 4; t++) {
+            uint32_t xw[NA];
 #pragma unroll
-                for (int p = 0; p < NW; p++)
-                    wl[c][j][p] = __builtin_amdgcn_raw_buffer_load_b128(rw, (q[c] >= 0 && w_base[j] != 0xffffffffu && p < sh.w) ? w_base[j] + static_cast<uint32_t>(p) * w_plane + ko : 0xffffffffu, 0, 0);
-        }
-#ifdef QGTC_STAMPS
-        asm volatile("" ::"v"(xl[0][0]), "v"(wl[0][0][0]));
-        if (st_[2] == 0) RW_STAMP(2);
-#endif
+            for (int p = 0; p < NA; p++) xw[p] = xl[p][t];
+            i32x8 xa[NDA];
 #pragma unroll
-        for (int c = 0; c < RS_CHUNK; c++) {
-            if (__builtin_amdgcn_readfirstlane(q[c]) < 0) break;   // (lanes of half 0 hold the pair's first k-quad)
+            for (int da = 0; da < NDA; da++) xa[da] = strip_operand<NA>(xw, da);
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                uint32_t xw[NA];
+            for (int j = 0; j < CB; j++) {
+                uint32_t ww[NW];
 #pragma unroll
-                for (int p = 0; p < NA; p++) xw[p] = xl[c][p][t];
-                i32x8 xa[NDA];
+                for (int p = 0; p < NW; p++) ww[p] = wl[j][p][t];
 #pragma unroll
-                for (int da = 0; da < NDA; da++) xa[da] = strip_operand<NA>(xw, da);
+                for (int dw = 0; dw < NDW; dw++) {
+                    const i32x8 wb = strip_operand<NW>(ww, dw);
 #pragma unroll
-                for (int j = 0; j < CB; j++) {
-                    uint32_t ww[NW];
-#pragma unroll
-                    for (int p = 0; p < NW; p++) ww[p] = wl[c][j][p][t];
-#pragma unroll
-                    for (int dw = 0; dw < NDW; dw++) {
-                        const i32x8 wb = strip_operand<NW>(ww, dw);
-#pragma unroll
-                        for (int da = 0; da < NDA; da++)   // swapped: lane (fl, fh) register r holds C[row fl][column (r & 3) + 8 (r >> 2) + 4 fh]
-                            acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb, xa[da], acc[j], 4, 4, 0, 128 + 2 * dw, 0, 128 + 2 * da);
-                    }
+                    for (int da = 0; da < NDA; da++)   // swapped: lane (fl, fh) register r holds C[row fl][column (r & 3) + 8 (r >> 2) + 4 fh]
+                        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb, xa[da], acc[j], 4, 4, 0, 128 + 2 * dw, 0, 128 + 2 * da);
                 }
             }
+        }
+    };
+    {
+        u32x4 xa_[NA], wa_[CB][NW], xb_[NA], wb_[CB][NW];
+        auto pa = take();
+        load(pa.first, xa_, wa_);
+#ifdef QGTC_STAMPS
+        asm volatile("" ::"v"(xa_[0]), "v"(wa_[0][0]));
+        RW_STAMP(2);
+#endif
+        while (pa.second) {   // wave-uniform
+            auto pb = take();
+            if (pb.second) load(pb.first, xb_, wb_);
+            multiply(xa_, wa_);
+            if (!pb.second) break;
+            pa = take();
+            if (pa.second) load(pa.first, xa_, wa_);
+            multiply(xb_, wb_);
         }
     }
 
