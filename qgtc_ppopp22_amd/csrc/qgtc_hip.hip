@@ -19,6 +19,7 @@
 //   bitmm_popcount.hip.h     the bit-GEMM on AND + popcount (engine "popcount", and every plane count the matrix-core
 //                            kernels do not cover) - start at the comment above `mm_tile`
 //   bitmm_mfma.hip.h         the bit-GEMM on the matrix cores, 128 x 128 tiles (wide right operands)
+//   fp4_expand.hip.h         packed words -> E2M1 MFMA operands in place (one AND per dword; digits)
 //   bitmm_fp4_one.hip.h      the same for narrow right operands (N <= 256) and K <= 4096: the headline kernel
 //   bitmm_fp4_skinny.hip.h   the same for longer K: no LDS staging
 //   bitmm_fp4_wave.hip.h     grouped launches over cluster batches: one wave per 32 x 32 tile
@@ -58,6 +59,7 @@
 #define QGTC_LAYER_MFMA 1
 #define QGTC_LAYER_WAVE 1
 #include "bitmm_layer.hip.h"
+#include "fp4_expand.hip.h"
 #include "bitmm_fp4_wide.hip.h"
 #include "launch_fp4.hip.h"
 #include "launch_mfma.hip.h"
