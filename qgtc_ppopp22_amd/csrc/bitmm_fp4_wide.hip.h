@@ -60,15 +60,16 @@ __device__ __forceinline__ void wd_dma(uint32_t lds_dst, uint32_t voff, i32x4 rs
 // MODE 0: packed bits [ob][out_lines][STEP128(Rc) * 4], a word = 32 consecutive right-hand lines of one left-hand line
 // (rows layout, kernel.h:357-389, or - operands exchanged by the host - the cols layout, kernel.h:651-810);
 // MODE 2: float32 [Lc][Rc] (kernel.h:915-930).
-// RF x CF fragments per wave (CF a multiple of 4: whole output words): 4 x 4 when the grid fills the chip, 2 x 4
-// (64 x 256 workgroup tiles, 3.75 instead of 2.5 VALU operations per MFMA) when it would leave half the CUs idle.
+// RF x CF fragments per wave: 4 x 4 when the grid fills the chip, else 2 x 4 (64 x 256 workgroup tiles, 3.75 instead of
+// 2.5 VALU operations per MFMA) or 4 x 2 (128 x 128 tiles: the right-hand operand's expansions, the costlier ones when it
+// has more planes, are still shared by four fragments).
 // GB bytes of every line per group of K (128 for one-plane operands, 64 when the stage has to hold more planes).
 template <int NL, int NR, int MODE, int RF, int CF, int GB>
 __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
     const uint32_t *__restrict__ Lp, const uint32_t *__restrict__ Rp, void *__restrict__ outp, uint32_t l_bytes,
     uint32_t r_bytes, uint32_t out_bytes, int Lc, int Rc, int K, int l_lines, int r_lines, int out_lines,
     uint32_t cfg /* ob | tiles along R << 8; host: ob <= 23, every byte count < 2^32 */) {
-    static_assert(CF % 4 == 0 && (RF == 2 || RF == 4) && (GB == 64 || GB == 128), "fragment grid of a wave, group of K");
+    static_assert((CF % 4 == 0 || CF == 2) && (RF == 2 || RF == 4) && (GB == 64 || GB == 128), "fragment grid of a wave, group of K");
     static_assert((NL == 1 || NL == 2 || NL == 4) && (NR == 1 || NR == 2 || NR == 4), "planes: one, or whole base-4 digits");
     constexpr int NDL = wd_digits(NL), NDR = wd_digits(NR);
     constexpr int WD_STAGES = wd_stages(NL, NR, RF, CF, GB);
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
         const int rr = lane >> 2, cc = lane & 3;
         const uint32_t swz = static_cast<uint32_t>(cc ^ ((0x78 >> (2 * (rr >> 2))) & 3)) * 16u;
         voff_l = static_cast<uint32_t>(tl * TL + rr) * row_bytes + swz;
-        voff_r = static_cast<uint32_t>(tr * TR + (rr & 7) + 32 * (rr >> 3)) * row_bytes + swz;   // (a right-hand fragment: two runs of 8 lines)
+        // (a right-hand fragment: two runs of 8 lines, or - CF = 2 - four runs of 4)
+        voff_r = static_cast<uint32_t>(tr * TR + (CF == 2 ? (rr & 3) + 8 * (rr >> 2) : (rr & 7) + 32 * (rr >> 3))) * row_bytes + swz;
     }
     const uint32_t l_plane = static_cast<uint32_t>(l_lines) * row_bytes, r_plane = static_cast<uint32_t>(r_lines) * row_bytes;
     auto issue = [&](int g) {   // group g -> stage g % 3 (groups past the last: garbage into a stage nobody reads)
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
                 wd_dma(base + static_cast<uint32_t>(t) * WD_PIECE, voff_l, rs_l, ko + static_cast<uint32_t>(p) * l_plane + static_cast<uint32_t>(PL * q) * row_bytes);
             } else if (TOT % WD_WAVES == 0 || t < TOT) {
                 const int p = (t - LPC) / RPP, q = (t - LPC) % RPP;
-                const int line = GB == 128 ? 8 * q : 64 * (q >> 2) + 8 * (q & 3);
+                const int line = GB == 128 ? 8 * q : CF == 2 ? 32 * (q >> 1) + 4 * (q & 1) : 64 * (q >> 2) + 8 * (q & 3);
                 wd_dma(base + static_cast<uint32_t>(t) * WD_PIECE, voff_r, rs_r, ko + static_cast<uint32_t>(p) * r_plane + static_cast<uint32_t>(line) * row_bytes);
             } else {   // (keeps the count of outstanding loads the same for every wave: lands in a spare piece)
                 wd_dma(lds0 + static_cast<uint32_t>(WD_STAGES) * STAGE, voff_l, rs_l, 0xfffffff0u);
@@ -150,19 +152,29 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
 
     // ---- the fragment reads of this wave: lane (li, kg) takes chunk 4 u + kg of line li of the fragment. Left-hand
     // fragment fr = lines 16 fr .. 16 fr + 15 of the wave's 16 RF; right-hand fragment fc = lines 8 (fc & 3) .. + 7 and
-    // 32 + 8 (fc & 3) .. + 7 of block fc >> 2 of 64 lines (a lane's 16 values of a line and block = half of every byte of one word)
+    // 32 + 8 (fc & 3) .. + 7 of block fc >> 2 of 64 lines (a lane's 16 values of a line and block = half of every byte of
+    // one word); with CF = 2 (32 lines, one word per wave) fragment fc = lines 8 g + 4 fc .. + 3, g = 0..3: a lane's 8
+    // values of a line are ONE byte of the word
     uint32_t la0, ra0;   // + the fragment's and the plane's pieces
     if constexpr (GB == 128) {
         const uint32_t frag_off = static_cast<uint32_t>(li & 7) * 128u + static_cast<uint32_t>(kg ^ (li & 6)) * 16u;
         la0 = static_cast<uint32_t>(2 * RF * wr + (li >> 3)) * WD_PIECE + frag_off;
-        ra0 = static_cast<uint32_t>(LPC + 2 * CF * wc + 4 * (li >> 3)) * WD_PIECE + frag_off;
+        if constexpr (CF == 2)   // line 8 (li >> 2) + 4 fc + (li & 3) of the wave's 32: piece li >> 2, row 4 fc + (li & 3) of it
+            ra0 = static_cast<uint32_t>(LPC + 4 * wc + (li >> 2)) * WD_PIECE + static_cast<uint32_t>(li & 3) * 128u + static_cast<uint32_t>(kg ^ (li & 2)) * 16u;
+        else
+            ra0 = static_cast<uint32_t>(LPC + 2 * CF * wc + 4 * (li >> 3)) * WD_PIECE + frag_off;
     } else {
         const uint32_t frag_off = static_cast<uint32_t>(li) * 64u + static_cast<uint32_t>(kg ^ ((0x78 >> (2 * (li >> 2))) & 3)) * 16u;
         la0 = static_cast<uint32_t>(RF * wr) * WD_PIECE + frag_off;
         ra0 = static_cast<uint32_t>(LPC + CF * wc) * WD_PIECE + frag_off;
     }
-    auto l_piece = [](int f, int p) { return GB == 128 ? 2 * f + p * LPP : f + p * LPP; };
-    auto r_piece = [](int f, int p) { return GB == 128 ? 8 * (f >> 2) + (f & 3) + p * RPP : f + p * RPP; };
+    auto l_addr = [&](int f, int p, int u) { return (la0 + static_cast<uint32_t>((GB == 128 ? 2 * f : f) + p * LPP) * WD_PIECE) ^ (64u * u); };
+    auto r_addr = [&](int f, int p, int u) {
+        if constexpr (GB == 128 && CF == 2)   // (row 4 f + .. of the piece: its swizzle term and the chunk's 4 u share bit 6)
+            return (ra0 + static_cast<uint32_t>(p * RPP) * WD_PIECE + 512u * f) ^ (64u * (u ^ f));
+        else
+            return (ra0 + static_cast<uint32_t>((GB == 128 ? 8 * (f >> 2) + (f & 3) : f) + p * RPP) * WD_PIECE) ^ (64u * u);
+    };
 
     f32x4 acc[RF][CF];
 #pragma unroll
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
                 u32x4 raw[NL];
 #pragma unroll
                 for (int p = 0; p < NL; p++) {
-                    raw[p] = *reinterpret_cast<const u32x4 *>(stage + ((la0 + static_cast<uint32_t>(l_piece(f, p)) * WD_PIECE) ^ (64u * u)));
+                    raw[p] = *reinterpret_cast<const u32x4 *>(stage + l_addr(f, p, u));
                     if (TAIL && !live) raw[p] = u32x4{0u, 0u, 0u, 0u};
                 }
 #pragma unroll
@@ -206,7 +218,7 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
                 u32x4 raw[NR];
 #pragma unroll
                 for (int p = 0; p < NR; p++)
-                    raw[p] = *reinterpret_cast<const u32x4 *>(stage + ((ra0 + static_cast<uint32_t>(r_piece(f, p)) * WD_PIECE) ^ (64u * u)));
+                    raw[p] = *reinterpret_cast<const u32x4 *>(stage + r_addr(f, p, u));
 #pragma unroll
                 for (int d = 0; d < NDR; d++) wd_prep<NR>(raw, d, rp[f][d]);
             }
@@ -247,10 +259,84 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the two groups issued past the end)
     WD_STAMP(11);
 
-    // ---- epilogue, from the accumulators. Element 4 kg + j of fragment fc is the right-hand line
-    // 64 (fc >> 2) + 32 (kg >> 1) + 8 (fc & 3) + 4 (kg & 1) + j of the wave's lines.
+    // ---- epilogue, from the accumulators
     const __amdgpu_buffer_rsrc_t ro_ = __builtin_amdgcn_make_buffer_rsrc(outp, 0, static_cast<int>(out_bytes), 0x00020000);
     const int line0 = tl * TL + 16 * RF * wr + li;
+    if constexpr (CF == 2) {
+        // element 4 kg + j of fragment fc is the right-hand line 8 kg + 4 fc + j of the wave's 32: byte 3 - kg of ONE word
+        const int c0 = tr * TR + 32 * wc;
+        if (MODE == 2) {
+#pragma unroll
+            for (int fr = 0; fr < RF; fr++) {
+                const int line = line0 + 16 * fr;
+#pragma unroll
+                for (int fc = 0; fc < 2; fc++) {
+                    const int c = c0 + 8 * kg + 4 * fc;
+                    const uint32_t off = (static_cast<uint32_t>(line) * static_cast<uint32_t>(Rc) + static_cast<uint32_t>(c)) * 4u;
+                    if (line < Lc && c + 3 < Rc && (Rc & 3) == 0) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[fr][fc]), ro_, off, 0, 0);
+                    } else if (line < Lc) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (c + j < Rc) {
+                                const float v = acc[fr][fc][j];
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro_, off + 4u * j, 0, 0);
+                            }
+                    }
+                }
+            }
+        } else {
+            const int pitch = step128(Rc) * 4, word = c0 >> 5;
+            const uint32_t oplane_bytes = static_cast<uint32_t>(out_lines) * static_cast<uint32_t>(pitch) * 4u;
+            const int valid = min(max(Rc - c0, 0), 32);
+            const uint32_t wmask = valid >= 32 ? 0xffffffffu : ~(0xffffffffu >> valid);
+            const int maxi = 1 << ob;
+            const float lim = static_cast<float>(maxi), onesf = static_cast<float>(maxi - 1);
+#pragma unroll
+            for (int fr = 0; fr < RF; fr++) {
+                const int line = line0 + 16 * fr;
+                const bool store = kg == 0 && line < out_lines && word < pitch;
+                uint32_t off = store ? (static_cast<uint32_t>(line) * static_cast<uint32_t>(pitch) + static_cast<uint32_t>(word)) * 4u : 0xffffffffu;
+                const uint32_t keep = line < Lc ? wmask : 0u;
+                uint32_t P[2] = {0u, 0u};   // byte 3 - j of P[fc] = re-quantised value (fc, j), planes below 8
+                int q[2][4];
+#pragma unroll
+                for (int fc = 0; fc < 2; fc++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (ob <= 4) {      // (compare and select on the float, v_cvt_pk_u8_f32 converts and inserts: requant_pack16)
+                            float f = acc[fr][fc][j];
+                            f = f > lim ? onesf : f;
+                            P[fc] = __builtin_amdgcn_cvt_pk_u8_f32(f, 3 - j, P[fc]);
+                        } else {
+                            const int c = static_cast<int>(acc[fr][fc][j]);
+                            q[fc][j] = c > maxi ? maxi - 1 : c;
+                            P[fc] |= (static_cast<uint32_t>(q[fc][j]) & 255u) << (8 * (3 - j));
+                        }
+                    }
+                for (int p = 0; p < ob; p++, off += store ? oplane_bytes : 0u) {
+                    uint32_t byte;
+                    if (p < 8) {
+                        const uint32_t t0 = (P[0] >> p) & 0x01010101u, t1 = (P[1] >> p) & 0x01010101u;
+                        const uint32_t n0 = (((t0 >> 21) | (t0 >> 14)) | ((t0 >> 7) | t0)) & 0xfu, n1 = (((t1 >> 21) | (t1 >> 14)) | ((t1 >> 7) | t1)) & 0xfu;
+                        byte = n0 << 4 | n1;
+                    } else {
+                        byte = 0u;
+#pragma unroll
+                        for (int fc = 0; fc < 2; fc++)
+#pragma unroll
+                            for (int j = 0; j < 4; j++) byte |= ((static_cast<uint32_t>(q[fc][j]) >> p) & 1u) << (7 - 4 * fc - j);
+                    }
+                    uint32_t x = byte << (8u * (3u - static_cast<uint32_t>(kg)));
+                    const auto s16 = __builtin_amdgcn_permlane16_swap(x, x, false, false);   // lanes (li, kg) and (li, kg ^ 1)
+                    x = s16[0] | s16[1];
+                    x = or_with_partner_half(x) & keep;                                      // and (li, kg ^ 2)
+                    __builtin_amdgcn_raw_buffer_store_b32(x, ro_, off, 0, 0);
+                }
+            }
+        }
+    } else {
+    // element 4 kg + j of fragment fc is the right-hand line 64 (fc >> 2) + 32 (kg >> 1) + 8 (fc & 3) + 4 (kg & 1) + j
     const int col0 = tr * TR + 16 * CF * wc + 32 * (kg >> 1);   // first right-hand line of the lane's output word of block 0
     if (MODE == 2) {
 #pragma unroll
@@ -318,6 +404,7 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
         if (ob == 1) finish(std::integral_constant<int, 1>{});
         else if (ob == 2) finish(std::integral_constant<int, 2>{});
         else finish(std::integral_constant<int, 0>{});
+    }
     }
 #ifdef QGTC_STAMPS
     WD_STAMP(12);

@@ -96,20 +96,26 @@ inline bool wide_ok(const qgtc_problem &pr, int a, int w, int ob, int mode) {
 // The kernel is bound by VALU issue: per MFMA and SIMD 7.8 ns + 1.55 ns per VALU operation, two waves
 // per SIMD; expanding a fragment for one MFMA position costs 5 operations per one-plane operand, 12 per base-4 digit.
 // Measured against that model (tools/wide_check.py): +3 % with 128-byte groups of K (1 x 1 planes), +27 % with 64-byte
-// groups, plus ~3.5 us of launch, first DMA and epilogue. rf = the left-hand fragments per wave (4: 128 x 256 tiles,
-// 2: 64 x 256, twice the workgroups) that give the shorter launch; returns its estimated time in us.
-inline double wide_plan(int lines, int R, int K, int a, int w, int *rf) {
+// groups, plus ~3.5 us of launch, first DMA and epilogue. rf x cf = the fragments per wave (4 x 4: 128 x 256 tiles,
+// 2 x 4: 64 x 256, 4 x 2: 128 x 128, twice the workgroups either way) that give the shortest launch; returns its
+// estimated time in us.
+inline double wide_plan(int lines, int R, int K, int a, int w, int *rf, int *cf = nullptr) {
     auto digits = [](int p) { return p == 1 ? 1 : p / 2; };
     auto expand = [&](int p) { return p == 1 ? 5.0 : 12.0 * digits(p); };
-    const double tr = (R + 255) / 256, nd = digits(a) * digits(w);
+    const double nd = digits(a) * digits(w);
+    const int shapes[3][2] = {{4, 4}, {2, 4}, {4, 2}};   // fragments per wave: 128 x 256, 64 x 256, 128 x 128 tiles
     double best = 0.0;
-    for (int f = a == 4 ? 2 : 4; f >= 2; f -= 2) {   // (four left-hand planes: 2 x 4 fragments only)
-        const double v = (f * expand(a) + 4 * expand(w)) / (f * 4 * nd);
-        const double per_group = 2.0 * f * 4 * 8 * nd * (7.8 + 1.55 * v) * 1e-3 * (a + w == 2 ? 1.03 : 1.27);   // us per 1024 bits of K and round
-        const double t = std::ceil(((lines + 32 * f - 1) / (32 * f)) * tr / 256.0) * per_group;
+    for (const auto &sh : shapes) {
+        const int f = sh[0], c = sh[1];
+        if (a == 4 && f == 4) continue;   // (four left-hand planes: 2 x 4 fragments only)
+        const double v = (f * expand(a) + c * expand(w)) / (f * c * nd);
+        const double per_group = 2.0 * f * c * 8 * nd * (7.8 + 1.55 * v) * 1e-3 * (a + w == 2 ? 1.03 : 1.27);   // us per 1024 bits of K and round
+        const double tiles = static_cast<double>((lines + 32 * f - 1) / (32 * f)) * ((R + 64 * c - 1) / (64 * c));
+        const double t = std::ceil(tiles / 256.0) * per_group;
         if (best == 0.0 || t < best) {
             best = t;
             if (rf) *rf = f;
+            if (cf) *cf = c;
         }
     }
     return 3.5 + (step128(K) / 8.0) * best;

@@ -1,7 +1,8 @@
 // launch_wide.hip.h — part of libqgtc_hip.so (qgtc_wide.hip): launcher of the wide-operand FP4 kernel.
 #pragma once
 
-#define QGTC_WD_FOR_PLANES(F, NL, NR, GB) F(NL, NR, 0, 4, 4, GB) F(NL, NR, 2, 4, 4, GB) F(NL, NR, 0, 2, 4, GB) F(NL, NR, 2, 2, 4, GB)
+#define QGTC_WD_FOR_PLANES(F, NL, NR, GB) \
+    F(NL, NR, 0, 4, 4, GB) F(NL, NR, 2, 4, 4, GB) F(NL, NR, 0, 2, 4, GB) F(NL, NR, 2, 2, 4, GB) F(NL, NR, 0, 4, 2, GB) F(NL, NR, 2, 4, 2, GB)
 #define QGTC_WD_FOR_ALL(F)                                                                                                   \
     QGTC_WD_FOR_PLANES(F, 1, 1, 128) QGTC_WD_FOR_PLANES(F, 1, 2, 64) QGTC_WD_FOR_PLANES(F, 2, 1, 64) QGTC_WD_FOR_PLANES(F, 2, 2, 64) \
     QGTC_WD_FOR_PLANES(F, 1, 4, 64) QGTC_WD_FOR_PLANES(F, 2, 4, 64) F(4, 1, 0, 2, 4, 64) F(4, 1, 2, 2, 4, 64) F(4, 2, 0, 2, 4, 64) F(4, 2, 2, 2, 4, 64)
@@ -27,18 +28,22 @@ int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hip
     if (arc != QGTC_OK) return arc;
     const int nl = swap ? w : a, nr = swap ? a : w;   // planes of the left / right operand (1, 2 or 4 each, not 4 x 4: wide_ok)
     const int cover = mode == 2 ? Lc : out_lines;   // (the padding lines of the bit layouts are written as zeros)
-    const int nt_r = (Rc + wd_tr(4) - 1) / wd_tr(4);
-    int rf = 4;
-    wide_plan(cover, Rc, pr.K, nl, nr, &rf);
-    if (const char *e = std::getenv("QGTC_WIDE_RF")) rf = std::atoi(e) == 2 ? 2 : 4;   // (tuning only)
-    if (nl == 4) rf = 2;   // (four left-hand planes on 4 x 4 fragments spill registers: not instantiated)
+    int rf = 4, cf = 4;
+    wide_plan(cover, Rc, pr.K, nl, nr, &rf, &cf);
+    if (const char *e = std::getenv("QGTC_WIDE_RF")) {   // (tuning only: 4 = 4 x 4 fragments per wave, 2 = 2 x 4, 42 = 4 x 2)
+        const int v = std::atoi(e);
+        rf = v == 2 ? 2 : 4;
+        cf = v == 42 ? 2 : 4;
+    }
+    if (nl == 4) rf = 2, cf = 4;   // (four left-hand planes on four fragments per wave spill registers: not instantiated)
+    const int nt_r = (Rc + wd_tr(cf) - 1) / wd_tr(cf);
     const int nt_l = (cover + wd_tl(rf) - 1) / wd_tl(rf);
     const uint32_t cfg = static_cast<uint32_t>(ob) | static_cast<uint32_t>(nt_r) << 8;
     const dim3 grid(static_cast<unsigned>(nt_l * nt_r)), block(64 * WD_WAVES);
     const int md = mode == 2 ? 2 : 0;
     bool launched = false;
 #define QGTC_WD_LAUNCH(NL, NR, MD, RF, CF, GB)                                                                                              \
-    if (!launched && nl == NL && nr == NR && md == MD && rf == RF) {                                                                        \
+    if (!launched && nl == NL && nr == NR && md == MD && rf == RF && cf == CF) {                                                                        \
         hipLaunchKernelGGL((k_bitmm_fp4_wide<NL, NR, MD, RF, CF, GB>), grid, block, wd_lds_bytes(NL, NR, RF, CF, GB), st, Lp, Rp, pr.out, l_bytes, \
                            r_bytes, static_cast<uint32_t>(out_bytes), Lc, Rc, pr.K, l_lines, r_lines, out_lines, cfg);                      \
         launched = true;                                                                                                                    \

@@ -632,12 +632,12 @@ def test_row_block_kernel_for_sparse_left_operands(qgtc, oracle, a, w, ob):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rf", ["", "2", "4"])
+@pytest.mark.parametrize("rf", ["", "2", "4", "42"])
 @pytest.mark.parametrize("a,w", [(1, 1), (1, 2), (2, 1), (2, 2), (1, 4), (4, 1), (2, 4), (4, 2)])
 def test_wide_operand_kernel_equals_the_oracle(qgtc, oracle, monkeypatch, rf, a, w):
     """k_bitmm_fp4_wide (one-, two- and four-plane operands, N > 256: packed words staged by LDS-DMA, expanded in
     registers, base-4 digits for four planes) against the oracle in all three output forms: ragged M and N, K with 1..8 k-quads in the last group, fewer lines than
-    a tile, several output widths (one / two planes have their own epilogue), both tile shapes forced in turn."""
+    a tile, several output widths (one / two planes have their own epilogue), the three tile shapes forced in turn."""
     import torch
     from helpers import rand_q, to_dev
     from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
