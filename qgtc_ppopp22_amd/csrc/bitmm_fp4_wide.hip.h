@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * WD_WAVES) void k_bitmm_fp4_wide(
     uint32_t r_bytes, uint32_t out_bytes, int Lc, int Rc, int K, int l_lines, int r_lines, int out_lines,
     uint32_t cfg /* ob | tiles along R << 8; host: ob <= 23, every byte count < 2^32 */) {
     static_assert((CF % 4 == 0 || CF == 2) && (RF == 2 || RF == 4) && (GB == 64 || GB == 128), "fragment grid of a wave, group of K");
-    static_assert((NL == 1 || NL == 2 || NL == 4) && (NR == 1 || NR == 2 || NR == 4), "planes: one, or whole base-4 digits");
+    static_assert((NL == 1 || NL == 2 || NL == 4 || NL == 8) && (NR == 1 || NR == 2 || NR == 4 || NR == 8), "planes: one, or whole base-4 digits");
     constexpr int NDL = wd_digits(NL), NDR = wd_digits(NR);
     constexpr int WD_STAGES = wd_stages(NL, NR, RF, CF, GB);
     constexpr int TL = wd_tl(RF), TR = wd_tr(CF);

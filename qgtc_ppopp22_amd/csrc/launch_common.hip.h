@@ -84,12 +84,14 @@ inline bool fp4_ok(int K, int a, int w) {
     return a <= 2 && w <= 2 && static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
 }
 
-// wide right operands; one, two or four planes per operand (not 4 x 4: its stage does not fit the LDS): packed words
+// wide right operands; 1, 2, 4 or 8 planes on one side with 1 or 2 on the other (a stage of 4 x 4 planes and up does
+// not fit the LDS): packed words
 // staged by LDS-DMA, expanded in the multiplying waves' registers (bitmm_fp4_wide.hip.h)
 inline bool wide_ok(const qgtc_problem &pr, int a, int w, int ob, int mode) {
     const size_t out_bytes = mode == 2 ? static_cast<size_t>(pr.M) * pr.N * 4u
                                        : static_cast<size_t>(ob) * (mode == 1 ? pad128(pr.N) : pad8(pr.M)) * step128(mode == 1 ? pr.M : pr.N) * 16u;
-    const bool planes = (a == 1 || a == 2 || a == 4) && (w == 1 || w == 2 || w == 4) && a * w < 16;
+    const int nl = mode == 1 ? w : a, nr = mode == 1 ? a : w;   // planes of the operand that supplies the output lines / bits
+    const bool planes = ((nl == 1 || nl == 2) && (nr == 1 || nr == 2 || nr == 4 || nr == 8)) || ((nl == 4 || nl == 8) && (nr == 1 || nr == 2));
     return planes && static_cast<double>(pr.K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0 && (mode == 2 || (ob >= 1 && ob <= 23)) &&
            pr.x_words < (1ull << 30) && pr.w_words < (1ull << 30) && out_bytes < (1ull << 32) && !getenv_flag("QGTC_NO_WIDE");
 }
@@ -107,7 +109,7 @@ inline double wide_plan(int lines, int R, int K, int a, int w, int *rf, int *cf 
     double best = 0.0;
     for (const auto &sh : shapes) {
         const int f = sh[0], c = sh[1];
-        if (a == 4 && f == 4) continue;   // (four left-hand planes: 2 x 4 fragments only)
+        if ((a >= 4 && f == 4) || (w == 8 && c == 4)) continue;   // (many left-hand planes: 2 x 4 fragments only; eight right-hand ones: 4 x 2 only)
         const double v = (f * expand(a) + c * expand(w)) / (f * c * nd);
         const double per_group = 2.0 * f * c * 8 * nd * (7.8 + 1.55 * v) * 1e-3 * (a + w == 2 ? 1.03 : 1.27);   // us per 1024 bits of K and round
         const double tiles = static_cast<double>((lines + 32 * f - 1) / (32 * f)) * ((R + 64 * c - 1) / (64 * c));

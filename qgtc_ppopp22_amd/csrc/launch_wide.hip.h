@@ -5,7 +5,8 @@
     F(NL, NR, 0, 4, 4, GB) F(NL, NR, 2, 4, 4, GB) F(NL, NR, 0, 2, 4, GB) F(NL, NR, 2, 2, 4, GB) F(NL, NR, 0, 4, 2, GB) F(NL, NR, 2, 4, 2, GB)
 #define QGTC_WD_FOR_ALL(F)                                                                                                   \
     QGTC_WD_FOR_PLANES(F, 1, 1, 128) QGTC_WD_FOR_PLANES(F, 1, 2, 64) QGTC_WD_FOR_PLANES(F, 2, 1, 64) QGTC_WD_FOR_PLANES(F, 2, 2, 64) \
-    QGTC_WD_FOR_PLANES(F, 1, 4, 64) QGTC_WD_FOR_PLANES(F, 2, 4, 64) F(4, 1, 0, 2, 4, 64) F(4, 1, 2, 2, 4, 64) F(4, 2, 0, 2, 4, 64) F(4, 2, 2, 2, 4, 64)
+    QGTC_WD_FOR_PLANES(F, 1, 4, 64) QGTC_WD_FOR_PLANES(F, 2, 4, 64) F(4, 1, 0, 2, 4, 64) F(4, 1, 2, 2, 4, 64) F(4, 2, 0, 2, 4, 64) F(4, 2, 2, 2, 4, 64) \
+    F(1, 8, 0, 4, 2, 64) F(1, 8, 2, 4, 2, 64) F(2, 8, 0, 4, 2, 64) F(2, 8, 2, 4, 2, 64) F(8, 1, 0, 2, 4, 64) F(8, 1, 2, 2, 4, 64) F(8, 2, 0, 2, 4, 64) F(8, 2, 2, 2, 4, 64)
 
 // mode 0 rows-layout bits, 1 cols-layout bits (the operands change places: a cols-layout word runs along M), 2 float32
 int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st) {
@@ -26,7 +27,7 @@ int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hip
         return QGTC_OK;
     });
     if (arc != QGTC_OK) return arc;
-    const int nl = swap ? w : a, nr = swap ? a : w;   // planes of the left / right operand (1, 2 or 4 each, not 4 x 4: wide_ok)
+    const int nl = swap ? w : a, nr = swap ? a : w;   // planes of the left / right operand (wide_planes_ok)
     const int cover = mode == 2 ? Lc : out_lines;   // (the padding lines of the bit layouts are written as zeros)
     int rf = 4, cf = 4;
     wide_plan(cover, Rc, pr.K, nl, nr, &rf, &cf);
@@ -35,7 +36,8 @@ int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hip
         rf = v == 2 ? 2 : 4;
         cf = v == 42 ? 2 : 4;
     }
-    if (nl == 4) rf = 2, cf = 4;   // (four left-hand planes on four fragments per wave spill registers: not instantiated)
+    if (nl >= 4) rf = 2, cf = 4;   // (four or eight left-hand planes: only on 2 x 4 fragments per wave - registers, LDS)
+    if (nr == 8) rf = 4, cf = 2;   // (eight right-hand planes: only on 4 x 2 - the stage of a wider tile does not fit the LDS)
     const int nt_r = (Rc + wd_tr(cf) - 1) / wd_tr(cf);
     const int nt_l = (cover + wd_tl(rf) - 1) / wd_tl(rf);
     const uint32_t cfg = static_cast<uint32_t>(ob) | static_cast<uint32_t>(nt_r) << 8;

@@ -633,7 +633,7 @@ def test_row_block_kernel_for_sparse_left_operands(qgtc, oracle, a, w, ob):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rf", ["", "2", "4", "42"])
-@pytest.mark.parametrize("a,w", [(1, 1), (1, 2), (2, 1), (2, 2), (1, 4), (4, 1), (2, 4), (4, 2)])
+@pytest.mark.parametrize("a,w", [(1, 1), (1, 2), (2, 1), (2, 2), (1, 4), (4, 1), (2, 4), (4, 2), (1, 8), (2, 8), (8, 1), (8, 2)])
 def test_wide_operand_kernel_equals_the_oracle(qgtc, oracle, monkeypatch, rf, a, w):
     """k_bitmm_fp4_wide (one-, two- and four-plane operands, N > 256: packed words staged by LDS-DMA, expanded in
     registers, base-4 digits for four planes) against the oracle in all three output forms: ragged M and N, K with 1..8 k-quads in the last group, fewer lines than

@@ -10,7 +10,7 @@ shapes = [(128, 1024, 512), (129, 1024, 257), (1000, 1152, 300), (77, 128, 1000)
 if len(sys.argv) > 1 and sys.argv[1] == "time":
     shapes = []
 for (M, K, N) in shapes:
-  for (a, w) in ((1, 1), (1, 2), (2, 1), (2, 2), (1, 4), (4, 1), (2, 4), (4, 2)):
+  for (a, w) in ((1, 1), (1, 2), (2, 1), (2, 2), (1, 4), (4, 1), (2, 4), (4, 2), (1, 8), (2, 8), (8, 1), (8, 2)):
     A = torch.randint(0, 2 ** a, (M, K)).float().cuda()
     X = torch.randint(0, 2 ** w, (K, N)).float().cuda()
     bA, bX = QGTC.val2bit(A, a, False, False), QGTC.val2bit(X, w, True, False)
@@ -28,7 +28,7 @@ for (M, K, N) in shapes:
     print(f"{M}x{K}x{N} a={a} w={w} checked", flush=True)
 print("mismatches:", bad)
 for (M, K, N) in ((4096, 4096, 512), (4096, 4096, 1024), (8192, 4096, 1024), (8192, 8192, 2048), (4096, 4096, 2048)):
-  for (a, w) in ((1, 1), (1, 2), (2, 2), (1, 4), (2, 4), (4, 1)):
+  for (a, w) in ((1, 1), (1, 2), (2, 2), (1, 4), (2, 4), (4, 1), (1, 8), (2, 8)):
     A = torch.randint(0, 2 ** a, (M, K)).float().cuda()
     X = torch.randint(0, 2 ** w, (K, N)).float().cuda()
     bA, bX = QGTC.val2bit(A, a, False, False), QGTC.val2bit(X, w, True, False)
