@@ -43,15 +43,15 @@ __device__ __forceinline__ void one_expand(const u32x4 (&pl)[NP], int digit, uin
             ops[3][t] = (wd >> 3) & 0x11111111u;   // (code 8 would be -0)
         }
         scale[0] = 128; scale[1] = 127; scale[2] = 126; scale[3] = 128;
-    } else {
+    } else {   // the 2-bit code of (plane 2d, plane 2d + 1), built for the even and the odd bit positions of a word at once
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            uint32_t wd[2], e[4];
-            wd[0] = pl[2 * digit][t];
-            wd[1] = 2 * digit + 1 < NP ? pl[(2 * digit + 1) % NP][t] : 0u;
-            expand_word_fp4<2>(wd, 2, e);
-#pragma unroll
-            for (int s = 0; s < 4; s++) ops[s][t] = e[s];
+            const uint32_t w0 = pl[2 * digit][t], w1 = 2 * digit + 1 < NP ? pl[(2 * digit + 1) % NP][t] : 0u;
+            const uint32_t ev = (w0 & 0x55555555u) | ((w1 & 0x55555555u) << 1), od = ((w0 >> 1) & 0x55555555u) | (w1 & 0xaaaaaaaau);
+            ops[0][t] = ev & 0x33333333u;
+            ops[1][t] = od & 0x33333333u;
+            ops[2][t] = (ev >> 2) & 0x33333333u;
+            ops[3][t] = (od >> 2) & 0x33333333u;
         }
 #pragma unroll
         for (int s = 0; s < 4; s++) scale[s] = 128 + 2 * digit;
