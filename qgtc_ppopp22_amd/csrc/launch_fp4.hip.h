@@ -14,7 +14,12 @@ static bool one_ok(const qgtc_problem &pr, int ob, int mode) {
 // K <= 4096: one super-step per wave, the latency-trimmed kernel (bitmm_fp4_one.hip.h)
 static int launch_one(const qgtc_problem &pr, int a, int w, int ob, int mode, bool zero_skip, hipStream_t st) {
     const bool wide = pr.N > 32 || mode == 1;   // 32 x 32 tiles (two column tiles at N = 64), else 16 x 32
-    const dim3 grid(wide ? (pr.M + 31) / 32 : (pr.M + 15) / 16, (pr.N + 31) / 32), block(64 * ONE_WAVES);
+    // more than four right-hand planes: 64 x 16 tiles - a workgroup then fetches and expands a quarter of W instead of
+    // half of it (4096 x 4096 x 64 at 8 bits: 32 -> 16 MB out of L2, 424 -> 272 VALU operations per wave: 7.9 -> 6.4 us; no
+    // change at 4 bits). Every output
+    // word must be covered by two column tiles: N a multiple of 32.
+    const bool tall = w > 4 && mode != 1 && pr.N % 32 == 0 && pr.M >= 2048 && !getenv_flag("QGTC_NO_TALL");
+    const dim3 grid(tall ? (pr.M + 63) / 64 : wide ? (pr.M + 31) / 32 : (pr.M + 15) / 16, tall ? pr.N / 16 : (pr.N + 31) / 32), block(64 * ONE_WAVES);
     const uint32_t cfg = static_cast<uint32_t>(a) | static_cast<uint32_t>(w) << 8 | static_cast<uint32_t>(mode == 2 ? 1 : ob) << 16 |
                          (zero_skip ? 1u : 0u) << 24
 #ifdef QGTC_ABL
@@ -26,6 +31,12 @@ static int launch_one(const qgtc_problem &pr, int a, int w, int ob, int mode, bo
 #define QGTC_ONE_GO(NA_, NW_, MODE_, RF_)                                                                          \
     hipLaunchKernelGGL((k_bitmm_fp4_one<NA_, NW_, MODE_, RF_, 2>), grid, block, 0, st, pr.X, pr.W, pr.out, xb, wb, ob_, pr.M, \
                        pr.K, pr.N, pr.w_lines, cfg)
+#define QGTC_ONE_TALL(NA_, NW_)                                                                                               \
+    if (!done && tall && a <= NA_ && w <= NW_) {                                                                               \
+        done = true;                                                                                                           \
+        if (mode == 2) hipLaunchKernelGGL((k_bitmm_fp4_one<NA_, NW_, 2, 4, 1>), grid, block, 0, st, pr.X, pr.W, pr.out, xb, wb, ob_, pr.M, pr.K, pr.N, pr.w_lines, cfg); \
+        else hipLaunchKernelGGL((k_bitmm_fp4_one<NA_, NW_, 0, 4, 1>), grid, block, 0, st, pr.X, pr.W, pr.out, xb, wb, ob_, pr.M, pr.K, pr.N, pr.w_lines, cfg);           \
+    }
 #define QGTC_ONE_LAUNCH(NA_, NW_)                                       \
     if (!done && a <= NA_ && w <= NW_) {                                \
         done = true;                                                    \
@@ -34,9 +45,11 @@ static int launch_one(const qgtc_problem &pr, int a, int w, int ob, int mode, bo
         else { if (wide) { QGTC_ONE_GO(NA_, NW_, 0, 2); } else { QGTC_ONE_GO(NA_, NW_, 0, 1); } }                \
     }
     bool done = false;
+    QGTC_ONE_TALL(1, 8) QGTC_ONE_TALL(2, 8)
     QGTC_ONE_LAUNCH(1, 1) QGTC_ONE_LAUNCH(1, 2) QGTC_ONE_LAUNCH(1, 4) QGTC_ONE_LAUNCH(1, 8)
     QGTC_ONE_LAUNCH(2, 1) QGTC_ONE_LAUNCH(2, 2) QGTC_ONE_LAUNCH(2, 4) QGTC_ONE_LAUNCH(2, 8)
 #undef QGTC_ONE_LAUNCH
+#undef QGTC_ONE_TALL
 #undef QGTC_ONE_GO
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
