@@ -16,9 +16,9 @@ static int launch_one(const qgtc_problem &pr, int a, int w, int ob, int mode, bo
     const bool wide = pr.N > 32 || mode == 1;   // 32 x 32 tiles (two column tiles at N = 64), else 16 x 32
     // more than four right-hand planes: 64 x 16 tiles - a workgroup then fetches and expands a quarter of W instead of
     // half of it (4096 x 4096 x 64 at 8 bits: 32 -> 16 MB out of L2, 424 -> 272 VALU operations per wave: 7.9 -> 6.4 us; no
-    // change at 4 bits). Every output
+    // change at 4 bits; measured ahead from 512 x 512 x 64 up, at N = 32 only from M = 4096). Every output
     // word must be covered by two column tiles: N a multiple of 32.
-    const bool tall = w > 4 && mode != 1 && pr.N % 32 == 0 && pr.M >= 2048 && !getenv_flag("QGTC_NO_TALL");
+    const bool tall = w > 4 && mode != 1 && pr.N % 32 == 0 && ((pr.N >= 64 && pr.M >= 512) || pr.M >= 4096) && !getenv_flag("QGTC_NO_TALL");
     const dim3 grid(tall ? (pr.M + 63) / 64 : wide ? (pr.M + 31) / 32 : (pr.M + 15) / 16, tall ? pr.N / 16 : (pr.N + 31) / 32), block(64 * ONE_WAVES);
     const uint32_t cfg = static_cast<uint32_t>(a) | static_cast<uint32_t>(w) << 8 | static_cast<uint32_t>(mode == 2 ? 1 : ob) << 16 |
                          (zero_skip ? 1u : 0u) << 24

@@ -697,13 +697,13 @@ def test_wide_kernel_at_the_float32_exactness_bound(qgtc, engine):
 @pytest.mark.gpu
 @pytest.mark.parametrize("a,w", [(1, 8), (1, 5), (2, 7)])
 def test_headline_kernel_on_tall_tiles(qgtc, oracle, a, w):
-    """k_bitmm_fp4_one on 64 x 16 tiles (more than four right-hand planes, M >= 2048, N a multiple of 32): ragged M and K,
+    """k_bitmm_fp4_one on 64 x 16 tiles (more than four right-hand planes, N a multiple of 32): ragged M and K,
     rows-layout bits and float32, against the oracle."""
     import torch
     from helpers import rand_q, to_dev
     from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
     rng = np.random.default_rng(500 + 10 * a + w)
-    for (M, K, N) in ((2050, 640, 64), (2111, 1000, 32), (2300, 4096, 96)):
+    for (M, K, N) in ((2050, 640, 64), (4100, 1000, 32), (2300, 4096, 96), (515, 300, 64)):
         qx, qw = rand_q(rng, M, K, a), rand_q(rng, K, N, w)
         X, Wt = oracle.pack(qx, a, False), oracle.pack(qw, w, True)
         bX, bW = to_dev(torch, X, rows_shape(M, K, a)), to_dev(torch, Wt, cols_shape(K, N, w))
