@@ -644,7 +644,8 @@ def test_wide_operand_kernel_equals_the_oracle(qgtc, oracle, monkeypatch, rf, a,
     if rf:
         monkeypatch.setenv("QGTC_WIDE_RF", rf)
     rng = np.random.default_rng(77 + 10 * a + w)
-    shapes = ((129, 1024, 257), (300, 896, 513), (8, 3968, 264), (77, 128, 1000), (513, 2176, 1030), (1000, 1152, 300), (64, 8320, 520))
+    shapes = ((129, 1024, 257), (300, 896, 513), (8, 3968, 264), (77, 128, 1000), (513, 2176, 1030), (1000, 1152, 300), (64, 8320, 520),
+              (1, 5, 300), (3, 4097, 258))
     for (M, K, N) in (shapes if not rf else shapes[1:4]):
         qx, qw = rand_q(rng, M, K, a), rand_q(rng, K, N, w)
         X, Wt = oracle.pack(qx, a, False), oracle.pack(qw, w, True)
