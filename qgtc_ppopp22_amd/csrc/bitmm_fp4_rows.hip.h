@@ -35,9 +35,17 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
 #define RW_STAMP(i) do { } while (0)
 #endif
     RW_STAMP(0);
-    const qgtc_problem pr = prs[blockIdx.y];
+    // sh.per != 0: the row blocks of a batch run on ONE XCD (they share its T lines and descriptor in that L2; spread
+    // round-robin over the eight, every XCD fetched every batch's T: rocprofv3 counted 18.5 MB of fetches per launch for
+    // 5.6 MB of operands)
+    int rb = static_cast<int>(blockIdx.x), batch = static_cast<int>(blockIdx.y);
+    if (sh.per) {
+        const int v = xcd_consecutive(batch * static_cast<int>(gridDim.x) + rb, static_cast<int>(gridDim.x * gridDim.y));
+        batch = v / static_cast<int>(gridDim.x);
+        rb = v - batch * static_cast<int>(gridDim.x);
+    }
+    const qgtc_problem pr = prs[batch];
     const int M = pr.M, K = pr.K, N = pr.N;
-    const int rb = static_cast<int>(blockIdx.x);
     if (32 * rb >= M) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
 #ifdef QGTC_STAMPS
     RW_STAMP(4);
     if (tid == 0) {
-        const int slot = (blockIdx.y * gridDim.x + blockIdx.x) % 1024;
+        const int slot = (batch * gridDim.x + rb) % 1024;
         for (int i = 0; i < 8; i++) g_stamps[slot * 16 + i] = st_[i];
     }
 #endif

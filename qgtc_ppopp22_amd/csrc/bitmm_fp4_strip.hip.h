@@ -75,9 +75,19 @@ template <int NA, int NW, int OB>
 __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_strip(const qgtc_problem *__restrict__ prs, MMShape sh) {
     constexpr int NDA = (NA + 1) / 2, NDW = (NW + 1) / 2;   // base-4 digits
     extern __shared__ __attribute__((aligned(16))) uint32_t strip_words[];   // [ob][32 columns][line_words | 1]
-    const qgtc_problem pr = prs[blockIdx.y];
+    // sh.per != 0: the strips (and parts) of a batch run on ONE XCD - they all read the batch's X rows (bitmm_fp4_rows.hip.h)
+    int strip = static_cast<int>(blockIdx.x), batch = static_cast<int>(blockIdx.y), part = static_cast<int>(blockIdx.z);
+    if (sh.per) {
+        const int gx = static_cast<int>(gridDim.x), gy = static_cast<int>(gridDim.y), gz = static_cast<int>(gridDim.z);
+        const int v = xcd_consecutive(strip + gx * (batch + gy * part), gx * gy * gz);
+        batch = v / (gx * gz);
+        const int rem = v - batch * (gx * gz);
+        part = rem / gx;
+        strip = rem - part * gx;
+    }
+    const qgtc_problem pr = prs[batch];
     const int M = pr.M, N = pr.N;
-    const int n0 = static_cast<int>(blockIdx.x) * 32;
+    const int n0 = strip * 32;
     const int lines = pad128(N), line_words = step128(M) * 4;
     if (n0 >= lines) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_strip(const qgtc_pr
     // lines (the last part also the zero words past the last row block). More, smaller workgroups balance better over
     // the CUs: the stage is bound by the VALU work of the re-quantise + pack epilogue, ~190 operations per 32 x 32 block.
     const int per = (line_words + static_cast<int>(gridDim.z) - 1) / static_cast<int>(gridDim.z);
-    const int rb0 = static_cast<int>(blockIdx.z) * per, w1 = min(line_words, rb0 + per), rb1 = min(nrb, w1);
+    const int rb0 = part * per, w1 = min(line_words, rb0 + per), rb1 = min(nrb, w1);
     if (rb0 >= line_words) return;
     const int ps = per | 1;   // odd LDS pitch between a plane's columns: 32 lanes write one word each, 32 different banks
 #ifdef QGTC_STAMPS
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_strip(const qgtc_pr
 #ifdef QGTC_STAMPS
     ST_STAMP(5);
     if (tid == 0) {
-        const int slot = (blockIdx.y * gridDim.x + blockIdx.x) % 1024;
+        const int slot = (batch * gridDim.x + strip) % 1024;
         for (int i = 0; i < 8; i++) g_stamps[slot * 16 + i] = st_[i];
     }
 #endif

@@ -58,6 +58,13 @@ __device__ __forceinline__ uint32_t quant1(float x, float ub, float ubm1) {
     return r >= 4294967296.0f ? 0u : static_cast<uint32_t>(r);  // low 32 bits (nbits >= 31 only)
 }
 
+// Workgroups whose ids are congruent mod 8 run on the same XCD (round-robin placement): give those CONSECUTIVE virtual
+// ids, so that neighbours in the work list share one L2. Bijective for every n (MI355X guide: the simple remap is not).
+__device__ __forceinline__ int xcd_consecutive(int id, int n) {
+    const int q = n >> 3, r = n & 7, x = id & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+}
+
 constexpr int AUX_SC1 = 16;   // cache-policy operand of the raw buffer builtins on gfx940+: bit 4 = sc1 (agent scope)
 
 // A packed output word. PUB = the fused layer's first stage: the word is read by OTHER workgroups (possibly on another

@@ -140,6 +140,7 @@ int qgtc_launch_layer_wave(const LayerArgs &la, hipStream_t st) {
 int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, 1);
     sh.nowrap = 1;
+    sh.per = getenv_flag("QGTC_NO_XCD") ? 0 : 1;   // (here: the workgroups of a batch on one XCD)
     // a strip's rows can be split over several workgroups (gridDim.z): 300 whole strips on 256 CUs leave 44 CUs with two
     // (the stage is bound by the epilogue's VALU work per CU), halves balance better. Measured on the ogbn-arxiv-sized
     // epoch (75 batches x 4 strips): 1 / 2 / 3 / 4 parts 9.7 / 8.6 / 9.0 / 9.6 us per stage - every extra workgroup
@@ -173,6 +174,7 @@ int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, 
 int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, mode);
     sh.nowrap = 1;
+    sh.per = getenv_flag("QGTC_NO_XCD") ? 0 : 1;   // (here: row blocks of a batch on one XCD)
     const int blocks = mode == 2 ? (max_N + 31) / 32 : step128(max_N) * 4;   // 32-column blocks: per 32 columns / per word of a packed row
     // (two column blocks per wave - half the waves, one round of them on the chip instead of 1.4 - measured no faster:
     // 11.1 against 10.6 us on the ogbn-arxiv-sized A-stages; kept as a tuning switch)
