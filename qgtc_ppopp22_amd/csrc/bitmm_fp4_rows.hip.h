@@ -160,16 +160,21 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
     asm volatile("" ::"v"(acc[0][0]));
 #endif
     RW_STAMP(3);
-    if (MODE == 2) {   // float32 [M,N] (reference kernel.h:915-930)
+    if (MODE == 2) {   // float32 [M,N] (reference kernel.h:915-930): registers 4 g .. 4 g + 3 are four consecutive columns
         if (m < M) {
 #pragma unroll
             for (int j = 0; j < CB; j++) {
                 float *dst = static_cast<float *>(pr.out) + static_cast<size_t>(m) * N + n0 + 32 * j;
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int e = (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    const float v = acc[j][r];
-                    if (n0 + 32 * j + e < N) dst[e] = v;
+                for (int g = 0; g < 4; g++) {
+                    const int e = 8 * g + 4 * fh;
+                    if ((N & 3) == 0 && n0 + 32 * j + e + 3 < N) {   // one 16-byte store (scalar stores of a column run over 32 rows x 512 bytes)
+                        *reinterpret_cast<f32x4 *>(dst + e) = f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; t++)
+                            if (n0 + 32 * j + e + t < N) dst[e + t] = acc[j][4 * g + t];
+                    }
                 }
             }
         }

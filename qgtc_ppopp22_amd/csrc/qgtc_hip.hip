@@ -275,8 +275,8 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
     const int ob_ = mode == 2 ? 1 : output_bit;
     if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && mode == 1 && strip_ok(max_M, max_K, bit1, bit2, ob_))   // X . W stages: column strips
         return qgtc_launch_strip(problems, count, max_M, max_N, bit1, bit2, ob_, st);
-    if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && ((flags & QGTC_ZERO_JUMP) || max_N <= 64) &&
-        rows_ok(max_K, max_N, bit1, bit2, ob_, mode))   // sparse left operands / narrow outputs: one workgroup per 32-row block
+    if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && ((flags & QGTC_ZERO_JUMP) || max_N <= 64 || max_K <= 256) &&
+        rows_ok(max_K, max_N, bit1, bit2, ob_, mode))   // sparse left operands / narrow outputs / one or two k-quads: one workgroup per 32-row block
         return qgtc_launch_rows(problems, count, max_M, max_N, bit1, bit2, ob_, mode, st);
     if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && fp4_wave_ok(max_K, max_N, bit1, bit2))   // narrow outputs: one wave per 32 x 32 tile
         return qgtc_launch_fp4_wave(problems, count, max_M, max_N, bit1, bit2, ob_, mode, !(flags & QGTC_NO_ZERO_SKIP), st);
