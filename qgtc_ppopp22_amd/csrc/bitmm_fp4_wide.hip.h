@@ -1,5 +1,6 @@
 // bitmm_fp4_wide.hip.h — part of libqgtc_hip.so (qgtc_wide.hip).
-// The bit-GEMM on the matrix cores for WIDE right operands (N > 256) and one- or two-plane operands: packed words
+// The bit-GEMM on the matrix cores for WIDE right operands (N > 256), 1 / 2 / 4 / 8 planes on one side with 1 or 2 on
+// the other: packed words
 // staged in LDS as they are (LDS-DMA, no expansion pass, no expander waves), expanded in the registers of the
 // multiplying waves with one AND per dword.
 #pragma once
@@ -11,7 +12,8 @@ namespace {
 // packed byte, an expander / multiplier hand-over per k-quad, and 59 cycles per 16x16x128 MFMA at 8192 x 4096 x 1024
 // where the matrix pipe needs 8.75 (tools/mfma_rates2.hip). Here:
 //   * a workgroup (8 waves, two per SIMD: the VALU work of one overlaps the MFMAs of the other) owns 128 lines of the
-//     left operand x 256 lines of the right one, a wave 64 x 64 = 4 x 4 fragments of v_mfma_scale_f32_16x16x128_f8f6f4;
+//     left operand x 256 lines of the right one, a wave 64 x 64 = 4 x 4 fragments of v_mfma_scale_f32_16x16x128_f8f6f4
+//     (64 x 256 or 128 x 128 per workgroup, 2 x 4 / 4 x 2 fragments per wave, when the grid would leave CUs idle);
 //   * K is walked in groups of 1024 bits: 128 bytes of every line = one full cache line, fetched ONCE per workgroup by
 //     LDS-DMA (buffer_load_dwordx4 .. lds, no registers, no write pass) in pieces of 8 lines x 128 bytes; the 16-byte
 //     chunks of a line are XOR-swizzled on the SOURCE address so that a fragment read (16 lines x 4 chunks) touches
@@ -20,7 +22,7 @@ namespace {
 //     takes bits s, s + 4, .. of all four IN PLACE: nibble code 1 << s = 0.5, 1, 2 with the E8M0 scale 2^(1 - s)
 //     (the fourth with one shift: code 8 is -0). Which 128 elements of K an instruction covers is free as long as both
 //     operands agree. 2.5 VALU operations per MFMA for one-plane operands; two planes become the 2-bit code of one
-//     nibble (6.5 per MFMA), four planes two such base-4 digits (an MFMA per pair of digits);
+//     nibble (6.5 per MFMA), four / eight planes two / four such base-4 digits (an MFMA per pair of digits);
 //   * operands swapped (D = R-fragment x L-fragment^T): a lane owns ONE output line and four consecutive elements of it
 //     per fragment; fragment fc of a wave is made of the right-hand lines 8 fc .. 8 fc + 7 and 32 + 8 fc .. 32 + 8 fc + 7
 //     of the wave's 64, so that the 16 values a lane holds of a line are half of every byte of one output word: byte-
@@ -39,7 +41,7 @@ constexpr int wd_tr(int cf) { return 4 * 16 * cf; }
 // per stage: pieces of 16 lines = one fragment)
 constexpr int wd_pieces(int nl, int nr, int rf, int cf, int gb) { return (nl * wd_tl(rf) + nr * wd_tr(cf)) * gb / WD_PIECE; }
 constexpr int wd_spare(int nl, int nr, int rf, int cf, int gb) { return wd_pieces(nl, nr, rf, cf, gb) % WD_WAVES ? 1 : 0; }
-// three stages (two groups in flight) where they fit the 160 KB of a CU, else two (four-plane operands)
+// three stages (two groups in flight) where they fit the 160 KB of a CU, else two (four- and eight-plane operands)
 constexpr int wd_stages(int nl, int nr, int rf, int cf, int gb) {
     return (3 * wd_pieces(nl, nr, rf, cf, gb) + wd_spare(nl, nr, rf, cf, gb)) * WD_PIECE <= WD_LDS_MAX ? 3 : 2;
 }
