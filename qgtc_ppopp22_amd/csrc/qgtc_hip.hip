@@ -25,6 +25,7 @@
 //   bitmm_fp4_wave.hip.h     grouped launches over cluster batches: one wave per 32 x 32 tile
 //   bitmm_fp4_strip.hip.h    grouped X . W stages (K <= 128, cols-layout output): one workgroup per 32-column strip
 //   bitmm_fp4_rows.hip.h     grouped A . (XW) stages (sparse left operand): one workgroup per 32-row block
+//   bitmm_fp4_chain.hip.h    an A . T stage with the next layer's X . W stage in its tail (qgtc_gcn_chain_batched)
 //   bitmm_layer.hip.h        both stages of a GNN layer in one launch (qgtc_gcn_layer_batched, on request)
 //   launch_common.hip.h      launch constants, kernel-family predicates (shared with qgtc_mfma.hip / qgtc_fp4.hip)
 //   launch.hip.h             split-K plan, kernel selection, launchers
@@ -56,6 +57,7 @@
 #include "bitmm_fp4_one.hip.h"
 #include "bitmm_fp4_strip.hip.h"
 #include "bitmm_fp4_rows.hip.h"
+#include "bitmm_fp4_chain.hip.h"
 #define QGTC_LAYER_MFMA 1
 #define QGTC_LAYER_WAVE 1
 #include "bitmm_layer.hip.h"
@@ -315,6 +317,21 @@ int qgtc_gcn_layer_batched(const qgtc_problem *stage1, const qgtc_problem *stage
     int rc = qgtc_bitmm_batched(stage1, count, max_M, max_K1, max_N, x_bits, w_bits, t_bits, 1, f2 & ~QGTC_ZERO_JUMP, stream);
     if (rc != QGTC_OK) return rc;
     return qgtc_bitmm_batched(stage2, count, max_M, max_K2, max_N, a_bits, t_bits, mode == 2 ? 1 : output_bit, mode, f2, stream);
+}
+
+int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stage_xw, int count, int max_M, int max_K,
+                           int max_N1, int max_N2, int a_bits, int t_bits, int act_bits, int w_bits, int out_bits,
+                           unsigned flags, void *stream) {
+    if (!stage_a || !stage_xw || count <= 0 || count > 65535) return QGTC_EINVAL;
+    if (max_M <= 0 || max_K <= 0 || max_N1 <= 0 || max_N2 <= 0) return QGTC_EINVAL;
+    if (!bits_ok(a_bits) || !bits_ok(t_bits) || !bits_ok(act_bits) || !bits_ok(w_bits) || !bits_ok(out_bits)) return QGTC_EINVAL;
+    // one launch on the matrix cores where the shapes and plane counts allow it (bitmm_fp4_chain.hip.h), else the two
+    // grouped launches it stands for
+    if ((flags & (QGTC_ENGINE_AUTO | QGTC_ENGINE_MFMA)) && chain_ok(max_K, max_N1, max_N2, a_bits, t_bits, act_bits, w_bits, out_bits))
+        return qgtc_launch_chain(stage_a, stage_xw, count, max_M, t_bits, act_bits, w_bits, out_bits, static_cast<hipStream_t>(stream));
+    int rc = qgtc_bitmm_batched(stage_a, count, max_M, max_K, max_N1, a_bits, t_bits, act_bits, 0, flags, stream);
+    if (rc != QGTC_OK) return rc;
+    return qgtc_bitmm_batched(stage_xw, count, max_M, max_N1, max_N2, act_bits, w_bits, out_bits, 1, flags & ~QGTC_ZERO_JUMP, stream);
 }
 
 size_t qgtc_occupancy_words(int M, int K) {

@@ -612,6 +612,35 @@ struct FusedLayer {
     }
 };
 
+// An aggregation stage and the next layer's feature transform in one call (qgtc_gcn_chain_batched): stage_a produces
+// rows-layout bits (mode 0) that are stage_xw's left operands; stage_xw produces cols-layout bits (mode 1).
+struct ChainedPair {
+    std::shared_ptr<BatchedGemm> sa, sx;
+
+    ChainedPair(std::shared_ptr<BatchedGemm> stage_a, std::shared_ptr<BatchedGemm> stage_xw) : sa(std::move(stage_a)), sx(std::move(stage_xw)) {
+        TORCH_CHECK(sa && sx, "ChainedPair needs two BatchedGemm plans");
+        TORCH_CHECK(sa->count == sx->count, "both stages must cover the same cluster batches");
+        TORCH_CHECK(sa->mode == 0, "the aggregation stage must produce rows-layout bits (mode 0)");
+        TORCH_CHECK(sx->mode == 1, "the feature-transform stage must produce cols-layout bits (mode 1)");
+        TORCH_CHECK(sa->ob == sx->bit1, "the first stage's output bits must be the second stage's left-operand planes");
+        TORCH_CHECK(sa->descs.device() == sx->descs.device(), "both stages must live on one device");
+        for (int i = 0; i < sa->count; i++) {
+            const qgtc_problem &a = sa->host_descs[i], &b = sx->host_descs[i];
+            TORCH_CHECK(b.X == static_cast<const uint32_t *>(a.out), "the second stage's left operand ", i, " must be the first stage's output ", i);
+            TORCH_CHECK(a.M == b.M && a.N == b.K, "batch ", i, ": stage shapes do not chain (n x n x f, then n x f x f')");
+        }
+    }
+
+    void run() {
+        c10::DeviceGuard guard(sa->descs.device());
+        check_rc(qgtc_gcn_chain_batched(reinterpret_cast<const qgtc_problem *>(sa->descs.data_ptr()),
+                                        reinterpret_cast<const qgtc_problem *>(sx->descs.data_ptr()), sa->count,
+                                        std::max(sa->max_M, sx->max_M), sa->max_K, sa->max_N, sx->max_N, sa->bit1, sa->bit2, sa->ob,
+                                        sx->bit2, sx->ob, mm_flags() | (sa->jump_asked ? QGTC_ZERO_JUMP : 0u), current_stream(sa->descs)),
+                 "ChainedPair.run");
+    }
+};
+
 // One quantised GNN layer on ONE subgraph in one launch: requant(A . requant(X . W)) (QGTC_conv.py:14-22). bit_A: rows
 // layout, 1.. planes, [n, n]; bit_X: rows layout [n, f_in]; bit_W: cols layout [f_in, f_out]. Returns the packed
 // activations (rows layout, act_bit planes) or, with output = true, float32 [n, f_out].
@@ -734,6 +763,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("a_bit") = 1, py::arg("act_bit") = 2, py::arg("w_bit") = 2, py::arg("output") = false,
           py::arg("one_launch") = false);
 
+    py::class_<ChainedPair>(m, "ChainedPair")
+        .def(py::init<std::shared_ptr<BatchedGemm>, std::shared_ptr<BatchedGemm>>(), py::arg("stage_a"), py::arg("stage_xw"))
+        .def("run", &ChainedPair::run, "A.(XW) of one layer and X.W of the next for every cluster batch, one launch where eligible")
+        .def_property_readonly("outs", [](const ChainedPair &c) { return c.sx->outs; });
     py::class_<FusedLayer>(m, "FusedLayer")
         .def(py::init<std::shared_ptr<BatchedGemm>, std::shared_ptr<BatchedGemm>, bool>(), py::arg("stage1"), py::arg("stage2"),
              py::arg("one_launch") = false)

@@ -60,6 +60,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--no-fuse", action="store_true",
                    help="with --batched --chain correct: issue the two products of a layer as two separate calls "
                         "(default: one call of the library's layer entry per layer)")
+    p.add_argument("--no-chain", action="store_true",
+                   help="with --batched --chain correct: do not join an aggregation stage with the next layer's X.W stage "
+                        "(default: one launch for the pair, qgtc_gcn_chain_batched)")
     p.add_argument("--one-launch", action="store_true",
                    help="with --batched --chain correct: both products of a layer in ONE launch (in-launch hand-off; "
                         "measured slower than the two grouped launches the library uses by default)")
@@ -178,7 +181,8 @@ class BatchedEpoch:
     """Builds the six grouped GEMMs of an epoch once (outputs preallocated and chained); run()
     issues six launches."""
 
-    def __init__(self, Q, cts, params, W, b, chain: str, run_gin: bool, fuse: bool = True, one_launch: bool = False):
+    def __init__(self, Q, cts, params, W, b, chain: str, run_gin: bool, fuse: bool = True, one_launch: bool = False,
+                 chain_stages: bool = True):
         H, C = W["hidden"], W["classes"]
         bitA = [c.bit_A for c in cts]
         bitX = [c.bit_X for c in cts]
@@ -236,7 +240,15 @@ class BatchedEpoch:
         # library runs a pair as two grouped launches (measured faster) unless one_launch asks for the in-launch
         # hand-off form.
         self.launches = list(self.stages)
-        if fuse and chain == "correct":
+        if fuse and chain == "correct" and chain_stages and not one_launch:
+            # An aggregation stage and the NEXT layer's X.W stage are one call (Q.ChainedPair -> qgtc_gcn_chain_batched):
+            # X.W is row-local, so the workgroup that has a 32-row block of the aggregate multiplies it with W right away.
+            # GCN: X.W1 | A.T1 + X.W2 | A.T2 + X.W3 | A.T3 (four launches); GIN: A.X + X.W1 | A.T1 + X.W2 | A.T2 | X.W3.
+            pairs = [(1, 2), (3, 4)] if not run_gin else [(0, 1), (2, 3)]
+            first = {i: Q.ChainedPair(self.stages[i], self.stages[j]) for i, j in pairs}
+            second = {j for _, j in pairs}
+            self.launches = [first.get(i, g) for i, g in enumerate(self.stages) if i not in second]
+        elif fuse and chain == "correct":
             pairs = [(0, 1), (2, 3), (4, 5)] if not run_gin else [(1, 2), (3, 4)]
             first = {i: Q.FusedLayer(self.stages[i], self.stages[j], one_launch) for i, j in pairs}
             second = {j for _, j in pairs}
@@ -339,7 +351,7 @@ def _run_epochs(args, Q, it, feat_size, b, device):
     if args.batched or args.streams > 0:
         cts = [c.to(device) for c in it.cTensor_li]
         plan = BatchedEpoch(Q, cts, it.cluster_param_li, W, b, args.chain, args.run_GIN, fuse=not getattr(args, "no_fuse", False),
-                            one_launch=getattr(args, "one_launch", False))
+                            one_launch=getattr(args, "one_launch", False), chain_stages=not getattr(args, "no_chain", False))
         for _ in range(args.n_epochs):
             outs = plan.run() if args.batched else plan.run_per_batch(args.streams)
     elif args.graph:

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_errors(lib):
-    assert lib.qgtc_abi_version() == 5
+    assert lib.qgtc_abi_version() == 6
     assert lib.qgtc_strerror(0) == b"ok"
     for code in range(1, 6):
         assert lib.qgtc_strerror(code) not in (b"ok", b"unknown error")
