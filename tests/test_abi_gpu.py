@@ -127,3 +127,44 @@ def test_layer_entry_with_raw_descriptors(lib, oracle, flags):
     # bad arguments are error codes
     assert lib.qgtc_gcn_layer_batched(None, descs.data_ptr(), count, 10, 10, 10, 10, 2, 2, 2, 1, 1, 2, arrival.data_ptr(), 1, flags, st) == 1
     assert lib.qgtc_gcn_layer_batched(descs.data_ptr(), descs.data_ptr(), count, 10, 10, 10, 10, 2, 2, 2, 1, 1, 1, arrival.data_ptr(), 1, flags, st) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0x10, 0x10 | 0x4, 0])
+def test_chain_entry_with_raw_descriptors(lib, oracle, flags):
+    """qgtc_gcn_chain_batched through ctypes (host-written descriptors, raw device pointers): the aggregation stage and the
+    next layer's X.W stage against the oracle's two products; one launch on the matrix cores (0x10 = QGTC_ENGINE_AUTO, with
+    and without QGTC_ZERO_JUMP - the descriptors carry no bitmaps, so every k-quad is visited) and as the two grouped
+    launches of the popcount engine (flags 0)."""
+    import torch
+    lib.qgtc_gcn_chain_batched.argtypes = [vp, vp, ctypes.c_int] + [ctypes.c_int] * 4 + [ctypes.c_int] * 5 + [ctypes.c_uint, vp]
+    rng = np.random.default_rng(23 + flags)
+    act, wb, f1, f2 = 2, 2, 128, 96
+    ns = [150, 333, 40]
+    W2 = oracle.pack(rand_q(rng, f1, f2, wb), wb, True)
+    dW2 = torch.from_numpy(W2.view(np.int32)).cuda()
+    keep, sa, sx, want = [dW2], [], [], []
+    P128 = lambda x: (x + 127) // 128 * 128   # noqa: E731
+    for n in ns:
+        qa = (rng.random((n, n)) < 0.03).astype(np.int32)
+        A, T = oracle.pack(qa, 1, False), oracle.pack(rand_q(rng, n, f1, act), act, True)
+        dA, dT = torch.from_numpy(A.view(np.int32)).cuda(), torch.from_numpy(T.view(np.int32)).cuda()
+        out = torch.full((int(lib.qgtc_rows_words(n, f1, act)),), -1, dtype=torch.int32, device="cuda")
+        T2 = torch.full((int(lib.qgtc_cols_words(n, f2, act, 0)),), -1, dtype=torch.int32, device="cuda")
+        keep += [dA, dT, out, T2]
+        sa.append(QgtcProblem(dA.data_ptr(), dT.data_ptr(), out.data_ptr(), dA.numel(), dT.numel(), n, n, f1, P128(f1), 0, None))
+        sx.append(QgtcProblem(out.data_ptr(), dW2.data_ptr(), T2.data_ptr(), out.numel(), dW2.numel(), n, f1, f2, P128(f2), 0, None))
+        out_o = oracle.bitmm2bit(A, T, n, n, f1, 1, act, act)
+        want.append((out, out_o, T2, oracle.bitmm2bit(out_o, W2, n, f1, f2, act, wb, act, col=True)))
+    count = len(ns)
+    host = (QgtcProblem * (2 * count))(*(sa + sx))
+    descs = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr() + 72 * count, count, max(ns), max(ns), f1, f2, 1, act, act, wb, act, flags, st)
+    assert rc == 0, lib.qgtc_strerror(rc)
+    torch.cuda.synchronize()
+    for (out, out_o, T2, T2_o) in want:
+        np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32).reshape(out_o.shape), out_o)
+        np.testing.assert_array_equal(T2.cpu().numpy().view(np.uint32).reshape(T2_o.shape), T2_o)
+    assert lib.qgtc_gcn_chain_batched(None, descs.data_ptr(), count, 10, 10, 10, 10, 1, 2, 2, 2, 2, flags, st) == 1
+    assert lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr(), count, 10, 10, 10, 10, 1, 2, 2, 2, 0, flags, st) == 1

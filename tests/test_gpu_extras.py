@@ -715,3 +715,69 @@ def test_headline_kernel_on_tall_tiles(qgtc, oracle, a, w):
                                                   err_msg=f"{M}x{K}x{N} rows ob={ob} {eng}")
                 np.testing.assert_array_equal(qgtc.bitMM2Int(bX, bW, M, K, N, a, w, True).cpu().numpy(), oracle.bitmm2int(X, Wt, M, K, N, a, w, True),
                                               err_msg=f"{M}x{K}x{N} float {eng}")
+
+
+# ---------------------------------------------------------------------------------------------
+# qgtc_gcn_chain_batched: an aggregation stage with the NEXT layer's X.W stage in the same call
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("f1,f2,act,wb", [(128, 128, 2, 2), (128, 10, 2, 2), (64, 64, 4, 4), (50, 64, 4, 4), (100, 77, 2, 1),
+                                          (128, 128, 1, 1), (200, 64, 2, 2), (64, 200, 2, 2), (128, 128, 3, 2)])
+@pytest.mark.parametrize("engine", ["auto", "popcount"])
+@pytest.mark.parametrize("zero_jump", [False, True])
+def test_chained_pair_matches_oracle(qgtc, oracle, f1, f2, act, wb, engine, zero_jump):
+    """ChainedPair (out = requant(A . T), then T' = requant(out . W') in the cols layout) against the oracle's two
+    products: ragged batches (fewer rows than a block, row counts that leave padding words in T'), widths inside and
+    outside the one-launch kernel's range (more than 128 columns, plane counts it is not built for, the popcount engine:
+    those take the two grouped launches), with and without occupancy bitmaps, run twice over poisoned outputs."""
+    import torch
+    from helpers import rand_q, to_dev
+    from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
+    rng = np.random.default_rng(31 * f1 + f2 + act + wb)
+    ns = [1213, 640, 37, 129, 300, 1025]
+    qw = rand_q(rng, f1, f2, wb)
+    W2 = oracle.pack(qw, wb, True)
+    dW2 = to_dev(torch, W2, cols_shape(f1, f2, wb))
+    As, Ts, want = [], [], []
+    for n in ns:
+        qa = rand_q(rng, n, n, 1, 0.01)
+        for blk in range(0, n, 64):
+            qa[blk:blk + 64, blk:blk + 64] = rng.integers(0, 2, size=qa[blk:blk + 64, blk:blk + 64].shape)
+        qt = rand_q(rng, n, f1, act)
+        A, T = oracle.pack(qa, 1, False), oracle.pack(qt, act, True)
+        As.append(to_dev(torch, A, rows_shape(n, n, 1)))
+        Ts.append(to_dev(torch, T, cols_shape(n, f1, act)))
+        out = oracle.bitmm2bit(A, T, n, n, f1, 1, act, act)
+        want.append((out, oracle.bitmm2bit(out, W2, n, f1, f2, act, wb, act, col=True)))
+    with use_engine(qgtc, engine):
+        sa = qgtc.BatchedGemm(As, Ts, [(n, n, f1) for n in ns], 1, act, act, 0, True, zero_jump)
+        sx = qgtc.BatchedGemm(sa.outs, [dW2], [(n, f1, f2) for n in ns], act, wb, act, 1, True)
+        pair = qgtc.ChainedPair(sa, sx)
+        for rep in range(2):
+            for o in list(sa.outs) + list(sx.outs):
+                o.fill_(-1)
+            pair.run()
+            torch.cuda.synchronize()
+            for i, n in enumerate(ns):
+                np.testing.assert_array_equal(to_np_u32(sa.outs[i]), want[i][0], err_msg=f"aggregate of batch {i} (n = {n}), run {rep}")
+                np.testing.assert_array_equal(to_np_u32(pair.outs[i]), want[i][1], err_msg=f"T' of batch {i} (n = {n}), run {rep}")
+
+
+@pytest.mark.gpu
+def test_chained_pair_rejects_plans_that_do_not_chain(qgtc, oracle):
+    import torch
+    from helpers import rand_q, to_dev
+    from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
+    rng = np.random.default_rng(8)
+    n, f = 100, 64
+    A = to_dev(torch, oracle.pack(rand_q(rng, n, n, 1), 1, False), rows_shape(n, n, 1))
+    T = to_dev(torch, oracle.pack(rand_q(rng, n, f, 2), 2, True), cols_shape(n, f, 2))
+    W = to_dev(torch, oracle.pack(rand_q(rng, f, f, 2), 2, True), cols_shape(f, f, 2))
+    sa = qgtc.BatchedGemm([A], [T], [(n, n, f)], 1, 2, 2, 0, True)
+    other = qgtc.BatchedGemm([A], [T], [(n, n, f)], 1, 2, 2, 0, True)
+    with pytest.raises(RuntimeError):      # the second stage does not read the first one's output
+        qgtc.ChainedPair(sa, qgtc.BatchedGemm(other.outs, [W], [(n, f, f)], 2, 2, 2, 1, True))
+    with pytest.raises(RuntimeError):      # rows-layout output where the cols layout is needed
+        qgtc.ChainedPair(sa, qgtc.BatchedGemm(sa.outs, [W], [(n, f, f)], 2, 2, 2, 0, True))
+    with pytest.raises(RuntimeError):      # plane counts that do not chain
+        qgtc.ChainedPair(sa, qgtc.BatchedGemm(sa.outs, [W], [(n, f, f)], 1, 2, 2, 1, True))
