@@ -237,14 +237,18 @@ def epoch_roofline(Q, graph, device_index, dataset, bits, hidden, gin):
     occ = [round(g.occupied_fraction, 4) for g in plan.stages if g.zero_jump or g.occupied_fraction < 1.0]
     floors = {"hbm_us": round(algo_bytes / (HBM_PEAK_GBS * 1e9) * 1e6, 2), "mfma_fp4_us": round(mfma_ops / (FP4_PEAK_TFLOPS * 1e12) * 1e6, 2),
               "launch_gaps_us": round(1.5 * (len(plan.launches) - 1), 1)}
-    return {"kernel_us_per_epoch": round(epoch_us, 2), "kernel_us_per_stage": stage_us, "calls_per_epoch": len(plan.launches),
-            "launches_per_epoch": len(plan.stages), "host_plan_build_and_weight_pack_ms": round(host_ms, 3),
+    chained = sum(1 for g in plan.launches if type(g).__name__ == "ChainedPair")
+    return {"kernel_us_per_epoch": round(epoch_us, 2), "kernel_us_per_operator_alone": stage_us, "calls_per_epoch": len(plan.launches),
+            "launches_per_epoch": len(plan.launches) if chained else len(plan.stages),
+            "launch_structure": (f"{len(plan.stages)} operators in {len(plan.launches)} launches: {chained} aggregation stages carry the next "
+                                 "layer's X.W stage (qgtc_gcn_chain_batched)") if chained else f"{len(plan.stages)} grouped launches",
+            "host_plan_build_and_weight_pack_ms": round(host_ms, 3),
             "algorithmic_bytes_per_epoch": int(algo_bytes), "effective_ops_per_epoch": eff_ops,
             "eff_TOPS": round(eff_ops / epoch_us / 1e6, 1), "floors": floors,
             "roofline": {"bound": "hbm", "achieved": round(algo_bytes / epoch_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(algo_bytes / epoch_us / 1e3 / HBM_PEAK_GBS, 4),
                          "frac_mfma": round(mfma_ops / epoch_us / 1e6 / FP4_PEAK_TFLOPS, 4),
-                         "note": "75 x 10 workgroups of fixed cost per stage: latency- and occupancy-bound, see DESIGN.md section 6"},
+                         "note": "a few thousand short workgroups per launch: bound by launch floors, dependent load chains and the epilogues' VALU work, see DESIGN.md section 6"},
             "adjacency_tiles_occupied": occ[:1], "rocprof": "profiles/r02/summary_epoch%s.json" % ("_gin" if gin else "")}
 
 
