@@ -187,16 +187,17 @@ int qgtc_gcn_layer_batched(const qgtc_problem *stage1, const qgtc_problem *stage
 /* An aggregation stage and the NEXT layer's feature-transform stage in one call (main_qgtc.py:148-153: t1 = MM2Bit(bA, t0),
  * t2 = MM2Bit(t1, bW2), as the layout-correct chain issues them: the second with a cols-layout output). For every cluster
  * batch i: stage_a[i] is  out_i = requant(A_i . T_i)  (rows-layout bits, act_bits planes; A_i rows layout with a_bits
- * planes, T_i cols layout with t_bits planes), stage_xw[i] is  T'_i = requant(out_i . W')  (cols-layout bits, out_bits
- * planes; W' cols layout with w_bits planes): stage_xw[i].X must be stage_a[i].out, stage_xw[i].K = stage_a[i].N,
- * stage_xw[i].M = stage_a[i].M. Word for word the result of qgtc_bitmm_batched(stage_a, mode 0) followed by
- * qgtc_bitmm_batched(stage_xw, mode 1) - both outputs are written. One launch (T' is row-local: a workgroup that has a
+ * planes, T_i cols layout with t_bits planes), stage_xw[i] is  T'_i = requant(out_i . W')  (out_mode 1: cols-layout bits,
+ * out_bits planes) or the output layer  float32(out_i . W')  (out_mode 2: [M, N'] floats, out_bits ignored; w_lines of the
+ * descriptor as for qgtc_bitmm2int); W' cols layout with w_bits planes: stage_xw[i].X must be stage_a[i].out,
+ * stage_xw[i].K = stage_a[i].N, stage_xw[i].M = stage_a[i].M. Word for word the result of qgtc_bitmm_batched(stage_a,
+ * mode 0) followed by qgtc_bitmm_batched(stage_xw, mode out_mode) - both outputs are written. One launch (T' is row-local: a workgroup that has a
  * 32-row block of out_i multiplies it with W' right away) when QGTC_ENGINE_AUTO / _MFMA is set, a_bits = 1, both products
  * have at most 128 columns and the plane counts are 2 / 2 / 2 / 2 or 4 / 4 / 4 / 4 at most; else the two grouped launches.
  * QGTC_ZERO_JUMP applies to stage_a (its .occ bitmaps). max_* are hard preconditions as for qgtc_bitmm_batched. */
 int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stage_xw, int count, int max_M, int max_K,
                            int max_N1, int max_N2, int a_bits, int t_bits, int act_bits, int w_bits, int out_bits,
-                           unsigned flags, void *stream);
+                           int out_mode, unsigned flags, void *stream);
 
 /* Adjacency bit planes from an edge list — replaces the dense detour of sampler.py:80-101
  * (torch.sparse.FloatTensor(...).to_dense() then QGTC.val2bit(A, nbits, False, False)): the n x n

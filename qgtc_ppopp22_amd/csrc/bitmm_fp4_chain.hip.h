@@ -19,11 +19,12 @@ namespace {
 //   * the partial-line stores (4 bytes at the line pitch) merge in ONE L2: all row blocks of a batch run on one XCD
 //     (xcd_consecutive), which is also where the next stage reads T'.
 // An epoch of the layout-correct Cluster-GCN chain is then four launches instead of six (X.W1 | A.T1 + X.W2 | A.T2 +
-// X.W3 | A.T3 -> float32).
+// X.W3 | A.T3 -> float32), a Batched-GIN epoch three (A.X + X.W1 | A.T1 + X.W2 | A.T2 + X.W3 -> float32).
 // Conditions (host): one-plane A, N <= 128 (the four words of a row of `out` = the whole K of the next product),
 // N' <= 128, the plane counts instantiated below.
 // ------------------------------------------------------------------------------------------
-template <int NW, int OB, int NW2, int OB2>
+// MODE2: 1 = T' as cols-layout bits (OB2 planes), 2 = float32 [M, N'] (the output layer: kernel.h:915-930; OB2 unused)
+template <int NW, int OB, int NW2, int OB2, int MODE2>
 __global__ __launch_bounds__(64 * 4) void k_bitmm_fp4_chain(const qgtc_problem *__restrict__ prs, const qgtc_problem *__restrict__ prs2,
                                                             MMShape sh, MMShape sh2) {
     constexpr int NDW = (NW + 1) / 2, NDX2 = (OB + 1) / 2, NDW2 = (NW2 + 1) / 2;   // base-4 digits
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(64 * 4) void k_bitmm_fp4_chain(const qgtc_problem *
     const qgtc_problem pr = prs[batch], pr2 = prs2[batch];
     const int M = pr.M, K = pr.K, N = pr.N, N2 = pr2.N;
     const int line_words2 = step128(M) * 4, lines2 = pad128(N2);
-    if (rb >= line_words2) return;                           // (not even a padding word of T')
+    if (MODE2 == 2 ? 32 * rb >= M : rb >= line_words2) return;   // (no rows / not even a padding word of T')
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 31, fh = lane >> 5;
@@ -171,8 +172,20 @@ __global__ __launch_bounds__(64 * 4) void k_bitmm_fp4_chain(const qgtc_problem *
                     acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa, w2b[h][dw], acc2, 4, 4, 0, 128 + 2 * da, 0, 128 + 2 * dw);
             }
     }
-    {   // cols layout [ob'][PAD128(N')][STEP128(M) * 4] (kernel.h:651-810 as intended): word rb of line n2, rows past M and
-        // lines past N' are zero (their operands were)
+    if constexpr (MODE2 == 2) {   // float32 rows: lane (fl, fh) register r is row (r & 3) + 8 (r >> 2) + 4 fh of the block, column n2
+        // Branch-free (the range check drops the stores of the columns past N' and the rows past M): with the stores
+        // under `if (n2 < N2)`, hipcc sank the MFMAs and the expansion of their operands into that branch - and an MFMA
+        // reads the operand registers of ALL lanes, whatever EXEC says: rows past N' came out as garbage.
+        const __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc(pr2.out, 0, static_cast<int>(static_cast<uint32_t>(M) * static_cast<uint32_t>(N2) * 4u), 0x00020000);
+        const uint32_t base = n2 < N2 ? (static_cast<uint32_t>(32 * rb) * static_cast<uint32_t>(N2) + static_cast<uint32_t>(n2)) * 4u : 0xffffffffu;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+            const float v = acc2[r];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro2, (base != 0xffffffffu && 32 * rb + row < M) ? base + static_cast<uint32_t>(row) * static_cast<uint32_t>(N2) * 4u : 0xffffffffu, 0, 0);
+        }
+    } else {   // cols layout [ob'][PAD128(N')][STEP128(M) * 4] (kernel.h:651-810 as intended): word rb of line n2, rows past M
+        // and lines past N' are zero (their operands were)
         uint32_t qv[16], P[4];
         requant_pack16<OB2>(acc2, OB2, P, qv);
         const size_t oplane2 = static_cast<size_t>(lines2) * line_words2;

@@ -16,7 +16,7 @@ int qgtc_launch_fp4_wave(const qgtc_problem *prs, int count, int max_M, int max_
                          bool zero_skip, hipStream_t st);
 int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, hipStream_t st);
 int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode, hipStream_t st);
-int qgtc_launch_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int w, int ob, int w2, int ob2, hipStream_t st);
+int qgtc_launch_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int w, int ob, int w2, int ob2, int mode2, hipStream_t st);
 
 // defined in qgtc_wide.hip
 int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st);
@@ -167,9 +167,9 @@ inline bool rows_ok(int max_K, int max_N, int a, int w, int ob, int mode) {
 // an "A . T" stage followed by the next layer's "X . W" stage, in one launch (bitmm_fp4_chain.hip.h): one-plane A, at most
 // 128 columns in both products (the four words of a row of the first output are the whole K of the second), the plane
 // combinations of the two epochs (2-bit / 4-bit everything)
-inline bool chain_ok(int max_K, int max_N1, int max_N2, int a, int w, int ob, int w2, int ob2) {
-    const bool planes = (ob == 2 && ob2 == 2 && w <= 2 && w2 <= 2) || (ob == 4 && ob2 == 4 && w <= 4 && w2 <= 4);
-    return a == 1 && planes && max_N1 <= 128 && max_N2 <= 128 && rows_ok(max_K, max_N1, a, w, ob, 0) && !getenv_flag("QGTC_NO_CHAIN");
+inline bool chain_ok(int max_K, int max_N1, int max_N2, int a, int w, int ob, int w2, int ob2, int mode2) {
+    const bool planes = (ob == 2 && (mode2 == 2 || ob2 == 2) && w <= 2 && w2 <= 2) || (ob == 4 && (mode2 == 2 || ob2 == 4) && w <= 4 && w2 <= 4);
+    return a == 1 && planes && max_N1 <= 128 && max_N2 <= 128 && rows_ok(max_K, max_N1, a, w, ob, 0) && !getenv_flag("QGTC_NO_CHAIN");   // (float32 outputs: M N' < 2^30 by the 16 MB-scale batches this is for; the torch binding's pools are below 2^31 bytes)
 }
 
 // grouped launches on the matrix cores, one wave per 32 x 32 tile (bitmm_fp4_wave.hip.h): for NARROW outputs.

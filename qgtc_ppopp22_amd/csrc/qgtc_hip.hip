@@ -321,17 +321,19 @@ int qgtc_gcn_layer_batched(const qgtc_problem *stage1, const qgtc_problem *stage
 
 int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stage_xw, int count, int max_M, int max_K,
                            int max_N1, int max_N2, int a_bits, int t_bits, int act_bits, int w_bits, int out_bits,
-                           unsigned flags, void *stream) {
+                           int out_mode, unsigned flags, void *stream) {
     if (!stage_a || !stage_xw || count <= 0 || count > 65535) return QGTC_EINVAL;
     if (max_M <= 0 || max_K <= 0 || max_N1 <= 0 || max_N2 <= 0) return QGTC_EINVAL;
-    if (!bits_ok(a_bits) || !bits_ok(t_bits) || !bits_ok(act_bits) || !bits_ok(w_bits) || !bits_ok(out_bits)) return QGTC_EINVAL;
+    if (!bits_ok(a_bits) || !bits_ok(t_bits) || !bits_ok(act_bits) || !bits_ok(w_bits)) return QGTC_EINVAL;
+    if (out_mode != 1 && out_mode != 2) return QGTC_EINVAL;
+    if (out_mode == 1 && !bits_ok(out_bits)) return QGTC_EINVAL;
     // one launch on the matrix cores where the shapes and plane counts allow it (bitmm_fp4_chain.hip.h), else the two
     // grouped launches it stands for
-    if ((flags & (QGTC_ENGINE_AUTO | QGTC_ENGINE_MFMA)) && chain_ok(max_K, max_N1, max_N2, a_bits, t_bits, act_bits, w_bits, out_bits))
-        return qgtc_launch_chain(stage_a, stage_xw, count, max_M, t_bits, act_bits, w_bits, out_bits, static_cast<hipStream_t>(stream));
+    if ((flags & (QGTC_ENGINE_AUTO | QGTC_ENGINE_MFMA)) && chain_ok(max_K, max_N1, max_N2, a_bits, t_bits, act_bits, w_bits, out_bits, out_mode))
+        return qgtc_launch_chain(stage_a, stage_xw, count, max_M, t_bits, act_bits, w_bits, out_bits, out_mode, static_cast<hipStream_t>(stream));
     int rc = qgtc_bitmm_batched(stage_a, count, max_M, max_K, max_N1, a_bits, t_bits, act_bits, 0, flags, stream);
     if (rc != QGTC_OK) return rc;
-    return qgtc_bitmm_batched(stage_xw, count, max_M, max_N1, max_N2, act_bits, w_bits, out_bits, 1, flags & ~QGTC_ZERO_JUMP, stream);
+    return qgtc_bitmm_batched(stage_xw, count, max_M, max_N1, max_N2, act_bits, w_bits, out_mode == 2 ? 1 : out_bits, out_mode, flags & ~QGTC_ZERO_JUMP, stream);
 }
 
 size_t qgtc_occupancy_words(int M, int K) {

@@ -621,7 +621,7 @@ struct ChainedPair {
         TORCH_CHECK(sa && sx, "ChainedPair needs two BatchedGemm plans");
         TORCH_CHECK(sa->count == sx->count, "both stages must cover the same cluster batches");
         TORCH_CHECK(sa->mode == 0, "the aggregation stage must produce rows-layout bits (mode 0)");
-        TORCH_CHECK(sx->mode == 1, "the feature-transform stage must produce cols-layout bits (mode 1)");
+        TORCH_CHECK(sx->mode == 1 || sx->mode == 2, "the feature-transform stage must produce cols-layout bits (mode 1) or float32 (mode 2)");
         TORCH_CHECK(sa->ob == sx->bit1, "the first stage's output bits must be the second stage's left-operand planes");
         TORCH_CHECK(sa->descs.device() == sx->descs.device(), "both stages must live on one device");
         for (int i = 0; i < sa->count; i++) {
@@ -636,7 +636,7 @@ struct ChainedPair {
         check_rc(qgtc_gcn_chain_batched(reinterpret_cast<const qgtc_problem *>(sa->descs.data_ptr()),
                                         reinterpret_cast<const qgtc_problem *>(sx->descs.data_ptr()), sa->count,
                                         std::max(sa->max_M, sx->max_M), sa->max_K, sa->max_N, sx->max_N, sa->bit1, sa->bit2, sa->ob,
-                                        sx->bit2, sx->ob, mm_flags() | (sa->jump_asked ? QGTC_ZERO_JUMP : 0u), current_stream(sa->descs)),
+                                        sx->bit2, sx->ob, sx->mode, mm_flags() | (sa->jump_asked ? QGTC_ZERO_JUMP : 0u), current_stream(sa->descs)),
                  "ChainedPair.run");
     }
 };

@@ -243,8 +243,8 @@ class BatchedEpoch:
         if fuse and chain == "correct" and chain_stages and not one_launch:
             # An aggregation stage and the NEXT layer's X.W stage are one call (Q.ChainedPair -> qgtc_gcn_chain_batched):
             # X.W is row-local, so the workgroup that has a 32-row block of the aggregate multiplies it with W right away.
-            # GCN: X.W1 | A.T1 + X.W2 | A.T2 + X.W3 | A.T3 (four launches); GIN: A.X + X.W1 | A.T1 + X.W2 | A.T2 | X.W3.
-            pairs = [(1, 2), (3, 4)] if not run_gin else [(0, 1), (2, 3)]
+            # GCN: X.W1 | A.T1 + X.W2 | A.T2 + X.W3 | A.T3 (four launches); GIN: A.X + X.W1 | A.T1 + X.W2 | A.T2 + X.W3 (three).
+            pairs = [(1, 2), (3, 4)] if not run_gin else [(0, 1), (2, 3), (4, 5)]
             first = {i: Q.ChainedPair(self.stages[i], self.stages[j]) for i, j in pairs}
             second = {j for _, j in pairs}
             self.launches = [first.get(i, g) for i, g in enumerate(self.stages) if i not in second]

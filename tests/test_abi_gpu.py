@@ -137,7 +137,7 @@ def test_chain_entry_with_raw_descriptors(lib, oracle, flags):
     and without QGTC_ZERO_JUMP - the descriptors carry no bitmaps, so every k-quad is visited) and as the two grouped
     launches of the popcount engine (flags 0)."""
     import torch
-    lib.qgtc_gcn_chain_batched.argtypes = [vp, vp, ctypes.c_int] + [ctypes.c_int] * 4 + [ctypes.c_int] * 5 + [ctypes.c_uint, vp]
+    lib.qgtc_gcn_chain_batched.argtypes = [vp, vp, ctypes.c_int] + [ctypes.c_int] * 4 + [ctypes.c_int] * 6 + [ctypes.c_uint, vp]
     rng = np.random.default_rng(23 + flags)
     act, wb, f1, f2 = 2, 2, 128, 96
     ns = [150, 333, 40]
@@ -160,11 +160,12 @@ def test_chain_entry_with_raw_descriptors(lib, oracle, flags):
     host = (QgtcProblem * (2 * count))(*(sa + sx))
     descs = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    rc = lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr() + 72 * count, count, max(ns), max(ns), f1, f2, 1, act, act, wb, act, flags, st)
+    rc = lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr() + 72 * count, count, max(ns), max(ns), f1, f2, 1, act, act, wb, act, 1, flags, st)
     assert rc == 0, lib.qgtc_strerror(rc)
     torch.cuda.synchronize()
     for (out, out_o, T2, T2_o) in want:
         np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32).reshape(out_o.shape), out_o)
         np.testing.assert_array_equal(T2.cpu().numpy().view(np.uint32).reshape(T2_o.shape), T2_o)
-    assert lib.qgtc_gcn_chain_batched(None, descs.data_ptr(), count, 10, 10, 10, 10, 1, 2, 2, 2, 2, flags, st) == 1
-    assert lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr(), count, 10, 10, 10, 10, 1, 2, 2, 2, 0, flags, st) == 1
+    assert lib.qgtc_gcn_chain_batched(None, descs.data_ptr(), count, 10, 10, 10, 10, 1, 2, 2, 2, 2, 1, flags, st) == 1
+    assert lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr(), count, 10, 10, 10, 10, 1, 2, 2, 2, 0, 1, flags, st) == 1
+    assert lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr(), count, 10, 10, 10, 10, 1, 2, 2, 2, 2, 0, flags, st) == 1
