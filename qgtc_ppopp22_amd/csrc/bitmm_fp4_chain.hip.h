@@ -25,7 +25,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // MODE2: 1 = T' as cols-layout bits (OB2 planes), 2 = float32 [M, N'] (the output layer: kernel.h:915-930; OB2 unused)
 template <int NW, int OB, int NW2, int OB2, int MODE2>
-__global__ __launch_bounds__(64 * 4) void k_bitmm_fp4_chain(const qgtc_problem *__restrict__ prs, const qgtc_problem *__restrict__ prs2,
+__global__ __launch_bounds__(64 * 4) __attribute__((amdgpu_waves_per_eu(OB <= 2 ? 8 : 4, 8))) void k_bitmm_fp4_chain(const qgtc_problem *__restrict__ prs, const qgtc_problem *__restrict__ prs2,
                                                             MMShape sh, MMShape sh2) {
     constexpr int NDW = (NW + 1) / 2, NDX2 = (OB + 1) / 2, NDW2 = (NW2 + 1) / 2;   // base-4 digits
     __shared__ __attribute__((aligned(16))) uint32_t xchg[OB][32][4];             // [plane][row of the block][word of the row]
@@ -142,13 +142,12 @@ __global__ __launch_bounds__(64 * 4) void k_bitmm_fp4_chain(const qgtc_problem *
             if (fh == 0) xchg[p][fl][wv] = x;
         }
     }
-    // W' expanded while the other waves finish
-    i32x8 w2b[2][NDW2];
+    __syncthreads();
+    i32x8 w2b[2][NDW2];   // (expanded after the barrier: before it, the codes would be live beside the first product's registers)
 #pragma unroll
     for (int h = 0; h < 2; h++)
 #pragma unroll
         for (int d = 0; d < NDW2; d++) w2b[h][d] = strip_operand<NW2>(w2l[h], d);
-    __syncthreads();
 
     // ---- second product: T'[32 rows of the block][columns n0 .. n0 + 31] = out . W' over the one k-quad (K' = N <= 128)
     f32x16 acc2;
