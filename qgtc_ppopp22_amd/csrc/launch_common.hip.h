@@ -16,6 +16,7 @@ int qgtc_launch_fp4_wave(const qgtc_problem *prs, int count, int max_M, int max_
                          bool zero_skip, hipStream_t st);
 int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, hipStream_t st);
 int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode, hipStream_t st);
+int qgtc_launch_xw_rows(const qgtc_problem *prs, int count, int max_M, int a, int w, int ob, hipStream_t st);
 int qgtc_launch_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int w, int ob, int w2, int ob2, int mode2, hipStream_t st);
 
 // defined in qgtc_wide.hip
@@ -162,6 +163,11 @@ inline bool strip_ok(int max_M, int max_K, int a, int w, int ob) {
 inline bool rows_ok(int max_K, int max_N, int a, int w, int ob, int mode) {
     return (mode == 0 || mode == 2) && max_K <= 8192 && max_N <= 256 && a <= 4 && w <= 8 && (mode == 2 || (ob >= 1 && ob <= 23)) &&
            static_cast<double>(max_K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0 && !getenv_flag("QGTC_NO_ROWS");
+}
+
+// grouped "X . W" stages by row blocks instead of column strips (k_bitmm_fp4_xw_rows)
+inline bool xw_rows_ok(int max_K, int max_N, int a, int w, int ob) {
+    return max_K <= 128 && max_N <= 128 && ((a <= 2 && w <= 2 && ob == 2) || (a <= 4 && w <= 4 && ob == 4)) && !getenv_flag("QGTC_NO_XWROWS");
 }
 
 // an "A . T" stage followed by the next layer's "X . W" stage, in one launch (bitmm_fp4_chain.hip.h): one-plane A, at most

@@ -170,6 +170,20 @@ int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, 
     return QGTC_OK;
 }
 
+// grouped "X . W" stages by row blocks (bitmm_fp4_chain.hip.h: k_bitmm_fp4_xw_rows): K <= 128, N <= 128, the plane counts of
+// the two epochs
+int qgtc_launch_xw_rows(const qgtc_problem *prs, int count, int max_M, int a, int w, int ob, hipStream_t st) {
+    MMShape sh = base_shape(a, w, ob, 1);
+    sh.nowrap = 1;
+    sh.per = getenv_flag("QGTC_NO_XCD") ? 0 : 1;
+    const dim3 grid(step128(max_M) * 4, count), block(64 * 4);
+    if (a <= 2 && w <= 2 && ob == 2) hipLaunchKernelGGL((k_bitmm_fp4_xw_rows<2, 2, 2>), grid, block, 0, st, prs, sh);
+    else if (a <= 4 && w <= 4 && ob == 4) hipLaunchKernelGGL((k_bitmm_fp4_xw_rows<4, 4, 4>), grid, block, 0, st, prs, sh);
+    else return QGTC_EINVAL;
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
 // an "A . T" stage with the next layer's "X . W" stage in its tail (bitmm_fp4_chain.hip.h): w / ob = planes of T / of the
 // first product's output (= of the second product's left operand), w2 / ob2 = planes of W' / of T'
 int qgtc_launch_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int w, int ob, int w2, int ob2, int mode2, hipStream_t st) {

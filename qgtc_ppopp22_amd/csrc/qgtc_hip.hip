@@ -275,6 +275,8 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
     // choice is correct; this only affects speed.
     const int k_hint = max_K;
     const int ob_ = mode == 2 ? 1 : output_bit;
+    if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && mode == 1 && xw_rows_ok(max_K, max_N, bit1, bit2, ob_))   // X . W stages: row blocks
+        return qgtc_launch_xw_rows(problems, count, max_M, bit1, bit2, ob_, st);
     if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && mode == 1 && strip_ok(max_M, max_K, bit1, bit2, ob_))   // X . W stages: column strips
         return qgtc_launch_strip(problems, count, max_M, max_N, bit1, bit2, ob_, st);
     if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && ((flags & QGTC_ZERO_JUMP) || max_N <= 64 || max_K <= 256) &&
