@@ -24,11 +24,14 @@ namespace {
 // N' <= 128, the plane counts instantiated below.
 // ------------------------------------------------------------------------------------------
 // MODE2: 1 = T' as cols-layout bits (OB2 planes), 2 = float32 [M, N'] (the output layer: kernel.h:915-930; OB2 unused)
-template <int NW, int OB, int NW2, int OB2, int MODE2>
+// DISC: `out` itself is not wanted (QGTC_CHAIN_DISCARD): it is neither packed nor stored - the re-quantised values go to
+// the second product as the E2M1 codes they are (a nibble each, in the order the W' expansion uses: column e of a word
+// = nibble 7 - e / 4 of dword 3 - e % 4), 16 instead of 36 + 28 VALU operations per wave between the two products
+template <int NW, int OB, int NW2, int OB2, int MODE2, bool DISC>
 __global__ __launch_bounds__(64 * 4) __attribute__((amdgpu_waves_per_eu(OB <= 2 ? 8 : 4, 8))) void k_bitmm_fp4_chain(const qgtc_problem *__restrict__ prs, const qgtc_problem *__restrict__ prs2,
                                                             MMShape sh, MMShape sh2) {
     constexpr int NDW = (NW + 1) / 2, NDX2 = (OB + 1) / 2, NDW2 = (NW2 + 1) / 2;   // base-4 digits
-    __shared__ __attribute__((aligned(16))) uint32_t xchg[OB][32][4];             // [plane][row of the block][word of the row]
+    __shared__ __attribute__((aligned(16))) uint32_t xchg[DISC ? 4 : OB][32][4];   // [plane][row of the block][word of the row]; DISC: [word][row][dword of codes]
     int rb = static_cast<int>(blockIdx.x), batch = static_cast<int>(blockIdx.y);
     if (sh.per) {   // the row blocks of a batch on ONE XCD (bitmm_fp4_rows.hip.h)
         const int v = xcd_consecutive(batch * static_cast<int>(gridDim.x) + rb, static_cast<int>(gridDim.x * gridDim.y));
@@ -126,7 +129,17 @@ __global__ __launch_bounds__(64 * 4) __attribute__((amdgpu_waves_per_eu(OB <= 2 
             multiply(xb_, wb_);
         }
     }
-    {   // re-quantise, pack, store the word of `out` (rows layout, kernel.h:357-389) and hand it to the second product
+    if constexpr (DISC) {   // re-quantise; the values themselves (low OB bits: kernel.h:350 keeps c == 2^ob, which packs as 0) are the codes
+        uint32_t qv[16], P[4];
+        requant_pack16<OB>(acc, ob, P, qv);   // P[t] byte 3 - gq = value of column t + 8 gq + 4 fh
+        uint32_t x[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            x[t] = (P[t] & (OB <= 2 ? 0x03030303u : 0x0f0f0f0fu)) << (4u - 4u * static_cast<uint32_t>(fh));   // nibble 7 - 2 gq - fh of dword 3 - t
+            x[t] = or_with_partner_half(x[t]);
+        }
+        if (fh == 0) *reinterpret_cast<u32x4 *>(&xchg[wv][fl][0]) = u32x4{x[3], x[2], x[1], x[0]};
+    } else {   // re-quantise, pack, store the word of `out` (rows layout, kernel.h:357-389) and hand it to the second product
         const int row_words = step128(N) * 4, rows_pad = pad8(M);
         const size_t oplane = static_cast<size_t>(rows_pad) * row_words;
         const bool store = fh == 0 && m < rows_pad && wv < row_words;
@@ -153,7 +166,22 @@ __global__ __launch_bounds__(64 * 4) __attribute__((amdgpu_waves_per_eu(OB <= 2 
     f32x16 acc2;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc2[r] = 0.0f;
-    {
+    if constexpr (DISC) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const u32x4 c = *reinterpret_cast<const u32x4 *>(&xchg[2 * fh + h][fl][0]);   // the codes of word 2 fh + h of row fl
+#pragma unroll
+            for (int da = 0; da < NDX2; da++) {
+                i32x8 xa;
+                if constexpr (OB <= 2) xa = i32x8{static_cast<int>(c[0]), static_cast<int>(c[1]), static_cast<int>(c[2]), static_cast<int>(c[3]), 0, 0, 0, 0};
+                else xa = i32x8{static_cast<int>((c[0] >> (2 * da)) & 0x33333333u), static_cast<int>((c[1] >> (2 * da)) & 0x33333333u),
+                                static_cast<int>((c[2] >> (2 * da)) & 0x33333333u), static_cast<int>((c[3] >> (2 * da)) & 0x33333333u), 0, 0, 0, 0};
+#pragma unroll
+                for (int dw = 0; dw < NDW2; dw++)
+                    acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa, w2b[h][dw], acc2, 4, 4, 0, 128 + 2 * da, 0, 128 + 2 * dw);
+            }
+        }
+    } else {
         uint32_t xd[2][OB];   // [k half][plane]: words 2 fh, 2 fh + 1 of row fl
 #pragma unroll
         for (int p = 0; p < OB; p++) {

@@ -182,7 +182,7 @@ class BatchedEpoch:
     issues six launches."""
 
     def __init__(self, Q, cts, params, W, b, chain: str, run_gin: bool, fuse: bool = True, one_launch: bool = False,
-                 chain_stages: bool = True):
+                 chain_stages: bool = True, keep_aggregates: bool = False):
         H, C = W["hidden"], W["classes"]
         bitA = [c.bit_A for c in cts]
         bitX = [c.bit_X for c in cts]
@@ -240,12 +240,16 @@ class BatchedEpoch:
         # library runs a pair as two grouped launches (measured faster) unless one_launch asks for the in-launch
         # hand-off form.
         self.launches = list(self.stages)
+        self.discarded = set()   # stages whose outputs are not materialised
         if fuse and chain == "correct" and chain_stages and not one_launch:
             # An aggregation stage and the NEXT layer's X.W stage are one call (Q.ChainedPair -> qgtc_gcn_chain_batched):
             # X.W is row-local, so the workgroup that has a 32-row block of the aggregate multiplies it with W right away.
             # GCN: X.W1 | A.T1 + X.W2 | A.T2 + X.W3 | A.T3 (four launches); GIN: A.X + X.W1 | A.T1 + X.W2 | A.T2 + X.W3 (three).
             pairs = [(1, 2), (3, 4)] if not run_gin else [(0, 1), (2, 3), (4, 5)]
-            first = {i: Q.ChainedPair(self.stages[i], self.stages[j]) for i, j in pairs}
+            # The aggregates themselves feed nothing but the X.W stage that rides on them: not materialised (keep_aggregates
+            # writes them, e.g. to compare every operator's output)
+            first = {i: Q.ChainedPair(self.stages[i], self.stages[j], not keep_aggregates) for i, j in pairs}
+            self.discarded = set() if keep_aggregates else {i for i, _ in pairs}
             second = {j for _, j in pairs}
             self.launches = [first.get(i, g) for i, g in enumerate(self.stages) if i not in second]
         elif fuse and chain == "correct":

@@ -28,7 +28,7 @@ for gin in (False, True):
         plan.run()
         if i % 5 == 4: plan.run()          # back to back as well
         torch.cuda.synchronize()
-        ok = all(torch.equal(x, y) for g, ws in zip(plan.stages, want) for x, y in zip(g.outs, ws))
+        ok = all(torch.equal(x, y) for i, (g, ws) in enumerate(zip(plan.stages, want)) if i not in plan.discarded for x, y in zip(g.outs, ws))
         n_bad += 0 if ok else 1
     print(f"{'GIN' if gin else 'GCN'}: 300 epochs of {len(plan.launches)} launches, {n_bad} differ from the six-launch plan's outputs", flush=True)
     bad += n_bad
