@@ -129,7 +129,21 @@ __global__ __launch_bounds__(64 * 4) __attribute__((amdgpu_waves_per_eu(OB <= 2 
             multiply(xb_, wb_);
         }
     }
-    if constexpr (DISC) {   // re-quantise; the values themselves (low OB bits: kernel.h:350 keeps c == 2^ob, which packs as 0) are the codes
+    const bool live1 = n0 < N;   // (wave-uniform: a wave past the last column of `out` holds zeros - no arithmetic on them)
+    if (!live1) {
+        if constexpr (DISC) {
+            if (fh == 0) *reinterpret_cast<u32x4 *>(&xchg[wv][fl][0]) = u32x4{0u, 0u, 0u, 0u};
+        } else {
+            const int row_words = step128(N) * 4, rows_pad = pad8(M);
+            const size_t oplane = static_cast<size_t>(rows_pad) * row_words;
+            uint32_t *dst = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(m) * row_words + wv;
+#pragma unroll
+            for (int p = 0; p < OB; p++) {
+                if (fh == 0 && m < rows_pad && wv < row_words) dst[p * oplane] = 0u;
+                if (fh == 0) xchg[p][fl][wv] = 0u;
+            }
+        }
+    } else if constexpr (DISC) {   // re-quantise; the values themselves (low OB bits: kernel.h:350 keeps c == 2^ob, which packs as 0) are the codes
         uint32_t qv[16], P[4];
         requant_pack16<OB>(acc, ob, P, qv);   // P[t] byte 3 - gq = value of column t + 8 gq + 4 fh
         uint32_t x[4];
@@ -156,6 +170,16 @@ __global__ __launch_bounds__(64 * 4) __attribute__((amdgpu_waves_per_eu(OB <= 2 
         }
     }
     __syncthreads();
+    if (n0 >= N2) {   // (wave-uniform) no column of T' here: zero lines of the cols layout, nothing for float32
+        if constexpr (MODE2 != 2) {
+            const size_t oplane2 = static_cast<size_t>(lines2) * line_words2;
+            uint32_t *dst = static_cast<uint32_t *>(pr2.out) + static_cast<size_t>(n2) * line_words2 + rb;
+#pragma unroll
+            for (int p = 0; p < OB2; p++)
+                if (fh == 0 && n2 < lines2) dst[p * oplane2] = 0u;
+        }
+        return;
+    }
     i32x8 w2b[2][NDW2];   // (expanded after the barrier: before it, the codes would be live beside the first product's registers)
 #pragma unroll
     for (int h = 0; h < 2; h++)
