@@ -27,10 +27,17 @@ namespace {
 // DISC: `out` itself is not wanted (QGTC_CHAIN_DISCARD): it is neither packed nor stored - the re-quantised values go to
 // the second product as the E2M1 codes they are (a nibble each, in the order the W' expansion uses: column e of a word
 // = nibble 7 - e / 4 of dword 3 - e % 4), 16 instead of 36 + 28 VALU operations per wave between the two products
-template <int NW, int OB, int NW2, int OB2, int MODE2, bool DISC>
+// CODES: bit 0 - T (the first product's right operand) arrives as E2M1 codes, bit 1 - T' is written as codes (4-bit
+// products only, where the codes are exactly as large as the packed planes): [line][k-quad][word][dword], 16 bytes of
+// codes per packed word, nibble 7 - e / 4 of dword 3 - e % 4 for element e - finished MFMA operands, written by the X.W
+// phase of the launch before, never seen outside a chain of these launches (QGTC_CHAIN_CODES_IN / _OUT)
+template <int NW, int OB, int NW2, int OB2, int MODE2, bool DISC, int CODES = 0>
 __global__ __launch_bounds__(64 * 4) __attribute__((amdgpu_waves_per_eu(OB <= 2 ? 8 : 4, 8))) void k_bitmm_fp4_chain(const qgtc_problem *__restrict__ prs, const qgtc_problem *__restrict__ prs2,
                                                             MMShape sh, MMShape sh2) {
     constexpr int NDW = (NW + 1) / 2, NDX2 = (OB + 1) / 2, NDW2 = (NW2 + 1) / 2;   // base-4 digits
+    constexpr bool CIN = (CODES & 1) != 0, COUT = (CODES & 2) != 0;
+    static_assert(!CIN || NW == 4, "code-form T: 4-bit products");
+    static_assert(!COUT || (OB2 == 4 && MODE2 == 1), "code-form T': 4-bit products, bits mode");
     __shared__ __attribute__((aligned(16))) uint32_t xchg[DISC ? 4 : OB][32][4];   // [plane][row of the block][word of the row]; DISC: [word][row][dword of codes]
     int rb = static_cast<int>(blockIdx.x), batch = static_cast<int>(blockIdx.y);
     if (sh.per) {   // the row blocks of a batch on ONE XCD (bitmm_fp4_rows.hip.h)
@@ -94,12 +101,18 @@ __global__ __launch_bounds__(64 * 4) __attribute__((amdgpu_waves_per_eu(OB <= 2 
             left &= left - 1ull;
             return Pair{qa < 0 ? -1 : (fh ? qb : qa), qa >= 0};
         };
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(   // (code-form T: 64 bytes per line and k-quad)
+            const_cast<uint32_t *>(pr.W), 0, static_cast<int>(static_cast<uint32_t>(pad128(N)) * static_cast<uint32_t>(kq) * 64u), 0x00020000);
         auto load = [&](int q, u32x4 &xl, u32x4 (&wl)[NW]) {
             const uint32_t ko = static_cast<uint32_t>(q) * 16u;
             xl = __builtin_amdgcn_raw_buffer_load_b128(rx, (q >= 0 && x_base != 0xffffffffu) ? x_base + ko : 0xffffffffu, 0, 0);
 #pragma unroll
-            for (int p = 0; p < NW; p++)
-                wl[p] = __builtin_amdgcn_raw_buffer_load_b128(rw, (q >= 0 && w_base != 0xffffffffu && p < sh.w) ? w_base + static_cast<uint32_t>(p) * w_plane + ko : 0xffffffffu, 0, 0);
+            for (int p = 0; p < NW; p++) {
+                if constexpr (CIN)   // wl[t] = the codes of word t of the k-quad (NW = 4 doubles as the word count)
+                    wl[p] = __builtin_amdgcn_raw_buffer_load_b128(rc, (q >= 0 && w_base != 0xffffffffu) ? (w_base + ko) * 4u + 16u * p : 0xffffffffu, 0, 0);
+                else
+                    wl[p] = __builtin_amdgcn_raw_buffer_load_b128(rw, (q >= 0 && w_base != 0xffffffffu && p < sh.w) ? w_base + static_cast<uint32_t>(p) * w_plane + ko : 0xffffffffu, 0, 0);
+            }
         };
         auto multiply = [&](const u32x4 &xl, const u32x4 (&wl)[NW]) {
 #pragma unroll
@@ -111,7 +124,10 @@ __global__ __launch_bounds__(64 * 4) __attribute__((amdgpu_waves_per_eu(OB <= 2 
                 for (int p = 0; p < NW; p++) ww[p] = wl[p][t];
 #pragma unroll
                 for (int dw = 0; dw < NDW; dw++) {
-                    const i32x8 wb = strip_operand<NW>(ww, dw);   // swapped: lane (fl, fh) register r holds C[row fl][column (r & 3) + 8 (r >> 2) + 4 fh]
+                    i32x8 wb;   // swapped: lane (fl, fh) register r holds C[row fl][column (r & 3) + 8 (r >> 2) + 4 fh]
+                    if constexpr (CIN) wb = i32x8{static_cast<int>((wl[t][0] >> (2 * dw)) & 0x33333333u), static_cast<int>((wl[t][1] >> (2 * dw)) & 0x33333333u),
+                                                  static_cast<int>((wl[t][2] >> (2 * dw)) & 0x33333333u), static_cast<int>((wl[t][3] >> (2 * dw)) & 0x33333333u), 0, 0, 0, 0};
+                    else wb = strip_operand<NW>(ww, dw);
                     acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb, xa, acc, 4, 4, 0, 128 + 2 * dw, 0, 128);
                 }
             }
@@ -171,7 +187,10 @@ __global__ __launch_bounds__(64 * 4) __attribute__((amdgpu_waves_per_eu(OB <= 2 
     }
     __syncthreads();
     if (n0 >= N2) {   // (wave-uniform) no column of T' here: zero lines of the cols layout, nothing for float32
-        if constexpr (MODE2 != 2) {
+        if constexpr (COUT) {
+            if (fh == 0 && n2 < lines2)
+                *reinterpret_cast<u32x4 *>(static_cast<uint32_t *>(pr2.out) + ((static_cast<size_t>(n2) * step128(M) + (rb >> 2)) * 4 + (rb & 3)) * 4) = u32x4{0u, 0u, 0u, 0u};
+        } else if constexpr (MODE2 != 2) {
             const size_t oplane2 = static_cast<size_t>(lines2) * line_words2;
             uint32_t *dst = static_cast<uint32_t *>(pr2.out) + static_cast<size_t>(n2) * line_words2 + rb;
 #pragma unroll
@@ -235,6 +254,17 @@ __global__ __launch_bounds__(64 * 4) __attribute__((amdgpu_waves_per_eu(OB <= 2 
             const float v = acc2[r];
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro2, (base != 0xffffffffu && 32 * rb + row < M) ? base + static_cast<uint32_t>(row) * static_cast<uint32_t>(N2) * 4u : 0xffffffffu, 0, 0);
         }
+    } else if constexpr (COUT) {   // the re-quantised values of word rb of line n2 as codes (see CODES above)
+        uint32_t qv[16], P[4];
+        requant_pack16<OB2>(acc2, OB2, P, qv);
+        uint32_t x[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            x[t] = (P[t] & 0x0f0f0f0fu) << (4u - 4u * static_cast<uint32_t>(fh));
+            x[t] = or_with_partner_half(x[t]);
+        }
+        if (fh == 0 && n2 < lines2)
+            *reinterpret_cast<u32x4 *>(static_cast<uint32_t *>(pr2.out) + ((static_cast<size_t>(n2) * step128(M) + (rb >> 2)) * 4 + (rb & 3)) * 4) = u32x4{x[3], x[2], x[1], x[0]};
     } else {   // cols layout [ob'][PAD128(N')][STEP128(M) * 4] (kernel.h:651-810 as intended): word rb of line n2, rows past M
         // and lines past N' are zero (their operands were)
         uint32_t qv[16], P[4];

@@ -186,21 +186,27 @@ int qgtc_launch_xw_rows(const qgtc_problem *prs, int count, int max_M, int a, in
 
 // an "A . T" stage with the next layer's "X . W" stage in its tail (bitmm_fp4_chain.hip.h): w / ob = planes of T / of the
 // first product's output (= of the second product's left operand), w2 / ob2 = planes of W' / of T'
-int qgtc_launch_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int w, int ob, int w2, int ob2, int mode2, bool discard, hipStream_t st) {
+int qgtc_launch_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int w, int ob, int w2, int ob2, int mode2, bool discard, int codes, hipStream_t st) {
     MMShape sh = base_shape(1, w, ob, 0), sh2 = base_shape(ob, w2, mode2 == 2 ? 1 : ob2, mode2);
     sh.nowrap = sh2.nowrap = 1;
     sh.per = getenv_flag("QGTC_NO_XCD") ? 0 : 1;   // (here: row blocks of a batch on one XCD)
     const dim3 grid(step128(max_M) * 4, count), block(64 * 4);   // a workgroup per word of T' (32 rows; the last ones padding)
-#define QGTC_CH_GO(NW_, OB_, NW2_, OB2_, MODE2_)                                                                                   \
-    do {                                                                                                                             \
-        if (discard) hipLaunchKernelGGL((k_bitmm_fp4_chain<NW_, OB_, NW2_, OB2_, MODE2_, true>), grid, block, 0, st, p1, p2, sh, sh2); \
-        else hipLaunchKernelGGL((k_bitmm_fp4_chain<NW_, OB_, NW2_, OB2_, MODE2_, false>), grid, block, 0, st, p1, p2, sh, sh2);       \
+#define QGTC_CH_GO(NW_, OB_, NW2_, OB2_, MODE2_, CODES_)                                                                                      \
+    do {                                                                                                                                        \
+        if (discard) hipLaunchKernelGGL((k_bitmm_fp4_chain<NW_, OB_, NW2_, OB2_, MODE2_, true, CODES_>), grid, block, 0, st, p1, p2, sh, sh2);  \
+        else hipLaunchKernelGGL((k_bitmm_fp4_chain<NW_, OB_, NW2_, OB2_, MODE2_, false, CODES_>), grid, block, 0, st, p1, p2, sh, sh2);        \
     } while (0)
-    if (mode2 == 2 && ob == 2 && w <= 2 && w2 <= 2) QGTC_CH_GO(2, 2, 2, 1, 2);
-    else if (mode2 == 2 && ob == 4 && w <= 4 && w2 <= 4) QGTC_CH_GO(4, 4, 4, 1, 2);
-    else if (mode2 == 1 && ob == 2 && ob2 == 2 && w <= 2 && w2 <= 2) QGTC_CH_GO(2, 2, 2, 2, 1);
-    else if (mode2 == 1 && ob == 4 && ob2 == 4 && w <= 4 && w2 <= 4) QGTC_CH_GO(4, 4, 4, 4, 1);
-    else return QGTC_EINVAL;
+    // code-form T / T' (QGTC_CHAIN_CODES_IN / _OUT): the 4-bit kernels only - a chain's launches all have the same widths
+    const int cin = codes & 1, cout = codes & 2;
+    if (mode2 == 2 && ob == 2 && w <= 2 && w2 <= 2) QGTC_CH_GO(2, 2, 2, 1, 2, 0);
+    else if (mode2 == 2 && ob == 4 && w <= 4 && w2 <= 4) { if (cin) QGTC_CH_GO(4, 4, 4, 1, 2, 1); else QGTC_CH_GO(4, 4, 4, 1, 2, 0); }
+    else if (mode2 == 1 && ob == 2 && ob2 == 2 && w <= 2 && w2 <= 2) QGTC_CH_GO(2, 2, 2, 2, 1, 0);
+    else if (mode2 == 1 && ob == 4 && ob2 == 4 && w <= 4 && w2 <= 4) {
+        if (cin && cout) QGTC_CH_GO(4, 4, 4, 4, 1, 3);
+        else if (cout) QGTC_CH_GO(4, 4, 4, 4, 1, 2);
+        else if (cin) QGTC_CH_GO(4, 4, 4, 4, 1, 1);
+        else QGTC_CH_GO(4, 4, 4, 4, 1, 0);
+    }
 #undef QGTC_CH_GO
     HIP_TRY(hipGetLastError());
     return QGTC_OK;

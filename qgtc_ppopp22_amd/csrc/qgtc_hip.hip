@@ -332,7 +332,8 @@ int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stag
     // one launch on the matrix cores where the shapes and plane counts allow it (bitmm_fp4_chain.hip.h), else the two
     // grouped launches it stands for
     if ((flags & (QGTC_ENGINE_AUTO | QGTC_ENGINE_MFMA)) && chain_ok(max_K, max_N1, max_N2, a_bits, t_bits, act_bits, w_bits, out_bits, out_mode))
-        return qgtc_launch_chain(stage_a, stage_xw, count, max_M, t_bits, act_bits, w_bits, out_bits, out_mode, (flags & QGTC_CHAIN_DISCARD) != 0u, static_cast<hipStream_t>(stream));
+        return qgtc_launch_chain(stage_a, stage_xw, count, max_M, t_bits, act_bits, w_bits, out_bits, out_mode, (flags & QGTC_CHAIN_DISCARD) != 0u,
+                                 ((flags & QGTC_CHAIN_CODES_IN) ? 1 : 0) | ((flags & QGTC_CHAIN_CODES_OUT) ? 2 : 0), static_cast<hipStream_t>(stream));
     int rc = qgtc_bitmm_batched(stage_a, count, max_M, max_K, max_N1, a_bits, t_bits, act_bits, 0, flags, stream);
     if (rc != QGTC_OK) return rc;
     return qgtc_bitmm_batched(stage_xw, count, max_M, max_N1, max_N2, act_bits, w_bits, out_mode == 2 ? 1 : out_bits, out_mode, flags & ~QGTC_ZERO_JUMP, stream);

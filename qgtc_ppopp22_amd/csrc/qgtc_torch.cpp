@@ -617,8 +617,10 @@ struct FusedLayer {
 struct ChainedPair {
     std::shared_ptr<BatchedGemm> sa, sx;
     bool discard = false;   // the aggregate itself is not wanted: stage_a's outputs are left unspecified (QGTC_CHAIN_DISCARD)
+    int codes = 0;          // bit 0 / 1: QGTC_CHAIN_CODES_IN / _OUT (T / T' in the kernel's operand format between chained calls)
 
-    ChainedPair(std::shared_ptr<BatchedGemm> stage_a, std::shared_ptr<BatchedGemm> stage_xw, bool discard_) : sa(std::move(stage_a)), sx(std::move(stage_xw)), discard(discard_) {
+    ChainedPair(std::shared_ptr<BatchedGemm> stage_a, std::shared_ptr<BatchedGemm> stage_xw, bool discard_, int codes_)
+        : sa(std::move(stage_a)), sx(std::move(stage_xw)), discard(discard_), codes(codes_) {
         TORCH_CHECK(sa && sx, "ChainedPair needs two BatchedGemm plans");
         TORCH_CHECK(sa->count == sx->count, "both stages must cover the same cluster batches");
         TORCH_CHECK(sa->mode == 0, "the aggregation stage must produce rows-layout bits (mode 0)");
@@ -637,7 +639,8 @@ struct ChainedPair {
         check_rc(qgtc_gcn_chain_batched(reinterpret_cast<const qgtc_problem *>(sa->descs.data_ptr()),
                                         reinterpret_cast<const qgtc_problem *>(sx->descs.data_ptr()), sa->count,
                                         std::max(sa->max_M, sx->max_M), sa->max_K, sa->max_N, sx->max_N, sa->bit1, sa->bit2, sa->ob,
-                                        sx->bit2, sx->ob, sx->mode, mm_flags() | (sa->jump_asked ? QGTC_ZERO_JUMP : 0u) | (discard ? QGTC_CHAIN_DISCARD : 0u), current_stream(sa->descs)),
+                                        sx->bit2, sx->ob, sx->mode, mm_flags() | (sa->jump_asked ? QGTC_ZERO_JUMP : 0u) | (discard ? QGTC_CHAIN_DISCARD : 0u) | ((codes & 1) ? QGTC_CHAIN_CODES_IN : 0u) | ((codes & 2) ? QGTC_CHAIN_CODES_OUT : 0u),
+                                        current_stream(sa->descs)),
                  "ChainedPair.run");
     }
 };
@@ -765,7 +768,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("one_launch") = false);
 
     py::class_<ChainedPair>(m, "ChainedPair")
-        .def(py::init<std::shared_ptr<BatchedGemm>, std::shared_ptr<BatchedGemm>, bool>(), py::arg("stage_a"), py::arg("stage_xw"), py::arg("discard") = false)
+        .def(py::init<std::shared_ptr<BatchedGemm>, std::shared_ptr<BatchedGemm>, bool, int>(), py::arg("stage_a"), py::arg("stage_xw"), py::arg("discard") = false,
+             py::arg("codes") = 0)
         .def_readonly("discard", &ChainedPair::discard)
         .def("run", &ChainedPair::run, "A.(XW) of one layer and X.W of the next for every cluster batch, one launch where eligible")
         .def_property_readonly("outs", [](const ChainedPair &c) { return c.sx->outs; });

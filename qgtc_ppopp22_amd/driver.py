@@ -248,8 +248,16 @@ class BatchedEpoch:
             pairs = [(1, 2), (3, 4)] if not run_gin else [(0, 1), (2, 3), (4, 5)]
             # The aggregates themselves feed nothing but the X.W stage that rides on them: not materialised (keep_aggregates
             # writes them, e.g. to compare every operator's output)
-            first = {i: Q.ChainedPair(self.stages[i], self.stages[j], not keep_aggregates) for i, j in pairs}
+            # In the 4-bit GIN chain every T' is read by the next chained call only: it stays in the kernel's operand format
+            # (QGTC_CHAIN_CODES_OUT / _IN; the library ignores the request outside the 4-bit one-launch kernel - every pair
+            # of the chain takes the same route, they share widths and engine)
+            codes = {}
+            if run_gin and not keep_aggregates and b == 4 and max(F, H, C) <= 128 and max(n) <= 8192:   # (every pair inside the kernel's range)
+                codes = {0: 2, 2: 3, 4: 1}
+            first = {i: Q.ChainedPair(self.stages[i], self.stages[j], not keep_aggregates, codes.get(i, 0)) for i, j in pairs}
             self.discarded = set() if keep_aggregates else {i for i, _ in pairs}
+            if codes:
+                self.discarded |= {1, 3}   # (T' of the first two pairs: codes, not packed planes)
             second = {j for _, j in pairs}
             self.launches = [first.get(i, g) for i, g in enumerate(self.stages) if i not in second]
         elif fuse and chain == "correct":
