@@ -275,6 +275,7 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
     // choice is correct; this only affects speed.
     const int k_hint = max_K;
     const int ob_ = mode == 2 ? 1 : output_bit;
+    if (flags & (QGTC_CHAIN_CODES_IN | QGTC_CHAIN_CODES_OUT)) return QGTC_EINVAL;   // (qgtc_gcn_chain_batched's one-launch kernel only)
     if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && mode == 1 && xw_rows_ok(max_K, max_N, bit1, bit2, ob_))   // X . W stages: row blocks
         return qgtc_launch_xw_rows(problems, count, max_M, bit1, bit2, ob_, st);
     if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && mode == 1 && strip_ok(max_M, max_K, bit1, bit2, ob_))   // X . W stages: column strips
@@ -331,9 +332,12 @@ int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stag
     if (out_mode == 1 && !bits_ok(out_bits)) return QGTC_EINVAL;
     // one launch on the matrix cores where the shapes and plane counts allow it (bitmm_fp4_chain.hip.h), else the two
     // grouped launches it stands for
-    if ((flags & (QGTC_ENGINE_AUTO | QGTC_ENGINE_MFMA)) && chain_ok(max_K, max_N1, max_N2, a_bits, t_bits, act_bits, w_bits, out_bits, out_mode))
+    const bool codes = (flags & (QGTC_CHAIN_CODES_IN | QGTC_CHAIN_CODES_OUT)) != 0u;
+    if ((flags & (QGTC_ENGINE_AUTO | QGTC_ENGINE_MFMA)) && chain_ok(max_K, max_N1, max_N2, a_bits, t_bits, act_bits, w_bits, out_bits, out_mode) &&
+        (!codes || act_bits == 4))   // (code-form T: the 4-bit kernels)
         return qgtc_launch_chain(stage_a, stage_xw, count, max_M, t_bits, act_bits, w_bits, out_bits, out_mode, (flags & QGTC_CHAIN_DISCARD) != 0u,
                                  ((flags & QGTC_CHAIN_CODES_IN) ? 1 : 0) | ((flags & QGTC_CHAIN_CODES_OUT) ? 2 : 0), static_cast<hipStream_t>(stream));
+    if (codes) return QGTC_EINVAL;   // (a link that cannot keep the format would misread its neighbour's buffer)
     int rc = qgtc_bitmm_batched(stage_a, count, max_M, max_K, max_N1, a_bits, t_bits, act_bits, 0, flags, stream);
     if (rc != QGTC_OK) return rc;
     return qgtc_bitmm_batched(stage_xw, count, max_M, max_N1, max_N2, act_bits, w_bits, out_mode == 2 ? 1 : out_bits, out_mode, flags & ~QGTC_ZERO_JUMP, stream);

@@ -24,6 +24,7 @@ Three ways to run the same math:
 from __future__ import annotations
 
 import argparse
+import os
 import random
 import time
 
@@ -248,11 +249,12 @@ class BatchedEpoch:
             pairs = [(1, 2), (3, 4)] if not run_gin else [(0, 1), (2, 3), (4, 5)]
             # The aggregates themselves feed nothing but the X.W stage that rides on them: not materialised (keep_aggregates
             # writes them, e.g. to compare every operator's output)
-            # In the 4-bit GIN chain every T' is read by the next chained call only: it stays in the kernel's operand format
-            # (QGTC_CHAIN_CODES_OUT / _IN; the library ignores the request outside the 4-bit one-launch kernel - every pair
-            # of the chain takes the same route, they share widths and engine)
             codes = {}
-            if run_gin and not keep_aggregates and b == 4 and max(F, H, C) <= 128 and max(n) <= 8192:   # (every pair inside the kernel's range)
+            if (run_gin and not keep_aggregates and b == 4 and max(F, H, C) <= 128 and max(n) <= 8192 and Q.get_engine() != "popcount" and
+                    not any(k.startswith("QGTC_NO_") for k in os.environ)):   # (every pair inside the one-launch kernel's range, no debugging switch rerouting one)
+                # In the 4-bit GIN chain every T' is read by the next chained call only: it stays in the kernel's operand
+                # format (QGTC_CHAIN_CODES_OUT / _IN; the library refuses the request outside the 4-bit one-launch kernel).
+                # Not for the 2-bit GCN chain: codes are 4 bits a value, twice its packed T - measured 36.5 us against 34.5
                 codes = {0: 2, 2: 3, 4: 1}
             first = {i: Q.ChainedPair(self.stages[i], self.stages[j], not keep_aggregates, codes.get(i, 0)) for i, j in pairs}
             self.discarded = set() if keep_aggregates else {i for i, _ in pairs}

@@ -169,3 +169,7 @@ def test_chain_entry_with_raw_descriptors(lib, oracle, flags):
     assert lib.qgtc_gcn_chain_batched(None, descs.data_ptr(), count, 10, 10, 10, 10, 1, 2, 2, 2, 2, 1, flags, st) == 1
     assert lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr(), count, 10, 10, 10, 10, 1, 2, 2, 2, 0, 1, flags, st) == 1
     assert lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr(), count, 10, 10, 10, 10, 1, 2, 2, 2, 2, 0, flags, st) == 1
+    # code-form T' (QGTC_CHAIN_CODES_OUT 0x100 / _IN 0x80) exists in the 4-bit one-launch kernel only: a call that could not keep
+    # the format is refused, not run with the flags dropped (its neighbour would misread the buffer)
+    assert lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr() + 72 * count, count, max(ns), max(ns), f1, f2, 1, 2, 2, 2, 2, 1, flags | 0x100, st) == 1
+    assert lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr() + 72 * count, count, max(ns), max(ns), 256, f2, 1, 4, 4, 4, 4, 1, flags | 0x80, st) == 1
