@@ -58,8 +58,8 @@ enum {
 #define QGTC_LAYER_ONE_LAUNCH 0x20u /* qgtc_gcn_layer_batched: both products of the layer in ONE launch (in-launch
                                   hand-off through per-batch arrival counters) instead of two grouped launches */
 #define QGTC_CHAIN_DISCARD 0x40u    /* qgtc_gcn_chain_batched: the caller does not need stage_a's output itself */
-#define QGTC_CHAIN_CODES_IN 0x80u   /* qgtc_gcn_chain_batched: stage_a's right operands were written by a launch with _CODES_OUT */
-#define QGTC_CHAIN_CODES_OUT 0x100u /* qgtc_gcn_chain_batched: stage_xw's outputs are only read by a launch with _CODES_IN */
+#define QGTC_CHAIN_CODES_IN 0x80u   /* qgtc_gcn_chain_batched / qgtc_bitmm_batched: the right operands were written by a launch with _CODES_OUT */
+#define QGTC_CHAIN_CODES_OUT 0x100u /* qgtc_gcn_chain_batched / qgtc_bitmm_batched (mode 1): the outputs are only read by a launch with _CODES_IN */
 
 int qgtc_abi_version(void);
 const char *qgtc_strerror(int code);
@@ -199,10 +199,12 @@ int qgtc_gcn_layer_batched(const qgtc_problem *stage1, const qgtc_problem *stage
  * have at most 128 columns and the plane counts are 2 / 2 / 2 / 2 or 4 / 4 / 4 / 4 at most; else the two grouped launches.
  * QGTC_ZERO_JUMP applies to stage_a (its .occ bitmaps). QGTC_CHAIN_DISCARD: the aggregate itself is not wanted - the
  * one-launch kernel then neither packs nor stores stage_a[i].out (its contents are unspecified afterwards; the two-launch
- * route still writes it). QGTC_CHAIN_CODES_OUT / _IN: a T' that only the next call of this entry reads may be left in the
- * kernel's own operand format (4-bit chains: same buffer, same size). Only the one-launch kernel reads and writes that
- * format: a call with these flags that would take the two-launch route (engine flags absent, more than 128 columns, other
- * plane counts) returns QGTC_EINVAL rather than misread its neighbour's buffer, and so does qgtc_bitmm_batched.
+ * route still writes it). QGTC_CHAIN_CODES_OUT / _IN: a T' that only the next launch of the chain reads may be left in the
+ * kernels' own format (same buffer, same size: E2M1 codes in the 4-bit chains, bit planes in k-quad-major order in the
+ * 2-bit ones; unspecified to the caller). A 2-bit chain's first X.W stage and last aggregation go through
+ * qgtc_bitmm_batched with _CODES_OUT / _CODES_IN. Only the matrix-core row-block kernels read and write these formats: a
+ * call with the flags that would take another route (engine flags absent, more than 128 columns, other plane counts)
+ * returns QGTC_EINVAL rather than misread its neighbour's buffer.
  * max_* are hard preconditions as for qgtc_bitmm_batched. */
 int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stage_xw, int count, int max_M, int max_K,
                            int max_N1, int max_N2, int a_bits, int t_bits, int act_bits, int w_bits, int out_bits,

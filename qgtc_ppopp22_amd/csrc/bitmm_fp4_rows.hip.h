@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
         for (int j = 0; j < CB; j++)
 #pragma unroll
             for (int p = 0; p < NW; p++)
-                wl[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rw, (q >= 0 && w_base[j] != 0xffffffffu && p < sh.w) ? w_base[j] + static_cast<uint32_t>(p) * w_plane + ko : 0xffffffffu, 0, 0);
+                wl[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rw, (q >= 0 && w_base[j] != 0xffffffffu && p < sh.w) ? static_cast<uint32_t>(p) * w_plane + ((sh.qmajor & 1) ? static_cast<uint32_t>(q * pr.w_lines + n0 + 32 * j + fl) * 16u : w_base[j] + ko) : 0xffffffffu, 0, 0);   // (quad-major T of a chain: bitmm_fp4_chain.hip.h)
     };
     auto multiply = [&](const u32x4 (&xl)[NA], const u32x4 (&wl)[CB][NW]) {
 #pragma unroll

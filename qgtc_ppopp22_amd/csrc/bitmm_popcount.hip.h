@@ -66,6 +66,8 @@ struct MMShape {           // per-launch constants
     uint32_t inv_tiles_n;  // floor(2^32 / tiles_n), single launches only (tiles_n >= 2; else 0xffffffff)
     float maxv, maxm1;     // 2^ob and 2^ob - 1 as float (requant)
     int nowrap;            // K (2^a - 1)(2^w - 1) < 2^31: no accumulator can wrap negative
+    int qmajor;            // row-block kernels of a chain (bitmm_fp4_chain.hip.h): bit 0 the right operand is read, bit 1 the cols-layout
+                           // output is written, in QUAD-MAJOR order (qmajor_word below)
 };
 
 constexpr int MR = 4, MC = 4;        // per-lane micro-tile

@@ -172,10 +172,11 @@ int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, 
 
 // grouped "X . W" stages by row blocks (bitmm_fp4_chain.hip.h: k_bitmm_fp4_xw_rows): K <= 128, N <= 128, the plane counts of
 // the two epochs
-int qgtc_launch_xw_rows(const qgtc_problem *prs, int count, int max_M, int a, int w, int ob, hipStream_t st) {
+int qgtc_launch_xw_rows(const qgtc_problem *prs, int count, int max_M, int a, int w, int ob, bool qmajor_out, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, 1);
     sh.nowrap = 1;
     sh.per = getenv_flag("QGTC_NO_XCD") ? 0 : 1;
+    sh.qmajor = qmajor_out ? 2 : 0;
     const dim3 grid(step128(max_M) * 4, count), block(64 * 4);
     if (a <= 2 && w <= 2 && ob == 2) hipLaunchKernelGGL((k_bitmm_fp4_xw_rows<2, 2, 2>), grid, block, 0, st, prs, sh);
     else if (a <= 4 && w <= 4 && ob == 4) hipLaunchKernelGGL((k_bitmm_fp4_xw_rows<4, 4, 4>), grid, block, 0, st, prs, sh);
@@ -196,8 +197,10 @@ int qgtc_launch_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count,
         if (discard) hipLaunchKernelGGL((k_bitmm_fp4_chain<NW_, OB_, NW2_, OB2_, MODE2_, true, CODES_>), grid, block, 0, st, p1, p2, sh, sh2);  \
         else hipLaunchKernelGGL((k_bitmm_fp4_chain<NW_, OB_, NW2_, OB2_, MODE2_, false, CODES_>), grid, block, 0, st, p1, p2, sh, sh2);        \
     } while (0)
-    // code-form T / T' (QGTC_CHAIN_CODES_IN / _OUT): the 4-bit kernels only - a chain's launches all have the same widths
+    // T / T' in the chain's own format (QGTC_CHAIN_CODES_IN / _OUT): E2M1 codes in the 4-bit kernels, quad-major bit planes
+    // in the 2-bit ones (a chain's launches all have the same widths)
     const int cin = codes & 1, cout = codes & 2;
+    if (ob == 2) sh.qmajor = codes & 3;
     if (mode2 == 2 && ob == 2 && w <= 2 && w2 <= 2) QGTC_CH_GO(2, 2, 2, 1, 2, 0);
     else if (mode2 == 2 && ob == 4 && w <= 4 && w2 <= 4) { if (cin) QGTC_CH_GO(4, 4, 4, 1, 2, 1); else QGTC_CH_GO(4, 4, 4, 1, 2, 0); }
     else if (mode2 == 1 && ob == 2 && ob2 == 2 && w <= 2 && w2 <= 2) QGTC_CH_GO(2, 2, 2, 2, 1, 0);
@@ -213,10 +216,11 @@ int qgtc_launch_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count,
 }
 
 // grouped "A . (XW)" stages: one workgroup per 32-row block of a batch, only the occupied k-quads (bitmm_fp4_rows.hip.h)
-int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode, hipStream_t st) {
+int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode, bool qmajor_in, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, mode);
     sh.nowrap = 1;
     sh.per = getenv_flag("QGTC_NO_XCD") ? 0 : 1;   // (here: row blocks of a batch on one XCD)
+    sh.qmajor = qmajor_in ? 1 : 0;
     const int blocks = mode == 2 ? (max_N + 31) / 32 : step128(max_N) * 4;   // 32-column blocks: per 32 columns / per word of a packed row
     // (two column blocks per wave - half the waves, one round of them on the chip instead of 1.4 - measured no faster:
     // 11.1 against 10.6 us on the ogbn-arxiv-sized A-stages; kept as a tuning switch)

@@ -275,14 +275,21 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
     // choice is correct; this only affects speed.
     const int k_hint = max_K;
     const int ob_ = mode == 2 ? 1 : output_bit;
-    if (flags & (QGTC_CHAIN_CODES_IN | QGTC_CHAIN_CODES_OUT)) return QGTC_EINVAL;   // (qgtc_gcn_chain_batched's one-launch kernel only)
+    const bool engine = (flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) != 0u;
+    const bool rows_route = engine && ((flags & QGTC_ZERO_JUMP) || max_N <= 64 || max_K <= 256) && rows_ok(max_K, max_N, bit1, bit2, ob_, mode);
+    if (flags & (QGTC_CHAIN_CODES_IN | QGTC_CHAIN_CODES_OUT)) {
+        // the first X.W / the last aggregation of a 2-bit chain (quad-major T, bitmm_fp4_chain.hip.h): only the row-block
+        // kernels read and write that order, and a link that cannot would misread its neighbour's buffer - refused instead
+        const bool out_ok = (flags & QGTC_CHAIN_CODES_OUT) && !(flags & QGTC_CHAIN_CODES_IN) && engine && mode == 1 && ob_ == 2 && xw_rows_ok(max_K, max_N, bit1, bit2, ob_);
+        const bool in_ok = (flags & QGTC_CHAIN_CODES_IN) && !(flags & QGTC_CHAIN_CODES_OUT) && mode != 1 && bit2 == 2 && rows_route;
+        if (!out_ok && !in_ok) return QGTC_EINVAL;
+    }
     if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && mode == 1 && xw_rows_ok(max_K, max_N, bit1, bit2, ob_))   // X . W stages: row blocks
-        return qgtc_launch_xw_rows(problems, count, max_M, bit1, bit2, ob_, st);
+        return qgtc_launch_xw_rows(problems, count, max_M, bit1, bit2, ob_, (flags & QGTC_CHAIN_CODES_OUT) != 0u, st);
     if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && mode == 1 && strip_ok(max_M, max_K, bit1, bit2, ob_))   // X . W stages: column strips
         return qgtc_launch_strip(problems, count, max_M, max_N, bit1, bit2, ob_, st);
-    if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && ((flags & QGTC_ZERO_JUMP) || max_N <= 64 || max_K <= 256) &&
-        rows_ok(max_K, max_N, bit1, bit2, ob_, mode))   // sparse left operands / narrow outputs / one or two k-quads: one workgroup per 32-row block
-        return qgtc_launch_rows(problems, count, max_M, max_N, bit1, bit2, ob_, mode, st);
+    if (rows_route)   // sparse left operands / narrow outputs / one or two k-quads: one workgroup per 32-row block
+        return qgtc_launch_rows(problems, count, max_M, max_N, bit1, bit2, ob_, mode, (flags & QGTC_CHAIN_CODES_IN) != 0u, st);
     if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && fp4_wave_ok(max_K, max_N, bit1, bit2))   // narrow outputs: one wave per 32 x 32 tile
         return qgtc_launch_fp4_wave(problems, count, max_M, max_N, bit1, bit2, ob_, mode, !(flags & QGTC_NO_ZERO_SKIP), st);
     if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) ||  // problems with a one-word bitmap jump zero tiles
@@ -334,7 +341,8 @@ int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stag
     // grouped launches it stands for
     const bool codes = (flags & (QGTC_CHAIN_CODES_IN | QGTC_CHAIN_CODES_OUT)) != 0u;
     if ((flags & (QGTC_ENGINE_AUTO | QGTC_ENGINE_MFMA)) && chain_ok(max_K, max_N1, max_N2, a_bits, t_bits, act_bits, w_bits, out_bits, out_mode) &&
-        (!codes || act_bits == 4))   // (code-form T: the 4-bit kernels)
+        (!codes || act_bits == 4 || (act_bits == 2 && (!(flags & QGTC_CHAIN_CODES_IN) || t_bits == 2) && (!(flags & QGTC_CHAIN_CODES_OUT) || out_mode == 1))))
+        // (the chain's own T format: E2M1 codes in the 4-bit kernels, quad-major planes in the 2-bit ones)
         return qgtc_launch_chain(stage_a, stage_xw, count, max_M, t_bits, act_bits, w_bits, out_bits, out_mode, (flags & QGTC_CHAIN_DISCARD) != 0u,
                                  ((flags & QGTC_CHAIN_CODES_IN) ? 1 : 0) | ((flags & QGTC_CHAIN_CODES_OUT) ? 2 : 0), static_cast<hipStream_t>(stream));
     if (codes) return QGTC_EINVAL;   // (a link that cannot keep the format would misread its neighbour's buffer)

@@ -405,6 +405,7 @@ struct BatchedGemm {
     torch::Tensor stats;  // device: [occupied, all] 32-row x 128-bit tiles of the left operands (zero_jump)
     int count = 0, max_M = 0, max_K = 0, max_N = 0, bit1 = 1, bit2 = 1, ob = 1, mode = 0;
     bool jump_asked = false;
+    int codes = 0;   // bit 0 / 1: QGTC_CHAIN_CODES_IN / _OUT for run() (the first / last launch of a chain that keeps T in the kernels' own format)
     static constexpr double kJumpBelow = 0.25;  // measured: at 19 % occupied tiles jumping gains 10 %, at 43 % it loses 15 %
 
     // Xs[i]: rows-layout left operand of problem i; Ws: one shared right operand (len 1) or one
@@ -562,7 +563,8 @@ struct BatchedGemm {
         c10::DeviceGuard guard(descs.device());
         check_rc(qgtc_bitmm_batched(reinterpret_cast<const qgtc_problem *>(descs.data_ptr()), count,
                                     max_M, max_K, max_N, bit1, bit2, ob, mode,
-                                    mm_flags() | (jump_asked ? QGTC_ZERO_JUMP : 0u), current_stream(descs)),
+                                    mm_flags() | (jump_asked ? QGTC_ZERO_JUMP : 0u) | ((codes & 1) ? QGTC_CHAIN_CODES_IN : 0u) | ((codes & 2) ? QGTC_CHAIN_CODES_OUT : 0u),
+                                    current_stream(descs)),
                  "BatchedGemm.run");
     }
 };
@@ -793,6 +795,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def("run_per_problem", &BatchedGemm::run_per_problem, py::arg("n_streams") = 1)
         .def_readonly("outs", &BatchedGemm::outs)
         .def_readonly("count", &BatchedGemm::count)
+        .def_readwrite("codes", &BatchedGemm::codes, "1: the right operands / 2: the outputs are in a chain's own format (QGTC_CHAIN_CODES_IN / _OUT): the "
+                       "first X.W stage / last aggregation of a chain of ChainedPair(..., codes) launches")
         .def_property_readonly("zero_jump", &BatchedGemm::zero_jump)
         .def_property_readonly("occupied_fraction", &BatchedGemm::occupied_fraction);
 }

@@ -250,16 +250,19 @@ class BatchedEpoch:
             # The aggregates themselves feed nothing but the X.W stage that rides on them: not materialised (keep_aggregates
             # writes them, e.g. to compare every operator's output)
             codes = {}
-            if (run_gin and not keep_aggregates and b == 4 and max(F, H, C) <= 128 and max(n) <= 8192 and Q.get_engine() != "popcount" and
-                    not any(k.startswith("QGTC_NO_") for k in os.environ)):   # (every pair inside the one-launch kernel's range, no debugging switch rerouting one)
-                # In the 4-bit GIN chain every T' is read by the next chained call only: it stays in the kernel's operand
-                # format (QGTC_CHAIN_CODES_OUT / _IN; the library refuses the request outside the 4-bit one-launch kernel).
-                # Not for the 2-bit GCN chain: codes are 4 bits a value, twice its packed T - measured 36.5 us against 34.5
-                codes = {0: 2, 2: 3, 4: 1}
+            if (not keep_aggregates and (b == 2 or (run_gin and b == 4)) and max(F, H, C) <= 128 and max(n) <= 8192 and Q.get_engine() != "popcount" and
+                    not any(k.startswith("QGTC_NO_") for k in os.environ)):   # (every launch inside the row-block kernels' range, no debugging switch rerouting one)
+                # Every T' is read by the next launch of the chain only: it stays in the kernels' own format
+                # (QGTC_CHAIN_CODES_OUT / _IN: E2M1 codes in the 4-bit chain - no expansion in the reader -, k-quad-major
+                # bit planes in the 2-bit ones - a wave's loads and stores of T touch 4 cache lines instead of 32). The
+                # library refuses the request where a launch could not keep the format.
+                codes = {0: 2, 2: 3, 4: 1} if run_gin else {0: 2, 1: 3, 3: 3, 5: 1}
+                if not run_gin:
+                    self.stages[0].codes, self.stages[5].codes = 2, 1
             first = {i: Q.ChainedPair(self.stages[i], self.stages[j], not keep_aggregates, codes.get(i, 0)) for i, j in pairs}
             self.discarded = set() if keep_aggregates else {i for i, _ in pairs}
             if codes:
-                self.discarded |= {1, 3}   # (T' of the first two pairs: codes, not packed planes)
+                self.discarded |= {1, 3} if run_gin else {0, 2, 4}   # (the T's: the chain's own format, not the cols layout)
             second = {j for _, j in pairs}
             self.launches = [first.get(i, g) for i, g in enumerate(self.stages) if i not in second]
         elif fuse and chain == "correct":

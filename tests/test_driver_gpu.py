@@ -188,14 +188,15 @@ def test_full_size_epoch_matches_oracle_and_per_batch_launches(qgtc, oracle, dat
     assert min(sizes) > (1100 if dataset == "ogbn-arxiv" else 500)
 
 
-@pytest.mark.parametrize("gin", [False, True])
+@pytest.mark.parametrize("gin", [False, True, 2])
 def test_layer_entry_routes_give_the_same_epoch(qgtc, gin):
     """--batched --chain correct: one call of the library's layer entry per layer (default), the same as ONE launch per
     layer (--one-launch, in-launch hand-off), and the six separate grouped launches (--no-fuse): identical outputs."""
     import torch
     from qgtc_ppopp22_amd import driver
 
-    base = ["--batched", "--chain", "correct"] + (["--run_GIN", "--bit_width", "4"] if gin else [])
+    base = ["--batched", "--chain", "correct"] + (["--run_GIN", "--bit_width", "2" if gin == 2 else "4"] if gin else [])   # (the default
+    # plan keeps T between its launches in the kernels' own formats: codes at 4 bits, k-quad-major planes at 2)
     ref = driver.run(_args(base + ["--no-fuse"]), Q=qgtc)["outs"]
     for extra in ([], ["--one-launch"]):
         got = driver.run(_args(base + extra), Q=qgtc)["outs"]
