@@ -207,8 +207,9 @@ def epoch_roofline(Q, graph, device_index, dataset, bits, hidden, gin):
     torch.cuda.synchronize()
     host_ms = (time.perf_counter() - t0) * 1e3
 
-    def ev(fn, reps=20):
-        fn()
+    def ev(fn, reps=100):   # (a 20-epoch window is 0.6 ms, of which the queue's start-up is 5 - 10 %)
+        for _ in range(3):
+            fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
