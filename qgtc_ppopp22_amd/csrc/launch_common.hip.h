@@ -55,11 +55,13 @@ struct PerDeviceOnce {
     }
 };
 
-// diagnostic switches read once per process (tools/ only; the product never sets them)
-inline bool getenv_flag(const char *name) {
+// diagnostic switches (tools/ only; the product never sets them), read ONCE per process and call site: a getenv() walks
+// the whole environment, and three of them per launch were 0.3 - 0.5 us of the host side of a 3 us launch
+inline bool getenv_flag_now(const char *name) {
     const char *v = std::getenv(name);
     return v && v[0] && v[0] != '0';
 }
+#define getenv_flag(name) ([]() -> bool { static const bool v_ = getenv_flag_now(name); return v_; }())
 
 inline MMShape base_shape(int a, int w, int ob, int mode) {
     MMShape sh{};
