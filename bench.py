@@ -154,7 +154,14 @@ def cpu_baseline(M, K, N, w, A, X, budget_s):
             "sample": f"full {M}x{K}x{N} {w}-bit workload x {reps} reps ({dt:.1f} s, OpenMP C oracle)"}, ref
 
 
-def epoch_leg(Q, rank, world, device_index, dataset="ogbn-arxiv", bits=2, hidden=128, gin=False, full=True):
+def batch_summaries(outs):
+    """[n_local, 2] float64 on the outputs' device: (sum, element count) of every batch this rank ran."""
+    return torch.stack([torch.stack([o.double().sum(), torch.tensor(float(o.numel()), device=o.device, dtype=torch.float64)])
+                        for o in outs])
+
+
+def epoch_leg(Q, rank, world, device_index, dataset="ogbn-arxiv", bits=2, hidden=128, gin=False, full=True, psize=1500,
+              batch_size=20, only=None):
     """Epoch time (BASELINE.json configs 3/4/5): a synthetic graph of the dataset's size, 75 batches,
     sharded round-robin over the ranks. Per-batch launches (the reference's structure: six extension
     calls per batch), the same with the packed batches parked on the CPU and uploaded every iteration
@@ -164,8 +171,10 @@ def epoch_leg(Q, rank, world, device_index, dataset="ogbn-arxiv", bits=2, hidden
 
     base = ["--dataset", dataset, "--n-hidden", str(hidden), "--n-classes", "10", "--bit_width", str(bits),
             "--use_QGTC", "--gpu", str(device_index), "--quiet", "--n-epochs", "20"] + (["--run_GIN"] if gin else [])
-    graph = G.make_graph(dataset, 1500)
-    ids = D.shard_round_robin(1500 // 20, rank, world)
+    base += ["--psize", str(psize), "--batch-size", str(batch_size)]
+    n_batches = psize // batch_size
+    graph = G.make_graph(dataset, psize)
+    ids = D.shard_round_robin(n_batches, rank, world)
     res = {}
     legs = [("per_batch_reference_chain", []), ("batched_reference_chain", ["--batched"]),
             ("batched_correct_chain", ["--batched", "--chain", "correct"]),
@@ -175,6 +184,8 @@ def epoch_leg(Q, rank, world, device_index, dataset="ogbn-arxiv", bits=2, hidden
                      ("per_batch_graph_reference_chain", ["--graph"]),
                      ("per_batch_2_streams_reference_chain", ["--streams", "2"]),
                      ("per_batch_pack_on_the_fly_reference_chain", ["--pack-on-the-fly"])]   # cluster_gcn.py's structure
+    if only is not None:
+        legs = [l for l in legs if l[0] in only]
     for name, extra in legs:
         args = driver.build_parser().parse_args(base + extra)
         driver.run(args, Q=Q, batch_ids=ids, graph=graph)          # warm-up (allocator, attributes)
@@ -182,11 +193,9 @@ def epoch_leg(Q, rank, world, device_index, dataset="ogbn-arxiv", bits=2, hidden
         r = driver.run(args, Q=Q, batch_ids=ids, graph=graph)
         res[name + "_ms"] = round(D.max_over_ranks(r["avg_epoch_ms"], torch.device("cuda", device_index)), 4)
     if world > 1:   # the one exchange of the path: gather per-batch checksums (RCCL over xGMI)
-        outs = r["outs"]
-        local = torch.stack([torch.stack([o.double().sum(), torch.tensor(float(o.numel()), device=o.device,
-                                                                         dtype=torch.float64)]) for o in outs])
-        allsum = D.gather_batch_summaries(local, 1500 // 20, rank, world)
+        allsum = D.gather_batch_summaries(batch_summaries(r["outs"]), n_batches, rank, world)
         res["gathered_batches"] = int(allsum.size(0))
+        res["gathered_summaries"] = allsum.cpu().tolist()       # (sum, numel) per batch in global batch order, on every rank
     return res, graph
 
 
@@ -288,6 +297,16 @@ REF_ADJ = {16: (5.831, 16.323, 34.425), 32: (11.717, 32.027, 40.175), 64: (23.15
            256: (32.089, 44.151, 59.508), 512: (41.743, 49.687, 64.172), 1024: (37.954, 52.970, 66.490)}
 
 
+def identical_and_closed_form(Q, words, M, K, N, w):
+    """Per-point parity flag of the benchmark tables: the default engine's packed words equal the AND + popcount
+    kernels' AND decode to the closed form of the all-ones inputs (C = K everywhere, re-quantised: 2^w - 1 where
+    K > 2^w; 2_7c_QGTC_GEMM_INT8.py:30-41). Full-size comparison with the oracle: tests/test_gpu_fullsize.py."""
+    same = torch.equal(words["auto"], words["popcount"])
+    back = Q.bit2val(words["auto"], w, M, N, False, False)
+    want = (2 ** w - 1) if K > 2 ** w else (K & (2 ** w - 1))
+    return bool(same and bool((back == want).all().item()))
+
+
 def adj_size_table(Q, device):
     """The reference's adjacency-size study (5_9_adjmatrix_size.py): 1-bit, M = K in 1024/2048/4096,
     N = 16 .. 1024, all-ones inputs, 200 launches per point, best of 3."""
@@ -297,10 +316,13 @@ def adj_size_table(Q, device):
         for mi, mk in enumerate((1024, 2048, 4096)):
             _, _, ba, bx = make_workload(Q, mk, mk, nn, 1, device, seed=3, ones=True)
             row[f"M{mk}"] = {"ref_sm86": ref[mi]}
+            words = {}
             for eng, key in (("auto", "TOPS"), ("popcount", "TOPS_engine_popcount")):
                 with engine(Q, eng):
                     ms = best_of_3(Q, ba, bx, mk, mk, nn, 1)
+                    words[eng] = Q.bitMM2Bit(ba, bx, mk, mk, nn, 1, 1, 1)
                 row[f"M{mk}"][key] = round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2)
+            row[f"M{mk}"]["identical"] = identical_and_closed_form(Q, words, mk, mk, nn, 1)
         out[f"N{nn}"] = row
     return out
 
@@ -314,10 +336,13 @@ def micro_bench_table(Q, device):
         for wi, ww in enumerate((1, 2, 4, 8)):
             _, _, ba, bx = make_workload(Q, mk, mk, nn, ww, device, seed=3, ones=True)
             row[f"w{ww}"] = {"ref_sm86": ref[wi]}
+            words = {}
             for eng, key in (("auto", "TOPS"), ("popcount", "TOPS_engine_popcount")):
                 with engine(Q, eng):
                     ms = best_of_3(Q, ba, bx, mk, mk, nn, ww)
+                    words[eng] = Q.bitMM2Bit(ba, bx, mk, mk, nn, 1, ww, ww)
                 row[f"w{ww}"][key] = round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2)
+            row[f"w{ww}"]["identical"] = identical_and_closed_form(Q, words, mk, mk, nn, ww)
         out[f"{mk}x{mk}x{nn}"] = row
     return out
 

@@ -45,6 +45,9 @@ def gather_batch_summaries(local: torch.Tensor, n_batches: int, rank: int, world
     in global batch order. One all_gather on buffers padded to the largest shard."""
     if world == 1:
         return local
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # (two ranks sharing one GPU in the tests: RCCL refuses duplicate devices, gloo gathers host buffers)
+        return gather_batch_summaries(local.cpu(), n_batches, rank, world).to(local.device)
     d = local.size(1)
     per = (n_batches + world - 1) // world
     buf = torch.zeros((per, d), dtype=local.dtype, device=local.device)
@@ -59,6 +62,8 @@ def gather_batch_summaries(local: torch.Tensor, n_batches: int, rank: int, world
 def max_over_ranks(value: float, device) -> float:
     if not dist.is_initialized():
         return value
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

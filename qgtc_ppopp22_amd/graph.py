@@ -72,8 +72,9 @@ def locality_partition(src: np.ndarray, dst: np.ndarray, n_nodes: int, psize: in
     1. reverse Cuthill-McKee ordering of the symmetrised graph (bandwidth reduction: neighbours get close ranks),
        cut into psize equal runs;
     2. sweeps of size-capped label propagation: a node moves to the part holding most of its neighbours when that
-       part has room (cap = 1.05 x the mean size) and its own part is above half the mean size, most-gaining nodes
-       first; stops early when fewer than 0.1 % of the nodes still want to move.
+       part has room (cap = 1.05 x the mean size) and its own part stays above half the mean size (arrivals AND
+       departures are counted within the sweep), most-gaining nodes first; stops early when fewer than 0.1 % of the
+       nodes still want to move. No part ends up empty.
     On the ogbn-arxiv-sized SBM graph with shuffled node ids: 45 % of the edges inside their partition after 12
     sweeps (planted blocks: 89 %, contiguous id ranges: 0.07 %), ~7 s.
     Deterministic; O(E) per sweep with scipy.sparse."""
@@ -112,7 +113,16 @@ def locality_partition(src: np.ndarray, dst: np.ndarray, n_nodes: int, psize: in
         arrival = np.arange(tgt_sorted.size) - first      # 0, 1, 2.. within each target part
         ok = arrival < (cap - size[tgt_sorted])
         chosen = movers[o[ok]]
+        # departures are capped the same way (gain order within each source part): a part gives up nodes only while it
+        # stays above the floor, so no part can be emptied - or left far below half the mean - by one sweep
+        src_part = part[chosen]
+        o2 = np.argsort(src_part, kind="stable")
+        sp_sorted = src_part[o2]
+        first2 = np.searchsorted(sp_sorted, sp_sorted, side="left")
+        leaving = np.arange(sp_sorted.size) - first2
+        chosen = chosen[o2[leaving < (size[sp_sorted] - floor)]]
         part[chosen] = best[chosen]
+    assert np.bincount(part, minlength=psize).min() > 0, "locality_partition produced an empty part"
     return part
 
 

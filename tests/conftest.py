@@ -12,6 +12,12 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """tests/test_aa_two_ranks_one_gpu.py starts its rank processes before this process initialises the GPU: keep it
+    ahead of every other test whatever the collection order."""
+    items.sort(key=lambda it: 0 if "test_aa_two_ranks_one_gpu" in it.nodeid else 1)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (plain C via ctypes). Test infrastructure only."""

@@ -74,6 +74,9 @@ def test_extension_imports_and_keeps_the_reference_surface():
     import QGTC  # the reference's module name
 
     assert QGTC.bitMM2Bit is ext.bitMM2Bit
+    # the names BASELINE.json's north_star uses for the same operators (QGTC_conv.py's vocabulary): aliases, not copies
+    assert QGTC.bit_qnt is QGTC.val2bit and QGTC.mm_v1 is QGTC.bitMM2Bit and QGTC.mm_v2 is QGTC.bitMM2Int
+    assert ext.bit_qnt is ext.val2bit and ext.mm_v1 is ext.bitMM2Bit and ext.mm_v2 is ext.bitMM2Int
 
 
 def test_engine_env_default():

@@ -201,3 +201,53 @@ def test_layer_entry_routes_give_the_same_epoch(qgtc, gin):
     for extra in ([], ["--one-launch"]):
         got = driver.run(_args(base + extra), Q=qgtc)["outs"]
         assert len(got) == len(ref) and all(torch.equal(x, y) for x, y in zip(got, ref)), extra
+
+
+@pytest.mark.parametrize("gin", [False, True])
+def test_npz_graph_through_the_locality_partitioner_matches_the_oracle_chain(qgtc, oracle, tmp_path, gin):
+    """SURVEY 8 f4 end to end on the GPU: an edge list in the reference's `.npz` format (dataset.py:48-53) with shuffled
+    node ids -> graph.load_npz_graph -> graph.locality_partition (the METIS stand-in, partition_utils.py:11-18) ->
+    ClusterIter -> the grouped, layout-correct HIP epoch; every batch's packed operands and float output against the
+    oracle's chain on the same partition."""
+    from qgtc_ppopp22_amd import driver, graph as G
+
+    src_g = G.make_sbm_graph("t", 2400, 48, 7.0, 16, seed=11)
+    perm = np.random.default_rng(3).permutation(src_g.n_nodes)
+    path = str(tmp_path / "edges.npz")
+    np.savez(path, src_li=perm[src_g.src], dst_li=perm[src_g.dst])
+    psize, bs, bits, hidden = 48, 6, (4 if gin else 2), 64
+    argv = ["--dataset", path, "--dim", "16", "--psize", str(psize), "--batch-size", str(bs), "--n-hidden", str(hidden),
+            "--n-classes", "10", "--bit_width", str(bits), "--n-epochs", "1", "--use_QGTC", "--quiet", "--batched",
+            "--chain", "correct"] + (["--run_GIN"] if gin else [])
+    res = driver.run(driver.build_parser().parse_args(argv), Q=qgtc)
+    graph = G.load_npz_graph(path, 16, psize)              # deterministic: the same partition the driver built
+    assert G.edge_locality(graph) > 0.3                    # the partitioner found the planted blocks again
+    random.seed(2)
+    par = G.partition_list(graph, psize)
+    random.shuffle(par)
+    W = oracle_weights(oracle, 16, hidden, 10, bits)
+    assert len(res["outs"]) == psize // bs
+    for cid in range(psize // bs):
+        bi = oracle_batch_inputs(oracle, graph, par, cid, psize, bs, bits)
+        ct = res["iter"].cTensor_li[cid]
+        np.testing.assert_array_equal(to_np_u32(ct.bit_A), bi["bit_A"])
+        np.testing.assert_array_equal(to_np_u32(ct.bit_X), bi["bit_X"])
+        expect = oracle_chain(oracle, bi, W, bits, "correct", gin)[-1]
+        np.testing.assert_array_equal(res["outs"][cid].cpu().numpy(), expect, err_msg=f"batch {cid}")
+        assert res["outs"][cid].abs().sum().item() > 0
+
+
+def test_north_star_alias_names_run_the_same_operators(qgtc, oracle):
+    """BASELINE.json's names for the operator surface (bit_qnt / mm_v1 / mm_v2) called on the device."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    n, F, b = 150, 40, 2
+    A = (rng.random((n, n)) < 0.05).astype(np.float32)
+    X = rng.uniform(-1, 5, size=(n, F)).astype(np.float32)
+    bA = qgtc.bit_qnt(torch.from_numpy(A).cuda(), 1, False, False)
+    bX = qgtc.bit_qnt(torch.from_numpy(X).cuda(), b, True, False)
+    oA, oX = oracle.val2bit(A, 1), oracle.val2bit(X, b, True)
+    np.testing.assert_array_equal(to_np_u32(bA), oA)
+    np.testing.assert_array_equal(to_np_u32(qgtc.mm_v1(bA, bX, n, n, F, 1, b, b)), oracle.bitmm2bit(oA, oX, n, n, F, 1, b, b))
+    np.testing.assert_array_equal(qgtc.mm_v2(bA, bX, n, n, F, 1, b, True).cpu().numpy(), oracle.bitmm2int(oA, oX, n, n, F, 1, b, True))

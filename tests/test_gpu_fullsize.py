@@ -197,3 +197,39 @@ def test_mid_width_products_all_engines_and_checksum(qgtc, NW_, w):
             assert torch.equal(x, y), eng
     row = (qa.to(torch.float64) @ qx.to(torch.float64).sum(1)).to(torch.int64)
     assert torch.equal(ref[2].to(torch.int64).sum(1), row)
+
+
+# BASELINE.json configs[1] = the reference's whole micro-benchmark grid (2_7c_QGTC_GEMM_INT8.py:6-19): M = K in
+# {1024, 2048, 4096}, N in {16, 32, 64}, 1-bit adjacency x w-bit features, w = ob in {1, 2, 4, 8}. Every point selects
+# its own kernel instantiation and grid on the default engine (k_bitmm_fp4_one<NA,NW,MODE,RF,CF>: 16 x 32 tiles at
+# N <= 32, 32 x 32 at N = 64, 64 x 16 for more than four planes) - each is compared with the oracle at FULL size.
+MICRO_SHAPES = [(mk, nn) for nn in (16, 32, 64) for mk in (1024, 2048, 4096)]
+
+
+@pytest.mark.parametrize("w", [1, 2, 4, 8])
+@pytest.mark.parametrize("mk,nn", MICRO_SHAPES)
+@pytest.mark.parametrize("engine", ["auto", "popcount"])
+def test_micro_bench_shapes_equal_the_oracle(qgtc, oracle, engine, mk, nn, w):
+    """All nine 2_7c shapes x four widths, seeded random operands, `bitMM2Bit` words (what the benchmark launches) and
+    the float32 accumulators against the C oracle, on the default engine and on the AND + popcount kernels. Also the
+    benchmark's own all-ones inputs (2_7c:30-41) against their closed form through the same launch."""
+    import torch
+    qgtc.set_engine(engine)     # (the autouse fixture puts the default back)
+    g = torch.Generator(device="cpu").manual_seed(1000 * w + mk + nn)
+    qa = (torch.rand((mk, mk), generator=g) < 0.5).to(torch.float32)
+    qx = torch.randint(0, 2 ** w, (mk, nn), generator=g).to(torch.float32)
+    bit_A = qgtc.val2bit(qa.cuda(), 1, False, False)
+    bit_X = qgtc.val2bit(qx.cuda(), w, True, False)
+    A_o = oracle.val2bit(qa.numpy(), 1, False, False)
+    X_o = oracle.val2bit(qx.numpy(), w, True, False)
+    np.testing.assert_array_equal(to_np_u32(bit_A), A_o)
+    np.testing.assert_array_equal(to_np_u32(bit_X), X_o)
+    np.testing.assert_array_equal(to_np_u32(qgtc.bitMM2Bit(bit_A, bit_X, mk, mk, nn, 1, w, w)),
+                                  oracle.bitmm2bit(A_o, X_o, mk, mk, nn, 1, w, w))
+    np.testing.assert_array_equal(qgtc.bitMM2Int(bit_A, bit_X, mk, mk, nn, 1, w, True).cpu().numpy(),
+                                  oracle.bitmm2int(A_o, X_o, mk, mk, nn, 1, w, True))
+    # the benchmark's inputs: ones x ones -> C = K > 2^w everywhere -> every decoded element 2^w - 1
+    ones_A = qgtc.val2bit(torch.ones((mk, mk), device="cuda"), 1, False, False)
+    ones_X = qgtc.val2bit(torch.ones((mk, nn), device="cuda"), w, True, False)
+    back = qgtc.bit2val(qgtc.bitMM2Bit(ones_A, ones_X, mk, mk, nn, 1, w, w), w, mk, nn, False, False)
+    assert torch.equal(back, torch.full((mk, nn), 2 ** w - 1, device="cuda", dtype=back.dtype))

@@ -131,6 +131,7 @@ def test_npz_loader_and_locality_partitioner(tmp_path):
         parts = G.partition_list(h, 100)
         assert sorted(np.concatenate(parts).tolist()) == list(range(h.n_nodes))     # a partition of the node set
     assert np.bincount(loc.block_of, minlength=100).max() <= int(np.ceil(1.05 * loc.n_nodes / 100))
+    assert np.bincount(loc.block_of, minlength=100).min() >= loc.n_nodes // 200      # departures are capped: no part below half the mean
     assert G.edge_locality(con) < 0.05
     assert G.edge_locality(loc) > 0.4 and G.edge_locality(loc) > 10 * G.edge_locality(con)
     # deterministic
@@ -143,6 +144,21 @@ def test_npz_loader_and_locality_partitioner(tmp_path):
     np.savez(bad, src_li=np.array([0, -1]), dst_li=np.array([1, 2]))
     with pytest.raises(ValueError):
         G.load_npz_graph(bad, 4, 2)
+
+
+def test_locality_partitioner_never_empties_a_part():
+    """A star-heavy graph where every node of many parts would rather be in the hubs' parts: arrivals are capped by
+    the target's room and departures by the source's floor, so every part keeps at least half the mean size."""
+    from qgtc_ppopp22_amd import graph as G
+
+    rng = np.random.default_rng(7)
+    n, psize = 3000, 60
+    hubs = rng.integers(0, 50, size=12000)                 # all edges point into 50 hub nodes
+    src = rng.integers(0, n, size=12000)
+    part = G.locality_partition(src.astype(np.int64), hubs.astype(np.int64), n, psize)
+    sizes = np.bincount(part, minlength=psize)
+    assert sizes.min() >= n // (2 * psize) and sizes.max() <= int(np.ceil(1.05 * n / psize))
+    assert sizes.sum() == n
 
 
 def test_zerotile_row_is_what_parse_counter_computes():
