@@ -188,9 +188,21 @@ def epoch_leg(Q, rank, world, device_index, dataset="ogbn-arxiv", bits=2, hidden
         legs = [l for l in legs if l[0] in only]
     for name, extra in legs:
         args = driver.build_parser().parse_args(base + extra)
-        driver.run(args, Q=Q, batch_ids=ids, graph=graph)          # warm-up (allocator, attributes)
+        it = None
+        if driver.uses_planned_epoch(args):
+            # Grouped epochs are GPU-bound (a 20-epoch run is ~0.6 ms of kernels), so the chip's clock state decides the
+            # figure: the iterator is built ONCE, ahead of the clock as in main_qgtc.py:74-93, and the chip is kept busy
+            # between the warm-up run and the measured one (time_steps does the same for the headline)
+            it = driver.make_iter(args, Q, graph, ids)
+        r0 = driver.run(args, Q=Q, batch_ids=ids, graph=graph, it=it)          # warm-up (allocator, attributes)
+        if it is not None and "plan" in r0:
+            t_w = time.perf_counter()
+            while time.perf_counter() - t_w < CLOCK_WARMUP_S:
+                for _ in range(20):
+                    r0["plan"].run()
+                torch.cuda.synchronize()
         D.barrier()
-        r = driver.run(args, Q=Q, batch_ids=ids, graph=graph)
+        r = driver.run(args, Q=Q, batch_ids=ids, graph=graph, it=it)
         res[name + "_ms"] = round(D.max_over_ranks(r["avg_epoch_ms"], torch.device("cuda", device_index)), 4)
     if world > 1:   # the one exchange of the path: gather per-batch checksums (RCCL over xGMI)
         allsum = D.gather_batch_summaries(batch_summaries(r["outs"]), n_batches, rank, world)
@@ -210,11 +222,8 @@ def epoch_roofline(Q, graph, device_index, dataset, bits, hidden, gin):
 
     dev = torch.device("cuda", device_index)
     it = ClusterIter(dataset, graph, 1500, 20, bit_width=bits, run_GIN=gin, device=dev, qgtc=Q, with_rows_X=True)
-    t0 = time.perf_counter()
-    W = driver.pack_weights(Q, graph.feat.shape[1], hidden, 10, bits, dev)
-    plan = driver.BatchedEpoch(Q, it.cTensor_li, it.cluster_param_li, W, bits, "correct", gin)
+    data = it.epoch_data(Q)            # the data loader's share (per-batch table, adjacency bitmaps), ahead of the clock
     torch.cuda.synchronize()
-    host_ms = (time.perf_counter() - t0) * 1e3
 
     def ev(fn, reps=100):   # (a 20-epoch window is 0.6 ms, of which the queue's start-up is 5 - 10 %)
         for _ in range(3):
@@ -228,8 +237,21 @@ def epoch_roofline(Q, graph, device_index, dataset, bits, hidden, gin):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / reps
 
+    # every operator on its own: a six-launch plan whose outputs are all in the public layouts (the chained plan keeps T
+    # in the kernels' own formats between its launches - its stages cannot run alone)
+    W = driver.pack_weights(Q, graph.feat.shape[1], hidden, 10, bits, dev)
+    six = driver.PlannedEpoch(Q, data, it.cluster_param_li, W, bits, "correct", gin, fuse=False)
+    stage_us = [round(ev(lambda i=i: data.run_launch(i)), 2) for i in range(six.n_launches)]
+    torch.cuda.synchronize()
+    host = []
+    for _ in range(5):                  # what main_qgtc.py:96 puts inside its epoch clock besides the launches
+        t0 = time.perf_counter()
+        W = driver.pack_weights(Q, graph.feat.shape[1], hidden, 10, bits, dev)
+        plan = driver.PlannedEpoch(Q, data, it.cluster_param_li, W, bits, "correct", gin)
+        host.append((time.perf_counter() - t0) * 1e3)
+        torch.cuda.synchronize()
+    host_ms = min(host)
     epoch_us = ev(plan.run)
-    stage_us = [round(ev(g.run), 2) for g in plan.stages]
     F, H, C, b = graph.feat.shape[1], hidden, 10, bits
     digits = lambda p: (p + 1) // 2       # noqa: E731
     ops = [  # (K_is_n, K, N, a, w, out: "bits"|"f32") per operator of the layout-correct chain
@@ -244,22 +266,25 @@ def epoch_roofline(Q, graph, device_index, dataset, bits, hidden, gin):
             algo_bytes += a * n * K / 8 + w * K * N / 8 + (4 * n * N if out == "f32" else b * n * N / 8)
             mfma_ops += 2.0 * n * K * N * digits(a) * digits(w)
             eff_ops += 2.0 * n * K * N
-    occ = [round(g.occupied_fraction, 4) for g in plan.stages if g.zero_jump or g.occupied_fraction < 1.0]
+    occ = [round(data.occupied_fraction, 4)]
     floors = {"hbm_us": round(algo_bytes / (HBM_PEAK_GBS * 1e9) * 1e6, 2), "mfma_fp4_us": round(mfma_ops / (FP4_PEAK_TFLOPS * 1e12) * 1e6, 2),
               "launch_gaps_us": round(1.5 * (len(plan.launches) - 1), 1)}
-    chained = sum(1 for g in plan.launches if type(g).__name__ == "ChainedPair")
-    return {"kernel_us_per_epoch": round(epoch_us, 2), "kernel_us_per_operator_alone": stage_us, "calls_per_epoch": len(plan.launches),
-            "launches_per_epoch": len(plan.launches) if chained else len(plan.stages),
-            "launch_structure": (f"{len(plan.stages)} operators in {len(plan.launches)} launches: {chained} aggregation stages carry the next "
-                                 "layer's X.W stage (qgtc_gcn_chain_batched)") if chained else f"{len(plan.stages)} grouped launches",
-            "host_plan_build_and_weight_pack_ms": round(host_ms, 3),
+    chained = 6 - plan.n_launches
+    return {"kernel_us_per_epoch": round(epoch_us, 2), "kernel_us_per_operator_alone": stage_us, "calls_per_epoch": plan.n_launches,
+            "launches_per_epoch": plan.n_launches,
+            "launch_structure": (f"6 operators in {plan.n_launches} launches: {chained} aggregation stages carry the next "
+                                 "layer's X.W stage (qgtc_gcn_chain_batched)") if chained else "6 grouped launches",
+            "host_weight_pack_and_plan_bind_ms": round(host_ms, 4),
+            "host_note": "host time of the two calls main_qgtc.py:96 puts inside its clock besides the launches: one fill + one pack "
+                         "launch for the three weights, one allocation + ONE launch that fills every stage's descriptors on the device "
+                         "(round 2 built 6 x 75 descriptors on the host: 1.26 ms)",
             "algorithmic_bytes_per_epoch": int(algo_bytes), "effective_ops_per_epoch": eff_ops,
             "eff_TOPS": round(eff_ops / epoch_us / 1e6, 1), "floors": floors,
             "roofline": {"bound": "hbm", "achieved": round(algo_bytes / epoch_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(algo_bytes / epoch_us / 1e3 / HBM_PEAK_GBS, 4),
                          "frac_mfma": round(mfma_ops / epoch_us / 1e6 / FP4_PEAK_TFLOPS, 4),
                          "note": "a few thousand short workgroups per launch: bound by launch floors, dependent load chains and the epilogues' VALU work, see DESIGN.md section 6"},
-            "adjacency_tiles_occupied": occ[:1], "rocprof": "profiles/r02/summary_epoch%s.json" % ("_gin" if gin else "")}
+            "adjacency_tiles_occupied": occ[:1], "rocprof": "profiles/r03/summary_epoch%s.json" % ("_gin" if gin else "")}
 
 
 def zero_tile_rows(Q, graph_arxiv, device_index):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QGTC_ABI_VERSION 6
+#define QGTC_ABI_VERSION 7
 
 enum {
     QGTC_OK = 0,
@@ -60,6 +60,9 @@ enum {
 #define QGTC_CHAIN_DISCARD 0x40u    /* qgtc_gcn_chain_batched: the caller does not need stage_a's output itself */
 #define QGTC_CHAIN_CODES_IN 0x80u   /* qgtc_gcn_chain_batched / qgtc_bitmm_batched: the right operands were written by a launch with _CODES_OUT */
 #define QGTC_CHAIN_CODES_OUT 0x100u /* qgtc_gcn_chain_batched / qgtc_bitmm_batched (mode 1): the outputs are only read by a launch with _CODES_IN */
+#define QGTC_CHECK_DESCRIPTORS 0x200u /* grouped entry points: a one-workgroup kernel ahead of the product compares every DEVICE
+                                  descriptor with the stated max_M / max_K / max_N (and the chaining rules of the two-stage
+                                  entries) and records the first violation on the device; qgtc_last_batched_violation() reads it */
 
 int qgtc_abi_version(void);
 const char *qgtc_strerror(int code);
@@ -236,6 +239,83 @@ int qgtc_i8gemm(const int8_t *A, const int8_t *Bt, int M, int K, int N, float *C
                 void *stream);
 int qgtc_i8gemm_profile(const int8_t *A, const int8_t *Bt, int M, int K, int N, float *C,
                         size_t c_elems, int reps, float *elapsed_ms, void *stream);
+
+/* ---- Detecting (not just documenting) the grouped entries' preconditions ------------------------------------------
+ * The descriptors of qgtc_bitmm_batched / qgtc_gcn_layer_batched / qgtc_gcn_chain_batched live in device memory, so the
+ * host side cannot compare them with the stated maxima (from which the grid, the split-K plan and the choice between the
+ * float32 and int32 kernels are derived). With QGTC_CHECK_DESCRIPTORS in `flags` those entries first launch a
+ * one-workgroup kernel on `stream` that checks every descriptor: M <= max_M, K <= max_K, N <= max_N, all positive,
+ * non-NULL 16-byte aligned operands, and for the two-stage entries that stage 2 really reads stage 1's output. The
+ * product still runs (its results for an offending problem are unspecified, exactly as without the flag); the first
+ * violation is kept in a per-device record until it is read.
+ * qgtc_last_batched_violation(): waits for `stream`, returns QGTC_OK when no checked launch since the last call found a
+ * violation, else QGTC_EINVAL with *problem = index of the first offending descriptor and *field = one of QGTC_VIOL_*;
+ * the record is cleared. `problem` / `field` may be NULL. */
+enum { QGTC_VIOL_NONE = 0, QGTC_VIOL_M = 1, QGTC_VIOL_K = 2, QGTC_VIOL_N = 3, QGTC_VIOL_POINTER = 4, QGTC_VIOL_CHAINING = 5 };
+int qgtc_last_batched_violation(int *problem, int *field, void *stream);
+
+/* Which route qgtc_gcn_layer_batched takes for these arguments: 1 = both stages in ONE launch (the form that advances the
+ * arrival counters and needs `epoch`), 0 = two grouped launches (counters untouched), negative = -QGTC_E* for arguments
+ * the entry would reject. A caller that owns arrival counters advances its epoch only when this says 1. */
+int qgtc_gcn_layer_route(int count, int max_M, int max_K1, int max_K2, int max_N, int x_bits, int w_bits, int t_bits,
+                         int a_bits, int output_bit, int mode, unsigned flags);
+
+/* val2bit of several matrices in ONE launch (the three weight matrices an epoch packs inside its clock,
+ * main_qgtc.py:100-110: `QGTC.val2bit(W1.cuda(), w_bit, True, False)` x 3). `jobs` is a HOST array of at most
+ * QGTC_MAX_PACK_JOBS entries; each job is exactly one qgtc_val2bit call (same words, every padding word written). */
+#define QGTC_MAX_PACK_JOBS 8
+typedef struct qgtc_pack_job {
+    const float *x;      /* float32 [H, W] row-major, device */
+    uint32_t *out;       /* packed result, device */
+    uint64_t out_words;  /* capacity of `out` */
+    int32_t H, W, nbits, col_major, output_layer;
+    int32_t reserved;
+} qgtc_pack_job;
+int qgtc_val2bit_batched(const qgtc_pack_job *jobs, int n_jobs, void *stream);
+
+/* ---- Epoch plans: the descriptors of every grouped launch of an epoch, filled ON THE DEVICE by one kernel -------------
+ * The reference's epoch clock (main_qgtc.py:96-159) starts before the weights are packed and covers every per-batch
+ * output allocation and launch. A grouped epoch needs, per stage, one qgtc_problem per cluster batch whose pointers chain
+ * the stages' outputs; filling those on the host (75 descriptors x 6 stages, six uploads) cost more than the epoch's
+ * kernels. Here the data loader's part - one qgtc_batch per cluster batch: the packed adjacency and features it built
+ * (sampler.py:92-105) and the adjacency's occupancy bitmap - is made once beside the packing, and inside the clock ONE
+ * launch turns `stages` (what each of the epoch's operators multiplies, main_qgtc.py:131-154) into device descriptors:
+ * every stage's outputs are carved out of one pool, in batch order, each 16-byte aligned; stage s's descriptors are
+ * descs[s * count .. s * count + count - 1].
+ *   left / right: where an operand comes from - QGTC_SRC_A / _X / _XR of the batch, QGTC_SRC_WEIGHT + k = weights[k] (shared
+ *   by all batches), QGTC_SRC_STAGE + j = the output of stage j < s of the same batch.
+ *   M is the batch's node count n; K is `K`, or n when K == QGTC_DIM_NODES; N is `N`.
+ *   mode / ob / pad128 as qgtc_bitmm_batched / qgtc_bitmm2int; use_occ: the descriptors carry the batch's bitmap.
+ * qgtc_epoch_pool_layout (host only, no device work) gives the pool size in 32-bit words for the same arguments and,
+ * optionally, every output's offset (offsets[s * count + b], in words) - the fill kernel uses the same rule. */
+enum { QGTC_SRC_A = 0, QGTC_SRC_X = 1, QGTC_SRC_XR = 2, QGTC_SRC_WEIGHT = 16, QGTC_SRC_STAGE = 32 };
+#define QGTC_DIM_NODES (-1)
+#define QGTC_MAX_STAGES 8
+#define QGTC_MAX_WEIGHTS 8
+typedef struct qgtc_operand {
+    const uint32_t *ptr;
+    uint64_t words;
+} qgtc_operand;
+typedef struct qgtc_batch {
+    qgtc_operand A;      /* adjacency, rows layout [n, n] */
+    qgtc_operand X;      /* features, cols layout [n, F] (a right operand: sampler.py:99) */
+    qgtc_operand XR;     /* features, rows layout [n, F] (a left operand), or {NULL, 0} */
+    const uint64_t *occ; /* occupancy bitmap of A (qgtc_tile_occupancy) or NULL */
+    int32_t n;           /* nodes of the batch */
+    int32_t occ_words;   /* 64-bit words per row tile of `occ` */
+} qgtc_batch;
+typedef struct qgtc_stage {
+    int32_t left, right; /* QGTC_SRC_* */
+    int32_t K, N;        /* K: a number or QGTC_DIM_NODES */
+    int32_t bit1, bit2, ob;
+    int32_t mode;        /* 0 rows-layout bits, 1 cols-layout bits, 2 float32 */
+    int32_t pad128;      /* mode 2: the right operand's planes have PAD128(N) lines (else PAD8(N)) */
+    int32_t use_occ;     /* carry the batch's occupancy bitmap (left must be QGTC_SRC_A) */
+} qgtc_stage;
+size_t qgtc_epoch_pool_layout(const int32_t *nodes, int count, const qgtc_stage *stages, int n_stages, uint64_t *offsets);
+int qgtc_epoch_plan_fill(const qgtc_batch *batches, int count, const qgtc_stage *stages, int n_stages,
+                         const qgtc_operand *weights, int n_weights, void *pool, size_t pool_words,
+                         qgtc_problem *descs, void *stream);
 
 #ifdef __cplusplus
 }

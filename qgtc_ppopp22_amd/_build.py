@@ -1,6 +1,6 @@
 """In-tree build of the native pieces (called by __graft_entry__.build()).
 
-  libqgtc_hip.so                    hipcc --offload-arch=gfx950  csrc/qgtc_hip.hip + qgtc_mfma.hip + qgtc_fp4.hip + qgtc_wide.hip (four translation
+  libqgtc_hip.so                    hipcc --offload-arch=gfx950  csrc/qgtc_hip.hip + qgtc_mfma.hip + qgtc_fp4.hip + qgtc_wide.hip + qgtc_epoch.hip (five translation
                                     units compiled in parallel; they include csrc/*.hip.h, the kernels)
   QGTC.cpython-*.so                 g++                          csrc/qgtc_torch.cpp (pybind11 binding)
 
@@ -37,7 +37,7 @@ def _run(cmd: list[str]) -> None:
     subprocess.run(cmd, check=True)
 
 
-HIP_UNITS = ("qgtc_hip.hip", "qgtc_mfma.hip", "qgtc_fp4.hip", "qgtc_wide.hip")   # translation units of libqgtc_hip.so, compiled in parallel
+HIP_UNITS = ("qgtc_hip.hip", "qgtc_mfma.hip", "qgtc_fp4.hip", "qgtc_wide.hip", "qgtc_epoch.hip")   # translation units of libqgtc_hip.so, compiled in parallel
 
 
 def build_hip(force: bool = False) -> str:

@@ -1,0 +1,169 @@
+// epoch_plan.hip.h — part of libqgtc_hip.so (qgtc_epoch.hip).
+// What an epoch needs besides its products, done ON THE DEVICE so that the host's share of the reference's epoch clock
+// (main_qgtc.py:96-159: weights packed, outputs allocated and every operator launched inside it) is a handful of calls:
+//   * k_val2bit_jobs      - val2bit of several small matrices in one launch (the three weight matrices, main_qgtc.py:100-110)
+//   * k_epoch_plan_fill   - the qgtc_problem descriptors of every stage of a grouped epoch from the data loader's
+//                           per-batch table (qgtc_batch) and the stage recipes (qgtc_stage): outputs carved out of one pool
+//   * k_check_descriptors - QGTC_CHECK_DESCRIPTORS: the grouped entries' preconditions, checked where the descriptors live
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// val2bit jobs: one thread per packed WORD of a job's output (all planes of it). Weights are a few thousand words; the
+// point is one launch instead of three or four, not bandwidth. Same words as k_val2bit_rows / k_val2bit_cols: element i of
+// a line at word i >> 5, bit 31 - (i & 31); lines and words past the matrix are zero (reference kernel.h:75-106, :204-242).
+// ------------------------------------------------------------------------------------------
+struct PackJobs {
+    qgtc_pack_job job[QGTC_MAX_PACK_JOBS];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void k_val2bit_jobs(PackJobs jobs) {
+    const qgtc_pack_job j = jobs.job[blockIdx.y];
+    const int H = j.H, W = j.W, nbits = j.nbits;
+    // lines x words of one plane; `along` = the matrix dimension packed into a line's bits
+    const int lines = j.col_major ? (j.output_layer ? pad8(W) : pad128(W)) : pad8(H);
+    const int line_words = step128(j.col_major ? H : W) * 4;
+    const size_t plane = static_cast<size_t>(lines) * line_words;
+    const float ub = __builtin_ldexpf(1.0f, nbits), ubm1 = ub - 1.0f;
+    for (size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < plane; t += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        // cols layout: consecutive threads take consecutive COLUMNS (lines) of one word index - coalesced reads of x rows
+        const int line = j.col_major ? static_cast<int>(t % lines) : static_cast<int>(t / line_words);
+        const int wi = j.col_major ? static_cast<int>(t / lines) : static_cast<int>(t % line_words);
+        uint32_t q[32];
+#pragma unroll
+        for (int e = 0; e < 32; e++) {
+            const int pos = wi * 32 + e;
+            const int r = j.col_major ? pos : line, c = j.col_major ? line : pos;
+            q[e] = (r < H && c < W) ? quant1(j.x[static_cast<size_t>(r) * W + c], ub, ubm1) : 0u;
+        }
+        for (int p = 0; p < nbits; p++) {
+            uint32_t word = 0u;
+#pragma unroll
+            for (int e = 0; e < 32; e++) word |= ((q[e] >> p) & 1u) << (31 - e);
+            j.out[p * plane + static_cast<size_t>(line) * line_words + wi] = word;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Epoch plan. The pool rule shared with the host (qgtc_epoch_pool_layout): outputs in (stage, batch) order, each a
+// multiple of four words (16-byte aligned views).
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline unsigned long long stage_out_words(const qgtc_stage &st, int n) {
+    if (st.mode == 2) return (static_cast<unsigned long long>(n) * st.N + 3ull) & ~3ull;
+    if (st.mode == 1) return static_cast<unsigned long long>(st.ob) * step128(n) * 4ull * pad128(st.N);
+    return static_cast<unsigned long long>(st.ob) * pad8(n) * step128(st.N) * 4ull;
+}
+
+struct PlanArgs {
+    qgtc_stage stage[QGTC_MAX_STAGES];
+    qgtc_operand weight[QGTC_MAX_WEIGHTS];
+    int n_stages, n_weights, count;
+};
+
+__global__ __launch_bounds__(1024) void k_epoch_plan_fill(const qgtc_batch *__restrict__ batches, PlanArgs pa, uint32_t *__restrict__ pool,
+                                                          unsigned long long pool_words, qgtc_problem *__restrict__ descs, int *__restrict__ record) {
+    __shared__ unsigned long long scan[1024];
+    __shared__ unsigned long long carry;
+    const int tid = threadIdx.x, count = pa.count;
+    if (tid == 0) carry = 0ull;
+    __syncthreads();
+    for (int s = 0; s < pa.n_stages; s++) {
+        const qgtc_stage st = pa.stage[s];
+        for (int b0 = 0; b0 < count; b0 += 1024) {
+            const int b = b0 + tid;
+            qgtc_batch bt{};
+            unsigned long long words = 0ull;
+            if (b < count) {
+                bt = batches[b];
+                words = stage_out_words(st, bt.n);
+            }
+            scan[tid] = words;
+            __syncthreads();
+            for (int o = 1; o < 1024; o <<= 1) {   // inclusive scan
+                const unsigned long long v = tid >= o ? scan[tid - o] : 0ull;
+                __syncthreads();
+                scan[tid] += v;
+                __syncthreads();
+            }
+            unsigned long long off = carry + scan[tid] - words;
+            if (b < count) {
+                bool fits = true;
+                if (off + words > pool_words) {   // a pool smaller than qgtc_epoch_pool_layout says: recorded, and no pointer leaves the pool
+                    atomicMin(record, b * 8 + QGTC_VIOL_POINTER);
+                    fits = words <= pool_words;
+                    off = fits ? pool_words - words : 0ull;
+                }
+                auto operand = [&](int src, const uint32_t *&ptr, unsigned long long &w) {
+                    if (src >= QGTC_SRC_STAGE) {   // the output of an earlier stage of the SAME batch: this thread wrote that descriptor
+                        const int j = src - QGTC_SRC_STAGE;
+                        ptr = static_cast<const uint32_t *>(descs[static_cast<size_t>(j) * count + b].out);
+                        w = stage_out_words(pa.stage[j], bt.n);
+                    } else if (src >= QGTC_SRC_WEIGHT) {
+                        ptr = pa.weight[src - QGTC_SRC_WEIGHT].ptr;
+                        w = pa.weight[src - QGTC_SRC_WEIGHT].words;
+                    } else {
+                        const qgtc_operand o = src == QGTC_SRC_A ? bt.A : (src == QGTC_SRC_X ? bt.X : bt.XR);
+                        ptr = o.ptr;
+                        w = o.words;
+                    }
+                };
+                qgtc_problem pr{};
+                unsigned long long xw = 0ull, ww = 0ull;
+                operand(st.left, pr.X, xw);
+                operand(st.right, pr.W, ww);
+                pr.x_words = xw;
+                pr.w_words = ww;
+                pr.out = pool + off;
+                pr.M = fits ? bt.n : 0;
+                pr.K = st.K == QGTC_DIM_NODES ? bt.n : st.K;
+                pr.N = st.N;
+                pr.w_lines = (st.mode == 2 && !st.pad128) ? pad8(st.N) : pad128(st.N);
+                const bool occ = st.use_occ && bt.occ != nullptr;
+                pr.occ = occ ? bt.occ : nullptr;
+                pr.occ_words = occ ? bt.occ_words : 0;
+                descs[static_cast<size_t>(s) * count + b] = pr;
+            }
+            __syncthreads();
+            if (tid == 1023) carry += scan[1023];
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// QGTC_CHECK_DESCRIPTORS. kind 0: one stage; 1: layer (stage 2's W is stage 1's output); 2: chain (stage 2's X is stage
+// 1's output, K2 = N1). The first violation (lowest problem index, then lowest field code) wins: record = problem * 8 +
+// field, kept with atomicMin (INT_MAX = none).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_check_descriptors(const qgtc_problem *__restrict__ p1, const qgtc_problem *__restrict__ p2, int count,
+                                                           int max_M, int max_K1, int max_N1, int max_K2, int max_N2, int kind,
+                                                           int *__restrict__ record) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        int field = QGTC_VIOL_NONE;
+        auto one = [&](const qgtc_problem &p, int mk, int mn) {
+            if (field) return;
+            if (p.M <= 0 || p.M > max_M) field = QGTC_VIOL_M;
+            else if (p.K <= 0 || p.K > mk) field = QGTC_VIOL_K;
+            else if (p.N <= 0 || p.N > mn) field = QGTC_VIOL_N;
+            else if (!p.X || !p.W || !p.out || (reinterpret_cast<uintptr_t>(p.X) & 15u) || (reinterpret_cast<uintptr_t>(p.W) & 15u) ||
+                     p.x_words >= (1ull << 30) || p.w_words >= (1ull << 30))
+                field = QGTC_VIOL_POINTER;
+        };
+        const qgtc_problem a = p1[i];
+        one(a, max_K1, max_N1);
+        if (p2) {
+            const qgtc_problem b = p2[i];
+            one(b, max_K2, max_N2);
+            if (!field) {
+                if (kind == 1 && (b.W != static_cast<const uint32_t *>(a.out) || a.M != b.M || a.N != b.N)) field = QGTC_VIOL_CHAINING;
+                if (kind == 2 && (b.X != static_cast<const uint32_t *>(a.out) || a.M != b.M || a.N != b.K)) field = QGTC_VIOL_CHAINING;
+            }
+        }
+        if (field) atomicMin(record, i * 8 + field);
+    }
+}
+
+}  // namespace

@@ -21,6 +21,9 @@ int qgtc_launch_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count,
 
 // defined in qgtc_wide.hip
 int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st);
+// defined in qgtc_epoch.hip: QGTC_CHECK_DESCRIPTORS (kind 0 one stage / 1 layer / 2 chain; p2 may be NULL)
+int qgtc_launch_check_descriptors(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int max_K1, int max_N1,
+                                  int max_K2, int max_N2, int kind, hipStream_t st);
 
 // fused GNN layer (bitmm_layer.hip.h): defined in qgtc_mfma.hip (wide layers) and qgtc_fp4.hip (narrow layers)
 struct LayerArgs {

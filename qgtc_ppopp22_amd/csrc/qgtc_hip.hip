@@ -271,6 +271,11 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
     if (mode != 2 && !bits_ok(output_bit)) return QGTC_EINVAL;
     if (count > 65535) return QGTC_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (flags & QGTC_CHECK_DESCRIPTORS) {
+        const int crc = qgtc_launch_check_descriptors(problems, nullptr, count, max_M, max_K, max_N, 0, 0, 0, st);
+        if (crc != QGTC_OK) return crc;
+        flags &= ~QGTC_CHECK_DESCRIPTORS;
+    }
     // K is per problem; the split-K factor and chunk size are chosen for the longest K. Any
     // choice is correct; this only affects speed.
     const int k_hint = max_K;
@@ -302,27 +307,47 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
     return dispatch_batched<true, false>(problems, count, max_M, max_N, k_hint, bit1, bit2, ob_, mode, st);
 }
 
+// 1: the narrow one-launch form (one wave per 32 x 32 tile), 2: the wide one (128 x 128 tiles), 0: two grouped launches
+static int layer_route(int count, int max_M, int max_K1, int max_K2, int max_N, int x_bits, int w_bits, int t_bits, int a_bits,
+                       int output_bit, int mode, unsigned flags) {
+    if (count <= 0 || count > 65535) return -QGTC_EINVAL;
+    if (max_M <= 0 || max_K1 <= 0 || max_K2 <= 0 || max_N <= 0) return -QGTC_EINVAL;
+    if (!bits_ok(x_bits) || !bits_ok(w_bits) || !bits_ok(t_bits) || !bits_ok(a_bits)) return -QGTC_EINVAL;
+    if (mode != 0 && mode != 2) return -QGTC_EINVAL;
+    if (mode == 0 && !bits_ok(output_bit)) return -QGTC_EINVAL;
+    // Default: the two grouped launches (measured faster, bitmm_layer.hip.h). The one-launch forms run on the matrix
+    // cores: they need QGTC_LAYER_ONE_LAUNCH and QGTC_ENGINE_AUTO / _MFMA and plane counts inside their range.
+    const bool want = (flags & QGTC_LAYER_ONE_LAUNCH) && (flags & (QGTC_ENGINE_AUTO | QGTC_ENGINE_MFMA)) != 0u;
+    if (want && max_N <= 64 && fp4_wave_ok(max_K1, max_N, x_bits, w_bits) && fp4_wave_ok(max_K2, max_N, a_bits, t_bits) &&
+        std::max(x_bits, a_bits) <= 4 && std::max(w_bits, t_bits) <= 8)
+        return 1;
+    if (want && max_N > 64 && max_M >= 128 && mfma_ok(x_bits, w_bits) && mfma_ok(a_bits, t_bits)) return 2;
+    return 0;
+}
+
+int qgtc_gcn_layer_route(int count, int max_M, int max_K1, int max_K2, int max_N, int x_bits, int w_bits, int t_bits,
+                         int a_bits, int output_bit, int mode, unsigned flags) {
+    const int r = layer_route(count, max_M, max_K1, max_K2, max_N, x_bits, w_bits, t_bits, a_bits, output_bit, mode, flags);
+    return r < 0 ? r : (r != 0);
+}
+
 int qgtc_gcn_layer_batched(const qgtc_problem *stage1, const qgtc_problem *stage2, int count, int max_M, int max_K1,
                            int max_K2, int max_N, int x_bits, int w_bits, int t_bits, int a_bits, int output_bit,
                            int mode, uint32_t *arrival, uint32_t epoch, unsigned flags, void *stream) {
-    if (!stage1 || !stage2 || count <= 0 || count > 65535) return QGTC_EINVAL;
-    if (max_M <= 0 || max_K1 <= 0 || max_K2 <= 0 || max_N <= 0) return QGTC_EINVAL;
-    const bool one_launch = (flags & QGTC_LAYER_ONE_LAUNCH) != 0u;
-    if (one_launch && (!arrival || epoch == 0u)) return QGTC_EINVAL;
-    if (!bits_ok(x_bits) || !bits_ok(w_bits) || !bits_ok(t_bits) || !bits_ok(a_bits)) return QGTC_EINVAL;
-    if (mode != 0 && mode != 2) return QGTC_EINVAL;
-    if (mode == 0 && !bits_ok(output_bit)) return QGTC_EINVAL;
+    if (!stage1 || !stage2) return QGTC_EINVAL;
+    const int route = layer_route(count, max_M, max_K1, max_K2, max_N, x_bits, w_bits, t_bits, a_bits, output_bit, mode, flags);
+    if (route < 0) return -route;
+    if (route != 0 && (!arrival || epoch == 0u)) return QGTC_EINVAL;   // (the one-launch forms own arrival counters)
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (flags & QGTC_CHECK_DESCRIPTORS) {
+        const int crc = qgtc_launch_check_descriptors(stage1, stage2, count, max_M, max_K1, max_N, max_K2, max_N, 1, st);
+        if (crc != QGTC_OK) return crc;
+        flags &= ~QGTC_CHECK_DESCRIPTORS;
+    }
     const LayerArgs la{stage1, stage2, arrival, count, max_M, max_K1, max_K2, max_N, x_bits, w_bits, t_bits,
                        a_bits, output_bit, mode, epoch, !(flags & QGTC_NO_ZERO_SKIP)};
-    // Default: the two grouped launches (measured faster, bitmm_layer.hip.h). The one-launch forms run on the matrix
-    // cores: they need QGTC_LAYER_ONE_LAUNCH and QGTC_ENGINE_AUTO / _MFMA and plane counts inside their range.
-    const bool want = one_launch && (flags & (QGTC_ENGINE_AUTO | QGTC_ENGINE_MFMA)) != 0u;
-    if (want && max_N <= 64 && fp4_wave_ok(max_K1, max_N, x_bits, w_bits) && fp4_wave_ok(max_K2, max_N, a_bits, t_bits) &&
-        std::max(x_bits, a_bits) <= 4 && std::max(w_bits, t_bits) <= 8)
-        return qgtc_launch_layer_wave(la, st);
-    if (want && max_N > 64 && max_M >= 128 && mfma_ok(x_bits, w_bits) && mfma_ok(a_bits, t_bits))
-        return qgtc_launch_layer_mfma(la, st);
+    if (route == 1) return qgtc_launch_layer_wave(la, st);
+    if (route == 2) return qgtc_launch_layer_mfma(la, st);
     const unsigned f2 = flags & ~QGTC_LAYER_ONE_LAUNCH;
     int rc = qgtc_bitmm_batched(stage1, count, max_M, max_K1, max_N, x_bits, w_bits, t_bits, 1, f2 & ~QGTC_ZERO_JUMP, stream);
     if (rc != QGTC_OK) return rc;
@@ -337,6 +362,11 @@ int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stag
     if (!bits_ok(a_bits) || !bits_ok(t_bits) || !bits_ok(act_bits) || !bits_ok(w_bits)) return QGTC_EINVAL;
     if (out_mode != 1 && out_mode != 2) return QGTC_EINVAL;
     if (out_mode == 1 && !bits_ok(out_bits)) return QGTC_EINVAL;
+    if (flags & QGTC_CHECK_DESCRIPTORS) {
+        const int crc = qgtc_launch_check_descriptors(stage_a, stage_xw, count, max_M, max_K, max_N1, max_N1, max_N2, 2, static_cast<hipStream_t>(stream));
+        if (crc != QGTC_OK) return crc;
+        flags &= ~QGTC_CHECK_DESCRIPTORS;
+    }
     // one launch on the matrix cores where the shapes and plane counts allow it (bitmm_fp4_chain.hip.h), else the two
     // grouped launches it stands for
     const bool codes = (flags & (QGTC_CHAIN_CODES_IN | QGTC_CHAIN_CODES_OUT)) != 0u;

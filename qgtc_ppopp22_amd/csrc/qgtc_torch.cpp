@@ -17,6 +17,7 @@
 #include <c10/hip/HIPStream.h>
 
 #include <array>
+#include <pybind11/stl.h>
 #include <atomic>
 #include <cstdio>
 #include <memory>
@@ -598,19 +599,31 @@ struct FusedLayer {
 
     void run() {
         c10::DeviceGuard guard(s1->descs.device());
-        epoch++;
-        if (epoch == 0u) {   // 2^32 launches: start the counters over
+        const int max_M = std::max(s1->max_M, s2->max_M), max_N = std::max(s1->max_N, s2->max_N);
+        const unsigned flags = mm_flags() | (s2->jump_asked ? QGTC_ZERO_JUMP : 0u) | (one_launch ? QGTC_LAYER_ONE_LAUNCH : 0u);
+        // The arrival counters advance only when the ONE-LAUNCH kernel runs - and whether it does is re-decided on every
+        // call from the engine switch (a run under set_engine("popcount") takes the two grouped launches and leaves the
+        // counters alone): `epoch` follows the route the library reports, never the call count.
+        const int route = qgtc_gcn_layer_route(s1->count, max_M, s1->max_K, s2->max_K, max_N, s1->bit1, s1->bit2, s1->ob, s2->bit1,
+                                               s2->ob, s2->mode, flags);
+        TORCH_CHECK(route >= 0, "QGTC.FusedLayer.run: ", qgtc_strerror(-route));
+        if (route == 1 && epoch == 0xffffffffu) {   // 2^32 - 1 one-launch runs: start the counters over
             arrival.zero_();
-            epoch = 1;
+            epoch = 0;
         }
-        check_rc(qgtc_gcn_layer_batched(reinterpret_cast<const qgtc_problem *>(s1->descs.data_ptr()),
-                                        reinterpret_cast<const qgtc_problem *>(s2->descs.data_ptr()), s1->count,
-                                        std::max(s1->max_M, s2->max_M), s1->max_K, s2->max_K, std::max(s1->max_N, s2->max_N),
-                                        s1->bit1, s1->bit2, s1->ob, s2->bit1, s2->ob, s2->mode,
-                                        reinterpret_cast<uint32_t *>(arrival.data_ptr<int32_t>()), epoch,
-                                        mm_flags() | (s2->jump_asked ? QGTC_ZERO_JUMP : 0u) | (one_launch ? QGTC_LAYER_ONE_LAUNCH : 0u),
-                                        current_stream(arrival)),
-                 "FusedLayer.run");
+        const int rc = qgtc_gcn_layer_batched(reinterpret_cast<const qgtc_problem *>(s1->descs.data_ptr()),
+                                              reinterpret_cast<const qgtc_problem *>(s2->descs.data_ptr()), s1->count,
+                                              max_M, s1->max_K, s2->max_K, max_N,
+                                              s1->bit1, s1->bit2, s1->ob, s2->bit1, s2->ob, s2->mode,
+                                              reinterpret_cast<uint32_t *>(arrival.data_ptr<int32_t>()), route == 1 ? epoch + 1u : 1u,
+                                              flags, current_stream(arrival));
+        if (rc != QGTC_OK) {   // whatever was or was not launched: counters and epoch start over together
+            arrival.zero_();
+            epoch = 0;
+        } else if (route == 1) {
+            epoch++;
+        }
+        check_rc(rc, "FusedLayer.run");
     }
 };
 
@@ -663,6 +676,13 @@ torch::Tensor gcn_layer(torch::Tensor bit_A, torch::Tensor bit_X, torch::Tensor 
     TORCH_CHECK(bit_A.numel() < (1LL << 30) && bit_X.numel() < (1LL << 30) && bit_W.numel() < (1LL << 30), "packed operand too large (>= 4 GiB)");
     const auto dev = bit_A.device();
     c10::DeviceGuard guard(dev);
+    if (!one_launch) {
+        // One subgraph, two products: the tuned single-problem kernels, two fully asynchronous launches, no descriptors in
+        // device memory, no host synchronisation (word for word what the grouped entry computes for count = 1)
+        torch::Tensor T1 = mm2bit_impl(bit_X, bit_W, n, f_in, f_out, act_bit, w_bit, act_bit, true, "gcn_layer");
+        if (output) return bitMM2Int(bit_A, T1, n, n, f_out, a_bit, act_bit, true);
+        return mm2bit_impl(bit_A, T1, n, n, f_out, a_bit, act_bit, act_bit, false, "gcn_layer");
+    }
     const auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(dev);
     torch::Tensor T = torch::empty({static_cast<int64_t>(act_bit) * S128(n) * 4, P128(f_out)}, i32);   // QGTC_device.cu:456
     torch::Tensor out = output ? torch::empty({n, f_out}, torch::TensorOptions().dtype(torch::kFloat32).device(dev))
@@ -672,9 +692,9 @@ torch::Tensor gcn_layer(torch::Tensor bit_A, torch::Tensor bit_X, torch::Tensor 
                         n, f_in, f_out, P128(f_out), 0, nullptr};
     h[1] = qgtc_problem{words(bit_A), words(T), out.data_ptr(), static_cast<uint64_t>(bit_A.numel()), static_cast<uint64_t>(T.numel()),
                         n, n, f_out, P128(f_out), 0, nullptr};
-    auto host = torch::empty({static_cast<int64_t>(2 * sizeof(qgtc_problem))}, torch::TensorOptions().dtype(torch::kUInt8));
+    auto host = torch::empty({static_cast<int64_t>(2 * sizeof(qgtc_problem))}, torch::TensorOptions().dtype(torch::kUInt8).pinned_memory(true));
     std::memcpy(host.data_ptr(), h, sizeof(h));
-    torch::Tensor descs = host.to(dev);
+    torch::Tensor descs = host.to(dev, /*non_blocking=*/true);
     torch::Tensor arrival = torch::zeros({QGTC_ARRIVAL_STRIDE}, i32);
     const qgtc_problem *dp = reinterpret_cast<const qgtc_problem *>(descs.data_ptr());
     check_rc(qgtc_gcn_layer_batched(dp, dp + 1, 1, n, f_in, n, f_out, act_bit, w_bit, act_bit, a_bit, act_bit, output ? 2 : 0,
@@ -683,6 +703,220 @@ torch::Tensor gcn_layer(torch::Tensor bit_A, torch::Tensor bit_X, torch::Tensor 
              "gcn_layer");
     return out;   // (T, descs and arrival go back to the stream-ordered allocator: reuse happens behind this launch)
 }
+
+
+// val2bit of up to QGTC_MAX_PACK_JOBS matrices in ONE launch (qgtc_val2bit_batched): what an epoch does to its three weight
+// matrices inside the clock (main_qgtc.py:100-110). Every output is exactly val2bit(inputs[i], nbits, col_major[i], output_layer[i]).
+std::vector<torch::Tensor> val2bit_many(std::vector<torch::Tensor> inputs, int nbits, std::vector<bool> col_major,
+                                        std::vector<bool> output_layer) {
+    const int n = static_cast<int>(inputs.size());
+    TORCH_CHECK(n >= 1 && n <= QGTC_MAX_PACK_JOBS, "val2bit_many takes 1..", QGTC_MAX_PACK_JOBS, " matrices");
+    TORCH_CHECK(static_cast<int>(col_major.size()) == n && static_cast<int>(output_layer.size()) == n, "one col_major / output_layer flag per matrix");
+    const auto dev = inputs[0].device();
+    c10::DeviceGuard guard(dev);
+    const auto opts = torch::TensorOptions().dtype(torch::kInt32).device(dev);
+    qgtc_pack_job jobs[QGTC_MAX_PACK_JOBS];
+    std::vector<torch::Tensor> outs;
+    for (int i = 0; i < n; i++) {
+        const torch::Tensor &x = inputs[i];
+        CHECK_INPUT(x);
+        TORCH_CHECK(x.scalar_type() == torch::kFloat32 && x.dim() == 2 && x.device() == dev, "inputs must be 2-D float32 tensors on one device");
+        const int H = x.size(0), W = x.size(1);
+        torch::Tensor out = col_major[i] ? torch::empty({static_cast<int64_t>(nbits) * S128(H) * 4, output_layer[i] ? P8(W) : P128(W)}, opts)   // QGTC_device.cu:83,97
+                                         : torch::empty({static_cast<int64_t>(nbits) * P8(H), S128(W) * 4}, opts);                                // QGTC_device.cu:115
+        jobs[i] = qgtc_pack_job{x.data_ptr<float>(), words_mut(out), static_cast<uint64_t>(out.numel()), H, W, nbits, col_major[i] ? 1 : 0,
+                                output_layer[i] ? 1 : 0, 0};
+        outs.push_back(out);
+    }
+    check_rc(qgtc_val2bit_batched(jobs, n, current_stream(inputs[0])), "val2bit_many");
+    return outs;
+}
+
+// ---------------------------------------------------------------------------------------------
+// EpochPlan: a grouped epoch whose descriptors are filled ON THE DEVICE (qgtc_epoch_plan_fill).
+//   * the constructor is the DATA LOADER's part (beside ClusterIter's packing, sampler.py:92-105, outside the epoch clock):
+//     one qgtc_batch per cluster batch on the device, the adjacency's occupancy bitmaps and the jump-or-not decision;
+//   * bind() is what the epoch clock sees of the plan (main_qgtc.py:96 starts it before the weights exist): one pool
+//     allocation, one descriptor allocation, ONE launch;
+//   * run() issues the epoch's launches; outs(stage) makes the per-batch views on demand (never inside the clock).
+// ---------------------------------------------------------------------------------------------
+struct EpochPlan {
+    std::vector<torch::Tensor> keep;    // packed batches, bitmaps
+    torch::Tensor batches;              // device: qgtc_batch[count]
+    torch::Tensor stats;                // device: [occupied, all] tiles of the adjacencies
+    std::vector<int32_t> nodes;
+    int count = 0, max_n = 0, a_bits = 1;
+    bool jumping = false;
+    double occupied = 1.0;
+    // bound state
+    std::vector<qgtc_stage> stages;
+    std::vector<torch::Tensor> weights;
+    torch::Tensor pool, descs;
+    struct Launch {
+        int kind;        // 0 grouped GEMM, 1 chained pair (qgtc_gcn_chain_batched), 2 layer (qgtc_gcn_layer_batched, two launches)
+        int s1, s2;
+        unsigned extra;  // QGTC_CHAIN_* flags
+    };
+    std::vector<Launch> launches;
+    std::vector<uint64_t> offsets;      // lazily: word offset of every (stage, batch) output in the pool
+    static constexpr double kJumpBelow = BatchedGemm::kJumpBelow;
+
+    EpochPlan(std::vector<torch::Tensor> As, std::vector<torch::Tensor> Xs, std::vector<torch::Tensor> Xrs, std::vector<int> ns,
+              int a_bits_, bool zero_jump) : a_bits(a_bits_) {
+        count = static_cast<int>(As.size());
+        TORCH_CHECK(count > 0 && count <= 65535, "1..65535 cluster batches");
+        TORCH_CHECK(static_cast<int>(Xs.size()) == count && static_cast<int>(ns.size()) == count, "one X and one node count per batch");
+        TORCH_CHECK(Xrs.empty() || static_cast<int>(Xrs.size()) == count, "Xrs: none, or one per batch");
+        const auto dev = As[0].device();
+        c10::DeviceGuard guard(dev);
+        std::vector<qgtc_batch> h(count);
+        std::vector<int64_t> occ_off(count + 1, 0);
+        for (int i = 0; i < count; i++) {
+            TORCH_CHECK(ns[i] > 0, "bad node count");
+            occ_off[i + 1] = occ_off[i] + static_cast<int64_t>(qgtc_occupancy_words(ns[i], ns[i]));
+        }
+        torch::Tensor occ_pool;
+        if (zero_jump) occ_pool = torch::empty({occ_off[count]}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
+        auto operand = [&](const torch::Tensor &t, const char *name) {
+            CHECK_INPUT(t);
+            check_bits_tensor(t, name);
+            TORCH_CHECK(t.device() == dev, "all batches must live on one device");
+            TORCH_CHECK(t.numel() < (1LL << 30), "packed operand too large (>= 4 GiB)");
+            TORCH_CHECK((reinterpret_cast<uintptr_t>(t.data_ptr()) & 15) == 0, "packed operands must be 16-byte aligned");
+            keep.push_back(t);
+            return qgtc_operand{words(t), static_cast<uint64_t>(t.numel())};
+        };
+        std::vector<qgtc_problem> tmp(count);   // the adjacencies as left operands, for the bitmap launch
+        for (int i = 0; i < count; i++) {
+            h[i].A = operand(As[i], "A");
+            h[i].X = operand(Xs[i], "X");
+            h[i].XR = Xrs.empty() ? qgtc_operand{nullptr, 0} : operand(Xrs[i], "Xr");
+            h[i].n = ns[i];
+            h[i].occ = nullptr;
+            h[i].occ_words = 0;
+            if (zero_jump) {
+                h[i].occ = reinterpret_cast<const uint64_t *>(occ_pool.data_ptr<int64_t>() + occ_off[i]);
+                h[i].occ_words = (S128(ns[i]) + 63) / 64;
+            }
+            tmp[i] = qgtc_problem{h[i].A.ptr, h[i].A.ptr, nullptr, h[i].A.words, h[i].A.words, ns[i], ns[i], 1, 128, h[i].occ_words, h[i].occ};
+            max_n = std::max(max_n, ns[i]);
+            nodes.push_back(ns[i]);
+        }
+        if (zero_jump) {
+            // bitmaps of all adjacencies in one launch; whether jumping pays (a quarter of the tiles occupied at most) is read
+            // back HERE, beside the packing - the plan's descriptors then carry the bitmaps or do not
+            keep.push_back(occ_pool);
+            auto th = torch::empty({static_cast<int64_t>(count * sizeof(qgtc_problem))}, torch::TensorOptions().dtype(torch::kUInt8));
+            std::memcpy(th.data_ptr(), tmp.data(), count * sizeof(qgtc_problem));
+            torch::Tensor td = th.to(dev);
+            stats = torch::empty({2}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
+            check_rc(qgtc_tile_occupancy_batched(reinterpret_cast<qgtc_problem *>(td.data_ptr()), count, max_n, max_n, a_bits, 2.0f,
+                                                 reinterpret_cast<uint64_t *>(stats.data_ptr<int64_t>()), current_stream(td)),
+                     "EpochPlan (tile occupancy)");
+            auto sh = stats.cpu();
+            const double set = static_cast<double>(sh.data_ptr<int64_t>()[0]), all = static_cast<double>(sh.data_ptr<int64_t>()[1]);
+            occupied = all > 0.0 ? set / all : 1.0;
+            jumping = occupied <= kJumpBelow;
+            if (!jumping)
+                for (auto &b : h) {
+                    b.occ = nullptr;
+                    b.occ_words = 0;
+                }
+        }
+        auto host = torch::empty({static_cast<int64_t>(count * sizeof(qgtc_batch))}, torch::TensorOptions().dtype(torch::kUInt8));
+        std::memcpy(host.data_ptr(), h.data(), count * sizeof(qgtc_batch));
+        batches = host.to(dev);
+    }
+
+    // stages: (left, right, K, N, bit1, bit2, ob, mode, pad128, use_occ) per operator; launches: (kind, s1, s2, extra flags)
+    void bind(std::vector<torch::Tensor> weights_, std::vector<std::array<int, 10>> stages_, std::vector<std::array<int, 4>> launches_) {
+        c10::DeviceGuard guard(batches.device());
+        const int ns = static_cast<int>(stages_.size()), nw = static_cast<int>(weights_.size());
+        TORCH_CHECK(ns >= 1 && ns <= QGTC_MAX_STAGES && nw <= QGTC_MAX_WEIGHTS, "too many stages / weights");
+        stages.clear();
+        for (const auto &t : stages_)
+            stages.push_back(qgtc_stage{t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]});
+        qgtc_operand wops[QGTC_MAX_WEIGHTS];
+        for (int k = 0; k < nw; k++) {
+            const torch::Tensor &w = weights_[k];
+            CHECK_INPUT(w);
+            check_bits_tensor(w, "weight");
+            TORCH_CHECK(w.device() == batches.device(), "weights must live on the batches' device");
+            wops[k] = qgtc_operand{words(w), static_cast<uint64_t>(w.numel())};
+        }
+        weights = std::move(weights_);
+        launches.clear();
+        for (const auto &l : launches_) {
+            TORCH_CHECK(l[0] >= 0 && l[0] <= 2 && l[1] >= 0 && l[1] < ns && (l[0] == 0 || (l[2] >= 0 && l[2] < ns)), "bad launch entry");
+            launches.push_back(Launch{l[0], l[1], l[2], static_cast<unsigned>(l[3])});
+        }
+        offsets.clear();
+        const size_t pool_words = qgtc_epoch_pool_layout(nodes.data(), count, stages.data(), ns, nullptr);
+        TORCH_CHECK(pool_words > 0 && pool_words < (1ull << 40), "bad pool size");
+        const auto dev = batches.device();
+        pool = torch::empty({static_cast<int64_t>(pool_words)}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
+        descs = torch::empty({static_cast<int64_t>(ns) * count * static_cast<int64_t>(sizeof(qgtc_problem))}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+        check_rc(qgtc_epoch_plan_fill(reinterpret_cast<const qgtc_batch *>(batches.data_ptr()), count, stages.data(), ns, wops, nw,
+                                      pool.data_ptr(), pool_words, reinterpret_cast<qgtc_problem *>(descs.data_ptr()), current_stream(pool)),
+                 "EpochPlan.bind");
+    }
+
+    const qgtc_problem *stage_descs(int s) const { return reinterpret_cast<const qgtc_problem *>(descs.data_ptr()) + static_cast<size_t>(s) * count; }
+    int dimK(const qgtc_stage &st) const { return st.K == QGTC_DIM_NODES ? max_n : st.K; }
+
+    void run_launch(const Launch &l, unsigned check) {
+        const unsigned base = mm_flags() | check;
+        void *st = current_stream(descs);
+        if (l.kind == 0) {
+            const qgtc_stage &a = stages[l.s1];
+            check_rc(qgtc_bitmm_batched(stage_descs(l.s1), count, max_n, dimK(a), a.N, a.bit1, a.bit2, a.ob, a.mode,
+                                        base | ((a.use_occ && jumping) ? QGTC_ZERO_JUMP : 0u) | l.extra, st), "EpochPlan.run (grouped GEMM)");
+        } else if (l.kind == 1) {
+            const qgtc_stage &a = stages[l.s1], &x = stages[l.s2];
+            check_rc(qgtc_gcn_chain_batched(stage_descs(l.s1), stage_descs(l.s2), count, max_n, dimK(a), a.N, x.N, a.bit1, a.bit2, a.ob, x.bit2, x.ob,
+                                            x.mode, base | ((a.use_occ && jumping) ? QGTC_ZERO_JUMP : 0u) | l.extra, st), "EpochPlan.run (chained pair)");
+        } else {
+            const qgtc_stage &a = stages[l.s1], &b = stages[l.s2];
+            check_rc(qgtc_gcn_layer_batched(stage_descs(l.s1), stage_descs(l.s2), count, max_n, dimK(a), dimK(b), std::max(a.N, b.N), a.bit1, a.bit2, a.ob,
+                                            b.bit1, b.ob, b.mode, nullptr, 1u, base | ((b.use_occ && jumping) ? QGTC_ZERO_JUMP : 0u), st), "EpochPlan.run (layer)");
+        }
+    }
+
+    void run() {
+        TORCH_CHECK(descs.defined(), "EpochPlan.run before bind");
+        c10::DeviceGuard guard(descs.device());
+        for (const Launch &l : launches) run_launch(l, 0u);
+    }
+
+    // one epoch with QGTC_CHECK_DESCRIPTORS on every launch; raises if a descriptor breaks a grouped entry's preconditions
+    void run_checked() {
+        TORCH_CHECK(descs.defined(), "EpochPlan.run before bind");
+        c10::DeviceGuard guard(descs.device());
+        for (const Launch &l : launches) run_launch(l, QGTC_CHECK_DESCRIPTORS);
+        int problem = -1, field = 0;
+        const int rc = qgtc_last_batched_violation(&problem, &field, current_stream(descs));
+        TORCH_CHECK(rc == QGTC_OK, "EpochPlan: descriptor ", problem, " violates a grouped launch's preconditions (field ", field, ")");
+    }
+
+    // the per-batch outputs of one stage: views into the pool, made on demand
+    std::vector<torch::Tensor> outs(int s) {
+        TORCH_CHECK(descs.defined() && s >= 0 && s < static_cast<int>(stages.size()), "no such stage");
+        if (offsets.empty()) {
+            offsets.resize(stages.size() * static_cast<size_t>(count));
+            qgtc_epoch_pool_layout(nodes.data(), count, stages.data(), static_cast<int>(stages.size()), offsets.data());
+        }
+        const qgtc_stage &st = stages[s];
+        std::vector<torch::Tensor> v;
+        for (int b = 0; b < count; b++) {
+            const int64_t off = static_cast<int64_t>(offsets[static_cast<size_t>(s) * count + b]);
+            const int n = nodes[b];
+            if (st.mode == 2) v.push_back(pool.narrow(0, off, static_cast<int64_t>(n) * st.N).view(torch::kFloat32).view({n, st.N}));
+            else if (st.mode == 1) v.push_back(pool.narrow(0, off, static_cast<int64_t>(st.ob) * S128(n) * 4 * P128(st.N)).view({static_cast<int64_t>(st.ob) * S128(n) * 4, P128(st.N)}));
+            else v.push_back(pool.narrow(0, off, static_cast<int64_t>(st.ob) * P8(n) * S128(st.N) * 4).view({static_cast<int64_t>(st.ob) * P8(n), S128(st.N) * 4}));
+        }
+        return v;
+    }
+};
 
 }  // namespace
 
@@ -768,6 +1002,41 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("bit_A"), py::arg("bit_X"), py::arg("bit_W"), py::arg("n"), py::arg("f_in"), py::arg("f_out"),
           py::arg("a_bit") = 1, py::arg("act_bit") = 2, py::arg("w_bit") = 2, py::arg("output") = false,
           py::arg("one_launch") = false);
+
+    m.def("val2bit_many", &val2bit_many, "val2bit of up to 8 matrices in one launch (the weights an epoch packs inside its clock)",
+          py::arg("inputs"), py::arg("nbits"), py::arg("col_major"), py::arg("output_layer"));
+    m.def("last_batched_violation", [](torch::Tensor on) {
+        c10::DeviceGuard guard(on.device());
+        int problem = -1, field = 0;
+        const int rc = qgtc_last_batched_violation(&problem, &field, current_stream(on));
+        return py::make_tuple(rc, problem, field);
+    }, "(rc, problem, field) of the first descriptor a QGTC_CHECK_DESCRIPTORS launch on this tensor's device found in violation");
+    py::class_<EpochPlan, std::shared_ptr<EpochPlan>>(m, "EpochPlan")
+        .def(py::init<std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<int>, int, bool>(),
+             py::arg("As"), py::arg("Xs"), py::arg("Xrs"), py::arg("nodes"), py::arg("a_bits") = 1, py::arg("zero_jump") = true)
+        .def("bind", &EpochPlan::bind, py::arg("weights"), py::arg("stages"), py::arg("launches"),
+             "weights: packed tensors; stages: (left, right, K, N, bit1, bit2, ob, mode, pad128, use_occ); launches: (kind, s1, s2, flags)")
+        .def("run", &EpochPlan::run)
+        .def("run_checked", &EpochPlan::run_checked)
+        .def("run_launch", [](EpochPlan &p, int i) {
+            TORCH_CHECK(p.descs.defined() && i >= 0 && i < static_cast<int>(p.launches.size()), "no such launch");
+            c10::DeviceGuard guard(p.descs.device());
+            p.run_launch(p.launches[i], 0u);
+        }, "one launch of the bound plan (timing a stage on its own)")
+        .def("outs", &EpochPlan::outs, py::arg("stage"))
+        .def_readonly("count", &EpochPlan::count)
+        .def_readonly("zero_jump", &EpochPlan::jumping)
+        .def_readonly("occupied_fraction", &EpochPlan::occupied)
+        .def_property_readonly("n_launches", [](const EpochPlan &p) { return p.launches.size(); });
+    m.attr("SRC_A") = static_cast<int>(QGTC_SRC_A);
+    m.attr("SRC_X") = static_cast<int>(QGTC_SRC_X);
+    m.attr("SRC_XR") = static_cast<int>(QGTC_SRC_XR);
+    m.attr("SRC_WEIGHT") = static_cast<int>(QGTC_SRC_WEIGHT);
+    m.attr("SRC_STAGE") = static_cast<int>(QGTC_SRC_STAGE);
+    m.attr("DIM_NODES") = static_cast<int>(QGTC_DIM_NODES);
+    m.attr("CHAIN_DISCARD") = static_cast<int>(QGTC_CHAIN_DISCARD);
+    m.attr("CHAIN_CODES_IN") = static_cast<int>(QGTC_CHAIN_CODES_IN);
+    m.attr("CHAIN_CODES_OUT") = static_cast<int>(QGTC_CHAIN_CODES_OUT);
 
     py::class_<ChainedPair>(m, "ChainedPair")
         .def(py::init<std::shared_ptr<BatchedGemm>, std::shared_ptr<BatchedGemm>, bool, int>(), py::arg("stage_a"), py::arg("stage_xw"), py::arg("discard") = false,

@@ -88,14 +88,17 @@ def build_parser() -> argparse.ArgumentParser:
 
 
 def pack_weights(Q, feat, hidden, classes, bw, device):
-    """main_qgtc.py:100-110: all-ones weights, cols layout, W3 with output_layer=True."""
-    W1 = torch.ones((feat, hidden), device=device)
-    W2 = torch.ones((hidden, hidden), device=device)
-    W3 = torch.ones((hidden, classes), device=device)
+    """main_qgtc.py:100-110: all-ones weights, cols layout, W3 with output_layer=True. Inside the reference's epoch clock,
+    so it is ONE fill and ONE pack launch here (Q.val2bit_many: the same words as four val2bit calls)."""
+    ones = torch.ones(feat * hidden + hidden * hidden + hidden * classes, device=device)
+    W1 = ones[:feat * hidden].view(feat, hidden)
+    W2 = ones[feat * hidden:feat * hidden + hidden * hidden].view(hidden, hidden)
+    W3 = ones[feat * hidden + hidden * hidden:].view(hidden, classes)
+    p1, p2, p3, p3h = Q.val2bit_many([W1, W2, W3, W3], bw, [True, True, True, True], [False, False, True, False])
     return {
-        "W1": Q.val2bit(W1, bw, True, False), "W2": Q.val2bit(W2, bw, True, False),
-        "W3": Q.val2bit(W3, bw, True, True),          # main_qgtc.py:110
-        "W3h": Q.val2bit(W3, bw, True, False),        # hidden-style W3 for the layout-correct GCN chain
+        "W1": p1, "W2": p2,
+        "W3": p3,           # main_qgtc.py:110 (output_layer=True)
+        "W3h": p3h,         # hidden-style W3 for the layout-correct GCN chain
         "feat": feat, "hidden": hidden, "classes": classes,
     }
 
@@ -284,10 +287,95 @@ class BatchedEpoch:
         return self.outs
 
 
+def stage_recipes(Q, chain: str, run_gin: bool, F: int, H: int, C: int, b: int):
+    """The six operators of an epoch (main_qgtc.py:131-154; the layout-correct forms as unitest.py:100-109 builds them) as
+    qgtc_stage tuples (left, right, K, N, bit1, bit2, ob, mode, pad128, use_occ) for Q.EpochPlan.bind; weights are
+    [W1, W2, W3, W3h]."""
+    A, X, XR, N_ = Q.SRC_A, Q.SRC_X, Q.SRC_XR, Q.DIM_NODES
+    W = lambda k: Q.SRC_WEIGHT + k          # noqa: E731
+    S = lambda j: Q.SRC_STAGE + j           # noqa: E731
+    if chain == "reference" and not run_gin:
+        return [(X, W(0), F, H, b, b, b, 0, 0, 0), (A, S(0), N_, H, 1, b, b, 0, 0, 1), (S(1), W(1), H, H, b, b, b, 0, 0, 0),
+                (A, S(2), N_, H, 1, b, b, 0, 0, 1), (S(3), W(2), H, C, b, b, b, 0, 0, 0), (A, S(4), N_, H, 1, b, 1, 2, 0, 1)]
+    if chain == "reference":
+        return [(A, X, N_, F, 1, b, b, 0, 0, 1), (S(0), W(0), F, H, b, b, b, 0, 0, 0), (A, S(1), N_, H, 1, b, b, 0, 0, 1),
+                (S(2), W(1), H, H, b, b, b, 0, 0, 0), (A, S(3), N_, H, 1, b, b, 0, 0, 1), (S(4), W(2), H, C, b, b, 1, 2, 0, 0)]
+    if not run_gin:
+        return [(XR, W(0), F, H, b, b, b, 1, 0, 0), (A, S(0), N_, H, 1, b, b, 0, 0, 1), (S(1), W(1), H, H, b, b, b, 1, 0, 0),
+                (A, S(2), N_, H, 1, b, b, 0, 0, 1), (S(3), W(3), H, C, b, b, b, 1, 0, 0), (A, S(4), N_, C, 1, b, 1, 2, 1, 1)]
+    return [(A, X, N_, F, 1, b, b, 0, 0, 1), (S(0), W(0), F, H, b, b, b, 1, 0, 0), (A, S(1), N_, H, 1, b, b, 0, 0, 1),
+            (S(2), W(1), H, H, b, b, b, 1, 0, 0), (A, S(3), N_, H, 1, b, b, 0, 0, 1), (S(4), W(2), H, C, b, b, 1, 2, 0, 0)]
+
+
+class PlannedEpoch:
+    """The grouped epoch on a device-filled plan (Q.EpochPlan): what BatchedEpoch builds on the host - 6 x 75 descriptors,
+    pooled outputs, occupancy bitmaps - is split into the data loader's part (`data`, made once beside the packing:
+    ClusterIter.epoch_data) and ONE bind launch inside the epoch clock. Same launches, same words as BatchedEpoch."""
+
+    def __init__(self, Q, data, params, W, b, chain: str, run_gin: bool, fuse: bool = True, chain_stages: bool = True,
+                 keep_aggregates: bool = False):
+        H, C = W["hidden"], W["classes"]
+        F = params[0][3]
+        self.data = data
+        self.final = 5
+        stages = stage_recipes(Q, chain, run_gin, F, H, C, b)
+        launches = [(0, i, 0, 0) for i in range(6)]
+        self.discarded = set()
+        if fuse and chain == "correct" and chain_stages:
+            # an aggregation stage and the NEXT layer's X.W stage are one call (qgtc_gcn_chain_batched), T between the
+            # launches of a chain in the kernels' own format where every launch can keep it (see BatchedEpoch)
+            pairs = [(1, 2), (3, 4)] if not run_gin else [(0, 1), (2, 3), (4, 5)]
+            codes = {}
+            max_n = max(p[0] for p in params)
+            if (not keep_aggregates and (b == 2 or (run_gin and b == 4)) and max(F, H, C) <= 128 and max_n <= 8192 and Q.get_engine() != "popcount"
+                    and not any(k.startswith("QGTC_NO_") for k in os.environ)):
+                codes = {0: 2, 2: 3, 4: 1} if run_gin else {0: 2, 1: 3, 3: 3, 5: 1}
+            flag = lambda c: ((Q.CHAIN_CODES_IN if c & 1 else 0) | (Q.CHAIN_CODES_OUT if c & 2 else 0))   # noqa: E731
+            first = {i: (1, i, j, (0 if keep_aggregates else Q.CHAIN_DISCARD) | flag(codes.get(i, 0))) for i, j in pairs}
+            second = {j for _, j in pairs}
+            launches = [first.get(i, (0, i, 0, flag(codes.get(i, 0)) if codes else 0)) for i in range(6) if i not in second]
+            self.discarded = set() if keep_aggregates else {i for i, _ in pairs}
+            if codes:
+                self.discarded |= {1, 3} if run_gin else {0, 2, 4}
+        elif fuse and chain == "correct":
+            pairs = [(0, 1), (2, 3), (4, 5)] if not run_gin else [(1, 2), (3, 4)]
+            first = {i: (2, i, j, 0) for i, j in pairs}
+            second = {j for _, j in pairs}
+            launches = [first.get(i, (0, i, 0, 0)) for i in range(6) if i not in second]
+        self.n_launches = len(launches)
+        data.bind([W["W1"], W["W2"], W["W3"], W["W3h"]], [list(t) for t in stages], [list(l) for l in launches])
+
+    def run(self):
+        self.data.run()
+
+    @property
+    def outs(self):
+        return self.data.outs(self.final)
+
+    def stage_outs(self, i):
+        return self.data.outs(i)
+
+
 # ---------------------------------------------------------------------------------------------
-def run(args, Q=None, batch_ids=None, graph=None):
+def uses_planned_epoch(args) -> bool:
+    """--batched runs on a device-filled plan (PlannedEpoch) unless a switch asks for something only the host-built plan
+    (BatchedEpoch) has: the in-launch hand-off of --one-launch."""
+    return bool(args.batched) and not getattr(args, "one_launch", False) and not args.non_resident and not args.zerotile_jump \
+        and not getattr(args, "pack_on_the_fly", False)
+
+
+def make_iter(args, Q, graph, batch_ids=None):
+    """The ClusterIter of a run (main_qgtc.py:74-93 builds it ahead of the epoch clock)."""
+    return ClusterIter(args.dataset, graph, args.psize, args.batch_size, bit_width=args.bit_width,
+                       run_GIN=args.run_GIN, device=torch.device(f"cuda:{args.gpu}"), resident=not args.non_resident, qgtc=Q,
+                       batch_ids=batch_ids, with_rows_X=(args.chain == "correct"),
+                       keep_raw=getattr(args, "pack_on_the_fly", False))
+
+
+def run(args, Q=None, batch_ids=None, graph=None, it=None):
     """Runs the epoch loop; returns a dict with avg_epoch_ms, the last epoch's per-batch outputs
-    and the iterator. `batch_ids` restricts this process to a shard of the batches."""
+    and the iterator. `batch_ids` restricts this process to a shard of the batches; `it` = a ClusterIter built earlier
+    for the same arguments (the reference builds it once, ahead of the epoch clock: main_qgtc.py:74-93)."""
     if Q is None:
         import QGTC as Q
     torch.manual_seed(3)      # main_qgtc.py:45-47
@@ -296,17 +384,17 @@ def run(args, Q=None, batch_ids=None, graph=None):
     device = torch.device(f"cuda:{args.gpu}")
     torch.cuda.set_device(device)
 
-    if graph is None:
+    if graph is None and it is None:
         if args.dataset.endswith(".npz"):
             graph = G.load_npz_graph(args.dataset, args.dim, args.psize)
         else:
             graph = G.make_graph(args.dataset, args.psize)
-    feat_size = graph.feat.shape[1]
+    feat_size = (graph if graph is not None else it.g).feat.shape[1]
     b = args.bit_width
-    it = ClusterIter(args.dataset, graph, args.psize, args.batch_size, bit_width=b,
-                     run_GIN=args.run_GIN, device=device, resident=not args.non_resident, qgtc=Q,
-                     batch_ids=batch_ids, with_rows_X=(args.chain == "correct"),
-                     keep_raw=getattr(args, "pack_on_the_fly", False))
+    if it is None:
+        it = make_iter(args, Q, graph, batch_ids)
+    if uses_planned_epoch(args):
+        it.epoch_data(Q)      # the data loader's share of a grouped epoch (per-batch table, adjacency bitmaps): beside the packing
     torch.cuda.synchronize()
 
     prev_engine = Q.get_engine()
@@ -365,6 +453,17 @@ def _run_epochs(args, Q, it, feat_size, b, device):
         return {"avg_epoch_ms": avg, "outs": outs, "iter": it, "trans_ms": transfering / args.n_epochs * 1e3,
                 "compute_ms": running_time / args.n_epochs * 1e3}
 
+    if uses_planned_epoch(args):
+        plan = PlannedEpoch(Q, it.epoch_data(Q), it.cluster_param_li, W, b, args.chain, args.run_GIN, fuse=not getattr(args, "no_fuse", False),
+                            chain_stages=not getattr(args, "no_chain", False))
+        for _ in range(args.n_epochs):
+            plan.run()
+        torch.cuda.synchronize()
+        end_time = time.time()
+        avg = (end_time - start_time) * 1000 / args.n_epochs
+        if not args.quiet:
+            print("Avg. Epoch: {:.3f} ms".format(avg))       # main_qgtc.py:159
+        return {"avg_epoch_ms": avg, "outs": plan.outs, "iter": it, "plan": plan}   # (the per-batch views are made here, after the clock)
     if args.batched or args.streams > 0:
         cts = [c.to(device) for c in it.cTensor_li]
         plan = BatchedEpoch(Q, cts, it.cluster_param_li, W, b, args.chain, args.run_GIN, fuse=not getattr(args, "no_fuse", False),

@@ -95,6 +95,19 @@ class ClusterIter:
             if keep_raw:
                 self.raw_li.append((r_dev, c_dev, X) if resident else (r_dev.cpu(), c_dev.cpu(), X.cpu()))
 
+    def epoch_data(self, qgtc=None):
+        """The data loader's share of a GROUPED epoch, made once beside the packing (outside the epoch clock, like the
+        packing itself: main_qgtc.py:74-93): the per-batch table on the device and the adjacencies' occupancy bitmaps
+        (Q.EpochPlan). The epoch then binds weights and outputs to it with one launch (driver.PlannedEpoch)."""
+        if getattr(self, "_epoch_data", None) is None:
+            if qgtc is None:
+                import QGTC as qgtc
+            assert self.resident, "a grouped epoch needs the packed batches on the device"
+            cts = self.cTensor_li
+            rows = [c.bit_X_rows for c in cts] if cts and cts[0].bit_X_rows is not None else []
+            self._epoch_data = qgtc.EpochPlan([c.bit_A for c in cts], [c.bit_X for c in cts], rows, [p[0] for p in self.cluster_param_li], 1, True)
+        return self._epoch_data
+
     def __len__(self):
         return len(self.cTensor_li)
 

@@ -177,3 +177,128 @@ def test_chain_entry_with_raw_descriptors(lib, oracle, flags):
     assert lib.qgtc_bitmm_batched(descs.data_ptr(), count, max(ns), max(ns), 512, 1, 2, 2, 0, flags | 0x80, st) == 1    # (512 columns: not the row-block kernel)
     assert lib.qgtc_bitmm_batched(descs.data_ptr(), count, max(ns), 256, f2, 2, 2, 2, 1, flags | 0x100, st) == 1        # (K = 256: not the X.W row-block kernel)
     assert lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr() + 72 * count, count, max(ns), max(ns), 256, f2, 1, 4, 4, 4, 4, 1, flags | 0x80, st) == 1
+
+
+class QgtcOperand(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("words", ctypes.c_uint64)]
+
+
+class QgtcBatch(ctypes.Structure):
+    """include/qgtc.h: struct qgtc_batch - what the data loader knows of one cluster batch."""
+    _fields_ = [("A", QgtcOperand), ("X", QgtcOperand), ("XR", QgtcOperand), ("occ", ctypes.c_void_p), ("n", ctypes.c_int32),
+                ("occ_words", ctypes.c_int32)]
+
+
+class QgtcStage(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in ("left", "right", "K", "N", "bit1", "bit2", "ob", "mode", "pad128", "use_occ")]
+
+
+class QgtcPackJob(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_words", ctypes.c_uint64), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("nbits", ctypes.c_int32), ("col_major", ctypes.c_int32), ("output_layer", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+SRC_A, SRC_X, SRC_XR, SRC_WEIGHT, SRC_STAGE, DIM_NODES = 0, 1, 2, 16, 32, -1
+
+
+def test_epoch_plan_filled_on_the_device_with_raw_pointers(lib, oracle):
+    """qgtc_val2bit_batched + qgtc_epoch_pool_layout + qgtc_epoch_plan_fill + the grouped entries through ctypes: the three
+    weights packed in one launch, the descriptors of a layout-correct two-layer GCN slice (X.W1 -> A.T1 -> .W2 -> A.T2 as
+    float32) filled by ONE launch from the per-batch table, QGTC_CHECK_DESCRIPTORS on every launch - against the oracle."""
+    import torch
+    assert ctypes.sizeof(QgtcBatch) == 64 and ctypes.sizeof(QgtcStage) == 40 and ctypes.sizeof(QgtcPackJob) == 48
+    lib.qgtc_val2bit_batched.argtypes = [vp, ctypes.c_int, vp]
+    lib.qgtc_epoch_pool_layout.restype = ctypes.c_size_t
+    lib.qgtc_epoch_pool_layout.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp]
+    lib.qgtc_epoch_plan_fill.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_size_t, vp, vp]
+    lib.qgtc_bitmm_batched.argtypes = [vp, ctypes.c_int] + [ctypes.c_int] * 3 + [ctypes.c_int] * 4 + [ctypes.c_uint, vp]
+    lib.qgtc_last_batched_violation.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), vp]
+    rng = np.random.default_rng(41)
+    b, F, H, C = 2, 48, 64, 10
+    ns = [150, 333, 40, 97]
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # weights: float matrices -> packed, one launch
+    Wf = [rng.uniform(-1, 5, size=s).astype(np.float32) for s in ((F, H), (H, C))]
+    dWf = [torch.from_numpy(w).cuda() for w in Wf]
+    words = [int(lib.qgtc_cols_words(F, H, b, 0)), int(lib.qgtc_cols_words(H, C, b, 0))]
+    dW = [torch.full((w,), -1, dtype=torch.int32, device="cuda") for w in words]
+    jobs = (QgtcPackJob * 2)(QgtcPackJob(dWf[0].data_ptr(), dW[0].data_ptr(), words[0], F, H, b, 1, 0, 0),
+                             QgtcPackJob(dWf[1].data_ptr(), dW[1].data_ptr(), words[1], H, C, b, 1, 0, 0))
+    assert lib.qgtc_val2bit_batched(ctypes.addressof(jobs), 2, st) == 0
+    W_o = [oracle.val2bit(Wf[0], b, True, False), oracle.val2bit(Wf[1], b, True, False)]
+    for d, o in zip(dW, W_o):
+        np.testing.assert_array_equal(d.cpu().numpy().view(np.uint32), o)
+    assert lib.qgtc_val2bit_batched(ctypes.addressof(jobs), 9, st) == 1            # more jobs than QGTC_MAX_PACK_JOBS
+    jobs[1].out_words = 3
+    assert lib.qgtc_val2bit_batched(ctypes.addressof(jobs), 2, st) == 2            # an undersized output is an error code
+    # the data loader's table
+    keep, hb, ref = [], [], []
+    for n in ns:
+        qa = (rng.random((n, n)) < 0.03).astype(np.int32)
+        qx = rand_q(rng, n, F, b)
+        A, Xr = oracle.pack(qa, 1, False), oracle.pack(qx, b, False)
+        dA, dXr = torch.from_numpy(A.view(np.int32)).cuda(), torch.from_numpy(Xr.view(np.int32)).cuda()
+        keep += [dA, dXr]
+        hb.append(QgtcBatch(QgtcOperand(dA.data_ptr(), dA.numel()), QgtcOperand(None, 0), QgtcOperand(dXr.data_ptr(), dXr.numel()), None, n, 0))
+        t1 = oracle.bitmm2bit(Xr, W_o[0], n, F, H, b, b, b, col=True)
+        h1 = oracle.bitmm2bit(A, t1, n, n, H, 1, b, b)
+        t2 = oracle.bitmm2bit(h1, W_o[1], n, H, C, b, b, b, col=True)
+        ref.append((t1, h1, t2, oracle.bitmm2int(A, t2, n, n, C, 1, b, True)))
+    count = len(ns)
+    batches = torch.frombuffer(bytearray(bytes((QgtcBatch * count)(*hb))), dtype=torch.uint8).cuda()
+    stages = (QgtcStage * 4)(QgtcStage(SRC_XR, SRC_WEIGHT + 0, F, H, b, b, b, 1, 0, 0), QgtcStage(SRC_A, SRC_STAGE + 0, DIM_NODES, H, 1, b, b, 0, 0, 0),
+                             QgtcStage(SRC_STAGE + 1, SRC_WEIGHT + 1, H, C, b, b, b, 1, 0, 0), QgtcStage(SRC_A, SRC_STAGE + 2, DIM_NODES, C, 1, b, 1, 2, 1, 0))
+    weights = (QgtcOperand * 2)(QgtcOperand(dW[0].data_ptr(), dW[0].numel()), QgtcOperand(dW[1].data_ptr(), dW[1].numel()))
+    nodes = (ctypes.c_int32 * count)(*ns)
+    offs = (ctypes.c_uint64 * (4 * count))()
+    pool_words = lib.qgtc_epoch_pool_layout(ctypes.addressof(nodes), count, ctypes.addressof(stages), 4, ctypes.addressof(offs))
+    want_words = sum(lib.qgtc_cols_words(n, H, b, 0) + lib.qgtc_rows_words(n, H, b) + lib.qgtc_cols_words(n, C, b, 0) + (n * C + 3) // 4 * 4 for n in ns)
+    assert pool_words == want_words and offs[0] == 0 and all(o % 4 == 0 for o in offs)
+    pool = torch.full((pool_words,), -1, dtype=torch.int32, device="cuda")
+    descs = torch.zeros(4 * count * 72, dtype=torch.uint8, device="cuda")
+    rc = lib.qgtc_epoch_plan_fill(batches.data_ptr(), count, ctypes.addressof(stages), 4, ctypes.addressof(weights), 2, pool.data_ptr(), pool_words,
+                                  descs.data_ptr(), st)
+    assert rc == 0, lib.qgtc_strerror(rc)
+    got = (QgtcProblem * (4 * count)).from_buffer_copy(descs.cpu().numpy().tobytes())
+    for s in range(4):
+        for i, n in enumerate(ns):
+            d = got[s * count + i]
+            assert d.out == pool.data_ptr() + 4 * offs[s * count + i] and d.M == n and d.N == (H if s < 2 else C)
+            assert d.K == (n if s in (1, 3) else (F if s == 0 else H)) and d.occ is None
+    assert got[count].W == got[0].out and got[2 * count].X == got[count].out and got[3 * count].W == got[2 * count].out
+    CHECK, AUTO = 0x200, 0x10
+    mx = max(ns)
+    for s, (K, N, b1, b2, ob, mode) in enumerate(((F, H, b, b, b, 1), (mx, H, 1, b, b, 0), (H, C, b, b, b, 1), (mx, C, 1, b, 1, 2))):
+        rc = lib.qgtc_bitmm_batched(descs.data_ptr() + 72 * count * s, count, mx, K, N, b1, b2, ob, mode, AUTO | CHECK, st)
+        assert rc == 0, lib.qgtc_strerror(rc)
+    prob, field = ctypes.c_int(7), ctypes.c_int(7)
+    assert lib.qgtc_last_batched_violation(ctypes.byref(prob), ctypes.byref(field), st) == 0 and prob.value == -1 and field.value == 0
+    P = pool.cpu().numpy().view(np.uint32)
+    for i, n in enumerate(ns):
+        for s in range(3):
+            o = int(offs[s * count + i])
+            np.testing.assert_array_equal(P[o:o + ref[i][s].size], ref[i][s].reshape(-1), err_msg=f"stage {s} batch {i}")
+        o = int(offs[3 * count + i])
+        np.testing.assert_array_equal(P[o:o + n * C].view(np.float32).reshape(n, C), ref[i][3])
+    # ---- detected, not documented: a descriptor above the stated maxima sets the record (field 1 = M, 2 = K, 3 = N)
+    assert lib.qgtc_bitmm_batched(descs.data_ptr() + 72 * count, count, 200, mx, H, 1, b, b, 0, AUTO | CHECK, st) == 0     # batch 1 has 333 rows
+    assert lib.qgtc_last_batched_violation(ctypes.byref(prob), ctypes.byref(field), st) == 1 and (prob.value, field.value) == (1, 1)
+    assert lib.qgtc_last_batched_violation(ctypes.byref(prob), ctypes.byref(field), st) == 0                                 # read once, then cleared
+    assert lib.qgtc_bitmm_batched(descs.data_ptr(), count, mx, F, H - 1, b, b, b, 1, AUTO | CHECK, st) == 0                # N above max_N in every problem
+    assert lib.qgtc_last_batched_violation(ctypes.byref(prob), ctypes.byref(field), st) == 1 and (prob.value, field.value) == (0, 3)
+    lib.qgtc_gcn_chain_batched.argtypes = [vp, vp, ctypes.c_int] + [ctypes.c_int] * 4 + [ctypes.c_int] * 6 + [ctypes.c_uint, vp]
+    # a "chain" whose second stage does not read the first one's output (stage 1 then stage 3)
+    assert lib.qgtc_gcn_chain_batched(descs.data_ptr() + 72 * count, descs.data_ptr() + 72 * count * 3, count, mx, mx, H, C, 1, b, b, b, b, 2, CHECK, st) == 0
+    assert lib.qgtc_last_batched_violation(ctypes.byref(prob), ctypes.byref(field), st) == 1 and field.value in (2, 5)
+    # without the flag nothing is recorded
+    assert lib.qgtc_bitmm_batched(descs.data_ptr() + 72 * count, count, 200, mx, H, 1, b, b, 0, AUTO, st) == 0
+    assert lib.qgtc_last_batched_violation(None, None, st) == 0
+    # a pool smaller than the layout says is found by the fill kernel itself
+    assert lib.qgtc_epoch_plan_fill(batches.data_ptr(), count, ctypes.addressof(stages), 4, ctypes.addressof(weights), 2, pool.data_ptr(), pool_words - 8,
+                                    descs.data_ptr(), st) == 0
+    assert lib.qgtc_last_batched_violation(ctypes.byref(prob), ctypes.byref(field), st) == 1 and field.value == 4
+    # bad recipes are error codes
+    stages[1].left = SRC_STAGE + 3
+    assert lib.qgtc_epoch_plan_fill(batches.data_ptr(), count, ctypes.addressof(stages), 4, ctypes.addressof(weights), 2, pool.data_ptr(), pool_words,
+                                    descs.data_ptr(), st) == 1
+    torch.cuda.synchronize()

@@ -4,7 +4,7 @@
 import numpy as np
 import pytest
 
-from helpers import to_np_u32, use_engine
+from helpers import edge_floats, rand_q, to_dev, to_np_u32, use_engine
 
 pytestmark = pytest.mark.gpu
 
@@ -786,3 +786,54 @@ def test_chained_pair_rejects_plans_that_do_not_chain(qgtc, oracle):
         qgtc.ChainedPair(sa, qgtc.BatchedGemm(sa.outs, [W], [(n, f, f)], 2, 2, 2, 0, True))
     with pytest.raises(RuntimeError):      # plane counts that do not chain
         qgtc.ChainedPair(sa, qgtc.BatchedGemm(sa.outs, [W], [(n, f, f)], 1, 2, 2, 1, True))
+
+
+@pytest.mark.parametrize("nbits", [1, 2, 4, 8, 11])
+def test_val2bit_many_equals_val2bit(qgtc, oracle, nbits):
+    """One launch for several matrices (the weights an epoch packs inside its clock): every output word for word the
+    single call's and the oracle's - cols layout with and without output_layer, rows layout, ragged shapes, edge values."""
+    import torch
+    rng = np.random.default_rng(nbits)
+    shapes = [(128, 128), (50, 64), (64, 10), (64, 10), (9, 300), (129, 1)]
+    col = [True, True, True, True, False, False]
+    outl = [False, False, True, False, False, False]
+    xs = [edge_floats(rng, h, w, nbits) for h, w in shapes]
+    got = qgtc.val2bit_many([torch.from_numpy(x).cuda() for x in xs], nbits, col, outl)
+    for x, c, o, g in zip(xs, col, outl, got):
+        one = qgtc.val2bit(torch.from_numpy(x).cuda(), nbits, c, o)
+        assert one.shape == g.shape and torch.equal(one, g)
+        np.testing.assert_array_equal(to_np_u32(g), oracle.val2bit(x, nbits, c, o))
+    with pytest.raises(RuntimeError):
+        qgtc.val2bit_many([torch.zeros((4, 4), device="cuda")] * 9, nbits, [True] * 9, [False] * 9)
+
+
+def test_one_launch_layer_survives_engine_changes_between_runs(qgtc, oracle):
+    """A FusedLayer built with one_launch=True, run on `auto` (the in-launch hand-off: arrival counters advance), then under
+    set_engine("popcount") (two grouped launches: counters untouched), then on `auto` again: the plan's epoch follows the
+    route the library reports, so the consumers never wait for arrivals that were not made. (Round 2 counted calls: the third
+    run hung the GPU.)"""
+    import torch
+    rng = np.random.default_rng(77)
+    act, wb, f_in, f_out = 2, 2, 64, 64
+    ns = [150, 333, 40]
+    Wt = oracle.pack(rand_q(rng, f_in, f_out, wb), wb, True)
+    dW = to_dev(torch, Wt, (-1,))
+    As, Xs, want = [], [], []
+    for n in ns:
+        A, X = oracle.pack((rng.random((n, n)) < 0.03).astype(np.int32), 1, False), oracle.pack(rand_q(rng, n, f_in, act), act, False)
+        As.append(to_dev(torch, A, (-1,)))
+        Xs.append(to_dev(torch, X, (-1,)))
+        T = oracle.bitmm2bit(X, Wt, n, f_in, f_out, act, wb, act, col=True)
+        want.append(oracle.bitmm2int(A, T, n, n, f_out, 1, act, True))
+    g1 = qgtc.BatchedGemm(Xs, [dW], [(n, f_in, f_out) for n in ns], act, wb, act, 1, False, False)
+    g2 = qgtc.BatchedGemm(As, g1.outs, [(n, n, f_out) for n in ns], 1, act, 1, 2, True, False)
+    layer = qgtc.FusedLayer(g1, g2, True)
+    for eng in ("auto", "popcount", "auto", "mfma", "popcount", "auto"):
+        qgtc.set_engine(eng)
+        for o in g2.outs:
+            o.fill_(-5.0)
+        layer.run()
+        torch.cuda.synchronize()
+        for o, w in zip(g2.outs, want):
+            np.testing.assert_array_equal(o.cpu().numpy(), w, err_msg=eng)
+    qgtc.set_engine("auto")

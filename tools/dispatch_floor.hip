@@ -8,30 +8,31 @@
 #include <cstdlib>
 #include <vector>
 
-struct Item { const uint4 *data; const unsigned long long *occ; uint32_t n, pad[11]; };   // 64 bytes
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct Item { const u32x4 *data; const unsigned long long *occ; uint32_t n, pad[11]; };   // 64 bytes
 
-__global__ __launch_bounds__(256) void k_none(const Item *it, uint4 *sink) { if (it && threadIdx.x == 9999) sink[0] = uint4{0, 0, 0, 0}; }
-__global__ __launch_bounds__(256) void k_desc(const Item *it, uint4 *sink) {
+__global__ __launch_bounds__(256) void k_none(const Item *it, u32x4 *sink) { if (it && threadIdx.x == 9999) sink[0] = u32x4{0, 0, 0, 0}; }
+__global__ __launch_bounds__(256) void k_desc(const Item *it, u32x4 *sink) {
     const Item d = it[blockIdx.x];
-    if (d.n == 0xdeadbeefu) sink[blockIdx.x] = uint4{d.n, 0, 0, 0};
+    if (d.n == 0xdeadbeefu) sink[blockIdx.x] = u32x4{d.n, 0, 0, 0};
 }
-__global__ __launch_bounds__(256) void k_chain(const Item *it, uint4 *sink) {
+__global__ __launch_bounds__(256) void k_chain(const Item *it, u32x4 *sink) {
     const Item d = it[blockIdx.x];
     const unsigned long long o = d.occ[blockIdx.x & 1023];
-    const uint4 v = d.data[(threadIdx.x + (unsigned)(o & 7)) & 1023];
+    const u32x4 v = d.data[(threadIdx.x + (unsigned)(o & 7)) & 1023];
     if (v.x == 0xdeadbeefu) sink[blockIdx.x] = v;
 }
 // one round trip: the item already holds the occupancy word
-__global__ __launch_bounds__(256) void k_chain1(const Item *it, uint4 *sink) {
+__global__ __launch_bounds__(256) void k_chain1(const Item *it, u32x4 *sink) {
     const Item d = it[blockIdx.x];
-    const uint4 v = d.data[(threadIdx.x + (d.n & 7)) & 1023];
+    const u32x4 v = d.data[(threadIdx.x + (d.n & 7)) & 1023];
     if (v.x == 0xdeadbeefu) sink[blockIdx.x] = v;
 }
 // persistent form: gridDim.x workgroups walk `total` items
-__global__ __launch_bounds__(256) void k_chain1_loop(const Item *it, uint4 *sink, int total) {
+__global__ __launch_bounds__(256) void k_chain1_loop(const Item *it, u32x4 *sink, int total) {
     for (int i = blockIdx.x; i < total; i += gridDim.x) {
         const Item d = it[i];
-        const uint4 v = d.data[(threadIdx.x + (d.n & 7)) & 1023];
+        const u32x4 v = d.data[(threadIdx.x + (d.n & 7)) & 1023];
         if (v.x == 0xdeadbeefu) sink[i] = v;
     }
 }
@@ -66,7 +67,7 @@ static float graph_us(hipStream_t st, F &&launch) {
 
 int main() {
     const int maxg = 16384;
-    uint4 *data, *sink;
+    u32x4 *data, *sink;
     unsigned long long *occ;
     Item *items;
     hipMalloc(&data, 1024 * 16);
