@@ -203,7 +203,16 @@ def epoch_leg(Q, rank, world, device_index, dataset="ogbn-arxiv", bits=2, hidden
                 torch.cuda.synchronize()
         D.barrier()
         r = driver.run(args, Q=Q, batch_ids=ids, graph=graph, it=it)
-        res[name + "_ms"] = round(D.max_over_ranks(r["avg_epoch_ms"], torch.device("cuda", device_index)), 4)
+        ms = [r["avg_epoch_ms"]]
+        if it is not None:
+            # a 20-epoch grouped run is < 1 ms of wall clock, of which 25 - 200 us is the host packing the weights and binding
+            # the plan (inside the clock, main_qgtc.py:96) with whatever jitter the host has at that moment: five runs, each
+            # with its own weights and plan, median reported (min and max beside it)
+            for _ in range(4):
+                r = driver.run(args, Q=Q, batch_ids=ids, graph=graph, it=it)
+                ms.append(r["avg_epoch_ms"])
+            res[name + "_ms_min_max_of_5"] = [round(min(ms), 4), round(max(ms), 4)]
+        res[name + "_ms"] = round(D.max_over_ranks(sorted(ms)[len(ms) // 2], torch.device("cuda", device_index)), 4)
     if world > 1:   # the one exchange of the path: gather per-batch checksums (RCCL over xGMI)
         allsum = D.gather_batch_summaries(batch_summaries(r["outs"]), n_batches, rank, world)
         res["gathered_batches"] = int(allsum.size(0))
@@ -268,7 +277,7 @@ def epoch_roofline(Q, graph, device_index, dataset, bits, hidden, gin):
             eff_ops += 2.0 * n * K * N
     occ = [round(data.occupied_fraction, 4)]
     floors = {"hbm_us": round(algo_bytes / (HBM_PEAK_GBS * 1e9) * 1e6, 2), "mfma_fp4_us": round(mfma_ops / (FP4_PEAK_TFLOPS * 1e12) * 1e6, 2),
-              "launch_gaps_us": round(1.5 * (len(plan.launches) - 1), 1)}
+              "launch_gaps_us": round(1.5 * (plan.n_launches - 1), 1)}
     chained = 6 - plan.n_launches
     return {"kernel_us_per_epoch": round(epoch_us, 2), "kernel_us_per_operator_alone": stage_us, "calls_per_epoch": plan.n_launches,
             "launches_per_epoch": plan.n_launches,

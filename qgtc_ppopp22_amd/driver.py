@@ -365,7 +365,11 @@ def uses_planned_epoch(args) -> bool:
 
 
 def make_iter(args, Q, graph, batch_ids=None):
-    """The ClusterIter of a run (main_qgtc.py:74-93 builds it ahead of the epoch clock)."""
+    """The ClusterIter of a run (main_qgtc.py:74-93 builds it ahead of the epoch clock), under the reference's seeds
+    (main_qgtc.py:45-47: the partition shuffle of sampler.py:68 draws from `random`)."""
+    torch.manual_seed(3)
+    np.random.seed(2)
+    random.seed(2)
     return ClusterIter(args.dataset, graph, args.psize, args.batch_size, bit_width=args.bit_width,
                        run_GIN=args.run_GIN, device=torch.device(f"cuda:{args.gpu}"), resident=not args.non_resident, qgtc=Q,
                        batch_ids=batch_ids, with_rows_X=(args.chain == "correct"),
