@@ -311,11 +311,42 @@ typedef struct qgtc_stage {
     int32_t mode;        /* 0 rows-layout bits, 1 cols-layout bits, 2 float32 */
     int32_t pad128;      /* mode 2: the right operand's planes have PAD128(N) lines (else PAD8(N)) */
     int32_t use_occ;     /* carry the batch's occupancy bitmap (left must be QGTC_SRC_A) */
+    int32_t fmt;         /* mode 1 only: 0 = the cols layout, 1 = the chain format of qgtc_chain_* (qgtc_chain_words(n, N) words) */
 } qgtc_stage;
 size_t qgtc_epoch_pool_layout(const int32_t *nodes, int count, const qgtc_stage *stages, int n_stages, uint64_t *offsets);
 int qgtc_epoch_plan_fill(const qgtc_batch *batches, int count, const qgtc_stage *stages, int n_stages,
                          const qgtc_operand *weights, int n_weights, void *pool, size_t pool_words,
                          qgtc_problem *descs, void *stream);
+
+/* ---- The chain entries: one wave per 32-row block for the whole output width (2-bit Cluster-GCN epochs) -----------------
+ * Between the launches of a layout-correct epoch (X.W1 | A.T1 + .W2 | A.T2 + .W3 | A.T3, main_qgtc.py:147-154 with every
+ * right operand in the cols layout) T is written by one launch and read by the next and by nobody else. These entries keep
+ * it in a private CHAIN FORMAT - the finished matrix-core operand, qgtc_chain_words(M, N) words per batch, unspecified to
+ * the caller - and take the weights PRE-EXPANDED (qgtc_expand_weights, once per plan; qgtc_weight_codes_words(N) words
+ * each). Word for word (after decoding) the results of the public entries; only the last call's float32 output is public.
+ *   qgtc_chain_transform:  T_b = requant(X_b . W)                stage[b] = {X_b rows layout (x_bits planes, K <= 128), -, T_b}
+ *   qgtc_chain_aggregate:  out_mode 0: out_b = float32(A_b . T_b)                      stage_a[b] = {A_b, T_b, out_b}; stage_xw = NULL
+ *                          out_mode 1: T'_b  = requant(requant(A_b . T_b) . W')        stage_a[b] = {A_b, T_b, -}, stage_xw[b] = {-, -, T'_b}
+ *                          out_mode 2: out_b = float32(requant(A_b . T_b) . W')        stage_xw[b] = {-, -, out_b [M, N2]}
+ * A_b: rows layout, ONE plane, K <= 8192 (occupancy bitmaps of the descriptors are followed); N, N2 <= 128; t_bits /
+ * act_bits / out_bits = bits of T / of the aggregate / of T' (2 supported, t_bits also 1); weights: 1 or 2 planes.
+ * QGTC_EINVAL outside that range: callers fall back to qgtc_gcn_chain_batched. w_codes: qgtc_expand_weights order 0 for
+ * qgtc_chain_transform (the left operand arrives as packed words), order 1 for qgtc_chain_aggregate (the left operand is
+ * the aggregate in the registers of the wave that computed it). max_M is a hard precondition (QGTC_CHECK_DESCRIPTORS). */
+typedef struct qgtc_expand_job {
+    const uint32_t *W;   /* cols layout [K, N], nbits planes of w_lines lines */
+    uint32_t *codes;     /* qgtc_weight_codes_words(N) words */
+    uint64_t w_words;
+    int32_t K, N, nbits, w_lines, order, reserved;
+} qgtc_expand_job;
+size_t qgtc_weight_codes_words(int N);
+size_t qgtc_chain_words(int M, int N);
+int qgtc_expand_weights(const qgtc_expand_job *jobs, int n_jobs, void *stream);
+int qgtc_chain_transform(const qgtc_problem *stage, int count, int max_M, int K, int N, int x_bits, int out_bits,
+                         const uint32_t *w_codes, unsigned flags, void *stream);
+int qgtc_chain_aggregate(const qgtc_problem *stage_a, const qgtc_problem *stage_xw, int count, int max_M, int max_K, int N1,
+                         int N2, int t_bits, int act_bits, int out_bits, int out_mode, const uint32_t *w2_codes,
+                         unsigned flags, void *stream);
 
 #ifdef __cplusplus
 }

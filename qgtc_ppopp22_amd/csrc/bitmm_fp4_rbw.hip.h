@@ -1,0 +1,434 @@
+// bitmm_fp4_rbw.hip.h — part of libqgtc_hip.so (qgtc_fp4.hip).
+// The 2-bit Cluster-GCN chain of a device-filled epoch plan, ONE WAVE PER 32-ROW BLOCK for the whole output width.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Why. The row-block kernels of bitmm_fp4_rows.hip.h / bitmm_fp4_chain.hip.h give every 32 x 32 output tile its own wave
+// (four waves per row block at 128 columns). rocprofv3 (profiles/r02): 54 VALU instructions per MFMA, 319 per wave - these
+// launches are bound by VALU issue, and most of that work is REPEATED or CONVERSION work:
+//   * every one of a row block's four waves expands the same adjacency words to E2M1 codes (28 operations per pair of
+//     k-quads), loads and expands W' (28), and goes through a barrier and LDS to hand its quarter of the aggregate's
+//     row to the other three for the second product;
+//   * T - written by one launch of the chain, read by the next and by nobody else - travels as bit planes that the
+//     producer packs (28 per tile) and the consumer expands again (56 per tile and pair of k-quads).
+// Here a wave owns a row block for ALL column blocks (NCB x 32 columns):
+//   * the adjacency word is expanded once per row block;
+//   * T / T' are CODES between the launches of a chain (two E2M1 nibbles per byte, the finished MFMA operand: no packing in
+//     the producer, no expansion in the consumer) - `fmt` 1 of qgtc_stage, twice the bytes of two bit planes;
+//   * the weights arrive PRE-EXPANDED (k_expand_weights, once per plan) in exactly the lane order the products use;
+//   * the second product's left operand never leaves the registers: after the first product lane (fl, fh) holds, of row
+//     fl of the aggregate, the 64 columns c with ((c >> 2) & 1) == fh - which 32 elements of K an MFMA's lane supplies is
+//     free as long as both operands agree, so MFMA m takes the lane's values of column blocks 2 m and 2 m + 1 as they sit
+//     (two nibbles per byte from v_cvt_pk_u8_f32 + one v_lshl_or), and W' was expanded in that order. No LDS, no barrier,
+//     no cross-lane operation between the two products.
+// Per row block of the 128-column chained launch: ~420 VALU operations instead of 4 x 319.
+//
+// Chain format of T ("codes", fmt 1): [k-quad q of the producing product's rows][word j of the k-quad][line n < pad128(N)]
+// [4 dwords]: element e (row 32 (4 q + j) + e) at nibble 7 - e / 4 of dword 3 - e % 4, the order expand_word_fp4 gives the
+// bits of a packed A word, so the consumer's A expansion and these codes agree on K. Lines are the INNER index: the 16
+// bytes the 32 lanes of a half-wave load (or store) for one (q, j) are 512 contiguous bytes - 8 cache lines per load
+// instruction; with the words of a line together ([q][n][j], the first form) every instruction touched 32 lines and the
+// four instructions of a column block touched the same 32: the waves of a CU then queued 4.4 k cycles at the address unit
+// (in-kernel stamps, tools/rbw_bench.hip). Size: step128(M) * pad128(N) * 16 words.
+// ------------------------------------------------------------------------------------------
+
+// lane (fl, fh) of the first product holds, per column block j, the values of columns 32 j + t + 8 gq + 4 fh in register
+// 4 gq + t. requant_pack16 puts them a byte each: P[t] byte 3 - gq. Two dwords per block: nibble 2 b + u of dword A (t = u)
+// and of dword B (t = 2 + u) is the value of byte b = 3 - gq. K index of the second product (MFMA m, half fh, dword d,
+// nibble i): column 32 (2 m + (d >> 1)) + (2 (d & 1) + (i & 1)) + 8 (3 - (i >> 1)) + 4 fh.
+__host__ __device__ constexpr int rbw_column(int m, int fh, int d, int i) {
+    return 32 * (2 * m + (d >> 1)) + (2 * (d & 1) + (i & 1)) + 8 * (3 - (i >> 1)) + 4 * fh;
+}
+
+// ------------------------------------------------------------------------------------------
+// Pre-expanded weights. order 0: the right operand of X . W where X arrives as packed words (K <= 128: one k-quad) - table
+// [column block jn][k half h][lane] of 16 bytes: the codes of word 2 fh + h of line 32 jn + fl (what strip_operand gives).
+// order 1: the right operand of (aggregate) . W' in the register order above - table [jn][m][lane]: dword d nibble i = the
+// value of W'[rbw_column(m, fh, d, i)][32 jn + fl]. Values are the low two planes (2-bit weights: one base-4 digit).
+// ------------------------------------------------------------------------------------------
+struct ExpandJob {
+    const uint32_t *W;
+    uint32_t *codes;
+    unsigned long long w_words;
+    int K, N, w_lines, nbits, order, ncb;
+};
+struct ExpandJobs {
+    ExpandJob job[QGTC_MAX_WEIGHTS];
+};
+
+__global__ __launch_bounds__(64) void k_expand_weights(ExpandJobs jobs) {
+    const ExpandJob j = jobs.job[blockIdx.y];
+    const int jn = static_cast<int>(blockIdx.x) >> 1, s = static_cast<int>(blockIdx.x) & 1;
+    if (jn >= j.ncb) return;
+    const int lane = threadIdx.x, fl = lane & 31, fh = lane >> 5;
+    const int n = 32 * jn + fl;
+    const int line_words = step128(j.K) * 4;
+    const size_t plane = static_cast<size_t>(j.w_lines) * line_words;
+    auto bit = [&](int p, int c) -> uint32_t {   // bit of plane p for K index c of line n
+        if (n >= j.N || c >= j.K || p >= j.nbits) return 0u;
+        const size_t wi = p * plane + static_cast<size_t>(n) * line_words + (c >> 5);
+        return wi < j.w_words ? (j.W[wi] >> (31 - (c & 31))) & 1u : 0u;
+    };
+    uint32_t out[4] = {0u, 0u, 0u, 0u};
+    for (int d = 0; d < 4; d++)
+        for (int i = 0; i < 8; i++) {
+            int c;
+            if (j.order == 0) c = 32 * (2 * fh + s) + 31 - (d + 4 * i);   // bit d + 4 i of word 2 fh + s = element 31 - (d + 4 i)
+            else c = rbw_column(s, fh, d, i);
+            out[d] |= (bit(0, c) | (bit(1, c) << 1)) << (4 * i);
+        }
+    *reinterpret_cast<u32x4 *>(j.codes + (static_cast<size_t>(blockIdx.x) * 64 + lane) * 4) = u32x4{out[0], out[1], out[2], out[3]};
+}
+
+// An FP4 MFMA operand from its four dwords: the instruction takes a 256-bit register tuple but reads only the first 128
+// bits of an FP4 operand - the upper half is left UNDEFINED (zeros there cost four v_mov per operand, a third of this
+// kernel's VALU instructions in its first build)
+__device__ __forceinline__ i32x8 fp4_op(const u32x4 &v) {
+    const i32x4 t = __builtin_bit_cast(i32x4, v);
+    return __builtin_shufflevector(t, t, 0, 1, 2, 3, -1, -1, -1, -1);
+}
+__device__ __forceinline__ i32x8 fp4_op(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return fp4_op(u32x4{a, b, c, d}); }
+__device__ __forceinline__ i32x8 fp4_op(const i32x8 &v) { return __builtin_shufflevector(v, v, 0, 1, 2, 3, -1, -1, -1, -1); }
+__device__ __forceinline__ f32x16 f32x16_zero() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; r++) z[r] = 0.0f;
+    return z;
+}
+
+struct RbwShape {
+    int per;      // != 0: all workgroups of a batch on one XCD
+    int a, w;     // planes of the packed left operand (k_rbw_xw) / unused
+};
+
+__device__ __forceinline__ void rbw_ids(const RbwShape &sh, int &grp, int &batch) {
+    grp = static_cast<int>(blockIdx.x);
+    batch = static_cast<int>(blockIdx.y);
+    if (sh.per) {
+        const int v = xcd_consecutive(batch * static_cast<int>(gridDim.x) + grp, static_cast<int>(gridDim.x * gridDim.y));
+        batch = v / static_cast<int>(gridDim.x);
+        grp = v - batch * static_cast<int>(gridDim.x);
+    }
+}
+
+// 16 re-quantised values (low OB bits of each byte of P) -> the two code dwords of a column block (see rbw_column)
+template <int OB>
+__device__ __forceinline__ void rbw_nibbles(const uint32_t (&P)[4], uint32_t &A, uint32_t &B) {
+    constexpr uint32_t mask = OB == 1 ? 0x01010101u : 0x03030303u;
+    A = (P[0] & mask) | ((P[1] & mask) << 4);
+    B = (P[2] & mask) | ((P[3] & mask) << 4);
+}
+
+// codes of word (rb & 3) of line n2 of T' from the 16 values a lane holds of column n2 (not swapped: rows t + 8 gq + 4 fh)
+template <int OB>
+__device__ __forceinline__ void rbw_store_codes(const f32x16 &acc, uint32_t *__restrict__ dst, int fh, bool ok) {
+    uint32_t qv[16], P[4];
+    requant_pack16<OB>(acc, OB, P, qv);
+    uint32_t x[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        x[t] = (P[t] & (OB == 1 ? 0x01010101u : (OB == 2 ? 0x03030303u : 0x0f0f0f0fu))) << (4u - 4u * static_cast<uint32_t>(fh));   // nibble 7 - 2 gq - fh of dword 3 - t
+        x[t] = or_with_partner_half(x[t]);
+    }
+    if (fh == 0 && ok) *reinterpret_cast<u32x4 *>(dst) = u32x4{x[3], x[2], x[1], x[0]};
+}
+
+// ------------------------------------------------------------------------------------------
+// T = requant(X . W) for every cluster batch (main_qgtc.py:147, layout-correct form): X = packed rows-layout planes (K <=
+// 128), W pre-expanded (order 0), T in the chain format. A workgroup = four row blocks (one k-quad of T), a wave = one.
+// ------------------------------------------------------------------------------------------
+template <int NA, int OB, int NCB>
+__global__ __launch_bounds__(256) void k_rbw_xw(const qgtc_problem *__restrict__ prs, const u32x4 *__restrict__ w_codes, RbwShape sh) {
+    constexpr int NDA = (NA + 1) / 2;
+    int grp, batch;
+    rbw_ids(sh, grp, batch);
+    const qgtc_problem pr = prs[batch];
+    const int M = pr.M, N = pr.N;
+    if (grp >= step128(M)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fl = lane & 31, fh = lane >> 5;
+    const int rb = 4 * grp + wv, m = 32 * rb + fl;
+    const int lines = pad128(N);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(pr.X), 0, static_cast<int>(static_cast<uint32_t>(pr.x_words) * 4u), 0x00020000);
+    const uint32_t x_plane = static_cast<uint32_t>(pad8(M)) * 16u;
+    uint32_t xl[2][NA];   // [k half][plane]: words 2 fh, 2 fh + 1 of the lane's row
+#pragma unroll
+    for (int p = 0; p < NA; p++) {
+        const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, (m < M && p < sh.a) ? static_cast<uint32_t>(p) * x_plane + static_cast<uint32_t>(m) * 16u + 8u * fh : 0xffffffffu, 0, 0));
+        xl[0][p] = v.x;
+        xl[1][p] = v.y;
+    }
+    u32x4 wc[NCB][2];
+#pragma unroll
+    for (int jn = 0; jn < NCB; jn++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) wc[jn][h] = w_codes[(jn * 2 + h) * 64 + lane];
+    i32x8 xa[2][NDA];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int da = 0; da < NDA; da++) xa[h][da] = fp4_op(strip_operand<NA>(xl[h], da));
+    uint32_t *tbase = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(grp * 4 + wv) * lines * 4;   // word wv of k-quad grp
+#pragma unroll
+    for (int jn = 0; jn < NCB; jn++) {
+        f32x16 acc = f32x16_zero();   // (a constant C operand of the first MFMA, not sixteen v_mov)
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int da = 0; da < NDA; da++)
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[h][da], fp4_op(wc[jn][h]), acc, 4, 4, 0, 128 + 2 * da, 0, 128);   // not swapped: lane = column 32 jn + fl
+        const int n = 32 * jn + fl;
+        rbw_store_codes<OB>(acc, tbase + static_cast<size_t>(n) * 4, fh, n < lines);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// An aggregation stage with the next layer's X . W in its tail (main_qgtc.py:148-149 / :150-151), or the last aggregation
+// (main_qgtc.py:154: float32 out). prs: {A (rows layout, one plane), T (chain format, OB planes' worth of values), out
+// unused unless MODE2 == 0}; prs2 (MODE2 1 / 2): {-, -, T' (chain format) or float32 [M, N2]}.
+//   MODE2 0: out = float32(A . T) [M, N]              (no second product; NCB2 unused)
+//   MODE2 1: T' = requant(requant(A . T) . W')        chain format
+//   MODE2 2: out = float32(requant(A . T) . W')       [M, N2]
+// ------------------------------------------------------------------------------------------
+#ifdef QGTC_RBW_STAMPS   // tools/rbw_bench.hip: s_memtime at the phases of a wave, kept in scalar registers
+#define RBW_STAMP(i) st_[i] = __builtin_amdgcn_s_memtime()
+#else
+#define RBW_STAMP(i) do { } while (0)
+#endif
+
+template <int OB, int OB2, int MODE2, int NCB1, int NCB2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_rbw_chain(const qgtc_problem *__restrict__ prs, const qgtc_problem *__restrict__ prs2,
+                                                                                                const u32x4 *__restrict__ w2_codes, RbwShape sh) {
+    constexpr int MH = (NCB1 + 1) / 2;   // MFMAs (64 elements of K each) of the second product
+#ifdef QGTC_RBW_STAMPS
+    unsigned long long st_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    RBW_STAMP(0);
+    int grp, batch;
+    rbw_ids(sh, grp, batch);
+    const qgtc_problem pr = prs[batch];
+    const int M = pr.M, K = pr.K, N = pr.N;
+    if (grp >= step128(M)) return;
+#ifdef QGTC_RBW_STAMPS
+    asm volatile("" ::"s"(M), "s"(K));
+#endif
+    RBW_STAMP(1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fl = lane & 31, fh = lane >> 5;
+    const int rb = 4 * grp + wv, m = 32 * rb + fl;
+    // ---- what the whole workgroup needs, fetched FIRST and once, into LDS:
+    //  * W' (pre-expanded, NCB2 x MH x 1 KB): fetched per wave after the first product - two 16-byte loads per column block
+    //    out of L2, one behind the other for want of registers - it cost 0.7 us per column block;
+    //  * the DIAGONAL k-quad of T (8 KB of codes): the four row blocks of this workgroup are rows 128 grp .. 128 grp + 127, and
+    //    a cluster batch's adjacency is block-diagonal-dominant - their occupancy words almost always name k-quad grp. Every
+    //    wave loading it for itself is 16 load instructions x 1 KB per wave, and the CU's one address unit (64 bytes a clock)
+    //    was where the waves queued (in-kernel stamps: 2.4 k cycles from the occupancy word to the last load issued).
+    __shared__ __attribute__((aligned(16))) u32x4 w2_lds[MODE2 == 0 ? 1 : NCB2 * 2 * 64];
+    __shared__ __attribute__((aligned(16))) u32x4 t_lds[4 * 128];   // [word t of the k-quad][line n]
+    const int kq = step128(K);
+    const int lines = 128;   // pad128(N), N <= 128
+    const bool diag_ok = grp < kq;   // (workgroup-uniform; A is square in the epochs, so the diagonal k-quad exists)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(pr.X), 0, static_cast<int>(static_cast<uint32_t>(pr.x_words) * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(pr.W), 0, static_cast<int>(static_cast<uint32_t>(kq) * static_cast<uint32_t>(lines) * 64u), 0x00020000);
+    const uint32_t row_bytes = static_cast<uint32_t>(kq) * 16u;
+    const uint32_t x_base = m < M ? static_cast<uint32_t>(m) * row_bytes : 0xffffffffu;
+    {
+        u32x4 td[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+            td[i] = __builtin_amdgcn_raw_buffer_load_b128(rt, diag_ok ? (static_cast<uint32_t>(grp) * 512u + static_cast<uint32_t>(tid + 256 * i)) * 16u : 0xffffffffu, 0, 0);
+        if constexpr (MODE2 != 0) {
+#pragma unroll
+            for (int i = 0; i < (NCB2 * 2 * 64 + 255) / 256; i++) {
+                const int e = i * 256 + tid;
+                if (e < NCB2 * 2 * 64 && ((e >> 6) & 1) < MH) w2_lds[e] = w2_codes[e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) t_lds[tid + 256 * i] = td[i];
+    }
+    // the lane's words 2 fh, 2 fh + 1 of the diagonal k-quad of its adjacency row, and the occupancy word: in flight over the barrier
+    u32x2 xd = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, (diag_ok && x_base != 0xffffffffu) ? x_base + static_cast<uint32_t>(grp) * 16u + 8u * fh : 0xffffffffu, 0, 0));
+    unsigned long long todo = kq >= 64 ? ~0ull : ((1ull << kq) - 1ull);
+    if (pr.occ && 32 * rb < M) todo &= pr.occ[static_cast<size_t>(rb) * pr.occ_words];
+    __syncthreads();   // (every wave of the workgroup is still at its start)
+    if (MODE2 != 1 && 32 * rb >= M) return;   // (float32 rows: no rows here; T' still needs its padding words)
+
+    // ---- first product: acc[j] = (A . T)[row fl][columns 32 j + t + 8 gq + 4 fh], swapped operands
+    f32x16 acc[NCB1];
+    bool any = false;   // (wave-uniform)
+    if (32 * rb < M) {
+        unsigned todo_lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(todo)), todo_hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(todo >> 32));
+        unsigned long long left = (static_cast<unsigned long long>(todo_hi) << 32) | todo_lo;   // (wave-uniform: scalar registers)
+        const bool has_diag = diag_ok && ((left >> grp) & 1ull) != 0ull;
+        if (diag_ok) left &= ~(1ull << grp);
+#ifdef QGTC_RBW_STAMPS
+        asm volatile("" ::"s"(left));
+#endif
+        RBW_STAMP(2);
+        any = has_diag || left != 0ull;
+        if (any) {
+            // the OTHER occupied k-quads, in PAIRS: the lanes of half fh take the pair's k-quad fh. ONE per-lane offset per
+            // pair - word 0 of the lane's k-quad, line fl - and the (word, column block) part as the instruction's scalar
+            // offset (per load the first build spent seven VALU operations on its address). A missing k-quad (q < 0) keeps
+            // the lane offset at 0xffffffff: out of range whatever is added. Lines up to 32 NCB1 - 1 exist and were written
+            // (zeros past N) by the launch that produced T.
+            u32x4 xl, tl[NCB1][4];
+            auto load_pair = [&]() {
+                const int qa = __builtin_ctzll(left);
+                left &= left - 1ull;
+                const int qb = left != 0ull ? __builtin_ctzll(left) : -1;
+                left &= left - 1ull;
+                const int q = fh ? qb : qa;
+                xl = __builtin_amdgcn_raw_buffer_load_b128(rx, (q >= 0 && x_base != 0xffffffffu) ? x_base + static_cast<uint32_t>(q) * 16u : 0xffffffffu, 0, 0);
+                const uint32_t t_lane = q >= 0 ? (static_cast<uint32_t>(q) * 512u + static_cast<uint32_t>(fl)) * 16u : 0xffffffffu;
+#pragma unroll
+                for (int j = 0; j < NCB1; j++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) tl[j][t] = __builtin_amdgcn_raw_buffer_load_b128(rt, t_lane, (t * 128 + 32 * j) * 16, 0);
+            };
+            auto multiply_pair = [&]() {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const uint32_t xw[1] = {xl[t]};
+                    const i32x8 xa = fp4_op(strip_operand<1>(xw, 0));
+#pragma unroll
+                    for (int j = 0; j < NCB1; j++) {
+                        if constexpr (OB <= 2) {
+                            acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_op(tl[j][t]), xa, acc[j], 4, 4, 0, 128, 0, 128);
+                        } else {   // 4-bit values: two base-4 digits in a nibble
+                            acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_op(tl[j][t][0] & 0x33333333u, tl[j][t][1] & 0x33333333u, tl[j][t][2] & 0x33333333u, tl[j][t][3] & 0x33333333u),
+                                                                                     xa, acc[j], 4, 4, 0, 128, 0, 128);
+                            acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_op((tl[j][t][0] >> 2) & 0x33333333u, (tl[j][t][1] >> 2) & 0x33333333u, (tl[j][t][2] >> 2) & 0x33333333u, (tl[j][t][3] >> 2) & 0x33333333u),
+                                                                                     xa, acc[j], 4, 4, 0, 130, 0, 128);
+                        }
+                    }
+                }
+            };
+            RBW_STAMP(3);
+            // the diagonal k-quad from LDS: MFMA h takes word 2 fh + h of both operands. Always issued - a block whose
+            // occupancy word does not name it multiplies zeros - so that the accumulators START here, as the constant C
+            // operand of these MFMAs (64 v_mov less per row block) on every path
+            if (!has_diag) xd = u32x2{0u, 0u};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t xw[1] = {xd[h]};
+                const i32x8 xa = fp4_op(strip_operand<1>(xw, 0));
+#pragma unroll
+                for (int j = 0; j < NCB1; j++)
+                    acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_op(t_lds[(2 * fh + h) * 128 + 32 * j + fl]), xa, h == 0 ? f32x16_zero() : acc[j], 4, 4, 0, 128, 0, 128);
+            }
+            RBW_STAMP(4);
+            // (The first pair's loads issued AHEAD of the diagonal step - in flight during it - were measured: 151 registers
+            // instead of 104, three waves per SIMD instead of four, 6.78 against 6.64 us per 128 x 128 chained launch.)
+            while (left != 0ull) {   // (wave-uniform)
+                load_pair();
+                multiply_pair();
+            }
+        }
+    }
+    if (!any) {
+        // No occupied k-quad, or a padding block of T': the aggregate's rows are zero, so is everything after them - the
+        // wave stores its zeros and is done. (As a join of two paths into the products below, the accumulators had to be
+        // zeroed up front on BOTH: 64 v_mov per wave.)
+        if constexpr (MODE2 == 0) {
+            if (m < M)
+                for (int c = fh; c < N; c += 2) static_cast<float *>(pr.out)[static_cast<size_t>(m) * N + c] = 0.0f;
+        } else {
+            const qgtc_problem pz = prs2[batch];
+            if constexpr (MODE2 == 2) {
+                if (m < M)
+                    for (int c = fh; c < pz.N; c += 2) static_cast<float *>(pz.out)[static_cast<size_t>(m) * pz.N + c] = 0.0f;
+            } else {
+                uint32_t *tz = static_cast<uint32_t *>(pz.out) + static_cast<size_t>(grp * 4 + wv) * 128 * 4;
+#pragma unroll
+                for (int jn = 0; jn < NCB2; jn++)
+                    if (fh == 0) *reinterpret_cast<u32x4 *>(tz + (32 * jn + fl) * 4) = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        return;
+    }
+
+#ifdef QGTC_RBW_STAMPS
+    asm volatile("" ::"v"(acc[0][0]), "v"(acc[NCB1 - 1][15]));
+#endif
+    RBW_STAMP(5);
+    if constexpr (MODE2 == 0) {   // float32 [M, N] (kernel.h:915-930): registers 4 g .. 4 g + 3 are four consecutive columns of row m
+        if (m < M) {
+#pragma unroll
+            for (int j = 0; j < NCB1; j++) {
+                float *dst = static_cast<float *>(pr.out) + static_cast<size_t>(m) * N + 32 * j;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int e = 8 * g + 4 * fh;
+                    if ((N & 3) == 0 && 32 * j + e + 3 < N) {
+                        *reinterpret_cast<f32x4 *>(dst + e) = f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; t++)
+                            if (32 * j + e + t < N) dst[e + t] = acc[j][4 * g + t];
+                    }
+                }
+            }
+        }
+        return;
+    } else {
+        // ---- the aggregate's row as the second product's left operand, straight from the registers
+        static_assert(MODE2 == 0 || OB <= 2, "chained second product: 1- and 2-bit aggregates (one base-4 digit per nibble)");
+        uint32_t XA[MH][4];
+#pragma unroll
+        for (int mm = 0; mm < MH; mm++)
+#pragma unroll
+            for (int d = 0; d < 4; d++) XA[mm][d] = 0u;
+#pragma unroll
+        for (int j = 0; j < NCB1; j++) {
+            uint32_t qv[16], P[4];
+            requant_pack16<OB>(acc[j], OB, P, qv);
+            rbw_nibbles<OB>(P, XA[j >> 1][2 * (j & 1)], XA[j >> 1][2 * (j & 1) + 1]);
+        }
+#ifdef QGTC_RBW_STAMPS
+        asm volatile("" ::"v"(XA[0][0]), "v"(XA[MH - 1][3]));
+#endif
+        RBW_STAMP(6);
+        const qgtc_problem pr2 = prs2[batch];
+        const int N2 = pr2.N, lines2 = pad128(N2);
+        uint32_t *tbase = static_cast<uint32_t *>(pr2.out) + static_cast<size_t>(grp * 4 + wv) * lines2 * 4;   // word wv of k-quad grp
+        const __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc(pr2.out, 0, MODE2 == 2 ? static_cast<int>(static_cast<uint32_t>(M) * static_cast<uint32_t>(N2) * 4u) : 0, 0x00020000);
+#pragma unroll
+        for (int jn = 0; jn < NCB2; jn++) {
+            f32x16 acc2 = f32x16_zero();
+#pragma unroll
+            for (int mm = 0; mm < MH; mm++)
+                acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_op(XA[mm][0], XA[mm][1], XA[mm][2], XA[mm][3]), fp4_op(w2_lds[(jn * 2 + mm) * 64 + lane]), acc2, 4, 4, 0, 128, 0, 128);   // not swapped: lane = column 32 jn + fl of T'
+            const int n2 = 32 * jn + fl;
+            if constexpr (MODE2 == 2) {   // float32 rows; branch-free stores (see bitmm_fp4_chain.hip.h: an MFMA reads all lanes' operands)
+                const uint32_t base = n2 < N2 ? (static_cast<uint32_t>(32 * rb) * static_cast<uint32_t>(N2) + static_cast<uint32_t>(n2)) * 4u : 0xffffffffu;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc2[r]), ro2, (base != 0xffffffffu && 32 * rb + row < M) ? base + static_cast<uint32_t>(row) * static_cast<uint32_t>(N2) * 4u : 0xffffffffu, 0, 0);
+                }
+            } else {
+                rbw_store_codes<OB2>(acc2, tbase + static_cast<size_t>(n2) * 4, fh, n2 < lines2);
+            }
+        }
+        RBW_STAMP(8);
+#ifdef QGTC_RBW_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RBW_STAMP(9);
+        if (tid == 0) {
+            const int slot = (batch * static_cast<int>(gridDim.x) + grp) % 1024;
+            for (int i = 0; i < 10; i++) g_stamps[slot * 16 + i] = st_[i];
+        }
+#endif
+    }
+}
+
+}  // namespace

@@ -32,7 +32,7 @@ namespace {
 // ballots: one scalar bit per (X plane, k-quad) says whether the 32-row x 128-bit tile has any
 // bit set. All-zero tiles are skipped with a scalar branch (no divergence, no extra VALU work).
 // ------------------------------------------------------------------------------------------
-#ifdef QGTC_STAMPS  // diagnostic build only (tools/kbench.hip): per-phase s_memtime stamps
+#if defined(QGTC_STAMPS) || defined(QGTC_RBW_STAMPS)  // diagnostic builds only (tools/kbench.hip, tools/rbw_bench.hip): per-phase s_memtime stamps
 // The stamps stay in scalar registers while the kernel runs (a store per stamp would put memory
 // traffic and waits into the phases being timed); wave 0 of each workgroup writes them out at the end.
 __device__ unsigned long long g_stamps[1024 * 16];

@@ -19,6 +19,12 @@ int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, i
 int qgtc_launch_xw_rows(const qgtc_problem *prs, int count, int max_M, int a, int w, int ob, bool qmajor_out, hipStream_t st);
 int qgtc_launch_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int w, int ob, int w2, int ob2, int mode2, bool discard, int codes, hipStream_t st);
 
+// row block per wave (bitmm_fp4_rbw.hip.h), defined in qgtc_fp4.hip
+int qgtc_launch_expand_weights(const qgtc_expand_job *jobs, int n_jobs, hipStream_t st);
+int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int N, int a, int ob, const uint32_t *w_codes, hipStream_t st);
+int qgtc_launch_rbw_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int N1, int N2, int t_bits, int act_bits,
+                          int out_bits, int mode2, const uint32_t *w2_codes, hipStream_t st);
+
 // defined in qgtc_wide.hip
 int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st);
 // defined in qgtc_epoch.hip: QGTC_CHECK_DESCRIPTORS (kind 0 one stage / 1 layer / 2 chain; p2 may be NULL)
@@ -181,6 +187,14 @@ inline bool xw_rows_ok(int max_K, int max_N, int a, int w, int ob) {
 inline bool chain_ok(int max_K, int max_N1, int max_N2, int a, int w, int ob, int w2, int ob2, int mode2) {
     const bool planes = (ob == 2 && (mode2 == 2 || ob2 == 2) && w <= 2 && w2 <= 2) || (ob == 4 && (mode2 == 2 || ob2 == 4) && w <= 4 && w2 <= 4);
     return a == 1 && planes && max_N1 <= 128 && max_N2 <= 128 && rows_ok(max_K, max_N1, a, w, ob, 0) && !getenv_flag("QGTC_NO_CHAIN");   // (float32 outputs: M N' < 2^30 by the 16 MB-scale batches this is for; the torch binding's pools are below 2^31 bytes)
+}
+
+// the chain entries (bitmm_fp4_rbw.hip.h): one wave per row block, T in the chain format, weights pre-expanded
+inline bool rbw_xw_ok(int K, int N, int x_bits, int out_bits) { return K >= 1 && K <= 128 && N >= 1 && N <= 128 && x_bits >= 1 && x_bits <= 2 && out_bits == 2; }
+inline bool rbw_chain_ok(int max_K, int N1, int N2, int t_bits, int act_bits, int out_bits, int mode2) {
+    if (max_K < 1 || max_K > 8192 || N1 < 1 || N1 > 128 || (t_bits != 1 && t_bits != 2)) return false;
+    if (mode2 == 0) return true;
+    return N2 >= 1 && N2 <= 128 && act_bits == 2 && (mode2 == 2 || out_bits == 2);
 }
 
 // grouped launches on the matrix cores, one wave per 32 x 32 tile (bitmm_fp4_wave.hip.h): for NARROW outputs.

@@ -250,3 +250,79 @@ int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, i
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
 }
+
+
+// ---- row block per wave (bitmm_fp4_rbw.hip.h)
+int qgtc_launch_expand_weights(const qgtc_expand_job *jobs, int n_jobs, hipStream_t st) {
+    ExpandJobs ej{};
+    int most = 0;
+    for (int i = 0; i < n_jobs; i++) {
+        const qgtc_expand_job &j = jobs[i];
+        ej.job[i] = ExpandJob{j.W, j.codes, j.w_words, j.K, j.N, j.w_lines, j.nbits, j.order, (j.N + 31) / 32};
+        most = std::max(most, (j.N + 31) / 32);
+    }
+    hipLaunchKernelGGL(k_expand_weights, dim3(2 * most, n_jobs), dim3(64), 0, st, ej);
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
+int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int N, int a, int ob, const uint32_t *w_codes, hipStream_t st) {
+    RbwShape sh{getenv_flag("QGTC_NO_XCD") ? 0 : 1, a, 0};
+    const dim3 grid(step128(max_M), count), block(256);
+    const u32x4 *wc = reinterpret_cast<const u32x4 *>(w_codes);
+    const int ncb = (N + 31) / 32;
+    if (ob != 2 || a > 2) return QGTC_EINVAL;
+    switch (ncb) {
+        case 1: hipLaunchKernelGGL((k_rbw_xw<2, 2, 1>), grid, block, 0, st, prs, wc, sh); break;
+        case 2: hipLaunchKernelGGL((k_rbw_xw<2, 2, 2>), grid, block, 0, st, prs, wc, sh); break;
+        case 3: hipLaunchKernelGGL((k_rbw_xw<2, 2, 3>), grid, block, 0, st, prs, wc, sh); break;
+        case 4: hipLaunchKernelGGL((k_rbw_xw<2, 2, 4>), grid, block, 0, st, prs, wc, sh); break;
+        default: return QGTC_EINVAL;
+    }
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
+int qgtc_launch_rbw_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int N1, int N2, int t_bits, int act_bits,
+                          int out_bits, int mode2, const uint32_t *w2_codes, hipStream_t st) {
+    (void)t_bits;   // (1- and 2-bit T are the same codes: one base-4 digit per nibble)
+    (void)act_bits;
+    (void)out_bits;
+    RbwShape sh{getenv_flag("QGTC_NO_XCD") ? 0 : 1, 1, 0};
+    const dim3 grid(step128(max_M), count), block(256);
+    const u32x4 *wc = reinterpret_cast<const u32x4 *>(w2_codes);
+    const int c1 = (N1 + 31) / 32, c2 = mode2 == 0 ? 1 : (N2 + 31) / 32;
+#define QGTC_RBW_GO(MODE2_, C1_, C2_) hipLaunchKernelGGL((k_rbw_chain<2, 2, MODE2_, C1_, C2_>), grid, block, 0, st, p1, p2, wc, sh)
+#define QGTC_RBW_C2(MODE2_, C1_)                       \
+    switch (c2) {                                      \
+        case 1: QGTC_RBW_GO(MODE2_, C1_, 1); break;    \
+        case 2: QGTC_RBW_GO(MODE2_, C1_, 2); break;    \
+        case 3: QGTC_RBW_GO(MODE2_, C1_, 3); break;    \
+        default: QGTC_RBW_GO(MODE2_, C1_, 4); break;   \
+    }
+#define QGTC_RBW_C1(MODE2_)                            \
+    switch (c1) {                                      \
+        case 1: QGTC_RBW_C2(MODE2_, 1) break;          \
+        case 2: QGTC_RBW_C2(MODE2_, 2) break;          \
+        case 3: QGTC_RBW_C2(MODE2_, 3) break;          \
+        default: QGTC_RBW_C2(MODE2_, 4) break;         \
+    }
+    if (c1 < 1 || c1 > 4 || c2 < 1 || c2 > 4) return QGTC_EINVAL;
+    if (mode2 == 0) {
+        switch (c1) {
+            case 1: QGTC_RBW_GO(0, 1, 1); break;
+            case 2: QGTC_RBW_GO(0, 2, 1); break;
+            case 3: QGTC_RBW_GO(0, 3, 1); break;
+            default: QGTC_RBW_GO(0, 4, 1); break;
+        }
+    } else if (mode2 == 1) {
+        QGTC_RBW_C1(1)
+    } else {
+        QGTC_RBW_C1(2)
+    }
+#undef QGTC_RBW_C1
+#undef QGTC_RBW_C2
+#undef QGTC_RBW_GO
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}

@@ -113,6 +113,7 @@ static bool stages_ok(const qgtc_stage *stages, int n_stages, int n_weights) {
         if ((st.K <= 0 && st.K != QGTC_DIM_NODES) || st.N <= 0) return false;
         if (!bits_ok(st.bit1) || !bits_ok(st.bit2) || st.mode < 0 || st.mode > 2 || (st.mode != 2 && !bits_ok(st.ob))) return false;
         if (st.use_occ && st.left != QGTC_SRC_A) return false;
+        if (st.fmt != 0 && (st.fmt != 1 || st.mode != 1)) return false;
     }
     return true;
 }

@@ -58,6 +58,7 @@
 #include "bitmm_fp4_strip.hip.h"
 #include "bitmm_fp4_rows.hip.h"
 #include "bitmm_fp4_chain.hip.h"
+#include "bitmm_fp4_rbw.hip.h"
 #define QGTC_LAYER_MFMA 1
 #define QGTC_LAYER_WAVE 1
 #include "bitmm_layer.hip.h"
@@ -381,6 +382,49 @@ int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stag
     return qgtc_bitmm_batched(stage_xw, count, max_M, max_N1, max_N2, act_bits, w_bits, out_mode == 2 ? 1 : out_bits, out_mode, flags & ~QGTC_ZERO_JUMP, stream);
 }
 
+size_t qgtc_weight_codes_words(int N) { return N > 0 ? static_cast<size_t>((N + 31) / 32) * 2u * 64u * 4u : 0u; }
+
+size_t qgtc_chain_words(int M, int N) { return (M > 0 && N > 0) ? static_cast<size_t>(step128(M)) * pad128(N) * 16u : 0u; }
+
+int qgtc_expand_weights(const qgtc_expand_job *jobs, int n_jobs, void *stream) {
+    if (!jobs || n_jobs <= 0 || n_jobs > QGTC_MAX_WEIGHTS) return QGTC_EINVAL;
+    for (int i = 0; i < n_jobs; i++) {
+        const qgtc_expand_job &j = jobs[i];
+        if (!j.W || !j.codes || j.K <= 0 || j.N <= 0 || j.N > 128 || j.nbits < 1 || j.nbits > 2 || j.w_lines < j.N || (j.order != 0 && j.order != 1)) return QGTC_EINVAL;
+        if (j.order == 0 && j.K > 128) return QGTC_EINVAL;
+        if (!aligned16(j.codes)) return QGTC_EALIGN;
+    }
+    return qgtc_launch_expand_weights(jobs, n_jobs, static_cast<hipStream_t>(stream));
+}
+
+int qgtc_chain_transform(const qgtc_problem *stage, int count, int max_M, int K, int N, int x_bits, int out_bits,
+                         const uint32_t *w_codes, unsigned flags, void *stream) {
+    if (!stage || !w_codes || count <= 0 || count > 65535 || max_M <= 0) return QGTC_EINVAL;
+    if (!rbw_xw_ok(K, N, x_bits, out_bits) || getenv_flag("QGTC_NO_RBW")) return QGTC_EINVAL;
+    if (!aligned16(w_codes)) return QGTC_EALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (flags & QGTC_CHECK_DESCRIPTORS) {
+        const int crc = qgtc_launch_check_descriptors(stage, nullptr, count, max_M, K, N, 0, 0, 0, st);
+        if (crc != QGTC_OK) return crc;
+    }
+    return qgtc_launch_rbw_xw(stage, count, max_M, N, x_bits, out_bits, w_codes, st);
+}
+
+int qgtc_chain_aggregate(const qgtc_problem *stage_a, const qgtc_problem *stage_xw, int count, int max_M, int max_K, int N1,
+                         int N2, int t_bits, int act_bits, int out_bits, int out_mode, const uint32_t *w2_codes,
+                         unsigned flags, void *stream) {
+    if (!stage_a || count <= 0 || count > 65535 || max_M <= 0) return QGTC_EINVAL;
+    if (out_mode < 0 || out_mode > 2 || (out_mode != 0 && (!stage_xw || !w2_codes))) return QGTC_EINVAL;
+    if (!rbw_chain_ok(max_K, N1, N2, t_bits, act_bits, out_bits, out_mode) || getenv_flag("QGTC_NO_RBW")) return QGTC_EINVAL;
+    if (w2_codes && !aligned16(w2_codes)) return QGTC_EALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (flags & QGTC_CHECK_DESCRIPTORS) {
+        const int crc = qgtc_launch_check_descriptors(stage_a, nullptr, count, max_M, max_K, N1, 0, 0, 0, st);
+        if (crc != QGTC_OK) return crc;
+    }
+    return qgtc_launch_rbw_chain(stage_a, out_mode == 0 ? nullptr : stage_xw, count, max_M, N1, N2, t_bits, act_bits, out_bits, out_mode, w2_codes, st);
+}
+
 size_t qgtc_occupancy_words(int M, int K) {
     return static_cast<size_t>((M + TM - 1) / TM) * ((step128(K) + 63) / 64);
 }
@@ -493,3 +537,7 @@ int qgtc_i8gemm_profile(const int8_t *A, const int8_t *Bt, int M, int K, int N, 
 }
 
 }  // extern "C"
+
+#ifdef QGTC_SINGLE_TU   // tools/*.hip: the plan / check translation unit too
+#include "qgtc_epoch.hip"
+#endif

@@ -753,10 +753,13 @@ struct EpochPlan {
     std::vector<torch::Tensor> weights;
     torch::Tensor pool, descs;
     struct Launch {
-        int kind;        // 0 grouped GEMM, 1 chained pair (qgtc_gcn_chain_batched), 2 layer (qgtc_gcn_layer_batched, two launches)
+        int kind;        // 0 grouped GEMM, 1 chained pair (qgtc_gcn_chain_batched), 2 layer (qgtc_gcn_layer_batched, two launches),
+                         // 3 qgtc_chain_transform (s1), 4 qgtc_chain_aggregate (s1, and s2 unless it is the float32 aggregation: s2 < 0)
         int s1, s2;
         unsigned extra;  // QGTC_CHAIN_* flags
+        int codes;       // kinds 3 / 4: index of the pre-expanded weight (weight_codes)
     };
+    std::vector<torch::Tensor> weight_codes;   // qgtc_expand_weights outputs, made by bind()
     std::vector<Launch> launches;
     std::vector<uint64_t> offsets;      // lazily: word offset of every (stage, batch) output in the pool
     static constexpr double kJumpBelow = BatchedGemm::kJumpBelow;
@@ -829,13 +832,15 @@ struct EpochPlan {
     }
 
     // stages: (left, right, K, N, bit1, bit2, ob, mode, pad128, use_occ) per operator; launches: (kind, s1, s2, extra flags)
-    void bind(std::vector<torch::Tensor> weights_, std::vector<std::array<int, 10>> stages_, std::vector<std::array<int, 4>> launches_) {
+    // expand: (weight index, K, N, nbits, order) per pre-expanded weight the launches of kinds 3 / 4 name
+    void bind(std::vector<torch::Tensor> weights_, std::vector<std::array<int, 11>> stages_, std::vector<std::array<int, 5>> launches_,
+              std::vector<std::array<int, 5>> expand) {
         c10::DeviceGuard guard(batches.device());
         const int ns = static_cast<int>(stages_.size()), nw = static_cast<int>(weights_.size());
         TORCH_CHECK(ns >= 1 && ns <= QGTC_MAX_STAGES && nw <= QGTC_MAX_WEIGHTS, "too many stages / weights");
         stages.clear();
         for (const auto &t : stages_)
-            stages.push_back(qgtc_stage{t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]});
+            stages.push_back(qgtc_stage{t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10]});
         qgtc_operand wops[QGTC_MAX_WEIGHTS];
         for (int k = 0; k < nw; k++) {
             const torch::Tensor &w = weights_[k];
@@ -846,14 +851,31 @@ struct EpochPlan {
         }
         weights = std::move(weights_);
         launches.clear();
+        const auto dev = batches.device();
+        weight_codes.clear();
+        if (!expand.empty()) {   // every pre-expanded weight of the plan in ONE launch
+            TORCH_CHECK(expand.size() <= QGTC_MAX_WEIGHTS, "too many pre-expanded weights");
+            qgtc_expand_job jobs[QGTC_MAX_WEIGHTS];
+            for (size_t i = 0; i < expand.size(); i++) {
+                const auto &e = expand[i];
+                TORCH_CHECK(e[0] >= 0 && e[0] < nw, "bad weight index");
+                const torch::Tensor &w = weights[e[0]];
+                torch::Tensor codes = torch::empty({static_cast<int64_t>(qgtc_weight_codes_words(e[2]))}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
+                jobs[i] = qgtc_expand_job{words(w), words_mut(codes), static_cast<uint64_t>(w.numel()), e[1], e[2], e[3],
+                                          static_cast<int32_t>(w.numel() / (static_cast<int64_t>(e[3]) * S128(e[1]) * 4)), e[4], 0};
+                weight_codes.push_back(codes);
+            }
+            check_rc(qgtc_expand_weights(jobs, static_cast<int>(expand.size()), current_stream(batches)), "EpochPlan.bind (weights)");
+        }
         for (const auto &l : launches_) {
-            TORCH_CHECK(l[0] >= 0 && l[0] <= 2 && l[1] >= 0 && l[1] < ns && (l[0] == 0 || (l[2] >= 0 && l[2] < ns)), "bad launch entry");
-            launches.push_back(Launch{l[0], l[1], l[2], static_cast<unsigned>(l[3])});
+            TORCH_CHECK(l[0] >= 0 && l[0] <= 4 && l[1] >= 0 && l[1] < ns, "bad launch entry");
+            TORCH_CHECK(l[0] == 0 || l[0] == 3 || (l[0] == 4 && l[2] < 0) || (l[2] >= 0 && l[2] < ns), "bad launch entry");
+            TORCH_CHECK(l[0] < 3 || (l[0] == 4 && l[2] < 0) || (l[4] >= 0 && l[4] < static_cast<int>(weight_codes.size())), "bad weight-codes index");
+            launches.push_back(Launch{l[0], l[1], l[2], static_cast<unsigned>(l[3]), l[4]});
         }
         offsets.clear();
         const size_t pool_words = qgtc_epoch_pool_layout(nodes.data(), count, stages.data(), ns, nullptr);
         TORCH_CHECK(pool_words > 0 && pool_words < (1ull << 40), "bad pool size");
-        const auto dev = batches.device();
         pool = torch::empty({static_cast<int64_t>(pool_words)}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
         descs = torch::empty({static_cast<int64_t>(ns) * count * static_cast<int64_t>(sizeof(qgtc_problem))}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
         check_rc(qgtc_epoch_plan_fill(reinterpret_cast<const qgtc_batch *>(batches.data_ptr()), count, stages.data(), ns, wops, nw,
@@ -875,6 +897,20 @@ struct EpochPlan {
             const qgtc_stage &a = stages[l.s1], &x = stages[l.s2];
             check_rc(qgtc_gcn_chain_batched(stage_descs(l.s1), stage_descs(l.s2), count, max_n, dimK(a), a.N, x.N, a.bit1, a.bit2, a.ob, x.bit2, x.ob,
                                             x.mode, base | ((a.use_occ && jumping) ? QGTC_ZERO_JUMP : 0u) | l.extra, st), "EpochPlan.run (chained pair)");
+        } else if (l.kind == 3) {
+            const qgtc_stage &a = stages[l.s1];
+            check_rc(qgtc_chain_transform(stage_descs(l.s1), count, max_n, dimK(a), a.N, a.bit1, a.ob, words(weight_codes[l.codes]), check, st),
+                     "EpochPlan.run (chain transform)");
+        } else if (l.kind == 4) {
+            const qgtc_stage &a = stages[l.s1];
+            if (l.s2 < 0) {
+                check_rc(qgtc_chain_aggregate(stage_descs(l.s1), nullptr, count, max_n, dimK(a), a.N, 0, a.bit2, 0, 0, 0, nullptr, check, st),
+                         "EpochPlan.run (chain aggregate, float32)");
+            } else {
+                const qgtc_stage &x = stages[l.s2];
+                check_rc(qgtc_chain_aggregate(stage_descs(l.s1), stage_descs(l.s2), count, max_n, dimK(a), a.N, x.N, a.bit2, a.ob, x.ob, x.mode,
+                                              words(weight_codes[l.codes]), check, st), "EpochPlan.run (chain aggregate)");
+            }
         } else {
             const qgtc_stage &a = stages[l.s1], &b = stages[l.s2];
             check_rc(qgtc_gcn_layer_batched(stage_descs(l.s1), stage_descs(l.s2), count, max_n, dimK(a), dimK(b), std::max(a.N, b.N), a.bit1, a.bit2, a.ob,
@@ -906,6 +942,7 @@ struct EpochPlan {
             qgtc_epoch_pool_layout(nodes.data(), count, stages.data(), static_cast<int>(stages.size()), offsets.data());
         }
         const qgtc_stage &st = stages[s];
+        TORCH_CHECK(st.fmt == 0, "stage ", s, " is kept in the chain's private format");
         std::vector<torch::Tensor> v;
         for (int b = 0; b < count; b++) {
             const int64_t off = static_cast<int64_t>(offsets[static_cast<size_t>(s) * count + b]);
@@ -1014,8 +1051,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     py::class_<EpochPlan, std::shared_ptr<EpochPlan>>(m, "EpochPlan")
         .def(py::init<std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<int>, int, bool>(),
              py::arg("As"), py::arg("Xs"), py::arg("Xrs"), py::arg("nodes"), py::arg("a_bits") = 1, py::arg("zero_jump") = true)
-        .def("bind", &EpochPlan::bind, py::arg("weights"), py::arg("stages"), py::arg("launches"),
-             "weights: packed tensors; stages: (left, right, K, N, bit1, bit2, ob, mode, pad128, use_occ); launches: (kind, s1, s2, flags)")
+        .def("bind", &EpochPlan::bind, py::arg("weights"), py::arg("stages"), py::arg("launches"), py::arg("expand") = std::vector<std::array<int, 5>>(),
+             "weights: packed tensors; stages: (left, right, K, N, bit1, bit2, ob, mode, pad128, use_occ, fmt); launches: (kind, s1, s2, flags, "
+             "codes); expand: (weight, K, N, nbits, order) per pre-expanded weight")
         .def("run", &EpochPlan::run)
         .def("run_checked", &EpochPlan::run_checked)
         .def("run_launch", [](EpochPlan &p, int i) {

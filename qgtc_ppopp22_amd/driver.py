@@ -289,8 +289,15 @@ class BatchedEpoch:
 
 def stage_recipes(Q, chain: str, run_gin: bool, F: int, H: int, C: int, b: int):
     """The six operators of an epoch (main_qgtc.py:131-154; the layout-correct forms as unitest.py:100-109 builds them) as
-    qgtc_stage tuples (left, right, K, N, bit1, bit2, ob, mode, pad128, use_occ) for Q.EpochPlan.bind; weights are
+    qgtc_stage tuples (left, right, K, N, bit1, bit2, ob, mode, pad128, use_occ, fmt) for Q.EpochPlan.bind; weights are
     [W1, W2, W3, W3h]."""
+    A, X, XR, N_ = Q.SRC_A, Q.SRC_X, Q.SRC_XR, Q.DIM_NODES
+    W = lambda k: Q.SRC_WEIGHT + k          # noqa: E731
+    S = lambda j: Q.SRC_STAGE + j           # noqa: E731
+    return [t + (0,) for t in _stage_recipes(Q, chain, run_gin, F, H, C, b)]
+
+
+def _stage_recipes(Q, chain, run_gin, F, H, C, b):
     A, X, XR, N_ = Q.SRC_A, Q.SRC_X, Q.SRC_XR, Q.DIM_NODES
     W = lambda k: Q.SRC_WEIGHT + k          # noqa: E731
     S = lambda j: Q.SRC_STAGE + j           # noqa: E731
@@ -319,31 +326,43 @@ class PlannedEpoch:
         self.data = data
         self.final = 5
         stages = stage_recipes(Q, chain, run_gin, F, H, C, b)
-        launches = [(0, i, 0, 0) for i in range(6)]
+        launches = [(0, i, 0, 0, 0) for i in range(6)]
+        expand = []
         self.discarded = set()
-        if fuse and chain == "correct" and chain_stages:
+        max_n = max(p[0] for p in params)
+        switches = any(k.startswith("QGTC_NO_") for k in os.environ)
+        if (fuse and chain == "correct" and chain_stages and not run_gin and not keep_aggregates and b == 2 and max(F, H, C) <= 128 and max_n <= 8192
+                and Q.get_engine() != "popcount" and not switches):
+            # The 2-bit Cluster-GCN chain on the chain entries (qgtc_chain_transform / qgtc_chain_aggregate): one wave per row
+            # block for the whole width, T between the launches as finished matrix-core operands, weights pre-expanded once
+            # per plan. X.W1 | A.T1 + .W2 | A.T2 + .W3 | A.T3 -> float32: four launches.
+            for i in (0, 2, 4):
+                stages[i] = stages[i][:10] + (1,)
+            expand = [(0, F, H, b, 0), (1, H, H, b, 1), (3, H, C, b, 1)]     # (weight, K, N, bits, order)
+            launches = [(3, 0, 0, 0, 0), (4, 1, 2, 0, 1), (4, 3, 4, 0, 2), (4, 5, -1, 0, 0)]
+            self.discarded = {0, 1, 2, 3, 4}
+        elif fuse and chain == "correct" and chain_stages:
             # an aggregation stage and the NEXT layer's X.W stage are one call (qgtc_gcn_chain_batched), T between the
             # launches of a chain in the kernels' own format where every launch can keep it (see BatchedEpoch)
             pairs = [(1, 2), (3, 4)] if not run_gin else [(0, 1), (2, 3), (4, 5)]
             codes = {}
-            max_n = max(p[0] for p in params)
             if (not keep_aggregates and (b == 2 or (run_gin and b == 4)) and max(F, H, C) <= 128 and max_n <= 8192 and Q.get_engine() != "popcount"
-                    and not any(k.startswith("QGTC_NO_") for k in os.environ)):
+                    and not switches):
                 codes = {0: 2, 2: 3, 4: 1} if run_gin else {0: 2, 1: 3, 3: 3, 5: 1}
             flag = lambda c: ((Q.CHAIN_CODES_IN if c & 1 else 0) | (Q.CHAIN_CODES_OUT if c & 2 else 0))   # noqa: E731
-            first = {i: (1, i, j, (0 if keep_aggregates else Q.CHAIN_DISCARD) | flag(codes.get(i, 0))) for i, j in pairs}
+            first = {i: (1, i, j, (0 if keep_aggregates else Q.CHAIN_DISCARD) | flag(codes.get(i, 0)), 0) for i, j in pairs}
             second = {j for _, j in pairs}
-            launches = [first.get(i, (0, i, 0, flag(codes.get(i, 0)) if codes else 0)) for i in range(6) if i not in second]
+            launches = [first.get(i, (0, i, 0, flag(codes.get(i, 0)) if codes else 0, 0)) for i in range(6) if i not in second]
             self.discarded = set() if keep_aggregates else {i for i, _ in pairs}
             if codes:
                 self.discarded |= {1, 3} if run_gin else {0, 2, 4}
         elif fuse and chain == "correct":
             pairs = [(0, 1), (2, 3), (4, 5)] if not run_gin else [(1, 2), (3, 4)]
-            first = {i: (2, i, j, 0) for i, j in pairs}
+            first = {i: (2, i, j, 0, 0) for i, j in pairs}
             second = {j for _, j in pairs}
-            launches = [first.get(i, (0, i, 0, 0)) for i in range(6) if i not in second]
+            launches = [first.get(i, (0, i, 0, 0, 0)) for i in range(6) if i not in second]
         self.n_launches = len(launches)
-        data.bind([W["W1"], W["W2"], W["W3"], W["W3h"]], [list(t) for t in stages], [list(l) for l in launches])
+        data.bind([W["W1"], W["W2"], W["W3"], W["W3h"]], [list(t) for t in stages], [list(l) for l in launches], [list(e) for e in expand])
 
     def run(self):
         self.data.run()

@@ -190,7 +190,7 @@ class QgtcBatch(ctypes.Structure):
 
 
 class QgtcStage(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_int32) for k in ("left", "right", "K", "N", "bit1", "bit2", "ob", "mode", "pad128", "use_occ")]
+    _fields_ = [(k, ctypes.c_int32) for k in ("left", "right", "K", "N", "bit1", "bit2", "ob", "mode", "pad128", "use_occ", "fmt")]
 
 
 class QgtcPackJob(ctypes.Structure):
@@ -206,7 +206,7 @@ def test_epoch_plan_filled_on_the_device_with_raw_pointers(lib, oracle):
     weights packed in one launch, the descriptors of a layout-correct two-layer GCN slice (X.W1 -> A.T1 -> .W2 -> A.T2 as
     float32) filled by ONE launch from the per-batch table, QGTC_CHECK_DESCRIPTORS on every launch - against the oracle."""
     import torch
-    assert ctypes.sizeof(QgtcBatch) == 64 and ctypes.sizeof(QgtcStage) == 40 and ctypes.sizeof(QgtcPackJob) == 48
+    assert ctypes.sizeof(QgtcBatch) == 64 and ctypes.sizeof(QgtcStage) == 44 and ctypes.sizeof(QgtcPackJob) == 48
     lib.qgtc_val2bit_batched.argtypes = [vp, ctypes.c_int, vp]
     lib.qgtc_epoch_pool_layout.restype = ctypes.c_size_t
     lib.qgtc_epoch_pool_layout.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp]
@@ -246,8 +246,8 @@ def test_epoch_plan_filled_on_the_device_with_raw_pointers(lib, oracle):
         ref.append((t1, h1, t2, oracle.bitmm2int(A, t2, n, n, C, 1, b, True)))
     count = len(ns)
     batches = torch.frombuffer(bytearray(bytes((QgtcBatch * count)(*hb))), dtype=torch.uint8).cuda()
-    stages = (QgtcStage * 4)(QgtcStage(SRC_XR, SRC_WEIGHT + 0, F, H, b, b, b, 1, 0, 0), QgtcStage(SRC_A, SRC_STAGE + 0, DIM_NODES, H, 1, b, b, 0, 0, 0),
-                             QgtcStage(SRC_STAGE + 1, SRC_WEIGHT + 1, H, C, b, b, b, 1, 0, 0), QgtcStage(SRC_A, SRC_STAGE + 2, DIM_NODES, C, 1, b, 1, 2, 1, 0))
+    stages = (QgtcStage * 4)(QgtcStage(SRC_XR, SRC_WEIGHT + 0, F, H, b, b, b, 1, 0, 0, 0), QgtcStage(SRC_A, SRC_STAGE + 0, DIM_NODES, H, 1, b, b, 0, 0, 0, 0),
+                             QgtcStage(SRC_STAGE + 1, SRC_WEIGHT + 1, H, C, b, b, b, 1, 0, 0, 0), QgtcStage(SRC_A, SRC_STAGE + 2, DIM_NODES, C, 1, b, 1, 2, 1, 0, 0))
     weights = (QgtcOperand * 2)(QgtcOperand(dW[0].data_ptr(), dW[0].numel()), QgtcOperand(dW[1].data_ptr(), dW[1].numel()))
     nodes = (ctypes.c_int32 * count)(*ns)
     offs = (ctypes.c_uint64 * (4 * count))()

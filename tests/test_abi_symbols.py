@@ -100,16 +100,21 @@ def test_epoch_pool_layout_and_layer_route_are_host_side(lib, oracle):
     order, each a multiple of four words, sizes = the reference's allocation rules QGTC_device.cu:223,456,507) and the
     route qgtc_gcn_layer_batched would take."""
     class Stage(ctypes.Structure):
-        _fields_ = [(k, ctypes.c_int32) for k in ("left", "right", "K", "N", "bit1", "bit2", "ob", "mode", "pad128", "use_occ")]
+        _fields_ = [(k, ctypes.c_int32) for k in ("left", "right", "K", "N", "bit1", "bit2", "ob", "mode", "pad128", "use_occ", "fmt")]
 
     lib.qgtc_epoch_pool_layout.restype = ctypes.c_size_t
     lib.qgtc_epoch_pool_layout.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.qgtc_chain_words.restype = lib.qgtc_weight_codes_words.restype = ctypes.c_size_t
     ns = [1213, 599, 37, 8, 1]
-    stages = (Stage * 3)(Stage(2, 16, 128, 128, 2, 2, 2, 1, 0, 0), Stage(0, 32, -1, 128, 1, 2, 3, 0, 0, 1), Stage(0, 33, -1, 10, 1, 2, 1, 2, 1, 1))
+    stages = (Stage * 4)(Stage(2, 16, 128, 128, 2, 2, 2, 1, 0, 0, 0), Stage(0, 32, -1, 128, 1, 2, 3, 0, 0, 1, 0), Stage(0, 33, -1, 10, 1, 2, 1, 2, 1, 1, 0),
+                         Stage(2, 16, 128, 100, 2, 2, 2, 1, 0, 0, 1))
     nodes = (ctypes.c_int32 * len(ns))(*ns)
-    offs = (ctypes.c_uint64 * (3 * len(ns)))()
-    total = lib.qgtc_epoch_pool_layout(ctypes.addressof(nodes), len(ns), ctypes.addressof(stages), 3, ctypes.addressof(offs))
-    sizes = [oracle.cols_words(n, 128, 2, False) for n in ns] + [oracle.rows_words(n, 128, 3) for n in ns] + [(n * 10 + 3) // 4 * 4 for n in ns]
+    offs = (ctypes.c_uint64 * (4 * len(ns)))()
+    total = lib.qgtc_epoch_pool_layout(ctypes.addressof(nodes), len(ns), ctypes.addressof(stages), 4, ctypes.addressof(offs))
+    sizes = [oracle.cols_words(n, 128, 2, False) for n in ns] + [oracle.rows_words(n, 128, 3) for n in ns] + [(n * 10 + 3) // 4 * 4 for n in ns] \
+        + [lib.qgtc_chain_words(n, 100) for n in ns]                       # fmt 1: the chain format of qgtc_chain_*
+    assert [lib.qgtc_chain_words(n, 100) for n in ns] == [(n + 127) // 128 * 128 * 16 for n in ns]
+    assert lib.qgtc_weight_codes_words(100) == 4 * 2 * 64 * 4
     assert total == sum(sizes)
     assert list(offs) == [sum(sizes[:i]) for i in range(len(sizes))]
     assert lib.qgtc_epoch_pool_layout(None, 3, ctypes.addressof(stages), 3, None) == 0
