@@ -136,7 +136,7 @@ __global__ __launch_bounds__(1024) void k_epoch_plan_fill(const qgtc_batch *__re
 
 // ------------------------------------------------------------------------------------------
 // QGTC_CHECK_DESCRIPTORS. kind 0: one stage; 1: layer (stage 2's W is stage 1's output); 2: chain (stage 2's X is stage
-// 1's output, K2 = N1). The first violation (lowest problem index, then lowest field code) wins: record = problem * 8 +
+// 1's output, K2 = N1); 3: one stage whose `out` is not used (qgtc_chain_aggregate with a second product). The first violation (lowest problem index, then lowest field code) wins: record = problem * 8 +
 // field, kept with atomicMin (INT_MAX = none).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_check_descriptors(const qgtc_problem *__restrict__ p1, const qgtc_problem *__restrict__ p2, int count,
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_check_descriptors(const qgtc_problem *_
             if (p.M <= 0 || p.M > max_M) field = QGTC_VIOL_M;
             else if (p.K <= 0 || p.K > mk) field = QGTC_VIOL_K;
             else if (p.N <= 0 || p.N > mn) field = QGTC_VIOL_N;
-            else if (!p.X || !p.W || !p.out || (reinterpret_cast<uintptr_t>(p.X) & 15u) || (reinterpret_cast<uintptr_t>(p.W) & 15u) ||
+            else if (!p.X || !p.W || (!p.out && kind != 3) || (reinterpret_cast<uintptr_t>(p.X) & 15u) || (reinterpret_cast<uintptr_t>(p.W) & 15u) ||
                      p.x_words >= (1ull << 30) || p.w_words >= (1ull << 30))
                 field = QGTC_VIOL_POINTER;
         };

@@ -302,3 +302,94 @@ def test_epoch_plan_filled_on_the_device_with_raw_pointers(lib, oracle):
     assert lib.qgtc_epoch_plan_fill(batches.data_ptr(), count, ctypes.addressof(stages), 4, ctypes.addressof(weights), 2, pool.data_ptr(), pool_words,
                                     descs.data_ptr(), st) == 1
     torch.cuda.synchronize()
+
+
+class QgtcExpandJob(ctypes.Structure):
+    _fields_ = [("W", ctypes.c_void_p), ("codes", ctypes.c_void_p), ("w_words", ctypes.c_uint64), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
+                ("nbits", ctypes.c_int32), ("w_lines", ctypes.c_int32), ("order", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+@pytest.mark.parametrize("M,K,F,H,C,bitmaps", [(333, 333, 48, 128, 10, True), (150, 150, 128, 64, 128, False), (300, 150, 32, 100, 33, True),
+                                               (150, 300, 100, 33, 70, True), (1213, 1213, 128, 128, 128, True), (40, 40, 7, 5, 3, False)])
+def test_chain_entries_with_raw_descriptors(lib, oracle, M, K, F, H, C, bitmaps):
+    """qgtc_expand_weights + qgtc_chain_transform + qgtc_chain_aggregate through ctypes: T = requant(X . W1) in the chain's
+    private format, T' = requant(requant(A . T) . W2) (out_mode 1), then float32(A2 . T') (out_mode 0) and
+    float32(requant(A . T) . W2) (out_mode 2) against the oracle's public operators. Ragged sizes, widths that are not
+    multiples of 32, non-square adjacencies (the diagonal k-quad does not exist for every row group), with and without
+    occupancy bitmaps, three batches per launch."""
+    import torch
+    b = 2
+    lib.qgtc_weight_codes_words.restype = lib.qgtc_chain_words.restype = lib.qgtc_occupancy_words.restype = ctypes.c_size_t
+    lib.qgtc_expand_weights.argtypes = [vp, ctypes.c_int, vp]
+    lib.qgtc_chain_transform.argtypes = [vp, ctypes.c_int] + [ctypes.c_int] * 5 + [vp, ctypes.c_uint, vp]
+    lib.qgtc_chain_aggregate.argtypes = [vp, vp, ctypes.c_int] + [ctypes.c_int] * 8 + [vp, ctypes.c_uint, vp]
+    lib.qgtc_tile_occupancy.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+    rng = np.random.default_rng(M + 3 * K + F)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P128 = lambda x: (x + 127) // 128 * 128   # noqa: E731
+    W1, W2 = oracle.pack(rand_q(rng, F, H, b), b, True), oracle.pack(rand_q(rng, H, C, b), b, True)
+    dW1, dW2 = torch.from_numpy(W1.view(np.int32)).cuda(), torch.from_numpy(W2.view(np.int32)).cuda()
+    c1 = torch.full((int(lib.qgtc_weight_codes_words(H)),), -1, dtype=torch.int32, device="cuda")
+    c2 = torch.full((int(lib.qgtc_weight_codes_words(C)),), -1, dtype=torch.int32, device="cuda")
+    jobs = (QgtcExpandJob * 2)(QgtcExpandJob(dW1.data_ptr(), c1.data_ptr(), dW1.numel(), F, H, b, P128(H), 0, 0),
+                               QgtcExpandJob(dW2.data_ptr(), c2.data_ptr(), dW2.numel(), H, C, b, P128(C), 1, 0))
+    assert lib.qgtc_expand_weights(ctypes.addressof(jobs), 2, st) == 0
+    count = 3
+    keep, s_x, s_a, s_xw, s_a2, s_f, want = [dW1, dW2, c1, c2], [], [], [], [], [], []
+    for i in range(count):
+        k = max(1, K - 17 * i)          # ragged batches
+        m = max(1, M - 29 * i)
+        qx = rand_q(rng, k, F, b)
+        qa = (rng.random((m, k)) < 0.04).astype(np.int32)
+        qa[:, (k // 2):(k // 2 + k // 4)] = 0                      # whole k-quads of zeros for the bitmaps to name
+        qa2 = (rng.random((m, m)) < 0.05).astype(np.int32)
+        X, A, A2 = oracle.pack(qx, b, False), oracle.pack(qa, 1, False), oracle.pack(qa2, 1, False)
+        dX, dA, dA2 = (torch.from_numpy(t.view(np.int32)).cuda() for t in (X, A, A2))
+        T = torch.full((int(lib.qgtc_chain_words(k, H)),), -1, dtype=torch.int32, device="cuda")
+        T2 = torch.full((int(lib.qgtc_chain_words(m, C)),), -1, dtype=torch.int32, device="cuda")
+        out0 = torch.full((m * C,), -7.0, dtype=torch.float32, device="cuda")
+        out2 = torch.full((m * C,), -7.0, dtype=torch.float32, device="cuda")
+        occ = occ2 = None
+        if bitmaps:
+            occ = torch.empty(int(lib.qgtc_occupancy_words(m, k)), dtype=torch.int64, device="cuda")
+            occ2 = torch.empty(int(lib.qgtc_occupancy_words(m, m)), dtype=torch.int64, device="cuda")
+            assert lib.qgtc_tile_occupancy(dA.data_ptr(), dA.numel(), m, k, 1, occ.data_ptr(), occ.numel(), st) == 0
+            assert lib.qgtc_tile_occupancy(dA2.data_ptr(), dA2.numel(), m, m, 1, occ2.data_ptr(), occ2.numel(), st) == 0
+        keep += [dX, dA, dA2, T, T2, out0, out2, occ, occ2]
+        ow = lambda kk: (((kk + 127) // 128) + 63) // 64      # noqa: E731
+        s_x.append(QgtcProblem(dX.data_ptr(), dW1.data_ptr(), T.data_ptr(), dX.numel(), dW1.numel(), k, F, H, P128(H), 0, None))
+        s_a.append(QgtcProblem(dA.data_ptr(), T.data_ptr(), None, dA.numel(), T.numel(), m, k, H, P128(H), ow(k) if bitmaps else 0, occ.data_ptr() if bitmaps else None))
+        s_xw.append(QgtcProblem(None, dW2.data_ptr(), T2.data_ptr(), 0, dW2.numel(), m, H, C, P128(C), 0, None))
+        s_f.append(QgtcProblem(None, dW2.data_ptr(), out2.data_ptr(), 0, dW2.numel(), m, H, C, P128(C), 0, None))
+        s_a2.append(QgtcProblem(dA2.data_ptr(), T2.data_ptr(), out0.data_ptr(), dA2.numel(), T2.numel(), m, m, C, P128(C), ow(m) if bitmaps else 0, occ2.data_ptr() if bitmaps else None))
+        t_o = oracle.bitmm2bit(X, W1, k, F, H, b, b, b, col=True)
+        h_o = oracle.bitmm2bit(A, t_o, m, k, H, 1, b, b)
+        t2_o = oracle.bitmm2bit(h_o, W2, m, H, C, b, b, b, col=True)
+        want.append((out0, oracle.bitmm2int(A2, t2_o, m, m, C, 1, b, True), out2, oracle.bitmm2int(h_o, W2, m, H, C, b, b, True)))
+    host = (QgtcProblem * (5 * count))(*(s_x + s_a + s_xw + s_f + s_a2))
+    descs = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
+    d = lambda i: descs.data_ptr() + 72 * count * i       # noqa: E731
+    CHECK = 0x200
+    for rep in range(2):     # (a second pass over the same buffers: nothing depends on what a launch left behind)
+        rc = lib.qgtc_chain_transform(d(0), count, K, F, H, b, b, c1.data_ptr(), CHECK, st)
+        assert rc == 0, lib.qgtc_strerror(rc)
+        rc = lib.qgtc_chain_aggregate(d(1), d(2), count, M, K, H, C, b, b, b, 1, c2.data_ptr(), CHECK, st)
+        assert rc == 0, lib.qgtc_strerror(rc)
+        rc = lib.qgtc_chain_aggregate(d(1), d(3), count, M, K, H, C, b, b, b, 2, c2.data_ptr(), 0, st)
+        assert rc == 0, lib.qgtc_strerror(rc)
+        rc = lib.qgtc_chain_aggregate(d(4), None, count, M, M, C, 0, b, 0, 0, 0, None, CHECK, st)
+        assert rc == 0, lib.qgtc_strerror(rc)
+        torch.cuda.synchronize()
+        for i, (o0, w0, o2, w2) in enumerate(want):
+            np.testing.assert_array_equal(o2.cpu().numpy().reshape(w2.shape), w2, err_msg=f"out_mode 2, batch {i}")
+            np.testing.assert_array_equal(o0.cpu().numpy().reshape(w0.shape), w0, err_msg=f"out_mode 0 after out_mode 1, batch {i}")
+            o0.fill_(-7.0)
+            o2.fill_(-7.0)
+    lib.qgtc_last_batched_violation.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), vp]
+    assert lib.qgtc_last_batched_violation(None, None, st) == 0
+    # outside the entries' range: error codes (callers fall back to qgtc_gcn_chain_batched)
+    assert lib.qgtc_chain_transform(d(0), count, K, 129, H, b, b, c1.data_ptr(), 0, st) == 1          # K > 128
+    assert lib.qgtc_chain_transform(d(0), count, K, F, H, b, 4, c1.data_ptr(), 0, st) == 1            # 4-bit T
+    assert lib.qgtc_chain_aggregate(d(1), d(2), count, M, K, 129, C, b, b, b, 1, c2.data_ptr(), 0, st) == 1
+    assert lib.qgtc_chain_aggregate(d(1), None, count, M, K, H, C, b, b, b, 1, c2.data_ptr(), 0, st) == 1
+    assert lib.qgtc_expand_weights(ctypes.addressof(jobs), 9, st) == 1
