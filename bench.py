@@ -96,9 +96,14 @@ CLOCK_WARMUP_S = 0.3
 
 
 def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams=1):
-    """warmup untimed launches, then EXACTLY `steps` launches between barrier+synchronize pairs.
-    Returns (wall seconds, mean kernel-stream time per launch in seconds from HIP events recorded
-    on the stream the kernels are launched on)."""
+    """warmup untimed launches, then EXACTLY `steps` launches between barrier+synchronize pairs (the contract's timed
+    region: wall seconds), then the SAME `steps` launches once more between two HIP events recorded on the stream the
+    kernels are launched on (the roofline's live launch duration). Returns (wall seconds, mean stream time per launch in
+    seconds, wall seconds of the event-bracketed region).
+    Why two regions: recording the two events INSIDE the timed region costs 11-12 us of its wall clock whatever the host's
+    wait policy (tools/steps20c.py: 84 us with them, 72 us without, for 20 launches that take 63 us on the stream) - the
+    instrument would be a seventh of the measurement. The second region is issued right behind the first, same buffers,
+    same stream; its own wall clock is reported beside `value` (extras) so that the cost of the instrument stays visible."""
     if streams > 1:
         outs = [out] + [torch.empty_like(out) for _ in range(streams - 1)]
         enqueue = lambda n: Q.bitMM2Bit_enqueue_streams(outs, bit_A, bit_X, M, K, N, 1, w, w, n)  # noqa: E731
@@ -119,13 +124,19 @@ def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    enqueue(steps)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    # the same region again, bracketed by HIP events on the launch stream
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
     ev0.record()
     enqueue(steps)
     ev1.record()
     torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    barrier()
-    return t1 - t0, ev0.elapsed_time(ev1) * 1e-3 / steps
+    t3 = time.perf_counter()
+    return t1 - t0, ev0.elapsed_time(ev1) * 1e-3 / steps, t3 - t2
 
 
 def cpu_baseline(M, K, N, w, A, X, budget_s):
@@ -472,13 +483,13 @@ def main():
     with engine(Q, args.engine):
         out_e = Q.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w)
         assert torch.equal(out_e, out), "engines disagree"
-        wall, kern = time_steps(Q, out_e, bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams)
+        wall, kern, wall_ev = time_steps(Q, out_e, bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams)
     # the same headline launches on the other engine (identical words), measured back to back with the headline
     # (before the CPU baseline occupies every host core)
     other_engine, other_headline = ("popcount" if args.engine != "popcount" else "auto"), None
     if rank == 0 and world == 1 and not args.no_extras:
         with engine(Q, other_engine):
-            o_wall, o_kern = time_steps(Q, torch.empty_like(out), bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams)
+            o_wall, o_kern, _ = time_steps(Q, torch.empty_like(out), bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams)
         other_headline = {"TOPS": round(args.steps * 2.0 * M * K * N / o_wall / 1e12, 3), "us_per_launch": round(o_kern * 1e6, 3)}
     # what runs at this shape: the FP4 matrix-core kernel for narrow right operands (launch.hip.h: skinny_ok -
     # N <= 64, at most 2 x 8 planes, float32 sums exact: K (2^a - 1)(2^w - 1) < 2^24)
@@ -520,8 +531,10 @@ def main():
                     "achieved": round(algo_bytes / kern / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac_hbm,
                     "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes),
                     "avg_launch_us": round(kern * 1e6, 3),
-                    "avg_launch_source": "HIP events on the launch stream around the timed steps, divided by the steps: kernel + "
-                                         "dependent-launch gap (~1.5 us), i.e. what a caller gets per launch",
+                    "avg_launch_source": "HIP events on the launch stream around the same K steps issued once more right behind the timed "
+                                         "region (inside it the two event records cost 11-12 us of a 72 us window), divided by the "
+                                         "steps: kernel + dependent-launch gap (~1.5 us), i.e. what a caller gets per launch",
+                    "wall_ms_per_step_of_the_event_bracketed_region": round(wall_ev * 1e3 / args.steps, 6),
                     "frac_hbm": frac_hbm, "frac_mfma": round(eff_ops / kern / 1e12 / FP4_PEAK_TFLOPS, 5),
                     "floors_us": {"hbm": round(hbm_floor_us, 3), "mfma_fp4": round(mfma_floor_us, 3)},
                     "rocprof": rocprof,

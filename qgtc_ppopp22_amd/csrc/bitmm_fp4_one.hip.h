@@ -144,18 +144,19 @@ __global__ __launch_bounds__(64 * ONE_WAVES) void k_bitmm_fp4_one(
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(outp, 0, static_cast<int>(out_bytes), 0x00020000);
     const uint32_t sh = 12u - 4u * static_cast<uint32_t>(g);
     if (worker) {
-#pragma unroll
-        for (int i = 0; i < RF; i++)
-#pragma unroll
-            for (int j = 0; j < CF; j++) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
         ONE_STAMP(1);
         uint32_t any = 0u;
 #pragma unroll
         for (int i = 0; i < RF; i++)
 #pragma unroll
             for (int p = 0; p < NA; p++) any |= (xr[i][p].x | xr[i][p].y) | (xr[i][p].z | xr[i][p].w);
-        if (!zero_skip || __ballot(any != 0u) != 0ull) {   // wave-uniform: an all-zero (tile rows) x 512-bit X tile is skipped
+        const bool mult = !zero_skip || __ballot(any != 0u) != 0ull;   // wave-uniform: an all-zero (tile rows) x 512-bit X tile is skipped
+        if (!mult) {
+#pragma unroll
+            for (int i = 0; i < RF; i++)
+#pragma unroll
+                for (int j = 0; j < CF; j++) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        } else {
             uint32_t xo[RF][NDA][4][4], wo[4][4];
             int xs[RF][NDA][4], ws[4];
 #pragma unroll
@@ -169,16 +170,22 @@ __global__ __launch_bounds__(64 * ONE_WAVES) void k_bitmm_fp4_one(
                     one_expand<NW>(wr[j], dw, wo, ws);
 #pragma unroll
                     for (int s = 0; s < 4; s++) {
-                        const i32x8 b8 = {static_cast<int>(wo[s][0]), static_cast<int>(wo[s][1]), static_cast<int>(wo[s][2]), static_cast<int>(wo[s][3]), 0, 0, 0, 0};
+                        // (an FP4 operand is the first 128 bits of the instruction's 256-bit register tuple: the upper half
+                        // stays undefined - zeros there were four v_mov per operand)
+                        const i32x4 b4 = {static_cast<int>(wo[s][0]), static_cast<int>(wo[s][1]), static_cast<int>(wo[s][2]), static_cast<int>(wo[s][3])};
+                        const i32x8 b8 = __builtin_shufflevector(b4, b4, 0, 1, 2, 3, -1, -1, -1, -1);
 #pragma unroll
                         for (int i = 0; i < RF; i++)
 #pragma unroll
                             for (int da = 0; da < NDA; da++) {
-                                const i32x8 a8 = {static_cast<int>(xo[i][da][s][0]), static_cast<int>(xo[i][da][s][1]), static_cast<int>(xo[i][da][s][2]), static_cast<int>(xo[i][da][s][3]), 0, 0, 0, 0};
+                                const i32x4 a4 = {static_cast<int>(xo[i][da][s][0]), static_cast<int>(xo[i][da][s][1]), static_cast<int>(xo[i][da][s][2]), static_cast<int>(xo[i][da][s][3])};
+                                const i32x8 a8 = __builtin_shufflevector(a4, a4, 0, 1, 2, 3, -1, -1, -1, -1);
+                                // the accumulators START as the constant C operand of their first MFMA
+                                const f32x4 c = (dw == 0 && s == 0 && da == 0) ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : acc[i][j];
                                 // cbsz = blgp = 4: E2M1 operands. SWAP: D = W-fragment x X-fragment^T, i.e. lane (li, g) register r
                                 // holds C[row 16 i + li][column 16 j + 4 g + r]; else C[row 16 i + 4 g + r][column 16 j + li]
-                                if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b8, a8, acc[i][j], 4, 4, 0, ws[s], 0, xs[i][da][s]);
-                                else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[i][j], 4, 4, 0, xs[i][da][s], 0, ws[s]);
+                                if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b8, a8, c, 4, 4, 0, ws[s], 0, xs[i][da][s]);
+                                else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, c, 4, 4, 0, xs[i][da][s], 0, ws[s]);
                             }
                     }
                 }

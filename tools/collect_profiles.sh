@@ -5,9 +5,9 @@
 # gpurun_out/prof_<tag>/summary_<target>.json; copy what is to be judged into profiles/.
 #   tools/collect_profiles.sh <tag> [targets...]
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 shift
-TARGETS=${@:-headline wide1 wide8k wide2 wide4 epoch epoch_gin pack}
+TARGETS=${@:-headline popcount w8 epoch epoch_gin pack}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 """One kernel family per invocation, for rocprofv3 (tools/collect_profiles.sh):
 
-    python3 tools/profile_targets.py headline|wide1|wide8k|wide2|wide4|epoch|epoch_gin|pack [reps]
+    python3 tools/profile_targets.py headline|popcount|w8|epoch|epoch_gin|pack|wide1|wide8k|wide2|wide4 [reps]
 
 Runs the named workload `reps` times after a warm-up and prints one JSON line with the HIP-event time per launch
 (events recorded on the launch stream), so that the trace's per-kernel averages can be put beside it."""
@@ -26,7 +26,8 @@ def events(fn, reps):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-def gemm_target(M, K, N, w, reps):
+def gemm_target(M, K, N, w, reps, engine="auto"):
+    Q.set_engine(engine)
     g = torch.Generator(device="cpu").manual_seed(3)
     A = (torch.rand((M, K), generator=g) < 0.5).float().cuda()
     X = torch.randint(0, 2 ** w, (K, N), generator=g).float().cuda()
@@ -39,18 +40,21 @@ def gemm_target(M, K, N, w, reps):
 
 
 def epoch_target(gin, reps):
+    """The grouped, layout-correct epoch on its device-filled plan (driver.PlannedEpoch): what bench.py's epoch legs run."""
     from qgtc_ppopp22_amd import driver, graph as G
-    from qgtc_ppopp22_amd.sampler import ClusterIter
     dataset, b, hidden = ("ppi", 4, 64) if gin else ("ogbn-arxiv", 2, 128)
     graph = G.make_graph(dataset, 1500)
     dev = torch.device("cuda:0")
-    it = ClusterIter(dataset, graph, 1500, 20, bit_width=b, run_GIN=gin, device=dev, qgtc=Q, with_rows_X=True)
+    args = driver.build_parser().parse_args(["--dataset", dataset, "--n-hidden", str(hidden), "--bit_width", str(b), "--use_QGTC", "--quiet", "--batched",
+                                             "--chain", "correct"] + (["--run_GIN"] if gin else []))
+    it = driver.make_iter(args, Q, graph)
+    data = it.epoch_data(Q)
     W = driver.pack_weights(Q, graph.feat.shape[1], hidden, 10, b, dev)
-    plan = driver.BatchedEpoch(Q, it.cTensor_li, it.cluster_param_li, W, b, "correct", gin)
+    plan = driver.PlannedEpoch(Q, data, it.cluster_param_li, W, b, "correct", gin)
     us = events(plan.run, reps)
-    stages = [round(events(g.run, reps), 2) for g in plan.stages]
-    return {"workload": f"{dataset}-sized epoch, 75 cluster batches, layout-correct chain, grouped launches",
-            "us_per_epoch_hip_events": round(us, 2), "us_per_stage_hip_events": stages, "epochs": 7 * (reps + 1)}
+    launches = [round(events(lambda i=i: data.run_launch(i), reps), 2) for i in range(plan.n_launches)]
+    return {"workload": f"{dataset}-sized epoch, 75 cluster batches, layout-correct chain, {plan.n_launches} grouped launches (device-filled plan)",
+            "us_per_epoch_hip_events": round(us, 2), "us_per_launch_alone_hip_events": launches, "epochs": (1 + plan.n_launches) * (reps + 1)}
 
 
 def pack_target(reps):
@@ -67,6 +71,15 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     if t == "headline":
         r = gemm_target(4096, 4096, 64, 1, reps)
+    elif t == "popcount":   # the AND + v_bcnt engine BASELINE.json's north star names, same workload
+        r = gemm_target(4096, 4096, 64, 1, reps, engine="popcount")
+        r["valu_peaks"] = {"pair_rate_measured_lane_instr_per_s": 4.2e13, "survey_8d_lane_instr_per_s": 7.864e13,
+                           "note": "bit-ops = 2 M K N a w; one v_and_b32 + v_bcnt_u32_b32 pair = 32 bit-MACs = 64 bit-ops"}
+        bitops = 2.0 * 4096 * 4096 * 64
+        r["valu_frac_of_measured_pair_rate"] = round(bitops / (r["us_per_launch_hip_events"] * 1e-6) / (4.2e13 * 32), 4)
+        r["valu_frac_of_survey_8d_peak"] = round(bitops / (r["us_per_launch_hip_events"] * 1e-6) / (7.864e13 * 32), 4)
+    elif t == "w8":
+        r = gemm_target(4096, 4096, 64, 8, reps)
     elif t == "wide1":
         r = gemm_target(4096, 4096, 1024, 1, reps)
     elif t == "wide8k":
