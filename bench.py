@@ -36,7 +36,14 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 # VALU issue rate of the v_and_b32 + v_bcnt_u32_b32 pair measured on MI355X with
 # tools/valu_peak.hip (4.2e13 lane-instr/s at 8 waves/SIMD); one pair = 32 bit-MACs = 64 bit-ops.
 VALU_PEAK_BITOPS = 4.2e13 * 32
+# SURVEY.md 8(d)'s definition of the same roofline: 256 CUs x 4 SIMDs x 32 lane-instr/clk x 2.4 GHz = 7.864e13 lane-instr/s
+# (an issue rate the v_and + v_bcnt pair does not reach: v_bcnt is VOP3, ~4.2 cycles per wave64 instruction). Both are printed.
+VALU_PEAK_BITOPS_SURVEY = 7.864e13 * 32
 FP4_PEAK_TFLOPS = 10000.0        # MI355X_MICROARCH.md: ~10 PF dense FP4 / FP6 MFMA
+
+
+def eff_ops_of(M, K, N):
+    return 2.0 * M * K * N
 
 
 def parse():
@@ -491,6 +498,10 @@ def main():
         with engine(Q, other_engine):
             o_wall, o_kern, _ = time_steps(Q, torch.empty_like(out), bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams)
         other_headline = {"TOPS": round(args.steps * 2.0 * M * K * N / o_wall / 1e12, 3), "us_per_launch": round(o_kern * 1e6, 3)}
+        if other_engine == "popcount":   # the engine BASELINE.json's north star names, against BOTH statements of its VALU roofline
+            other_headline["valu_frac_of_measured_pair_rate_4.2e13"] = round(eff_ops_of(M, K, N) * w / o_kern / VALU_PEAK_BITOPS, 4)
+            other_headline["valu_frac_of_survey_8d_peak_7.864e13"] = round(eff_ops_of(M, K, N) * w / o_kern / VALU_PEAK_BITOPS_SURVEY, 4)
+            other_headline["rocprof"] = "profiles/r03/summary_popcount.json"
     # what runs at this shape: the FP4 matrix-core kernel for narrow right operands (launch.hip.h: skinny_ok -
     # N <= 64, at most 2 x 8 planes, float32 sums exact: K (2^a - 1)(2^w - 1) < 2^24)
     fp4_kernel = args.engine != "popcount" and w <= 8 and K * (2 ** w - 1) < 2 ** 24
@@ -547,6 +558,8 @@ def main():
                     "avg_launch_us": round(kern * 1e6, 3), "frac_hbm": frac_hbm,
                     "valu": {"achieved_bitops": round(eff_ops * w / kern, 1), "peak_bitops": VALU_PEAK_BITOPS,
                              "frac": round(eff_ops * w / kern / VALU_PEAK_BITOPS, 4),
+                             "peak_bitops_survey_8d": VALU_PEAK_BITOPS_SURVEY,
+                             "frac_of_survey_8d_peak": round(eff_ops * w / kern / VALU_PEAK_BITOPS_SURVEY, 4),
                              "note": "binding roofline of the popcount path: v_and_b32+v_bcnt_u32_b32 issue, peak measured by tools/valu_peak.hip"}}
 
     line = {
@@ -694,8 +707,16 @@ def main():
             graphsage_cpu_epoch(graph, par, 1500, 20, 128, 10, n_batches=2)
             secs, nb = graphsage_cpu_epoch(graph, par, 1500, 20, 128, 10, n_batches=15)
             extras["dgl_style_fp32_cpu_epoch_ms"] = {"value": round(secs * 1e3 * 75 / nb, 2), "cores": torch.get_num_threads(),
-                                                      "sample": f"{nb} of 75 batches, scaled x{75 / nb:.0f}",
+                                                      "sample": f"ogbn-arxiv-sized graph, {nb} of 75 batches, scaled x{75 / nb:.0f}",
                                                       "kind": "port (torch-CPU GraphSAGE-sum x3; DGL not installable)"}
+            # BASELINE.json configs[0] names ppi: the same stand-in on the ppi-sized graph (1_7a_eval_DGL_cluster_GCN.py's dataset)
+            g_ppi = G.make_graph("ppi", 1500)
+            par_ppi = G.partition_list(g_ppi, 1500)
+            graphsage_cpu_epoch(g_ppi, par_ppi, 1500, 20, 128, 10, n_batches=2)
+            secs_p, nb_p = graphsage_cpu_epoch(g_ppi, par_ppi, 1500, 20, 128, 10, n_batches=15)
+            extras["dgl_style_fp32_cpu_epoch_ms_ppi"] = {"value": round(secs_p * 1e3 * 75 / nb_p, 2), "cores": torch.get_num_threads(),
+                                                          "sample": f"ppi-sized graph (BASELINE.json configs[0]), {nb_p} of 75 batches, scaled x{75 / nb_p:.0f}",
+                                                          "kind": "port (torch-CPU GraphSAGE-sum x3; DGL not installable)"}
     if world > 1:
         extras["rank_checksums"] = [float(v) for v in sums.view(-1).tolist()]
     line["extras"] = extras

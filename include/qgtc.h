@@ -282,13 +282,13 @@ int qgtc_val2bit_batched(const qgtc_pack_job *jobs, int n_jobs, void *stream);
  * launch turns `stages` (what each of the epoch's operators multiplies, main_qgtc.py:131-154) into device descriptors:
  * every stage's outputs are carved out of one pool, in batch order, each 16-byte aligned; stage s's descriptors are
  * descs[s * count .. s * count + count - 1].
- *   left / right: where an operand comes from - QGTC_SRC_A / _X / _XR of the batch, QGTC_SRC_WEIGHT + k = weights[k] (shared
+ *   left / right: where an operand comes from - QGTC_SRC_A / _X / _XR / _XC of the batch, QGTC_SRC_WEIGHT + k = weights[k] (shared
  *   by all batches), QGTC_SRC_STAGE + j = the output of stage j < s of the same batch.
  *   M is the batch's node count n; K is `K`, or n when K == QGTC_DIM_NODES; N is `N`.
  *   mode / ob / pad128 as qgtc_bitmm_batched / qgtc_bitmm2int; use_occ: the descriptors carry the batch's bitmap.
  * qgtc_epoch_pool_layout (host only, no device work) gives the pool size in 32-bit words for the same arguments and,
  * optionally, every output's offset (offsets[s * count + b], in words) - the fill kernel uses the same rule. */
-enum { QGTC_SRC_A = 0, QGTC_SRC_X = 1, QGTC_SRC_XR = 2, QGTC_SRC_WEIGHT = 16, QGTC_SRC_STAGE = 32 };
+enum { QGTC_SRC_A = 0, QGTC_SRC_X = 1, QGTC_SRC_XR = 2, QGTC_SRC_XC = 3, QGTC_SRC_WEIGHT = 16, QGTC_SRC_STAGE = 32 };
 #define QGTC_DIM_NODES (-1)
 #define QGTC_MAX_STAGES 8
 #define QGTC_MAX_WEIGHTS 8
@@ -300,6 +300,7 @@ typedef struct qgtc_batch {
     qgtc_operand A;      /* adjacency, rows layout [n, n] */
     qgtc_operand X;      /* features, cols layout [n, F] (a right operand: sampler.py:99) */
     qgtc_operand XR;     /* features, rows layout [n, F] (a left operand), or {NULL, 0} */
+    qgtc_operand XC;     /* features in the chain format of qgtc_chain_* (qgtc_chain_from_cols of X), or {NULL, 0} */
     const uint64_t *occ; /* occupancy bitmap of A (qgtc_tile_occupancy) or NULL */
     int32_t n;           /* nodes of the batch */
     int32_t occ_words;   /* 64-bit words per row tile of `occ` */
@@ -328,19 +329,25 @@ int qgtc_epoch_plan_fill(const qgtc_batch *batches, int count, const qgtc_stage 
  *   qgtc_chain_aggregate:  out_mode 0: out_b = float32(A_b . T_b)                      stage_a[b] = {A_b, T_b, out_b}; stage_xw = NULL
  *                          out_mode 1: T'_b  = requant(requant(A_b . T_b) . W')        stage_a[b] = {A_b, T_b, -}, stage_xw[b] = {-, -, T'_b}
  *                          out_mode 2: out_b = float32(requant(A_b . T_b) . W')        stage_xw[b] = {-, -, out_b [M, N2]}
- * A_b: rows layout, ONE plane, K <= 8192 (occupancy bitmaps of the descriptors are followed); N, N2 <= 128; t_bits /
- * act_bits / out_bits = bits of T / of the aggregate / of T' (2 supported, t_bits also 1); weights: 1 or 2 planes.
+ * A_b: rows layout, ONE plane, K <= 8192 (occupancy bitmaps of the descriptors are followed); t_bits / act_bits /
+ * out_bits = bits of T / of the aggregate / of T': all 2 with N, N2 <= 128 and 1- or 2-plane weights (t_bits also 1), or all
+ * 4 with N, N2 <= 64 and 4-plane weights (Batched-GIN on ppi); qgtc_chain_transform: 2-bit only.
  * QGTC_EINVAL outside that range: callers fall back to qgtc_gcn_chain_batched. w_codes: qgtc_expand_weights order 0 for
  * qgtc_chain_transform (the left operand arrives as packed words), order 1 for qgtc_chain_aggregate (the left operand is
  * the aggregate in the registers of the wave that computed it). max_M is a hard precondition (QGTC_CHECK_DESCRIPTORS). */
 typedef struct qgtc_expand_job {
     const uint32_t *W;   /* cols layout [K, N], nbits planes of w_lines lines */
-    uint32_t *codes;     /* qgtc_weight_codes_words(N) words */
+    uint32_t *codes;     /* qgtc_weight_codes_words(N, nbits) words */
     uint64_t w_words;
     int32_t K, N, nbits, w_lines, order, reserved;
 } qgtc_expand_job;
-size_t qgtc_weight_codes_words(int N);
+size_t qgtc_weight_codes_words(int N, int nbits);
 size_t qgtc_chain_words(int M, int N);
+/* A cols-layout right operand (the public format: X of sampler.py:99, [H, W] with nbits <= 4 planes) in the chain format:
+ * what a data loader does once beside the packing when the epoch's FIRST product is an aggregation (Batched-GIN: A . X,
+ * main_qgtc.py:131). chain: qgtc_chain_words(H, W) words. */
+int qgtc_chain_from_cols(const uint32_t *cols, size_t cols_words, int H, int W, int nbits, uint32_t *chain, size_t chain_words,
+                         void *stream);
 int qgtc_expand_weights(const qgtc_expand_job *jobs, int n_jobs, void *stream);
 int qgtc_chain_transform(const qgtc_problem *stage, int count, int max_M, int K, int N, int x_bits, int out_bits,
                          const uint32_t *w_codes, unsigned flags, void *stream);

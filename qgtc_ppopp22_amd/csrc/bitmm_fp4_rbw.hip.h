@@ -46,7 +46,8 @@ __host__ __device__ constexpr int rbw_column(int m, int fh, int d, int i) {
 // Pre-expanded weights. order 0: the right operand of X . W where X arrives as packed words (K <= 128: one k-quad) - table
 // [column block jn][k half h][lane] of 16 bytes: the codes of word 2 fh + h of line 32 jn + fl (what strip_operand gives).
 // order 1: the right operand of (aggregate) . W' in the register order above - table [jn][m][lane]: dword d nibble i = the
-// value of W'[rbw_column(m, fh, d, i)][32 jn + fl]. Values are the low two planes (2-bit weights: one base-4 digit).
+// value of W'[rbw_column(m, fh, d, i)][32 jn + fl]. One table per base-4 digit (planes 2 dg, 2 dg + 1) of the weight:
+// entry ((jn * 2 + s) * ND + dg) * 64 + lane, ND = ceil(nbits / 2) (1- and 2-bit weights: one digit; 4-bit: two).
 // ------------------------------------------------------------------------------------------
 struct ExpandJob {
     const uint32_t *W;
@@ -71,15 +72,18 @@ __global__ __launch_bounds__(64) void k_expand_weights(ExpandJobs jobs) {
         const size_t wi = p * plane + static_cast<size_t>(n) * line_words + (c >> 5);
         return wi < j.w_words ? (j.W[wi] >> (31 - (c & 31))) & 1u : 0u;
     };
-    uint32_t out[4] = {0u, 0u, 0u, 0u};
-    for (int d = 0; d < 4; d++)
-        for (int i = 0; i < 8; i++) {
-            int c;
-            if (j.order == 0) c = 32 * (2 * fh + s) + 31 - (d + 4 * i);   // bit d + 4 i of word 2 fh + s = element 31 - (d + 4 i)
-            else c = rbw_column(s, fh, d, i);
-            out[d] |= (bit(0, c) | (bit(1, c) << 1)) << (4 * i);
-        }
-    *reinterpret_cast<u32x4 *>(j.codes + (static_cast<size_t>(blockIdx.x) * 64 + lane) * 4) = u32x4{out[0], out[1], out[2], out[3]};
+    const int nd = (j.nbits + 1) / 2;
+    for (int dg = 0; dg < nd; dg++) {
+        uint32_t out[4] = {0u, 0u, 0u, 0u};
+        for (int d = 0; d < 4; d++)
+            for (int i = 0; i < 8; i++) {
+                int c;
+                if (j.order == 0) c = 32 * (2 * fh + s) + 31 - (d + 4 * i);   // bit d + 4 i of word 2 fh + s = element 31 - (d + 4 i)
+                else c = rbw_column(s, fh, d, i);
+                out[d] |= (bit(2 * dg, c) | (bit(2 * dg + 1, c) << 1)) << (4 * i);
+            }
+        *reinterpret_cast<u32x4 *>(j.codes + ((static_cast<size_t>(blockIdx.x) * nd + dg) * 64 + lane) * 4) = u32x4{out[0], out[1], out[2], out[3]};
+    }
 }
 
 // An FP4 MFMA operand from its four dwords: the instruction takes a 256-bit register tuple but reads only the first 128
@@ -96,6 +100,29 @@ __device__ __forceinline__ f32x16 f32x16_zero() {
 #pragma unroll
     for (int r = 0; r < 16; r++) z[r] = 0.0f;
     return z;
+}
+
+// A cols-layout operand (public format: [plane][line n][word], QGTC_device.cu:97) -> the chain format, for right operands
+// the DATA LOADER supplies (Batched-GIN's first product is A . X, main_qgtc.py:131, X packed by sampler.py:99): done once
+// beside the packing. One thread per (k-quad, word, line): nibble i of dword d = sum_p bit (d + 4 i) of plane p's word << p.
+__global__ __launch_bounds__(256) void k_cols_to_chain(const uint32_t *__restrict__ cols, unsigned long long words, int H, int W, int nbits,
+                                                       uint32_t *__restrict__ chain) {
+    const int lines = pad128(W), line_words = step128(H) * 4;
+    const size_t plane = static_cast<size_t>(lines) * line_words, total = static_cast<size_t>(line_words) * lines;
+    for (size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const int n = static_cast<int>(t % lines), wj = static_cast<int>(t / lines);   // wj = 4 q + j
+        uint32_t out[4] = {0u, 0u, 0u, 0u};
+        for (int p = 0; p < nbits && p < 4; p++) {
+            const size_t wi = p * plane + static_cast<size_t>(n) * line_words + wj;
+            const uint32_t r = (n < W && wi < words) ? cols[wi] : 0u;
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t sh = d > p ? r >> (d - p) : (d < p ? r << (p - d) : r);   // bits d + 4 i to bits p + 4 i
+                out[d] |= sh & (0x11111111u << p);
+            }
+        }
+        *reinterpret_cast<u32x4 *>(chain + (static_cast<size_t>(wj) * lines + n) * 4) = u32x4{out[0], out[1], out[2], out[3]};
+    }
 }
 
 struct RbwShape {
@@ -116,7 +143,7 @@ __device__ __forceinline__ void rbw_ids(const RbwShape &sh, int &grp, int &batch
 // 16 re-quantised values (low OB bits of each byte of P) -> the two code dwords of a column block (see rbw_column)
 template <int OB>
 __device__ __forceinline__ void rbw_nibbles(const uint32_t (&P)[4], uint32_t &A, uint32_t &B) {
-    constexpr uint32_t mask = OB == 1 ? 0x01010101u : 0x03030303u;
+    constexpr uint32_t mask = OB == 1 ? 0x01010101u : (OB == 2 ? 0x03030303u : 0x0f0f0f0fu);
     A = (P[0] & mask) | ((P[1] & mask) << 4);
     B = (P[2] & mask) | ((P[3] & mask) << 4);
 }
@@ -228,7 +255,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     //    a cluster batch's adjacency is block-diagonal-dominant - their occupancy words almost always name k-quad grp. Every
     //    wave loading it for itself is 16 load instructions x 1 KB per wave, and the CU's one address unit (64 bytes a clock)
     //    was where the waves queued (in-kernel stamps: 2.4 k cycles from the occupancy word to the last load issued).
-    __shared__ __attribute__((aligned(16))) u32x4 w2_lds[MODE2 == 0 ? 1 : NCB2 * 2 * 64];
+    constexpr int ND = OB > 2 ? 2 : 1;   // base-4 digits of the aggregate's values and of W' (the epochs' widths: 2 / 2 or 4 / 4 bits)
+    __shared__ __attribute__((aligned(16))) u32x4 w2_lds[MODE2 == 0 ? 1 : NCB2 * 2 * ND * 64];
     __shared__ __attribute__((aligned(16))) u32x4 t_lds[4 * 128];   // [word t of the k-quad][line n]
     const int kq = step128(K);
     const int lines = 128;   // pad128(N), N <= 128
@@ -246,9 +274,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             td[i] = __builtin_amdgcn_raw_buffer_load_b128(rt, diag_ok ? (static_cast<uint32_t>(grp) * 512u + static_cast<uint32_t>(tid + 256 * i)) * 16u : 0xffffffffu, 0, 0);
         if constexpr (MODE2 != 0) {
 #pragma unroll
-            for (int i = 0; i < (NCB2 * 2 * 64 + 255) / 256; i++) {
+            for (int i = 0; i < (NCB2 * 2 * ND * 64 + 255) / 256; i++) {
                 const int e = i * 256 + tid;
-                if (e < NCB2 * 2 * 64 && ((e >> 6) & 1) < MH) w2_lds[e] = w2_codes[e];
+                if (e < NCB2 * 2 * ND * 64 && ((e / (64 * ND)) & 1) < MH) w2_lds[e] = w2_codes[e];
             }
         }
 #pragma unroll
@@ -322,8 +350,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                 const uint32_t xw[1] = {xd[h]};
                 const i32x8 xa = fp4_op(strip_operand<1>(xw, 0));
 #pragma unroll
-                for (int j = 0; j < NCB1; j++)
-                    acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_op(t_lds[(2 * fh + h) * 128 + 32 * j + fl]), xa, h == 0 ? f32x16_zero() : acc[j], 4, 4, 0, 128, 0, 128);
+                for (int j = 0; j < NCB1; j++) {
+                    const u32x4 tc = t_lds[(2 * fh + h) * 128 + 32 * j + fl];
+                    if constexpr (OB <= 2) {
+                        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_op(tc), xa, h == 0 ? f32x16_zero() : acc[j], 4, 4, 0, 128, 0, 128);
+                    } else {   // 4-bit values: two base-4 digits in a nibble
+                        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_op(tc[0] & 0x33333333u, tc[1] & 0x33333333u, tc[2] & 0x33333333u, tc[3] & 0x33333333u), xa,
+                                                                                 h == 0 ? f32x16_zero() : acc[j], 4, 4, 0, 128, 0, 128);
+                        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_op((tc[0] >> 2) & 0x33333333u, (tc[1] >> 2) & 0x33333333u, (tc[2] >> 2) & 0x33333333u, (tc[3] >> 2) & 0x33333333u), xa,
+                                                                                 acc[j], 4, 4, 0, 130, 0, 128);
+                    }
+                }
             }
             RBW_STAMP(4);
             // (The first pair's loads issued AHEAD of the diagonal step - in flight during it - were measured: 151 registers
@@ -381,7 +418,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         return;
     } else {
         // ---- the aggregate's row as the second product's left operand, straight from the registers
-        static_assert(MODE2 == 0 || OB <= 2, "chained second product: 1- and 2-bit aggregates (one base-4 digit per nibble)");
         uint32_t XA[MH][4];
 #pragma unroll
         for (int mm = 0; mm < MH; mm++)
@@ -405,8 +441,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         for (int jn = 0; jn < NCB2; jn++) {
             f32x16 acc2 = f32x16_zero();
 #pragma unroll
-            for (int mm = 0; mm < MH; mm++)
-                acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_op(XA[mm][0], XA[mm][1], XA[mm][2], XA[mm][3]), fp4_op(w2_lds[(jn * 2 + mm) * 64 + lane]), acc2, 4, 4, 0, 128, 0, 128);   // not swapped: lane = column 32 jn + fl of T'
+            for (int mm = 0; mm < MH; mm++) {
+                if constexpr (ND == 1) {
+                    acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_op(XA[mm][0], XA[mm][1], XA[mm][2], XA[mm][3]), fp4_op(w2_lds[(jn * 2 + mm) * 64 + lane]), acc2, 4, 4, 0, 128, 0, 128);   // not swapped: lane = column 32 jn + fl of T'
+                } else {   // 4-bit aggregate x 4-bit W': two base-4 digits each, the E8M0 scales carry 4^(da + dw)
+#pragma unroll
+                    for (int da = 0; da < 2; da++) {
+                        const i32x8 xa = fp4_op((XA[mm][0] >> (2 * da)) & 0x33333333u, (XA[mm][1] >> (2 * da)) & 0x33333333u, (XA[mm][2] >> (2 * da)) & 0x33333333u, (XA[mm][3] >> (2 * da)) & 0x33333333u);
+#pragma unroll
+                        for (int dw = 0; dw < 2; dw++)
+                            acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa, fp4_op(w2_lds[((jn * 2 + mm) * 2 + dw) * 64 + lane]), acc2, 4, 4, 0, 128 + 2 * da, 0, 128 + 2 * dw);
+                    }
+                }
+            }
             const int n2 = 32 * jn + fl;
             if constexpr (MODE2 == 2) {   // float32 rows; branch-free stores (see bitmm_fp4_chain.hip.h: an MFMA reads all lanes' operands)
                 const uint32_t base = n2 < N2 ? (static_cast<uint32_t>(32 * rb) * static_cast<uint32_t>(N2) + static_cast<uint32_t>(n2)) * 4u : 0xffffffffu;

@@ -21,6 +21,7 @@ int qgtc_launch_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count,
 
 // row block per wave (bitmm_fp4_rbw.hip.h), defined in qgtc_fp4.hip
 int qgtc_launch_expand_weights(const qgtc_expand_job *jobs, int n_jobs, hipStream_t st);
+int qgtc_launch_cols_to_chain(const uint32_t *cols, size_t words, int H, int W, int nbits, uint32_t *chain, hipStream_t st);
 int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int N, int a, int ob, const uint32_t *w_codes, hipStream_t st);
 int qgtc_launch_rbw_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int N1, int N2, int t_bits, int act_bits,
                           int out_bits, int mode2, const uint32_t *w2_codes, hipStream_t st);
@@ -192,7 +193,13 @@ inline bool chain_ok(int max_K, int max_N1, int max_N2, int a, int w, int ob, in
 // the chain entries (bitmm_fp4_rbw.hip.h): one wave per row block, T in the chain format, weights pre-expanded
 inline bool rbw_xw_ok(int K, int N, int x_bits, int out_bits) { return K >= 1 && K <= 128 && N >= 1 && N <= 128 && x_bits >= 1 && x_bits <= 2 && out_bits == 2; }
 inline bool rbw_chain_ok(int max_K, int N1, int N2, int t_bits, int act_bits, int out_bits, int mode2) {
-    if (max_K < 1 || max_K > 8192 || N1 < 1 || N1 > 128 || (t_bits != 1 && t_bits != 2)) return false;
+    if (max_K < 1 || N1 < 1) return false;
+    if (t_bits == 4) {   // 4-bit values (two base-4 digits a nibble): the widths of the ppi epochs
+        if (N1 > 64 || static_cast<double>(max_K) * 15.0 >= 16777216.0 || max_K > 8192) return false;
+        if (mode2 == 0) return true;
+        return N2 >= 1 && N2 <= 64 && act_bits == 4 && (mode2 == 2 || out_bits == 4);
+    }
+    if (max_K > 8192 || N1 > 128 || (t_bits != 1 && t_bits != 2)) return false;
     if (mode2 == 0) return true;
     return N2 >= 1 && N2 <= 128 && act_bits == 2 && (mode2 == 2 || out_bits == 2);
 }

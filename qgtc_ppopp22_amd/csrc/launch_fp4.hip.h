@@ -266,6 +266,14 @@ int qgtc_launch_expand_weights(const qgtc_expand_job *jobs, int n_jobs, hipStrea
     return QGTC_OK;
 }
 
+int qgtc_launch_cols_to_chain(const uint32_t *cols, size_t words, int H, int W, int nbits, uint32_t *chain, hipStream_t st) {
+    const size_t total = static_cast<size_t>(step128(H)) * 4u * pad128(W);
+    hipLaunchKernelGGL(k_cols_to_chain, dim3(static_cast<unsigned>(std::min<size_t>((total + 255) / 256, 4096))), dim3(256), 0, st, cols,
+                       static_cast<unsigned long long>(words), H, W, nbits, chain);
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
 int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int N, int a, int ob, const uint32_t *w_codes, hipStream_t st) {
     RbwShape sh{getenv_flag("QGTC_NO_XCD") ? 0 : 1, a, 0};
     const dim3 grid(step128(max_M), count), block(256);
@@ -285,13 +293,27 @@ int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int N, int
 
 int qgtc_launch_rbw_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int N1, int N2, int t_bits, int act_bits,
                           int out_bits, int mode2, const uint32_t *w2_codes, hipStream_t st) {
-    (void)t_bits;   // (1- and 2-bit T are the same codes: one base-4 digit per nibble)
-    (void)act_bits;
+    (void)act_bits;   // (1- and 2-bit T are the same codes: one base-4 digit per nibble)
     (void)out_bits;
     RbwShape sh{getenv_flag("QGTC_NO_XCD") ? 0 : 1, 1, 0};
     const dim3 grid(step128(max_M), count), block(256);
     const u32x4 *wc = reinterpret_cast<const u32x4 *>(w2_codes);
     const int c1 = (N1 + 31) / 32, c2 = mode2 == 0 ? 1 : (N2 + 31) / 32;
+    if (t_bits == 4) {   // the 4-bit chains: N, N' <= 64
+#define QGTC_RBW4_GO(MODE2_, C1_, C2_) hipLaunchKernelGGL((k_rbw_chain<4, 4, MODE2_, C1_, C2_>), grid, block, 0, st, p1, p2, wc, sh)
+        if (c1 > 2 || c2 > 2) return QGTC_EINVAL;
+        if (mode2 == 0) { if (c1 == 1) QGTC_RBW4_GO(0, 1, 1); else QGTC_RBW4_GO(0, 2, 1); }
+        else if (mode2 == 1) {
+            if (c1 == 1) { if (c2 == 1) QGTC_RBW4_GO(1, 1, 1); else QGTC_RBW4_GO(1, 1, 2); }
+            else { if (c2 == 1) QGTC_RBW4_GO(1, 2, 1); else QGTC_RBW4_GO(1, 2, 2); }
+        } else {
+            if (c1 == 1) { if (c2 == 1) QGTC_RBW4_GO(2, 1, 1); else QGTC_RBW4_GO(2, 1, 2); }
+            else { if (c2 == 1) QGTC_RBW4_GO(2, 2, 1); else QGTC_RBW4_GO(2, 2, 2); }
+        }
+#undef QGTC_RBW4_GO
+        HIP_TRY(hipGetLastError());
+        return QGTC_OK;
+    }
 #define QGTC_RBW_GO(MODE2_, C1_, C2_) hipLaunchKernelGGL((k_rbw_chain<2, 2, MODE2_, C1_, C2_>), grid, block, 0, st, p1, p2, wc, sh)
 #define QGTC_RBW_C2(MODE2_, C1_)                       \
     switch (c2) {                                      \

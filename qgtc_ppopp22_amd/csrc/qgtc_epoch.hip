@@ -106,7 +106,7 @@ static bool stages_ok(const qgtc_stage *stages, int n_stages, int n_weights) {
         auto src_ok = [&](int src) {
             if (src >= QGTC_SRC_STAGE) return src - QGTC_SRC_STAGE < s && stages[src - QGTC_SRC_STAGE].mode != 2;
             if (src >= QGTC_SRC_WEIGHT) return src - QGTC_SRC_WEIGHT < n_weights;
-            return src == QGTC_SRC_A || src == QGTC_SRC_X || src == QGTC_SRC_XR;
+            return src == QGTC_SRC_A || src == QGTC_SRC_X || src == QGTC_SRC_XR || src == QGTC_SRC_XC;
         };
         const bool l_ok = src_ok(st.left), r_ok = src_ok(st.right);
         if (!l_ok || !r_ok) return false;

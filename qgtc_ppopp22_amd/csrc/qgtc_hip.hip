@@ -382,7 +382,17 @@ int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stag
     return qgtc_bitmm_batched(stage_xw, count, max_M, max_N1, max_N2, act_bits, w_bits, out_mode == 2 ? 1 : out_bits, out_mode, flags & ~QGTC_ZERO_JUMP, stream);
 }
 
-size_t qgtc_weight_codes_words(int N) { return N > 0 ? static_cast<size_t>((N + 31) / 32) * 2u * 64u * 4u : 0u; }
+size_t qgtc_weight_codes_words(int N, int nbits) {
+    return (N > 0 && nbits >= 1 && nbits <= 4) ? static_cast<size_t>((N + 31) / 32) * 2u * ((nbits + 1) / 2) * 64u * 4u : 0u;
+}
+
+int qgtc_chain_from_cols(const uint32_t *cols, size_t cols_words, int H, int W, int nbits, uint32_t *chain, size_t chain_words,
+                         void *stream) {
+    if (!cols || !chain || H <= 0 || W <= 0 || nbits < 1 || nbits > 4) return QGTC_EINVAL;
+    if (chain_words < qgtc_chain_words(H, W)) return QGTC_ESIZE;
+    if (!aligned16(chain)) return QGTC_EALIGN;
+    return qgtc_launch_cols_to_chain(cols, cols_words, H, W, nbits, chain, static_cast<hipStream_t>(stream));
+}
 
 size_t qgtc_chain_words(int M, int N) { return (M > 0 && N > 0) ? static_cast<size_t>(step128(M)) * pad128(N) * 16u : 0u; }
 
@@ -390,7 +400,7 @@ int qgtc_expand_weights(const qgtc_expand_job *jobs, int n_jobs, void *stream) {
     if (!jobs || n_jobs <= 0 || n_jobs > QGTC_MAX_WEIGHTS) return QGTC_EINVAL;
     for (int i = 0; i < n_jobs; i++) {
         const qgtc_expand_job &j = jobs[i];
-        if (!j.W || !j.codes || j.K <= 0 || j.N <= 0 || j.N > 128 || j.nbits < 1 || j.nbits > 2 || j.w_lines < j.N || (j.order != 0 && j.order != 1)) return QGTC_EINVAL;
+        if (!j.W || !j.codes || j.K <= 0 || j.N <= 0 || j.N > 128 || j.nbits < 1 || j.nbits > 4 || j.w_lines < j.N || (j.order != 0 && j.order != 1)) return QGTC_EINVAL;
         if (j.order == 0 && j.K > 128) return QGTC_EINVAL;
         if (!aligned16(j.codes)) return QGTC_EALIGN;
     }

@@ -747,6 +747,7 @@ struct EpochPlan {
     std::vector<int32_t> nodes;
     int count = 0, max_n = 0, a_bits = 1;
     bool jumping = false;
+    bool x_chain = false;   // the batches' X also exists in the chain format (QGTC_SRC_XC)
     double occupied = 1.0;
     // bound state
     std::vector<qgtc_stage> stages;
@@ -764,9 +765,12 @@ struct EpochPlan {
     std::vector<uint64_t> offsets;      // lazily: word offset of every (stage, batch) output in the pool
     static constexpr double kJumpBelow = BatchedGemm::kJumpBelow;
 
+    // x_chain_bits > 0: every X (cols layout [n, x_cols], x_chain_bits planes) is also kept in the chain format of the
+    // chain entries (qgtc_chain_from_cols) - for epochs whose FIRST product is an aggregation A . X (Batched-GIN)
     EpochPlan(std::vector<torch::Tensor> As, std::vector<torch::Tensor> Xs, std::vector<torch::Tensor> Xrs, std::vector<int> ns,
-              int a_bits_, bool zero_jump) : a_bits(a_bits_) {
+              int a_bits_, bool zero_jump, int x_chain_bits, int x_cols) : a_bits(a_bits_) {
         count = static_cast<int>(As.size());
+        x_chain = x_chain_bits > 0;
         TORCH_CHECK(count > 0 && count <= 65535, "1..65535 cluster batches");
         TORCH_CHECK(static_cast<int>(Xs.size()) == count && static_cast<int>(ns.size()) == count, "one X and one node count per batch");
         TORCH_CHECK(Xrs.empty() || static_cast<int>(Xrs.size()) == count, "Xrs: none, or one per batch");
@@ -794,6 +798,14 @@ struct EpochPlan {
             h[i].A = operand(As[i], "A");
             h[i].X = operand(Xs[i], "X");
             h[i].XR = Xrs.empty() ? qgtc_operand{nullptr, 0} : operand(Xrs[i], "Xr");
+            h[i].XC = qgtc_operand{nullptr, 0};
+            if (x_chain_bits > 0) {
+                TORCH_CHECK(x_cols > 0 && x_chain_bits <= 4, "x_chain_bits in 1..4 and the feature count");
+                torch::Tensor xc = torch::empty({static_cast<int64_t>(qgtc_chain_words(ns[i], x_cols))}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
+                check_rc(qgtc_chain_from_cols(words(Xs[i]), Xs[i].numel(), ns[i], x_cols, x_chain_bits, words_mut(xc), xc.numel(), current_stream(xc)), "EpochPlan (X in the chain format)");
+                h[i].XC = qgtc_operand{words(xc), static_cast<uint64_t>(xc.numel())};
+                keep.push_back(xc);
+            }
             h[i].n = ns[i];
             h[i].occ = nullptr;
             h[i].occ_words = 0;
@@ -860,7 +872,7 @@ struct EpochPlan {
                 const auto &e = expand[i];
                 TORCH_CHECK(e[0] >= 0 && e[0] < nw, "bad weight index");
                 const torch::Tensor &w = weights[e[0]];
-                torch::Tensor codes = torch::empty({static_cast<int64_t>(qgtc_weight_codes_words(e[2]))}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
+                torch::Tensor codes = torch::empty({static_cast<int64_t>(qgtc_weight_codes_words(e[2], e[3]))}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
                 jobs[i] = qgtc_expand_job{words(w), words_mut(codes), static_cast<uint64_t>(w.numel()), e[1], e[2], e[3],
                                           static_cast<int32_t>(w.numel() / (static_cast<int64_t>(e[3]) * S128(e[1]) * 4)), e[4], 0};
                 weight_codes.push_back(codes);
@@ -1049,8 +1061,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         return py::make_tuple(rc, problem, field);
     }, "(rc, problem, field) of the first descriptor a QGTC_CHECK_DESCRIPTORS launch on this tensor's device found in violation");
     py::class_<EpochPlan, std::shared_ptr<EpochPlan>>(m, "EpochPlan")
-        .def(py::init<std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<int>, int, bool>(),
-             py::arg("As"), py::arg("Xs"), py::arg("Xrs"), py::arg("nodes"), py::arg("a_bits") = 1, py::arg("zero_jump") = true)
+        .def(py::init<std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<int>, int, bool, int, int>(),
+             py::arg("As"), py::arg("Xs"), py::arg("Xrs"), py::arg("nodes"), py::arg("a_bits") = 1, py::arg("zero_jump") = true,
+             py::arg("x_chain_bits") = 0, py::arg("x_cols") = 0)
         .def("bind", &EpochPlan::bind, py::arg("weights"), py::arg("stages"), py::arg("launches"), py::arg("expand") = std::vector<std::array<int, 5>>(),
              "weights: packed tensors; stages: (left, right, K, N, bit1, bit2, ob, mode, pad128, use_occ, fmt); launches: (kind, s1, s2, flags, "
              "codes); expand: (weight, K, N, nbits, order) per pre-expanded weight")
@@ -1064,11 +1077,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def("outs", &EpochPlan::outs, py::arg("stage"))
         .def_readonly("count", &EpochPlan::count)
         .def_readonly("zero_jump", &EpochPlan::jumping)
+        .def_readonly("x_chain", &EpochPlan::x_chain)
         .def_readonly("occupied_fraction", &EpochPlan::occupied)
         .def_property_readonly("n_launches", [](const EpochPlan &p) { return p.launches.size(); });
     m.attr("SRC_A") = static_cast<int>(QGTC_SRC_A);
     m.attr("SRC_X") = static_cast<int>(QGTC_SRC_X);
     m.attr("SRC_XR") = static_cast<int>(QGTC_SRC_XR);
+    m.attr("SRC_XC") = static_cast<int>(QGTC_SRC_XC);
     m.attr("SRC_WEIGHT") = static_cast<int>(QGTC_SRC_WEIGHT);
     m.attr("SRC_STAGE") = static_cast<int>(QGTC_SRC_STAGE);
     m.attr("DIM_NODES") = static_cast<int>(QGTC_DIM_NODES);

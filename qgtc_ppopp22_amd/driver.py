@@ -341,6 +341,16 @@ class PlannedEpoch:
             expand = [(0, F, H, b, 0), (1, H, H, b, 1), (3, H, C, b, 1)]     # (weight, K, N, bits, order)
             launches = [(3, 0, 0, 0, 0), (4, 1, 2, 0, 1), (4, 3, 4, 0, 2), (4, 5, -1, 0, 0)]
             self.discarded = {0, 1, 2, 3, 4}
+        elif (fuse and chain == "correct" and chain_stages and run_gin and not keep_aggregates and b == 4 and max(F, H, C) <= 64 and max_n <= 8192
+                and Q.get_engine() != "popcount" and not switches and getattr(data, "x_chain", False)):
+            # Batched-GIN at 4 bits on the same entries: A.X + .W1 | A.T1 + .W2 | A.T2 + .W3 -> float32, three launches; X in the
+            # chain format from the data loader (ClusterIter.epoch_data), T between the launches likewise
+            stages[0] = (stages[0][0], Q.SRC_XC) + stages[0][2:]
+            for i in (1, 3):
+                stages[i] = stages[i][:10] + (1,)
+            expand = [(0, F, H, b, 1), (1, H, H, b, 1), (2, H, C, b, 1)]
+            launches = [(4, 0, 1, 0, 0), (4, 2, 3, 0, 1), (4, 4, 5, 0, 2)]
+            self.discarded = {0, 1, 2, 3, 4}
         elif fuse and chain == "correct" and chain_stages:
             # an aggregation stage and the NEXT layer's X.W stage are one call (qgtc_gcn_chain_batched), T between the
             # launches of a chain in the kernels' own format where every launch can keep it (see BatchedEpoch)

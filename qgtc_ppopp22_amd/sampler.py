@@ -55,6 +55,7 @@ class ClusterIter:
         self.psize = psize
         self.batch_size = batch_size
         self.bit_width = bit_width
+        self.run_GIN = run_GIN
         self.device = torch.device(device)
         self.resident = resident
         self.par_li = G.partition_list(g, psize)
@@ -105,7 +106,13 @@ class ClusterIter:
             assert self.resident, "a grouped epoch needs the packed batches on the device"
             cts = self.cTensor_li
             rows = [c.bit_X_rows for c in cts] if cts and cts[0].bit_X_rows is not None else []
-            self._epoch_data = qgtc.EpochPlan([c.bit_A for c in cts], [c.bit_X for c in cts], rows, [p[0] for p in self.cluster_param_li], 1, True)
+            # X also in the chain format of the chain entries when an epoch's first product is A . X (Batched-GIN) and the
+            # widths are the ones those entries cover (4 bits, at most 64 features)
+            feat = self.cluster_param_li[0][3] if self.cluster_param_li else 0
+            x_chain = self.bit_width if (self.run_GIN and self.bit_width == 4 and feat <= 64) else 0
+            self._epoch_data = qgtc.EpochPlan([c.bit_A for c in cts], [c.bit_X for c in cts], rows, [p[0] for p in self.cluster_param_li], 1, True,
+                                              x_chain, feat)
+            self.x_in_chain_format = x_chain > 0
         return self._epoch_data
 
     def __len__(self):

@@ -185,7 +185,7 @@ class QgtcOperand(ctypes.Structure):
 
 class QgtcBatch(ctypes.Structure):
     """include/qgtc.h: struct qgtc_batch - what the data loader knows of one cluster batch."""
-    _fields_ = [("A", QgtcOperand), ("X", QgtcOperand), ("XR", QgtcOperand), ("occ", ctypes.c_void_p), ("n", ctypes.c_int32),
+    _fields_ = [("A", QgtcOperand), ("X", QgtcOperand), ("XR", QgtcOperand), ("XC", QgtcOperand), ("occ", ctypes.c_void_p), ("n", ctypes.c_int32),
                 ("occ_words", ctypes.c_int32)]
 
 
@@ -206,7 +206,7 @@ def test_epoch_plan_filled_on_the_device_with_raw_pointers(lib, oracle):
     weights packed in one launch, the descriptors of a layout-correct two-layer GCN slice (X.W1 -> A.T1 -> .W2 -> A.T2 as
     float32) filled by ONE launch from the per-batch table, QGTC_CHECK_DESCRIPTORS on every launch - against the oracle."""
     import torch
-    assert ctypes.sizeof(QgtcBatch) == 64 and ctypes.sizeof(QgtcStage) == 44 and ctypes.sizeof(QgtcPackJob) == 48
+    assert ctypes.sizeof(QgtcBatch) == 80 and ctypes.sizeof(QgtcStage) == 44 and ctypes.sizeof(QgtcPackJob) == 48
     lib.qgtc_val2bit_batched.argtypes = [vp, ctypes.c_int, vp]
     lib.qgtc_epoch_pool_layout.restype = ctypes.c_size_t
     lib.qgtc_epoch_pool_layout.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp]
@@ -239,7 +239,7 @@ def test_epoch_plan_filled_on_the_device_with_raw_pointers(lib, oracle):
         A, Xr = oracle.pack(qa, 1, False), oracle.pack(qx, b, False)
         dA, dXr = torch.from_numpy(A.view(np.int32)).cuda(), torch.from_numpy(Xr.view(np.int32)).cuda()
         keep += [dA, dXr]
-        hb.append(QgtcBatch(QgtcOperand(dA.data_ptr(), dA.numel()), QgtcOperand(None, 0), QgtcOperand(dXr.data_ptr(), dXr.numel()), None, n, 0))
+        hb.append(QgtcBatch(QgtcOperand(dA.data_ptr(), dA.numel()), QgtcOperand(None, 0), QgtcOperand(dXr.data_ptr(), dXr.numel()), QgtcOperand(None, 0), None, n, 0))
         t1 = oracle.bitmm2bit(Xr, W_o[0], n, F, H, b, b, b, col=True)
         h1 = oracle.bitmm2bit(A, t1, n, n, H, 1, b, b)
         t2 = oracle.bitmm2bit(h1, W_o[1], n, H, C, b, b, b, col=True)
@@ -329,8 +329,8 @@ def test_chain_entries_with_raw_descriptors(lib, oracle, M, K, F, H, C, bitmaps)
     P128 = lambda x: (x + 127) // 128 * 128   # noqa: E731
     W1, W2 = oracle.pack(rand_q(rng, F, H, b), b, True), oracle.pack(rand_q(rng, H, C, b), b, True)
     dW1, dW2 = torch.from_numpy(W1.view(np.int32)).cuda(), torch.from_numpy(W2.view(np.int32)).cuda()
-    c1 = torch.full((int(lib.qgtc_weight_codes_words(H)),), -1, dtype=torch.int32, device="cuda")
-    c2 = torch.full((int(lib.qgtc_weight_codes_words(C)),), -1, dtype=torch.int32, device="cuda")
+    c1 = torch.full((int(lib.qgtc_weight_codes_words(H, b)),), -1, dtype=torch.int32, device="cuda")
+    c2 = torch.full((int(lib.qgtc_weight_codes_words(C, b)),), -1, dtype=torch.int32, device="cuda")
     jobs = (QgtcExpandJob * 2)(QgtcExpandJob(dW1.data_ptr(), c1.data_ptr(), dW1.numel(), F, H, b, P128(H), 0, 0),
                                QgtcExpandJob(dW2.data_ptr(), c2.data_ptr(), dW2.numel(), H, C, b, P128(C), 1, 0))
     assert lib.qgtc_expand_weights(ctypes.addressof(jobs), 2, st) == 0

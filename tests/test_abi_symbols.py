@@ -114,7 +114,7 @@ def test_epoch_pool_layout_and_layer_route_are_host_side(lib, oracle):
     sizes = [oracle.cols_words(n, 128, 2, False) for n in ns] + [oracle.rows_words(n, 128, 3) for n in ns] + [(n * 10 + 3) // 4 * 4 for n in ns] \
         + [lib.qgtc_chain_words(n, 100) for n in ns]                       # fmt 1: the chain format of qgtc_chain_*
     assert [lib.qgtc_chain_words(n, 100) for n in ns] == [(n + 127) // 128 * 128 * 16 for n in ns]
-    assert lib.qgtc_weight_codes_words(100) == 4 * 2 * 64 * 4
+    assert lib.qgtc_weight_codes_words(100, 2) == 4 * 2 * 64 * 4 and lib.qgtc_weight_codes_words(50, 4) == 2 * 2 * 2 * 64 * 4
     assert total == sum(sizes)
     assert list(offs) == [sum(sizes[:i]) for i in range(len(sizes))]
     assert lib.qgtc_epoch_pool_layout(None, 3, ctypes.addressof(stages), 3, None) == 0

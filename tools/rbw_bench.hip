@@ -48,7 +48,7 @@ int main(int argc, char **argv) {
     size_t set = 0;
     for (auto v : hocc) set += __builtin_popcountll(v);
     printf("adjacency: %zu of %zu 32-row x 128-bit tiles occupied (%.3f), %.2f k-quads per row block\n", set, occw * ((n + 127) / 128), (double)set / (occw * ((n + 127) / 128)), (double)set / occw);
-    const size_t ww = qgtc_cols_words(N1, N2, 2, 0), wcw = qgtc_weight_codes_words(N2);
+    const size_t ww = qgtc_cols_words(N1, N2, 2, 0), wcw = qgtc_weight_codes_words(N2, 2);
     std::vector<uint32_t> hw(ww);
     for (auto &v : hw) v = rng();
     CK(hipMalloc(&dW, ww * 4)); CK(hipMalloc(&dWc, wcw * 4));
