@@ -393,3 +393,72 @@ def test_chain_entries_with_raw_descriptors(lib, oracle, M, K, F, H, C, bitmaps)
     assert lib.qgtc_chain_aggregate(d(1), d(2), count, M, K, 129, C, b, b, b, 1, c2.data_ptr(), 0, st) == 1
     assert lib.qgtc_chain_aggregate(d(1), None, count, M, K, H, C, b, b, b, 1, c2.data_ptr(), 0, st) == 1
     assert lib.qgtc_expand_weights(ctypes.addressof(jobs), 9, st) == 1
+
+
+@pytest.mark.parametrize("M,F,H,C,bitmaps", [(599, 50, 64, 10, True), (333, 64, 33, 64, False), (40, 7, 5, 3, True)])
+def test_chain_entries_at_four_bits(lib, oracle, M, F, H, C, bitmaps):
+    """The Batched-GIN shape of the chain entries (main_qgtc.py:131-138 with every right operand in the cols layout): X arrives in
+    the PUBLIC cols layout and is converted once (qgtc_chain_from_cols, the data loader's step), then
+    T1 = requant(requant(A . X) . W1) (out_mode 1), out = float32(requant(A . T1) . W2) (out_mode 2) - 4-bit values, two base-4
+    digits a nibble, 4-plane weights (W2 in val2bit's output_layer form: PAD8 lines) - against the oracle."""
+    import torch
+    b = 4
+    lib.qgtc_weight_codes_words.restype = lib.qgtc_chain_words.restype = lib.qgtc_occupancy_words.restype = ctypes.c_size_t
+    lib.qgtc_expand_weights.argtypes = [vp, ctypes.c_int, vp]
+    lib.qgtc_chain_from_cols.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+    lib.qgtc_chain_aggregate.argtypes = [vp, vp, ctypes.c_int] + [ctypes.c_int] * 8 + [vp, ctypes.c_uint, vp]
+    lib.qgtc_tile_occupancy.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+    rng = np.random.default_rng(M + F)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P128, P8 = (lambda x: (x + 127) // 128 * 128), (lambda x: (x + 7) // 8 * 8)   # noqa: E731
+    W1, W2 = oracle.pack(rand_q(rng, F, H, b), b, True), oracle.pack(rand_q(rng, H, C, b), b, True, True)
+    dW1, dW2 = torch.from_numpy(W1.view(np.int32)).cuda(), torch.from_numpy(W2.view(np.int32)).cuda()
+    c1 = torch.full((int(lib.qgtc_weight_codes_words(H, b)),), -1, dtype=torch.int32, device="cuda")
+    c2 = torch.full((int(lib.qgtc_weight_codes_words(C, b)),), -1, dtype=torch.int32, device="cuda")
+    jobs = (QgtcExpandJob * 2)(QgtcExpandJob(dW1.data_ptr(), c1.data_ptr(), dW1.numel(), F, H, b, P128(H), 1, 0),
+                               QgtcExpandJob(dW2.data_ptr(), c2.data_ptr(), dW2.numel(), H, C, b, P8(C), 1, 0))
+    assert lib.qgtc_expand_weights(ctypes.addressof(jobs), 2, st) == 0
+    count = 3
+    keep, s0, s1, s2, s3, want = [], [], [], [], [], []
+    for i in range(count):
+        m = max(1, M - 23 * i)
+        qx = rand_q(rng, m, F, b)
+        qa = (rng.random((m, m)) < 0.05).astype(np.int32)
+        X, A = oracle.pack(qx, b, True), oracle.pack(qa, 1, False)
+        dX, dA = torch.from_numpy(X.view(np.int32)).cuda(), torch.from_numpy(A.view(np.int32)).cuda()
+        XC = torch.full((int(lib.qgtc_chain_words(m, F)),), -1, dtype=torch.int32, device="cuda")
+        assert lib.qgtc_chain_from_cols(dX.data_ptr(), dX.numel(), m, F, b, XC.data_ptr(), XC.numel(), st) == 0
+        T1 = torch.full((int(lib.qgtc_chain_words(m, H)),), -1, dtype=torch.int32, device="cuda")
+        out = torch.full((m * C,), -7.0, dtype=torch.float32, device="cuda")
+        occ = None
+        if bitmaps:
+            occ = torch.empty(int(lib.qgtc_occupancy_words(m, m)), dtype=torch.int64, device="cuda")
+            assert lib.qgtc_tile_occupancy(dA.data_ptr(), dA.numel(), m, m, 1, occ.data_ptr(), occ.numel(), st) == 0
+        keep += [dX, dA, XC, T1, out, occ]
+        ow = (((m + 127) // 128) + 63) // 64
+        oc = (ow if bitmaps else 0, occ.data_ptr() if bitmaps else None)
+        s0.append(QgtcProblem(dA.data_ptr(), XC.data_ptr(), None, dA.numel(), XC.numel(), m, m, F, P128(F), *oc))
+        s1.append(QgtcProblem(None, dW1.data_ptr(), T1.data_ptr(), 0, dW1.numel(), m, F, H, P128(H), 0, None))
+        s2.append(QgtcProblem(dA.data_ptr(), T1.data_ptr(), None, dA.numel(), T1.numel(), m, m, H, P128(H), *oc))
+        s3.append(QgtcProblem(None, dW2.data_ptr(), out.data_ptr(), 0, dW2.numel(), m, H, C, P8(C), 0, None))
+        ax = oracle.bitmm2bit(A, X, m, m, F, 1, b, b)
+        t1 = oracle.bitmm2bit(ax, W1, m, F, H, b, b, b, col=True)
+        a1 = oracle.bitmm2bit(A, t1, m, m, H, 1, b, b)
+        want.append((out, oracle.bitmm2int(a1, W2, m, H, C, b, b, False)))
+    host = (QgtcProblem * (4 * count))(*(s0 + s1 + s2 + s3))
+    descs = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
+    d = lambda i: descs.data_ptr() + 72 * count * i       # noqa: E731
+    for rep in range(2):
+        rc = lib.qgtc_chain_aggregate(d(0), d(1), count, M, M, F, H, b, b, b, 1, c1.data_ptr(), 0x200, st)
+        assert rc == 0, lib.qgtc_strerror(rc)
+        rc = lib.qgtc_chain_aggregate(d(2), d(3), count, M, M, H, C, b, b, b, 2, c2.data_ptr(), 0x200, st)
+        assert rc == 0, lib.qgtc_strerror(rc)
+        torch.cuda.synchronize()
+        for i, (o, w) in enumerate(want):
+            np.testing.assert_array_equal(o.cpu().numpy().reshape(w.shape), w, err_msg=f"batch {i}")
+            o.fill_(-7.0)
+    lib.qgtc_last_batched_violation.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), vp]
+    assert lib.qgtc_last_batched_violation(None, None, st) == 0
+    assert lib.qgtc_chain_aggregate(d(0), d(1), count, M, M, 65, H, b, b, b, 1, c1.data_ptr(), 0, st) == 1     # 4-bit chains: N <= 64
+    assert lib.qgtc_chain_from_cols(dX.data_ptr(), dX.numel(), 10, 10, 5, XC.data_ptr(), XC.numel(), st) == 1   # at most four planes
+    assert lib.qgtc_chain_from_cols(dX.data_ptr(), dX.numel(), M, F, b, XC.data_ptr(), 3, st) == 2
