@@ -355,6 +355,22 @@ int qgtc_chain_aggregate(const qgtc_problem *stage_a, const qgtc_problem *stage_
                          int N2, int t_bits, int act_bits, int out_bits, int out_mode, const uint32_t *w2_codes,
                          unsigned flags, void *stream);
 
+/* ---- A whole layout-correct epoch in ONE launch --------------------------------------------------------------------------
+ * The chain entries above, back to back inside one kernel: a workgroup keeps its 128 rows of one cluster batch through every
+ * stage, and two stages are separated only by a barrier among the workgroups of THAT batch (all on one XCD, whose L2 is their
+ * coherence point; per-batch counters in `sync`, which only grow: `epoch` = 1, 2, 3 .. counts the launches made with them).
+ * kind 0: Cluster-GCN, 2 bits (stages[0..5] = X.W1, A.T1, .W2, A.T2, .W3, A.T3 as qgtc_chain_transform / _aggregate take them;
+ * F <= 128, H <= 128, C <= 32); kind 1: Batched-GIN, 4 bits (A.X, .W1, A.T1, .W2, A.T2, .W3; F, H <= 64, C <= 32, X in the
+ * chain format). `stages` and `w_codes` are HOST arrays of six / three DEVICE pointers. `sync`: qgtc_chain_epoch_sync_words(count)
+ * words, zeroed once. Needs every workgroup of the launch resident at once and workgroup ids congruent mod 8 on one XCD - both
+ * checked (the first once per device): QGTC_ENODEVICE when they do not hold, QGTC_EINVAL outside the supported widths; callers
+ * then issue the per-stage entries. A barrier that waits longer than ~2^21 polls sets the error word and goes on:
+ * qgtc_chain_epoch_failed() (waits for `stream`) returns QGTC_EHIP if that happened since `sync` was zeroed. */
+size_t qgtc_chain_epoch_sync_words(int count);
+int qgtc_chain_epoch(const qgtc_problem *const *stages, int kind, int count, int max_M, int F, int H, int C, int x_bits,
+                     const uint32_t *const *w_codes, uint32_t *sync, uint32_t epoch, unsigned flags, void *stream);
+int qgtc_chain_epoch_failed(const uint32_t *sync, int count, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,13 +167,9 @@ __device__ __forceinline__ void rbw_store_codes(const f32x16 &acc, uint32_t *__r
 // 128), W pre-expanded (order 0), T in the chain format. A workgroup = four row blocks (one k-quad of T), a wave = one.
 // ------------------------------------------------------------------------------------------
 template <int NA, int OB, int NCB>
-__global__ __launch_bounds__(256) void k_rbw_xw(const qgtc_problem *__restrict__ prs, const u32x4 *__restrict__ w_codes, RbwShape sh) {
+__device__ __forceinline__ void rbw_xw_body(const qgtc_problem &pr, const u32x4 *__restrict__ w_codes, const RbwShape &sh, int grp) {
     constexpr int NDA = (NA + 1) / 2;
-    int grp, batch;
-    rbw_ids(sh, grp, batch);
-    const qgtc_problem pr = prs[batch];
     const int M = pr.M, N = pr.N;
-    if (grp >= step128(M)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 31, fh = lane >> 5;
@@ -213,6 +209,15 @@ __global__ __launch_bounds__(256) void k_rbw_xw(const qgtc_problem *__restrict__
     }
 }
 
+template <int NA, int OB, int NCB>
+__global__ __launch_bounds__(256) void k_rbw_xw(const qgtc_problem *__restrict__ prs, const u32x4 *__restrict__ w_codes, RbwShape sh) {
+    int grp, batch;
+    rbw_ids(sh, grp, batch);
+    const qgtc_problem pr = prs[batch];
+    if (grp >= step128(pr.M)) return;
+    rbw_xw_body<NA, OB, NCB>(pr, w_codes, sh, grp);
+}
+
 // ------------------------------------------------------------------------------------------
 // An aggregation stage with the next layer's X . W in its tail (main_qgtc.py:148-149 / :150-151), or the last aggregation
 // (main_qgtc.py:154: float32 out). prs: {A (rows layout, one plane), T (chain format, OB planes' worth of values), out
@@ -227,19 +232,17 @@ __global__ __launch_bounds__(256) void k_rbw_xw(const qgtc_problem *__restrict__
 #define RBW_STAMP(i) do { } while (0)
 #endif
 
-template <int OB, int OB2, int MODE2, int NCB1, int NCB2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_rbw_chain(const qgtc_problem *__restrict__ prs, const qgtc_problem *__restrict__ prs2,
-                                                                                                const u32x4 *__restrict__ w2_codes, RbwShape sh) {
-    constexpr int MH = (NCB1 + 1) / 2;   // MFMAs (64 elements of K each) of the second product
+// AUX: cache policy of the loads of T (0, or AUX_SC1 = agent scope: past the CU's L1 - the whole-epoch kernel below reads a T that
+// other workgroups wrote earlier in the SAME launch). w2_lds / t_lds: the workgroup's staging areas (NCB2 x 2 x ND x 64 and 512 u32x4).
+template <int OB, int OB2, int MODE2, int NCB1, int NCB2, int AUX>
+__device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgtc_problem *__restrict__ pr2p, const u32x4 *__restrict__ w2_codes,
+                                               int grp, int batch, u32x4 *__restrict__ w2_lds, u32x4 *__restrict__ t_lds
 #ifdef QGTC_RBW_STAMPS
-    unsigned long long st_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                                               , unsigned long long (&st_)[10]
 #endif
-    RBW_STAMP(0);
-    int grp, batch;
-    rbw_ids(sh, grp, batch);
-    const qgtc_problem pr = prs[batch];
+) {
+    constexpr int MH = (NCB1 + 1) / 2;   // MFMAs (64 elements of K each) of the second product
     const int M = pr.M, K = pr.K, N = pr.N;
-    if (grp >= step128(M)) return;
 #ifdef QGTC_RBW_STAMPS
     asm volatile("" ::"s"(M), "s"(K));
 #endif
@@ -256,8 +259,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     //    wave loading it for itself is 16 load instructions x 1 KB per wave, and the CU's one address unit (64 bytes a clock)
     //    was where the waves queued (in-kernel stamps: 2.4 k cycles from the occupancy word to the last load issued).
     constexpr int ND = OB > 2 ? 2 : 1;   // base-4 digits of the aggregate's values and of W' (the epochs' widths: 2 / 2 or 4 / 4 bits)
-    __shared__ __attribute__((aligned(16))) u32x4 w2_lds[MODE2 == 0 ? 1 : NCB2 * 2 * ND * 64];
-    __shared__ __attribute__((aligned(16))) u32x4 t_lds[4 * 128];   // [word t of the k-quad][line n]
     const int kq = step128(K);
     const int lines = 128;   // pad128(N), N <= 128
     const bool diag_ok = grp < kq;   // (workgroup-uniform; A is square in the epochs, so the diagonal k-quad exists)
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         u32x4 td[2];
 #pragma unroll
         for (int i = 0; i < 2; i++)
-            td[i] = __builtin_amdgcn_raw_buffer_load_b128(rt, diag_ok ? (static_cast<uint32_t>(grp) * 512u + static_cast<uint32_t>(tid + 256 * i)) * 16u : 0xffffffffu, 0, 0);
+            td[i] = __builtin_amdgcn_raw_buffer_load_b128(rt, diag_ok ? (static_cast<uint32_t>(grp) * 512u + static_cast<uint32_t>(tid + 256 * i)) * 16u : 0xffffffffu, 0, AUX);
         if constexpr (MODE2 != 0) {
 #pragma unroll
             for (int i = 0; i < (NCB2 * 2 * ND * 64 + 255) / 256; i++) {
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 #pragma unroll
                 for (int j = 0; j < NCB1; j++)
 #pragma unroll
-                    for (int t = 0; t < 4; t++) tl[j][t] = __builtin_amdgcn_raw_buffer_load_b128(rt, t_lane, (t * 128 + 32 * j) * 16, 0);
+                    for (int t = 0; t < 4; t++) tl[j][t] = __builtin_amdgcn_raw_buffer_load_b128(rt, t_lane, (t * 128 + 32 * j) * 16, AUX);
             };
             auto multiply_pair = [&]() {
 #pragma unroll
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             if (m < M)
                 for (int c = fh; c < N; c += 2) static_cast<float *>(pr.out)[static_cast<size_t>(m) * N + c] = 0.0f;
         } else {
-            const qgtc_problem pz = prs2[batch];
+            const qgtc_problem pz = *pr2p;
             if constexpr (MODE2 == 2) {
                 if (m < M)
                     for (int c = fh; c < pz.N; c += 2) static_cast<float *>(pz.out)[static_cast<size_t>(m) * pz.N + c] = 0.0f;
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         asm volatile("" ::"v"(XA[0][0]), "v"(XA[MH - 1][3]));
 #endif
         RBW_STAMP(6);
-        const qgtc_problem pr2 = prs2[batch];
+        const qgtc_problem pr2 = *pr2p;
         const int N2 = pr2.N, lines2 = pad128(N2);
         uint32_t *tbase = static_cast<uint32_t *>(pr2.out) + static_cast<size_t>(grp * 4 + wv) * lines2 * 4;   // word wv of k-quad grp
         const __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc(pr2.out, 0, MODE2 == 2 ? static_cast<int>(static_cast<uint32_t>(M) * static_cast<uint32_t>(N2) * 4u) : 0, 0x00020000);
@@ -476,6 +477,148 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         }
 #endif
     }
+}
+
+template <int OB, int OB2, int MODE2, int NCB1, int NCB2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_rbw_chain(const qgtc_problem *__restrict__ prs, const qgtc_problem *__restrict__ prs2,
+                                                                                                const u32x4 *__restrict__ w2_codes, RbwShape sh) {
+    constexpr int ND = OB > 2 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) u32x4 w2_lds[MODE2 == 0 ? 1 : NCB2 * 2 * ND * 64];
+    __shared__ __attribute__((aligned(16))) u32x4 t_lds[4 * 128];   // [word t of the k-quad][line n]
+#ifdef QGTC_RBW_STAMPS
+    unsigned long long st_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    RBW_STAMP(0);
+    int grp, batch;
+    rbw_ids(sh, grp, batch);
+    const qgtc_problem pr = prs[batch];
+    if (grp >= step128(pr.M)) return;
+    rbw_chain_body<OB, OB2, MODE2, NCB1, NCB2, 0>(pr, MODE2 == 0 ? nullptr : prs2 + batch, w2_codes, grp, batch, w2_lds, t_lds
+#ifdef QGTC_RBW_STAMPS
+                                                  , st_
+#endif
+    );
+}
+
+
+// ------------------------------------------------------------------------------------------
+// The WHOLE epoch in one launch (qgtc_chain_epoch). After the kernels above an epoch is four (three) launches of 4 - 7 us,
+// each of them ~1.7 us of launch boundary plus one exposed latency chain per wave - and the chip drains and refills at
+// every boundary although nothing crosses it between DIFFERENT cluster batches. Here a workgroup keeps its k-quad of one
+// batch (rows 128 g .. 128 g + 127) through all stages, and the only thing that separates two stages is a barrier among the
+// workgroups of ITS batch (ten at 1213 nodes): batches drift apart and fill each other's waits.
+//   * Every workgroup of the launch is resident at once (the host checks the grid against the kernel's occupancy), so a
+//     workgroup that waits never keeps the one it waits for off the chip.
+//   * All workgroups of a batch run on ONE XCD - workgroup ids congruent mod 8 share an XCD, batch b takes the ids of XCD
+//     b mod 8 - so that XCD's L2 is their coherence point: T is written with plain stores (the vector L1 writes through),
+//     `s_waitcnt vmcnt(0)` + a relaxed agent-scope atomic add on the batch's counter publishes a workgroup's k-quad, the
+//     readers poll the counter (one lane, s_sleep between relaxed loads) and then load T with the sc1 bit (past their CU's
+//     L1, which may hold the previous epoch's T). No fence instruction: a fence would write back / invalidate the XCD's
+//     whole L2 (measured in round 2: 100 us).
+//   * The counters only grow: epoch e, barrier k of a batch of G workgroups waits for ((e - 1) x NB + k) x G. A wait that
+//     exceeds ~2^21 polls sets the error word and goes on (garbage, but no hang): the host then stops using this entry.
+// ------------------------------------------------------------------------------------------
+#ifdef QGTC_EPOCH_NOSC1   // timing-only build: T loaded through the L1 (stale reads possible)
+#define RBW_EPOCH_AUX 0
+#else
+#define RBW_EPOCH_AUX AUX_SC1
+#endif
+struct EpochArgs {
+    const qgtc_problem *st[6];   // the stages' descriptor arrays (one descriptor per batch each)
+    const u32x4 *wc[3];          // pre-expanded weights of the three transforms
+    uint32_t *sync;              // batch b's counter at word 64 b; the error word at 64 count
+    uint32_t epoch;              // 1, 2, 3 .. : launches made with these counters
+    int count, groups;           // batches; workgroups per batch slot (step128 of the largest batch)
+    int a_planes;                // planes of the packed X of the first transform (GCN)
+};
+
+__device__ __forceinline__ bool rbw_epoch_ids(const EpochArgs &ea, int &grp, int &batch) {
+    const int pid = static_cast<int>(blockIdx.x), xcd = pid & 7, slot = pid >> 3;
+    const int lb = slot / ea.groups;
+    grp = slot - lb * ea.groups;
+    batch = xcd + 8 * lb;
+    return batch < ea.count;
+}
+
+// barrier k (1 ..) of NB among the G workgroups of the batch
+template <int NB>
+__device__ __forceinline__ void rbw_batch_barrier(const EpochArgs &ea, int batch, int G, int k) {
+#ifdef QGTC_EPOCH_NOBARRIER   // timing-only build (tools/rbw_bench.hip): the stages back to back, results wrong
+    __syncthreads();
+    return;
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have reached the L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t *c = ea.sync + 64 * batch;
+        const uint32_t target = ((ea.epoch - 1u) * NB + static_cast<uint32_t>(k)) * static_cast<uint32_t>(G);
+        __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int polls = 0;
+        while (static_cast<int>(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++polls > (1 << 21)) {
+                __hip_atomic_store(ea.sync + 64 * ea.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+#ifdef QGTC_RBW_STAMPS
+#define RBW_ST_ARG , st_
+#else
+#define RBW_ST_ARG
+#endif
+
+// Cluster-GCN, 2 bits: T1 = rq(X . W1) | T2 = rq(rq(A . T1) . W2) | T3 = rq(rq(A . T2) . W3) | out = float32(A . T3)
+// (main_qgtc.py:147-154 with every right operand in the cols layout). NCBH / NCBC: 32-column blocks of the hidden / class widths.
+template <int NCBH, int NCBC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_rbw_epoch_gcn(EpochArgs ea) {
+    __shared__ __attribute__((aligned(16))) u32x4 w2_lds[(NCBH > NCBC ? NCBH : NCBC) * 2 * 64];
+    __shared__ __attribute__((aligned(16))) u32x4 t_lds[4 * 128];
+#ifdef QGTC_RBW_STAMPS
+    unsigned long long st_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    int grp, batch;
+    if (!rbw_epoch_ids(ea, grp, batch)) return;
+    const qgtc_problem p0 = ea.st[0][batch];
+    const int G = step128(p0.M);
+    if (grp >= G) return;   // (workgroup-uniform: this slot has no k-quad of the batch)
+    const RbwShape sh{0, ea.a_planes, 0};
+    rbw_xw_body<2, 2, NCBH>(p0, ea.wc[0], sh, grp);
+    rbw_batch_barrier<3>(ea, batch, G, 1);
+    rbw_chain_body<2, 2, 1, NCBH, NCBH, RBW_EPOCH_AUX>(ea.st[1][batch], ea.st[2] + batch, ea.wc[1], grp, batch, w2_lds, t_lds RBW_ST_ARG);
+    rbw_batch_barrier<3>(ea, batch, G, 2);
+    rbw_chain_body<2, 2, 1, NCBH, NCBC, RBW_EPOCH_AUX>(ea.st[3][batch], ea.st[4] + batch, ea.wc[2], grp, batch, w2_lds, t_lds RBW_ST_ARG);
+    rbw_batch_barrier<3>(ea, batch, G, 3);
+    rbw_chain_body<2, 2, 0, NCBC, 1, RBW_EPOCH_AUX>(ea.st[5][batch], nullptr, nullptr, grp, batch, w2_lds, t_lds RBW_ST_ARG);
+}
+
+// Batched-GIN, 4 bits: T1 = rq(rq(A . X) . W1) | T2 = rq(rq(A . T1) . W2) | out = float32(rq(A . T2) . W3) (main_qgtc.py:131-138)
+template <int NCBF, int NCBH, int NCBC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_rbw_epoch_gin(EpochArgs ea) {
+    __shared__ __attribute__((aligned(16))) u32x4 w2_lds[(NCBH > NCBC ? NCBH : NCBC) * 2 * 2 * 64];
+    __shared__ __attribute__((aligned(16))) u32x4 t_lds[4 * 128];
+#ifdef QGTC_RBW_STAMPS
+    unsigned long long st_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    int grp, batch;
+    if (!rbw_epoch_ids(ea, grp, batch)) return;
+    const qgtc_problem p0 = ea.st[0][batch];
+    const int G = step128(p0.M);
+    if (grp >= G) return;
+    rbw_chain_body<4, 4, 1, NCBF, NCBH, 0>(p0, ea.st[1] + batch, ea.wc[0], grp, batch, w2_lds, t_lds RBW_ST_ARG);
+    rbw_batch_barrier<2>(ea, batch, G, 1);
+    rbw_chain_body<4, 4, 1, NCBH, NCBH, RBW_EPOCH_AUX>(ea.st[2][batch], ea.st[3] + batch, ea.wc[1], grp, batch, w2_lds, t_lds RBW_ST_ARG);
+    rbw_batch_barrier<2>(ea, batch, G, 2);
+    rbw_chain_body<4, 4, 2, NCBH, NCBC, RBW_EPOCH_AUX>(ea.st[4][batch], ea.st[5] + batch, ea.wc[2], grp, batch, w2_lds, t_lds RBW_ST_ARG);
+}
+#undef RBW_ST_ARG
+
+// which XCC a workgroup runs on (one word per workgroup): the host checks once per device that ids congruent mod 8 share one
+__global__ __launch_bounds__(64) void k_xcc_probe(uint32_t *__restrict__ out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (31 << 11)) & 15u;   // HW_REG_XCC_ID, bits 3:0
 }
 
 }  // namespace

@@ -435,6 +435,37 @@ int qgtc_chain_aggregate(const qgtc_problem *stage_a, const qgtc_problem *stage_
     return qgtc_launch_rbw_chain(stage_a, out_mode == 0 ? nullptr : stage_xw, count, max_M, N1, N2, t_bits, act_bits, out_bits, out_mode, w2_codes, st);
 }
 
+size_t qgtc_chain_epoch_sync_words(int count) { return count > 0 ? static_cast<size_t>(count + 1) * 64u : 0u; }
+
+int qgtc_chain_epoch(const qgtc_problem *const *stages, int kind, int count, int max_M, int F, int H, int C, int x_bits,
+                     const uint32_t *const *w_codes, uint32_t *sync, uint32_t epoch, unsigned flags, void *stream) {
+    if (!stages || !w_codes || !sync || epoch == 0u || count <= 0 || count > 65535 || max_M <= 0 || (kind != 0 && kind != 1)) return QGTC_EINVAL;
+    for (int i = 0; i < 6; i++)
+        if (!stages[i]) return QGTC_EINVAL;
+    for (int i = 0; i < 3; i++)
+        if (!w_codes[i] || !aligned16(w_codes[i])) return QGTC_EINVAL;
+    if (F <= 0 || H <= 0 || C <= 0 || max_M > 8192 || getenv_flag("QGTC_NO_RBW") || getenv_flag("QGTC_NO_EPOCH_KERNEL")) return QGTC_EINVAL;
+    if (kind == 0 && !(rbw_xw_ok(F, H, x_bits, 2) && rbw_chain_ok(max_M, H, H, 2, 2, 2, 1) && rbw_chain_ok(max_M, H, C, 2, 2, 2, 1) && C <= 32)) return QGTC_EINVAL;
+    if (kind == 1 && !(rbw_chain_ok(max_M, F, H, 4, 4, 4, 1) && rbw_chain_ok(max_M, H, H, 4, 4, 4, 1) && rbw_chain_ok(max_M, H, C, 4, 4, 4, 2) && C <= 32)) return QGTC_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (flags & QGTC_CHECK_DESCRIPTORS) {
+        for (int i = 0; i < 6; i += (kind == 0 && i == 0) ? 1 : 2) {   // the stages whose left operand is read: X.W1 (GCN) and every aggregation
+            const bool agg = !(kind == 0 && i == 0);
+            const int crc = qgtc_launch_check_descriptors(stages[i], nullptr, count, max_M, agg ? max_M : F, 128, 0, 0, 3, st);
+            if (crc != QGTC_OK) return crc;
+        }
+    }
+    return qgtc_launch_rbw_epoch(stages, kind, count, max_M, F, H, C, x_bits, w_codes, sync, epoch, st);
+}
+
+int qgtc_chain_epoch_failed(const uint32_t *sync, int count, void *stream) {
+    if (!sync || count <= 0) return QGTC_EINVAL;
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    uint32_t v = 0u;
+    HIP_TRY(hipMemcpy(&v, sync + static_cast<size_t>(count) * 64u, sizeof(v), hipMemcpyDeviceToHost));
+    return v ? QGTC_EHIP : QGTC_OK;
+}
+
 size_t qgtc_occupancy_words(int M, int K) {
     return static_cast<size_t>((M + TM - 1) / TM) * ((step128(K) + 63) / 64);
 }

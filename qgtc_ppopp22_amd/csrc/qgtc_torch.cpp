@@ -761,6 +761,12 @@ struct EpochPlan {
         int codes;       // kinds 3 / 4: index of the pre-expanded weight (weight_codes)
     };
     std::vector<torch::Tensor> weight_codes;   // qgtc_expand_weights outputs, made by bind()
+    // the whole epoch in ONE launch (qgtc_chain_epoch), when bind() was given `whole` = (kind, F, H, C, x_bits, codes0, codes1, codes2)
+    // and the library accepts it; `launches` stay as the fallback
+    std::vector<int> whole;
+    torch::Tensor sync;          // per-batch barrier counters + error word
+    uint32_t sync_epoch = 0;
+    bool whole_ok = false;
     std::vector<Launch> launches;
     std::vector<uint64_t> offsets;      // lazily: word offset of every (stage, batch) output in the pool
     static constexpr double kJumpBelow = BatchedGemm::kJumpBelow;
@@ -846,7 +852,7 @@ struct EpochPlan {
     // stages: (left, right, K, N, bit1, bit2, ob, mode, pad128, use_occ) per operator; launches: (kind, s1, s2, extra flags)
     // expand: (weight index, K, N, nbits, order) per pre-expanded weight the launches of kinds 3 / 4 name
     void bind(std::vector<torch::Tensor> weights_, std::vector<std::array<int, 11>> stages_, std::vector<std::array<int, 5>> launches_,
-              std::vector<std::array<int, 5>> expand) {
+              std::vector<std::array<int, 5>> expand, std::vector<int> whole_) {
         c10::DeviceGuard guard(batches.device());
         const int ns = static_cast<int>(stages_.size()), nw = static_cast<int>(weights_.size());
         TORCH_CHECK(ns >= 1 && ns <= QGTC_MAX_STAGES && nw <= QGTC_MAX_WEIGHTS, "too many stages / weights");
@@ -884,6 +890,16 @@ struct EpochPlan {
             TORCH_CHECK(l[0] == 0 || l[0] == 3 || (l[0] == 4 && l[2] < 0) || (l[2] >= 0 && l[2] < ns), "bad launch entry");
             TORCH_CHECK(l[0] < 3 || (l[0] == 4 && l[2] < 0) || (l[4] >= 0 && l[4] < static_cast<int>(weight_codes.size())), "bad weight-codes index");
             launches.push_back(Launch{l[0], l[1], l[2], static_cast<unsigned>(l[3]), l[4]});
+        }
+        whole = std::move(whole_);
+        whole_ok = false;
+        if (!whole.empty()) {
+            TORCH_CHECK(whole.size() == 8 && ns == 6, "whole-epoch launch: (kind, F, H, C, x_bits, codes0, codes1, codes2) and six stages");
+            for (int i = 5; i < 8; i++) TORCH_CHECK(whole[i] >= 0 && whole[i] < static_cast<int>(weight_codes.size()), "bad weight-codes index");
+            // counters zeroed once per bind: the epoch number restarts with them
+            sync = torch::zeros({static_cast<int64_t>(qgtc_chain_epoch_sync_words(count))}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
+            sync_epoch = 0;
+            whole_ok = true;
         }
         offsets.clear();
         const size_t pool_words = qgtc_epoch_pool_layout(nodes.data(), count, stages.data(), ns, nullptr);
@@ -930,9 +946,26 @@ struct EpochPlan {
         }
     }
 
+    // the epoch as ONE launch; false when the library declines (widths, residency, XCD placement): the caller then issues `launches`
+    bool run_whole(unsigned check) {
+        const qgtc_problem *st[6];
+        for (int i = 0; i < 6; i++) st[i] = stage_descs(i);
+        const uint32_t *wc[3] = {words(weight_codes[whole[5]]), words(weight_codes[whole[6]]), words(weight_codes[whole[7]])};
+        const int rc = qgtc_chain_epoch(st, whole[0], count, max_n, whole[1], whole[2], whole[3], whole[4], wc,
+                                        reinterpret_cast<uint32_t *>(sync.data_ptr<int32_t>()), sync_epoch + 1u, mm_flags() | check, current_stream(descs));
+        if (rc == QGTC_ENODEVICE || rc == QGTC_EINVAL) {
+            whole_ok = false;
+            return false;
+        }
+        check_rc(rc, "EpochPlan.run (whole epoch)");
+        sync_epoch++;
+        return true;
+    }
+
     void run() {
         TORCH_CHECK(descs.defined(), "EpochPlan.run before bind");
         c10::DeviceGuard guard(descs.device());
+        if (whole_ok && run_whole(0u)) return;
         for (const Launch &l : launches) run_launch(l, 0u);
     }
 
@@ -940,7 +973,15 @@ struct EpochPlan {
     void run_checked() {
         TORCH_CHECK(descs.defined(), "EpochPlan.run before bind");
         c10::DeviceGuard guard(descs.device());
-        for (const Launch &l : launches) run_launch(l, QGTC_CHECK_DESCRIPTORS);
+        if (whole_ok && run_whole(QGTC_CHECK_DESCRIPTORS)) {
+            const int frc = qgtc_chain_epoch_failed(reinterpret_cast<const uint32_t *>(sync.data_ptr<int32_t>()), count, current_stream(descs));
+            if (frc != QGTC_OK) {   // a batch barrier gave up waiting: never use this entry again on this plan, redo the epoch stage by stage
+                whole_ok = false;
+                for (const Launch &l : launches) run_launch(l, QGTC_CHECK_DESCRIPTORS);
+            }
+        } else {
+            for (const Launch &l : launches) run_launch(l, QGTC_CHECK_DESCRIPTORS);
+        }
         int problem = -1, field = 0;
         const int rc = qgtc_last_batched_violation(&problem, &field, current_stream(descs));
         TORCH_CHECK(rc == QGTC_OK, "EpochPlan: descriptor ", problem, " violates a grouped launch's preconditions (field ", field, ")");
@@ -1065,6 +1106,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
              py::arg("As"), py::arg("Xs"), py::arg("Xrs"), py::arg("nodes"), py::arg("a_bits") = 1, py::arg("zero_jump") = true,
              py::arg("x_chain_bits") = 0, py::arg("x_cols") = 0)
         .def("bind", &EpochPlan::bind, py::arg("weights"), py::arg("stages"), py::arg("launches"), py::arg("expand") = std::vector<std::array<int, 5>>(),
+             py::arg("whole") = std::vector<int>(),
              "weights: packed tensors; stages: (left, right, K, N, bit1, bit2, ob, mode, pad128, use_occ, fmt); launches: (kind, s1, s2, flags, "
              "codes); expand: (weight, K, N, nbits, order) per pre-expanded weight")
         .def("run", &EpochPlan::run)
@@ -1078,6 +1120,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def_readonly("count", &EpochPlan::count)
         .def_readonly("zero_jump", &EpochPlan::jumping)
         .def_readonly("x_chain", &EpochPlan::x_chain)
+        .def_readonly("whole_epoch", &EpochPlan::whole_ok, "the bound plan runs as ONE launch (qgtc_chain_epoch)")
+        .def("whole_epoch_failed", [](EpochPlan &p) {
+            if (!p.sync.defined()) return false;
+            c10::DeviceGuard guard(p.descs.device());
+            return qgtc_chain_epoch_failed(reinterpret_cast<const uint32_t *>(p.sync.data_ptr<int32_t>()), p.count, current_stream(p.descs)) != QGTC_OK;
+        }, "a batch barrier of the one-launch epoch timed out since bind (waits for the stream)")
         .def_readonly("occupied_fraction", &EpochPlan::occupied)
         .def_property_readonly("n_launches", [](const EpochPlan &p) { return p.launches.size(); });
     m.attr("SRC_A") = static_cast<int>(QGTC_SRC_A);

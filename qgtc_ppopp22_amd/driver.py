@@ -64,6 +64,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--no-chain", action="store_true",
                    help="with --batched --chain correct: do not join an aggregation stage with the next layer's X.W stage "
                         "(default: one launch for the pair, qgtc_gcn_chain_batched)")
+    p.add_argument("--epoch-kernel", action="store_true",
+                   help="with --batched --chain correct: the whole epoch in ONE launch (qgtc_chain_epoch: per-batch barriers inside the "
+                        "kernel) instead of one launch per stage pair - built, correct, measured slower on MI355X (DESIGN.md 5.7)")
     p.add_argument("--one-launch", action="store_true",
                    help="with --batched --chain correct: both products of a layer in ONE launch (in-launch hand-off; "
                         "measured slower than the two grouped launches the library uses by default)")
@@ -320,7 +323,7 @@ class PlannedEpoch:
     ClusterIter.epoch_data) and ONE bind launch inside the epoch clock. Same launches, same words as BatchedEpoch."""
 
     def __init__(self, Q, data, params, W, b, chain: str, run_gin: bool, fuse: bool = True, chain_stages: bool = True,
-                 keep_aggregates: bool = False):
+                 keep_aggregates: bool = False, whole_epoch: bool = False):
         H, C = W["hidden"], W["classes"]
         F = params[0][3]
         self.data = data
@@ -328,6 +331,7 @@ class PlannedEpoch:
         stages = stage_recipes(Q, chain, run_gin, F, H, C, b)
         launches = [(0, i, 0, 0, 0) for i in range(6)]
         expand = []
+        whole = []        # the epoch as ONE launch (qgtc_chain_epoch) where the library takes it; `launches` stay as the fallback
         self.discarded = set()
         max_n = max(p[0] for p in params)
         switches = any(k.startswith("QGTC_NO_") for k in os.environ)
@@ -341,6 +345,8 @@ class PlannedEpoch:
             expand = [(0, F, H, b, 0), (1, H, H, b, 1), (3, H, C, b, 1)]     # (weight, K, N, bits, order)
             launches = [(3, 0, 0, 0, 0), (4, 1, 2, 0, 1), (4, 3, 4, 0, 2), (4, 5, -1, 0, 0)]
             self.discarded = {0, 1, 2, 3, 4}
+            if whole_epoch and C <= 32:
+                whole = [0, F, H, C, b, 0, 1, 2]
         elif (fuse and chain == "correct" and chain_stages and run_gin and not keep_aggregates and b == 4 and max(F, H, C) <= 64 and max_n <= 8192
                 and Q.get_engine() != "popcount" and not switches and getattr(data, "x_chain", False)):
             # Batched-GIN at 4 bits on the same entries: A.X + .W1 | A.T1 + .W2 | A.T2 + .W3 -> float32, three launches; X in the
@@ -351,6 +357,8 @@ class PlannedEpoch:
             expand = [(0, F, H, b, 1), (1, H, H, b, 1), (2, H, C, b, 1)]
             launches = [(4, 0, 1, 0, 0), (4, 2, 3, 0, 1), (4, 4, 5, 0, 2)]
             self.discarded = {0, 1, 2, 3, 4}
+            if whole_epoch and C <= 32:
+                whole = [1, F, H, C, b, 0, 1, 2]
         elif fuse and chain == "correct" and chain_stages:
             # an aggregation stage and the NEXT layer's X.W stage are one call (qgtc_gcn_chain_batched), T between the
             # launches of a chain in the kernels' own format where every launch can keep it (see BatchedEpoch)
@@ -372,7 +380,8 @@ class PlannedEpoch:
             second = {j for _, j in pairs}
             launches = [first.get(i, (0, i, 0, 0, 0)) for i in range(6) if i not in second]
         self.n_launches = len(launches)
-        data.bind([W["W1"], W["W2"], W["W3"], W["W3h"]], [list(t) for t in stages], [list(l) for l in launches], [list(e) for e in expand])
+        data.bind([W["W1"], W["W2"], W["W3"], W["W3h"]], [list(t) for t in stages], [list(l) for l in launches], [list(e) for e in expand], whole)
+        self.whole_epoch = bool(whole)
 
     def run(self):
         self.data.run()
@@ -488,7 +497,7 @@ def _run_epochs(args, Q, it, feat_size, b, device):
 
     if uses_planned_epoch(args):
         plan = PlannedEpoch(Q, it.epoch_data(Q), it.cluster_param_li, W, b, args.chain, args.run_GIN, fuse=not getattr(args, "no_fuse", False),
-                            chain_stages=not getattr(args, "no_chain", False))
+                            chain_stages=not getattr(args, "no_chain", False), whole_epoch=getattr(args, "epoch_kernel", False))
         for _ in range(args.n_epochs):
             plan.run()
         torch.cuda.synchronize()

@@ -82,6 +82,73 @@ int main(int argc, char **argv) {
         best = std::min(best, ms);
     }
     printf("chain aggregate count=%d n=%d N1=%d N2=%d mode2=%d: %.2f us per launch (200 eager launches, best of 5)\n", count, n, N1, N2, mode2, best * 1e3 / 200);
+    if (getenv("EPOCH")) {   // the whole Cluster-GCN epoch in one launch (qgtc_chain_epoch) on the same synthetic batches, F = H = 128, C = 10
+        const int F = 128, H = 128, C = 10;
+        const size_t xw_ = qgtc_rows_words(n, F, 2), th = qgtc_chain_words(n, H), tc = qgtc_chain_words(n, C);
+        uint32_t *dX, *dT1, *dT2, *dT3, *dW1, *dW2, *dW3, *c1, *c2, *c3, *dsync;
+        float *dout;
+        CK(hipMalloc(&dX, xw_ * 4 * count)); CK(hipMalloc(&dT1, th * 4 * count)); CK(hipMalloc(&dT2, th * 4 * count)); CK(hipMalloc(&dT3, tc * 4 * count));
+        CK(hipMalloc(&dout, (size_t)n * C * 4 * count));
+        std::vector<uint32_t> hx(xw_);
+        for (auto &v : hx) v = rng();
+        for (int b = 0; b < count; b++) CK(hipMemcpy(dX + xw_ * b, hx.data(), xw_ * 4, hipMemcpyHostToDevice));
+        const size_t w1 = qgtc_cols_words(F, H, 2, 0), w2 = qgtc_cols_words(H, H, 2, 0), w3 = qgtc_cols_words(H, C, 2, 0);
+        std::vector<uint32_t> hw1(w1), hw2(w2), hw3(w3);
+        for (auto &v : hw1) v = rng();
+        for (auto &v : hw2) v = rng();
+        for (auto &v : hw3) v = rng();
+        CK(hipMalloc(&dW1, w1 * 4)); CK(hipMalloc(&dW2, w2 * 4)); CK(hipMalloc(&dW3, w3 * 4));
+        CK(hipMemcpy(dW1, hw1.data(), w1 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW2, hw2.data(), w2 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW3, hw3.data(), w3 * 4, hipMemcpyHostToDevice));
+        CK(hipMalloc(&c1, qgtc_weight_codes_words(H, 2) * 4)); CK(hipMalloc(&c2, qgtc_weight_codes_words(H, 2) * 4)); CK(hipMalloc(&c3, qgtc_weight_codes_words(C, 2) * 4));
+        qgtc_expand_job ej3[3] = {{dW1, c1, w1, F, H, 2, 128, 0, 0}, {dW2, c2, w2, H, H, 2, 128, 1, 0}, {dW3, c3, w3, H, C, 2, 128, 1, 0}};
+        if (int rc = qgtc_expand_weights(ej3, 3, nullptr)) { printf("expand rc=%d\n", rc); return 1; }
+        std::vector<qgtc_problem> hs(6 * count);
+        for (int b = 0; b < count; b++) {
+            const qgtc_problem A1{dA + aw * b, dT1 + th * b, nullptr, aw, th, n, n, H, 128, 1, getenv("NOOCC") ? nullptr : docc + occw * b};
+            qgtc_problem A2 = A1, A3 = A1;
+            A2.W = dT2 + th * b;
+            A3.W = dT3 + tc * b; A3.w_words = tc; A3.N = C; A3.out = dout + (size_t)n * C * b;
+            hs[0 * count + b] = qgtc_problem{dX + xw_ * b, dW1, dT1 + th * b, xw_, w1, n, F, H, 128, 0, nullptr};
+            hs[1 * count + b] = A1;
+            hs[2 * count + b] = qgtc_problem{nullptr, dW2, dT2 + th * b, 0, w2, n, H, H, 128, 0, nullptr};
+            hs[3 * count + b] = A2;
+            hs[4 * count + b] = qgtc_problem{nullptr, dW3, dT3 + tc * b, 0, w3, n, H, C, 128, 0, nullptr};
+            hs[5 * count + b] = A3;
+        }
+        qgtc_problem *ds;
+        CK(hipMalloc(&ds, hs.size() * sizeof(qgtc_problem)));
+        CK(hipMemcpy(ds, hs.data(), hs.size() * sizeof(qgtc_problem), hipMemcpyHostToDevice));
+        CK(hipMalloc(&dsync, qgtc_chain_epoch_sync_words(count) * 4));
+        CK(hipMemset(dsync, 0, qgtc_chain_epoch_sync_words(count) * 4));
+        const qgtc_problem *st6[6];
+        for (int i = 0; i < 6; i++) st6[i] = ds + (size_t)i * count;
+        const uint32_t *wc3[3] = {c1, c2, c3};
+        uint32_t ep = 0;
+        auto whole = [&]() { return qgtc_chain_epoch(st6, 0, count, n, F, H, C, 2, wc3, dsync, ++ep, 0, st); };
+        auto four = [&]() {
+            int rc = qgtc_chain_transform(st6[0], count, n, F, H, 2, 2, c1, 0, st);
+            if (!rc) rc = qgtc_chain_aggregate(st6[1], st6[2], count, n, n, H, H, 2, 2, 2, 1, c2, 0, st);
+            if (!rc) rc = qgtc_chain_aggregate(st6[3], st6[4], count, n, n, H, C, 2, 2, 2, 1, c3, 0, st);
+            if (!rc) rc = qgtc_chain_aggregate(st6[5], nullptr, count, n, n, C, 0, 2, 0, 0, 0, nullptr, 0, st);
+            return rc;
+        };
+        for (int variant = 0; variant < 2; variant++) {
+            if (int rc = variant ? whole() : four()) { printf("epoch variant %d rc=%d %s\n", variant, rc, qgtc_strerror(rc)); continue; }
+            CK(hipStreamSynchronize(st));
+            float best2 = 1e9f;
+            for (int rep = 0; rep < 5; rep++) {
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < 100; i++) variant ? whole() : four();
+                CK(hipEventRecord(e1, st));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                best2 = std::min(best2, ms);
+            }
+            printf("Cluster-GCN epoch (%s): %.2f us per epoch (100 epochs from a C loop, best of 5)%s\n", variant ? "ONE launch" : "four launches", best2 * 1e3 / 100,
+                   variant && qgtc_chain_epoch_failed(dsync, count, st) ? "  BARRIER TIMEOUT" : "");
+        }
+    }
 #ifdef QGTC_RBW_STAMPS
     {
         go();
