@@ -531,14 +531,14 @@ def main():
     traffic, rocprof = None, None
     try:
         if w == 1 and fp4_kernel:
-            with open(os.path.join(ROOT, "profiles", "r02", "summary_headline.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r03", "summary_headline.json")) as f:
                 prof = json.load(f)
             ks = [k for k in prof["kernel_stats"] if "k_bitmm_fp4_one" in k["name"]][0]
-            rocprof = {"file": "profiles/r02/kernel_stats_headline.csv", "calls": ks["calls"], "avg_us": round(ks["avg_ns"] / 1e3, 3),
+            rocprof = {"file": "profiles/r03/kernel_stats_headline.csv", "calls": ks["calls"], "avg_us": round(ks["avg_ns"] / 1e3, 3),
                        "min_us": round(ks["min_ns"] / 1e3, 3),
                        "hbm_frac_at_avg": round(algo_bytes / (ks["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBS, 5),
                        "note": "kernel span per dispatch under the tracer (no launch gap; the tracer's completion signals "
-                               "stretch a dispatch this short, see profiles/r02/README.md)"}
+                               "stretch a dispatch this short, see profiles/r03/README.md)"}
             pm = [v for k, v in prof["pmc_per_dispatch_mean"].items() if "k_bitmm_fp4_one" in k][0]
             traffic = int(2 * 1024 * pm["FETCH_SIZE"]["mean"] + 1024 * pm["WRITE_SIZE"]["mean"])
     except (OSError, KeyError, ValueError, IndexError):
