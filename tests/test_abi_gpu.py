@@ -462,3 +462,78 @@ def test_chain_entries_at_four_bits(lib, oracle, M, F, H, C, bitmaps):
     assert lib.qgtc_chain_aggregate(d(0), d(1), count, M, M, 65, H, b, b, b, 1, c1.data_ptr(), 0, st) == 1     # 4-bit chains: N <= 64
     assert lib.qgtc_chain_from_cols(dX.data_ptr(), dX.numel(), 10, 10, 5, XC.data_ptr(), XC.numel(), st) == 1   # at most four planes
     assert lib.qgtc_chain_from_cols(dX.data_ptr(), dX.numel(), M, F, b, XC.data_ptr(), 3, st) == 2
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_chain_entries_random_sweep(lib, oracle, seed):
+    """Random shapes through the chain entries against the oracle: node counts around the 32 / 128 boundaries (and below 32), widths
+    around the 32-column blocks, 2-bit (N <= 128) and 4-bit (N <= 64) chains, adjacency density from empty to dense, K != M, pooled
+    and absent bitmaps - X.W (or the converted X) -> aggregation + transform -> float32 aggregation."""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    lib.qgtc_weight_codes_words.restype = lib.qgtc_chain_words.restype = lib.qgtc_occupancy_words.restype = ctypes.c_size_t
+    lib.qgtc_expand_weights.argtypes = [vp, ctypes.c_int, vp]
+    lib.qgtc_chain_from_cols.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+    lib.qgtc_chain_transform.argtypes = [vp, ctypes.c_int] + [ctypes.c_int] * 5 + [vp, ctypes.c_uint, vp]
+    lib.qgtc_chain_aggregate.argtypes = [vp, vp, ctypes.c_int] + [ctypes.c_int] * 8 + [vp, ctypes.c_uint, vp]
+    lib.qgtc_tile_occupancy.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P128 = lambda x: (x + 127) // 128 * 128   # noqa: E731
+    b = int(rng.choice([2, 2, 4]))
+    wmax = 128 if b == 2 else 64
+    pick = lambda hi: int(rng.choice([1, 7, 31, 32, 33, 63, 64, 65, 96, 127, 128, int(rng.integers(1, hi + 1))]))   # noqa: E731
+    F, H, C = min(pick(wmax), wmax), min(pick(wmax), wmax), min(pick(wmax), wmax)
+    count = int(rng.integers(1, 5))
+    bitmaps = bool(rng.integers(0, 2))
+    density = float(rng.choice([0.0, 0.01, 0.05, 0.5, 1.0]))
+    W1, W2 = oracle.pack(rand_q(rng, F, H, b), b, True), oracle.pack(rand_q(rng, H, C, b), b, True)
+    dW1, dW2 = torch.from_numpy(W1.view(np.int32)).cuda(), torch.from_numpy(W2.view(np.int32)).cuda()
+    c1 = torch.full((int(lib.qgtc_weight_codes_words(H, b)),), -1, dtype=torch.int32, device="cuda")
+    c2 = torch.full((int(lib.qgtc_weight_codes_words(C, b)),), -1, dtype=torch.int32, device="cuda")
+    jobs = (QgtcExpandJob * 2)(QgtcExpandJob(dW1.data_ptr(), c1.data_ptr(), dW1.numel(), F, H, b, P128(H), 0 if b == 2 else 1, 0),
+                               QgtcExpandJob(dW2.data_ptr(), c2.data_ptr(), dW2.numel(), H, C, b, P128(C), 1, 0))
+    assert lib.qgtc_expand_weights(ctypes.addressof(jobs), 2, st) == 0
+    keep, sx, sa, sw, sf, want, ms, ks = [], [], [], [], [], [], [], []
+    for i in range(count):
+        m = int(rng.choice([1, 31, 32, 33, 127, 128, 129, 200, 257, int(rng.integers(1, 700))]))
+        k = m if rng.integers(0, 2) else int(rng.integers(1, 700))          # K != M half the time
+        ms.append(m)
+        ks.append(k)
+        qa = (rng.random((m, k)) < density).astype(np.int32)
+        A = oracle.pack(qa, 1, False)
+        dA = torch.from_numpy(A.view(np.int32)).cuda()
+        T = torch.full((int(lib.qgtc_chain_words(k, H)),), -1, dtype=torch.int32, device="cuda")     # requant(X . W1), or the converted X'
+        if b == 2:    # T = requant(X . W1): X [k, F] rows layout
+            X = oracle.pack(rand_q(rng, k, F, b), b, False)
+            dX = torch.from_numpy(X.view(np.int32)).cuda()
+            sx.append(QgtcProblem(dX.data_ptr(), dW1.data_ptr(), T.data_ptr(), dX.numel(), dW1.numel(), k, F, H, P128(H), 0, None))
+            t_o = oracle.bitmm2bit(X, W1, k, F, H, b, b, b, col=True)
+        else:         # 4 bits: T = a data-loader operand [k, H] converted from the public cols layout
+            t_o = oracle.pack(rand_q(rng, k, H, b), b, True)
+            dX = torch.from_numpy(t_o.view(np.int32)).cuda()
+            assert lib.qgtc_chain_from_cols(dX.data_ptr(), dX.numel(), k, H, b, T.data_ptr(), T.numel(), st) == 0
+        T2 = torch.full((int(lib.qgtc_chain_words(m, C)),), -1, dtype=torch.int32, device="cuda")
+        out = torch.full((m * C,), -7.0, dtype=torch.float32, device="cuda")
+        occ = None
+        if bitmaps:
+            occ = torch.empty(int(lib.qgtc_occupancy_words(m, k)), dtype=torch.int64, device="cuda")
+            assert lib.qgtc_tile_occupancy(dA.data_ptr(), dA.numel(), m, k, 1, occ.data_ptr(), occ.numel(), st) == 0
+        keep += [dA, dX, T, T2, out, occ]
+        ow = (((k + 127) // 128) + 63) // 64
+        sa.append(QgtcProblem(dA.data_ptr(), T.data_ptr(), None, dA.numel(), T.numel(), m, k, H, P128(H), ow if bitmaps else 0, occ.data_ptr() if bitmaps else None))
+        sf.append(QgtcProblem(None, dW2.data_ptr(), out.data_ptr(), 0, dW2.numel(), m, H, C, P128(C), 0, None))
+        h_o = oracle.bitmm2bit(A, t_o, m, k, H, 1, b, b)
+        want.append((out, oracle.bitmm2int(h_o, W2, m, H, C, b, b, True)))
+    host = (QgtcProblem * (3 * count))(*((sx if b == 2 else sa) + sa + sf))
+    descs = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
+    d = lambda i: descs.data_ptr() + 72 * count * i       # noqa: E731
+    if b == 2:
+        rc = lib.qgtc_chain_transform(d(0), count, max(ks), F, H, b, b, c1.data_ptr(), 0x200, st)
+        assert rc == 0, lib.qgtc_strerror(rc)
+    rc = lib.qgtc_chain_aggregate(d(1), d(2), count, max(ms), max(ks), H, C, b, b, b, 2, c2.data_ptr(), 0x200, st)
+    assert rc == 0, lib.qgtc_strerror(rc)
+    torch.cuda.synchronize()
+    for i, (o, w) in enumerate(want):
+        np.testing.assert_array_equal(o.cpu().numpy().reshape(w.shape), w, err_msg=f"seed {seed} b={b} F={F} H={H} C={C} m={ms[i]} k={ks[i]} density={density} bitmaps={bitmaps}")
+    lib.qgtc_last_batched_violation.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), vp]
+    assert lib.qgtc_last_batched_violation(None, None, st) == 0
