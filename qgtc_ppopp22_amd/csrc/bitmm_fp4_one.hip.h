@@ -246,9 +246,16 @@ __global__ __launch_bounds__(64 * ONE_WAVES) void k_bitmm_fp4_one(
     f32x4 sum;
     if (nwv == ONE_WAVES) {   // every partial exists: eight reads in flight, then a tree of adds
         f32x4 pv[ONE_WAVES];
+#ifdef QGTC_ABL_HALFRED   // timing-only build (wrong sums): what a reducer wave would save if it read and added HALF of the partials -
+                          // more than an all-eight-waves reduction can gain, which adds the cross-half exchange on top
+#pragma unroll
+        for (int p = 0; p < ONE_WAVES / 2; p++) pv[p] = part[p][wv][lane];
+        sum = (pv[0] + pv[1]) + (pv[2] + pv[3]);
+#else
 #pragma unroll
         for (int p = 0; p < ONE_WAVES; p++) pv[p] = part[p][wv][lane];
         sum = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
+#endif
     } else {
         sum = part[0][wv][lane];
         for (int p = 1; p < nwv; p++) sum += part[p][wv][lane];

@@ -264,10 +264,18 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
     const bool diag_ok = grp < kq;   // (workgroup-uniform; A is square in the epochs, so the diagonal k-quad exists)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(pr.X), 0, static_cast<int>(static_cast<uint32_t>(pr.x_words) * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t *>(pr.W), 0, static_cast<int>(static_cast<uint32_t>(kq) * static_cast<uint32_t>(lines) * 64u), 0x00020000);
+    // (the extent of T: what the chain format of a K x N operand takes, and never more than the descriptor says the buffer holds -
+    // reads past either come back as zeros)
+    const uint32_t t_bytes = static_cast<uint32_t>(kq) * static_cast<uint32_t>(lines) * 64u, t_have = static_cast<uint32_t>(pr.w_words) * 4u;
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(pr.W), 0, static_cast<int>(t_bytes < t_have ? t_bytes : t_have), 0x00020000);
     const uint32_t row_bytes = static_cast<uint32_t>(kq) * 16u;
+#ifdef QGTC_ABL_ATILES   // timing-only build: the adjacency as 512-byte tiles [row block][k-quad][32 rows][16 bytes]
+    const uint32_t x_base = m < M ? (static_cast<uint32_t>(rb) * static_cast<uint32_t>(kq) * 32u + static_cast<uint32_t>(fl)) * 16u : 0xffffffffu;
+#define RBW_XQ(q) (static_cast<uint32_t>(q) * 512u)
+#else
     const uint32_t x_base = m < M ? static_cast<uint32_t>(m) * row_bytes : 0xffffffffu;
+#define RBW_XQ(q) (static_cast<uint32_t>(q) * 16u)
+#endif
     {
         u32x4 td[2];
 #pragma unroll
@@ -284,7 +292,7 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
         for (int i = 0; i < 2; i++) t_lds[tid + 256 * i] = td[i];
     }
     // the lane's words 2 fh, 2 fh + 1 of the diagonal k-quad of its adjacency row, and the occupancy word: in flight over the barrier
-    u32x2 xd = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, (diag_ok && x_base != 0xffffffffu) ? x_base + static_cast<uint32_t>(grp) * 16u + 8u * fh : 0xffffffffu, 0, 0));
+    u32x2 xd = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, (diag_ok && x_base != 0xffffffffu) ? x_base + RBW_XQ(grp) + 8u * fh : 0xffffffffu, 0, 0));
     unsigned long long todo = kq >= 64 ? ~0ull : ((1ull << kq) - 1ull);
     if (pr.occ && 32 * rb < M) todo &= pr.occ[static_cast<size_t>(rb) * pr.occ_words];
     __syncthreads();   // (every wave of the workgroup is still at its start)
@@ -316,7 +324,7 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
                 const int qb = left != 0ull ? __builtin_ctzll(left) : -1;
                 left &= left - 1ull;
                 const int q = fh ? qb : qa;
-                xl = __builtin_amdgcn_raw_buffer_load_b128(rx, (q >= 0 && x_base != 0xffffffffu) ? x_base + static_cast<uint32_t>(q) * 16u : 0xffffffffu, 0, 0);
+                xl = __builtin_amdgcn_raw_buffer_load_b128(rx, (q >= 0 && x_base != 0xffffffffu) ? x_base + RBW_XQ(q) : 0xffffffffu, 0, 0);
                 const uint32_t t_lane = q >= 0 ? (static_cast<uint32_t>(q) * 512u + static_cast<uint32_t>(fl)) * 16u : 0xffffffffu;
 #pragma unroll
                 for (int j = 0; j < NCB1; j++)
@@ -366,9 +374,44 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
             RBW_STAMP(4);
             // (The first pair's loads issued AHEAD of the diagonal step - in flight during it - were measured: 151 registers
             // instead of 104, three waves per SIMD instead of four, 6.78 against 6.64 us per 128 x 128 chained launch.)
-            while (left != 0ull) {   // (wave-uniform)
+#ifdef QGTC_RBW_NO_SINGLE   // timing-only switch of tools/rbw_bench: a last k-quad without a partner runs as a pair
+            while (left != 0ull) {
                 load_pair();
                 multiply_pair();
+            }
+#endif
+            while ((left & (left - 1ull)) != 0ull) {   // (wave-uniform) at least two left
+                load_pair();
+                multiply_pair();
+            }
+            if (left != 0ull) {
+                // ONE k-quad left (the commonest row block of a cluster batch has exactly one beside its diagonal): as a "pair"
+                // with a missing partner it was 16 load instructions and 4 NCB1 MFMAs with half the lanes on zeros. Shared between
+                // the halves like the diagonal step instead - half fh takes words 2 fh, 2 fh + 1 of both operands: 2 NCB1 loads of
+                // T, 2 NCB1 MFMAs.
+                const int q = __builtin_ctzll(left);
+                const u32x2 xs = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, x_base != 0xffffffffu ? x_base + RBW_XQ(q) + 8u * fh : 0xffffffffu, 0, 0));
+                const uint32_t t_lane = (static_cast<uint32_t>(q) * 512u + static_cast<uint32_t>(256 * fh + fl)) * 16u;
+#pragma unroll
+                for (int j = 0; j < NCB1; j++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) tl[j][h] = __builtin_amdgcn_raw_buffer_load_b128(rt, t_lane, (h * 128 + 32 * j) * 16, AUX);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t xw[1] = {xs[h]};
+                    const i32x8 xa = fp4_op(strip_operand<1>(xw, 0));
+#pragma unroll
+                    for (int j = 0; j < NCB1; j++) {
+                        if constexpr (OB <= 2) {
+                            acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_op(tl[j][h]), xa, acc[j], 4, 4, 0, 128, 0, 128);
+                        } else {
+                            acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_op(tl[j][h][0] & 0x33333333u, tl[j][h][1] & 0x33333333u, tl[j][h][2] & 0x33333333u, tl[j][h][3] & 0x33333333u),
+                                                                                     xa, acc[j], 4, 4, 0, 128, 0, 128);
+                            acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_op((tl[j][h][0] >> 2) & 0x33333333u, (tl[j][h][1] >> 2) & 0x33333333u, (tl[j][h][2] >> 2) & 0x33333333u, (tl[j][h][3] >> 2) & 0x33333333u),
+                                                                                     xa, acc[j], 4, 4, 0, 130, 0, 128);
+                        }
+                    }
+                }
             }
         }
     }

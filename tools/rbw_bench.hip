@@ -1,6 +1,6 @@
 // tools/rbw_bench.hip — standalone (no torch) timing of the chain entries (bitmm_fp4_rbw.hip.h) on cluster-batch-like operands:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -mllvm -amdgpu-kernarg-preload-count=16 [-DQGTC_RBW_STAMPS] -o tools/rbw_bench tools/rbw_bench.hip
-//   tools/rbw_bench [count=75] [n=1213] [N1=128] [N2=128] [mode2=1] [extra_prob=0.03]
+//   [BITS=4] tools/rbw_bench [count=75] [n=1213] [N1=128] [N2=128] [mode2=1] [extra_prob=0.03]
 // 200 launches between two events (best of 5), the occupied-tile statistics of the synthetic adjacency, and with
 // -DQGTC_RBW_STAMPS the s_memtime stamps of wave 0 of the first 1024 workgroups.
 #define QGTC_SINGLE_TU 1
@@ -16,6 +16,7 @@ int main(int argc, char **argv) {
     const int count = argc > 1 ? atoi(argv[1]) : 75, n = argc > 2 ? atoi(argv[2]) : 1213;
     const int N1 = argc > 3 ? atoi(argv[3]) : 128, N2 = argc > 4 ? atoi(argv[4]) : 128, mode2 = argc > 5 ? atoi(argv[5]) : 1;
     const double extra = argc > 6 ? atof(argv[6]) : 0.03;
+    const int bits = getenv("BITS") ? atoi(getenv("BITS")) : 2;   // 2 (N1, N2 <= 128) or 4 (<= 64): the widths of the two epochs
     std::mt19937 rng(3);
     const size_t aw = qgtc_rows_words(n, n, 1), tw = qgtc_chain_words(n, N1), t2w = mode2 == 1 ? qgtc_chain_words(n, N2) : (size_t)n * (mode2 == 0 ? N1 : N2);
     const int rw = (n + 127) / 128 * 4;
@@ -33,7 +34,7 @@ int main(int argc, char **argv) {
         }
     }
     std::vector<uint32_t> ht(tw);
-    for (auto &v : ht) v = rng() & 0x33333333u;
+    for (auto &v : ht) v = rng() & (bits == 2 ? 0x33333333u : 0xffffffffu);
     uint32_t *dA, *dT, *dT2, *dW, *dWc;
     uint64_t *docc;
     const size_t occw = qgtc_occupancy_words(n, n);
@@ -48,12 +49,12 @@ int main(int argc, char **argv) {
     size_t set = 0;
     for (auto v : hocc) set += __builtin_popcountll(v);
     printf("adjacency: %zu of %zu 32-row x 128-bit tiles occupied (%.3f), %.2f k-quads per row block\n", set, occw * ((n + 127) / 128), (double)set / (occw * ((n + 127) / 128)), (double)set / occw);
-    const size_t ww = qgtc_cols_words(N1, N2, 2, 0), wcw = qgtc_weight_codes_words(N2, 2);
+    const size_t ww = qgtc_cols_words(N1, N2, bits, 0), wcw = qgtc_weight_codes_words(N2, bits);
     std::vector<uint32_t> hw(ww);
     for (auto &v : hw) v = rng();
     CK(hipMalloc(&dW, ww * 4)); CK(hipMalloc(&dWc, wcw * 4));
     CK(hipMemcpy(dW, hw.data(), ww * 4, hipMemcpyHostToDevice));
-    qgtc_expand_job ej{dW, dWc, ww, N1, N2, 2, (N2 + 127) / 128 * 128, 1, 0};
+    qgtc_expand_job ej{dW, dWc, ww, N1, N2, bits, (N2 + 127) / 128 * 128, 1, 0};
     if (int rc = qgtc_expand_weights(&ej, 1, nullptr)) { printf("expand rc=%d\n", rc); return 1; }
     std::vector<qgtc_problem> h1(count), h2(count);
     for (int b = 0; b < count; b++) {
@@ -68,7 +69,7 @@ int main(int argc, char **argv) {
     CK(hipStreamCreate(&st));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto go = [&]() { return qgtc_chain_aggregate(d1, mode2 == 0 ? nullptr : d2, count, n, n, N1, N2, 2, 2, 2, mode2, dWc, 0, st); };
+    auto go = [&]() { return qgtc_chain_aggregate(d1, mode2 == 0 ? nullptr : d2, count, n, n, N1, N2, bits, bits, bits, mode2, dWc, 0, st); };
     if (int rc = go()) { printf("rc=%d %s\n", rc, qgtc_strerror(rc)); return 1; }
     CK(hipStreamSynchronize(st));
     float best = 1e9f;
@@ -165,6 +166,17 @@ int main(int argc, char **argv) {
             for (int i = 1; i < 10; i++) sum[i] += (double)(p[i] - p[0]);
             first = std::min(first, p[0]);
             last = std::max(last, p[9]);
+        }
+        {   // when the recorded waves started and how long they ran (the dispatch ramp and the per-wave chain)
+            double s0 = 0, d = 0;
+            unsigned long long s0max = 0, dmax = 0;
+            for (int s = 0; s < 1024; s++) {
+                const unsigned long long *p = &hs[s * 16];
+                if (!p[0] || !p[9]) continue;
+                s0 += (double)(p[0] - first); d += (double)(p[9] - p[0]);
+                s0max = std::max(s0max, p[0] - first); dmax = std::max(dmax, p[9] - p[0]);
+            }
+            printf("wave starts after the first: mean %.2f us, last %.2f us; a wave runs: mean %.2f us, longest %.2f us\n", s0 / cnt * 0.01, s0max * 0.01, d / cnt * 0.01, dmax * 0.01);
         }
         printf("stamps (mean ticks from the wave's start over %d waves; 100 MHz ticks = 10 ns): desc %.0f occ %.0f loads-issued %.0f data %.0f product1 %.0f epi1 %.0f product2 %.0f epi2 %.0f end %.0f | first start -> last end %.2f us\n",
                cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, sum[6] / cnt, sum[7] / cnt, sum[8] / cnt, sum[9] / cnt, (last - first) * 0.01);
