@@ -121,28 +121,6 @@ __global__ __launch_bounds__(64 * ONE_WAVES) void k_bitmm_fp4_one(
                 wr[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rw, (q_ok && n < N && p < w) ? off + static_cast<uint32_t>(p) * w_plane : 0xffffffffu, 0, 0);
         }
     }
-    // ---- the reducer waves' epilogue plan, computed while the loads fly: reducer wave f = fi CF + fj finishes fragment
-    // f; its lane (li, g) owns "line" li of the fragment (a row for the rows layout / float32, a column for the cols
-    // layout) and four consecutive elements 4 g .. 4 g + 3 along it
-    const int fi = wv / CF, fj = wv % CF;
-    const int line = (SWAP ? m0 + 16 * fi : n0 + 16 * fj) + li;
-    const int elem0 = (SWAP ? n0 + 16 * fj : m0 + 16 * fi) + 4 * g;
-    const int line_lim = SWAP ? M : N, elem_lim = SWAP ? N : M;
-    const int n_valid = line < line_lim ? min(max(elem_lim - elem0, 0), 4) : 0;   // leading elements inside the matrix
-    const uint32_t vnib = (0xf0u >> n_valid) & 0xfu;                              // element e at bit 3 - e of the nibble
-    // bit modes: output word (line, elem / 32), element e at bit 31 - e (kernel.h:357-389 / :651-810 as intended). The
-    // fragment holds elements 16 h .. 16 h + 15 of the word: the HIGH halfword (byte offset 2) for h = 0.
-    const int pitch = SWAP ? step128(N) * 4 : step128(M) * 4;           // words per line
-    const int n_lines = SWAP ? pad8(M) : pad128(N);                      // lines that exist in the output
-    const uint32_t oplane_bytes = static_cast<uint32_t>(n_lines) * static_cast<uint32_t>(pitch) * 4u;
-    const int frag0 = SWAP ? n0 + 16 * fj : m0 + 16 * fi;               // first element of the fragment
-    const int word = frag0 >> 5;
-    uint32_t o_off = MODE == 2 ? (static_cast<uint32_t>(line) * static_cast<uint32_t>(N) + static_cast<uint32_t>(elem0)) * 4u
-                               : (static_cast<uint32_t>(line) * static_cast<uint32_t>(pitch) + static_cast<uint32_t>(word)) * 4u + ((frag0 & 16) ? 0u : 2u);
-    const bool store = MODE == 2 ? line < M : (g == 0 && line < n_lines && word < pitch);
-    if (!store) o_off = 0xffffffffu;                                     // the range check drops the store
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(outp, 0, static_cast<int>(out_bytes), 0x00020000);
-    const uint32_t sh = 12u - 4u * static_cast<uint32_t>(g);
     if (worker) {
         ONE_STAMP(1);
         uint32_t any = 0u;
@@ -199,8 +177,36 @@ __global__ __launch_bounds__(64 * ONE_WAVES) void k_bitmm_fp4_one(
 #pragma unroll
             for (int j = 0; j < CF; j++) part[wv][i * CF + j][lane] = acc[i][j];
     }
-    // (pin the plan above the barrier: what follows it is the exposed tail of the launch)
-    asm volatile("" : "+v"(o_off) : "v"(vnib), "v"(sh), "s"(oplane_bytes));
+    // ---- the reducer waves' epilogue plan, ahead of the barrier (what follows it is the exposed tail of the launch) and in the
+    // reducer waves ONLY: the other waves are the second ones of their SIMDs - the ones the barrier waits for (3.20 -> 3.14 us
+    // at 4096 x 4096 x 64, 1 bit; 3.85 -> 3.75 at 2 bits, 6.43 -> 6.33 at 8). Reducer wave f = fi CF + fj finishes fragment f; its
+    // lane (li, g) owns "line" li of the fragment (a row for the rows layout / float32, a column for the cols layout) and four
+    // consecutive elements 4 g .. 4 g + 3 along it
+    int n_valid = 0;
+    uint32_t vnib = 0u, oplane_bytes = 0u, o_off = 0xffffffffu, sh = 0u;
+    bool store = false;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(outp, 0, static_cast<int>(out_bytes), 0x00020000);
+    if (wv < NF) {
+        const int fi = wv / CF, fj = wv % CF;
+        const int line = (SWAP ? m0 + 16 * fi : n0 + 16 * fj) + li;
+        const int elem0 = (SWAP ? n0 + 16 * fj : m0 + 16 * fi) + 4 * g;
+        const int line_lim = SWAP ? M : N, elem_lim = SWAP ? N : M;
+        n_valid = line < line_lim ? min(max(elem_lim - elem0, 0), 4) : 0;   // leading elements inside the matrix
+        vnib = (0xf0u >> n_valid) & 0xfu;                                   // element e at bit 3 - e of the nibble
+        // bit modes: output word (line, elem / 32), element e at bit 31 - e (kernel.h:357-389 / :651-810 as intended). The
+        // fragment holds elements 16 h .. 16 h + 15 of the word: the HIGH halfword (byte offset 2) for h = 0.
+        const int pitch = SWAP ? step128(N) * 4 : step128(M) * 4;           // words per line
+        const int n_lines = SWAP ? pad8(M) : pad128(N);                      // lines that exist in the output
+        oplane_bytes = static_cast<uint32_t>(n_lines) * static_cast<uint32_t>(pitch) * 4u;
+        const int frag0 = SWAP ? n0 + 16 * fj : m0 + 16 * fi;               // first element of the fragment
+        const int word = frag0 >> 5;
+        o_off = MODE == 2 ? (static_cast<uint32_t>(line) * static_cast<uint32_t>(N) + static_cast<uint32_t>(elem0)) * 4u
+                          : (static_cast<uint32_t>(line) * static_cast<uint32_t>(pitch) + static_cast<uint32_t>(word)) * 4u + ((frag0 & 16) ? 0u : 2u);
+        store = MODE == 2 ? line < M : (g == 0 && line < n_lines && word < pitch);
+        if (!store) o_off = 0xffffffffu;                                     // the range check drops the store
+        sh = 12u - 4u * static_cast<uint32_t>(g);
+        asm volatile("" : "+v"(o_off) : "v"(vnib), "v"(sh), "s"(oplane_bytes));
+    }
     ONE_STAMP(3);
     __syncthreads();
     ONE_STAMP(4);
