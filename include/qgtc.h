@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QGTC_ABI_VERSION 7
+#define QGTC_ABI_VERSION 8
 
 enum {
     QGTC_OK = 0,
@@ -60,6 +60,7 @@ enum {
 #define QGTC_CHAIN_DISCARD 0x40u    /* qgtc_gcn_chain_batched: the caller does not need stage_a's output itself */
 #define QGTC_CHAIN_CODES_IN 0x80u   /* qgtc_gcn_chain_batched / qgtc_bitmm_batched: the right operands were written by a launch with _CODES_OUT */
 #define QGTC_CHAIN_CODES_OUT 0x100u /* qgtc_gcn_chain_batched / qgtc_bitmm_batched (mode 1): the outputs are only read by a launch with _CODES_IN */
+#define QGTC_CHAIN_ADJ_TILES 0x400u /* qgtc_chain_aggregate: the adjacencies (stage_a[b].X) are in the tile format of qgtc_adj_tiles_from_rows */
 #define QGTC_CHECK_DESCRIPTORS 0x200u /* grouped entry points: a one-workgroup kernel ahead of the product compares every DEVICE
                                   descriptor with the stated max_M / max_K / max_N (and the chaining rules of the two-stage
                                   entries) and records the first violation on the device; qgtc_last_batched_violation() reads it */
@@ -288,7 +289,7 @@ int qgtc_val2bit_batched(const qgtc_pack_job *jobs, int n_jobs, void *stream);
  *   mode / ob / pad128 as qgtc_bitmm_batched / qgtc_bitmm2int; use_occ: the descriptors carry the batch's bitmap.
  * qgtc_epoch_pool_layout (host only, no device work) gives the pool size in 32-bit words for the same arguments and,
  * optionally, every output's offset (offsets[s * count + b], in words) - the fill kernel uses the same rule. */
-enum { QGTC_SRC_A = 0, QGTC_SRC_X = 1, QGTC_SRC_XR = 2, QGTC_SRC_XC = 3, QGTC_SRC_WEIGHT = 16, QGTC_SRC_STAGE = 32 };
+enum { QGTC_SRC_A = 0, QGTC_SRC_X = 1, QGTC_SRC_XR = 2, QGTC_SRC_XC = 3, QGTC_SRC_AT = 4, QGTC_SRC_WEIGHT = 16, QGTC_SRC_STAGE = 32 };
 #define QGTC_DIM_NODES (-1)
 #define QGTC_MAX_STAGES 8
 #define QGTC_MAX_WEIGHTS 8
@@ -301,6 +302,7 @@ typedef struct qgtc_batch {
     qgtc_operand X;      /* features, cols layout [n, F] (a right operand: sampler.py:99) */
     qgtc_operand XR;     /* features, rows layout [n, F] (a left operand), or {NULL, 0} */
     qgtc_operand XC;     /* features in the chain format of qgtc_chain_* (qgtc_chain_from_cols of X), or {NULL, 0} */
+    qgtc_operand AT;     /* adjacency in the tile format of qgtc_chain_aggregate (qgtc_adj_tiles_from_rows of A), or {NULL, 0} */
     const uint64_t *occ; /* occupancy bitmap of A (qgtc_tile_occupancy) or NULL */
     int32_t n;           /* nodes of the batch */
     int32_t occ_words;   /* 64-bit words per row tile of `occ` */
@@ -311,7 +313,7 @@ typedef struct qgtc_stage {
     int32_t bit1, bit2, ob;
     int32_t mode;        /* 0 rows-layout bits, 1 cols-layout bits, 2 float32 */
     int32_t pad128;      /* mode 2: the right operand's planes have PAD128(N) lines (else PAD8(N)) */
-    int32_t use_occ;     /* carry the batch's occupancy bitmap (left must be QGTC_SRC_A) */
+    int32_t use_occ;     /* carry the batch's occupancy bitmap (left must be QGTC_SRC_A or QGTC_SRC_AT) */
     int32_t fmt;         /* mode 1 only: 0 = the cols layout, 1 = the chain format of qgtc_chain_* (qgtc_chain_words(n, N) words) */
 } qgtc_stage;
 size_t qgtc_epoch_pool_layout(const int32_t *nodes, int count, const qgtc_stage *stages, int n_stages, uint64_t *offsets);
@@ -329,7 +331,8 @@ int qgtc_epoch_plan_fill(const qgtc_batch *batches, int count, const qgtc_stage 
  *   qgtc_chain_aggregate:  out_mode 0: out_b = float32(A_b . T_b)                      stage_a[b] = {A_b, T_b, out_b}; stage_xw = NULL
  *                          out_mode 1: T'_b  = requant(requant(A_b . T_b) . W')        stage_a[b] = {A_b, T_b, -}, stage_xw[b] = {-, -, T'_b}
  *                          out_mode 2: out_b = float32(requant(A_b . T_b) . W')        stage_xw[b] = {-, -, out_b [M, N2]}
- * A_b: rows layout, ONE plane, K <= 8192 (occupancy bitmaps of the descriptors are followed); t_bits / act_bits /
+ * A_b: rows layout (or, with QGTC_CHAIN_ADJ_TILES, the tile format of qgtc_adj_tiles_from_rows), ONE plane, K <= 8192
+ * (occupancy bitmaps of the descriptors are followed); t_bits / act_bits /
  * out_bits = bits of T / of the aggregate / of T': all 2 with N, N2 <= 128 and 1- or 2-plane weights (t_bits also 1), or all
  * 4 with N, N2 <= 64 and 4-plane weights (Batched-GIN on ppi); qgtc_chain_transform: 2-bit only.
  * QGTC_EINVAL outside that range: callers fall back to qgtc_gcn_chain_batched. w_codes: qgtc_expand_weights order 0 for
@@ -349,6 +352,13 @@ size_t qgtc_chain_words(int M, int N);
 int qgtc_chain_from_cols(const uint32_t *cols, size_t cols_words, int H, int W, int nbits, uint32_t *chain, size_t chain_words,
                          void *stream);
 int qgtc_expand_weights(const qgtc_expand_job *jobs, int n_jobs, void *stream);
+/* A one-plane rows-layout adjacency (the public format: bit_A of sampler.py:98, [M, K]) as 512-byte tiles
+ * [32-row block][k-quad][32 rows][4 words], qgtc_adj_tiles_words(M, K) words: what a data loader makes once beside the
+ * packing for qgtc_chain_aggregate(QGTC_CHAIN_ADJ_TILES). In the rows layout the 32 rows of a tile are a whole row apart, so a
+ * launch that reads only the OCCUPIED tiles still pulls every cache line of A; as tiles it reads what it uses. Rows past M are
+ * zero. The occupancy bitmaps (qgtc_tile_occupancy of the rows layout) describe both. */
+size_t qgtc_adj_tiles_words(int M, int K);
+int qgtc_adj_tiles_from_rows(const uint32_t *rows, size_t rows_words, int M, int K, uint32_t *tiles, size_t tiles_words, void *stream);
 int qgtc_chain_transform(const qgtc_problem *stage, int count, int max_M, int K, int N, int x_bits, int out_bits,
                          const uint32_t *w_codes, unsigned flags, void *stream);
 int qgtc_chain_aggregate(const qgtc_problem *stage_a, const qgtc_problem *stage_xw, int count, int max_M, int max_K, int N1,

@@ -125,9 +125,29 @@ __global__ __launch_bounds__(256) void k_cols_to_chain(const uint32_t *__restric
     }
 }
 
+// A rows-layout adjacency (one plane, [PAD8(M)][STEP128(K) * 4 words]: QGTC_device.cu:83) as 512-byte TILES
+// [row block of 32][k-quad][32 rows][4 words] - what the aggregation kernels below read when told so (RbwShape::tiles). In the
+// rows layout the 32 lanes of a half-wave that load one k-quad touch 32 different rows (160 bytes apart in a 1213-node batch):
+// every launch pulled ALL of A out of HBM although a fifth of its tiles is occupied, and each load instruction cost the
+// address unit 32 cache lines instead of 4. Done once by the data loader beside the packing. One thread per 16 bytes.
+__global__ __launch_bounds__(256) void k_rows_to_tiles(const uint32_t *__restrict__ rows, unsigned long long words, int M, int K, uint32_t *__restrict__ tiles) {
+    const int kq = step128(K);
+    const size_t total = static_cast<size_t>((M + 31) / 32) * kq * 32;
+    for (size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const int r = static_cast<int>(t & 31);
+        const size_t tq = t >> 5;
+        const int q = static_cast<int>(tq % kq), rb = static_cast<int>(tq / kq);
+        const size_t src = (static_cast<size_t>(32 * rb + r) * kq + q) * 4u;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (32 * rb + r < pad8(M) && src + 4u <= words) v = *reinterpret_cast<const u32x4 *>(rows + src);
+        *reinterpret_cast<u32x4 *>(tiles + t * 4u) = v;
+    }
+}
+
 struct RbwShape {
     int per;      // != 0: all workgroups of a batch on one XCD
-    int a, w;     // planes of the packed left operand (k_rbw_xw) / unused
+    int a;        // planes of the packed left operand (k_rbw_xw)
+    int tiles;    // k_rbw_chain: the adjacency is in the tile format of k_rows_to_tiles (else the rows layout)
 };
 
 __device__ __forceinline__ void rbw_ids(const RbwShape &sh, int &grp, int &batch) {
@@ -236,7 +256,7 @@ __global__ __launch_bounds__(256) void k_rbw_xw(const qgtc_problem *__restrict__
 // other workgroups wrote earlier in the SAME launch). w2_lds / t_lds: the workgroup's staging areas (NCB2 x 2 x ND x 64 and 512 u32x4).
 template <int OB, int OB2, int MODE2, int NCB1, int NCB2, int AUX>
 __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgtc_problem *__restrict__ pr2p, const u32x4 *__restrict__ w2_codes,
-                                               int grp, int batch, u32x4 *__restrict__ w2_lds, u32x4 *__restrict__ t_lds
+                                               int grp, int batch, u32x4 *__restrict__ w2_lds, u32x4 *__restrict__ t_lds, bool a_tiles
 #ifdef QGTC_RBW_STAMPS
                                                , unsigned long long (&st_)[10]
 #endif
@@ -269,13 +289,12 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
     const uint32_t t_bytes = static_cast<uint32_t>(kq) * static_cast<uint32_t>(lines) * 64u, t_have = static_cast<uint32_t>(pr.w_words) * 4u;
     const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(pr.W), 0, static_cast<int>(t_bytes < t_have ? t_bytes : t_have), 0x00020000);
     const uint32_t row_bytes = static_cast<uint32_t>(kq) * 16u;
-#ifdef QGTC_ABL_ATILES   // timing-only build: the adjacency as 512-byte tiles [row block][k-quad][32 rows][16 bytes]
-    const uint32_t x_base = m < M ? (static_cast<uint32_t>(rb) * static_cast<uint32_t>(kq) * 32u + static_cast<uint32_t>(fl)) * 16u : 0xffffffffu;
-#define RBW_XQ(q) (static_cast<uint32_t>(q) * 512u)
-#else
-    const uint32_t x_base = m < M ? static_cast<uint32_t>(m) * row_bytes : 0xffffffffu;
-#define RBW_XQ(q) (static_cast<uint32_t>(q) * 16u)
-#endif
+    // the lane's row of the adjacency: k-quad q at x_base + q * xq_bytes (rows layout: 16 bytes on along the row; tiles
+    // [row block][k-quad][32 rows][16 bytes]: one tile on)   (a_tiles is launch-uniform: scalar selects)
+    const uint32_t xq_bytes = a_tiles ? 512u : 16u;
+    const uint32_t x_base = m >= M ? 0xffffffffu : (a_tiles ? (static_cast<uint32_t>(rb) * static_cast<uint32_t>(kq) * 32u + static_cast<uint32_t>(fl)) * 16u
+                                                              : static_cast<uint32_t>(m) * row_bytes);
+#define RBW_XQ(q) (static_cast<uint32_t>(q) * xq_bytes)
     {
         u32x4 td[2];
 #pragma unroll
@@ -536,7 +555,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     rbw_ids(sh, grp, batch);
     const qgtc_problem pr = prs[batch];
     if (grp >= step128(pr.M)) return;
-    rbw_chain_body<OB, OB2, MODE2, NCB1, NCB2, 0>(pr, MODE2 == 0 ? nullptr : prs2 + batch, w2_codes, grp, batch, w2_lds, t_lds
+    rbw_chain_body<OB, OB2, MODE2, NCB1, NCB2, 0>(pr, MODE2 == 0 ? nullptr : prs2 + batch, w2_codes, grp, batch, w2_lds, t_lds, sh.tiles != 0
 #ifdef QGTC_RBW_STAMPS
                                                   , st_
 #endif
@@ -631,11 +650,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const RbwShape sh{0, ea.a_planes, 0};
     rbw_xw_body<2, 2, NCBH>(p0, ea.wc[0], sh, grp);
     rbw_batch_barrier<3>(ea, batch, G, 1);
-    rbw_chain_body<2, 2, 1, NCBH, NCBH, RBW_EPOCH_AUX>(ea.st[1][batch], ea.st[2] + batch, ea.wc[1], grp, batch, w2_lds, t_lds RBW_ST_ARG);
+    rbw_chain_body<2, 2, 1, NCBH, NCBH, RBW_EPOCH_AUX>(ea.st[1][batch], ea.st[2] + batch, ea.wc[1], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
     rbw_batch_barrier<3>(ea, batch, G, 2);
-    rbw_chain_body<2, 2, 1, NCBH, NCBC, RBW_EPOCH_AUX>(ea.st[3][batch], ea.st[4] + batch, ea.wc[2], grp, batch, w2_lds, t_lds RBW_ST_ARG);
+    rbw_chain_body<2, 2, 1, NCBH, NCBC, RBW_EPOCH_AUX>(ea.st[3][batch], ea.st[4] + batch, ea.wc[2], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
     rbw_batch_barrier<3>(ea, batch, G, 3);
-    rbw_chain_body<2, 2, 0, NCBC, 1, RBW_EPOCH_AUX>(ea.st[5][batch], nullptr, nullptr, grp, batch, w2_lds, t_lds RBW_ST_ARG);
+    rbw_chain_body<2, 2, 0, NCBC, 1, RBW_EPOCH_AUX>(ea.st[5][batch], nullptr, nullptr, grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
 }
 
 // Batched-GIN, 4 bits: T1 = rq(rq(A . X) . W1) | T2 = rq(rq(A . T1) . W2) | out = float32(rq(A . T2) . W3) (main_qgtc.py:131-138)
@@ -651,11 +670,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const qgtc_problem p0 = ea.st[0][batch];
     const int G = step128(p0.M);
     if (grp >= G) return;
-    rbw_chain_body<4, 4, 1, NCBF, NCBH, 0>(p0, ea.st[1] + batch, ea.wc[0], grp, batch, w2_lds, t_lds RBW_ST_ARG);
+    rbw_chain_body<4, 4, 1, NCBF, NCBH, 0>(p0, ea.st[1] + batch, ea.wc[0], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
     rbw_batch_barrier<2>(ea, batch, G, 1);
-    rbw_chain_body<4, 4, 1, NCBH, NCBH, RBW_EPOCH_AUX>(ea.st[2][batch], ea.st[3] + batch, ea.wc[1], grp, batch, w2_lds, t_lds RBW_ST_ARG);
+    rbw_chain_body<4, 4, 1, NCBH, NCBH, RBW_EPOCH_AUX>(ea.st[2][batch], ea.st[3] + batch, ea.wc[1], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
     rbw_batch_barrier<2>(ea, batch, G, 2);
-    rbw_chain_body<4, 4, 2, NCBH, NCBC, RBW_EPOCH_AUX>(ea.st[4][batch], ea.st[5] + batch, ea.wc[2], grp, batch, w2_lds, t_lds RBW_ST_ARG);
+    rbw_chain_body<4, 4, 2, NCBH, NCBC, RBW_EPOCH_AUX>(ea.st[4][batch], ea.st[5] + batch, ea.wc[2], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
 }
 #undef RBW_ST_ARG
 

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(1024) void k_epoch_plan_fill(const qgtc_batch *__re
                         ptr = pa.weight[src - QGTC_SRC_WEIGHT].ptr;
                         w = pa.weight[src - QGTC_SRC_WEIGHT].words;
                     } else {
-                        const qgtc_operand o = src == QGTC_SRC_A ? bt.A : (src == QGTC_SRC_X ? bt.X : (src == QGTC_SRC_XR ? bt.XR : bt.XC));
+                        const qgtc_operand o = src == QGTC_SRC_A ? bt.A : (src == QGTC_SRC_X ? bt.X : (src == QGTC_SRC_XR ? bt.XR : (src == QGTC_SRC_XC ? bt.XC : bt.AT)));
                         ptr = o.ptr;
                         w = o.words;
                     }

@@ -26,7 +26,8 @@ int qgtc_launch_rbw_epoch(const qgtc_problem *const *stages, int kind, int count
 int qgtc_launch_cols_to_chain(const uint32_t *cols, size_t words, int H, int W, int nbits, uint32_t *chain, hipStream_t st);
 int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int N, int a, int ob, const uint32_t *w_codes, hipStream_t st);
 int qgtc_launch_rbw_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int N1, int N2, int t_bits, int act_bits,
-                          int out_bits, int mode2, const uint32_t *w2_codes, hipStream_t st);
+                          int out_bits, int mode2, const uint32_t *w2_codes, bool a_tiles, hipStream_t st);
+int qgtc_launch_rows_to_tiles(const uint32_t *rows, size_t words, int M, int K, uint32_t *tiles, hipStream_t st);
 
 // defined in qgtc_wide.hip
 int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st);

@@ -291,11 +291,19 @@ int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int N, int
     return QGTC_OK;
 }
 
+int qgtc_launch_rows_to_tiles(const uint32_t *rows, size_t words, int M, int K, uint32_t *tiles, hipStream_t st) {
+    const size_t total = static_cast<size_t>((M + 31) / 32) * step128(K) * 32u;
+    hipLaunchKernelGGL(k_rows_to_tiles, dim3(static_cast<unsigned>(std::min<size_t>((total + 255) / 256, 4096))), dim3(256), 0, st, rows,
+                       static_cast<unsigned long long>(words), M, K, tiles);
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
 int qgtc_launch_rbw_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int N1, int N2, int t_bits, int act_bits,
-                          int out_bits, int mode2, const uint32_t *w2_codes, hipStream_t st) {
+                          int out_bits, int mode2, const uint32_t *w2_codes, bool a_tiles, hipStream_t st) {
     (void)act_bits;   // (1- and 2-bit T are the same codes: one base-4 digit per nibble)
     (void)out_bits;
-    RbwShape sh{getenv_flag("QGTC_NO_XCD") ? 0 : 1, 1, 0};
+    RbwShape sh{getenv_flag("QGTC_NO_XCD") ? 0 : 1, 1, a_tiles ? 1 : 0};
     const dim3 grid(step128(max_M), count), block(256);
     const u32x4 *wc = reinterpret_cast<const u32x4 *>(w2_codes);
     const int c1 = (N1 + 31) / 32, c2 = mode2 == 0 ? 1 : (N2 + 31) / 32;

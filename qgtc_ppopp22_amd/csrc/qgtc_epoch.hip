@@ -106,13 +106,13 @@ static bool stages_ok(const qgtc_stage *stages, int n_stages, int n_weights) {
         auto src_ok = [&](int src) {
             if (src >= QGTC_SRC_STAGE) return src - QGTC_SRC_STAGE < s && stages[src - QGTC_SRC_STAGE].mode != 2;
             if (src >= QGTC_SRC_WEIGHT) return src - QGTC_SRC_WEIGHT < n_weights;
-            return src == QGTC_SRC_A || src == QGTC_SRC_X || src == QGTC_SRC_XR || src == QGTC_SRC_XC;
+            return src == QGTC_SRC_A || src == QGTC_SRC_X || src == QGTC_SRC_XR || src == QGTC_SRC_XC || src == QGTC_SRC_AT;
         };
         const bool l_ok = src_ok(st.left), r_ok = src_ok(st.right);
         if (!l_ok || !r_ok) return false;
         if ((st.K <= 0 && st.K != QGTC_DIM_NODES) || st.N <= 0) return false;
         if (!bits_ok(st.bit1) || !bits_ok(st.bit2) || st.mode < 0 || st.mode > 2 || (st.mode != 2 && !bits_ok(st.ob))) return false;
-        if (st.use_occ && st.left != QGTC_SRC_A) return false;
+        if (st.use_occ && st.left != QGTC_SRC_A && st.left != QGTC_SRC_AT) return false;
         if (st.fmt != 0 && (st.fmt != 1 || st.mode != 1)) return false;
     }
     return true;

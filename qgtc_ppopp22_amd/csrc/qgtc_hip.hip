@@ -432,7 +432,17 @@ int qgtc_chain_aggregate(const qgtc_problem *stage_a, const qgtc_problem *stage_
         const int crc = qgtc_launch_check_descriptors(stage_a, nullptr, count, max_M, max_K, N1, 0, 0, out_mode == 0 ? 0 : 3, st);
         if (crc != QGTC_OK) return crc;
     }
-    return qgtc_launch_rbw_chain(stage_a, out_mode == 0 ? nullptr : stage_xw, count, max_M, N1, N2, t_bits, act_bits, out_bits, out_mode, w2_codes, st);
+    return qgtc_launch_rbw_chain(stage_a, out_mode == 0 ? nullptr : stage_xw, count, max_M, N1, N2, t_bits, act_bits, out_bits, out_mode, w2_codes,
+                                 (flags & QGTC_CHAIN_ADJ_TILES) != 0u, st);
+}
+
+size_t qgtc_adj_tiles_words(int M, int K) { return (M > 0 && K > 0) ? static_cast<size_t>((M + 31) / 32) * step128(K) * 128u : 0u; }
+
+int qgtc_adj_tiles_from_rows(const uint32_t *rows, size_t rows_words, int M, int K, uint32_t *tiles, size_t tiles_words, void *stream) {
+    if (!rows || !tiles || M <= 0 || K <= 0) return QGTC_EINVAL;
+    if (tiles_words < qgtc_adj_tiles_words(M, K)) return QGTC_ESIZE;
+    if (!aligned16(rows) || !aligned16(tiles)) return QGTC_EALIGN;
+    return qgtc_launch_rows_to_tiles(rows, rows_words, M, K, tiles, static_cast<hipStream_t>(stream));
 }
 
 size_t qgtc_chain_epoch_sync_words(int count) { return count > 0 ? static_cast<size_t>(count + 1) * 64u : 0u; }

@@ -748,6 +748,7 @@ struct EpochPlan {
     int count = 0, max_n = 0, a_bits = 1;
     bool jumping = false;
     bool x_chain = false;   // the batches' X also exists in the chain format (QGTC_SRC_XC)
+    bool a_tiles = false;   // the batches' adjacency also exists in the tile format of qgtc_chain_aggregate (QGTC_SRC_AT)
     double occupied = 1.0;
     // bound state
     std::vector<qgtc_stage> stages;
@@ -773,10 +774,13 @@ struct EpochPlan {
 
     // x_chain_bits > 0: every X (cols layout [n, x_cols], x_chain_bits planes) is also kept in the chain format of the
     // chain entries (qgtc_chain_from_cols) - for epochs whose FIRST product is an aggregation A . X (Batched-GIN)
+    // a_tiles_: every one-plane adjacency is also kept as 512-byte tiles (qgtc_adj_tiles_from_rows) for the aggregation launches of
+    // the chain entries - one pooled allocation, converted here, beside the packing
     EpochPlan(std::vector<torch::Tensor> As, std::vector<torch::Tensor> Xs, std::vector<torch::Tensor> Xrs, std::vector<int> ns,
-              int a_bits_, bool zero_jump, int x_chain_bits, int x_cols) : a_bits(a_bits_) {
+              int a_bits_, bool zero_jump, int x_chain_bits, int x_cols, bool a_tiles_) : a_bits(a_bits_) {
         count = static_cast<int>(As.size());
         x_chain = x_chain_bits > 0;
+        a_tiles = a_tiles_ && a_bits_ == 1;
         TORCH_CHECK(count > 0 && count <= 65535, "1..65535 cluster batches");
         TORCH_CHECK(static_cast<int>(Xs.size()) == count && static_cast<int>(ns.size()) == count, "one X and one node count per batch");
         TORCH_CHECK(Xrs.empty() || static_cast<int>(Xrs.size()) == count, "Xrs: none, or one per batch");
@@ -800,8 +804,22 @@ struct EpochPlan {
             return qgtc_operand{words(t), static_cast<uint64_t>(t.numel())};
         };
         std::vector<qgtc_problem> tmp(count);   // the adjacencies as left operands, for the bitmap launch
+        torch::Tensor tile_pool;
+        std::vector<int64_t> tile_off(count + 1, 0);
+        if (a_tiles) {
+            for (int i = 0; i < count; i++) tile_off[i + 1] = tile_off[i] + static_cast<int64_t>(qgtc_adj_tiles_words(ns[i], ns[i]));
+            tile_pool = torch::empty({tile_off[count]}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
+            keep.push_back(tile_pool);
+        }
         for (int i = 0; i < count; i++) {
             h[i].A = operand(As[i], "A");
+            h[i].AT = qgtc_operand{nullptr, 0};
+            if (a_tiles) {
+                uint32_t *tp = words_mut(tile_pool) + tile_off[i];
+                const size_t tw = static_cast<size_t>(tile_off[i + 1] - tile_off[i]);
+                check_rc(qgtc_adj_tiles_from_rows(h[i].A.ptr, h[i].A.words, ns[i], ns[i], tp, tw, current_stream(tile_pool)), "EpochPlan (adjacency tiles)");
+                h[i].AT = qgtc_operand{tp, static_cast<uint64_t>(tw)};
+            }
             h[i].X = operand(Xs[i], "X");
             h[i].XR = Xrs.empty() ? qgtc_operand{nullptr, 0} : operand(Xrs[i], "Xr");
             h[i].XC = qgtc_operand{nullptr, 0};
@@ -931,13 +949,14 @@ struct EpochPlan {
                      "EpochPlan.run (chain transform)");
         } else if (l.kind == 4) {
             const qgtc_stage &a = stages[l.s1];
+            const unsigned tiles = a.left == QGTC_SRC_AT ? QGTC_CHAIN_ADJ_TILES : 0u;
             if (l.s2 < 0) {
-                check_rc(qgtc_chain_aggregate(stage_descs(l.s1), nullptr, count, max_n, dimK(a), a.N, 0, a.bit2, 0, 0, 0, nullptr, check, st),
+                check_rc(qgtc_chain_aggregate(stage_descs(l.s1), nullptr, count, max_n, dimK(a), a.N, 0, a.bit2, 0, 0, 0, nullptr, check | tiles, st),
                          "EpochPlan.run (chain aggregate, float32)");
             } else {
                 const qgtc_stage &x = stages[l.s2];
                 check_rc(qgtc_chain_aggregate(stage_descs(l.s1), stage_descs(l.s2), count, max_n, dimK(a), a.N, x.N, a.bit2, a.ob, x.ob, x.mode,
-                                              words(weight_codes[l.codes]), check, st), "EpochPlan.run (chain aggregate)");
+                                              words(weight_codes[l.codes]), check | tiles, st), "EpochPlan.run (chain aggregate)");
             }
         } else {
             const qgtc_stage &a = stages[l.s1], &b = stages[l.s2];
@@ -1102,9 +1121,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         return py::make_tuple(rc, problem, field);
     }, "(rc, problem, field) of the first descriptor a QGTC_CHECK_DESCRIPTORS launch on this tensor's device found in violation");
     py::class_<EpochPlan, std::shared_ptr<EpochPlan>>(m, "EpochPlan")
-        .def(py::init<std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<int>, int, bool, int, int>(),
+        .def(py::init<std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<int>, int, bool, int, int, bool>(),
              py::arg("As"), py::arg("Xs"), py::arg("Xrs"), py::arg("nodes"), py::arg("a_bits") = 1, py::arg("zero_jump") = true,
-             py::arg("x_chain_bits") = 0, py::arg("x_cols") = 0)
+             py::arg("x_chain_bits") = 0, py::arg("x_cols") = 0, py::arg("a_tiles") = false)
         .def("bind", &EpochPlan::bind, py::arg("weights"), py::arg("stages"), py::arg("launches"), py::arg("expand") = std::vector<std::array<int, 5>>(),
              py::arg("whole") = std::vector<int>(),
              "weights: packed tensors; stages: (left, right, K, N, bit1, bit2, ob, mode, pad128, use_occ, fmt); launches: (kind, s1, s2, flags, "
@@ -1120,6 +1139,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def_readonly("count", &EpochPlan::count)
         .def_readonly("zero_jump", &EpochPlan::jumping)
         .def_readonly("x_chain", &EpochPlan::x_chain)
+        .def_readonly("a_tiles", &EpochPlan::a_tiles)
         .def_readonly("whole_epoch", &EpochPlan::whole_ok, "the bound plan runs as ONE launch (qgtc_chain_epoch)")
         .def("whole_epoch_failed", [](EpochPlan &p) {
             if (!p.sync.defined()) return false;
@@ -1132,6 +1152,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.attr("SRC_X") = static_cast<int>(QGTC_SRC_X);
     m.attr("SRC_XR") = static_cast<int>(QGTC_SRC_XR);
     m.attr("SRC_XC") = static_cast<int>(QGTC_SRC_XC);
+    m.attr("SRC_AT") = static_cast<int>(QGTC_SRC_AT);
     m.attr("SRC_WEIGHT") = static_cast<int>(QGTC_SRC_WEIGHT);
     m.attr("SRC_STAGE") = static_cast<int>(QGTC_SRC_STAGE);
     m.attr("DIM_NODES") = static_cast<int>(QGTC_DIM_NODES);

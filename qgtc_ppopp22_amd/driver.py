@@ -347,6 +347,9 @@ class PlannedEpoch:
             self.discarded = {0, 1, 2, 3, 4}
             if whole_epoch and C <= 32:
                 whole = [0, F, H, C, b, 0, 1, 2]
+            elif getattr(data, "a_tiles", False):   # the aggregations read the adjacency as tiles (the one-launch epoch reads rows)
+                for i in (1, 3, 5):
+                    stages[i] = (Q.SRC_AT,) + stages[i][1:]
         elif (fuse and chain == "correct" and chain_stages and run_gin and not keep_aggregates and b == 4 and max(F, H, C) <= 64 and max_n <= 8192
                 and Q.get_engine() != "popcount" and not switches and getattr(data, "x_chain", False)):
             # Batched-GIN at 4 bits on the same entries: A.X + .W1 | A.T1 + .W2 | A.T2 + .W3 -> float32, three launches; X in the
@@ -359,6 +362,9 @@ class PlannedEpoch:
             self.discarded = {0, 1, 2, 3, 4}
             if whole_epoch and C <= 32:
                 whole = [1, F, H, C, b, 0, 1, 2]
+            elif getattr(data, "a_tiles", False):
+                for i in (0, 2, 4):
+                    stages[i] = (Q.SRC_AT,) + stages[i][1:]
         elif fuse and chain == "correct" and chain_stages:
             # an aggregation stage and the NEXT layer's X.W stage are one call (qgtc_gcn_chain_batched), T between the
             # launches of a chain in the kernels' own format where every launch can keep it (see BatchedEpoch)

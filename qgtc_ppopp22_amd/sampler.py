@@ -110,8 +110,10 @@ class ClusterIter:
             # widths are the ones those entries cover (4 bits, at most 64 features)
             feat = self.cluster_param_li[0][3] if self.cluster_param_li else 0
             x_chain = self.bit_width if (self.run_GIN and self.bit_width == 4 and feat <= 64) else 0
+            # the adjacencies also as 512-byte tiles for the aggregation launches of those entries (2-bit Cluster-GCN, 4-bit Batched-GIN)
+            a_tiles = x_chain > 0 or (not self.run_GIN and self.bit_width == 2)
             self._epoch_data = qgtc.EpochPlan([c.bit_A for c in cts], [c.bit_X for c in cts], rows, [p[0] for p in self.cluster_param_li], 1, True,
-                                              x_chain, feat)
+                                              x_chain, feat, a_tiles)
             self.x_in_chain_format = x_chain > 0
         return self._epoch_data
 

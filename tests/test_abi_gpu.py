@@ -185,8 +185,8 @@ class QgtcOperand(ctypes.Structure):
 
 class QgtcBatch(ctypes.Structure):
     """include/qgtc.h: struct qgtc_batch - what the data loader knows of one cluster batch."""
-    _fields_ = [("A", QgtcOperand), ("X", QgtcOperand), ("XR", QgtcOperand), ("XC", QgtcOperand), ("occ", ctypes.c_void_p), ("n", ctypes.c_int32),
-                ("occ_words", ctypes.c_int32)]
+    _fields_ = [("A", QgtcOperand), ("X", QgtcOperand), ("XR", QgtcOperand), ("XC", QgtcOperand), ("AT", QgtcOperand), ("occ", ctypes.c_void_p),
+                ("n", ctypes.c_int32), ("occ_words", ctypes.c_int32)]
 
 
 class QgtcStage(ctypes.Structure):
@@ -206,7 +206,7 @@ def test_epoch_plan_filled_on_the_device_with_raw_pointers(lib, oracle):
     weights packed in one launch, the descriptors of a layout-correct two-layer GCN slice (X.W1 -> A.T1 -> .W2 -> A.T2 as
     float32) filled by ONE launch from the per-batch table, QGTC_CHECK_DESCRIPTORS on every launch - against the oracle."""
     import torch
-    assert ctypes.sizeof(QgtcBatch) == 80 and ctypes.sizeof(QgtcStage) == 44 and ctypes.sizeof(QgtcPackJob) == 48
+    assert ctypes.sizeof(QgtcBatch) == 96 and ctypes.sizeof(QgtcStage) == 44 and ctypes.sizeof(QgtcPackJob) == 48
     lib.qgtc_val2bit_batched.argtypes = [vp, ctypes.c_int, vp]
     lib.qgtc_epoch_pool_layout.restype = ctypes.c_size_t
     lib.qgtc_epoch_pool_layout.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp]
@@ -239,7 +239,7 @@ def test_epoch_plan_filled_on_the_device_with_raw_pointers(lib, oracle):
         A, Xr = oracle.pack(qa, 1, False), oracle.pack(qx, b, False)
         dA, dXr = torch.from_numpy(A.view(np.int32)).cuda(), torch.from_numpy(Xr.view(np.int32)).cuda()
         keep += [dA, dXr]
-        hb.append(QgtcBatch(QgtcOperand(dA.data_ptr(), dA.numel()), QgtcOperand(None, 0), QgtcOperand(dXr.data_ptr(), dXr.numel()), QgtcOperand(None, 0), None, n, 0))
+        hb.append(QgtcBatch(QgtcOperand(dA.data_ptr(), dA.numel()), QgtcOperand(None, 0), QgtcOperand(dXr.data_ptr(), dXr.numel()), QgtcOperand(None, 0), QgtcOperand(None, 0), None, n, 0))
         t1 = oracle.bitmm2bit(Xr, W_o[0], n, F, H, b, b, b, col=True)
         h1 = oracle.bitmm2bit(A, t1, n, n, H, 1, b, b)
         t2 = oracle.bitmm2bit(h1, W_o[1], n, H, C, b, b, b, col=True)
@@ -468,7 +468,8 @@ def test_chain_entries_at_four_bits(lib, oracle, M, F, H, C, bitmaps):
 def test_chain_entries_random_sweep(lib, oracle, seed):
     """Random shapes through the chain entries against the oracle: node counts around the 32 / 128 boundaries (and below 32), widths
     around the 32-column blocks, 2-bit (N <= 128) and 4-bit (N <= 64) chains, adjacency density from empty to dense, K != M, pooled
-    and absent bitmaps - X.W (or the converted X) -> aggregation + transform -> float32 aggregation."""
+    and absent bitmaps, the adjacency in the rows layout (even seeds) or as tiles (odd seeds: qgtc_adj_tiles_from_rows, checked word
+    for word, + QGTC_CHAIN_ADJ_TILES) - X.W (or the converted X) -> aggregation + transform -> float32 aggregation."""
     import torch
     rng = np.random.default_rng(1000 + seed)
     lib.qgtc_weight_codes_words.restype = lib.qgtc_chain_words.restype = lib.qgtc_occupancy_words.restype = ctypes.c_size_t
@@ -477,8 +478,11 @@ def test_chain_entries_random_sweep(lib, oracle, seed):
     lib.qgtc_chain_transform.argtypes = [vp, ctypes.c_int] + [ctypes.c_int] * 5 + [vp, ctypes.c_uint, vp]
     lib.qgtc_chain_aggregate.argtypes = [vp, vp, ctypes.c_int] + [ctypes.c_int] * 8 + [vp, ctypes.c_uint, vp]
     lib.qgtc_tile_occupancy.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+    lib.qgtc_adj_tiles_words.restype = ctypes.c_size_t
+    lib.qgtc_adj_tiles_from_rows.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P128 = lambda x: (x + 127) // 128 * 128   # noqa: E731
+    tiles = seed % 2 == 1
     b = int(rng.choice([2, 2, 4]))
     wmax = 128 if b == 2 else 64
     pick = lambda hi: int(rng.choice([1, 7, 31, 32, 33, 63, 64, 65, 96, 127, 128, int(rng.integers(1, hi + 1))]))   # noqa: E731
@@ -520,6 +524,17 @@ def test_chain_entries_random_sweep(lib, oracle, seed):
             assert lib.qgtc_tile_occupancy(dA.data_ptr(), dA.numel(), m, k, 1, occ.data_ptr(), occ.numel(), st) == 0
         keep += [dA, dX, T, T2, out, occ]
         ow = (((k + 127) // 128) + 63) // 64
+        if tiles:   # [32-row block][k-quad][32 rows][4 words], zeros past the packed rows
+            kq, rbs = (k + 127) // 128, (m + 31) // 32
+            assert lib.qgtc_adj_tiles_words(m, k) == rbs * kq * 128
+            dT = torch.full((rbs * kq * 128,), -1, dtype=torch.int32, device="cuda")
+            assert lib.qgtc_adj_tiles_from_rows(dA.data_ptr(), dA.numel(), m, k, dT.data_ptr(), dT.numel() - 1, st) == 2      # undersized
+            assert lib.qgtc_adj_tiles_from_rows(dA.data_ptr(), dA.numel(), m, k, dT.data_ptr(), dT.numel(), st) == 0
+            rows = np.zeros((rbs * 32, kq, 4), dtype=np.uint32)
+            rows[:A.size // (kq * 4)] = A.reshape(-1, kq, 4)
+            np.testing.assert_array_equal(dT.cpu().numpy().view(np.uint32).reshape(rbs, kq, 32, 4), rows.reshape(rbs, 32, kq, 4).transpose(0, 2, 1, 3))
+            keep.append(dT)
+            dA = dT
         sa.append(QgtcProblem(dA.data_ptr(), T.data_ptr(), None, dA.numel(), T.numel(), m, k, H, P128(H), ow if bitmaps else 0, occ.data_ptr() if bitmaps else None))
         sf.append(QgtcProblem(None, dW2.data_ptr(), out.data_ptr(), 0, dW2.numel(), m, H, C, P128(C), 0, None))
         h_o = oracle.bitmm2bit(A, t_o, m, k, H, 1, b, b)
@@ -530,7 +545,7 @@ def test_chain_entries_random_sweep(lib, oracle, seed):
     if b == 2:
         rc = lib.qgtc_chain_transform(d(0), count, max(ks), F, H, b, b, c1.data_ptr(), 0x200, st)
         assert rc == 0, lib.qgtc_strerror(rc)
-    rc = lib.qgtc_chain_aggregate(d(1), d(2), count, max(ms), max(ks), H, C, b, b, b, 2, c2.data_ptr(), 0x200, st)
+    rc = lib.qgtc_chain_aggregate(d(1), d(2), count, max(ms), max(ks), H, C, b, b, b, 2, c2.data_ptr(), 0x200 | (0x400 if tiles else 0), st)
     assert rc == 0, lib.qgtc_strerror(rc)
     torch.cuda.synchronize()
     for i, (o, w) in enumerate(want):

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_errors(lib):
-    assert lib.qgtc_abi_version() == 7
+    assert lib.qgtc_abi_version() == 8
     assert lib.qgtc_strerror(0) == b"ok"
     for code in range(1, 6):
         assert lib.qgtc_strerror(code) not in (b"ok", b"unknown error")
@@ -114,6 +114,8 @@ def test_epoch_pool_layout_and_layer_route_are_host_side(lib, oracle):
     sizes = [oracle.cols_words(n, 128, 2, False) for n in ns] + [oracle.rows_words(n, 128, 3) for n in ns] + [(n * 10 + 3) // 4 * 4 for n in ns] \
         + [lib.qgtc_chain_words(n, 100) for n in ns]                       # fmt 1: the chain format of qgtc_chain_*
     assert [lib.qgtc_chain_words(n, 100) for n in ns] == [(n + 127) // 128 * 128 * 16 for n in ns]
+    lib.qgtc_adj_tiles_words.restype = ctypes.c_size_t                     # 512-byte tiles: [32-row block][k-quad][32 rows][4 words]
+    assert lib.qgtc_adj_tiles_words(1213, 1213) == 38 * 10 * 128 and lib.qgtc_adj_tiles_words(1, 129) == 2 * 128 and lib.qgtc_adj_tiles_words(0, 5) == 0
     assert lib.qgtc_weight_codes_words(100, 2) == 4 * 2 * 64 * 4 and lib.qgtc_weight_codes_words(50, 4) == 2 * 2 * 2 * 64 * 4
     assert total == sum(sizes)
     assert list(offs) == [sum(sizes[:i]) for i in range(len(sizes))]
