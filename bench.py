@@ -310,7 +310,8 @@ def epoch_roofline(Q, graph, device_index, dataset, bits, hidden, gin):
     return {"kernel_us_per_epoch": round(epoch_us, 2), "kernel_us_per_operator_alone": stage_us, "calls_per_epoch": plan.n_launches,
             "launches_per_epoch": plan.n_launches,
             "launch_structure": (f"6 operators in {plan.n_launches} launches: {chained} aggregation stages carry the next "
-                                 "layer's X.W stage (qgtc_gcn_chain_batched)") if chained else "6 grouped launches",
+                                 "layer's X.W stage (qgtc_chain_transform / qgtc_chain_aggregate; adjacency "
+                                 + ("as 512-byte tiles" if getattr(data, "a_tiles", False) else "in the rows layout") + ")") if chained else "6 grouped launches",
             "host_weight_pack_and_plan_bind_ms": round(host_ms, 4),
             "host_note": "host time of the two calls main_qgtc.py:96 puts inside its clock besides the launches: one fill + one pack "
                          "launch for the three weights, one allocation + ONE launch that fills every stage's descriptors on the device "

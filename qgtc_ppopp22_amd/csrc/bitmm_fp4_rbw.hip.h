@@ -179,7 +179,13 @@ __device__ __forceinline__ void rbw_store_codes(const f32x16 &acc, uint32_t *__r
         x[t] = (P[t] & (OB == 1 ? 0x01010101u : (OB == 2 ? 0x03030303u : 0x0f0f0f0fu))) << (4u - 4u * static_cast<uint32_t>(fh));   // nibble 7 - 2 gq - fh of dword 3 - t
         x[t] = or_with_partner_half(x[t]);
     }
+    // (non-temporal: nobody in THIS launch reads T', and what a launch leaves dirty in the L2s is written back at its end, before
+    // the next launch may start - 6 MB of T' per 128-column launch: 6.20 -> 5.90 us. -DQGTC_RBW_PLAIN_STORES: the A/B build)
+#ifdef QGTC_RBW_PLAIN_STORES
     if (fh == 0 && ok) *reinterpret_cast<u32x4 *>(dst) = u32x4{x[3], x[2], x[1], x[0]};
+#else
+    if (fh == 0 && ok) __builtin_nontemporal_store(u32x4{x[3], x[2], x[1], x[0]}, reinterpret_cast<u32x4 *>(dst));
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -473,7 +479,7 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
                     } else {
 #pragma unroll
                         for (int t = 0; t < 4; t++)
-                            if (32 * j + e + t < N) dst[e + t] = acc[j][4 * g + t];
+                            if (32 * j + e + t < N) dst[e + t] = acc[j][4 * g + t];   // (non-temporal here: 4.5 -> 5.8 us - partial lines go out one by one)
                     }
                 }
             }

@@ -1,6 +1,6 @@
 // tools/rbw_bench.hip — standalone (no torch) timing of the chain entries (bitmm_fp4_rbw.hip.h) on cluster-batch-like operands:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -mllvm -amdgpu-kernarg-preload-count=16 [-DQGTC_RBW_STAMPS] -o tools/rbw_bench tools/rbw_bench.hip
-//   [BITS=4] tools/rbw_bench [count=75] [n=1213] [N1=128] [N2=128] [mode2=1] [extra_prob=0.03]
+//   [BITS=4] [TILES=1] tools/rbw_bench [count=75] [n=1213] [N1=128] [N2=128] [mode2=1] [extra_prob=0.03]
 // 200 launches between two events (best of 5), the occupied-tile statistics of the synthetic adjacency, and with
 // -DQGTC_RBW_STAMPS the s_memtime stamps of wave 0 of the first 1024 workgroups.
 #define QGTC_SINGLE_TU 1
@@ -56,9 +56,18 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(dW, hw.data(), ww * 4, hipMemcpyHostToDevice));
     qgtc_expand_job ej{dW, dWc, ww, N1, N2, bits, (N2 + 127) / 128 * 128, 1, 0};
     if (int rc = qgtc_expand_weights(&ej, 1, nullptr)) { printf("expand rc=%d\n", rc); return 1; }
+    const bool tiles = getenv("TILES") != nullptr;   // the adjacency as 512-byte tiles (qgtc_adj_tiles_from_rows + QGTC_CHAIN_ADJ_TILES)
+    const size_t atw = qgtc_adj_tiles_words(n, n);
+    uint32_t *dAT = nullptr;
+    if (tiles) {
+        CK(hipMalloc(&dAT, atw * 4 * count));
+        for (int b = 0; b < count; b++)
+            if (int rc = qgtc_adj_tiles_from_rows(dA + aw * b, aw, n, n, dAT + atw * b, atw, nullptr)) { printf("tiles rc=%d\n", rc); return 1; }
+        CK(hipDeviceSynchronize());
+    }
     std::vector<qgtc_problem> h1(count), h2(count);
     for (int b = 0; b < count; b++) {
-        h1[b] = qgtc_problem{dA + aw * b, dT + tw * b, mode2 == 0 ? (void *)(dT2 + t2w * b) : nullptr, aw, tw, n, n, N1, 128, 1, getenv("NOOCC") ? nullptr : docc + occw * b};
+        h1[b] = qgtc_problem{tiles ? dAT + atw * b : dA + aw * b, dT + tw * b, mode2 == 0 ? (void *)(dT2 + t2w * b) : nullptr, tiles ? atw : aw, tw, n, n, N1, 128, 1, getenv("NOOCC") ? nullptr : docc + occw * b};
         h2[b] = qgtc_problem{nullptr, dW, dT2 + t2w * b, 0, ww, n, N1, N2, 128, 0, nullptr};
     }
     qgtc_problem *d1, *d2;
@@ -69,7 +78,7 @@ int main(int argc, char **argv) {
     CK(hipStreamCreate(&st));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto go = [&]() { return qgtc_chain_aggregate(d1, mode2 == 0 ? nullptr : d2, count, n, n, N1, N2, bits, bits, bits, mode2, dWc, 0, st); };
+    auto go = [&]() { return qgtc_chain_aggregate(d1, mode2 == 0 ? nullptr : d2, count, n, n, N1, N2, bits, bits, bits, mode2, dWc, tiles ? QGTC_CHAIN_ADJ_TILES : 0u, st); };
     if (int rc = go()) { printf("rc=%d %s\n", rc, qgtc_strerror(rc)); return 1; }
     CK(hipStreamSynchronize(st));
     float best = 1e9f;
