@@ -64,32 +64,58 @@ struct PlanArgs {
     int n_stages, n_weights, count;
 };
 
-__global__ __launch_bounds__(1024) void k_epoch_plan_fill(const qgtc_batch *__restrict__ batches, PlanArgs pa, uint32_t *__restrict__ pool,
+constexpr int PLAN_THREADS = 256;   // (1024 threads cap a thread at 128 registers: the descriptor assembly spilled)
+__global__ __launch_bounds__(PLAN_THREADS) void k_epoch_plan_fill(const qgtc_batch *__restrict__ batches, PlanArgs pa, uint32_t *__restrict__ pool,
                                                           unsigned long long pool_words, qgtc_problem *__restrict__ descs, int *__restrict__ record) {
-    __shared__ unsigned long long scan[1024];
-    __shared__ unsigned long long carry;
-    const int tid = threadIdx.x, count = pa.count;
-    if (tid == 0) carry = 0ull;
+    // One workgroup; per (stage, 256 batches) an exclusive scan of the outputs' sizes: inside a wave with shuffles, across the four
+    // waves through four LDS words - two barriers per pass. `carry` is the same number in every thread.
+    __shared__ unsigned long long wave_total[PLAN_THREADS / 64];
+    // the recipes and weights in LDS: indexed by run-time stage / source numbers below, and a by-value kernel argument indexed that
+    // way is copied to SCRATCH (200 bytes a thread here: the launch then waits for the queue's scratch allocation - 36 us under
+    // the tracer for a kernel with 3 us of work, inside the epoch clock)
+    __shared__ qgtc_stage sst[QGTC_MAX_STAGES];
+    __shared__ qgtc_operand swt[QGTC_MAX_WEIGHTS];
+    const int tid = threadIdx.x, count = pa.count, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) {
+#pragma unroll
+        for (int j = 0; j < QGTC_MAX_STAGES; j++) sst[j] = pa.stage[j];
+#pragma unroll
+        for (int j = 0; j < QGTC_MAX_WEIGHTS; j++) swt[j] = pa.weight[j];
+    }
     __syncthreads();
+    unsigned long long carry = 0ull;
+    // Up to 256 batches (one pass per stage): a thread keeps its batch's table line and the outputs it has handed out in registers -
+    // re-reading both from memory per stage (a 96-byte line, then a pointer this thread stored one stage earlier) was two exposed
+    // round trips per stage.
+    const bool one_pass = count <= PLAN_THREADS;
+    qgtc_batch mine{};
+    if (one_pass && tid < count) mine = batches[tid];
+    const uint32_t *handed[QGTC_MAX_STAGES];
+#pragma unroll
+    for (int j = 0; j < QGTC_MAX_STAGES; j++) handed[j] = nullptr;
     for (int s = 0; s < pa.n_stages; s++) {
-        const qgtc_stage st = pa.stage[s];
-        for (int b0 = 0; b0 < count; b0 += 1024) {
+        const qgtc_stage st = sst[s];
+        for (int b0 = 0; b0 < count; b0 += PLAN_THREADS) {
             const int b = b0 + tid;
-            qgtc_batch bt{};
-            unsigned long long words = 0ull;
-            if (b < count) {
-                bt = batches[b];
-                words = stage_out_words(st, bt.n);
+            qgtc_batch bt = mine;
+            if (!one_pass && b < count) bt = batches[b];
+            const unsigned long long words = b < count ? stage_out_words(st, bt.n) : 0ull;
+            unsigned long long incl = words;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {   // inclusive scan inside the wave
+                const unsigned long long v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
             }
-            scan[tid] = words;
+            if (lane == 63) wave_total[wv] = incl;
             __syncthreads();
-            for (int o = 1; o < 1024; o <<= 1) {   // inclusive scan
-                const unsigned long long v = tid >= o ? scan[tid - o] : 0ull;
-                __syncthreads();
-                scan[tid] += v;
-                __syncthreads();
+            unsigned long long before = 0ull, all = 0ull;
+#pragma unroll
+            for (int w = 0; w < PLAN_THREADS / 64; w++) {
+                const unsigned long long t = wave_total[w];
+                all += t;
+                if (w < wv) before += t;
             }
-            unsigned long long off = carry + scan[tid] - words;
+            unsigned long long off = carry + before + incl - words;
             if (b < count) {
                 bool fits = true;
                 if (off + words > pool_words) {   // a pool smaller than qgtc_epoch_pool_layout says: recorded, and no pointer leaves the pool
@@ -97,26 +123,39 @@ __global__ __launch_bounds__(1024) void k_epoch_plan_fill(const qgtc_batch *__re
                     fits = words <= pool_words;
                     off = fits ? pool_words - words : 0ull;
                 }
-                auto operand = [&](int src, const uint32_t *&ptr, unsigned long long &w) {
+                // (everything below in scalars: a struct handed to a lambda by reference, or selected whole by a ternary, lives in scratch)
+                const uint32_t *op_ptr[2];
+                unsigned long long op_words[2];
+#pragma unroll
+                for (int side = 0; side < 2; side++) {
+                    const int src = side == 0 ? st.left : st.right;
+                    const uint32_t *ptr = nullptr;
+                    unsigned long long w = 0ull;
                     if (src >= QGTC_SRC_STAGE) {   // the output of an earlier stage of the SAME batch: this thread wrote that descriptor
                         const int j = src - QGTC_SRC_STAGE;
-                        ptr = static_cast<const uint32_t *>(descs[static_cast<size_t>(j) * count + b].out);
-                        w = stage_out_words(pa.stage[j], bt.n);
+                        if (one_pass) {
+#pragma unroll
+                            for (int jj = 0; jj < QGTC_MAX_STAGES; jj++)
+                                if (jj == j) ptr = handed[jj];
+                        } else {
+                            ptr = static_cast<const uint32_t *>(descs[static_cast<size_t>(j) * count + b].out);
+                        }
+                        w = stage_out_words(sst[j], bt.n);
                     } else if (src >= QGTC_SRC_WEIGHT) {
-                        ptr = pa.weight[src - QGTC_SRC_WEIGHT].ptr;
-                        w = pa.weight[src - QGTC_SRC_WEIGHT].words;
+                        ptr = swt[src - QGTC_SRC_WEIGHT].ptr;
+                        w = swt[src - QGTC_SRC_WEIGHT].words;
                     } else {
-                        const qgtc_operand o = src == QGTC_SRC_A ? bt.A : (src == QGTC_SRC_X ? bt.X : (src == QGTC_SRC_XR ? bt.XR : (src == QGTC_SRC_XC ? bt.XC : bt.AT)));
-                        ptr = o.ptr;
-                        w = o.words;
+                        ptr = src == QGTC_SRC_A ? bt.A.ptr : (src == QGTC_SRC_X ? bt.X.ptr : (src == QGTC_SRC_XR ? bt.XR.ptr : (src == QGTC_SRC_XC ? bt.XC.ptr : bt.AT.ptr)));
+                        w = src == QGTC_SRC_A ? bt.A.words : (src == QGTC_SRC_X ? bt.X.words : (src == QGTC_SRC_XR ? bt.XR.words : (src == QGTC_SRC_XC ? bt.XC.words : bt.AT.words)));
                     }
-                };
+                    op_ptr[side] = ptr;
+                    op_words[side] = w;
+                }
                 qgtc_problem pr{};
-                unsigned long long xw = 0ull, ww = 0ull;
-                operand(st.left, pr.X, xw);
-                operand(st.right, pr.W, ww);
-                pr.x_words = xw;
-                pr.w_words = ww;
+                pr.X = op_ptr[0];
+                pr.W = op_ptr[1];
+                pr.x_words = op_words[0];
+                pr.w_words = op_words[1];
                 pr.out = pool + off;
                 pr.M = fits ? bt.n : 0;
                 pr.K = st.K == QGTC_DIM_NODES ? bt.n : st.K;
@@ -126,10 +165,12 @@ __global__ __launch_bounds__(1024) void k_epoch_plan_fill(const qgtc_batch *__re
                 pr.occ = occ ? bt.occ : nullptr;
                 pr.occ_words = occ ? bt.occ_words : 0;
                 descs[static_cast<size_t>(s) * count + b] = pr;
+#pragma unroll
+                for (int jj = 0; jj < QGTC_MAX_STAGES; jj++)
+                    if (jj == s) handed[jj] = static_cast<const uint32_t *>(pr.out);
             }
-            __syncthreads();
-            if (tid == 1023) carry += scan[1023];
-            __syncthreads();
+            carry += all;
+            __syncthreads();   // (wave_total is rewritten by the next pass)
         }
     }
 }

@@ -149,7 +149,7 @@ int qgtc_epoch_plan_fill(const qgtc_batch *batches, int count, const qgtc_stage 
     pa.count = count;
     for (int s = 0; s < n_stages; s++) pa.stage[s] = stages[s];
     for (int k = 0; k < n_weights; k++) pa.weight[k] = weights[k];
-    hipLaunchKernelGGL(k_epoch_plan_fill, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), batches, pa,
+    hipLaunchKernelGGL(k_epoch_plan_fill, dim3(1), dim3(PLAN_THREADS), 0, static_cast<hipStream_t>(stream), batches, pa,
                        static_cast<uint32_t *>(pool), static_cast<unsigned long long>(pool_words), descs, rec);
     HIP_TRY(hipGetLastError());
     return QGTC_OK;

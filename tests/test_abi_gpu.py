@@ -201,6 +201,55 @@ class QgtcPackJob(ctypes.Structure):
 SRC_A, SRC_X, SRC_XR, SRC_WEIGHT, SRC_STAGE, DIM_NODES = 0, 1, 2, 16, 32, -1
 
 
+@pytest.mark.parametrize("count", [1, 75, 256, 257, 1025, 2500])
+def test_epoch_plan_fill_offsets_for_many_batch_counts(lib, count):
+    """qgtc_epoch_plan_fill's descriptors against qgtc_epoch_pool_layout for batch counts on both sides of its 256-batch pass (one
+    pass keeps the table line and the handed-out pointers in registers, more than one re-reads them): every output where the host
+    layout puts it, every chained operand the pointer of the stage it names. No product is launched (the operands are never read)."""
+    import torch
+    lib.qgtc_epoch_pool_layout.restype = ctypes.c_size_t
+    lib.qgtc_epoch_pool_layout.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp]
+    lib.qgtc_epoch_plan_fill.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_size_t, vp, vp]
+    rng = np.random.default_rng(count)
+    ns = [int(v) for v in rng.integers(1, 300, size=count)]
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    base = torch.zeros(1024, dtype=torch.int32, device="cuda")       # one real allocation: every operand points into it
+    op = lambda k: QgtcOperand(base.data_ptr() + 16 * k, 4)          # noqa: E731
+    hb = [QgtcBatch(op(1), op(2), op(3), op(4), op(5), None, n, 0) for n in ns]
+    batches = torch.frombuffer(bytearray(bytes((QgtcBatch * count)(*hb))), dtype=torch.uint8).cuda()
+    F, H, C, b = 48, 64, 10, 2
+    SRC_XC, SRC_AT = 3, 4
+    recipes = [(SRC_XR, SRC_WEIGHT + 0, F, H, b, b, b, 1, 0, 0, 1), (SRC_AT, SRC_STAGE + 0, DIM_NODES, H, 1, b, b, 0, 0, 0, 0),
+               (SRC_STAGE + 1, SRC_WEIGHT + 1, H, C, b, b, b, 1, 0, 0, 0), (SRC_A, SRC_STAGE + 2, DIM_NODES, C, 1, b, 1, 2, 1, 0, 0),
+               (SRC_A, SRC_XC, DIM_NODES, F, 1, b, b, 0, 0, 0, 0)]
+    S = len(recipes)
+    stages = (QgtcStage * S)(*[QgtcStage(*r) for r in recipes])
+    weights = (QgtcOperand * 2)(op(6), op(7))
+    nodes = (ctypes.c_int32 * count)(*ns)
+    offs = (ctypes.c_uint64 * (S * count))()
+    pool_words = lib.qgtc_epoch_pool_layout(ctypes.addressof(nodes), count, ctypes.addressof(stages), S, ctypes.addressof(offs))
+    pool = torch.empty(pool_words, dtype=torch.int32, device="cuda")
+    descs = torch.zeros(S * count * 72, dtype=torch.uint8, device="cuda")
+    rc = lib.qgtc_epoch_plan_fill(batches.data_ptr(), count, ctypes.addressof(stages), S, ctypes.addressof(weights), 2, pool.data_ptr(), pool_words,
+                                  descs.data_ptr(), st)
+    assert rc == 0, lib.qgtc_strerror(rc)
+    got = np.frombuffer(descs.cpu().numpy().tobytes(), dtype=np.uint64).reshape(S, count, 9)    # X, W, out, x_words, w_words, (M, K), (N, w_lines), (occ_words, pad), occ
+    O = np.array(list(offs), dtype=np.uint64).reshape(S, count)
+    np.testing.assert_array_equal(got[:, :, 2], np.uint64(pool.data_ptr()) + np.uint64(4) * O)
+    np.testing.assert_array_equal(got[1, :, 1], got[0, :, 2])                                    # A . T1: T1 is stage 0's output
+    np.testing.assert_array_equal(got[2, :, 0], got[1, :, 2])
+    np.testing.assert_array_equal(got[3, :, 1], got[2, :, 2])
+    a = np.uint64(base.data_ptr())
+    assert (got[0, :, 0] == a + np.uint64(48)).all() and (got[1, :, 0] == a + np.uint64(80)).all() and (got[3, :, 0] == a + np.uint64(16)).all()   # XR, AT, A
+    assert (got[4, :, 1] == a + np.uint64(64)).all() and (got[0, :, 1] == a + np.uint64(96)).all()                                       # XC, weight 0
+    M = (got[:, :, 5] & np.uint64(0xffffffff)).astype(np.int64)
+    K = (got[:, :, 5] >> np.uint64(32)).astype(np.int64)
+    assert (M == np.array(ns)[None, :]).all() and (K[1] == np.array(ns)).all() and (K[0] == F).all() and (K[2] == H).all()
+    assert (np.diff(np.concatenate([O.reshape(-1), [pool_words]]).astype(np.int64)) >= 0).all()   # (stage, batch) order, nothing overlaps
+    lib.qgtc_last_batched_violation.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), vp]
+    assert lib.qgtc_last_batched_violation(None, None, st) == 0
+
+
 def test_epoch_plan_filled_on_the_device_with_raw_pointers(lib, oracle):
     """qgtc_val2bit_batched + qgtc_epoch_pool_layout + qgtc_epoch_plan_fill + the grouped entries through ctypes: the three
     weights packed in one launch, the descriptors of a layout-correct two-layer GCN slice (X.W1 -> A.T1 -> .W2 -> A.T2 as
