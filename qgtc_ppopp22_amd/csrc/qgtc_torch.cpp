@@ -855,12 +855,10 @@ struct EpochPlan {
             auto sh = stats.cpu();
             const double set = static_cast<double>(sh.data_ptr<int64_t>()[0]), all = static_cast<double>(sh.data_ptr<int64_t>()[1]);
             occupied = all > 0.0 ? set / all : 1.0;
+            // `jumping`: the rule measured for the tile kernels (a quarter of the tiles occupied at most: at 43 % they lose 15 %). The
+            // table keeps the bitmaps either way - the chain entries' aggregations (one wave per row block) gain from them at any
+            // occupancy (ppi-sized batches, 42 % occupied: 15.9 -> 14.7 us per epoch) - and bind() decides per stage.
             jumping = occupied <= kJumpBelow;
-            if (!jumping)
-                for (auto &b : h) {
-                    b.occ = nullptr;
-                    b.occ_words = 0;
-                }
         }
         auto host = torch::empty({static_cast<int64_t>(count * sizeof(qgtc_batch))}, torch::TensorOptions().dtype(torch::kUInt8));
         std::memcpy(host.data_ptr(), h.data(), count * sizeof(qgtc_batch));
@@ -903,6 +901,12 @@ struct EpochPlan {
             }
             check_rc(qgtc_expand_weights(jobs, static_cast<int>(expand.size()), current_stream(batches)), "EpochPlan.bind (weights)");
         }
+        if (!jumping)   // bitmaps only for the stages a chain-entry aggregation (kind 4) runs
+            for (int s = 0; s < ns; s++) {
+                bool rbw = false;
+                for (const auto &l : launches_) rbw = rbw || (l[0] == 4 && l[1] == s);
+                if (!rbw) stages[s].use_occ = 0;
+            }
         for (const auto &l : launches_) {
             TORCH_CHECK(l[0] >= 0 && l[0] <= 4 && l[1] >= 0 && l[1] < ns, "bad launch entry");
             TORCH_CHECK(l[0] == 0 || l[0] == 3 || (l[0] == 4 && l[2] < 0) || (l[2] >= 0 && l[2] < ns), "bad launch entry");
