@@ -150,14 +150,22 @@ struct RbwShape {
     int tiles;    // k_rbw_chain: the adjacency is in the tile format of k_rows_to_tiles (else the rows layout)
 };
 
-__device__ __forceinline__ void rbw_ids(const RbwShape &sh, int &grp, int &batch) {
+// (gx, gy = the grid, handed over as kernel arguments: gridDim lives in the HIDDEN kernel arguments, which are not preloaded into
+// scalar registers with the wave - reading it was one more dependent scalar-load round trip ahead of the descriptor's)
+__device__ __forceinline__ void rbw_ids(int per, int gx, int gy, int &grp, int &batch) {
     grp = static_cast<int>(blockIdx.x);
     batch = static_cast<int>(blockIdx.y);
-    if (sh.per) {
-        const int v = xcd_consecutive(batch * static_cast<int>(gridDim.x) + grp, static_cast<int>(gridDim.x * gridDim.y));
-        batch = v / static_cast<int>(gridDim.x);
-        grp = v - batch * static_cast<int>(gridDim.x);
+    if (per) {
+        const int v = xcd_consecutive(batch * gx + grp, gx * gy);
+        batch = v / gx;
+        grp = v - batch * gx;
     }
+}
+
+// every field of a descriptor in scalar registers NOW: left alone, the compiler loads M, tests the early exit and fetches the rest
+// behind the branch - two dependent round trips where one does
+__device__ __forceinline__ void rbw_pin(const qgtc_problem &pr) {
+    asm volatile("" ::"s"(pr.X), "s"(pr.W), "s"(pr.out), "s"(pr.x_words), "s"(pr.w_words), "s"(pr.K), "s"(pr.N), "s"(pr.occ), "s"(pr.occ_words));
 }
 
 // 16 re-quantised values (low OB bits of each byte of P) -> the two code dwords of a column block (see rbw_column)
@@ -222,6 +230,7 @@ __device__ __forceinline__ void rbw_xw_body(const qgtc_problem &pr, const u32x4 
 #pragma unroll
         for (int da = 0; da < NDA; da++) xa[h][da] = fp4_op(strip_operand<NA>(xl[h], da));
     uint32_t *tbase = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(grp * 4 + wv) * lines * 4;   // word wv of k-quad grp
+    f32x16 accs[NCB];   // (every column block's MFMAs before the first epilogue: see the second product of rbw_chain_body)
 #pragma unroll
     for (int jn = 0; jn < NCB; jn++) {
         f32x16 acc = f32x16_zero();   // (a constant C operand of the first MFMA, not sixteen v_mov)
@@ -230,17 +239,24 @@ __device__ __forceinline__ void rbw_xw_body(const qgtc_problem &pr, const u32x4 
 #pragma unroll
             for (int da = 0; da < NDA; da++)
                 acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[h][da], fp4_op(wc[jn][h]), acc, 4, 4, 0, 128 + 2 * da, 0, 128);   // not swapped: lane = column 32 jn + fl
+        accs[jn] = acc;
+    }
+#pragma unroll
+    for (int jn = 0; jn < NCB; jn++) {
         const int n = 32 * jn + fl;
-        rbw_store_codes<OB>(acc, tbase + static_cast<size_t>(n) * 4, fh, n < lines);
+        rbw_store_codes<OB>(accs[jn], tbase + static_cast<size_t>(n) * 4, fh, n < lines);
     }
 }
 
 template <int NA, int OB, int NCB>
-__global__ __launch_bounds__(256) void k_rbw_xw(const qgtc_problem *__restrict__ prs, const u32x4 *__restrict__ w_codes, RbwShape sh) {
+__global__ __launch_bounds__(256) void k_rbw_xw(const qgtc_problem *__restrict__ prs, const u32x4 *__restrict__ w_codes, int per, int a_planes, int gx, int gy) {
+    // (scalar kernel arguments only: a struct by value is not preloaded into SGPRs - its fields were s_load round trips of their own)
     int grp, batch;
-    rbw_ids(sh, grp, batch);
+    rbw_ids(per, gx, gy, grp, batch);
     const qgtc_problem pr = prs[batch];
+    rbw_pin(pr);
     if (grp >= step128(pr.M)) return;
+    const RbwShape sh{per, a_planes, 0};
     rbw_xw_body<NA, OB, NCB>(pr, w_codes, sh, grp);
 }
 
@@ -261,7 +277,7 @@ __global__ __launch_bounds__(256) void k_rbw_xw(const qgtc_problem *__restrict__
 // AUX: cache policy of the loads of T (0, or AUX_SC1 = agent scope: past the CU's L1 - the whole-epoch kernel below reads a T that
 // other workgroups wrote earlier in the SAME launch). w2_lds / t_lds: the workgroup's staging areas (NCB2 x 2 x ND x 64 and 512 u32x4).
 template <int OB, int OB2, int MODE2, int NCB1, int NCB2, int AUX>
-__device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgtc_problem *__restrict__ pr2p, const u32x4 *__restrict__ w2_codes,
+__device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgtc_problem &pr2, const u32x4 *__restrict__ w2_codes,
                                                int grp, int batch, u32x4 *__restrict__ w2_lds, u32x4 *__restrict__ t_lds, bool a_tiles
 #ifdef QGTC_RBW_STAMPS
                                                , unsigned long long (&st_)[10]
@@ -306,15 +322,27 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
 #pragma unroll
         for (int i = 0; i < 2; i++)
             td[i] = __builtin_amdgcn_raw_buffer_load_b128(rt, diag_ok ? (static_cast<uint32_t>(grp) * 512u + static_cast<uint32_t>(tid + 256 * i)) * 16u : 0xffffffffu, 0, AUX);
+        // (every load of the staging issued before the first LDS write: written as "w2_lds[e] = w2_codes[e]" per piece, each piece
+        // waited for ALL outstanding loads - the 8 KB of W' were two round trips one behind the other)
+        constexpr int NI = MODE2 == 0 ? 1 : (NCB2 * 2 * ND * 64 + 255) / 256;
+        u32x4 wreg[NI];
         if constexpr (MODE2 != 0) {
 #pragma unroll
-            for (int i = 0; i < (NCB2 * 2 * ND * 64 + 255) / 256; i++) {
+            for (int i = 0; i < NI; i++) {
                 const int e = i * 256 + tid;
-                if (e < NCB2 * 2 * ND * 64 && ((e / (64 * ND)) & 1) < MH) w2_lds[e] = w2_codes[e];
+                wreg[i] = u32x4{0u, 0u, 0u, 0u};
+                if (e < NCB2 * 2 * ND * 64 && ((e / (64 * ND)) & 1) < MH) wreg[i] = w2_codes[e];
             }
         }
 #pragma unroll
         for (int i = 0; i < 2; i++) t_lds[tid + 256 * i] = td[i];
+        if constexpr (MODE2 != 0) {
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                const int e = i * 256 + tid;
+                if (e < NCB2 * 2 * ND * 64) w2_lds[e] = wreg[i];
+            }
+        }
     }
     // the lane's words 2 fh, 2 fh + 1 of the diagonal k-quad of its adjacency row, and the occupancy word: in flight over the barrier
     u32x2 xd = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, (diag_ok && x_base != 0xffffffffu) ? x_base + RBW_XQ(grp) + 8u * fh : 0xffffffffu, 0, 0));
@@ -448,7 +476,7 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
             if (m < M)
                 for (int c = fh; c < N; c += 2) static_cast<float *>(pr.out)[static_cast<size_t>(m) * N + c] = 0.0f;
         } else {
-            const qgtc_problem pz = *pr2p;
+            const qgtc_problem &pz = pr2;
             if constexpr (MODE2 == 2) {
                 if (m < M)
                     for (int c = fh; c < pz.N; c += 2) static_cast<float *>(pz.out)[static_cast<size_t>(m) * pz.N + c] = 0.0f;
@@ -502,10 +530,13 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
         asm volatile("" ::"v"(XA[0][0]), "v"(XA[MH - 1][3]));
 #endif
         RBW_STAMP(6);
-        const qgtc_problem pr2 = *pr2p;
         const int N2 = pr2.N, lines2 = pad128(N2);
         uint32_t *tbase = static_cast<uint32_t *>(pr2.out) + static_cast<size_t>(grp * 4 + wv) * lines2 * 4;   // word wv of k-quad grp
         const __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc(pr2.out, 0, MODE2 == 2 ? static_cast<int>(static_cast<uint32_t>(M) * static_cast<uint32_t>(N2) * 4u) : 0, 0x00020000);
+        // ALL column blocks' MFMAs first, into accumulators of their own (the first product's are dead by now): written as "multiply a
+        // block, re-quantise it, store it" per block, every block reused the same sixteen registers and its MFMAs waited for the previous
+        // block's epilogue - 0.45 k cycles per block one behind the other (in-kernel stamps: 1.9 k for four blocks)
+        f32x16 acc2s[NCB2];
 #pragma unroll
         for (int jn = 0; jn < NCB2; jn++) {
             f32x16 acc2 = f32x16_zero();
@@ -523,6 +554,11 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
                     }
                 }
             }
+            acc2s[jn] = acc2;
+        }
+#pragma unroll
+        for (int jn = 0; jn < NCB2; jn++) {
+            const f32x16 &acc2 = acc2s[jn];
             const int n2 = 32 * jn + fl;
             if constexpr (MODE2 == 2) {   // float32 rows; branch-free stores (see bitmm_fp4_chain.hip.h: an MFMA reads all lanes' operands)
                 const uint32_t base = n2 < N2 ? (static_cast<uint32_t>(32 * rb) * static_cast<uint32_t>(N2) + static_cast<uint32_t>(n2)) * 4u : 0xffffffffu;
@@ -549,7 +585,7 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
 
 template <int OB, int OB2, int MODE2, int NCB1, int NCB2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_rbw_chain(const qgtc_problem *__restrict__ prs, const qgtc_problem *__restrict__ prs2,
-                                                                                                const u32x4 *__restrict__ w2_codes, RbwShape sh) {
+                                                                                                const u32x4 *__restrict__ w2_codes, int per, int tiles, int gx, int gy) {
     constexpr int ND = OB > 2 ? 2 : 1;
     __shared__ __attribute__((aligned(16))) u32x4 w2_lds[MODE2 == 0 ? 1 : NCB2 * 2 * ND * 64];
     __shared__ __attribute__((aligned(16))) u32x4 t_lds[4 * 128];   // [word t of the k-quad][line n]
@@ -558,10 +594,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 #endif
     RBW_STAMP(0);
     int grp, batch;
-    rbw_ids(sh, grp, batch);
+    rbw_ids(per, gx, gy, grp, batch);
+    // both descriptors at once, ahead of everything (the second stage's was fetched after the first product: a scalar-load round trip
+    // between the two products of every wave)
     const qgtc_problem pr = prs[batch];
+    const qgtc_problem pr2 = MODE2 == 0 ? pr : prs2[batch];
+    rbw_pin(pr);
+    if constexpr (MODE2 != 0) asm volatile("" ::"s"(pr2.out), "s"(pr2.N));
     if (grp >= step128(pr.M)) return;
-    rbw_chain_body<OB, OB2, MODE2, NCB1, NCB2, 0>(pr, MODE2 == 0 ? nullptr : prs2 + batch, w2_codes, grp, batch, w2_lds, t_lds, sh.tiles != 0
+    rbw_chain_body<OB, OB2, MODE2, NCB1, NCB2, 0>(pr, pr2, w2_codes, grp, batch, w2_lds, t_lds, tiles != 0
 #ifdef QGTC_RBW_STAMPS
                                                   , st_
 #endif
@@ -656,11 +697,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const RbwShape sh{0, ea.a_planes, 0};
     rbw_xw_body<2, 2, NCBH>(p0, ea.wc[0], sh, grp);
     rbw_batch_barrier<3>(ea, batch, G, 1);
-    rbw_chain_body<2, 2, 1, NCBH, NCBH, RBW_EPOCH_AUX>(ea.st[1][batch], ea.st[2] + batch, ea.wc[1], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
+    rbw_chain_body<2, 2, 1, NCBH, NCBH, RBW_EPOCH_AUX>(ea.st[1][batch], ea.st[2][batch], ea.wc[1], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
     rbw_batch_barrier<3>(ea, batch, G, 2);
-    rbw_chain_body<2, 2, 1, NCBH, NCBC, RBW_EPOCH_AUX>(ea.st[3][batch], ea.st[4] + batch, ea.wc[2], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
+    rbw_chain_body<2, 2, 1, NCBH, NCBC, RBW_EPOCH_AUX>(ea.st[3][batch], ea.st[4][batch], ea.wc[2], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
     rbw_batch_barrier<3>(ea, batch, G, 3);
-    rbw_chain_body<2, 2, 0, NCBC, 1, RBW_EPOCH_AUX>(ea.st[5][batch], nullptr, nullptr, grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
+    rbw_chain_body<2, 2, 0, NCBC, 1, RBW_EPOCH_AUX>(ea.st[5][batch], ea.st[5][batch], nullptr, grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
 }
 
 // Batched-GIN, 4 bits: T1 = rq(rq(A . X) . W1) | T2 = rq(rq(A . T1) . W2) | out = float32(rq(A . T2) . W3) (main_qgtc.py:131-138)
@@ -676,11 +717,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const qgtc_problem p0 = ea.st[0][batch];
     const int G = step128(p0.M);
     if (grp >= G) return;
-    rbw_chain_body<4, 4, 1, NCBF, NCBH, 0>(p0, ea.st[1] + batch, ea.wc[0], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
+    rbw_chain_body<4, 4, 1, NCBF, NCBH, 0>(p0, ea.st[1][batch], ea.wc[0], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
     rbw_batch_barrier<2>(ea, batch, G, 1);
-    rbw_chain_body<4, 4, 1, NCBH, NCBH, RBW_EPOCH_AUX>(ea.st[2][batch], ea.st[3] + batch, ea.wc[1], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
+    rbw_chain_body<4, 4, 1, NCBH, NCBH, RBW_EPOCH_AUX>(ea.st[2][batch], ea.st[3][batch], ea.wc[1], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
     rbw_batch_barrier<2>(ea, batch, G, 2);
-    rbw_chain_body<4, 4, 2, NCBH, NCBC, RBW_EPOCH_AUX>(ea.st[4][batch], ea.st[5] + batch, ea.wc[2], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
+    rbw_chain_body<4, 4, 2, NCBH, NCBC, RBW_EPOCH_AUX>(ea.st[4][batch], ea.st[5][batch], ea.wc[2], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
 }
 #undef RBW_ST_ARG
 

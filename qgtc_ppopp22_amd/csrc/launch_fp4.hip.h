@@ -275,16 +275,17 @@ int qgtc_launch_cols_to_chain(const uint32_t *cols, size_t words, int H, int W, 
 }
 
 int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int N, int a, int ob, const uint32_t *w_codes, hipStream_t st) {
-    RbwShape sh{getenv_flag("QGTC_NO_XCD") ? 0 : 1, a, 0};
+    const int per = getenv_flag("QGTC_NO_XCD") ? 0 : 1;   // (the workgroups of a batch on one XCD)
     const dim3 grid(step128(max_M), count), block(256);
+    const int gx = static_cast<int>(grid.x), gy = static_cast<int>(grid.y);
     const u32x4 *wc = reinterpret_cast<const u32x4 *>(w_codes);
     const int ncb = (N + 31) / 32;
     if (ob != 2 || a > 2) return QGTC_EINVAL;
     switch (ncb) {
-        case 1: hipLaunchKernelGGL((k_rbw_xw<2, 2, 1>), grid, block, 0, st, prs, wc, sh); break;
-        case 2: hipLaunchKernelGGL((k_rbw_xw<2, 2, 2>), grid, block, 0, st, prs, wc, sh); break;
-        case 3: hipLaunchKernelGGL((k_rbw_xw<2, 2, 3>), grid, block, 0, st, prs, wc, sh); break;
-        case 4: hipLaunchKernelGGL((k_rbw_xw<2, 2, 4>), grid, block, 0, st, prs, wc, sh); break;
+        case 1: hipLaunchKernelGGL((k_rbw_xw<2, 2, 1>), grid, block, 0, st, prs, wc, per, a, gx, gy); break;
+        case 2: hipLaunchKernelGGL((k_rbw_xw<2, 2, 2>), grid, block, 0, st, prs, wc, per, a, gx, gy); break;
+        case 3: hipLaunchKernelGGL((k_rbw_xw<2, 2, 3>), grid, block, 0, st, prs, wc, per, a, gx, gy); break;
+        case 4: hipLaunchKernelGGL((k_rbw_xw<2, 2, 4>), grid, block, 0, st, prs, wc, per, a, gx, gy); break;
         default: return QGTC_EINVAL;
     }
     HIP_TRY(hipGetLastError());
@@ -303,12 +304,13 @@ int qgtc_launch_rbw_chain(const qgtc_problem *p1, const qgtc_problem *p2, int co
                           int out_bits, int mode2, const uint32_t *w2_codes, bool a_tiles, hipStream_t st) {
     (void)act_bits;   // (1- and 2-bit T are the same codes: one base-4 digit per nibble)
     (void)out_bits;
-    RbwShape sh{getenv_flag("QGTC_NO_XCD") ? 0 : 1, 1, a_tiles ? 1 : 0};
+    const int per = getenv_flag("QGTC_NO_XCD") ? 0 : 1, tiles = a_tiles ? 1 : 0;   // (row blocks of a batch on one XCD)
     const dim3 grid(step128(max_M), count), block(256);
+    const int gx = static_cast<int>(grid.x), gy = static_cast<int>(grid.y);
     const u32x4 *wc = reinterpret_cast<const u32x4 *>(w2_codes);
     const int c1 = (N1 + 31) / 32, c2 = mode2 == 0 ? 1 : (N2 + 31) / 32;
     if (t_bits == 4) {   // the 4-bit chains: N, N' <= 64
-#define QGTC_RBW4_GO(MODE2_, C1_, C2_) hipLaunchKernelGGL((k_rbw_chain<4, 4, MODE2_, C1_, C2_>), grid, block, 0, st, p1, p2, wc, sh)
+#define QGTC_RBW4_GO(MODE2_, C1_, C2_) hipLaunchKernelGGL((k_rbw_chain<4, 4, MODE2_, C1_, C2_>), grid, block, 0, st, p1, p2, wc, per, tiles, gx, gy)
         if (c1 > 2 || c2 > 2) return QGTC_EINVAL;
         if (mode2 == 0) { if (c1 == 1) QGTC_RBW4_GO(0, 1, 1); else QGTC_RBW4_GO(0, 2, 1); }
         else if (mode2 == 1) {
@@ -322,7 +324,7 @@ int qgtc_launch_rbw_chain(const qgtc_problem *p1, const qgtc_problem *p2, int co
         HIP_TRY(hipGetLastError());
         return QGTC_OK;
     }
-#define QGTC_RBW_GO(MODE2_, C1_, C2_) hipLaunchKernelGGL((k_rbw_chain<2, 2, MODE2_, C1_, C2_>), grid, block, 0, st, p1, p2, wc, sh)
+#define QGTC_RBW_GO(MODE2_, C1_, C2_) hipLaunchKernelGGL((k_rbw_chain<2, 2, MODE2_, C1_, C2_>), grid, block, 0, st, p1, p2, wc, per, tiles, gx, gy)
 #define QGTC_RBW_C2(MODE2_, C1_)                       \
     switch (c2) {                                      \
         case 1: QGTC_RBW_GO(MODE2_, C1_, 1); break;    \
