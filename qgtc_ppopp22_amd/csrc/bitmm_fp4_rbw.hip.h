@@ -321,7 +321,7 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
         u32x4 td[2];
 #pragma unroll
         for (int i = 0; i < 2; i++)
-            td[i] = __builtin_amdgcn_raw_buffer_load_b128(rt, diag_ok ? (static_cast<uint32_t>(grp) * 512u + static_cast<uint32_t>(tid + 256 * i)) * 16u : 0xffffffffu, 0, AUX);
+            td[i] = __builtin_amdgcn_raw_buffer_load_b128(rt, (diag_ok && ((tid + 256 * i) & 127) < 32 * NCB1) ? (static_cast<uint32_t>(grp) * 512u + static_cast<uint32_t>(tid + 256 * i)) * 16u : 0xffffffffu, 0, AUX);   // (only the lines the first product reads)
         // (every load of the staging issued before the first LDS write: written as "w2_lds[e] = w2_codes[e]" per piece, each piece
         // waited for ALL outstanding loads - the 8 KB of W' were two round trips one behind the other)
         constexpr int NI = MODE2 == 0 ? 1 : (NCB2 * 2 * ND * 64 + 255) / 256;
