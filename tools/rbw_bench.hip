@@ -1,6 +1,6 @@
 // tools/rbw_bench.hip — standalone (no torch) timing of the chain entries (bitmm_fp4_rbw.hip.h) on cluster-batch-like operands:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -mllvm -amdgpu-kernarg-preload-count=16 [-DQGTC_RBW_STAMPS] -o tools/rbw_bench tools/rbw_bench.hip
-//   [BITS=4] [TILES=1] tools/rbw_bench [count=75] [n=1213] [N1=128] [N2=128] [mode2=1] [extra_prob=0.03]
+//   [BITS=4] [TILES=1] [SPLIT=parts] tools/rbw_bench [count=75] [n=1213] [N1=128] [N2=128] [mode2=1] [extra_prob=0.03]
 // 200 launches between two events (best of 5), the occupied-tile statistics of the synthetic adjacency, and with
 // -DQGTC_RBW_STAMPS the s_memtime stamps of wave 0 of the first 1024 workgroups.
 #define QGTC_SINGLE_TU 1
@@ -92,6 +92,60 @@ int main(int argc, char **argv) {
         best = std::min(best, ms);
     }
     printf("chain aggregate count=%d n=%d N1=%d N2=%d mode2=%d: %.2f us per launch (200 eager launches, best of 5)\n", count, n, N1, N2, mode2, best * 1e3 / 200);
+    if (getenv("SPLIT")) {   // the same launch as SPLIT parts on as many streams, 200 rounds captured into ONE graph (no host in the loop):
+                             // do the parts hide each other's launch boundaries and latency chains?
+        const int parts = std::max(2, atoi(getenv("SPLIT")));
+        std::vector<hipStream_t> ss(parts);
+        std::vector<hipEvent_t> done(parts);
+        for (auto &x : ss) CK(hipStreamCreate(&x));
+        for (auto &x : done) CK(hipEventCreate(&x));
+        hipEvent_t fork;
+        CK(hipEventCreate(&fork));
+        auto part = [&](int p, hipStream_t s_) {
+            const int b0 = count * p / parts, b1 = count * (p + 1) / parts;
+            return qgtc_chain_aggregate(d1 + b0, mode2 == 0 ? nullptr : d2 + b0, b1 - b0, n, n, N1, N2, bits, bits, bits, mode2, dWc, tiles ? QGTC_CHAIN_ADJ_TILES : 0u, s_);
+        };
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        CK(hipStreamBeginCapture(ss[0], hipStreamCaptureModeGlobal));
+        CK(hipEventRecord(fork, ss[0]));
+        for (int p = 1; p < parts; p++) CK(hipStreamWaitEvent(ss[p], fork, 0));
+        for (int i = 0; i < 200; i++)
+            for (int p = 0; p < parts; p++)
+                if (int rc = part(p, ss[p])) { printf("rc=%d\n", rc); return 1; }
+        for (int p = 1; p < parts; p++) { CK(hipEventRecord(done[p], ss[p])); CK(hipStreamWaitEvent(ss[0], done[p], 0)); }
+        CK(hipStreamEndCapture(ss[0], &graph));
+        CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        float bs = 1e9f;
+        for (int rep = 0; rep < 5; rep++) {
+            CK(hipEventRecord(e0, ss[0]));
+            CK(hipGraphLaunch(exec, ss[0]));
+            CK(hipEventRecord(e1, ss[0]));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            bs = std::min(bs, ms);
+        }
+        // and the unsplit launch replayed the same way, for the like-for-like figure
+        hipGraph_t g1;
+        hipGraphExec_t x1;
+        CK(hipStreamBeginCapture(ss[0], hipStreamCaptureModeGlobal));
+        for (int i = 0; i < 200; i++)
+            if (int rc = qgtc_chain_aggregate(d1, mode2 == 0 ? nullptr : d2, count, n, n, N1, N2, bits, bits, bits, mode2, dWc, tiles ? QGTC_CHAIN_ADJ_TILES : 0u, ss[0])) { printf("rc=%d\n", rc); return 1; }
+        CK(hipStreamEndCapture(ss[0], &g1));
+        CK(hipGraphInstantiate(&x1, g1, nullptr, nullptr, 0));
+        float b1 = 1e9f;
+        for (int rep = 0; rep < 5; rep++) {
+            CK(hipEventRecord(e0, ss[0]));
+            CK(hipGraphLaunch(x1, ss[0]));
+            CK(hipEventRecord(e1, ss[0]));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            b1 = std::min(b1, ms);
+        }
+        printf("as %d parts on %d streams (graph replay): %.2f us per round of the whole launch's work; unsplit, replayed the same way: %.2f us\n", parts, parts, bs * 1e3 / 200, b1 * 1e3 / 200);
+    }
     if (getenv("EPOCH")) {   // the whole Cluster-GCN epoch in one launch (qgtc_chain_epoch) on the same synthetic batches, F = H = 128, C = 10
         const int F = 128, H = 128, C = 10;
         const size_t xw_ = qgtc_rows_words(n, F, 2), th = qgtc_chain_words(n, H), tc = qgtc_chain_words(n, C);
