@@ -43,6 +43,7 @@ __global__ __launch_bounds__(64 * 4) __attribute__((amdgpu_waves_per_eu(OB <= 2 
     static_assert(!CIN || NW == 4, "code-form T: 4-bit products");
     static_assert(!COUT || (OB2 == 4 && MODE2 == 1), "code-form T': 4-bit products, bits mode");
     __shared__ __attribute__((aligned(16))) uint32_t xchg[DISC ? 4 : OB][32][4];   // [plane][row of the block][word of the row]; DISC: [word][row][dword of codes]
+    pin_shape(sh);
     int rb = static_cast<int>(blockIdx.x), batch = static_cast<int>(blockIdx.y);
     if (sh.per) {   // the row blocks of a batch on ONE XCD (bitmm_fp4_rows.hip.h)
         const int v = xcd_consecutive(batch * static_cast<int>(gridDim.x) + rb, static_cast<int>(gridDim.x * gridDim.y));
@@ -50,6 +51,8 @@ __global__ __launch_bounds__(64 * 4) __attribute__((amdgpu_waves_per_eu(OB <= 2 
         rb = v - batch * static_cast<int>(gridDim.x);
     }
     const qgtc_problem pr = prs[batch], pr2 = prs2[batch];
+    pin_problem(pr);
+    pin_problem(pr2);
     const int M = pr.M, K = pr.K, N = pr.N, N2 = pr2.N;
     const int line_words2 = step128(M) * 4, lines2 = pad128(N2);
     if (MODE2 == 2 ? 32 * rb >= M : rb >= line_words2) return;   // (no rows / not even a padding word of T')
@@ -295,6 +298,7 @@ template <int NA, int NW, int OB>
 __global__ __launch_bounds__(64 * 4) __attribute__((amdgpu_waves_per_eu(NA <= 2 ? 8 : 4, 8))) void k_bitmm_fp4_xw_rows(
     const qgtc_problem *__restrict__ prs, MMShape sh) {
     constexpr int NDA = (NA + 1) / 2, NDW = (NW + 1) / 2;   // base-4 digits
+    pin_shape(sh);
     int rb = static_cast<int>(blockIdx.x), batch = static_cast<int>(blockIdx.y);
     if (sh.per) {
         const int v = xcd_consecutive(batch * static_cast<int>(gridDim.x) + rb, static_cast<int>(gridDim.x * gridDim.y));
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(64 * 4) __attribute__((amdgpu_waves_per_eu(NA <= 2 
         rb = v - batch * static_cast<int>(gridDim.x);
     }
     const qgtc_problem pr = prs[batch];
+    pin_problem(pr);
     const int M = pr.M, N = pr.N;
     const int line_words = step128(M) * 4, lines = pad128(N);
     if (rb >= line_words) return;

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
 #define RW_STAMP(i) do { } while (0)
 #endif
     RW_STAMP(0);
+    pin_shape(sh);
     // sh.per != 0: the row blocks of a batch run on ONE XCD (they share its T lines and descriptor in that L2; spread
     // round-robin over the eight, every XCD fetched every batch's T: rocprofv3 counted 18.5 MB of fetches per launch for
     // 5.6 MB of operands)
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
         rb = v - batch * static_cast<int>(gridDim.x);
     }
     const qgtc_problem pr = prs[batch];
+    pin_problem(pr);
     const int M = pr.M, K = pr.K, N = pr.N;
     if (32 * rb >= M) return;
     const int tid = threadIdx.x, lane = tid & 63;

@@ -82,6 +82,7 @@ template <int NA, int NW, int OB>
 __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_strip(const qgtc_problem *__restrict__ prs, MMShape sh) {
     constexpr int NDA = (NA + 1) / 2, NDW = (NW + 1) / 2;   // base-4 digits
     extern __shared__ __attribute__((aligned(16))) uint32_t strip_words[];   // [ob][32 columns][line_words | 1]
+    pin_shape(sh);
     // sh.per != 0: the strips (and parts) of a batch run on ONE XCD - they all read the batch's X rows (bitmm_fp4_rows.hip.h)
     int strip = static_cast<int>(blockIdx.x), batch = static_cast<int>(blockIdx.y), part = static_cast<int>(blockIdx.z);
     if (sh.per) {
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_strip(const qgtc_pr
         strip = rem - part * gx;
     }
     const qgtc_problem pr = prs[batch];
+    pin_problem(pr);
     const int M = pr.M, N = pr.N;
     const int n0 = strip * 32;
     const int lines = pad128(N), line_words = step128(M) * 4;

@@ -70,6 +70,16 @@ struct MMShape {           // per-launch constants
                            // output is written, in QUAD-MAJOR order (qmajor_word below)
 };
 
+// Every launch constant a grouped kernel reads - the by-value shape and the grid (a HIDDEN kernel argument) - in scalar registers with
+// ONE round trip, and every field of a descriptor with one more: left alone hipcc loads them lazily, each use a dependent scalar-load
+// round trip ahead of the first global load (bitmm_fp4_rbw.hip.h measured 0.2 us of a 4.3 us launch).
+__device__ __forceinline__ void pin_shape(const MMShape &sh) {
+    asm volatile("" ::"s"(sh.a), "s"(sh.w), "s"(sh.ob), "s"(sh.mode), "s"(sh.per), "s"(sh.waves), "s"(sh.nowrap), "s"(sh.qmajor), "s"(gridDim.x), "s"(gridDim.y));
+}
+__device__ __forceinline__ void pin_problem(const qgtc_problem &pr) {
+    asm volatile("" ::"s"(pr.X), "s"(pr.W), "s"(pr.out), "s"(pr.x_words), "s"(pr.w_words), "s"(pr.M), "s"(pr.K), "s"(pr.N), "s"(pr.w_lines), "s"(pr.occ), "s"(pr.occ_words));
+}
+
 constexpr int MR = 4, MC = 4;        // per-lane micro-tile
 constexpr int GPT = 8;               // granules (16 B) a lane may hold per stage
 constexpr int SLAB_PITCH = 72;       // ints between the (i,j) planes of a wave's partial tile
