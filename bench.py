@@ -307,6 +307,23 @@ def epoch_roofline(Q, graph, device_index, dataset, bits, hidden, gin):
     floors = {"hbm_us": round(algo_bytes / (HBM_PEAK_GBS * 1e9) * 1e6, 2), "mfma_fp4_us": round(mfma_ops / (FP4_PEAK_TFLOPS * 1e12) * 1e6, 2),
               "launch_gaps_us": round(1.5 * (plan.n_launches - 1), 1)}
     chained = 6 - plan.n_launches
+    # HBM-side traffic of one epoch from the committed PMC passes of the same launches (profiles/r03/summary_epoch*.json: FETCH_SIZE x 2 on
+    # gfx950 + WRITE_SIZE, KiB per dispatch, times the dispatches an epoch makes of each kernel); None when the summary is absent
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03", "summary_epoch%s.json" % ("_gin" if gin else ""))) as f:
+            summ = json.load(f)
+        calls = {k["name"]: k["calls"] for k in summ.get("kernel_stats", []) if "k_rbw" in k["name"]}
+        base = min(calls.values()) if calls else 0
+        tot = 0.0
+        for name, cs in summ.get("pmc_per_dispatch_mean", {}).items():
+            if "k_rbw" not in name or not base:
+                continue
+            per_epoch = next((c for n_, c in calls.items() if n_[:60] == name[:60]), base) / base
+            tot += per_epoch * (2.0 * cs.get("FETCH_SIZE", {}).get("mean", 0.0) + cs.get("WRITE_SIZE", {}).get("mean", 0.0)) * 1024.0
+        traffic = int(tot) if tot > 0 else None
+    except Exception:   # noqa: BLE001 - evidence file optional at run time
+        traffic = None
     return {"kernel_us_per_epoch": round(epoch_us, 2), "kernel_us_per_operator_alone": stage_us, "calls_per_epoch": plan.n_launches,
             "launches_per_epoch": plan.n_launches,
             "launch_structure": (f"6 operators in {plan.n_launches} launches: {chained} aggregation stages carry the next "
@@ -321,6 +338,7 @@ def epoch_roofline(Q, graph, device_index, dataset, bits, hidden, gin):
             "roofline": {"bound": "hbm", "achieved": round(algo_bytes / epoch_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(algo_bytes / epoch_us / 1e3 / HBM_PEAK_GBS, 4),
                          "frac_mfma": round(mfma_ops / epoch_us / 1e6 / FP4_PEAK_TFLOPS, 4),
+                         "traffic": traffic,
                          "note": "a few thousand short workgroups per launch: bound by launch floors, dependent load chains and the epilogues' VALU work, see DESIGN.md section 6"},
             "adjacency_tiles_occupied": occ[:1], "rocprof": "profiles/r03/summary_epoch%s.json" % ("_gin" if gin else "")}
 
