@@ -47,7 +47,10 @@ __device__ __forceinline__ void one_expand(const u32x4 (&pl)[NP], int digit, uin
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const uint32_t w0 = pl[2 * digit][t], w1 = 2 * digit + 1 < NP ? pl[(2 * digit + 1) % NP][t] : 0u;
-            const uint32_t ev = (w0 & 0x55555555u) | ((w1 & 0x55555555u) << 1), od = ((w0 >> 1) & 0x55555555u) | (w1 & 0xaaaaaaaau);
+            uint32_t ev = (w0 & 0x55555555u) | ((w1 & 0x55555555u) << 1), od = ((w0 >> 1) & 0x55555555u) | (w1 & 0xaaaaaaaau);
+            // (opaque from here: hipcc otherwise re-derives ops[0] / ops[1] from the planes with masks folded in - two ANDs and a
+            // three-input op each beside the v_bfi that already made ev / od: 14 instructions a word where 10 do)
+            asm("" : "+v"(ev), "+v"(od));
             ops[0][t] = ev & 0x33333333u;
             ops[1][t] = od & 0x33333333u;
             ops[2][t] = (ev >> 2) & 0x33333333u;
