@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QGTC_ABI_VERSION 8
+#define QGTC_ABI_VERSION 9
 
 enum {
     QGTC_OK = 0,
@@ -55,8 +55,6 @@ enum {
                                   Grouped launches whose problems carry a one-word occupancy bitmap
                                   (K <= 8192) jump all-zero 128-row x 128-bit tiles */
 #define QGTC_ENGINE_AUTO 0x10u /* let rules fitted to MI355X measurements choose between the two engines */
-#define QGTC_LAYER_ONE_LAUNCH 0x20u /* qgtc_gcn_layer_batched: both products of the layer in ONE launch (in-launch
-                                  hand-off through per-batch arrival counters) instead of two grouped launches */
 #define QGTC_CHAIN_DISCARD 0x40u    /* qgtc_gcn_chain_batched: the caller does not need stage_a's output itself */
 #define QGTC_CHAIN_CODES_IN 0x80u   /* qgtc_gcn_chain_batched / qgtc_bitmm_batched: the right operands were written by a launch with _CODES_OUT */
 #define QGTC_CHAIN_CODES_OUT 0x100u /* qgtc_gcn_chain_batched / qgtc_bitmm_batched (mode 1): the outputs are only read by a launch with _CODES_IN */
@@ -171,25 +169,19 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
                        int bit1, int bit2, int output_bit, int mode, unsigned flags,
                        void *stream);
 
-/* One quantised GNN layer for `count` cluster batches in ONE launch - the fused form of the reference's per-layer
+/* One quantised GNN layer for `count` cluster batches in ONE call - the grouped form of the reference's per-layer
  * pair (QGTC_conv.py:14-22: X.W, then A.(XW); main_qgtc.py:147-154 issues it as two extension calls per batch):
  *   stage 1   T_b   = bitMM2Bit_col(X_b, W, x_bits, w_bits, t_bits)        (cols-layout bits, written to stage1[b].out)
  *   stage 2   out_b = bitMM2Bit(A_b, T_b, a_bits, t_bits, output_bit)      mode 0: rows-layout bits
  *                   = bitMM2Int(A_b, T_b, a_bits, t_bits, pad_128 = 1)     mode 2: float32
  * stage1[b] = {X_b, W, T_b, .., M = n_b, K = f_in, N = f_out}, stage2[b] = {A_b, T_b, out_b, .., M = n_b, K = n_b,
- * N = f_out} (stage2[b].W must be stage1[b].out; w_lines = PAD128(N) in both). Results are word for word those of the
- * two grouped launches - which is also how the call runs by default: measured on MI355X the two launches are the
- * faster form (30 us against 35 us for a 75-batch 128-wide layer). With QGTC_LAYER_ONE_LAUNCH (and
- * QGTC_ENGINE_AUTO / _MFMA) both stages share one launch: stage 2 of a batch starts as soon as the stage-1 tiles of THAT
- * batch have arrived (one arrival counter per batch, `arrival`: `count` x QGTC_ARRIVAL_STRIDE words - batch b's counter is word
- * b * QGTC_ARRIVAL_STRIDE - zeroed ONCE when the plan is made and never reset; `epoch` =
- * 1, 2, 3.. counts the launches made with these counters). max_* are hard preconditions as for qgtc_bitmm_batched.
- * `arrival` may be NULL when QGTC_LAYER_ONE_LAUNCH is not set. Plane counts the one-launch kernels do not cover run as
- * the two grouped launches - same results, same call. */
-#define QGTC_ARRIVAL_STRIDE 64   /* 32-bit words between the arrival counters of two batches (one 256-byte line each) */
+ * N = f_out} (stage2[b].W must be stage1[b].out; w_lines = PAD128(N) in both). Runs as two grouped launches on `stream`
+ * (word for word qgtc_bitmm_batched(stage1, mode 1) then qgtc_bitmm_batched(stage2, mode)); QGTC_ZERO_JUMP applies to
+ * stage 2. max_* are hard preconditions as for qgtc_bitmm_batched. (Up to ABI 8 the entry also had a one-launch form
+ * with in-kernel arrival counters; it measured slower and was removed - DESIGN.md appendix.) */
 int qgtc_gcn_layer_batched(const qgtc_problem *stage1, const qgtc_problem *stage2, int count, int max_M, int max_K1,
                            int max_K2, int max_N, int x_bits, int w_bits, int t_bits, int a_bits, int output_bit,
-                           int mode, uint32_t *arrival, uint32_t epoch, unsigned flags, void *stream);
+                           int mode, unsigned flags, void *stream);
 
 /* An aggregation stage and the NEXT layer's feature-transform stage in one call (main_qgtc.py:148-153: t1 = MM2Bit(bA, t0),
  * t2 = MM2Bit(t1, bW2), as the layout-correct chain issues them: the second with a cols-layout output). For every cluster
@@ -254,12 +246,6 @@ int qgtc_i8gemm_profile(const int8_t *A, const int8_t *Bt, int M, int K, int N, 
  * the record is cleared. `problem` / `field` may be NULL. */
 enum { QGTC_VIOL_NONE = 0, QGTC_VIOL_M = 1, QGTC_VIOL_K = 2, QGTC_VIOL_N = 3, QGTC_VIOL_POINTER = 4, QGTC_VIOL_CHAINING = 5 };
 int qgtc_last_batched_violation(int *problem, int *field, void *stream);
-
-/* Which route qgtc_gcn_layer_batched takes for these arguments: 1 = both stages in ONE launch (the form that advances the
- * arrival counters and needs `epoch`), 0 = two grouped launches (counters untouched), negative = -QGTC_E* for arguments
- * the entry would reject. A caller that owns arrival counters advances its epoch only when this says 1. */
-int qgtc_gcn_layer_route(int count, int max_M, int max_K1, int max_K2, int max_N, int x_bits, int w_bits, int t_bits,
-                         int a_bits, int output_bit, int mode, unsigned flags);
 
 /* val2bit of several matrices in ONE launch (the three weight matrices an epoch packs inside its clock,
  * main_qgtc.py:100-110: `QGTC.val2bit(W1.cuda(), w_bit, True, False)` x 3). `jobs` is a HOST array of at most
@@ -364,22 +350,6 @@ int qgtc_chain_transform(const qgtc_problem *stage, int count, int max_M, int K,
 int qgtc_chain_aggregate(const qgtc_problem *stage_a, const qgtc_problem *stage_xw, int count, int max_M, int max_K, int N1,
                          int N2, int t_bits, int act_bits, int out_bits, int out_mode, const uint32_t *w2_codes,
                          unsigned flags, void *stream);
-
-/* ---- A whole layout-correct epoch in ONE launch --------------------------------------------------------------------------
- * The chain entries above, back to back inside one kernel: a workgroup keeps its 128 rows of one cluster batch through every
- * stage, and two stages are separated only by a barrier among the workgroups of THAT batch (all on one XCD, whose L2 is their
- * coherence point; per-batch counters in `sync`, which only grow: `epoch` = 1, 2, 3 .. counts the launches made with them).
- * kind 0: Cluster-GCN, 2 bits (stages[0..5] = X.W1, A.T1, .W2, A.T2, .W3, A.T3 as qgtc_chain_transform / _aggregate take them;
- * F <= 128, H <= 128, C <= 32); kind 1: Batched-GIN, 4 bits (A.X, .W1, A.T1, .W2, A.T2, .W3; F, H <= 64, C <= 32, X in the
- * chain format). `stages` and `w_codes` are HOST arrays of six / three DEVICE pointers. `sync`: qgtc_chain_epoch_sync_words(count)
- * words, zeroed once. Needs every workgroup of the launch resident at once and workgroup ids congruent mod 8 on one XCD - both
- * checked (the first once per device): QGTC_ENODEVICE when they do not hold, QGTC_EINVAL outside the supported widths; callers
- * then issue the per-stage entries. A barrier that waits longer than ~2^21 polls sets the error word and goes on:
- * qgtc_chain_epoch_failed() (waits for `stream`) returns QGTC_EHIP if that happened since `sync` was zeroed. */
-size_t qgtc_chain_epoch_sync_words(int count);
-int qgtc_chain_epoch(const qgtc_problem *const *stages, int kind, int count, int max_M, int F, int H, int C, int x_bits,
-                     const uint32_t *const *w_codes, uint32_t *sync, uint32_t epoch, unsigned flags, void *stream);
-int qgtc_chain_epoch_failed(const uint32_t *sync, int count, void *stream);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,9 @@
   QGTC.cpython-*.so                 g++                          csrc/qgtc_torch.cpp (pybind11 binding)
 
 Both land next to this file so that they travel with the repo snapshot to the GPU box (they are
-git-ignored, not gpurun-ignored). hipcc cross-compiles gfx950 without a GPU.
+git-ignored, not gpurun-ignored). hipcc cross-compiles gfx950 without a GPU. The translation units'
+objects and -MD dependency files are kept under qgtc_ppopp22_amd/build/ (git- and gpurun-ignored):
+only the units whose sources changed are recompiled.
 """
 from __future__ import annotations
 
@@ -40,28 +42,40 @@ def _run(cmd: list[str]) -> None:
 HIP_UNITS = ("qgtc_hip.hip", "qgtc_mfma.hip", "qgtc_fp4.hip", "qgtc_wide.hip", "qgtc_epoch.hip")   # translation units of libqgtc_hip.so, compiled in parallel
 
 
+OBJ_DIR = os.path.join(PKG, "build")    # objects + dependency files of the translation units (git- and gpurun-ignored)
+
+
+def _unit_stale(obj: str, dep: str) -> bool:
+    """A translation unit is rebuilt when its object is missing or older than any file its last compile read (-MD)."""
+    if not (os.path.exists(obj) and os.path.exists(dep)):
+        return True
+    t = os.path.getmtime(obj)
+    text = open(dep).read().replace("\\\n", " ")
+    files = text.split(":", 1)[1].split() if ":" in text else []
+    return any((not os.path.exists(f)) or os.path.getmtime(f) > t for f in files if not f.startswith("/opt/rocm"))
+
+
 def build_hip(force: bool = False) -> str:
     units = [os.path.join(CSRC, u) for u in HIP_UNITS]
-    src = units + [os.path.join(INC, "qgtc.h")]
-    src += sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip.h"))
-    if not force and _newer(HIP_LIB, src):
-        return HIP_LIB
+    os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     objs, procs = [], []
     for u in units:
-        obj = os.path.join(PKG, os.path.basename(u) + ".o")
+        obj = os.path.join(OBJ_DIR, os.path.basename(u) + ".o")
+        dep = obj[:-2] + ".d"
+        objs.append(obj)
+        if not force and not _unit_stale(obj, dep):
+            continue
         # kernels with scalar arguments get them preloaded into SGPRs (no s_load round trip at the head of the kernel)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Wno-unused-value",
-               "-mllvm", "-amdgpu-kernarg-preload-count=16", f"-I{INC}", "-o", obj, u]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Wno-unused-value", "-Wno-pass-failed",
+               "-mllvm", "-amdgpu-kernarg-preload-count=16", f"-I{INC}", "-MD", "-MF", dep, "-o", obj, u]
         print("[qgtc build]", " ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(obj)
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    _run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", HIP_LIB] + objs)
-    for o in objs:
-        os.remove(o)
+    if procs or not os.path.exists(HIP_LIB) or any(os.path.getmtime(o) > os.path.getmtime(HIP_LIB) for o in objs):
+        _run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", HIP_LIB] + objs)
     return HIP_LIB
 
 

@@ -609,125 +609,4 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     );
 }
 
-
-// ------------------------------------------------------------------------------------------
-// The WHOLE epoch in one launch (qgtc_chain_epoch). After the kernels above an epoch is four (three) launches of 4 - 7 us,
-// each of them ~1.7 us of launch boundary plus one exposed latency chain per wave - and the chip drains and refills at
-// every boundary although nothing crosses it between DIFFERENT cluster batches. Here a workgroup keeps its k-quad of one
-// batch (rows 128 g .. 128 g + 127) through all stages, and the only thing that separates two stages is a barrier among the
-// workgroups of ITS batch (ten at 1213 nodes): batches drift apart and fill each other's waits.
-//   * Every workgroup of the launch is resident at once (the host checks the grid against the kernel's occupancy), so a
-//     workgroup that waits never keeps the one it waits for off the chip.
-//   * All workgroups of a batch run on ONE XCD - workgroup ids congruent mod 8 share an XCD, batch b takes the ids of XCD
-//     b mod 8 - so that XCD's L2 is their coherence point: T is written with plain stores (the vector L1 writes through),
-//     `s_waitcnt vmcnt(0)` + a relaxed agent-scope atomic add on the batch's counter publishes a workgroup's k-quad, the
-//     readers poll the counter (one lane, s_sleep between relaxed loads) and then load T with the sc1 bit (past their CU's
-//     L1, which may hold the previous epoch's T). No fence instruction: a fence would write back / invalidate the XCD's
-//     whole L2 (measured in round 2: 100 us).
-//   * The counters only grow: epoch e, barrier k of a batch of G workgroups waits for ((e - 1) x NB + k) x G. A wait that
-//     exceeds ~2^21 polls sets the error word and goes on (garbage, but no hang): the host then stops using this entry.
-// ------------------------------------------------------------------------------------------
-#ifdef QGTC_EPOCH_NOSC1   // timing-only build: T loaded through the L1 (stale reads possible)
-#define RBW_EPOCH_AUX 0
-#else
-#define RBW_EPOCH_AUX AUX_SC1
-#endif
-struct EpochArgs {
-    const qgtc_problem *st[6];   // the stages' descriptor arrays (one descriptor per batch each)
-    const u32x4 *wc[3];          // pre-expanded weights of the three transforms
-    uint32_t *sync;              // batch b's counter at word 64 b; the error word at 64 count
-    uint32_t epoch;              // 1, 2, 3 .. : launches made with these counters
-    int count, groups;           // batches; workgroups per batch slot (step128 of the largest batch)
-    int a_planes;                // planes of the packed X of the first transform (GCN)
-};
-
-__device__ __forceinline__ bool rbw_epoch_ids(const EpochArgs &ea, int &grp, int &batch) {
-    const int pid = static_cast<int>(blockIdx.x), xcd = pid & 7, slot = pid >> 3;
-    const int lb = slot / ea.groups;
-    grp = slot - lb * ea.groups;
-    batch = xcd + 8 * lb;
-    return batch < ea.count;
-}
-
-// barrier k (1 ..) of NB among the G workgroups of the batch
-template <int NB>
-__device__ __forceinline__ void rbw_batch_barrier(const EpochArgs &ea, int batch, int G, int k) {
-#ifdef QGTC_EPOCH_NOBARRIER   // timing-only build (tools/rbw_bench.hip): the stages back to back, results wrong
-    __syncthreads();
-    return;
-#endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have reached the L2
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t *c = ea.sync + 64 * batch;
-        const uint32_t target = ((ea.epoch - 1u) * NB + static_cast<uint32_t>(k)) * static_cast<uint32_t>(G);
-        __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int polls = 0;
-        while (static_cast<int>(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++polls > (1 << 21)) {
-                __hip_atomic_store(ea.sync + 64 * ea.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-}
-
-#ifdef QGTC_RBW_STAMPS
-#define RBW_ST_ARG , st_
-#else
-#define RBW_ST_ARG
-#endif
-
-// Cluster-GCN, 2 bits: T1 = rq(X . W1) | T2 = rq(rq(A . T1) . W2) | T3 = rq(rq(A . T2) . W3) | out = float32(A . T3)
-// (main_qgtc.py:147-154 with every right operand in the cols layout). NCBH / NCBC: 32-column blocks of the hidden / class widths.
-template <int NCBH, int NCBC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_rbw_epoch_gcn(EpochArgs ea) {
-    __shared__ __attribute__((aligned(16))) u32x4 w2_lds[(NCBH > NCBC ? NCBH : NCBC) * 2 * 64];
-    __shared__ __attribute__((aligned(16))) u32x4 t_lds[4 * 128];
-#ifdef QGTC_RBW_STAMPS
-    unsigned long long st_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    int grp, batch;
-    if (!rbw_epoch_ids(ea, grp, batch)) return;
-    const qgtc_problem p0 = ea.st[0][batch];
-    const int G = step128(p0.M);
-    if (grp >= G) return;   // (workgroup-uniform: this slot has no k-quad of the batch)
-    const RbwShape sh{0, ea.a_planes, 0};
-    rbw_xw_body<2, 2, NCBH>(p0, ea.wc[0], sh, grp);
-    rbw_batch_barrier<3>(ea, batch, G, 1);
-    rbw_chain_body<2, 2, 1, NCBH, NCBH, RBW_EPOCH_AUX>(ea.st[1][batch], ea.st[2][batch], ea.wc[1], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
-    rbw_batch_barrier<3>(ea, batch, G, 2);
-    rbw_chain_body<2, 2, 1, NCBH, NCBC, RBW_EPOCH_AUX>(ea.st[3][batch], ea.st[4][batch], ea.wc[2], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
-    rbw_batch_barrier<3>(ea, batch, G, 3);
-    rbw_chain_body<2, 2, 0, NCBC, 1, RBW_EPOCH_AUX>(ea.st[5][batch], ea.st[5][batch], nullptr, grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
-}
-
-// Batched-GIN, 4 bits: T1 = rq(rq(A . X) . W1) | T2 = rq(rq(A . T1) . W2) | out = float32(rq(A . T2) . W3) (main_qgtc.py:131-138)
-template <int NCBF, int NCBH, int NCBC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_rbw_epoch_gin(EpochArgs ea) {
-    __shared__ __attribute__((aligned(16))) u32x4 w2_lds[(NCBH > NCBC ? NCBH : NCBC) * 2 * 2 * 64];
-    __shared__ __attribute__((aligned(16))) u32x4 t_lds[4 * 128];
-#ifdef QGTC_RBW_STAMPS
-    unsigned long long st_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    int grp, batch;
-    if (!rbw_epoch_ids(ea, grp, batch)) return;
-    const qgtc_problem p0 = ea.st[0][batch];
-    const int G = step128(p0.M);
-    if (grp >= G) return;
-    rbw_chain_body<4, 4, 1, NCBF, NCBH, 0>(p0, ea.st[1][batch], ea.wc[0], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
-    rbw_batch_barrier<2>(ea, batch, G, 1);
-    rbw_chain_body<4, 4, 1, NCBH, NCBH, RBW_EPOCH_AUX>(ea.st[2][batch], ea.st[3][batch], ea.wc[1], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
-    rbw_batch_barrier<2>(ea, batch, G, 2);
-    rbw_chain_body<4, 4, 2, NCBH, NCBC, RBW_EPOCH_AUX>(ea.st[4][batch], ea.st[5][batch], ea.wc[2], grp, batch, w2_lds, t_lds, false RBW_ST_ARG);
-}
-#undef RBW_ST_ARG
-
-// which XCC a workgroup runs on (one word per workgroup): the host checks once per device that ids congruent mod 8 share one
-__global__ __launch_bounds__(64) void k_xcc_probe(uint32_t *__restrict__ out) {
-    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (31 << 11)) & 15u;   // HW_REG_XCC_ID, bits 3:0
-}
-
 }  // namespace

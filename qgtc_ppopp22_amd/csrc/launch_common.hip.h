@@ -21,8 +21,6 @@ int qgtc_launch_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count,
 
 // row block per wave (bitmm_fp4_rbw.hip.h), defined in qgtc_fp4.hip
 int qgtc_launch_expand_weights(const qgtc_expand_job *jobs, int n_jobs, hipStream_t st);
-int qgtc_launch_rbw_epoch(const qgtc_problem *const *stages, int kind, int count, int max_M, int F, int H, int C, int x_bits,
-                          const uint32_t *const *w_codes, uint32_t *sync, uint32_t epoch, hipStream_t st);
 int qgtc_launch_cols_to_chain(const uint32_t *cols, size_t words, int H, int W, int nbits, uint32_t *chain, hipStream_t st);
 int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int N, int a, int ob, const uint32_t *w_codes, hipStream_t st);
 int qgtc_launch_rbw_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int N1, int N2, int t_bits, int act_bits,
@@ -34,19 +32,6 @@ int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hip
 // defined in qgtc_epoch.hip: QGTC_CHECK_DESCRIPTORS (kind 0 one stage / 1 layer / 2 chain; p2 may be NULL)
 int qgtc_launch_check_descriptors(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int max_K1, int max_N1,
                                   int max_K2, int max_N2, int kind, hipStream_t st);
-
-// fused GNN layer (bitmm_layer.hip.h): defined in qgtc_mfma.hip (wide layers) and qgtc_fp4.hip (narrow layers)
-struct LayerArgs {
-    const qgtc_problem *p1, *p2;
-    uint32_t *arrival;
-    int count, max_M, max_K1, max_K2, max_N;
-    int a1, w1, ob1;       // stage 1: planes of X, planes of W, bits of T
-    int a2, ob2, mode2;    // stage 2: planes of A, output bits, 0 rows-layout bits / 2 float32
-    uint32_t epoch;
-    bool zero_skip;
-};
-int qgtc_launch_layer_mfma(const LayerArgs &la, hipStream_t st);
-int qgtc_launch_layer_wave(const LayerArgs &la, hipStream_t st);
 
 namespace {
 
@@ -214,12 +199,6 @@ inline bool rbw_chain_ok(int max_K, int N1, int N2, int t_bits, int act_bits, in
 // still (24 / 41 us: 2850 waves do not fill the chip).
 inline bool fp4_wave_ok(int K, int N, int a, int w) {
     return N <= 64 && a <= 4 && w <= 8 && static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
-}
-
-// slots between a batch's two stages in the fused layer launch: about half a chip of resident workgroups
-inline int layer_delay(int per_slot, int resident) {
-    if (const char *e = std::getenv("QGTC_LAYER_DELAY")) return std::max(0, std::atoi(e));   // (tuning only)
-    return std::max(1, resident / (2 * std::max(per_slot, 1)));
 }
 
 // the MFMA engine handles up to 8 planes per operand (8: offset by 128, corrected in the epilogue)

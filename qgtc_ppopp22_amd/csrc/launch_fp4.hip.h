@@ -106,36 +106,6 @@ int qgtc_launch_fp4_wave(const qgtc_problem *prs, int count, int max_M, int max_
 }
 
 
-// fused GNN layer, narrow form: both stages with one wave per 32 x 32 tile in one launch (bitmm_layer.hip.h)
-int qgtc_launch_layer_wave(const LayerArgs &la, hipStream_t st) {
-    LayerShape ls{};
-    ls.sh1 = base_shape(la.a1, la.w1, la.ob1, 1);
-    ls.sh1.nowrap = 1;
-    ls.sh2 = base_shape(la.a2, la.ob1, la.mode2 == 2 ? 1 : la.ob2, la.mode2);
-    ls.sh2.nowrap = 1;
-    const int tiles = ((la.max_M + 31) / 32) * ((la.max_N + 31) / 32);
-    ls.t1 = ls.t2 = tiles;
-    ls.count = la.count;
-    ls.delay = layer_delay(16 * tiles, 4096);     // in octets of batches
-    ls.epoch = la.epoch;
-    ls.zero_skip = la.zero_skip;
-    const dim3 grid(static_cast<unsigned>(((la.count + 7) / 8 + ls.delay) * 16 * tiles));
-    const int na = std::max(la.a1, la.a2), nw = std::max(la.w1, la.ob1);   // plane capacities covering both stages
-#define QGTC_LW_LAUNCH(NA_, NW_)                                                                                   \
-    if (!done && na <= NA_ && nw <= NW_) {                                                                         \
-        done = true;                                                                                               \
-        if (la.mode2 == 2) hipLaunchKernelGGL((k_layer_wave<NA_, NW_, 2>), grid, dim3(64), 0, st, la.p1, la.p2, la.arrival, ls); \
-        else hipLaunchKernelGGL((k_layer_wave<NA_, NW_, 0>), grid, dim3(64), 0, st, la.p1, la.p2, la.arrival, ls);               \
-    }
-    bool done = false;
-    QGTC_LW_LAUNCH(1, 1) QGTC_LW_LAUNCH(1, 2) QGTC_LW_LAUNCH(2, 2) QGTC_LW_LAUNCH(2, 4) QGTC_LW_LAUNCH(4, 4) QGTC_LW_LAUNCH(4, 8)
-#undef QGTC_LW_LAUNCH
-    if (!done) return QGTC_EINVAL;
-    HIP_TRY(hipGetLastError());
-    return QGTC_OK;
-}
-
-
 // grouped "X . W" stages with one k-quad of K and cols-layout output: one workgroup per 32-column strip (bitmm_fp4_strip.hip.h)
 int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, 1);
@@ -355,91 +325,6 @@ int qgtc_launch_rbw_chain(const qgtc_problem *p1, const qgtc_problem *p2, int co
 #undef QGTC_RBW_C1
 #undef QGTC_RBW_C2
 #undef QGTC_RBW_GO
-    HIP_TRY(hipGetLastError());
-    return QGTC_OK;
-}
-
-
-// ---- the whole epoch in one launch (bitmm_fp4_rbw.hip.h: k_rbw_epoch_gcn / k_rbw_epoch_gin)
-namespace {
-// once per device: do workgroup ids congruent mod 8 share an XCC? (1 yes, -1 no / could not tell)
-int xcc_ids_congruent(hipStream_t st) {
-    static std::atomic<int> verdict[kMaxDevices];   // 0 unknown
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -1;
-    int v = verdict[dev].load(std::memory_order_acquire);
-    if (v != 0) return v;
-    (void)st;
-    uint32_t *d = nullptr;
-    uint32_t h[64];
-    v = -1;
-    if (hipMalloc(&d, sizeof(h)) == hipSuccess) {
-        hipLaunchKernelGGL(k_xcc_probe, dim3(64), dim3(64), 0, nullptr, d);
-        if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-            v = 1;
-            for (int i = 8; i < 64; i++)
-                if (h[i] != h[i & 7]) v = -1;
-        }
-        (void)hipFree(d);
-    }
-    verdict[dev].store(v, std::memory_order_release);
-    return v;
-}
-
-template <typename K>
-int resident_workgroups(K kernel) {   // workgroups of 256 threads the device holds at once (cached per device and kernel)
-    static std::atomic<int> cached[kMaxDevices];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
-    int v = cached[dev].load(std::memory_order_acquire);
-    if (v != 0) return v;
-    int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    v = per_cu * cus;
-    cached[dev].store(v > 0 ? v : -1, std::memory_order_release);
-    return v;
-}
-}  // namespace
-
-int qgtc_launch_rbw_epoch(const qgtc_problem *const *stages, int kind, int count, int max_M, int F, int H, int C, int x_bits,
-                          const uint32_t *const *w_codes, uint32_t *sync, uint32_t epoch, hipStream_t st) {
-    if (xcc_ids_congruent(st) != 1) return QGTC_ENODEVICE;
-    EpochArgs ea{};
-    for (int i = 0; i < 6; i++) ea.st[i] = stages[i];
-    for (int i = 0; i < 3; i++) ea.wc[i] = reinterpret_cast<const u32x4 *>(w_codes[i]);
-    ea.sync = sync;
-    ea.epoch = epoch;
-    ea.count = count;
-    ea.groups = step128(max_M);
-    ea.a_planes = x_bits;
-    const int grid = 8 * ((count + 7) / 8) * ea.groups;
-    // every workgroup that DOES something (a slot past the last batch returns at once) must fit the chip at the same time: a
-    // workgroup waiting at a batch barrier keeps its slot, and the ones it waits for must not be queued behind it
-    const int active = count * ea.groups;
-    const int cf = (F + 31) / 32, ch = (H + 31) / 32, cc = (C + 31) / 32;
-#define QGTC_EP_GO(KERNEL)                                                            \
-    do {                                                                              \
-        if (resident_workgroups(KERNEL) < active) return QGTC_ENODEVICE;              \
-        hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), 0, st, ea);                 \
-    } while (0)
-    if (kind == 0) {
-        if (cc != 1 || F > 128) return QGTC_EINVAL;
-        switch (ch) {
-            case 1: QGTC_EP_GO((k_rbw_epoch_gcn<1, 1>)); break;
-            case 2: QGTC_EP_GO((k_rbw_epoch_gcn<2, 1>)); break;
-            case 3: QGTC_EP_GO((k_rbw_epoch_gcn<3, 1>)); break;
-            case 4: QGTC_EP_GO((k_rbw_epoch_gcn<4, 1>)); break;
-            default: return QGTC_EINVAL;
-        }
-    } else {
-        if (cc != 1 || cf > 2 || ch > 2) return QGTC_EINVAL;
-        if (cf == 1 && ch == 1) QGTC_EP_GO((k_rbw_epoch_gin<1, 1, 1>));
-        else if (cf == 1) QGTC_EP_GO((k_rbw_epoch_gin<1, 2, 1>));
-        else if (ch == 1) QGTC_EP_GO((k_rbw_epoch_gin<2, 1, 1>));
-        else QGTC_EP_GO((k_rbw_epoch_gin<2, 2, 1>));
-    }
-#undef QGTC_EP_GO
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
 }

@@ -69,41 +69,3 @@ int qgtc_launch_mfma_batched(const qgtc_problem *prs, int count, int max_M, int 
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
 }
-
-
-// fused GNN layer, wide form: both stages on 128 x 128 tiles in one launch (bitmm_layer.hip.h)
-int qgtc_launch_layer_mfma(const LayerArgs &la, hipStream_t st) {
-    LayerShape ls{};
-    ls.sh1 = base_shape(la.a1, la.w1, la.ob1, 1);
-    ls.sh1.nowrap = no_wrap(la.max_K1, la.a1, la.w1);
-    ls.sh2 = base_shape(la.a2, la.ob1, la.mode2 == 2 ? 1 : la.ob2, la.mode2);
-    ls.sh2.nowrap = no_wrap(la.max_K2, la.a2, la.ob1);
-    const int tiles = ((la.max_M + MF_T - 1) / MF_T) * ((la.max_N + MF_T - 1) / MF_T);
-    ls.t1 = ls.t2 = tiles;
-    ls.count = la.count;
-    ls.delay = layer_delay(16 * tiles, 512);     // in octets of batches
-    ls.epoch = la.epoch;
-    ls.zero_skip = la.zero_skip;
-    const int maxp = std::max(std::max(la.a1, la.w1), std::max(la.a2, la.ob1));
-    const bool fp4 = fp4_ok(la.max_K1, la.a1, la.w1) && fp4_ok(la.max_K2, la.a2, la.ob1);
-    const dim3 grid(static_cast<unsigned>(((la.count + 7) / 8 + ls.delay) * 16 * tiles));
-    static PerDeviceOnce attr;
-    const int arc = attr.run([]() -> int {
-#define QGTC_LY_ATTR(P, F4) \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_layer_mfma<P, F4>), hipFuncAttributeMaxDynamicSharedMemorySize, mf_lds_bytes(F4)));
-        QGTC_LY_ATTR(1, true) QGTC_LY_ATTR(2, true) QGTC_LY_ATTR(1, false) QGTC_LY_ATTR(2, false) QGTC_LY_ATTR(4, false) QGTC_LY_ATTR(8, false)
-#undef QGTC_LY_ATTR
-        return QGTC_OK;
-    });
-    if (arc != QGTC_OK) return arc;
-#define QGTC_LY_LAUNCH(P, F4) hipLaunchKernelGGL((k_layer_mfma<P, F4>), grid, dim3(512), mf_lds_bytes(F4), st, la.p1, la.p2, la.arrival, ls)
-    if (fp4 && maxp <= 1) QGTC_LY_LAUNCH(1, true);
-    else if (fp4) QGTC_LY_LAUNCH(2, true);
-    else if (maxp <= 1) QGTC_LY_LAUNCH(1, false);
-    else if (maxp <= 2) QGTC_LY_LAUNCH(2, false);
-    else if (maxp <= 4) QGTC_LY_LAUNCH(4, false);
-    else QGTC_LY_LAUNCH(8, false);
-#undef QGTC_LY_LAUNCH
-    HIP_TRY(hipGetLastError());
-    return QGTC_OK;
-}

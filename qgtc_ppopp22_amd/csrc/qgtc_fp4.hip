@@ -20,7 +20,5 @@
 #include "bitmm_fp4_rows.hip.h"
 #include "bitmm_fp4_chain.hip.h"
 #include "bitmm_fp4_rbw.hip.h"
-#define QGTC_LAYER_WAVE 1
-#include "bitmm_layer.hip.h"
 #include "launch_common.hip.h"
 #include "launch_fp4.hip.h"

@@ -26,7 +26,6 @@
 //   bitmm_fp4_strip.hip.h    grouped X . W stages (K <= 128, cols-layout output): one workgroup per 32-column strip
 //   bitmm_fp4_rows.hip.h     grouped A . (XW) stages (sparse left operand): one workgroup per 32-row block
 //   bitmm_fp4_chain.hip.h    an A . T stage with the next layer's X . W stage in its tail (qgtc_gcn_chain_batched)
-//   bitmm_layer.hip.h        both stages of a GNN layer in one launch (qgtc_gcn_layer_batched, on request)
 //   launch_common.hip.h      launch constants, kernel-family predicates (shared with qgtc_mfma.hip / qgtc_fp4.hip)
 //   launch.hip.h             split-K plan, kernel selection, launchers
 //   qgtc_mfma.hip            second translation unit: the 128 x 128-tile matrix-core engine and its launchers
@@ -59,9 +58,6 @@
 #include "bitmm_fp4_rows.hip.h"
 #include "bitmm_fp4_chain.hip.h"
 #include "bitmm_fp4_rbw.hip.h"
-#define QGTC_LAYER_MFMA 1
-#define QGTC_LAYER_WAVE 1
-#include "bitmm_layer.hip.h"
 #include "fp4_expand.hip.h"
 #include "bitmm_fp4_wide.hip.h"
 #include "launch_fp4.hip.h"
@@ -308,51 +304,25 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
     return dispatch_batched<true, false>(problems, count, max_M, max_N, k_hint, bit1, bit2, ob_, mode, st);
 }
 
-// 1: the narrow one-launch form (one wave per 32 x 32 tile), 2: the wide one (128 x 128 tiles), 0: two grouped launches
-static int layer_route(int count, int max_M, int max_K1, int max_K2, int max_N, int x_bits, int w_bits, int t_bits, int a_bits,
-                       int output_bit, int mode, unsigned flags) {
-    if (count <= 0 || count > 65535) return -QGTC_EINVAL;
-    if (max_M <= 0 || max_K1 <= 0 || max_K2 <= 0 || max_N <= 0) return -QGTC_EINVAL;
-    if (!bits_ok(x_bits) || !bits_ok(w_bits) || !bits_ok(t_bits) || !bits_ok(a_bits)) return -QGTC_EINVAL;
-    if (mode != 0 && mode != 2) return -QGTC_EINVAL;
-    if (mode == 0 && !bits_ok(output_bit)) return -QGTC_EINVAL;
-    // Default: the two grouped launches (measured faster, bitmm_layer.hip.h). The one-launch forms run on the matrix
-    // cores: they need QGTC_LAYER_ONE_LAUNCH and QGTC_ENGINE_AUTO / _MFMA and plane counts inside their range.
-    const bool want = (flags & QGTC_LAYER_ONE_LAUNCH) && (flags & (QGTC_ENGINE_AUTO | QGTC_ENGINE_MFMA)) != 0u;
-    if (want && max_N <= 64 && fp4_wave_ok(max_K1, max_N, x_bits, w_bits) && fp4_wave_ok(max_K2, max_N, a_bits, t_bits) &&
-        std::max(x_bits, a_bits) <= 4 && std::max(w_bits, t_bits) <= 8)
-        return 1;
-    if (want && max_N > 64 && max_M >= 128 && mfma_ok(x_bits, w_bits) && mfma_ok(a_bits, t_bits)) return 2;
-    return 0;
-}
-
-int qgtc_gcn_layer_route(int count, int max_M, int max_K1, int max_K2, int max_N, int x_bits, int w_bits, int t_bits,
-                         int a_bits, int output_bit, int mode, unsigned flags) {
-    const int r = layer_route(count, max_M, max_K1, max_K2, max_N, x_bits, w_bits, t_bits, a_bits, output_bit, mode, flags);
-    return r < 0 ? r : (r != 0);
-}
-
 int qgtc_gcn_layer_batched(const qgtc_problem *stage1, const qgtc_problem *stage2, int count, int max_M, int max_K1,
                            int max_K2, int max_N, int x_bits, int w_bits, int t_bits, int a_bits, int output_bit,
-                           int mode, uint32_t *arrival, uint32_t epoch, unsigned flags, void *stream) {
-    if (!stage1 || !stage2) return QGTC_EINVAL;
-    const int route = layer_route(count, max_M, max_K1, max_K2, max_N, x_bits, w_bits, t_bits, a_bits, output_bit, mode, flags);
-    if (route < 0) return -route;
-    if (route != 0 && (!arrival || epoch == 0u)) return QGTC_EINVAL;   // (the one-launch forms own arrival counters)
+                           int mode, unsigned flags, void *stream) {
+    if (!stage1 || !stage2 || count <= 0 || count > 65535) return QGTC_EINVAL;
+    if (max_M <= 0 || max_K1 <= 0 || max_K2 <= 0 || max_N <= 0) return QGTC_EINVAL;
+    if (!bits_ok(x_bits) || !bits_ok(w_bits) || !bits_ok(t_bits) || !bits_ok(a_bits)) return QGTC_EINVAL;
+    if (mode != 0 && mode != 2) return QGTC_EINVAL;
+    if (mode == 0 && !bits_ok(output_bit)) return QGTC_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (flags & QGTC_CHECK_DESCRIPTORS) {
         const int crc = qgtc_launch_check_descriptors(stage1, stage2, count, max_M, max_K1, max_N, max_K2, max_N, 1, st);
         if (crc != QGTC_OK) return crc;
         flags &= ~QGTC_CHECK_DESCRIPTORS;
     }
-    const LayerArgs la{stage1, stage2, arrival, count, max_M, max_K1, max_K2, max_N, x_bits, w_bits, t_bits,
-                       a_bits, output_bit, mode, epoch, !(flags & QGTC_NO_ZERO_SKIP)};
-    if (route == 1) return qgtc_launch_layer_wave(la, st);
-    if (route == 2) return qgtc_launch_layer_mfma(la, st);
-    const unsigned f2 = flags & ~QGTC_LAYER_ONE_LAUNCH;
-    int rc = qgtc_bitmm_batched(stage1, count, max_M, max_K1, max_N, x_bits, w_bits, t_bits, 1, f2 & ~QGTC_ZERO_JUMP, stream);
+    // two grouped launches on one stream (an in-launch hand-off between the stages was built in round 2 and measured
+    // slower: 35 against 30 us for a 75-batch 128-wide layer)
+    int rc = qgtc_bitmm_batched(stage1, count, max_M, max_K1, max_N, x_bits, w_bits, t_bits, 1, flags & ~QGTC_ZERO_JUMP, stream);
     if (rc != QGTC_OK) return rc;
-    return qgtc_bitmm_batched(stage2, count, max_M, max_K2, max_N, a_bits, t_bits, mode == 2 ? 1 : output_bit, mode, f2, stream);
+    return qgtc_bitmm_batched(stage2, count, max_M, max_K2, max_N, a_bits, t_bits, mode == 2 ? 1 : output_bit, mode, flags, stream);
 }
 
 int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stage_xw, int count, int max_M, int max_K,
@@ -443,37 +413,6 @@ int qgtc_adj_tiles_from_rows(const uint32_t *rows, size_t rows_words, int M, int
     if (tiles_words < qgtc_adj_tiles_words(M, K)) return QGTC_ESIZE;
     if (!aligned16(rows) || !aligned16(tiles)) return QGTC_EALIGN;
     return qgtc_launch_rows_to_tiles(rows, rows_words, M, K, tiles, static_cast<hipStream_t>(stream));
-}
-
-size_t qgtc_chain_epoch_sync_words(int count) { return count > 0 ? static_cast<size_t>(count + 1) * 64u : 0u; }
-
-int qgtc_chain_epoch(const qgtc_problem *const *stages, int kind, int count, int max_M, int F, int H, int C, int x_bits,
-                     const uint32_t *const *w_codes, uint32_t *sync, uint32_t epoch, unsigned flags, void *stream) {
-    if (!stages || !w_codes || !sync || epoch == 0u || count <= 0 || count > 65535 || max_M <= 0 || (kind != 0 && kind != 1)) return QGTC_EINVAL;
-    for (int i = 0; i < 6; i++)
-        if (!stages[i]) return QGTC_EINVAL;
-    for (int i = 0; i < 3; i++)
-        if (!w_codes[i] || !aligned16(w_codes[i])) return QGTC_EINVAL;
-    if (F <= 0 || H <= 0 || C <= 0 || max_M > 8192 || getenv_flag("QGTC_NO_RBW") || getenv_flag("QGTC_NO_EPOCH_KERNEL")) return QGTC_EINVAL;
-    if (kind == 0 && !(rbw_xw_ok(F, H, x_bits, 2) && rbw_chain_ok(max_M, H, H, 2, 2, 2, 1) && rbw_chain_ok(max_M, H, C, 2, 2, 2, 1) && C <= 32)) return QGTC_EINVAL;
-    if (kind == 1 && !(rbw_chain_ok(max_M, F, H, 4, 4, 4, 1) && rbw_chain_ok(max_M, H, H, 4, 4, 4, 1) && rbw_chain_ok(max_M, H, C, 4, 4, 4, 2) && C <= 32)) return QGTC_EINVAL;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (flags & QGTC_CHECK_DESCRIPTORS) {
-        for (int i = 0; i < 6; i += (kind == 0 && i == 0) ? 1 : 2) {   // the stages whose left operand is read: X.W1 (GCN) and every aggregation
-            const bool agg = !(kind == 0 && i == 0);
-            const int crc = qgtc_launch_check_descriptors(stages[i], nullptr, count, max_M, agg ? max_M : F, 128, 0, 0, 3, st);
-            if (crc != QGTC_OK) return crc;
-        }
-    }
-    return qgtc_launch_rbw_epoch(stages, kind, count, max_M, F, H, C, x_bits, w_codes, sync, epoch, st);
-}
-
-int qgtc_chain_epoch_failed(const uint32_t *sync, int count, void *stream) {
-    if (!sync || count <= 0) return QGTC_EINVAL;
-    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-    uint32_t v = 0u;
-    HIP_TRY(hipMemcpy(&v, sync + static_cast<size_t>(count) * 64u, sizeof(v), hipMemcpyDeviceToHost));
-    return v ? QGTC_EHIP : QGTC_OK;
 }
 
 size_t qgtc_occupancy_words(int M, int K) {

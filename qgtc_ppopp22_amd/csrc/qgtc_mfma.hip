@@ -13,7 +13,5 @@
 #include "common.hip.h"
 #include "bitmm_popcount.hip.h"   // MMShape, requant, the DPP ORs (templates only: nothing is instantiated here)
 #include "bitmm_mfma.hip.h"
-#define QGTC_LAYER_MFMA 1
-#include "bitmm_layer.hip.h"
 #include "launch_common.hip.h"
 #include "launch_mfma.hip.h"

@@ -570,17 +570,13 @@ struct BatchedGemm {
     }
 };
 
-// One quantised GNN layer for all cluster batches in ONE launch (qgtc_gcn_layer_batched): stage1 = the grouped
-// bitMM2Bit_col X.W (mode 1), stage2 = the grouped A.(XW) whose right operands ARE stage1's outputs. Owns the
-// per-batch arrival counters (zeroed once; monotonic) and counts its own launches.
+// One quantised GNN layer for all cluster batches in ONE call (qgtc_gcn_layer_batched): stage1 = the grouped
+// bitMM2Bit_col X.W (mode 1), stage2 = the grouped A.(XW) whose right operands ARE stage1's outputs.
 struct FusedLayer {
     std::shared_ptr<BatchedGemm> s1, s2;
-    torch::Tensor arrival;   // int32 [count x QGTC_ARRIVAL_STRIDE], device
-    uint32_t epoch = 0;
-    bool one_launch = false;  // both stages in one launch (in-launch hand-off); default: two grouped launches (faster)
 
-    FusedLayer(std::shared_ptr<BatchedGemm> stage1, std::shared_ptr<BatchedGemm> stage2, bool one_launch_)
-        : s1(std::move(stage1)), s2(std::move(stage2)), one_launch(one_launch_) {
+    FusedLayer(std::shared_ptr<BatchedGemm> stage1, std::shared_ptr<BatchedGemm> stage2)
+        : s1(std::move(stage1)), s2(std::move(stage2)) {
         TORCH_CHECK(s1 && s2, "FusedLayer needs two BatchedGemm plans");
         TORCH_CHECK(s1->count == s2->count, "both stages must cover the same cluster batches");
         TORCH_CHECK(s1->mode == 1, "stage 1 must produce cols-layout bits (mode 1: it is stage 2's right operand)");
@@ -593,37 +589,17 @@ struct FusedLayer {
             TORCH_CHECK(a.M == b.M && a.M == b.K && a.N == b.N, "batch ", i, ": stage shapes do not chain (n x f_in x f_out, then n x n x f_out)");
             TORCH_CHECK(b.w_lines == P128(b.N), "stage 2 reads a cols-layout operand with PAD128 lines");
         }
-        c10::DeviceGuard guard(s1->descs.device());
-        arrival = torch::zeros({static_cast<int64_t>(s1->count) * QGTC_ARRIVAL_STRIDE}, torch::TensorOptions().dtype(torch::kInt32).device(s1->descs.device()));
     }
 
     void run() {
         c10::DeviceGuard guard(s1->descs.device());
         const int max_M = std::max(s1->max_M, s2->max_M), max_N = std::max(s1->max_N, s2->max_N);
-        const unsigned flags = mm_flags() | (s2->jump_asked ? QGTC_ZERO_JUMP : 0u) | (one_launch ? QGTC_LAYER_ONE_LAUNCH : 0u);
-        // The arrival counters advance only when the ONE-LAUNCH kernel runs - and whether it does is re-decided on every
-        // call from the engine switch (a run under set_engine("popcount") takes the two grouped launches and leaves the
-        // counters alone): `epoch` follows the route the library reports, never the call count.
-        const int route = qgtc_gcn_layer_route(s1->count, max_M, s1->max_K, s2->max_K, max_N, s1->bit1, s1->bit2, s1->ob, s2->bit1,
-                                               s2->ob, s2->mode, flags);
-        TORCH_CHECK(route >= 0, "QGTC.FusedLayer.run: ", qgtc_strerror(-route));
-        if (route == 1 && epoch == 0xffffffffu) {   // 2^32 - 1 one-launch runs: start the counters over
-            arrival.zero_();
-            epoch = 0;
-        }
-        const int rc = qgtc_gcn_layer_batched(reinterpret_cast<const qgtc_problem *>(s1->descs.data_ptr()),
-                                              reinterpret_cast<const qgtc_problem *>(s2->descs.data_ptr()), s1->count,
-                                              max_M, s1->max_K, s2->max_K, max_N,
-                                              s1->bit1, s1->bit2, s1->ob, s2->bit1, s2->ob, s2->mode,
-                                              reinterpret_cast<uint32_t *>(arrival.data_ptr<int32_t>()), route == 1 ? epoch + 1u : 1u,
-                                              flags, current_stream(arrival));
-        if (rc != QGTC_OK) {   // whatever was or was not launched: counters and epoch start over together
-            arrival.zero_();
-            epoch = 0;
-        } else if (route == 1) {
-            epoch++;
-        }
-        check_rc(rc, "FusedLayer.run");
+        const unsigned flags = mm_flags() | (s2->jump_asked ? QGTC_ZERO_JUMP : 0u);
+        check_rc(qgtc_gcn_layer_batched(reinterpret_cast<const qgtc_problem *>(s1->descs.data_ptr()),
+                                        reinterpret_cast<const qgtc_problem *>(s2->descs.data_ptr()), s1->count,
+                                        max_M, s1->max_K, s2->max_K, max_N, s1->bit1, s1->bit2, s1->ob, s2->bit1, s2->ob, s2->mode,
+                                        flags, current_stream(s1->descs)),
+                 "FusedLayer.run");
     }
 };
 
@@ -660,48 +636,19 @@ struct ChainedPair {
     }
 };
 
-// One quantised GNN layer on ONE subgraph in one launch: requant(A . requant(X . W)) (QGTC_conv.py:14-22). bit_A: rows
+// One quantised GNN layer on ONE subgraph in one call: requant(A . requant(X . W)) (QGTC_conv.py:14-22). bit_A: rows
 // layout, 1.. planes, [n, n]; bit_X: rows layout [n, f_in]; bit_W: cols layout [f_in, f_out]. Returns the packed
-// activations (rows layout, act_bit planes) or, with output = true, float32 [n, f_out].
+// activations (rows layout, act_bit planes) or, with output = true, float32 [n, f_out]. Two fully asynchronous launches
+// of the tuned single-problem kernels: no descriptors in device memory, no host synchronisation.
 torch::Tensor gcn_layer(torch::Tensor bit_A, torch::Tensor bit_X, torch::Tensor bit_W, int n, int f_in, int f_out,
-                        int a_bit, int act_bit, int w_bit, bool output, bool one_launch) {
+                        int a_bit, int act_bit, int w_bit, bool output) {
     CHECK_INPUT(bit_A);
-    CHECK_INPUT(bit_X);
-    CHECK_INPUT(bit_W);
     check_bits_tensor(bit_A, "bit_A");
-    check_bits_tensor(bit_X, "bit_X");
-    check_bits_tensor(bit_W, "bit_W");
     TORCH_CHECK(bit_A.device() == bit_X.device() && bit_A.device() == bit_W.device(), "all operands must share a device");
     TORCH_CHECK(n > 0 && f_in > 0 && f_out > 0, "bad dimensions");
-    TORCH_CHECK(bit_A.numel() < (1LL << 30) && bit_X.numel() < (1LL << 30) && bit_W.numel() < (1LL << 30), "packed operand too large (>= 4 GiB)");
-    const auto dev = bit_A.device();
-    c10::DeviceGuard guard(dev);
-    if (!one_launch) {
-        // One subgraph, two products: the tuned single-problem kernels, two fully asynchronous launches, no descriptors in
-        // device memory, no host synchronisation (word for word what the grouped entry computes for count = 1)
-        torch::Tensor T1 = mm2bit_impl(bit_X, bit_W, n, f_in, f_out, act_bit, w_bit, act_bit, true, "gcn_layer");
-        if (output) return bitMM2Int(bit_A, T1, n, n, f_out, a_bit, act_bit, true);
-        return mm2bit_impl(bit_A, T1, n, n, f_out, a_bit, act_bit, act_bit, false, "gcn_layer");
-    }
-    const auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(dev);
-    torch::Tensor T = torch::empty({static_cast<int64_t>(act_bit) * S128(n) * 4, P128(f_out)}, i32);   // QGTC_device.cu:456
-    torch::Tensor out = output ? torch::empty({n, f_out}, torch::TensorOptions().dtype(torch::kFloat32).device(dev))
-                               : torch::empty({static_cast<int64_t>(act_bit) * P8(n), S128(f_out) * 4}, i32);   // QGTC_device.cu:223
-    qgtc_problem h[2];
-    h[0] = qgtc_problem{words(bit_X), words(bit_W), T.data_ptr(), static_cast<uint64_t>(bit_X.numel()), static_cast<uint64_t>(bit_W.numel()),
-                        n, f_in, f_out, P128(f_out), 0, nullptr};
-    h[1] = qgtc_problem{words(bit_A), words(T), out.data_ptr(), static_cast<uint64_t>(bit_A.numel()), static_cast<uint64_t>(T.numel()),
-                        n, n, f_out, P128(f_out), 0, nullptr};
-    auto host = torch::empty({static_cast<int64_t>(2 * sizeof(qgtc_problem))}, torch::TensorOptions().dtype(torch::kUInt8).pinned_memory(true));
-    std::memcpy(host.data_ptr(), h, sizeof(h));
-    torch::Tensor descs = host.to(dev, /*non_blocking=*/true);
-    torch::Tensor arrival = torch::zeros({QGTC_ARRIVAL_STRIDE}, i32);
-    const qgtc_problem *dp = reinterpret_cast<const qgtc_problem *>(descs.data_ptr());
-    check_rc(qgtc_gcn_layer_batched(dp, dp + 1, 1, n, f_in, n, f_out, act_bit, w_bit, act_bit, a_bit, act_bit, output ? 2 : 0,
-                                    reinterpret_cast<uint32_t *>(arrival.data_ptr<int32_t>()), 1u,
-                                    mm_flags() | (one_launch ? QGTC_LAYER_ONE_LAUNCH : 0u), current_stream(bit_A)),
-             "gcn_layer");
-    return out;   // (T, descs and arrival go back to the stream-ordered allocator: reuse happens behind this launch)
+    torch::Tensor T1 = mm2bit_impl(bit_X, bit_W, n, f_in, f_out, act_bit, w_bit, act_bit, true, "gcn_layer");
+    if (output) return bitMM2Int(bit_A, T1, n, n, f_out, a_bit, act_bit, true);
+    return mm2bit_impl(bit_A, T1, n, n, f_out, a_bit, act_bit, act_bit, false, "gcn_layer");
 }
 
 
@@ -762,12 +709,6 @@ struct EpochPlan {
         int codes;       // kinds 3 / 4: index of the pre-expanded weight (weight_codes)
     };
     std::vector<torch::Tensor> weight_codes;   // qgtc_expand_weights outputs, made by bind()
-    // the whole epoch in ONE launch (qgtc_chain_epoch), when bind() was given `whole` = (kind, F, H, C, x_bits, codes0, codes1, codes2)
-    // and the library accepts it; `launches` stay as the fallback
-    std::vector<int> whole;
-    torch::Tensor sync;          // per-batch barrier counters + error word
-    uint32_t sync_epoch = 0;
-    bool whole_ok = false;
     std::vector<Launch> launches;
     std::vector<uint64_t> offsets;      // lazily: word offset of every (stage, batch) output in the pool
     static constexpr double kJumpBelow = BatchedGemm::kJumpBelow;
@@ -868,7 +809,7 @@ struct EpochPlan {
     // stages: (left, right, K, N, bit1, bit2, ob, mode, pad128, use_occ) per operator; launches: (kind, s1, s2, extra flags)
     // expand: (weight index, K, N, nbits, order) per pre-expanded weight the launches of kinds 3 / 4 name
     void bind(std::vector<torch::Tensor> weights_, std::vector<std::array<int, 11>> stages_, std::vector<std::array<int, 5>> launches_,
-              std::vector<std::array<int, 5>> expand, std::vector<int> whole_) {
+              std::vector<std::array<int, 5>> expand) {
         c10::DeviceGuard guard(batches.device());
         const int ns = static_cast<int>(stages_.size()), nw = static_cast<int>(weights_.size());
         TORCH_CHECK(ns >= 1 && ns <= QGTC_MAX_STAGES && nw <= QGTC_MAX_WEIGHTS, "too many stages / weights");
@@ -913,16 +854,6 @@ struct EpochPlan {
             TORCH_CHECK(l[0] < 3 || (l[0] == 4 && l[2] < 0) || (l[4] >= 0 && l[4] < static_cast<int>(weight_codes.size())), "bad weight-codes index");
             launches.push_back(Launch{l[0], l[1], l[2], static_cast<unsigned>(l[3]), l[4]});
         }
-        whole = std::move(whole_);
-        whole_ok = false;
-        if (!whole.empty()) {
-            TORCH_CHECK(whole.size() == 8 && ns == 6, "whole-epoch launch: (kind, F, H, C, x_bits, codes0, codes1, codes2) and six stages");
-            for (int i = 5; i < 8; i++) TORCH_CHECK(whole[i] >= 0 && whole[i] < static_cast<int>(weight_codes.size()), "bad weight-codes index");
-            // counters zeroed once per bind: the epoch number restarts with them
-            sync = torch::zeros({static_cast<int64_t>(qgtc_chain_epoch_sync_words(count))}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
-            sync_epoch = 0;
-            whole_ok = true;
-        }
         offsets.clear();
         const size_t pool_words = qgtc_epoch_pool_layout(nodes.data(), count, stages.data(), ns, nullptr);
         TORCH_CHECK(pool_words > 0 && pool_words < (1ull << 40), "bad pool size");
@@ -965,30 +896,13 @@ struct EpochPlan {
         } else {
             const qgtc_stage &a = stages[l.s1], &b = stages[l.s2];
             check_rc(qgtc_gcn_layer_batched(stage_descs(l.s1), stage_descs(l.s2), count, max_n, dimK(a), dimK(b), std::max(a.N, b.N), a.bit1, a.bit2, a.ob,
-                                            b.bit1, b.ob, b.mode, nullptr, 1u, base | ((b.use_occ && jumping) ? QGTC_ZERO_JUMP : 0u), st), "EpochPlan.run (layer)");
+                                            b.bit1, b.ob, b.mode, base | ((b.use_occ && jumping) ? QGTC_ZERO_JUMP : 0u), st), "EpochPlan.run (layer)");
         }
-    }
-
-    // the epoch as ONE launch; false when the library declines (widths, residency, XCD placement): the caller then issues `launches`
-    bool run_whole(unsigned check) {
-        const qgtc_problem *st[6];
-        for (int i = 0; i < 6; i++) st[i] = stage_descs(i);
-        const uint32_t *wc[3] = {words(weight_codes[whole[5]]), words(weight_codes[whole[6]]), words(weight_codes[whole[7]])};
-        const int rc = qgtc_chain_epoch(st, whole[0], count, max_n, whole[1], whole[2], whole[3], whole[4], wc,
-                                        reinterpret_cast<uint32_t *>(sync.data_ptr<int32_t>()), sync_epoch + 1u, mm_flags() | check, current_stream(descs));
-        if (rc == QGTC_ENODEVICE || rc == QGTC_EINVAL) {
-            whole_ok = false;
-            return false;
-        }
-        check_rc(rc, "EpochPlan.run (whole epoch)");
-        sync_epoch++;
-        return true;
     }
 
     void run() {
         TORCH_CHECK(descs.defined(), "EpochPlan.run before bind");
         c10::DeviceGuard guard(descs.device());
-        if (whole_ok && run_whole(0u)) return;
         for (const Launch &l : launches) run_launch(l, 0u);
     }
 
@@ -996,15 +910,7 @@ struct EpochPlan {
     void run_checked() {
         TORCH_CHECK(descs.defined(), "EpochPlan.run before bind");
         c10::DeviceGuard guard(descs.device());
-        if (whole_ok && run_whole(QGTC_CHECK_DESCRIPTORS)) {
-            const int frc = qgtc_chain_epoch_failed(reinterpret_cast<const uint32_t *>(sync.data_ptr<int32_t>()), count, current_stream(descs));
-            if (frc != QGTC_OK) {   // a batch barrier gave up waiting: never use this entry again on this plan, redo the epoch stage by stage
-                whole_ok = false;
-                for (const Launch &l : launches) run_launch(l, QGTC_CHECK_DESCRIPTORS);
-            }
-        } else {
-            for (const Launch &l : launches) run_launch(l, QGTC_CHECK_DESCRIPTORS);
-        }
+        for (const Launch &l : launches) run_launch(l, QGTC_CHECK_DESCRIPTORS);
         int problem = -1, field = 0;
         const int rc = qgtc_last_batched_violation(&problem, &field, current_stream(descs));
         TORCH_CHECK(rc == QGTC_OK, "EpochPlan: descriptor ", problem, " violates a grouped launch's preconditions (field ", field, ")");
@@ -1113,8 +1019,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("gcn_layer", &gcn_layer, "one quantised GNN layer on a subgraph in one call: requant(A . requant(X . W)) "
           "(QGTC_conv.py:14-22); packed activations, or float32 with output=True",
           py::arg("bit_A"), py::arg("bit_X"), py::arg("bit_W"), py::arg("n"), py::arg("f_in"), py::arg("f_out"),
-          py::arg("a_bit") = 1, py::arg("act_bit") = 2, py::arg("w_bit") = 2, py::arg("output") = false,
-          py::arg("one_launch") = false);
+          py::arg("a_bit") = 1, py::arg("act_bit") = 2, py::arg("w_bit") = 2, py::arg("output") = false);
 
     m.def("val2bit_many", &val2bit_many, "val2bit of up to 8 matrices in one launch (the weights an epoch packs inside its clock)",
           py::arg("inputs"), py::arg("nbits"), py::arg("col_major"), py::arg("output_layer"));
@@ -1129,7 +1034,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
              py::arg("As"), py::arg("Xs"), py::arg("Xrs"), py::arg("nodes"), py::arg("a_bits") = 1, py::arg("zero_jump") = true,
              py::arg("x_chain_bits") = 0, py::arg("x_cols") = 0, py::arg("a_tiles") = false)
         .def("bind", &EpochPlan::bind, py::arg("weights"), py::arg("stages"), py::arg("launches"), py::arg("expand") = std::vector<std::array<int, 5>>(),
-             py::arg("whole") = std::vector<int>(),
              "weights: packed tensors; stages: (left, right, K, N, bit1, bit2, ob, mode, pad128, use_occ, fmt); launches: (kind, s1, s2, flags, "
              "codes); expand: (weight, K, N, nbits, order) per pre-expanded weight")
         .def("run", &EpochPlan::run)
@@ -1144,12 +1048,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def_readonly("zero_jump", &EpochPlan::jumping)
         .def_readonly("x_chain", &EpochPlan::x_chain)
         .def_readonly("a_tiles", &EpochPlan::a_tiles)
-        .def_readonly("whole_epoch", &EpochPlan::whole_ok, "the bound plan runs as ONE launch (qgtc_chain_epoch)")
-        .def("whole_epoch_failed", [](EpochPlan &p) {
-            if (!p.sync.defined()) return false;
-            c10::DeviceGuard guard(p.descs.device());
-            return qgtc_chain_epoch_failed(reinterpret_cast<const uint32_t *>(p.sync.data_ptr<int32_t>()), p.count, current_stream(p.descs)) != QGTC_OK;
-        }, "a batch barrier of the one-launch epoch timed out since bind (waits for the stream)")
         .def_readonly("occupied_fraction", &EpochPlan::occupied)
         .def_property_readonly("n_launches", [](const EpochPlan &p) { return p.launches.size(); });
     m.attr("SRC_A") = static_cast<int>(QGTC_SRC_A);
@@ -1171,11 +1069,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def("run", &ChainedPair::run, "A.(XW) of one layer and X.W of the next for every cluster batch, one launch where eligible")
         .def_property_readonly("outs", [](const ChainedPair &c) { return c.sx->outs; });
     py::class_<FusedLayer>(m, "FusedLayer")
-        .def(py::init<std::shared_ptr<BatchedGemm>, std::shared_ptr<BatchedGemm>, bool>(), py::arg("stage1"), py::arg("stage2"),
-             py::arg("one_launch") = false)
+        .def(py::init<std::shared_ptr<BatchedGemm>, std::shared_ptr<BatchedGemm>>(), py::arg("stage1"), py::arg("stage2"))
         .def("run", &FusedLayer::run, "one call per layer: X.W (cols-layout re-pack) then A.(XW) for every cluster batch")
-        .def_readonly("one_launch", &FusedLayer::one_launch)
-        .def_readonly("arrival", &FusedLayer::arrival)
         .def_property_readonly("outs", [](const FusedLayer &f) { return f.s2->outs; });
 
     py::class_<BatchedGemm, std::shared_ptr<BatchedGemm>>(m, "BatchedGemm")

@@ -64,12 +64,6 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--no-chain", action="store_true",
                    help="with --batched --chain correct: do not join an aggregation stage with the next layer's X.W stage "
                         "(default: one launch for the pair, qgtc_gcn_chain_batched)")
-    p.add_argument("--epoch-kernel", action="store_true",
-                   help="with --batched --chain correct: the whole epoch in ONE launch (qgtc_chain_epoch: per-batch barriers inside the "
-                        "kernel) instead of one launch per stage pair - built, correct, measured slower on MI355X (DESIGN.md 5.7)")
-    p.add_argument("--one-launch", action="store_true",
-                   help="with --batched --chain correct: both products of a layer in ONE launch (in-launch hand-off; "
-                        "measured slower than the two grouped launches the library uses by default)")
     p.add_argument("--streams", type=int, default=0,
                    help="one launch per batch and operator (the reference's structure), batches spread over "
                         "this many HIP streams by the extension (no Python in the loop)")
@@ -188,7 +182,7 @@ class BatchedEpoch:
     """Builds the six grouped GEMMs of an epoch once (outputs preallocated and chained); run()
     issues six launches."""
 
-    def __init__(self, Q, cts, params, W, b, chain: str, run_gin: bool, fuse: bool = True, one_launch: bool = False,
+    def __init__(self, Q, cts, params, W, b, chain: str, run_gin: bool, fuse: bool = True,
                  chain_stages: bool = True, keep_aggregates: bool = False):
         H, C = W["hidden"], W["classes"]
         bitA = [c.bit_A for c in cts]
@@ -243,12 +237,11 @@ class BatchedEpoch:
         self.stages = [g0, g1, g2, g3, g4, g5]
         self.outs = g5.outs
         # The layout-correct chains are pairs "X.W re-packed in the cols layout, then A.(XW)": each pair is one call of
-        # the library's layer entry (Q.FusedLayer -> qgtc_gcn_layer_batched): 3 calls per GCN epoch (4 for GIN). The
-        # library runs a pair as two grouped launches (measured faster) unless one_launch asks for the in-launch
-        # hand-off form.
+        # the library's layer entry (Q.FusedLayer -> qgtc_gcn_layer_batched): 3 calls per GCN epoch (4 for GIN), each two
+        # grouped launches.
         self.launches = list(self.stages)
         self.discarded = set()   # stages whose outputs are not materialised
-        if fuse and chain == "correct" and chain_stages and not one_launch:
+        if fuse and chain == "correct" and chain_stages:
             # An aggregation stage and the NEXT layer's X.W stage are one call (Q.ChainedPair -> qgtc_gcn_chain_batched):
             # X.W is row-local, so the workgroup that has a 32-row block of the aggregate multiplies it with W right away.
             # GCN: X.W1 | A.T1 + X.W2 | A.T2 + X.W3 | A.T3 (four launches); GIN: A.X + X.W1 | A.T1 + X.W2 | A.T2 + X.W3 (three).
@@ -273,7 +266,7 @@ class BatchedEpoch:
             self.launches = [first.get(i, g) for i, g in enumerate(self.stages) if i not in second]
         elif fuse and chain == "correct":
             pairs = [(0, 1), (2, 3), (4, 5)] if not run_gin else [(1, 2), (3, 4)]
-            first = {i: Q.FusedLayer(self.stages[i], self.stages[j], one_launch) for i, j in pairs}
+            first = {i: Q.FusedLayer(self.stages[i], self.stages[j]) for i, j in pairs}
             second = {j for _, j in pairs}
             self.launches = [first.get(i, g) for i, g in enumerate(self.stages) if i not in second]
 
@@ -323,7 +316,7 @@ class PlannedEpoch:
     ClusterIter.epoch_data) and ONE bind launch inside the epoch clock. Same launches, same words as BatchedEpoch."""
 
     def __init__(self, Q, data, params, W, b, chain: str, run_gin: bool, fuse: bool = True, chain_stages: bool = True,
-                 keep_aggregates: bool = False, whole_epoch: bool = False):
+                 keep_aggregates: bool = False):
         H, C = W["hidden"], W["classes"]
         F = params[0][3]
         self.data = data
@@ -331,7 +324,6 @@ class PlannedEpoch:
         stages = stage_recipes(Q, chain, run_gin, F, H, C, b)
         launches = [(0, i, 0, 0, 0) for i in range(6)]
         expand = []
-        whole = []        # the epoch as ONE launch (qgtc_chain_epoch) where the library takes it; `launches` stay as the fallback
         self.discarded = set()
         max_n = max(p[0] for p in params)
         switches = any(k.startswith("QGTC_NO_") for k in os.environ)
@@ -345,9 +337,7 @@ class PlannedEpoch:
             expand = [(0, F, H, b, 0), (1, H, H, b, 1), (3, H, C, b, 1)]     # (weight, K, N, bits, order)
             launches = [(3, 0, 0, 0, 0), (4, 1, 2, 0, 1), (4, 3, 4, 0, 2), (4, 5, -1, 0, 0)]
             self.discarded = {0, 1, 2, 3, 4}
-            if whole_epoch and C <= 32:
-                whole = [0, F, H, C, b, 0, 1, 2]
-            elif getattr(data, "a_tiles", False):   # the aggregations read the adjacency as tiles (the one-launch epoch reads rows)
+            if getattr(data, "a_tiles", False):   # the aggregations read the adjacency as 512-byte tiles
                 for i in (1, 3, 5):
                     stages[i] = (Q.SRC_AT,) + stages[i][1:]
         elif (fuse and chain == "correct" and chain_stages and run_gin and not keep_aggregates and b == 4 and max(F, H, C) <= 64 and max_n <= 8192
@@ -360,9 +350,7 @@ class PlannedEpoch:
             expand = [(0, F, H, b, 1), (1, H, H, b, 1), (2, H, C, b, 1)]
             launches = [(4, 0, 1, 0, 0), (4, 2, 3, 0, 1), (4, 4, 5, 0, 2)]
             self.discarded = {0, 1, 2, 3, 4}
-            if whole_epoch and C <= 32:
-                whole = [1, F, H, C, b, 0, 1, 2]
-            elif getattr(data, "a_tiles", False):
+            if getattr(data, "a_tiles", False):
                 for i in (0, 2, 4):
                     stages[i] = (Q.SRC_AT,) + stages[i][1:]
         elif fuse and chain == "correct" and chain_stages:
@@ -386,8 +374,7 @@ class PlannedEpoch:
             second = {j for _, j in pairs}
             launches = [first.get(i, (0, i, 0, 0, 0)) for i in range(6) if i not in second]
         self.n_launches = len(launches)
-        data.bind([W["W1"], W["W2"], W["W3"], W["W3h"]], [list(t) for t in stages], [list(l) for l in launches], [list(e) for e in expand], whole)
-        self.whole_epoch = bool(whole)
+        data.bind([W["W1"], W["W2"], W["W3"], W["W3h"]], [list(t) for t in stages], [list(l) for l in launches], [list(e) for e in expand])
 
     def run(self):
         self.data.run()
@@ -402,9 +389,9 @@ class PlannedEpoch:
 
 # ---------------------------------------------------------------------------------------------
 def uses_planned_epoch(args) -> bool:
-    """--batched runs on a device-filled plan (PlannedEpoch) unless a switch asks for something only the host-built plan
-    (BatchedEpoch) has: the in-launch hand-off of --one-launch."""
-    return bool(args.batched) and not getattr(args, "one_launch", False) and not args.non_resident and not args.zerotile_jump \
+    """--batched runs on a device-filled plan (PlannedEpoch); the host-built plan (BatchedEpoch) remains for --streams and
+    for callers that hold per-batch tensors of their own."""
+    return bool(args.batched) and not args.non_resident and not args.zerotile_jump \
         and not getattr(args, "pack_on_the_fly", False)
 
 
@@ -503,7 +490,7 @@ def _run_epochs(args, Q, it, feat_size, b, device):
 
     if uses_planned_epoch(args):
         plan = PlannedEpoch(Q, it.epoch_data(Q), it.cluster_param_li, W, b, args.chain, args.run_GIN, fuse=not getattr(args, "no_fuse", False),
-                            chain_stages=not getattr(args, "no_chain", False), whole_epoch=getattr(args, "epoch_kernel", False))
+                            chain_stages=not getattr(args, "no_chain", False))
         for _ in range(args.n_epochs):
             plan.run()
         torch.cuda.synchronize()
@@ -515,7 +502,7 @@ def _run_epochs(args, Q, it, feat_size, b, device):
     if args.batched or args.streams > 0:
         cts = [c.to(device) for c in it.cTensor_li]
         plan = BatchedEpoch(Q, cts, it.cluster_param_li, W, b, args.chain, args.run_GIN, fuse=not getattr(args, "no_fuse", False),
-                            one_launch=getattr(args, "one_launch", False), chain_stages=not getattr(args, "no_chain", False))
+                            chain_stages=not getattr(args, "no_chain", False))
         for _ in range(args.n_epochs):
             outs = plan.run() if args.batched else plan.run_per_batch(args.streams)
     elif args.graph:

@@ -83,13 +83,13 @@ class QgtcProblem(ctypes.Structure):
                 ("w_lines", ctypes.c_int32), ("occ_words", ctypes.c_int32), ("occ", ctypes.c_void_p)]
 
 
-@pytest.mark.parametrize("flags", [0x0, 0x10, 0x10 | 0x20], ids=["popcount", "auto", "auto-one-launch"])
+@pytest.mark.parametrize("flags", [0x0, 0x10, 0x8], ids=["popcount", "auto", "mfma"])
 def test_layer_entry_with_raw_descriptors(lib, oracle, flags):
     """qgtc_gcn_layer_batched through ctypes: descriptors written by the HOST into a device buffer (struct layout of
-    include/qgtc.h), raw device pointers, arrival counters with QGTC_ARRIVAL_STRIDE - against the oracle's two products."""
+    include/qgtc.h), raw device pointers - against the oracle's two products."""
     import torch
     assert ctypes.sizeof(QgtcProblem) == 72   # three pointers, two u64, five i32 (+4 padding), one pointer
-    lib.qgtc_gcn_layer_batched.argtypes = [vp, vp, ctypes.c_int] + [ctypes.c_int] * 4 + [ctypes.c_int] * 6 + [vp, ctypes.c_uint32, ctypes.c_uint, vp]
+    lib.qgtc_gcn_layer_batched.argtypes = [vp, vp, ctypes.c_int] + [ctypes.c_int] * 4 + [ctypes.c_int] * 6 + [ctypes.c_uint, vp]
     rng = np.random.default_rng(17 + flags)
     act, wb, f_in, f_out = 2, 2, 64, 96
     batches = [(150, f_in), (333, f_in), (40, f_in)]
@@ -113,11 +113,10 @@ def test_layer_entry_with_raw_descriptors(lib, oracle, flags):
     count = len(batches)
     host = (QgtcProblem * (2 * count))(*(s1 + s2))
     descs = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
-    arrival = torch.zeros(count * 64, dtype=torch.int32, device="cuda")       # QGTC_ARRIVAL_STRIDE = 64
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for epoch in (1, 2):
         rc = lib.qgtc_gcn_layer_batched(descs.data_ptr(), descs.data_ptr() + 72 * count, count, max(n for n, _ in batches), f_in,
-                                        max(n for n, _ in batches), f_out, act, wb, act, 1, 1, 2, arrival.data_ptr(), epoch, flags, st)
+                                        max(n for n, _ in batches), f_out, act, wb, act, 1, 1, 2, flags, st)
         assert rc == 0, lib.qgtc_strerror(rc)
         torch.cuda.synchronize()
         for (T, T_o, out, out_o) in want:
@@ -125,8 +124,8 @@ def test_layer_entry_with_raw_descriptors(lib, oracle, flags):
             np.testing.assert_array_equal(out.cpu().numpy().reshape(out_o.shape), out_o)
             out.fill_(-3.0)
     # bad arguments are error codes
-    assert lib.qgtc_gcn_layer_batched(None, descs.data_ptr(), count, 10, 10, 10, 10, 2, 2, 2, 1, 1, 2, arrival.data_ptr(), 1, flags, st) == 1
-    assert lib.qgtc_gcn_layer_batched(descs.data_ptr(), descs.data_ptr(), count, 10, 10, 10, 10, 2, 2, 2, 1, 1, 1, arrival.data_ptr(), 1, flags, st) == 1
+    assert lib.qgtc_gcn_layer_batched(None, descs.data_ptr(), count, 10, 10, 10, 10, 2, 2, 2, 1, 1, 2, flags, st) == 1
+    assert lib.qgtc_gcn_layer_batched(descs.data_ptr(), descs.data_ptr(), count, 10, 10, 10, 10, 2, 2, 2, 1, 1, 1, flags, st) == 1
 
 
 @pytest.mark.gpu

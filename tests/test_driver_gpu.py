@@ -190,15 +190,15 @@ def test_full_size_epoch_matches_oracle_and_per_batch_launches(qgtc, oracle, dat
 
 @pytest.mark.parametrize("gin", [False, True, 2])
 def test_layer_entry_routes_give_the_same_epoch(qgtc, gin):
-    """--batched --chain correct: one call of the library's layer entry per layer (default), the same as ONE launch per
-    layer (--one-launch, in-launch hand-off), and the six separate grouped launches (--no-fuse): identical outputs."""
+    """--batched --chain correct: the default plan (aggregation stages carrying the next X.W), the layer-entry plan
+    (--no-chain) and the six separate grouped launches (--no-fuse): identical outputs."""
     import torch
     from qgtc_ppopp22_amd import driver
 
     base = ["--batched", "--chain", "correct"] + (["--run_GIN", "--bit_width", "2" if gin == 2 else "4"] if gin else [])   # (the default
     # plan keeps T between its launches in the kernels' own formats: codes at 4 bits, k-quad-major planes at 2)
     ref = driver.run(_args(base + ["--no-fuse"]), Q=qgtc)["outs"]
-    for extra in ([], ["--one-launch"]):
+    for extra in ([], ["--no-chain"]):
         got = driver.run(_args(base + extra), Q=qgtc)["outs"]
         assert len(got) == len(ref) and all(torch.equal(x, y) for x, y in zip(got, ref)), extra
 
@@ -251,21 +251,3 @@ def test_north_star_alias_names_run_the_same_operators(qgtc, oracle):
     np.testing.assert_array_equal(to_np_u32(bA), oA)
     np.testing.assert_array_equal(to_np_u32(qgtc.mm_v1(bA, bX, n, n, F, 1, b, b)), oracle.bitmm2bit(oA, oX, n, n, F, 1, b, b))
     np.testing.assert_array_equal(qgtc.mm_v2(bA, bX, n, n, F, 1, b, True).cpu().numpy(), oracle.bitmm2int(oA, oX, n, n, F, 1, b, True))
-
-
-@pytest.mark.parametrize("gin", [False, True])
-def test_whole_epoch_in_one_launch_gives_the_same_outputs(qgtc, gin):
-    """--epoch-kernel: qgtc_chain_epoch - every stage of the layout-correct epoch inside ONE launch, the workgroups of a cluster batch
-    meeting at per-batch barriers (counters that only grow: three epochs on the same plan) - against the default plan's outputs (pinned to
-    the oracle above). Opt-in: measured slower than one launch per stage pair on MI355X."""
-    import torch
-    from qgtc_ppopp22_amd import driver
-
-    base = ["--batched", "--chain", "correct", "--n-epochs", "3"] + (["--run_GIN", "--bit_width", "4"] if gin else [])
-    ref = driver.run(_args(base), Q=qgtc)
-    got = driver.run(_args(base + ["--epoch-kernel"]), Q=qgtc)
-    assert got["plan"].whole_epoch and not ref["plan"].whole_epoch
-    data = got["iter"].epoch_data(qgtc)
-    assert data.whole_epoch, "the library declined the one-launch epoch (widths / residency / XCD placement)"
-    assert not data.whole_epoch_failed()
-    assert len(got["outs"]) == len(ref["outs"]) and all(torch.equal(x, y) for x, y in zip(got["outs"], ref["outs"]))

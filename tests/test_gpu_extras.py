@@ -468,7 +468,7 @@ def test_float32_exactness_bound_grouped(qgtc, oracle, a, w):
 
 
 # ---------------------------------------------------------------------------------------------
-# the fused GNN layer (qgtc_gcn_layer_batched): X.W re-packed in the cols layout, then A.(XW), ONE launch
+# the fused GNN layer (qgtc_gcn_layer_batched): X.W re-packed in the cols layout, then A.(XW), ONE call
 # ---------------------------------------------------------------------------------------------
 def _layer_batches(torch, oracle, rng, dims_nf, f_out, act, wb, a_bits=1):
     from helpers import rand_q, to_dev
@@ -494,12 +494,9 @@ def _layer_batches(torch, oracle, rng, dims_nf, f_out, act, wb, a_bits=1):
                                                (128, 128, 8, 8), (64, 10, 9, 2)])
 @pytest.mark.parametrize("engine", ["auto", "mfma", "popcount"])
 @pytest.mark.parametrize("zero_jump", [False, True])
-@pytest.mark.parametrize("one_launch", [False, True])
-def test_fused_layer_matches_oracle(qgtc, oracle, f_in, f_out, act, wb, engine, zero_jump, one_launch):
-    """FusedLayer (one call per GNN layer for a group of cluster batches; as two grouped launches - the default - and
-    as ONE launch with the in-launch hand-off) against the oracle's two products, both output forms, batches of ragged
-    sizes (incl. fewer rows than a tile), run several times (the arrival counters are monotonic), on every engine (the
-    popcount engine and plane counts outside the one-launch kernels' range take the two grouped launches either way)."""
+def test_fused_layer_matches_oracle(qgtc, oracle, f_in, f_out, act, wb, engine, zero_jump):
+    """FusedLayer (one call per GNN layer for a group of cluster batches: two grouped launches) against the oracle's two
+    products, both output forms, batches of ragged sizes (incl. fewer rows than a tile), run several times, on every engine."""
     import torch
     rng = np.random.default_rng(f_in * 7 + f_out + act + wb)
     dims_nf = [(1213, f_in), (640, f_in), (37, f_in), (129, f_in), (300, f_in)]
@@ -510,7 +507,7 @@ def test_fused_layer_matches_oracle(qgtc, oracle, f_in, f_out, act, wb, engine, 
         for mode2 in (0, 2):
             s1 = qgtc.BatchedGemm(Xs, [dW], d1, act, wb, act, 1, True)
             s2 = qgtc.BatchedGemm(As, s1.outs, d2, 1, act, act, mode2, True, zero_jump)
-            layer = qgtc.FusedLayer(s1, s2, one_launch)
+            layer = qgtc.FusedLayer(s1, s2)
             for rep in range(3):
                 layer.run()
                 torch.cuda.synchronize()
@@ -544,17 +541,16 @@ def test_fused_layer_rejects_plans_that_do_not_chain(qgtc, oracle):
 
 @pytest.mark.parametrize("n,f_in,f_out,act,wb", [(300, 64, 64, 2, 2), (1213, 128, 128, 2, 2), (599, 50, 10, 4, 4), (40, 33, 200, 3, 3)])
 def test_gcn_layer_single_subgraph(qgtc, oracle, n, f_in, f_out, act, wb):
-    """QGTC.gcn_layer (what conv.py's Aggregation_Qnt calls): one subgraph, one launch, both output forms."""
+    """QGTC.gcn_layer (what conv.py's Aggregation_Qnt calls): one subgraph, one call, both output forms."""
     import torch
     rng = np.random.default_rng(n + f_in + f_out)
     As, Xs, dW, want = _layer_batches(torch, oracle, rng, [(n, f_in)], f_out, act, wb)
     for engine in ("auto", "popcount"):
         with use_engine(qgtc, engine):
-            for one in (False, True):
-                bits = qgtc.gcn_layer(As[0], Xs[0], dW, n, f_in, f_out, 1, act, wb, False, one)
-                flt = qgtc.gcn_layer(As[0], Xs[0], dW, n, f_in, f_out, 1, act, wb, True, one)
-                np.testing.assert_array_equal(to_np_u32(bits), want[0][1])
-                np.testing.assert_array_equal(flt.cpu().numpy(), want[0][2])
+            bits = qgtc.gcn_layer(As[0], Xs[0], dW, n, f_in, f_out, 1, act, wb, False)
+            flt = qgtc.gcn_layer(As[0], Xs[0], dW, n, f_in, f_out, 1, act, wb, True)
+            np.testing.assert_array_equal(to_np_u32(bits), want[0][1])
+            np.testing.assert_array_equal(flt.cpu().numpy(), want[0][2])
 
 
 
@@ -807,11 +803,9 @@ def test_val2bit_many_equals_val2bit(qgtc, oracle, nbits):
         qgtc.val2bit_many([torch.zeros((4, 4), device="cuda")] * 9, nbits, [True] * 9, [False] * 9)
 
 
-def test_one_launch_layer_survives_engine_changes_between_runs(qgtc, oracle):
-    """A FusedLayer built with one_launch=True, run on `auto` (the in-launch hand-off: arrival counters advance), then under
-    set_engine("popcount") (two grouped launches: counters untouched), then on `auto` again: the plan's epoch follows the
-    route the library reports, so the consumers never wait for arrivals that were not made. (Round 2 counted calls: the third
-    run hung the GPU.)"""
+def test_layer_plan_survives_engine_changes_between_runs(qgtc, oracle):
+    """One FusedLayer plan run under a sequence of engine settings: the route is re-decided on every call and every route
+    gives the same float32 outputs."""
     import torch
     rng = np.random.default_rng(77)
     act, wb, f_in, f_out = 2, 2, 64, 64
@@ -827,7 +821,7 @@ def test_one_launch_layer_survives_engine_changes_between_runs(qgtc, oracle):
         want.append(oracle.bitmm2int(A, T, n, n, f_out, 1, act, True))
     g1 = qgtc.BatchedGemm(Xs, [dW], [(n, f_in, f_out) for n in ns], act, wb, act, 1, False, False)
     g2 = qgtc.BatchedGemm(As, g1.outs, [(n, n, f_out) for n in ns], 1, act, 1, 2, True, False)
-    layer = qgtc.FusedLayer(g1, g2, True)
+    layer = qgtc.FusedLayer(g1, g2)
     for eng in ("auto", "popcount", "auto", "mfma", "popcount", "auto"):
         qgtc.set_engine(eng)
         for o in g2.outs:

@@ -34,7 +34,7 @@ def timed(fn, reps=20):
 
 
 if chain == "correct":     # one fused launch per layer (qgtc_gcn_layer_batched) against the two grouped launches
-    fused = driver.BatchedEpoch(Q, it.cTensor_li, it.cluster_param_li, W, b, chain, gin, fuse=True, one_launch=True)
+    fused = driver.BatchedEpoch(Q, it.cTensor_li, it.cluster_param_li, W, b, chain, gin, fuse=True, chain_stages=False)
     for _ in range(3):
         fused.run()
     torch.cuda.synchronize()

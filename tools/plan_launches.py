@@ -28,7 +28,7 @@ for name in which:
     data = it.epoch_data(Q)
     dev = torch.device("cuda:0")
     W = driver.pack_weights(Q, g.feat.shape[1], hidden, 10, bits, dev)
-    plan = driver.PlannedEpoch(Q, data, it.cluster_param_li, W, bits, chain, gin, whole_epoch=bool(os.environ.get("EPOCH_KERNEL")))
+    plan = driver.PlannedEpoch(Q, data, it.cluster_param_li, W, bits, chain, gin)
     t_w = time.perf_counter()
     while time.perf_counter() - t_w < 0.3:
         for _ in range(20):
@@ -36,5 +36,5 @@ for name in which:
         torch.cuda.synchronize()
     per = [round(ev(lambda i=i: data.run_launch(i)), 2) for i in range(plan.n_launches)]
     ep = round(ev(plan.run, 100), 2)
-    print(name, chain, "launches", per, "sum", round(sum(per), 2), "epoch", ep, "(one launch)" if data.whole_epoch else "", "barrier timeout" if data.whole_epoch_failed() else "",
+    print(name, chain, "launches", per, "sum", round(sum(per), 2), "epoch", ep, 
           "occupied", round(data.occupied_fraction, 3), flush=True)

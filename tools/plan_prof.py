@@ -22,6 +22,6 @@ ms, g0 = t(lambda: Q.BatchedGemm(bitXr, [W["W1"]], dims, 2, 2, 2, 1, False, Fals
 dimsA = [(ni, ni, 128) for ni in n]
 ms, g1 = t(lambda: Q.BatchedGemm(bitA, g0.outs, dimsA, 1, 2, 2, 0, False, True)); print(f"BatchedGemm A.(XW) with bitmaps: {ms:.3f} ms")
 ms, g1b = t(lambda: Q.BatchedGemm(bitA, g0.outs, dimsA, 1, 2, 2, 0, False, True, g1.occs)); print(f"BatchedGemm A.(XW) reusing bitmaps: {ms:.3f} ms")
-ms, f = t(lambda: Q.FusedLayer(g0, g1, False)); print(f"FusedLayer: {ms:.3f} ms")
+ms, f = t(lambda: Q.FusedLayer(g0, g1)); print(f"FusedLayer: {ms:.3f} ms")
 ms, _ = t(lambda: [c.bit_A for c in cts]); print(f"python list of 75 tensors: {ms:.3f} ms")
 ms, _ = t(lambda: driver.BatchedEpoch(Q, cts, params, W, 2, "correct", False)); print(f"whole BatchedEpoch: {ms:.3f} ms")

@@ -146,10 +146,10 @@ int main(int argc, char **argv) {
         }
         printf("as %d parts on %d streams (graph replay): %.2f us per round of the whole launch's work; unsplit, replayed the same way: %.2f us\n", parts, parts, bs * 1e3 / 200, b1 * 1e3 / 200);
     }
-    if (getenv("EPOCH")) {   // the whole Cluster-GCN epoch in one launch (qgtc_chain_epoch) on the same synthetic batches, F = H = 128, C = 10
+    if (getenv("EPOCH")) {   // the Cluster-GCN epoch (four chain-entry launches) on the same synthetic batches, F = H = 128, C = 10
         const int F = 128, H = 128, C = 10;
         const size_t xw_ = qgtc_rows_words(n, F, 2), th = qgtc_chain_words(n, H), tc = qgtc_chain_words(n, C);
-        uint32_t *dX, *dT1, *dT2, *dT3, *dW1, *dW2, *dW3, *c1, *c2, *c3, *dsync;
+        uint32_t *dX, *dT1, *dT2, *dT3, *dW1, *dW2, *dW3, *c1, *c2, *c3;
         float *dout;
         CK(hipMalloc(&dX, xw_ * 4 * count)); CK(hipMalloc(&dT1, th * 4 * count)); CK(hipMalloc(&dT2, th * 4 * count)); CK(hipMalloc(&dT3, tc * 4 * count));
         CK(hipMalloc(&dout, (size_t)n * C * 4 * count));
@@ -182,13 +182,8 @@ int main(int argc, char **argv) {
         qgtc_problem *ds;
         CK(hipMalloc(&ds, hs.size() * sizeof(qgtc_problem)));
         CK(hipMemcpy(ds, hs.data(), hs.size() * sizeof(qgtc_problem), hipMemcpyHostToDevice));
-        CK(hipMalloc(&dsync, qgtc_chain_epoch_sync_words(count) * 4));
-        CK(hipMemset(dsync, 0, qgtc_chain_epoch_sync_words(count) * 4));
         const qgtc_problem *st6[6];
         for (int i = 0; i < 6; i++) st6[i] = ds + (size_t)i * count;
-        const uint32_t *wc3[3] = {c1, c2, c3};
-        uint32_t ep = 0;
-        auto whole = [&]() { return qgtc_chain_epoch(st6, 0, count, n, F, H, C, 2, wc3, dsync, ++ep, 0, st); };
         auto four = [&]() {
             int rc = qgtc_chain_transform(st6[0], count, n, F, H, 2, 2, c1, 0, st);
             if (!rc) rc = qgtc_chain_aggregate(st6[1], st6[2], count, n, n, H, H, 2, 2, 2, 1, c2, 0, st);
@@ -196,21 +191,20 @@ int main(int argc, char **argv) {
             if (!rc) rc = qgtc_chain_aggregate(st6[5], nullptr, count, n, n, C, 0, 2, 0, 0, 0, nullptr, 0, st);
             return rc;
         };
-        for (int variant = 0; variant < 2; variant++) {
-            if (int rc = variant ? whole() : four()) { printf("epoch variant %d rc=%d %s\n", variant, rc, qgtc_strerror(rc)); continue; }
+        for (int variant = 0; variant < 1; variant++) {
+            if (int rc = four()) { printf("epoch variant %d rc=%d %s\n", variant, rc, qgtc_strerror(rc)); continue; }
             CK(hipStreamSynchronize(st));
             float best2 = 1e9f;
             for (int rep = 0; rep < 5; rep++) {
                 CK(hipEventRecord(e0, st));
-                for (int i = 0; i < 100; i++) variant ? whole() : four();
+                for (int i = 0; i < 100; i++) four();
                 CK(hipEventRecord(e1, st));
                 CK(hipEventSynchronize(e1));
                 float ms;
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 best2 = std::min(best2, ms);
             }
-            printf("Cluster-GCN epoch (%s): %.2f us per epoch (100 epochs from a C loop, best of 5)%s\n", variant ? "ONE launch" : "four launches", best2 * 1e3 / 100,
-                   variant && qgtc_chain_epoch_failed(dsync, count, st) ? "  BARRIER TIMEOUT" : "");
+            printf("Cluster-GCN epoch (four launches): %.2f us per epoch (100 epochs from a C loop, best of 5)\n", best2 * 1e3 / 100);
         }
     }
 #ifdef QGTC_RBW_STAMPS
