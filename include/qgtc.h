@@ -59,7 +59,7 @@ enum {
 #define QGTC_CHAIN_CODES_IN 0x80u   /* qgtc_gcn_chain_batched / qgtc_bitmm_batched: the right operands were written by a launch with _CODES_OUT */
 #define QGTC_CHAIN_CODES_OUT 0x100u /* qgtc_gcn_chain_batched / qgtc_bitmm_batched (mode 1): the outputs are only read by a launch with _CODES_IN */
 #define QGTC_CHAIN_ADJ_TILES 0x400u /* qgtc_chain_aggregate: the adjacencies (stage_a[b].X) are in the tile format of qgtc_adj_tiles_from_rows */
-#define QGTC_CHECK_DESCRIPTORS 0x200u /* grouped entry points: a one-workgroup kernel ahead of the product compares every DEVICE
+#define QGTC_CHECK_DESCRIPTORS 0x200u /* grouped entry points: a small kernel (one thread per descriptor) ahead of the product compares every DEVICE
                                   descriptor with the stated max_M / max_K / max_N (and the chaining rules of the two-stage
                                   entries) and records the first violation on the device; qgtc_last_batched_violation() reads it */
 
@@ -237,7 +237,7 @@ int qgtc_i8gemm_profile(const int8_t *A, const int8_t *Bt, int M, int K, int N, 
  * The descriptors of qgtc_bitmm_batched / qgtc_gcn_layer_batched / qgtc_gcn_chain_batched live in device memory, so the
  * host side cannot compare them with the stated maxima (from which the grid, the split-K plan and the choice between the
  * float32 and int32 kernels are derived). With QGTC_CHECK_DESCRIPTORS in `flags` those entries first launch a
- * one-workgroup kernel on `stream` that checks every descriptor: M <= max_M, K <= max_K, N <= max_N, all positive,
+ * small kernel (one thread per descriptor) on `stream` that checks every descriptor: M <= max_M, K <= max_K, N <= max_N, all positive,
  * non-NULL 16-byte aligned operands, and for the two-stage entries that stage 2 really reads stage 1's output. The
  * product still runs (its results for an offending problem are unspecified, exactly as without the flag); the first
  * violation is kept in a per-device record until it is read.
@@ -350,6 +350,43 @@ int qgtc_chain_transform(const qgtc_problem *stage, int count, int max_M, int K,
 int qgtc_chain_aggregate(const qgtc_problem *stage_a, const qgtc_problem *stage_xw, int count, int max_M, int max_K, int N1,
                          int N2, int t_bits, int act_bits, int out_bits, int out_mode, const uint32_t *w2_codes,
                          unsigned flags, void *stream);
+
+/* ---- The data loader's packing for ALL cluster batches of an iterator in a handful of launches -------------------------
+ * sampler.py:76-106 packs every batch on its own: the batch's dense float adjacency from its edges, `QGTC.val2bit(A, 1, False,
+ * False)`, `QGTC.val2bit(X, bit_width, True, False)`. Here one call packs `count` batches: per batch the 1-bit adjacency in the
+ * rows layout straight from its edge list (the words qgtc_pack_edge_list gives: multiplicities 1, 2, >= 3 quantise to 1, 0, 1),
+ * the features in the cols layout (the reference's bit_X) and - each optional, NULL = not wanted - the features in the rows
+ * layout (left operand of the layout-correct chain's first X.W), the adjacency as 512-byte tiles (qgtc_adj_tiles_from_rows),
+ * its occupancy bitmap (qgtc_tile_occupancy) and the features in the chain format (qgtc_chain_from_cols; x_bits <= 4).
+ * Every output is word for word what the single-batch entry gives for that batch.
+ *   `batches`: DEVICE array of `count` entries (the caller uploads it); edge indices are LOCAL to the batch (row = src,
+ *   col = dst in [0, n)), int64, batch b's edges at src/dst[edge_off .. edge_off + n_edges); its features are rows
+ *   feat_row .. feat_row + n - 1 of `feats` (float32, F columns, row-major).
+ *   `zero` / `zero_bytes`: ONE region that contains every A, every scratch buffer and `stats`; the call clears it with one
+ *   memset (round 3 issued two memsets per batch). scratch: 2 x qgtc_rows_words(n, n, 1) words per batch.
+ *   max_n / max_edges: at least every batch's n / n_edges (grid sizes; hard preconditions like the grouped GEMM's maxima).
+ *   stats (optional, inside `zero`): stats[0] += occupied 32-row x 128-bit adjacency tiles of all batches.
+ *   bad_index (optional device int, cleared by the call): set to 1 when an edge index is out of range (such edges are skipped).
+ *   formats: which of the optional feature formats ANY batch asks for (QGTC_LOAD_X_ROWS, QGTC_LOAD_X_CHAIN): a launch nobody
+ *   needs is not made (the table itself lives on the device). */
+#define QGTC_LOAD_X_ROWS 0x1u
+#define QGTC_LOAD_X_CHAIN 0x2u
+typedef struct qgtc_loader_batch {
+    uint64_t edge_off, n_edges;
+    uint64_t feat_row;
+    int32_t n;
+    int32_t reserved;
+    uint32_t *A;       /* out: rows layout [n, n], one plane, qgtc_rows_words(n, n, 1) words (inside `zero`) */
+    uint32_t *scratch; /* 2 x qgtc_rows_words(n, n, 1) words (inside `zero`) */
+    uint32_t *AT;      /* out or NULL: qgtc_adj_tiles_words(n, n) words */
+    uint64_t *occ;     /* out or NULL: qgtc_occupancy_words(n, n) 64-bit words */
+    uint32_t *X;       /* out or NULL: cols layout [n, F], x_bits planes, qgtc_cols_words(n, F, x_bits, 0) words */
+    uint32_t *XR;      /* out or NULL: rows layout [n, F], x_bits planes, qgtc_rows_words(n, F, x_bits) words */
+    uint32_t *XC;      /* out or NULL: chain format, qgtc_chain_words(n, F) words (needs X) */
+} qgtc_loader_batch;
+int qgtc_load_batches(const qgtc_loader_batch *batches, int count, int max_n, uint64_t max_edges, const int64_t *src,
+                      const int64_t *dst, const float *feats, int F, int x_bits, void *zero, size_t zero_bytes,
+                      uint64_t *stats, int *bad_index, unsigned formats, void *stream);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,15 @@ int qo_num_threads(void) {
 #endif
 }
 
+/* bench.py's cpu_baseline leg picks the thread count that gives the best rate (a 2 MB problem thrashes on 128 threads) */
+void qo_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* QGTC_device.cu:115 — rows layout is allocated as {nbits*PAD8(H), STEP128(W)*4}. */
 size_t qo_rows_words(int H, int W, int nbits) {
     return (size_t)nbits * (size_t)qo_pad8(H) * (size_t)qo_step128(W) * 4u;

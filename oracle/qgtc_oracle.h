@@ -90,6 +90,7 @@ void qo_tile_counters(const uint32_t *X, size_t x_words, int M, int K, int N, in
 
 /* Number of OpenMP threads the oracle will use (1 when built without OpenMP). */
 int qo_num_threads(void);
+void qo_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -104,6 +104,9 @@ class Oracle:
     def num_threads(self):
         return int(self.L.qo_num_threads())
 
+    def set_num_threads(self, n):
+        self.L.qo_set_num_threads(int(n))
+
     # -- ops -----------------------------------------------------------------------------
     def quantize(self, x, nbits):
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -125,6 +125,27 @@ __global__ __launch_bounds__(256) void k_cols_to_chain(const uint32_t *__restric
     }
 }
 
+// the same for every batch of a grouped pack (qgtc_load_batches): blockIdx.y = batch, cols = the batch's X just written
+__global__ __launch_bounds__(256) void k_cols_to_chain_batched(const qgtc_loader_batch *__restrict__ tb, int W, int nbits) {
+    const qgtc_loader_batch b = tb[blockIdx.y];
+    if (!b.XC || !b.X) return;
+    const int H = b.n, lines = pad128(W), line_words = step128(H) * 4;
+    const size_t plane = static_cast<size_t>(lines) * line_words, total = static_cast<size_t>(line_words) * lines;
+    for (size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const int n = static_cast<int>(t % lines), wj = static_cast<int>(t / lines);
+        uint32_t out[4] = {0u, 0u, 0u, 0u};
+        for (int p = 0; p < nbits && p < 4; p++) {
+            const uint32_t r = n < W ? b.X[p * plane + static_cast<size_t>(n) * line_words + wj] : 0u;
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t sh = d > p ? r >> (d - p) : (d < p ? r << (p - d) : r);
+                out[d] |= sh & (0x11111111u << p);
+            }
+        }
+        *reinterpret_cast<u32x4 *>(b.XC + (static_cast<size_t>(wj) * lines + n) * 4) = u32x4{out[0], out[1], out[2], out[3]};
+    }
+}
+
 // A rows-layout adjacency (one plane, [PAD8(M)][STEP128(K) * 4 words]: QGTC_device.cu:83) as 512-byte TILES
 // [row block of 32][k-quad][32 rows][4 words] - what the aggregation kernels below read when told so (RbwShape::tiles). In the
 // rows layout the 32 lanes of a half-wave that load one k-quad touch 32 different rows (160 bytes apart in a 1213-node batch):

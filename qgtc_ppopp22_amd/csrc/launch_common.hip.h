@@ -22,6 +22,7 @@ int qgtc_launch_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count,
 // row block per wave (bitmm_fp4_rbw.hip.h), defined in qgtc_fp4.hip
 int qgtc_launch_expand_weights(const qgtc_expand_job *jobs, int n_jobs, hipStream_t st);
 int qgtc_launch_cols_to_chain(const uint32_t *cols, size_t words, int H, int W, int nbits, uint32_t *chain, hipStream_t st);
+int qgtc_launch_cols_to_chain_batched(const qgtc_loader_batch *batches, int count, int max_n, int W, int nbits, hipStream_t st);
 int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int N, int a, int ob, const uint32_t *w_codes, hipStream_t st);
 int qgtc_launch_rbw_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int N1, int N2, int t_bits, int act_bits,
                           int out_bits, int mode2, const uint32_t *w2_codes, bool a_tiles, hipStream_t st);

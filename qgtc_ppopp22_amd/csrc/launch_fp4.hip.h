@@ -244,6 +244,14 @@ int qgtc_launch_cols_to_chain(const uint32_t *cols, size_t words, int H, int W, 
     return QGTC_OK;
 }
 
+int qgtc_launch_cols_to_chain_batched(const qgtc_loader_batch *batches, int count, int max_n, int W, int nbits, hipStream_t st) {
+    const size_t total = static_cast<size_t>(step128(max_n)) * 4u * pad128(W);
+    hipLaunchKernelGGL(k_cols_to_chain_batched, dim3(static_cast<unsigned>(std::min<size_t>((total + 255) / 256, 4096)), count), dim3(256), 0, st,
+                       batches, W, nbits);
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
 int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int N, int a, int ob, const uint32_t *w_codes, hipStream_t st) {
     const int per = getenv_flag("QGTC_NO_XCD") ? 0 : 1;   // (the workgroups of a batch on one XCD)
     const dim3 grid(step128(max_M), count), block(256);

@@ -14,13 +14,10 @@ namespace {
 // keeps UNROLL KiB in flight. Every word of the padded output is written.
 // ------------------------------------------------------------------------------------------
 template <int UNROLL>
-__global__ __launch_bounds__(256) void k_val2bit_rows_v4(const float *__restrict__ x, int H, int W,
-                                                         int nbits, float ub, float ubm1,
-                                                         uint32_t *__restrict__ out, int rows_pad,
-                                                         int row_words) {
+__device__ __forceinline__ void val2bit_rows_v4_body(const float *__restrict__ x, int H, int W, int nbits, float ub, float ubm1,
+                                                     uint32_t *__restrict__ out, int rows_pad, int row_words, uint32_t wave,
+                                                     uint32_t nwaves) {
     const int lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const int chunks = (row_words + 7) >> 3;  // 256-column units per row
     const uint32_t units = static_cast<uint32_t>(rows_pad) * chunks;  // < 2^31 (host-checked)
     const size_t plane = static_cast<size_t>(rows_pad) * row_words;
@@ -57,19 +54,24 @@ __global__ __launch_bounds__(256) void k_val2bit_rows_v4(const float *__restrict
     }
 }
 
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_val2bit_rows_v4(const float *__restrict__ x, int H, int W,
+                                                         int nbits, float ub, float ubm1,
+                                                         uint32_t *__restrict__ out, int rows_pad,
+                                                         int row_words) {
+    val2bit_rows_v4_body<UNROLL>(x, H, W, nbits, ub, ubm1, out, rows_pad, row_words, (blockIdx.x * blockDim.x + threadIdx.x) >> 6,
+                                 (gridDim.x * blockDim.x) >> 6);
+}
+
 // ------------------------------------------------------------------------------------------
 // val2bit, rows layout: out[p][r][c>>5] bit(31-(c&31)) = bit p of quant(x[r][c])
 // One wave per (row, 256-column chunk): 4 coalesced loads per lane, one 64-bit ballot per
 // (plane, load), two bit-reversed words per ballot; lanes 0..7 store the chunk's 8 words.
 // Every word of the padded output is written.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_val2bit_rows(const float *__restrict__ x, int H, int W,
-                                                      int nbits, float ub, float ubm1,
-                                                      uint32_t *__restrict__ out, int rows_pad,
-                                                      int row_words) {
+__device__ __forceinline__ void val2bit_rows_body(const float *__restrict__ x, int H, int W, int nbits, float ub, float ubm1,
+                                                  uint32_t *__restrict__ out, int rows_pad, int row_words, long wave, long nwaves) {
     const int lane = threadIdx.x & 63;
-    const long wave = (static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-    const long nwaves = (static_cast<long>(gridDim.x) * blockDim.x) >> 6;
     const int chunks = (row_words + 7) >> 3;
     const long units = static_cast<long>(rows_pad) * chunks;
     const size_t plane = static_cast<size_t>(rows_pad) * row_words;
@@ -96,19 +98,23 @@ __global__ __launch_bounds__(256) void k_val2bit_rows(const float *__restrict__ 
     }
 }
 
+__global__ __launch_bounds__(256) void k_val2bit_rows(const float *__restrict__ x, int H, int W,
+                                                      int nbits, float ub, float ubm1,
+                                                      uint32_t *__restrict__ out, int rows_pad,
+                                                      int row_words) {
+    val2bit_rows_body(x, H, W, nbits, ub, ubm1, out, rows_pad, row_words, (static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6,
+                      (static_cast<long>(gridDim.x) * blockDim.x) >> 6);
+}
+
 // ------------------------------------------------------------------------------------------
 // val2bit, cols layout: out[p][c][r>>5] bit(31-(r&31)) = bit p of quant(x[r][c])
 // One wave per (64-column chunk, 32-row group): lane = column, 32 coalesced row reads in flight, each
 // lane assembles its column's word per plane in registers. NB = compile-time bound on nbits.
 // ------------------------------------------------------------------------------------------
 template <int NB>
-__global__ __launch_bounds__(256) void k_val2bit_cols(const float *__restrict__ x, int H, int W,
-                                                      int nbits, float ub, float ubm1,
-                                                      uint32_t *__restrict__ out, int lines,
-                                                      int line_words) {
+__device__ __forceinline__ void val2bit_cols_body(const float *__restrict__ x, int H, int W, int nbits, float ub, float ubm1,
+                                                  uint32_t *__restrict__ out, int lines, int line_words, long wave, long nwaves) {
     const int lane = threadIdx.x & 63;
-    const long wave = (static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-    const long nwaves = (static_cast<long>(gridDim.x) * blockDim.x) >> 6;
     const int cchunks = (lines + 63) >> 6;
     const long units = static_cast<long>(cchunks) * line_words;
     const size_t plane = static_cast<size_t>(lines) * line_words;
@@ -138,6 +144,15 @@ __global__ __launch_bounds__(256) void k_val2bit_cols(const float *__restrict__ 
                 if (p < nbits) out[p * plane + static_cast<size_t>(c) * line_words + rw] = wd[p];
         }
     }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void k_val2bit_cols(const float *__restrict__ x, int H, int W,
+                                                      int nbits, float ub, float ubm1,
+                                                      uint32_t *__restrict__ out, int lines,
+                                                      int line_words) {
+    val2bit_cols_body<NB>(x, H, W, nbits, ub, ubm1, out, lines, line_words, (static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6,
+                          (static_cast<long>(gridDim.x) * blockDim.x) >> 6);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@
 //   pack_kernels.hip.h       val2bit (rows / cols), bit2val, pack_edges
 //   i8gemm_kernel.hip.h      int8 MFMA comparison GEMM
 //   tile_stats_kernels.hip.h occupancy bitmaps, tile counters
+//   loader_kernels.hip.h     the data loader's packing for all cluster batches at once (qgtc_load_batches)
 //   bitmm_popcount.hip.h     the bit-GEMM on AND + popcount (engine "popcount", and every plane count the matrix-core
 //                            kernels do not cover) - start at the comment above `mm_tile`
 //   bitmm_mfma.hip.h         the bit-GEMM on the matrix cores, 128 x 128 tiles (wide right operands)
@@ -47,6 +48,7 @@
 #include "pack_kernels.hip.h"
 #include "i8gemm_kernel.hip.h"
 #include "tile_stats_kernels.hip.h"
+#include "loader_kernels.hip.h"
 #include "bitmm_popcount.hip.h"
 #include "bitmm_mfma.hip.h"
 #include "launch_common.hip.h"
@@ -488,6 +490,53 @@ int qgtc_pack_edge_list(const int64_t *src, const int64_t *dst, size_t n_edges, 
         hipLaunchKernelGGL(k_edge_list_finish, dim3(grid_for(words, 256)), dim3(256), 0, st, out, scratch,
                            scratch + words, words);
         HIP_TRY(hipGetLastError());
+    }
+    return QGTC_OK;
+}
+
+int qgtc_load_batches(const qgtc_loader_batch *batches, int count, int max_n, uint64_t max_edges, const int64_t *src,
+                      const int64_t *dst, const float *feats, int F, int x_bits, void *zero, size_t zero_bytes,
+                      uint64_t *stats, int *bad_index, unsigned formats, void *stream) {
+    if (!batches || count <= 0 || count > 65535 || max_n <= 0 || !zero || zero_bytes == 0) return QGTC_EINVAL;
+    if (max_edges && (!src || !dst)) return QGTC_EINVAL;
+    if (feats && (F <= 0 || !bits_ok(x_bits))) return QGTC_EINVAL;
+    if (max_edges >= (1ull << 40)) return QGTC_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(zero, 0, zero_bytes, st));
+    if (bad_index) HIP_TRY(hipMemsetAsync(bad_index, 0, sizeof(int), st));
+    if (max_edges) {
+        hipLaunchKernelGGL(k_load_edges, dim3(grid_for(static_cast<size_t>(max_edges), 256, 4096), count), dim3(256), 0, st, batches, src, dst, bad_index);
+        HIP_TRY(hipGetLastError());
+    }
+    {   // one wave per (32-row block, bitmap word) of the largest batch
+        const int waves = ((max_n + TM - 1) / TM) * ((step128(max_n) + 63) / 64);
+        hipLaunchKernelGGL(k_load_finish, dim3((waves + 3) / 4, count), dim3(256), 0, st, batches, reinterpret_cast<unsigned long long *>(stats));
+        HIP_TRY(hipGetLastError());
+    }
+    if (feats) {
+        const float ub = std::ldexp(1.0f, x_bits), ubm1 = ub - 1.0f;
+        {   // cols layout (k_val2bit_cols): a wave per (64-line chunk, 32-row word)
+            const size_t units = static_cast<size_t>((pad128(F) + 63) / 64) * (step128(max_n) * 4);
+            const dim3 g(grid_for(units, 4, 8192), count), b(256);
+            if (x_bits <= 1) hipLaunchKernelGGL(k_load_x_cols<1>, g, b, 0, st, batches, feats, F, x_bits, ub, ubm1);
+            else if (x_bits <= 2) hipLaunchKernelGGL(k_load_x_cols<2>, g, b, 0, st, batches, feats, F, x_bits, ub, ubm1);
+            else if (x_bits <= 4) hipLaunchKernelGGL(k_load_x_cols<4>, g, b, 0, st, batches, feats, F, x_bits, ub, ubm1);
+            else if (x_bits <= 8) hipLaunchKernelGGL(k_load_x_cols<8>, g, b, 0, st, batches, feats, F, x_bits, ub, ubm1);
+            else hipLaunchKernelGGL(k_load_x_cols<32>, g, b, 0, st, batches, feats, F, x_bits, ub, ubm1);
+        }
+        if (formats & QGTC_LOAD_X_ROWS) {   // rows layout (k_val2bit_rows_v4 / k_val2bit_rows): a wave per (row, 256-column chunk)
+            const size_t units = static_cast<size_t>(pad8(max_n)) * ((step128(F) * 4 + 7) / 8);
+            if ((F & 3) == 0 && aligned16(feats))
+                hipLaunchKernelGGL(k_load_x_rows<true>, dim3(grid_for((units + 1) / 2, 4, 8192), count), dim3(256), 0, st, batches, feats, F, x_bits, ub, ubm1);
+            else
+                hipLaunchKernelGGL(k_load_x_rows<false>, dim3(grid_for(units, 4, 8192), count), dim3(256), 0, st, batches, feats, F, x_bits, ub, ubm1);
+        }
+        HIP_TRY(hipGetLastError());
+        if (formats & QGTC_LOAD_X_CHAIN) {   // the chain format of the entries that have an XC (from the cols layout just written)
+            if (x_bits > 4) return QGTC_EINVAL;
+            const int rc = qgtc_launch_cols_to_chain_batched(batches, count, max_n, F, x_bits, st);
+            if (rc != QGTC_OK) return rc;
+        }
     }
     return QGTC_OK;
 }

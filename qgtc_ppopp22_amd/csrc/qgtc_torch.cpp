@@ -13,12 +13,16 @@
 //   * bit2val does not printf the tensor (QGTC_device.cu:169,187,201-202).
 #include <torch/extension.h>
 
+#include <ATen/hip/EmptyTensor.h>
 #include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPFunctions.h>
 #include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/python_variable.h>
 
 #include <array>
 #include <pybind11/stl.h>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <memory>
 #include <mutex>
@@ -709,6 +713,25 @@ struct EpochPlan {
         int codes;       // kinds 3 / 4: index of the pre-expanded weight (weight_codes)
     };
     std::vector<torch::Tensor> weight_codes;   // qgtc_expand_weights outputs, made by bind()
+    std::vector<torch::Tensor> As, Xs, Xrs;    // per-batch views of the packed batches (the loader route: views into pools)
+    std::vector<qgtc_batch> host_batches;      // the per-batch table as uploaded (format_of)
+    EpochPlan() = default;
+
+    // one batch's operand in a loader format, as a flat non-owning tensor (int32 words; the bitmap as int64): for inspection / tests.
+    // which: QGTC_SRC_A / _X / _XR / _XC / _AT, or -1 = the occupancy bitmap. Valid while the plan lives.
+    torch::Tensor format_of(int i, int which) const {
+        TORCH_CHECK(i >= 0 && i < count && static_cast<int>(host_batches.size()) == count, "no such batch");
+        const qgtc_batch &b = host_batches[i];
+        const auto dev = batches.device();
+        if (which < 0) {
+            TORCH_CHECK(b.occ != nullptr, "no occupancy bitmap");
+            return torch::from_blob(const_cast<uint64_t *>(b.occ), {static_cast<int64_t>(qgtc_occupancy_words(b.n, b.n))},
+                                    torch::TensorOptions().dtype(torch::kInt64).device(dev));
+        }
+        const qgtc_operand &o = which == QGTC_SRC_A ? b.A : (which == QGTC_SRC_X ? b.X : (which == QGTC_SRC_XR ? b.XR : (which == QGTC_SRC_XC ? b.XC : b.AT)));
+        TORCH_CHECK(o.ptr != nullptr, "the plan does not hold this format");
+        return torch::from_blob(const_cast<uint32_t *>(o.ptr), {static_cast<int64_t>(o.words)}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
+    }
     std::vector<Launch> launches;
     std::vector<uint64_t> offsets;      // lazily: word offset of every (stage, batch) output in the pool
     static constexpr double kJumpBelow = BatchedGemm::kJumpBelow;
@@ -804,6 +827,126 @@ struct EpochPlan {
         auto host = torch::empty({static_cast<int64_t>(count * sizeof(qgtc_batch))}, torch::TensorOptions().dtype(torch::kUInt8));
         std::memcpy(host.data_ptr(), h.data(), count * sizeof(qgtc_batch));
         batches = host.to(dev);
+        host_batches = h;
+    }
+
+
+    // The data loader's whole job in one call (qgtc_load_batches): `count` cluster batches packed from their concatenated edge
+    // lists (indices local to each batch) and feature rows - adjacency rows layout + tiles + bitmaps, X in the cols layout
+    // (+ rows layout, + chain format) - six launches and three uploads for the iterator instead of eight launches per batch.
+    // What sampler.py:76-106 does per batch; the per-batch tensors (.As / .Xs / .Xrs) are views into the pools.
+    static std::shared_ptr<EpochPlan> load(torch::Tensor src, torch::Tensor dst, std::vector<int64_t> edge_counts, torch::Tensor feats,
+                                           std::vector<int> ns, int x_bits, bool with_rows, int x_chain_bits, bool a_tiles_, bool validate) {
+        CHECK_INPUT(src);
+        CHECK_INPUT(dst);
+        CHECK_INPUT(feats);
+        TORCH_CHECK(src.scalar_type() == torch::kInt64 && dst.scalar_type() == torch::kInt64 && src.dim() == 1 && src.sizes() == dst.sizes(),
+                    "src and dst must be equally long 1-D int64 tensors");
+        TORCH_CHECK(feats.scalar_type() == torch::kFloat32 && feats.dim() == 2 && feats.size(1) > 0, "feats must be a 2-D float32 tensor");
+        TORCH_CHECK(src.device() == feats.device() && dst.device() == feats.device(), "src, dst and feats must share a device");
+        const int count = static_cast<int>(ns.size());
+        TORCH_CHECK(count > 0 && count <= 65535 && static_cast<int>(edge_counts.size()) == count, "1..65535 cluster batches, one edge count each");
+        TORCH_CHECK(x_bits >= 1 && x_bits <= 32 && (x_chain_bits == 0 || (x_chain_bits == x_bits && x_bits <= 4)), "bad bit widths");
+        const int F = static_cast<int>(feats.size(1));
+        const auto dev = feats.device();
+        c10::DeviceGuard guard(dev);
+        auto plan = std::make_shared<EpochPlan>();
+        EpochPlan &P = *plan;
+        P.count = count;
+        P.a_bits = 1;
+        P.x_chain = x_chain_bits > 0;
+        P.a_tiles = a_tiles_;
+        auto r4 = [](int64_t v) { return (v + 3) & ~int64_t(3); };
+        std::vector<int64_t> a_off(count + 1, 0), t_off(count + 1, 0), o_off(count + 1, 0), x_off(count + 1, 0), xr_off(count + 1, 0), xc_off(count + 1, 0),
+            e_off(count + 1, 0), f_off(count + 1, 0);
+        int64_t max_e = 0;
+        for (int i = 0; i < count; i++) {
+            const int n = ns[i];
+            TORCH_CHECK(n > 0 && edge_counts[i] >= 0, "bad node / edge count");
+            a_off[i + 1] = a_off[i] + static_cast<int64_t>(qgtc_rows_words(n, n, 1));
+            t_off[i + 1] = t_off[i] + (a_tiles_ ? static_cast<int64_t>(qgtc_adj_tiles_words(n, n)) : 0);
+            o_off[i + 1] = o_off[i] + static_cast<int64_t>(qgtc_occupancy_words(n, n));
+            x_off[i + 1] = x_off[i] + static_cast<int64_t>(qgtc_cols_words(n, F, x_bits, 0));
+            xr_off[i + 1] = xr_off[i] + (with_rows ? r4(static_cast<int64_t>(qgtc_rows_words(n, F, x_bits))) : 0);
+            xc_off[i + 1] = xc_off[i] + (x_chain_bits ? static_cast<int64_t>(qgtc_chain_words(n, F)) : 0);
+            e_off[i + 1] = e_off[i] + edge_counts[i];
+            f_off[i + 1] = f_off[i] + n;
+            max_e = std::max<int64_t>(max_e, edge_counts[i]);
+            P.max_n = std::max(P.max_n, n);
+            P.nodes.push_back(n);
+        }
+        TORCH_CHECK(e_off[count] == src.numel(), "the edge counts must add up to len(src)");
+        TORCH_CHECK(f_off[count] == feats.size(0), "the node counts must add up to feats.size(0)");
+        TORCH_CHECK(a_off[count] < (1LL << 40), "adjacency pool too large");
+        const auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(dev);
+        // one region for everything the call clears: [A of every batch | stats (two uint64) | scratch of every batch]
+        const int64_t zwords = 3 * a_off[count] + 4;
+        torch::Tensor zero = torch::empty({zwords}, i32);
+        torch::Tensor tiles = torch::empty({std::max<int64_t>(t_off[count], 4)}, i32);
+        torch::Tensor occ = torch::empty({std::max<int64_t>(o_off[count], 1)}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
+        torch::Tensor xp = torch::empty({x_off[count]}, i32), xrp = torch::empty({std::max<int64_t>(xr_off[count], 4)}, i32),
+                      xcp = torch::empty({std::max<int64_t>(xc_off[count], 4)}, i32);
+        torch::Tensor bad;
+        if (validate) bad = torch::empty({1}, i32);
+        uint32_t *zp = words_mut(zero);
+        uint64_t *stats = reinterpret_cast<uint64_t *>(zp + a_off[count]);
+        uint32_t *scratch0 = zp + a_off[count] + 4;
+        std::vector<qgtc_loader_batch> lt(count);
+        std::vector<qgtc_batch> h(count);
+        for (int i = 0; i < count; i++) {
+            const int n = ns[i];
+            qgtc_loader_batch &b = lt[i];
+            b.edge_off = static_cast<uint64_t>(e_off[i]);
+            b.n_edges = static_cast<uint64_t>(edge_counts[i]);
+            b.feat_row = static_cast<uint64_t>(f_off[i]);
+            b.n = n;
+            b.reserved = 0;
+            b.A = zp + a_off[i];
+            b.scratch = scratch0 + 2 * a_off[i];
+            b.AT = a_tiles_ ? words_mut(tiles) + t_off[i] : nullptr;
+            b.occ = reinterpret_cast<uint64_t *>(occ.data_ptr<int64_t>()) + o_off[i];
+            b.X = words_mut(xp) + x_off[i];
+            b.XR = with_rows ? words_mut(xrp) + xr_off[i] : nullptr;
+            b.XC = x_chain_bits ? words_mut(xcp) + xc_off[i] : nullptr;
+            h[i].A = qgtc_operand{b.A, static_cast<uint64_t>(a_off[i + 1] - a_off[i])};
+            h[i].X = qgtc_operand{b.X, static_cast<uint64_t>(x_off[i + 1] - x_off[i])};
+            h[i].XR = with_rows ? qgtc_operand{b.XR, static_cast<uint64_t>(qgtc_rows_words(n, F, x_bits))} : qgtc_operand{nullptr, 0};
+            h[i].XC = x_chain_bits ? qgtc_operand{b.XC, static_cast<uint64_t>(xc_off[i + 1] - xc_off[i])} : qgtc_operand{nullptr, 0};
+            h[i].AT = a_tiles_ ? qgtc_operand{b.AT, static_cast<uint64_t>(t_off[i + 1] - t_off[i])} : qgtc_operand{nullptr, 0};
+            h[i].occ = b.occ;
+            h[i].n = n;
+            h[i].occ_words = (S128(n) + 63) / 64;
+            P.As.push_back(zero.narrow(0, a_off[i], a_off[i + 1] - a_off[i]).view({P8(n), S128(n) * 4}));                                   // QGTC_device.cu:115
+            P.Xs.push_back(xp.narrow(0, x_off[i], x_off[i + 1] - x_off[i]).view({static_cast<int64_t>(x_bits) * S128(n) * 4, P128(F)}));      // QGTC_device.cu:97
+            if (with_rows)
+                P.Xrs.push_back(xrp.narrow(0, xr_off[i], static_cast<int64_t>(qgtc_rows_words(n, F, x_bits))).view({static_cast<int64_t>(x_bits) * P8(n), S128(F) * 4}));
+        }
+        // both tables in ONE upload: [qgtc_loader_batch x count | qgtc_batch x count]
+        const int64_t lt_bytes = static_cast<int64_t>(count * sizeof(qgtc_loader_batch)), bt_bytes = static_cast<int64_t>(count * sizeof(qgtc_batch));
+        static_assert(sizeof(qgtc_loader_batch) % 8 == 0, "the second table starts 8-byte aligned");
+        auto host = torch::empty({lt_bytes + bt_bytes}, torch::TensorOptions().dtype(torch::kUInt8));
+        std::memcpy(host.data_ptr(), lt.data(), lt_bytes);
+        std::memcpy(static_cast<char *>(host.data_ptr()) + lt_bytes, h.data(), bt_bytes);
+        torch::Tensor tables = host.to(dev);
+        P.batches = tables.narrow(0, lt_bytes, bt_bytes);
+        const unsigned formats = (with_rows ? QGTC_LOAD_X_ROWS : 0u) | (x_chain_bits ? QGTC_LOAD_X_CHAIN : 0u);
+        check_rc(qgtc_load_batches(reinterpret_cast<const qgtc_loader_batch *>(tables.data_ptr()), count, P.max_n, static_cast<uint64_t>(max_e),
+                                   src.numel() ? src.data_ptr<int64_t>() : nullptr, src.numel() ? dst.data_ptr<int64_t>() : nullptr,
+                                   feats.data_ptr<float>(), F, x_bits, zp, static_cast<size_t>(zwords) * 4u, stats,
+                                   validate ? bad.data_ptr<int>() : nullptr, formats, current_stream(zero)),
+                 "EpochPlan.load");
+        // the occupied-tile count comes back with the (optional) index check: ONE read-back, beside the packing (outside any epoch clock)
+        torch::Tensor sh = zero.narrow(0, a_off[count], 4).cpu();
+        if (validate) TORCH_CHECK(bad.item<int>() == 0, "edge index out of range");
+        uint64_t set = 0;
+        std::memcpy(&set, sh.data_ptr(), sizeof(set));
+        double all = 0.0;
+        for (int i = 0; i < count; i++) all += static_cast<double>((ns[i] + 31) / 32) * S128(ns[i]);
+        P.occupied = all > 0.0 ? static_cast<double>(set) / all : 1.0;
+        P.jumping = P.occupied <= kJumpBelow;
+        P.keep = {zero, tiles, occ, xp, xrp, xcp, tables, src, dst, feats};
+        P.host_batches = h;
+        return plan;
     }
 
     // stages: (left, right, K, N, bit1, bit2, ob, mode, pad128, use_occ) per operator; launches: (kind, s1, s2, extra flags)
@@ -937,6 +1080,161 @@ struct EpochPlan {
     }
 };
 
+
+// ---------------------------------------------------------------------------------------------
+// The lean call path of the four operators a driver calls per cluster batch (main_qgtc.py:128-154: six calls per batch,
+// 450 per epoch, each a 3 - 4 us kernel - the host side of a call IS the epoch time of an unchanged driver). The pybind11
+// functions above stay the reference for semantics and error messages; these METH_FASTCALL entries take the public names
+// and do the same work without pybind11's argument casters, the ATen dispatcher (at::detail::empty_cuda allocates from
+// the same caching allocator) and the device guard when the operands already live on the current device. Anything that is
+// not the plain good case - keyword arguments, a wrong type, a failed check, another device, an error code - is handed to
+// the pybind11 function, which raises exactly what it always raised. Measured split of a call: DESIGN.md section 6.
+// ---------------------------------------------------------------------------------------------
+namespace lean {
+
+PyObject *slow_val2bit = nullptr, *slow_mm2bit = nullptr, *slow_mm2bit_col = nullptr, *slow_mm2int = nullptr;
+
+inline bool as_int(PyObject *o, int *v) {
+    if (!PyLong_CheckExact(o)) return false;   // (bools, floats, numpy scalars: the pybind11 path decides)
+    int overflow = 0;
+    const long x = PyLong_AsLongAndOverflow(o, &overflow);
+    if (overflow || x < INT32_MIN || x > INT32_MAX) return false;
+    *v = static_cast<int>(x);
+    return true;
+}
+inline bool as_bool(PyObject *o, bool *v) {
+    if (o == Py_True) { *v = true; return true; }
+    if (o == Py_False) { *v = false; return true; }
+    return false;
+}
+// a contiguous device tensor of the given dtype
+inline const at::Tensor *operand(PyObject *o, c10::ScalarType dtype) {
+    if (!THPVariable_Check(o)) return nullptr;
+    const at::Tensor &t = THPVariable_Unpack(o);
+    if (!t.defined() || !t.is_cuda() || t.scalar_type() != dtype || !t.is_contiguous()) return nullptr;
+    return &t;
+}
+// both operands on the CURRENT device (asked only once a device tensor is in hand: without a GPU the query itself throws)
+inline bool on_current(const at::Tensor &a, const at::Tensor *b, c10::DeviceIndex *dev) {
+    *dev = c10::hip::current_device();
+    return a.get_device() == *dev && (!b || b->get_device() == *dev);
+}
+inline at::Tensor fresh(std::array<int64_t, 2> shape, c10::ScalarType dtype, c10::DeviceIndex dev) {
+    return at::Tensor(at::detail::empty_cuda(c10::IntArrayRef(shape.data(), 2), dtype, c10::Device(c10::DeviceType::CUDA, dev), std::nullopt));
+}
+
+// kind 0 bitMM2Bit, 1 bitMM2Bit_col, 2 bitMM2Int
+template <int KIND>
+PyObject *mm(PyObject *, PyObject *const *args, Py_ssize_t nargs, PyObject *kwnames) {
+    PyObject *slow = KIND == 0 ? slow_mm2bit : (KIND == 1 ? slow_mm2bit_col : slow_mm2int);
+    const Py_ssize_t n = PyVectorcall_NARGS(nargs);
+    int M, K, N, b1, b2, ob = 1;
+    bool pad = false;
+    if (kwnames == nullptr && (n == 8 || (KIND == 2 && n == 7)) && as_int(args[2], &M) && as_int(args[3], &K) && as_int(args[4], &N) &&
+        as_int(args[5], &b1) && as_int(args[6], &b2) && (n == 7 || (KIND == 2 ? as_bool(args[7], &pad) : as_int(args[7], &ob))) &&
+        M > 0 && K > 0 && N > 0 && ob >= 1 && ob <= 32) {
+        const at::Tensor *x1 = operand(args[0], at::kInt), *x2 = operand(args[1], at::kInt);
+        if (x1 && x2) {
+            try {
+                c10::DeviceIndex dev;
+                if (!on_current(*x1, x2, &dev)) return PyObject_Vectorcall(slow, args, nargs, kwnames);
+                at::Tensor out = KIND == 2 ? fresh({M, N}, at::kFloat, dev)
+                               : KIND == 1 ? fresh({static_cast<int64_t>(ob) * S128(M) * 4, P128(N)}, at::kInt, dev)    // QGTC_device.cu:456
+                                           : fresh({static_cast<int64_t>(ob) * P8(M), S128(N) * 4}, at::kInt, dev);      // QGTC_device.cu:223
+                void *st = static_cast<void *>(c10::hip::getCurrentHIPStream(dev).stream());
+                int rc;
+                if (KIND == 2)
+                    rc = qgtc_bitmm2int(words(*x1), x1->numel(), words(*x2), x2->numel(), M, K, N, b1, b2, pad, out.data_ptr<float>(),
+                                        out.numel(), mm_flags(), st);
+                else
+                    rc = qgtc_bitmm2bit(words(*x1), x1->numel(), words(*x2), x2->numel(), M, K, N, b1, b2, ob, words_mut(out), out.numel(),
+                                        mm_flags() | (KIND == 1 ? QGTC_OUT_COLS : 0u), st);
+                if (rc == QGTC_OK) return THPVariable_Wrap(std::move(out));
+            } catch (...) {   // (allocation failure: the pybind11 path raises it as the Python exception it is)
+            }
+        }
+    }
+    return PyObject_Vectorcall(slow, args, nargs, kwnames);
+}
+
+PyObject *val2bit_fast(PyObject *, PyObject *const *args, Py_ssize_t nargs, PyObject *kwnames) {
+    const Py_ssize_t n = PyVectorcall_NARGS(nargs);
+    int nbits;
+    bool col = false, outl = false;
+    if (kwnames == nullptr && n >= 2 && n <= 4 && as_int(args[1], &nbits) && (n < 3 || as_bool(args[2], &col)) && (n < 4 || as_bool(args[3], &outl))) {
+        const at::Tensor *x = operand(args[0], at::kFloat);
+        if (x && x->dim() == 2 && nbits >= 1 && nbits <= 32 && x->size(0) > 0 && x->size(1) > 0 && x->size(0) < (1 << 30) && x->size(1) < (1 << 30)) {
+            const int H = static_cast<int>(x->size(0)), W = static_cast<int>(x->size(1));
+            try {
+                c10::DeviceIndex dev;
+                if (!on_current(*x, nullptr, &dev)) return PyObject_Vectorcall(slow_val2bit, args, nargs, kwnames);
+                at::Tensor out = col ? fresh({static_cast<int64_t>(nbits) * S128(H) * 4, outl ? P8(W) : P128(W)}, at::kInt, dev)   // QGTC_device.cu:83,97
+                                     : fresh({static_cast<int64_t>(nbits) * P8(H), S128(W) * 4}, at::kInt, dev);                   // QGTC_device.cu:115
+                const int rc = qgtc_val2bit(x->data_ptr<float>(), H, W, nbits, col, outl, words_mut(out), out.numel(),
+                                            static_cast<void *>(c10::hip::getCurrentHIPStream(dev).stream()));
+                if (rc == QGTC_OK) return THPVariable_Wrap(std::move(out));
+            } catch (...) {
+            }
+        }
+    }
+    return PyObject_Vectorcall(slow_val2bit, args, nargs, kwnames);
+}
+
+#define QGTC_FAST(fn) reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)(void)>(fn))
+PyMethodDef methods[] = {
+    {"val2bit", QGTC_FAST(val2bit_fast), METH_FASTCALL | METH_KEYWORDS,
+     "val2bit(input, nbits, col_major=False, output_layer=False): quantize a [ float32 --> bit ] tensor"},
+    {"bitMM2Bit", QGTC_FAST(mm<0>), METH_FASTCALL | METH_KEYWORDS,
+     "bitMM2Bit(bit_X1, bit_X2, X1_height, X1_width, X2_width, bit1, bit2, output_bit): QGTC [ bit_A x bit_B --> bit_C ] forward"},
+    {"bitMM2Bit_col", QGTC_FAST(mm<1>), METH_FASTCALL | METH_KEYWORDS,
+     "bitMM2Bit_col(bit_X1, bit_X2, X1_height, X1_width, X2_width, bit1, bit2, output_bit): QGTC [ bit_A x bit_B --> bit_C (column major) ] forward"},
+    {"bitMM2Int", QGTC_FAST(mm<2>), METH_FASTCALL | METH_KEYWORDS,
+     "bitMM2Int(bit_X1, bit_X2, X1_height, X1_width, X2_width, bit1, bit2, pad_128=False): QGTC [ bit_A x bit_B --> float32 ] forward"},
+    {nullptr, nullptr, 0, nullptr}};
+#undef QGTC_FAST
+
+}  // namespace lean
+
+
+// Diagnostic (tools/call_cost.py): host microseconds of the pieces of one bitMM2Bit call, each timed over
+// `reps` repetitions with the GPU drained before and after (so that a full queue never blocks the host inside the timing).
+std::vector<double> host_parts(torch::Tensor bit_X1, torch::Tensor bit_X2, int M, int K, int N, int bit1, int bit2, int ob, int reps) {
+    CHECK_INPUT(bit_X1);
+    CHECK_INPUT(bit_X2);
+    TORCH_CHECK(reps > 0, "reps must be positive");
+    c10::DeviceGuard guard(bit_X1.device());
+    const auto dev = bit_X1.get_device();
+    const auto opts = torch::TensorOptions().dtype(torch::kInt32).device(bit_X1.device());
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(now() - a).count() / reps; };
+    std::vector<double> r;
+    TORCH_CHECK(hipDeviceSynchronize() == hipSuccess, "sync failed");
+    auto t = now();
+    for (int i = 0; i < reps; i++) { auto o = torch::empty({static_cast<int64_t>(ob) * P8(M), S128(N) * 4}, opts); (void)o; }
+    r.push_back(us(t));                                   // 0: torch::empty through the dispatcher
+    t = now();
+    for (int i = 0; i < reps; i++) { auto o = lean::fresh({static_cast<int64_t>(ob) * P8(M), S128(N) * 4}, at::kInt, dev); (void)o; }
+    r.push_back(us(t));                                   // 1: at::detail::empty_cuda
+    t = now();
+    for (int i = 0; i < reps; i++) { c10::DeviceGuard g(bit_X1.device()); void *st = current_stream(bit_X1); (void)st; }
+    r.push_back(us(t));                                   // 2: device guard + current stream
+    auto out = torch::empty({static_cast<int64_t>(ob) * P8(M), S128(N) * 4}, opts);
+    void *st = current_stream(bit_X1);
+    check_rc(qgtc_bitmm2bit(words(bit_X1), bit_X1.numel(), words(bit_X2), bit_X2.numel(), M, K, N, bit1, bit2, ob, words_mut(out), out.numel(), mm_flags(), st), "host_parts");
+    TORCH_CHECK(hipDeviceSynchronize() == hipSuccess, "sync failed");
+    // 3: the C-ABI call (argument checks, kernel choice, hipLaunchKernel) in bursts of 16 with a drain between bursts
+    double launch = 0.0;
+    for (int i = 0; i < reps; i += 16) {
+        auto t0 = now();
+        for (int j = 0; j < 16; j++)
+            (void)qgtc_bitmm2bit(words(bit_X1), bit_X1.numel(), words(bit_X2), bit_X2.numel(), M, K, N, bit1, bit2, ob, words_mut(out), out.numel(), mm_flags(), st);
+        launch += std::chrono::duration<double, std::micro>(now() - t0).count();
+        TORCH_CHECK(hipDeviceSynchronize() == hipSuccess, "sync failed");
+    }
+    r.push_back(launch / (((reps + 15) / 16) * 16));
+    return r;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -964,6 +1262,18 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("bitMM2Int", &bitMM2Int, "QGTC [ bit_A x bit_B --> float32 ] forward", py::arg("bit_X1"),
           py::arg("bit_X2"), py::arg("X1_height"), py::arg("X1_width"), py::arg("X2_width"),
           py::arg("bit1"), py::arg("bit2"), py::arg("pad_128") = false);
+
+    // The four per-batch operators get the lean call path (namespace lean above); the pybind11 functions stay reachable as
+    // the checked path every irregular call falls back to.
+    lean::slow_val2bit = py::object(m.attr("val2bit")).release().ptr();
+    lean::slow_mm2bit = py::object(m.attr("bitMM2Bit")).release().ptr();
+    lean::slow_mm2bit_col = py::object(m.attr("bitMM2Bit_col")).release().ptr();
+    lean::slow_mm2int = py::object(m.attr("bitMM2Int")).release().ptr();
+    m.attr("checked_val2bit") = m.attr("val2bit");
+    m.attr("checked_bitMM2Bit") = m.attr("bitMM2Bit");
+    m.attr("checked_bitMM2Bit_col") = m.attr("bitMM2Bit_col");
+    m.attr("checked_bitMM2Int") = m.attr("bitMM2Int");
+    TORCH_CHECK(PyModule_AddFunctions(m.ptr(), lean::methods) == 0, "could not register the lean entry points");
 
     // Names BASELINE.json's north_star uses for the same operators (aliases; see SURVEY.md note).
     m.attr("bit_qnt") = m.attr("val2bit");
@@ -1008,6 +1318,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("get_engine", [] { return std::string(g_engine == 1 ? "mfma" : (g_engine == 2 ? "auto" : "popcount")); });
     m.def("get_zero_skip", [] { return g_zero_skip.load(); });
     m.def("abi_version", [] { return qgtc_abi_version(); });
+    m.def("host_parts", &host_parts, "diagnostic: host us of [torch::empty, at::detail::empty_cuda, guard + stream, C-ABI launch] per call");
 
     m.def("pack_edges", &pack_edges, "rows-layout bit planes of the [height, width] adjacency of an edge list "
           "(= val2bit of the dense matrix, without materialising it)", py::arg("src"), py::arg("dst"),
@@ -1033,6 +1344,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def(py::init<std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<torch::Tensor>, std::vector<int>, int, bool, int, int, bool>(),
              py::arg("As"), py::arg("Xs"), py::arg("Xrs"), py::arg("nodes"), py::arg("a_bits") = 1, py::arg("zero_jump") = true,
              py::arg("x_chain_bits") = 0, py::arg("x_cols") = 0, py::arg("a_tiles") = false)
+        .def_static("load", &EpochPlan::load, py::arg("src"), py::arg("dst"), py::arg("edge_counts"), py::arg("feats"), py::arg("nodes"), py::arg("x_bits"),
+                    py::arg("with_rows") = false, py::arg("x_chain_bits") = 0, py::arg("a_tiles") = false, py::arg("validate") = false,
+                    "pack `len(nodes)` cluster batches from their concatenated edge lists (indices local to each batch) and feature rows in a "
+                    "handful of launches (qgtc_load_batches); .As / .Xs / .Xrs are the per-batch packed tensors (views into pools)")
+        .def("format_of", &EpochPlan::format_of, py::arg("batch"), py::arg("which"),
+             "one batch's operand in a loader format (SRC_A / SRC_X / SRC_XR / SRC_XC / SRC_AT, -1 = occupancy bitmap) as a flat non-owning tensor")
+        .def_readonly("As", &EpochPlan::As)
+        .def_readonly("Xs", &EpochPlan::Xs)
+        .def_readonly("Xrs", &EpochPlan::Xrs)
         .def("bind", &EpochPlan::bind, py::arg("weights"), py::arg("stages"), py::arg("launches"), py::arg("expand") = std::vector<std::array<int, 5>>(),
              "weights: packed tensors; stages: (left, right, K, N, bit1, bit2, ob, mode, pad128, use_occ, fmt); launches: (kind, s1, s2, flags, "
              "codes); expand: (weight, K, N, nbits, order) per pre-expanded weight")

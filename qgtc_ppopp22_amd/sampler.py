@@ -5,9 +5,10 @@ driver), `psize // batch_size` batches are built from `batch_size` consecutive p
 batch's dense float adjacency (row = src, col = dst, value = edge multiplicity) and features are
 packed ONCE with `QGTC.val2bit(A, 1, False, False)` and `QGTC.val2bit(X, bit_width, True, False)`,
 and the logical sizes `(A0, A1, X0, X1)` travel with the packed tensors.
-By default the adjacency planes are built straight from the batch's edge list
-(`QGTC.pack_edges`, word-for-word the same result); `dense_adjacency=True` takes the reference's
-dense float detour.
+By default ALL batches are packed by one library call straight from their edge lists
+(`QGTC.EpochPlan.load` -> `qgtc_load_batches`: six launches for the iterator, word-for-word the same tensors);
+`grouped=False` packs batch by batch (`QGTC.pack_edges` + `QGTC.val2bit`), `dense_adjacency=True` takes the
+reference's dense float detour.
 
 What is MI355X-first: packed batches stay resident in HBM by default (a 1213-node 2-bit batch is
 230 KiB; all 75 batches of an ogbn-arxiv-sized graph are 17 MiB of 288 GB) instead of being parked
@@ -33,6 +34,8 @@ class ClusterTensor:
         self.bit_X_rows = bit_X_rows  # rows-layout copy of X for the layout-correct chain
 
     def to(self, device, non_blocking: bool = False):
+        if self.bit_A.device == torch.device(device):      # resident batches: main_qgtc.py:115's `.cuda()` is a no-op
+            return self
         return ClusterTensor(self.bit_A.to(device, non_blocking=non_blocking),
                              self.bit_X.to(device, non_blocking=non_blocking),
                              None if self.bit_X_rows is None else self.bit_X_rows.to(device, non_blocking=non_blocking))
@@ -48,7 +51,7 @@ class ClusterIter:
     def __init__(self, dn, g: G.Graph, psize: int, batch_size: int, bit_width: int = 2,
                  run_GIN: bool = False, device="cuda", resident: bool = True, qgtc=None,
                  batch_ids=None, with_rows_X: bool = False, dense_adjacency: bool = False,
-                 keep_raw: bool = False):
+                 keep_raw: bool = False, grouped: bool = True):
         if qgtc is None:
             import QGTC as qgtc  # the HIP extension; there is no fallback
         self.g = g
@@ -67,6 +70,18 @@ class ClusterIter:
         # keep_raw: the unpacked batch (edge list, float features) for drivers that pack inside the epoch
         # loop as cluster_gcn.py:151-227 does
         self.raw_li = []
+        self._epoch_data = None
+        self.x_in_chain_format = False
+        feat = g.feat.shape[1]
+        # X also in the chain format of the chain entries when an epoch's first product is A . X (Batched-GIN) and the
+        # widths are the ones those entries cover (4 bits, at most 64 features); the adjacencies also as 512-byte tiles for
+        # the aggregation launches of those entries (2-bit Cluster-GCN, 4-bit Batched-GIN)
+        self._x_chain = bit_width if (run_GIN and bit_width == 4 and feat <= 64) else 0
+        self._a_tiles = self._x_chain > 0 or (not run_GIN and bit_width == 2)
+        self._with_rows = with_rows_X
+        if grouped and not dense_adjacency and self.batch_ids:
+            self._pack_grouped(qgtc, keep_raw)
+            return
         for cid in self.batch_ids:
             nodes = G.batch_nodes(self.par_li, cid, psize, batch_size)
             row, col = G.induced_edges(g, nodes)
@@ -96,25 +111,67 @@ class ClusterIter:
             if keep_raw:
                 self.raw_li.append((r_dev, c_dev, X) if resident else (r_dev.cpu(), c_dev.cpu(), X.cpu()))
 
+    def _pack_grouped(self, qgtc, keep_raw):
+        """Every batch of the iterator packed by ONE library call (QGTC.EpochPlan.load -> qgtc_load_batches): the batches' edge
+        lists (indices local to each batch) and feature rows are concatenated on the host, uploaded once, and a handful of
+        grouped launches write what sampler.py:76-106 builds per batch - plus, from the same registers, the formats the grouped
+        epoch reads (adjacency tiles, occupancy bitmaps, rows-layout / chain-format X). The per-batch tensors are views."""
+        g = self.g
+        rows, cols, feats, ns, ecounts = [], [], [], [], []
+        for cid in self.batch_ids:
+            nodes = G.batch_nodes(self.par_li, cid, self.psize, self.batch_size)
+            row, col = G.induced_edges(g, nodes)
+            rows.append(np.asarray(row, dtype=np.int64))
+            cols.append(np.asarray(col, dtype=np.int64))
+            feats.append(g.feat[nodes])
+            ns.append(int(nodes.size))
+            ecounts.append(int(row.size))
+        src = torch.from_numpy(np.concatenate(rows)).to(self.device)
+        dst = torch.from_numpy(np.concatenate(cols)).to(self.device)
+        X = torch.from_numpy(np.ascontiguousarray(np.concatenate(feats), dtype=np.float32)).to(self.device)
+        self.raw_src, self.raw_dst, self.raw_feats, self.raw_nodes, self.raw_edge_counts = src, dst, X, ns, ecounts
+        data = self.pack_now(qgtc)
+        F = X.size(1)
+        e0 = f0 = 0
+        for i, n in enumerate(ns):
+            ct = ClusterTensor(data.As[i], data.Xs[i], data.Xrs[i] if self._with_rows else None)
+            if not self.resident:
+                ct = ct.cpu()                                    # sampler.py:104
+            self.cTensor_li.append(ct)
+            self.cluster_param_li.append((n, n, n, F))           # sampler.py:92-95,105
+            self.n_edges.append(ecounts[i])
+            if keep_raw:
+                raw = (src[e0:e0 + ecounts[i]], dst[e0:e0 + ecounts[i]], X[f0:f0 + n])
+                self.raw_li.append(raw if self.resident else tuple(t.cpu() for t in raw))
+            e0 += ecounts[i]
+            f0 += n
+        if self.resident:
+            self._epoch_data = data
+            self.x_in_chain_format = self._x_chain > 0
+
+    def pack_now(self, qgtc=None):
+        """Pack every batch again from the resident raw arrays (one EpochPlan.load call): what a driver that packs INSIDE its
+        epoch loop (cluster_gcn.py:151-227) pays per epoch in the grouped form. Returns the new EpochPlan."""
+        if qgtc is None:
+            import QGTC as qgtc
+        return qgtc.EpochPlan.load(self.raw_src, self.raw_dst, self.raw_edge_counts, self.raw_feats, self.raw_nodes, self.bit_width,
+                                   self._with_rows, self._x_chain, self._a_tiles, False)
+
     def epoch_data(self, qgtc=None):
         """The data loader's share of a GROUPED epoch, made once beside the packing (outside the epoch clock, like the
         packing itself: main_qgtc.py:74-93): the per-batch table on the device and the adjacencies' occupancy bitmaps
-        (Q.EpochPlan). The epoch then binds weights and outputs to it with one launch (driver.PlannedEpoch)."""
+        (Q.EpochPlan). The epoch then binds weights and outputs to it with one launch (driver.PlannedEpoch). The grouped
+        loader (the default) has made it already; the per-batch routes build it here from their tensors."""
         if getattr(self, "_epoch_data", None) is None:
             if qgtc is None:
                 import QGTC as qgtc
             assert self.resident, "a grouped epoch needs the packed batches on the device"
             cts = self.cTensor_li
             rows = [c.bit_X_rows for c in cts] if cts and cts[0].bit_X_rows is not None else []
-            # X also in the chain format of the chain entries when an epoch's first product is A . X (Batched-GIN) and the
-            # widths are the ones those entries cover (4 bits, at most 64 features)
             feat = self.cluster_param_li[0][3] if self.cluster_param_li else 0
-            x_chain = self.bit_width if (self.run_GIN and self.bit_width == 4 and feat <= 64) else 0
-            # the adjacencies also as 512-byte tiles for the aggregation launches of those entries (2-bit Cluster-GCN, 4-bit Batched-GIN)
-            a_tiles = x_chain > 0 or (not self.run_GIN and self.bit_width == 2)
             self._epoch_data = qgtc.EpochPlan([c.bit_A for c in cts], [c.bit_X for c in cts], rows, [p[0] for p in self.cluster_param_li], 1, True,
-                                              x_chain, feat, a_tiles)
-            self.x_in_chain_format = x_chain > 0
+                                              self._x_chain, feat, self._a_tiles)
+            self.x_in_chain_format = self._x_chain > 0
         return self._epoch_data
 
     def __len__(self):

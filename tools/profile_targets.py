@@ -1,6 +1,6 @@
 """One kernel family per invocation, for rocprofv3 (tools/collect_profiles.sh):
 
-    python3 tools/profile_targets.py headline|popcount|w8|epoch|epoch_gin|pack|wide1|wide8k|wide2|wide4 [reps]
+    python3 tools/profile_targets.py headline|popcount|w8|epoch|epoch_gin|loader|loader_gin|pack|wide1|wide8k|wide2|wide4 [reps]
 
 Runs the named workload `reps` times after a warm-up and prints one JSON line with the HIP-event time per launch
 (events recorded on the launch stream), so that the trace's per-kernel averages can be put beside it."""
@@ -57,6 +57,39 @@ def epoch_target(gin, reps):
             "us_per_epoch_hip_events": round(us, 2), "us_per_launch_alone_hip_events": launches, "epochs": (1 + plan.n_launches) * (reps + 1)}
 
 
+def loader_target(gin, reps):
+    """The data loader's packing of the whole iterator (ClusterIter's default: one QGTC.EpochPlan.load call = qgtc_load_batches),
+    re-run from the resident raw arrays; beside it the batch-by-batch route (QGTC.pack_edges + QGTC.val2bit x 2 per batch + the epoch
+    formats) once."""
+    import time
+    from qgtc_ppopp22_amd import driver, graph as G
+    dataset, b, hidden = ("ppi", 4, 64) if gin else ("ogbn-arxiv", 2, 128)
+    graph = G.make_graph(dataset, 1500)
+    args = driver.build_parser().parse_args(["--dataset", dataset, "--n-hidden", str(hidden), "--bit_width", str(b), "--use_QGTC", "--quiet", "--batched",
+                                             "--chain", "correct"] + (["--run_GIN"] if gin else []))
+    it = driver.make_iter(args, Q, graph)
+    us = events(lambda: it.pack_now(Q), reps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        it.pack_now(Q)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps * 1e6
+    import random
+    random.seed(2)
+    from qgtc_ppopp22_amd.sampler import ClusterIter
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    old = ClusterIter(dataset, graph, 1500, 20, bit_width=b, run_GIN=gin, device="cuda", qgtc=Q, with_rows_X=True, grouped=False)
+    old.epoch_data(Q)
+    torch.cuda.synchronize()
+    old_ms = (time.perf_counter() - t0) * 1e3
+    edges, nodes = sum(it.n_edges), sum(p[0] for p in it.cluster_param_li)
+    return {"workload": f"{dataset}-sized iterator: 75 cluster batches, {nodes} nodes, {edges} edges, {graph.feat.shape[1]} features, {b}-bit",
+            "us_per_iterator_pack_hip_events": round(us, 1), "us_per_iterator_pack_wall_incl_host": round(wall, 1),
+            "batch_by_batch_route_wall_ms_incl_host_graph_slicing": round(old_ms, 2), "packs": 2 * reps + 1}
+
+
 def pack_target(reps):
     x = torch.rand((4096, 4096), device="cuda")
     us_r = events(lambda: Q.val2bit(x, 1, False, False), reps)
@@ -69,7 +102,9 @@ def pack_target(reps):
 def main():
     t = sys.argv[1]
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-    if t == "headline":
+    if t in ("loader", "loader_gin"):
+        r = loader_target(t == "loader_gin", reps)
+    elif t == "headline":
         r = gemm_target(4096, 4096, 64, 1, reps)
     elif t == "popcount":   # the AND + v_bcnt engine BASELINE.json's north star names, same workload
         r = gemm_target(4096, 4096, 64, 1, reps, engine="popcount")
