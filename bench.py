@@ -59,6 +59,9 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget")
     p.add_argument("--backend", choices=["nccl", "gloo"], default=None, help="torch.distributed backend (default: nccl = RCCL)")
     p.add_argument("--dry-run", action="store_true", help="exercise the rank launcher and the collectives only (no GPU)")
+    p.add_argument("--gather", choices=["summaries", "outputs"], default="summaries",
+                   help="what the end-of-epoch exchange of the sharded epoch legs moves over RCCL: per-batch (sum, numel) pairs, "
+                        "or the per-batch float32 outputs themselves padded to the largest batch (SURVEY.md 8e)")
     p.add_argument("--engine", choices=["popcount", "mfma", "auto"], default="auto",
                    help="engine of the headline launches (same words either way): popcount = AND + v_bcnt kernels, "
                         "auto = the library's choice per call (at this shape the FP4 matrix-core kernel for narrow "
@@ -80,10 +83,11 @@ def engine(Q, name):
         Q.set_engine(prev)
 
 
-def best_of_3(Q, ba, bx, M, K, N, w, reps=200):
-    """The reference's measurement (QGTC_device.cu:403-422): `reps` launches between two events; best of three."""
+def median_of_5(Q, ba, bx, M, K, N, w, reps=200):
+    """The reference's measurement (QGTC_device.cu:403-422): `reps` launches between two events; the median of five such
+    windows after an untimed one (200 reps per point, median of >= 5 runs)."""
     Q.profile(ba, bx, M, K, N, 1, w, w, max(reps // 10, 1))
-    return min(Q.profile(ba, bx, M, K, N, 1, w, w, reps) for _ in range(3))
+    return sorted(Q.profile(ba, bx, M, K, N, 1, w, w, reps) for _ in range(5))[2]
 
 
 def make_workload(Q, M, K, N, w, device, seed, ones=False):
@@ -157,8 +161,9 @@ def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams
 
 
 def cpu_baseline(M, K, N, w, A, X, budget_s):
-    """The C oracle (a port, not the reference: the reference has no CPU bit path) on the host
-    cores, same workload, repeated until ~budget_s of CPU time."""
+    """The C oracle (a port, not the reference: the reference has no CPU bit path) on the host cores, same workload. The
+    thread count is the one that gives the best rate in a short probe (a 2 MB problem thrashes on 128 threads: r03's figure
+    swung 2.7x between runs); the value is the MEDIAN of three timed blocks that share ~budget_s of CPU time."""
     from oracle.qgtc_oracle import Oracle
 
     try:
@@ -167,19 +172,53 @@ def cpu_baseline(M, K, N, w, A, X, budget_s):
         O = Oracle()
     bx = O.val2bit(A.numpy(), 1, False, False)
     bw = O.val2bit(X.numpy(), w, True, False)
-    O.bitmm2bit(bx, bw, M, K, N, 1, w, w)          # first call: thread pool start-up
-    t0 = time.perf_counter()
-    for _ in range(5):
-        O.bitmm2bit(bx, bw, M, K, N, 1, w, w)
-    one = (time.perf_counter() - t0) / 5
-    reps = max(1, min(1000, int(budget_s / max(one, 1e-6))))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        ref = O.bitmm2bit(bx, bw, M, K, N, 1, w, w)
-    dt = time.perf_counter() - t0
-    return {"value": round(2.0 * M * K * N * reps / dt / 1e12, 4), "unit": "effective TOPS",
-            "cores": O.num_threads(), "kind": "port",
-            "sample": f"full {M}x{K}x{N} {w}-bit workload x {reps} reps ({dt:.1f} s, OpenMP C oracle)"}, ref
+    cores = os.cpu_count() or 1
+    probe = {}
+    for t in sorted({c for c in (4, 8, 16, 32, 64, cores) if c <= cores}):
+        O.set_num_threads(t)
+        O.bitmm2bit(bx, bw, M, K, N, 1, w, w)          # first call on this team: thread start-up
+        t0 = time.perf_counter()
+        for _ in range(3):
+            O.bitmm2bit(bx, bw, M, K, N, 1, w, w)
+        probe[t] = (time.perf_counter() - t0) / 3
+    threads = min(probe, key=probe.get)
+    O.set_num_threads(threads)
+    one = probe[threads]
+    reps = max(1, min(400, int(budget_s / 3 / max(one, 1e-6))))
+    rates, total = [], 0.0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ref = O.bitmm2bit(bx, bw, M, K, N, 1, w, w)
+        dt = time.perf_counter() - t0
+        total += dt
+        rates.append(2.0 * M * K * N * reps / dt / 1e12)
+    return {"value": round(sorted(rates)[1], 4), "unit": "effective TOPS", "cores": threads, "kind": "port",
+            "sample": f"full {M}x{K}x{N} {w}-bit workload, 3 blocks x {reps} reps ({total:.1f} s), median; OpenMP C oracle on {threads} of {cores} host "
+                      f"threads (best of a probe over {sorted(probe)})",
+            "blocks_TOPS": [round(r, 4) for r in rates]}, ref
+
+
+PROFILE_DIR = "profiles/r04"
+
+
+def profile_summary(name):
+    """The committed rocprofv3 summary of a target (tools/collect_profiles.sh) - only when it was collected from THESE kernel
+    sources: the summary records the hash of csrc/ + include/qgtc.h it ran (qgtc_ppopp22_amd/_build.py::kernel_source_hash).
+    Returns (summary or None, a string that says where the counter figures come from or why there are none)."""
+    from qgtc_ppopp22_amd._build import kernel_source_hash
+
+    rel = f"{PROFILE_DIR}/summary_{name}.json"
+    here = kernel_source_hash()
+    try:
+        with open(os.path.join(ROOT, rel)) as f:
+            summ = json.load(f)
+    except (OSError, ValueError):
+        return None, f"none: {rel} absent"
+    got = summ.get("kernel_source_hash")
+    if got != here:
+        return None, f"none: {rel} was collected from kernel sources {got}, this tree is {here}"
+    return summ, f"{rel} (rocprofv3 --pmc passes, kernel sources {here})"
 
 
 def batch_summaries(outs):
@@ -188,21 +227,34 @@ def batch_summaries(outs):
                         for o in outs])
 
 
+def keep_clock_up(plan_run):
+    """The chip drops into a low power state within milliseconds of idling (time_steps has the numbers): CLOCK_WARMUP_S of
+    untimed grouped epochs ahead of a measured run."""
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < CLOCK_WARMUP_S:
+        for _ in range(20):
+            plan_run()
+        torch.cuda.synchronize()
+
+
 def epoch_leg(Q, rank, world, device_index, dataset="ogbn-arxiv", bits=2, hidden=128, gin=False, full=True, psize=1500,
-              batch_size=20, only=None):
-    """Epoch time (BASELINE.json configs 3/4/5): a synthetic graph of the dataset's size, 75 batches,
-    sharded round-robin over the ranks. Per-batch launches (the reference's structure: six extension
-    calls per batch), the same with the packed batches parked on the CPU and uploaded every iteration
-    (what main_qgtc.py:115 does), the same captured in a hipGraph, and grouped launches (one launch
-    per operator per epoch) of the reference's literal chain and of the layout-correct chain."""
+              batch_size=20, only=None, weak=False, gather="summaries"):
+    """Epoch time (BASELINE.json configs 3/4/5): a synthetic graph of the dataset's size, 75 batches. Legs: per-batch launches
+    (the reference's structure: six extension calls per batch), the same with the packed batches parked on the CPU and
+    uploaded every iteration (main_qgtc.py:115), the same captured in a hipGraph, cluster_gcn.py's pack-inside-the-loop
+    structure per batch and grouped, and grouped launches (one launch per operator per epoch) of the reference's literal chain
+    and of the layout-correct chain. EVERY leg: one iterator built ahead of the clock (main_qgtc.py:74-93), one untimed run,
+    the clock kept up, then five runs whose median is reported (min / max beside it).
+    Sharding (world > 1): `weak` False = the 75 batches round-robin over the ranks (strong scaling, BASELINE.json config 5);
+    `weak` True = every rank runs all 75 batches of ITS OWN graph of that size (seed + rank): per-GPU work fixed."""
     from qgtc_ppopp22_amd import dist as D, driver, graph as G
 
     base = ["--dataset", dataset, "--n-hidden", str(hidden), "--n-classes", "10", "--bit_width", str(bits),
             "--use_QGTC", "--gpu", str(device_index), "--quiet", "--n-epochs", "20"] + (["--run_GIN"] if gin else [])
     base += ["--psize", str(psize), "--batch-size", str(batch_size)]
     n_batches = psize // batch_size
-    graph = G.make_graph(dataset, psize)
-    ids = D.shard_round_robin(n_batches, rank, world)
+    graph = G.make_graph(dataset, psize, seed=2 + (rank if weak else 0))
+    ids = list(range(n_batches)) if weak else D.shard_round_robin(n_batches, rank, world)
     res = {}
     legs = [("per_batch_reference_chain", []), ("batched_reference_chain", ["--batched"]),
             ("batched_correct_chain", ["--batched", "--chain", "correct"]),
@@ -211,55 +263,57 @@ def epoch_leg(Q, rank, world, device_index, dataset="ogbn-arxiv", bits=2, hidden
         legs[1:1] = [("per_batch_nonresident_reference_chain", ["--non-resident"]),
                      ("per_batch_graph_reference_chain", ["--graph"]),
                      ("per_batch_2_streams_reference_chain", ["--streams", "2"]),
-                     ("per_batch_pack_on_the_fly_reference_chain", ["--pack-on-the-fly"])]   # cluster_gcn.py's structure
+                     ("per_batch_pack_on_the_fly_reference_chain", ["--pack-on-the-fly"]),   # cluster_gcn.py's structure
+                     ("batched_pack_on_the_fly_correct_chain", ["--batched", "--chain", "correct", "--pack-on-the-fly"])]
     if only is not None:
         legs = [l for l in legs if l[0] in only]
+    dev = torch.device("cuda", device_index)
+    r = None
     for name, extra in legs:
         args = driver.build_parser().parse_args(base + extra)
-        it = None
-        if driver.uses_planned_epoch(args):
-            # Grouped epochs are GPU-bound (a 20-epoch run is ~0.6 ms of kernels), so the chip's clock state decides the
-            # figure: the iterator is built ONCE, ahead of the clock as in main_qgtc.py:74-93, and the chip is kept busy
-            # between the warm-up run and the measured one (time_steps does the same for the headline)
-            it = driver.make_iter(args, Q, graph, ids)
-        r0 = driver.run(args, Q=Q, batch_ids=ids, graph=graph, it=it)          # warm-up (allocator, attributes)
-        if it is not None and "plan" in r0:
-            t_w = time.perf_counter()
-            while time.perf_counter() - t_w < CLOCK_WARMUP_S:
-                for _ in range(20):
-                    r0["plan"].run()
-                torch.cuda.synchronize()
+        it = driver.make_iter(args, Q, graph, ids)                              # ahead of the clock, once per leg
+        r0 = driver.run(args, Q=Q, batch_ids=ids, graph=graph, it=it)          # untimed run (allocator, kernel attributes)
+        if "plan" in r0:
+            keep_clock_up(r0["plan"].run)
         D.barrier()
-        r = driver.run(args, Q=Q, batch_ids=ids, graph=graph, it=it)
-        ms = [r["avg_epoch_ms"]]
-        if it is not None:
-            # a 20-epoch grouped run is < 1 ms of wall clock, of which 25 - 200 us is the host packing the weights and binding
-            # the plan (inside the clock, main_qgtc.py:96) with whatever jitter the host has at that moment: five runs, each
-            # with its own weights and plan, median reported (min and max beside it)
-            for _ in range(4):
-                r = driver.run(args, Q=Q, batch_ids=ids, graph=graph, it=it)
-                ms.append(r["avg_epoch_ms"])
-            res[name + "_ms_min_max_of_5"] = [round(min(ms), 4), round(max(ms), 4)]
-        res[name + "_ms"] = round(D.max_over_ranks(sorted(ms)[len(ms) // 2], torch.device("cuda", device_index)), 4)
-    if world > 1:   # the one exchange of the path: gather per-batch checksums (RCCL over xGMI)
-        allsum = D.gather_batch_summaries(batch_summaries(r["outs"]), n_batches, rank, world)
-        res["gathered_batches"] = int(allsum.size(0))
-        res["gathered_summaries"] = allsum.cpu().tolist()       # (sum, numel) per batch in global batch order, on every rank
+        ms = []
+        for _ in range(5):
+            r = driver.run(args, Q=Q, batch_ids=ids, graph=graph, it=it)
+            ms.append(r["avg_epoch_ms"])
+        res[name + "_ms_min_max_of_5"] = [round(min(ms), 4), round(max(ms), 4)]
+        res[name + "_ms"] = round(D.max_over_ranks(sorted(ms)[2], dev), 4)
+    if world > 1 and r is not None:   # the one exchange of the path (RCCL over xGMI), outside every epoch clock
+        total = n_batches * world if weak else n_batches
+        if gather == "outputs":       # the per-batch float outputs themselves, padded to the largest batch
+            t0 = time.perf_counter()
+            allout, nodes = D.gather_batch_outputs(r["outs"], n_batches, rank, world, replicas=weak)
+            torch.cuda.synchronize()
+            res["gather_outputs_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+            res["gathered_batches"] = int(allout.size(0))
+            res["gathered_output_bytes"] = int(allout.numel() * allout.element_size())
+            res["gathered_summaries"] = [[float(allout[i, :int(nodes[i])].double().sum().item()), float(int(nodes[i]) * allout.size(2))]
+                                         for i in range(allout.size(0))]
+        else:
+            allsum = D.gather_batch_summaries(batch_summaries(r["outs"]), total, rank, world) if not weak else \
+                D.gather_replica_summaries(batch_summaries(r["outs"]), world)
+            res["gathered_batches"] = int(allsum.size(0))
+            res["gathered_summaries"] = allsum.cpu().tolist()       # (sum, numel) per batch in global batch order, on every rank
     return res, graph
 
 
 def epoch_roofline(Q, graph, device_index, dataset, bits, hidden, gin):
-    """The second BASELINE metric against ITS floors: the grouped, layout-correct epoch (six grouped launches, the
-    default engine) timed with HIP events around the launches only - plan building and weight packing, which
-    main_qgtc.py:96 puts inside its epoch clock, are timed separately on the host. Algorithmic work is summed over
-    the six operators and 75 batches from the logical shapes: bytes = a M K / 8 + w K N / 8 + output,
-    FP4 MFMA ops = 2 M K N x (base-4 digit pairs)."""
+    """The second BASELINE metric against ITS floors: the grouped, layout-correct epoch (the default engine) timed with HIP
+    events around the launches only - plan building and weight packing, which main_qgtc.py:96 puts inside its epoch clock,
+    and the data loader's one-off packing of the iterator are timed separately. Algorithmic work is summed over the six
+    operators and 75 batches from the logical shapes: bytes = a M K / 8 + w K N / 8 + output, FP4 MFMA ops =
+    2 M K N x (base-4 digit pairs). `frac` divides the DENSE algorithmic bytes; `frac_on_traffic` divides what the counters say
+    was moved (zero-tile jumping skips most of A) - both over the same kernel time."""
     from qgtc_ppopp22_amd import driver
     from qgtc_ppopp22_amd.sampler import ClusterIter
 
     dev = torch.device("cuda", device_index)
     it = ClusterIter(dataset, graph, 1500, 20, bit_width=bits, run_GIN=gin, device=dev, qgtc=Q, with_rows_X=True)
-    data = it.epoch_data(Q)            # the data loader's share (per-batch table, adjacency bitmaps), ahead of the clock
+    data = it.epoch_data(Q)            # the data loader's share (one grouped pack of the iterator), ahead of the clock
     torch.cuda.synchronize()
 
     def ev(fn, reps=100):   # (a 20-epoch window is 0.6 ms, of which the queue's start-up is 5 - 10 %)
@@ -274,6 +328,13 @@ def epoch_roofline(Q, graph, device_index, dataset, bits, hidden, gin):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / reps
 
+    # the loader: the whole iterator packed again from the resident raw arrays (qgtc_load_batches: HIP events, and host wall clock)
+    loader_us = ev(lambda: it.pack_now(Q), 10)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        it.pack_now(Q)
+    torch.cuda.synchronize()
+    loader_wall_us = (time.perf_counter() - t0) / 10 * 1e6
     # every operator on its own: a six-launch plan whose outputs are all in the public layouts (the chained plan keeps T
     # in the kernels' own formats between its launches - its stages cannot run alone)
     W = driver.pack_weights(Q, graph.feat.shape[1], hidden, 10, bits, dev)
@@ -287,8 +348,9 @@ def epoch_roofline(Q, graph, device_index, dataset, bits, hidden, gin):
         plan = driver.PlannedEpoch(Q, data, it.cluster_param_li, W, bits, "correct", gin)
         host.append((time.perf_counter() - t0) * 1e3)
         torch.cuda.synchronize()
-    host_ms = min(host)
-    epoch_us = ev(plan.run)
+    host_ms = sorted(host)[2]
+    keep_clock_up(plan.run)
+    epoch_us = sorted(ev(plan.run) for _ in range(5))[2]
     F, H, C, b = graph.feat.shape[1], hidden, 10, bits
     digits = lambda p: (p + 1) // 2       # noqa: E731
     ops = [  # (K_is_n, K, N, a, w, out: "bits"|"f32") per operator of the layout-correct chain
@@ -307,12 +369,11 @@ def epoch_roofline(Q, graph, device_index, dataset, bits, hidden, gin):
     floors = {"hbm_us": round(algo_bytes / (HBM_PEAK_GBS * 1e9) * 1e6, 2), "mfma_fp4_us": round(mfma_ops / (FP4_PEAK_TFLOPS * 1e12) * 1e6, 2),
               "launch_gaps_us": round(1.5 * (plan.n_launches - 1), 1)}
     chained = 6 - plan.n_launches
-    # HBM-side traffic of one epoch from the committed PMC passes of the same launches (profiles/r03/summary_epoch*.json: FETCH_SIZE x 2 on
-    # gfx950 + WRITE_SIZE, KiB per dispatch, times the dispatches an epoch makes of each kernel); None when the summary is absent
+    # HBM-side traffic of one epoch from the committed PMC passes of the same launches (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, KiB
+    # per dispatch, times the dispatches an epoch makes of each kernel) - only when the summary was collected from THESE sources
     traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03", "summary_epoch%s.json" % ("_gin" if gin else ""))) as f:
-            summ = json.load(f)
+    summ, traffic_source = profile_summary("epoch_gin" if gin else "epoch")
+    if summ is not None:
         calls = {k["name"]: k["calls"] for k in summ.get("kernel_stats", []) if "k_rbw" in k["name"]}
         base = min(calls.values()) if calls else 0
         tot = 0.0
@@ -322,25 +383,40 @@ def epoch_roofline(Q, graph, device_index, dataset, bits, hidden, gin):
             per_epoch = next((c for n_, c in calls.items() if n_[:60] == name[:60]), base) / base
             tot += per_epoch * (2.0 * cs.get("FETCH_SIZE", {}).get("mean", 0.0) + cs.get("WRITE_SIZE", {}).get("mean", 0.0)) * 1024.0
         traffic = int(tot) if tot > 0 else None
-    except Exception:   # noqa: BLE001 - evidence file optional at run time
-        traffic = None
+    frac = algo_bytes / epoch_us / 1e3 / HBM_PEAK_GBS
     return {"kernel_us_per_epoch": round(epoch_us, 2), "kernel_us_per_operator_alone": stage_us, "calls_per_epoch": plan.n_launches,
             "launches_per_epoch": plan.n_launches,
             "launch_structure": (f"6 operators in {plan.n_launches} launches: {chained} aggregation stages carry the next "
                                  "layer's X.W stage (qgtc_chain_transform / qgtc_chain_aggregate; adjacency "
                                  + ("as 512-byte tiles" if getattr(data, "a_tiles", False) else "in the rows layout") + ")") if chained else "6 grouped launches",
             "host_weight_pack_and_plan_bind_ms": round(host_ms, 4),
-            "host_note": "host time of the two calls main_qgtc.py:96 puts inside its clock besides the launches: one fill + one pack "
-                         "launch for the three weights, one allocation + ONE launch that fills every stage's descriptors on the device "
-                         "(round 2 built 6 x 75 descriptors on the host: 1.26 ms)",
+            "host_note": "host time (median of 5) of the two calls main_qgtc.py:96 puts inside its clock besides the launches: one fill + one pack "
+                         "launch for the three weights, one allocation + ONE launch that fills every stage's descriptors on the device",
+            "loader_us_per_iterator_hip_events": round(loader_us, 1), "loader_us_per_iterator_wall": round(loader_wall_us, 1),
+            "loader_note": "the data loader's packing of all 75 batches (adjacency rows + tiles + bitmaps from the edge lists, X in the cols / rows / "
+                           "chain layouts): ONE qgtc_load_batches call, six launches, ahead of the epoch clock as in main_qgtc.py:74-93 "
+                           "(round 3: eight launches per batch, 2.6 ms of kernels)",
             "algorithmic_bytes_per_epoch": int(algo_bytes), "effective_ops_per_epoch": eff_ops,
             "eff_TOPS": round(eff_ops / epoch_us / 1e6, 1), "floors": floors,
             "roofline": {"bound": "hbm", "achieved": round(algo_bytes / epoch_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(algo_bytes / epoch_us / 1e3 / HBM_PEAK_GBS, 4),
+                         "frac": round(frac, 4),
                          "frac_mfma": round(mfma_ops / epoch_us / 1e6 / FP4_PEAK_TFLOPS, 4),
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "frac_on_traffic": round(traffic / epoch_us / 1e3 / HBM_PEAK_GBS, 4) if traffic else None,
                          "note": "a few thousand short workgroups per launch: bound by launch floors, dependent load chains and the epilogues' VALU work, see DESIGN.md section 6"},
-            "adjacency_tiles_occupied": occ[:1], "rocprof": "profiles/r03/summary_epoch%s.json" % ("_gin" if gin else "")}
+            "adjacency_tiles_occupied": occ[:1]}
+
+
+def epoch_block(ep, key="batched_correct_chain_ms"):
+    """The compact per-epoch block that goes INSIDE the line's `roofline` (the part of the line the driver's record keeps): both
+    halves of BASELINE.json's metric in one place."""
+    rf = ep["roofline_of_the_grouped_correct_chain"]
+    return {"ms_driver_style": ep[key], "kernel_us": rf["kernel_us_per_epoch"], "launches": rf["launches_per_epoch"],
+            "algorithmic_bytes": rf["algorithmic_bytes_per_epoch"], "traffic_bytes": rf["roofline"]["traffic"],
+            "frac": rf["roofline"]["frac"], "frac_on_traffic": rf["roofline"]["frac_on_traffic"],
+            "loader_ms_once": round(rf["loader_us_per_iterator_hip_events"] / 1e3, 4),
+            "plan_bind_ms": rf["host_weight_pack_and_plan_bind_ms"],
+            "per_batch_unchanged_driver_ms": ep.get("per_batch_reference_chain_ms")}
 
 
 def zero_tile_rows(Q, graph_arxiv, device_index):
@@ -390,7 +466,7 @@ def identical_and_closed_form(Q, words, M, K, N, w):
 
 def adj_size_table(Q, device):
     """The reference's adjacency-size study (5_9_adjmatrix_size.py): 1-bit, M = K in 1024/2048/4096,
-    N = 16 .. 1024, all-ones inputs, 200 launches per point, best of 3."""
+    N = 16 .. 1024, all-ones inputs, 200 launches per point, median of 5 windows."""
     out = {}
     for nn, ref in REF_ADJ.items():
         row = {}
@@ -400,7 +476,7 @@ def adj_size_table(Q, device):
             words = {}
             for eng, key in (("auto", "TOPS"), ("popcount", "TOPS_engine_popcount")):
                 with engine(Q, eng):
-                    ms = best_of_3(Q, ba, bx, mk, mk, nn, 1)
+                    ms = median_of_5(Q, ba, bx, mk, mk, nn, 1)
                     words[eng] = Q.bitMM2Bit(ba, bx, mk, mk, nn, 1, 1, 1)
                 row[f"M{mk}"][key] = round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2)
             row[f"M{mk}"]["identical"] = identical_and_closed_form(Q, words, mk, mk, nn, 1)
@@ -410,7 +486,7 @@ def adj_size_table(Q, device):
 
 def micro_bench_table(Q, device):
     """The reference's whole micro-benchmark (2_7c_QGTC_GEMM_INT8.py: 9 shapes x widths 1/2/4/8, 200
-    launches per point between two events, all-ones inputs as there), best of 3."""
+    launches per point between two events, all-ones inputs as there), median of 5 windows."""
     out = {}
     for (mk, nn), ref in REF_MICRO.items():
         row = {}
@@ -420,12 +496,39 @@ def micro_bench_table(Q, device):
             words = {}
             for eng, key in (("auto", "TOPS"), ("popcount", "TOPS_engine_popcount")):
                 with engine(Q, eng):
-                    ms = best_of_3(Q, ba, bx, mk, mk, nn, ww)
+                    ms = median_of_5(Q, ba, bx, mk, mk, nn, ww)
                     words[eng] = Q.bitMM2Bit(ba, bx, mk, mk, nn, 1, ww, ww)
                 row[f"w{ww}"][key] = round(2.0 * mk * mk * nn * 200 / (ms * 1e-3) / 1e12, 2)
             row[f"w{ww}"]["identical"] = identical_and_closed_form(Q, words, mk, mk, nn, ww)
         out[f"{mk}x{mk}x{nn}"] = row
     return out
+
+
+def unchanged_driver_in_a_child(env_extra, timeout=240):
+    """The reference's literal per-batch loop (main_qgtc.py:112-155: 75 batches x six extension calls, 20 epochs) in a FRESH child
+    process with extra environment - for process-wide HIP runtime settings that cannot be flipped once this process has touched
+    the GPU. Must be called BEFORE this process initialises the GPU. Returns the median `Avg. Epoch` (ms) of five runs after an
+    untimed one, or None."""
+    import subprocess
+
+    code = ("import json, sys; sys.path.insert(0, %r)\n"
+            "import torch, QGTC as Q\n"
+            "from qgtc_ppopp22_amd import driver, graph as G\n"
+            "args = driver.build_parser().parse_args(['--dataset', 'ogbn-arxiv', '--n-hidden', '128', '--n-classes', '10', '--bit_width', '2', "
+            "'--use_QGTC', '--quiet', '--n-epochs', '20'])\n"
+            "g = G.make_graph('ogbn-arxiv', 1500)\n"
+            "it = driver.make_iter(args, Q, g)\n"
+            "ms = [driver.run(args, Q=Q, graph=g, it=it)['avg_epoch_ms'] for _ in range(6)][1:]\n"
+            "print('CHILD_MS ' + json.dumps(sorted(ms)))\n") % ROOT
+    try:
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=timeout)
+        for ln in out.stdout.splitlines():
+            if ln.startswith("CHILD_MS "):
+                ms = json.loads(ln[len("CHILD_MS "):])
+                return round(ms[len(ms) // 2], 4)
+    except Exception:   # noqa: BLE001 - optional leg
+        return None
+    return None
 
 
 def launch_ranks(args) -> int:
@@ -487,10 +590,25 @@ def dry_run(args):
     sums = D.gather_batch_summaries(csum, world, rank, world)
     ids = D.shard_round_robin(75, rank, world)
     counts = D.gather_batch_summaries(torch.tensor([[float(len(ids))]], dtype=torch.float64), world, rank, world)
+    # the end-of-epoch exchange with the real payload's shape: ragged per-batch float outputs [n_i, 10] (n_i = 1190 + 7 i mod 50 nodes,
+    # every element = the batch id), sharded round-robin, gathered padded; and the weak-scaled form (every rank its own 3 batches)
+    fake = lambda i: torch.full((1190 + (7 * i) % 50, 10), float(i))     # noqa: E731
+    allout, nodes = D.gather_batch_outputs([fake(i) for i in ids], 75, rank, world)
+    rep_out, rep_nodes = D.gather_batch_outputs([fake(100 * rank + j) for j in range(3)], 3, rank, world, replicas=True)
+    rep_sums = D.gather_replica_summaries(torch.tensor([[float(rank), float(j)] for j in range(3)], dtype=torch.float64), world)
     if rank == 0:
         print(json.dumps({"metric": "dry run (no GPU work)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "max_wall_s": wall, "extras": {"rank_checksums": [float(v) for v in sums.view(-1).tolist()],
-                                                         "batches_per_rank": [int(v) for v in counts.view(-1).tolist()]}}), flush=True)
+                                                         "batches_per_rank": [int(v) for v in counts.view(-1).tolist()],
+                                                         "gathered_output_shape": list(allout.shape),
+                                                         "gathered_output_nodes": [int(v) for v in nodes.tolist()],
+                                                         "gathered_output_first_values": [float(allout[i, 0, 0]) for i in range(allout.size(0))],
+                                                         "gathered_output_padding_is_zero": bool(all(float(allout[i, int(nodes[i]):].abs().sum()) == 0.0
+                                                                                                     for i in range(allout.size(0)))),
+                                                         "replica_output_shape": list(rep_out.shape),
+                                                         "replica_output_first_values": [float(rep_out[i, 0, 0]) for i in range(rep_out.size(0))],
+                                                         "replica_nodes": [int(v) for v in rep_nodes.tolist()],
+                                                         "replica_summaries": rep_sums.tolist()}}), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
@@ -504,6 +622,10 @@ def main():
     from qgtc_ppopp22_amd import dist as D
 
     rank, world, local = D.init_from_env(backend=args.backend)
+    host_kernarg_ms = None
+    if rank == 0 and world == 1 and not args.no_extras and torch.cuda.device_count() > 0:
+        # (a child process, started before THIS process touches the GPU: the knob is read when the HIP runtime starts)
+        host_kernarg_ms = unchanged_driver_in_a_child({"HIP_FORCE_DEV_KERNARG": "0"})
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU (run `python bench.py --gpus N` " \
                                "or torch.distributed.run with --nproc-per-node N)"
@@ -530,7 +652,7 @@ def main():
         if other_engine == "popcount":   # the engine BASELINE.json's north star names, against BOTH statements of its VALU roofline
             other_headline["valu_frac_of_measured_pair_rate_4.2e13"] = round(eff_ops_of(M, K, N) * w / o_kern / VALU_PEAK_BITOPS, 4)
             other_headline["valu_frac_of_survey_8d_peak_7.864e13"] = round(eff_ops_of(M, K, N) * w / o_kern / VALU_PEAK_BITOPS_SURVEY, 4)
-            other_headline["rocprof"] = "profiles/r03/summary_popcount.json"
+            other_headline["rocprof"] = f"{PROFILE_DIR}/summary_popcount.json"
     # what runs at this shape: the FP4 matrix-core kernel for narrow right operands (launch.hip.h: skinny_ok -
     # N <= 64, at most 2 x 8 planes, float32 sums exact: K (2^a - 1)(2^w - 1) < 2^24)
     fp4_kernel = args.engine != "popcount" and w <= 8 and K * (2 ** w - 1) < 2 ** 24
@@ -547,21 +669,21 @@ def main():
     # tools/profile_targets.py headline): the kernel's per-dispatch duration under --kernel-trace and, from separate
     # --pmc passes, FETCH_SIZE / WRITE_SIZE in KiB per launch (HBM-side bytes = 2 x FETCH_SIZE + WRITE_SIZE: the gfx950
     # correction for 16-byte-per-lane reads, MI355X_MICROARCH.md). Only the 1-bit workload on the default engine has one.
-    traffic, rocprof = None, None
-    try:
-        if w == 1 and fp4_kernel:
-            with open(os.path.join(ROOT, "profiles", "r03", "summary_headline.json")) as f:
-                prof = json.load(f)
-            ks = [k for k in prof["kernel_stats"] if "k_bitmm_fp4_one" in k["name"]][0]
-            rocprof = {"file": "profiles/r03/kernel_stats_headline.csv", "calls": ks["calls"], "avg_us": round(ks["avg_ns"] / 1e3, 3),
-                       "min_us": round(ks["min_ns"] / 1e3, 3),
-                       "hbm_frac_at_avg": round(algo_bytes / (ks["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBS, 5),
-                       "note": "kernel span per dispatch under the tracer (no launch gap; the tracer's completion signals "
-                               "stretch a dispatch this short, see profiles/r03/README.md)"}
-            pm = [v for k, v in prof["pmc_per_dispatch_mean"].items() if "k_bitmm_fp4_one" in k][0]
-            traffic = int(2 * 1024 * pm["FETCH_SIZE"]["mean"] + 1024 * pm["WRITE_SIZE"]["mean"])
-    except (OSError, KeyError, ValueError, IndexError):
-        traffic, rocprof = None, None
+    traffic, rocprof, traffic_source = None, None, "none: only the 1-bit workload on the default engine is profiled"
+    if w == 1 and fp4_kernel:
+        prof, traffic_source = profile_summary("headline")
+        try:
+            if prof is not None:
+                ks = [k for k in prof["kernel_stats"] if "k_bitmm_fp4_one" in k["name"]][0]
+                rocprof = {"file": f"{PROFILE_DIR}/kernel_stats_headline.csv", "calls": ks["calls"], "avg_us": round(ks["avg_ns"] / 1e3, 3),
+                           "min_us": round(ks["min_ns"] / 1e3, 3),
+                           "hbm_frac_at_avg": round(algo_bytes / (ks["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBS, 5),
+                           "note": "kernel span per dispatch under the tracer (no launch gap; the tracer's completion signals "
+                                   f"stretch a dispatch this short, see {PROFILE_DIR}/README.md)"}
+                pm = [v for k, v in prof["pmc_per_dispatch_mean"].items() if "k_bitmm_fp4_one" in k][0]
+                traffic = int(2 * 1024 * pm["FETCH_SIZE"]["mean"] + 1024 * pm["WRITE_SIZE"]["mean"])
+        except (KeyError, ValueError, IndexError):
+            traffic, rocprof, traffic_source = None, None, "none: " + traffic_source + " (unreadable)"
     hbm_floor_us, mfma_floor_us = algo_bytes / (HBM_PEAK_GBS * 1e9) * 1e6, eff_ops / (FP4_PEAK_TFLOPS * 1e12) * 1e6
     frac_hbm = round(algo_bytes / kern / 1e9 / HBM_PEAK_GBS, 5)
     if fp4_kernel:
@@ -569,8 +691,8 @@ def main():
         # floor is the HBM one (2.16 MB / 8 TB/s = 0.27 us against 2.1 Gop / 10 PF = 0.21 us), so that is the bound named.
         roofline = {"bound": "hbm", "kernel": "k_bitmm_fp4_one<1,%d,0,2,2>" % ({1: 1, 2: 2}.get(w, 4 if w <= 4 else 8)),
                     "achieved": round(algo_bytes / kern / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac_hbm,
-                    "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes),
-                    "avg_launch_us": round(kern * 1e6, 3),
+                    "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(algo_bytes),
+                    "avg_launch_us": round(kern * 1e6, 3), "avg_launch_window": max(args.steps, EVENT_MIN_LAUNCHES),
                     "avg_launch_source": "HIP events on the launch stream around max(K, %d) of the same launches issued right behind the timed "
                                          "region (inside it the two event records cost 11-12 us of a 72 us window), divided by their "
                                          "number: kernel + dependent-launch gap (~1.5 us), i.e. what a caller gets per launch" % EVENT_MIN_LAUNCHES,
@@ -626,7 +748,7 @@ def main():
                     sweep[f"w{ww}_{label}"] = {"ref_sm86_TFLOPs": REF_TFLOPS_4096_64[ww]}
                     for eng, key in (("auto", "TOPS"), ("popcount", "TOPS_engine_popcount")):
                         with engine(Q, eng):
-                            ms = best_of_3(Q, ba, bx, M, K, N, ww)
+                            ms = median_of_5(Q, ba, bx, M, K, N, ww)
                         sweep[f"w{ww}_{label}"][key] = round(eff_ops * 200 / (ms * 1e-3) / 1e12, 2)
                         if eng == "auto":
                             sweep[f"w{ww}_{label}"]["us_per_launch"] = round(ms * 1e3 / 200, 3)
@@ -686,8 +808,8 @@ def main():
                         lib8 = None
                     _, _, ba, bx = make_workload(Q, mk, mk, nn, 1, device, seed=3)
                     with engine(Q, "popcount"):
-                        ms1 = best_of_3(Q, ba, bx, mk, mk, nn, 1)
-                    ms1a = best_of_3(Q, ba, bx, mk, mk, nn, 1)
+                        ms1 = median_of_5(Q, ba, bx, mk, mk, nn, 1)
+                    ms1a = median_of_5(Q, ba, bx, mk, mk, nn, 1)
                     ops = 2.0 * mk * mk * nn * 200
                     cmp9[f"{mk}x{mk}x{nn}"] = {"int8_mfma_TOPS": round(ops / (ms8 * 1e-3) / 1e12, 2),
                                               "int8_hipblaslt_TOPS": lib8,
@@ -711,23 +833,48 @@ def main():
                 outs_e = {}
                 for name in ("popcount", "mfma", "auto"):
                     with engine(Q, name):
-                        ms = best_of_3(Q, ba, bx, mm, kk, nn, ww, reps=50)
+                        ms = median_of_5(Q, ba, bx, mm, kk, nn, ww, reps=50)
                         outs_e[name] = Q.bitMM2Bit(ba, bx, mm, kk, nn, 1, ww, ww)
                     row[name + "_TOPS"] = round(2.0 * mm * kk * nn * 50 / (ms * 1e-3) / 1e12, 1)
                 row["outputs_identical"] = bool(torch.equal(outs_e["popcount"], outs_e["mfma"]) and torch.equal(outs_e["popcount"], outs_e["auto"]))
                 eng[f"{mm}x{kk}x{nn}_w{ww}"] = row
             extras["mfma_engine_vs_popcount_wide_products"] = eng
-        ep, graph = epoch_leg(Q, rank, world, local)
+        multi = ("per_batch_reference_chain", "batched_correct_chain") if world > 1 else None   # (N > 1: the unchanged-driver and the grouped leg)
+        ep, graph = epoch_leg(Q, rank, world, local, only=multi, gather=args.gather)
         extras["cluster_gcn_epoch_ogbn_arxiv_shape"] = ep
+        if world > 1:
+            ep["scaling"] = "strong: the 75 batches round-robin over the ranks (BASELINE.json configs[4]); epoch = max over ranks"
+            # the same epoch weak-scaled: every rank runs 75 batches of its own arxiv-sized graph (per-GPU work fixed, 75 x world batches)
+            ep_w, _ = epoch_leg(Q, rank, world, local, only=("batched_correct_chain",), weak=True, gather=args.gather)
+            ep_w["scaling"] = "weak: 75 batches per rank (each rank its own ogbn-arxiv-sized graph), %d batches in all; epoch = max over ranks" % (75 * world)
+            ep_w["batches_per_second"] = round(75 * world / (ep_w["batched_correct_chain_ms"] * 1e-3), 1)
+            extras["cluster_gcn_epoch_ogbn_arxiv_shape_weak_scaled"] = ep_w
         if rank == 0 and world == 1:
+            ep["per_batch_reference_chain_host_kernarg_ms"] = host_kernarg_ms
+            ep["per_batch_note"] = ("the unchanged driver's six extension calls per batch are host-bound: ~3.7 us of each call is hipLaunchKernel writing the "
+                                    "kernel arguments into device memory; with HIP_FORCE_DEV_KERNARG=0 (arguments in host memory: 2.4 us per launch, but "
+                                    "every kernel starts ~1.2 us later - the headline would drop to ~490 TOPS) the same loop is the *_host_kernarg figure, "
+                                    "measured in a fresh child process ahead of this one's GPU work; DESIGN.md section 6")
             ep["roofline_of_the_grouped_correct_chain"] = epoch_roofline(Q, graph, local, "ogbn-arxiv", 2, 128, False)
             extras["zero_tile_jumping"] = zero_tile_rows(Q, graph, local)
         # BASELINE.json configs[3]: Batched-GIN, ppi-sized graph, 4-bit weights/features, hidden 64 (0_7b's value)
-        ep_gin, _ = epoch_leg(Q, rank, world, local, dataset="ppi", bits=4, hidden=64, gin=True, full=False)
+        ep_gin, _ = epoch_leg(Q, rank, world, local, dataset="ppi", bits=4, hidden=64, gin=True, full=False, only=multi, gather=args.gather)
         extras["batched_gin_epoch_ppi_shape_4bit"] = ep_gin
         if rank == 0 and world == 1:
             from qgtc_ppopp22_amd import graph as G2
             ep_gin["roofline_of_the_grouped_correct_chain"] = epoch_roofline(Q, G2.make_graph("ppi", 1500), local, "ppi", 4, 64, True)
+            # both halves of BASELINE.json's metric inside the part of the line the driver's record keeps: nested blocks, and the same
+            # figures once more as flat scalars (a record that keeps only scalars still has them)
+            blocks = {"epoch_cluster_gcn": epoch_block(ep), "epoch_batched_gin": epoch_block(ep_gin)}
+            line["roofline"].update(blocks)
+            for tag, blk in (("gcn", blocks["epoch_cluster_gcn"]), ("gin", blocks["epoch_batched_gin"])):
+                for k in ("ms_driver_style", "kernel_us", "launches", "algorithmic_bytes", "traffic_bytes", "frac", "frac_on_traffic", "loader_ms_once",
+                          "plan_bind_ms", "per_batch_unchanged_driver_ms"):
+                    line["roofline"][f"epoch_{tag}_{k}"] = blk[k]
+            line["roofline"]["epoch_note"] = ("epoch_gcn_* = Cluster-GCN ogbn-arxiv-sized 2-bit (BASELINE.json configs[2]), epoch_gin_* = Batched-GIN "
+                                              "ppi-sized 4-bit (configs[3]); ms_driver_style = main_qgtc.py:157-159's Avg. Epoch of the grouped plan, "
+                                              "kernel_us = HIP events around the launches, frac = dense algorithmic bytes / kernel time / 8 TB/s, "
+                                              "frac_on_traffic = counter bytes instead; loader_ms_once = the iterator's one-off packing (GPU time)")
         if rank == 0 and world == 1:
             from oracle.dgl_cpu_baseline import graphsage_cpu_epoch
             from qgtc_ppopp22_amd import graph as G

@@ -101,6 +101,19 @@ def build_torch_ext(force: bool = False) -> str:
     return TORCH_EXT
 
 
+def kernel_source_hash() -> str:
+    """12 hex digits over the sources that define the kernels and their launchers (csrc/*.hip, csrc/*.hip.h, include/qgtc.h):
+    profiles/ summaries carry it, and bench.py prints counter-derived traffic only when the summary's hash is the tree's."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") or f.endswith(".hip.h"))
+    for f in files + [os.path.join(INC, "qgtc.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def build_all(force: bool = False) -> dict:
     return {"hip": build_hip(force), "torch_ext": build_torch_ext(force)}
 

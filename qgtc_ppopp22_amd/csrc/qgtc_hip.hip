@@ -481,8 +481,12 @@ int qgtc_pack_edge_list(const int64_t *src, const int64_t *dst, size_t n_edges, 
     const size_t words = qgtc_rows_words(H, W, 1);
     if (out_words < words || scratch_words < 2 * words) return QGTC_ESIZE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    HIP_TRY(hipMemsetAsync(out, 0, words * sizeof(uint32_t), st));
-    HIP_TRY(hipMemsetAsync(scratch, 0, 2 * words * sizeof(uint32_t), st));
+    if (scratch == out + words) {   // one allocation [out | scratch] (the PyTorch binding's): one memset
+        HIP_TRY(hipMemsetAsync(out, 0, 3 * words * sizeof(uint32_t), st));
+    } else {
+        HIP_TRY(hipMemsetAsync(out, 0, words * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(scratch, 0, 2 * words * sizeof(uint32_t), st));
+    }
     if (bad_index) HIP_TRY(hipMemsetAsync(bad_index, 0, sizeof(int), st));
     if (n_edges) {
         hipLaunchKernelGGL(k_edge_list_count, dim3(grid_for(n_edges, 256)), dim3(256), 0, st, src, dst, n_edges, H, W,

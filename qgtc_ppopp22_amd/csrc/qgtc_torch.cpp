@@ -331,20 +331,23 @@ torch::Tensor pack_edges(torch::Tensor src, torch::Tensor dst, const int height,
     TORCH_CHECK(src.dim() == 1 && src.sizes() == dst.sizes(), "src and dst must be 1-D and equally long");
     TORCH_CHECK(height > 0 && width > 0, "height and width must be positive");
     c10::DeviceGuard guard(src.device());
-    auto out = torch::empty({static_cast<int64_t>(nbits) * P8(height), S128(width) * 4},
-                            torch::TensorOptions().dtype(torch::kInt32).device(src.device()));
+    const auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(src.device());
     if (nbits == 1) {
-        // the adjacency case: raw edge list, no sort / unique, no host round trip unless validate asks for one
-        auto scratch = torch::empty({2 * out.numel()}, out.options());
+        // the adjacency case: raw edge list, no sort / unique, no host round trip unless validate asks for one. One allocation
+        // [out | scratch] (one memset in the library); the result is a view of its first third.
+        const int64_t words = static_cast<int64_t>(P8(height)) * S128(width) * 4;
+        auto buf = torch::empty({3 * words}, i32);
+        auto out = buf.narrow(0, 0, words).view({static_cast<int64_t>(P8(height)), S128(width) * 4});
         torch::Tensor bad;
-        if (validate) bad = torch::empty({1}, out.options());
+        if (validate) bad = torch::empty({1}, i32);
         check_rc(qgtc_pack_edge_list(src.numel() ? src.data_ptr<int64_t>() : nullptr, src.numel() ? dst.data_ptr<int64_t>() : nullptr,
-                                     src.numel(), height, width, words_mut(out), out.numel(), words_mut(scratch),
-                                     scratch.numel(), validate ? bad.data_ptr<int>() : nullptr, current_stream(src)),
+                                     src.numel(), height, width, words_mut(buf), words, words_mut(buf) + words,
+                                     2 * words, validate ? bad.data_ptr<int>() : nullptr, current_stream(src)),
                  "pack_edges");
         if (validate) TORCH_CHECK(bad.item<int>() == 0, "edge index out of range");
         return out;
     }
+    auto out = torch::empty({static_cast<int64_t>(nbits) * P8(height), S128(width) * 4}, i32);
     torch::Tensor cells, counts;
     if (src.numel() > 0) {
         TORCH_CHECK(src.min().item<int64_t>() >= 0 && src.max().item<int64_t>() < height &&

@@ -59,6 +59,52 @@ def gather_batch_summaries(local: torch.Tensor, n_batches: int, rank: int, world
     return torch.stack(rows)
 
 
+def gather_replica_summaries(local: torch.Tensor, world: int) -> torch.Tensor:
+    """Weak scaling (every rank ran ALL its own batches): [n, D] per rank -> [world * n, D], rank-major, on every rank."""
+    if world == 1:
+        return local
+    if local.is_cuda and dist.get_backend() == "gloo":
+        return gather_replica_summaries(local.cpu(), world).to(local.device)
+    out = torch.empty((world * local.size(0), local.size(1)), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out
+
+
+def gather_batch_outputs(outs, n_batches: int, rank: int, world: int, replicas: bool = False):
+    """SURVEY.md 8e's exchange with the REAL payload: the per-batch float32 outputs of an epoch ([n_i, C] each), gathered
+    to every rank with one all_gather_into_tensor on buffers padded to the largest batch (and, sharded, to the largest
+    shard), plus the node counts (one more small all_gather: the batches are ragged).
+    Sharded (replicas False): rank r holds batches r, r + world, ..; returns ([n_batches, max_n, C], nodes[n_batches]) in
+    global batch order. Replicas (weak scaling): every rank holds n_batches of its own; returns [world * n_batches, ..]."""
+    dev = outs[0].device if outs else torch.device("cpu")
+    C = outs[0].size(1) if outs else 1
+    if dist.is_initialized() and dev.type == "cuda" and dist.get_backend() == "gloo":
+        g, nodes = gather_batch_outputs([o.cpu() for o in outs], n_batches, rank, world, replicas)
+        return g.to(dev), nodes
+    per = n_batches if replicas else (n_batches + world - 1) // world
+    local_n = torch.zeros(per, dtype=torch.int64, device=dev)
+    if outs:
+        local_n[: len(outs)] = torch.tensor([o.size(0) for o in outs], dtype=torch.int64, device=dev)
+    if world == 1:
+        all_n = local_n.view(1, per)
+    else:
+        all_n = torch.empty((world, per), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(all_n.view(-1), local_n)
+    max_n = int(all_n.max().item()) if all_n.numel() else 0
+    buf = torch.zeros((per, max_n, C), dtype=torch.float32, device=dev)
+    for i, o in enumerate(outs):
+        buf[i, : o.size(0)] = o
+    if world == 1:
+        allbuf = buf.view(1, per, max_n, C)
+    else:
+        allbuf = torch.empty((world, per, max_n, C), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(allbuf.view(-1), buf.view(-1))
+    if replicas:
+        return allbuf.view(world * per, max_n, C), all_n.view(-1)
+    order = [(owner_of(i, world), i // world) for i in range(n_batches)]
+    return torch.stack([allbuf[r, j] for r, j in order]), torch.stack([all_n[r, j] for r, j in order])
+
+
 def max_over_ranks(value: float, device) -> float:
     if not dist.is_initialized():
         return value

@@ -75,7 +75,8 @@ def build_parser() -> argparse.ArgumentParser:
                    help="cluster_gcn.py's structure (:151-227): every iteration brings the batch's edge list and "
                         "float features to the device (Trans), then packs them and runs the six operators "
                         "(Compute), with synchronisation fences around both; prints its `Trans (ms): .., Compute "
-                        "(ms): ..` line too")
+                        "(ms): ..` line too. With --batched: the grouped form - one loader call per epoch packs every "
+                        "batch, then the grouped epoch")
     p.add_argument("--engine", choices=["popcount", "mfma", "auto"], default="auto",
                    help="auto (default): per launch the kernel family that measured fastest on MI355X; popcount: AND + "
                         "v_bcnt kernels only (the path BASELINE.json names); mfma: bit planes expanded on the matrix "
@@ -460,6 +461,23 @@ def _run_epochs(args, Q, it, feat_size, b, device):
             print(ZEROTILE_HEADER)
             print(row["line"])
         return {"avg_epoch_ms": float("nan"), "outs": [], "iter": it, "counters": Q.get_counters(), "zerotile": row}
+
+    if getattr(args, "pack_on_the_fly", False) and args.batched:
+        # cluster_gcn.py's structure (:151-227: pack inside the epoch loop) in the grouped form: per epoch ONE loader call packs
+        # every batch from the resident edge lists and features (qgtc_load_batches), one launch binds the plan, then the epoch's
+        # grouped launches. Everything inside the clock.
+        plan = None
+        for _ in range(args.n_epochs):
+            data = it.pack_now(Q)
+            plan = PlannedEpoch(Q, data, it.cluster_param_li, W, b, args.chain, args.run_GIN, fuse=not getattr(args, "no_fuse", False),
+                                chain_stages=not getattr(args, "no_chain", False))
+            plan.run()
+        torch.cuda.synchronize()
+        end_time = time.time()
+        avg = (end_time - start_time) * 1000 / args.n_epochs
+        if not args.quiet:
+            print("Avg. Epoch: {:.3f} ms".format(avg))       # cluster_gcn.py:246
+        return {"avg_epoch_ms": avg, "outs": plan.outs, "iter": it}
 
     if getattr(args, "pack_on_the_fly", False):
         from .sampler import ClusterTensor

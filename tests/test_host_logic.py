@@ -222,6 +222,28 @@ def test_bench_starts_its_own_ranks():
     assert line["max_wall_s"] == pytest.approx(0.002)        # the MAX over ranks
 
 
+def test_bench_dry_run_world8_gathers_75_ragged_batches():
+    """BASELINE.json configs[4] without hardware: eight gloo ranks, 75 ragged cluster batches round-robin (10 on ranks 0-2, 9 on
+    the others), the per-batch float outputs gathered padded into global batch order on every rank - and the weak-scaled
+    form (every rank its own batches, rank-major)."""
+    import json
+
+    out = _run_bench(["--gpus", "8", "--dry-run", "--backend", "gloo", "--steps", "2", "--warmup", "1"], timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    ex = line["extras"]
+    assert line["n_gpus"] == 8 and ex["batches_per_rank"] == [10, 10, 10, 9, 9, 9, 9, 9]
+    nodes = [1190 + (7 * i) % 50 for i in range(75)]
+    assert ex["gathered_output_shape"] == [75, max(nodes), 10]
+    assert ex["gathered_output_nodes"] == nodes
+    assert ex["gathered_output_first_values"] == [float(i) for i in range(75)]          # global batch order
+    assert ex["gathered_output_padding_is_zero"] is True
+    assert ex["replica_output_shape"][0] == 24
+    assert ex["replica_output_first_values"] == [float(100 * r + j) for r in range(8) for j in range(3)]   # rank-major
+    assert ex["replica_summaries"] == [[float(r), float(j)] for r in range(8) for j in range(3)]
+    assert ex["rank_checksums"] == [1000.0 + r for r in range(8)]
+
+
 def test_bench_fails_loudly_on_a_rank_count_mismatch():
     """A launcher that started a different number of ranks than --gpus says is an error, never a silent 1-GPU run."""
     out = _run_bench(["--gpus", "4", "--dry-run", "--backend", "gloo"],

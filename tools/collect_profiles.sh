@@ -7,21 +7,23 @@
 set -u
 TAG=${1:-r03}
 shift
-TARGETS=${@:-headline popcount w8 epoch epoch_gin pack}
+TARGETS=${@:-headline popcount w8 epoch epoch_gin loader pack}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for T in $TARGETS; do
-  REPS=200; [ "$T" = "epoch" -o "$T" = "epoch_gin" ] && REPS=20; case "$T" in wide*) REPS=50;; esac
+  REPS=200; [ "$T" = "epoch" -o "$T" = "epoch_gin" -o "$T" = "loader" -o "$T" = "loader_gin" ] && REPS=20; case "$T" in wide*) REPS=50;; esac
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$T -- python3 $GRAFT_REPO_ROOT/tools/profile_targets.py $T $REPS > $OUT/run_trace_$T.json 2> $OUT/trace_$T.err
   for C in FETCH_SIZE WRITE_SIZE "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
     N=$(echo $C | tr ' ' '_')
     rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${T}_$N -- python3 $GRAFT_REPO_ROOT/tools/profile_targets.py $T 20 > $OUT/run_pmc_${T}_$N.json 2> $OUT/pmc_${T}_$N.err
   done
   python3 - <<PY
-import csv, glob, json, collections
+import csv, glob, json, collections, sys
+sys.path.insert(0, "$GRAFT_REPO_ROOT")
+from qgtc_ppopp22_amd._build import kernel_source_hash
 out, t = "$OUT", "$T"
-res = {"target": t}
+res = {"target": t, "kernel_source_hash": kernel_source_hash()}
 try:
     res["hip_events"] = json.loads([l for l in open(f"{out}/run_trace_{t}.json") if l.startswith("{")][-1])
 except Exception as e:
