@@ -237,10 +237,15 @@ int qgtc_i8gemm_profile(const int8_t *A, const int8_t *Bt, int M, int K, int N, 
  * The descriptors of qgtc_bitmm_batched / qgtc_gcn_layer_batched / qgtc_gcn_chain_batched live in device memory, so the
  * host side cannot compare them with the stated maxima (from which the grid, the split-K plan and the choice between the
  * float32 and int32 kernels are derived). With QGTC_CHECK_DESCRIPTORS in `flags` those entries first launch a
- * small kernel (one thread per descriptor) on `stream` that checks every descriptor: M <= max_M, K <= max_K, N <= max_N, all positive,
- * non-NULL 16-byte aligned operands, and for the two-stage entries that stage 2 really reads stage 1's output. The
+ * small kernel (one thread per descriptor) on `stream` that checks every descriptor: M <= max_M, K <= max_K, N <= max_N, all
+ * positive, non-NULL 16-byte aligned operands AND outputs (the kernels store 16 bytes a lane), for the two-stage entries that
+ * stage 2 really reads stage 1's output, and for the chain entries (qgtc_chain_transform / qgtc_chain_aggregate, whose stores
+ * are sized from the HOST's N / N2) that every descriptor's N EQUALS the stated width - for qgtc_chain_aggregate's second
+ * product the stage_xw descriptors are checked too (output pointer, N = N2, M = stage_a's M). The
  * product still runs (its results for an offending problem are unspecified, exactly as without the flag); the first
- * violation is kept in a per-device record until it is read.
+ * violation is kept in a per-device record until it is read. qgtc_epoch_plan_fill records there as well: a pool smaller
+ * than qgtc_epoch_pool_layout's figure (QGTC_VIOL_POINTER) or a batch with n <= 0 (QGTC_VIOL_M) - such descriptors get M = 0,
+ * which every grouped kernel skips.
  * qgtc_last_batched_violation(): waits for `stream`, returns QGTC_OK when no checked launch since the last call found a
  * violation, else QGTC_EINVAL with *problem = index of the first offending descriptor and *field = one of QGTC_VIOL_*;
  * the record is cleared. `problem` / `field` may be NULL. */

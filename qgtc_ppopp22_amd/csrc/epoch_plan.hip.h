@@ -99,7 +99,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_epoch_plan_fill(const qgtc_bat
             const int b = b0 + tid;
             qgtc_batch bt = mine;
             if (!one_pass && b < count) bt = batches[b];
-            const unsigned long long words = b < count ? stage_out_words(st, bt.n) : 0ull;
+            const bool n_ok = bt.n > 0;   // (the table is device memory: a batch with no nodes gets M = 0 descriptors and a record)
+            const unsigned long long words = (b < count && n_ok) ? stage_out_words(st, bt.n) : 0ull;
             unsigned long long incl = words;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {   // inclusive scan inside the wave
@@ -117,11 +118,12 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_epoch_plan_fill(const qgtc_bat
             }
             unsigned long long off = carry + before + incl - words;
             if (b < count) {
-                bool fits = true;
-                if (off + words > pool_words) {   // a pool smaller than qgtc_epoch_pool_layout says: recorded, and no pointer leaves the pool
-                    atomicMin(record, b * 8 + QGTC_VIOL_POINTER);
-                    fits = words <= pool_words;
-                    off = fits ? pool_words - words : 0ull;
+                bool fits = n_ok;
+                if (!n_ok) atomicMin(record, b * 8 + QGTC_VIOL_M);
+                if (off + words > pool_words) {   // a pool smaller than qgtc_epoch_pool_layout says: recorded; the descriptor gets M = 0 (no
+                    atomicMin(record, b * 8 + QGTC_VIOL_POINTER);   // kernel touches it) and a pointer inside the pool, 16-byte aligned
+                    fits = false;
+                    off = words <= pool_words ? ((pool_words - words) & ~3ull) : 0ull;
                 }
                 // (everything below in scalars: a struct handed to a lambda by reference, or selected whole by a ternary, lives in scratch)
                 const uint32_t *op_ptr[2];
@@ -177,28 +179,38 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_epoch_plan_fill(const qgtc_bat
 
 // ------------------------------------------------------------------------------------------
 // QGTC_CHECK_DESCRIPTORS. kind 0: one stage; 1: layer (stage 2's W is stage 1's output); 2: chain (stage 2's X is stage
-// 1's output, K2 = N1); 3: one stage whose `out` is not used (qgtc_chain_aggregate with a second product). The first violation (lowest problem index, then lowest field code) wins: record = problem * 8 +
+// 1's output, K2 = N1); 3: one stage whose `out` is not used; 4: the pair of qgtc_chain_aggregate with a second product - p1 = the
+// aggregation (its `out` unused), p2 = the transform whose OUTPUT is all the entry uses (non-NULL, 16-byte aligned: the kernels
+// store 16 bytes a lane; M = p1's M). exact_N1 / exact_N2 != 0: the chain entries size their stores from the HOST's N, so the
+// descriptors' N must EQUAL it. The first violation (lowest problem index, then lowest field code) wins: record = problem * 8 +
 // field, kept with atomicMin (INT_MAX = none).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_check_descriptors(const qgtc_problem *__restrict__ p1, const qgtc_problem *__restrict__ p2, int count,
                                                            int max_M, int max_K1, int max_N1, int max_K2, int max_N2, int kind,
-                                                           int *__restrict__ record) {
+                                                           int exact_N1, int exact_N2, int *__restrict__ record) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
         int field = QGTC_VIOL_NONE;
-        auto one = [&](const qgtc_problem &p, int mk, int mn) {
+        auto one = [&](const qgtc_problem &p, int mk, int mn, int exact_n, bool out_used) {
             if (field) return;
             if (p.M <= 0 || p.M > max_M) field = QGTC_VIOL_M;
             else if (p.K <= 0 || p.K > mk) field = QGTC_VIOL_K;
-            else if (p.N <= 0 || p.N > mn) field = QGTC_VIOL_N;
-            else if (!p.X || !p.W || (!p.out && kind != 3) || (reinterpret_cast<uintptr_t>(p.X) & 15u) || (reinterpret_cast<uintptr_t>(p.W) & 15u) ||
-                     p.x_words >= (1ull << 30) || p.w_words >= (1ull << 30))
+            else if (p.N <= 0 || p.N > mn || (exact_n && p.N != exact_n)) field = QGTC_VIOL_N;
+            else if (!p.X || !p.W || (reinterpret_cast<uintptr_t>(p.X) & 15u) || (reinterpret_cast<uintptr_t>(p.W) & 15u) ||
+                     (out_used && (!p.out || (reinterpret_cast<uintptr_t>(p.out) & 15u))) || p.x_words >= (1ull << 30) || p.w_words >= (1ull << 30))
                 field = QGTC_VIOL_POINTER;
         };
         const qgtc_problem a = p1[i];
-        one(a, max_K1, max_N1);
-        if (p2) {
+        one(a, max_K1, max_N1, exact_N1, kind != 3 && kind != 4);
+        if (p2 && kind == 4) {
             const qgtc_problem b = p2[i];
-            one(b, max_K2, max_N2);
+            if (!field) {
+                if (b.M != a.M) field = QGTC_VIOL_CHAINING;
+                else if (b.N <= 0 || b.N > max_N2 || (exact_N2 && b.N != exact_N2)) field = QGTC_VIOL_N;
+                else if (!b.out || (reinterpret_cast<uintptr_t>(b.out) & 15u)) field = QGTC_VIOL_POINTER;
+            }
+        } else if (p2) {
+            const qgtc_problem b = p2[i];
+            one(b, max_K2, max_N2, exact_N2, true);
             if (!field) {
                 if (kind == 1 && (b.W != static_cast<const uint32_t *>(a.out) || a.M != b.M || a.N != b.N)) field = QGTC_VIOL_CHAINING;
                 if (kind == 2 && (b.X != static_cast<const uint32_t *>(a.out) || a.M != b.M || a.N != b.K)) field = QGTC_VIOL_CHAINING;

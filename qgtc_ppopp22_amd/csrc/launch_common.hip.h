@@ -30,9 +30,10 @@ int qgtc_launch_rows_to_tiles(const uint32_t *rows, size_t words, int M, int K, 
 
 // defined in qgtc_wide.hip
 int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st);
-// defined in qgtc_epoch.hip: QGTC_CHECK_DESCRIPTORS (kind 0 one stage / 1 layer / 2 chain; p2 may be NULL)
+// defined in qgtc_epoch.hip: QGTC_CHECK_DESCRIPTORS (kind 0 one stage / 1 layer / 2 chain / 3 one stage, `out` unused / 4 the pair of
+// qgtc_chain_aggregate; p2 may be NULL; exact_N*: the descriptors' N must equal it)
 int qgtc_launch_check_descriptors(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int max_K1, int max_N1,
-                                  int max_K2, int max_N2, int kind, hipStream_t st);
+                                  int max_K2, int max_N2, int kind, hipStream_t st, int exact_N1 = 0, int exact_N2 = 0);
 
 namespace {
 

@@ -386,7 +386,7 @@ int qgtc_chain_transform(const qgtc_problem *stage, int count, int max_M, int K,
     if (!aligned16(w_codes)) return QGTC_EALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (flags & QGTC_CHECK_DESCRIPTORS) {
-        const int crc = qgtc_launch_check_descriptors(stage, nullptr, count, max_M, K, N, 0, 0, 0, st);
+        const int crc = qgtc_launch_check_descriptors(stage, nullptr, count, max_M, K, N, 0, 0, 0, st, N, 0);
         if (crc != QGTC_OK) return crc;
     }
     return qgtc_launch_rbw_xw(stage, count, max_M, N, x_bits, out_bits, w_codes, st);
@@ -401,7 +401,8 @@ int qgtc_chain_aggregate(const qgtc_problem *stage_a, const qgtc_problem *stage_
     if (w2_codes && !aligned16(w2_codes)) return QGTC_EALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (flags & QGTC_CHECK_DESCRIPTORS) {
-        const int crc = qgtc_launch_check_descriptors(stage_a, nullptr, count, max_M, max_K, N1, 0, 0, out_mode == 0 ? 0 : 3, st);
+        const int crc = out_mode == 0 ? qgtc_launch_check_descriptors(stage_a, nullptr, count, max_M, max_K, N1, 0, 0, 0, st, N1, 0)
+                                      : qgtc_launch_check_descriptors(stage_a, stage_xw, count, max_M, max_K, N1, N1, N2, 4, st, N1, N2);
         if (crc != QGTC_OK) return crc;
     }
     return qgtc_launch_rbw_chain(stage_a, out_mode == 0 ? nullptr : stage_xw, count, max_M, N1, N2, t_bits, act_bits, out_bits, out_mode, w2_codes,

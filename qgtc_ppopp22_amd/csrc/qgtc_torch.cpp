@@ -737,6 +737,7 @@ struct EpochPlan {
     }
     std::vector<Launch> launches;
     std::vector<uint64_t> offsets;      // lazily: word offset of every (stage, batch) output in the pool
+    bool fill_checked = false;          // the plan-fill kernel's violation record has been read for this bind (outs(): after the clock)
     static constexpr double kJumpBelow = BatchedGemm::kJumpBelow;
 
     // x_chain_bits > 0: every X (cols layout [n, x_cols], x_chain_bits planes) is also kept in the chain format of the
@@ -1001,6 +1002,7 @@ struct EpochPlan {
             launches.push_back(Launch{l[0], l[1], l[2], static_cast<unsigned>(l[3]), l[4]});
         }
         offsets.clear();
+        fill_checked = false;
         const size_t pool_words = qgtc_epoch_pool_layout(nodes.data(), count, stages.data(), ns, nullptr);
         TORCH_CHECK(pool_words > 0 && pool_words < (1ull << 40), "bad pool size");
         pool = torch::empty({static_cast<int64_t>(pool_words)}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
@@ -1025,10 +1027,14 @@ struct EpochPlan {
             check_rc(qgtc_gcn_chain_batched(stage_descs(l.s1), stage_descs(l.s2), count, max_n, dimK(a), a.N, x.N, a.bit1, a.bit2, a.ob, x.bit2, x.ob,
                                             x.mode, base | ((a.use_occ && jumping) ? QGTC_ZERO_JUMP : 0u) | l.extra, st), "EpochPlan.run (chained pair)");
         } else if (l.kind == 3) {
+            TORCH_CHECK(base & (QGTC_ENGINE_AUTO | QGTC_ENGINE_MFMA), "EpochPlan: this plan was bound for the matrix-core chain entries (T in their "
+                        "private format); after set_engine('popcount') bind it again");
             const qgtc_stage &a = stages[l.s1];
             check_rc(qgtc_chain_transform(stage_descs(l.s1), count, max_n, dimK(a), a.N, a.bit1, a.ob, words(weight_codes[l.codes]), check, st),
                      "EpochPlan.run (chain transform)");
         } else if (l.kind == 4) {
+            TORCH_CHECK(base & (QGTC_ENGINE_AUTO | QGTC_ENGINE_MFMA), "EpochPlan: this plan was bound for the matrix-core chain entries (T in their "
+                        "private format); after set_engine('popcount') bind it again");
             const qgtc_stage &a = stages[l.s1];
             const unsigned tiles = a.left == QGTC_SRC_AT ? QGTC_CHAIN_ADJ_TILES : 0u;
             if (l.s2 < 0) {
@@ -1065,6 +1071,13 @@ struct EpochPlan {
     // the per-batch outputs of one stage: views into the pool, made on demand
     std::vector<torch::Tensor> outs(int s) {
         TORCH_CHECK(descs.defined() && s >= 0 && s < static_cast<int>(stages.size()), "no such stage");
+        if (!fill_checked) {   // what the fill kernel recorded (an undersized pool, a batch without nodes): read ONCE per bind, here - outs() is
+            fill_checked = true;   // called after the epoch clock, and it waits for the stream anyway
+            c10::DeviceGuard guard(descs.device());
+            int problem = -1, field = 0;
+            const int rc = qgtc_last_batched_violation(&problem, &field, current_stream(descs));
+            TORCH_CHECK(rc == QGTC_OK, "EpochPlan: batch ", problem, " could not be planned (field ", field, ": pool too small or no nodes)");
+        }
         if (offsets.empty()) {
             offsets.resize(stages.size() * static_cast<size_t>(count));
             qgtc_epoch_pool_layout(nodes.data(), count, stages.data(), static_cast<int>(stages.size()), offsets.data());

@@ -85,6 +85,15 @@ def build_parser() -> argparse.ArgumentParser:
     return p
 
 
+def routing_switches() -> bool:
+    """One of the library's ROUTING switches is set (launch_common.hip.h: getenv_flag - set and not starting with '0'): the chain
+    entries / chained pairs / row-block kernels are off, so a plan must not keep T in their private formats."""
+    def on(k):
+        v = os.environ.get(k, "")
+        return bool(v) and v[0] != "0"
+    return any(on(k) for k in ("QGTC_NO_RBW", "QGTC_NO_CHAIN", "QGTC_NO_ROWS", "QGTC_NO_XWROWS"))
+
+
 def pack_weights(Q, feat, hidden, classes, bw, device):
     """main_qgtc.py:100-110: all-ones weights, cols layout, W3 with output_layer=True. Inside the reference's epoch clock,
     so it is ONE fill and ONE pack launch here (Q.val2bit_many: the same words as four val2bit calls)."""
@@ -251,7 +260,7 @@ class BatchedEpoch:
             # writes them, e.g. to compare every operator's output)
             codes = {}
             if (not keep_aggregates and (b == 2 or (run_gin and b == 4)) and max(F, H, C) <= 128 and max(n) <= 8192 and Q.get_engine() != "popcount" and
-                    not any(k.startswith("QGTC_NO_") for k in os.environ)):   # (every launch inside the row-block kernels' range, no debugging switch rerouting one)
+                    not routing_switches()):   # (every launch inside the row-block kernels' range, no routing switch)
                 # Every T' is read by the next launch of the chain only: it stays in the kernels' own format
                 # (QGTC_CHAIN_CODES_OUT / _IN: E2M1 codes in the 4-bit chain - no expansion in the reader -, k-quad-major
                 # bit planes in the 2-bit ones - a wave's loads and stores of T touch 4 cache lines instead of 32). The
@@ -318,6 +327,12 @@ class PlannedEpoch:
 
     def __init__(self, Q, data, params, W, b, chain: str, run_gin: bool, fuse: bool = True, chain_stages: bool = True,
                  keep_aggregates: bool = False):
+        self._args = (Q, data, params, W, b, chain, run_gin, fuse, chain_stages, keep_aggregates)
+        self._bind()
+
+    def _bind(self):
+        Q, data, params, W, b, chain, run_gin, fuse, chain_stages, keep_aggregates = self._args
+        self._bound_engine = Q.get_engine()     # the route (chain entries / grouped GEMMs, T's format) is fixed per bind
         H, C = W["hidden"], W["classes"]
         F = params[0][3]
         self.data = data
@@ -327,7 +342,9 @@ class PlannedEpoch:
         expand = []
         self.discarded = set()
         max_n = max(p[0] for p in params)
-        switches = any(k.startswith("QGTC_NO_") for k in os.environ)
+        # the library's own routing switches that take the chain entries / chained pairs away (perf-only switches such as
+        # QGTC_NO_XCD leave the route alone)
+        switches = routing_switches()
         if (fuse and chain == "correct" and chain_stages and not run_gin and not keep_aggregates and b == 2 and max(F, H, C) <= 128 and max_n <= 8192
                 and Q.get_engine() != "popcount" and not switches):
             # The 2-bit Cluster-GCN chain on the chain entries (qgtc_chain_transform / qgtc_chain_aggregate): one wave per row
@@ -378,6 +395,8 @@ class PlannedEpoch:
         data.bind([W["W1"], W["W2"], W["W3"], W["W3h"]], [list(t) for t in stages], [list(l) for l in launches], [list(e) for e in expand])
 
     def run(self):
+        if self._args[0].get_engine() != self._bound_engine:    # set_engine() since the bind: another route, other formats of T
+            self._bind()
         self.data.run()
 
     @property

@@ -345,6 +345,20 @@ def test_epoch_plan_filled_on_the_device_with_raw_pointers(lib, oracle):
     assert lib.qgtc_epoch_plan_fill(batches.data_ptr(), count, ctypes.addressof(stages), 4, ctypes.addressof(weights), 2, pool.data_ptr(), pool_words - 8,
                                     descs.data_ptr(), st) == 0
     assert lib.qgtc_last_batched_violation(ctypes.byref(prob), ctypes.byref(field), st) == 1 and field.value == 4
+    torch.cuda.synchronize()
+    over = (QgtcProblem * (4 * count)).from_buffer_copy(descs.cpu().numpy().tobytes())
+    last = over[4 * count - 1]                                   # the output that passes the pool's end: M = 0 (every grouped kernel skips it),
+    assert last.M == 0 and pool.data_ptr() <= last.out <= pool.data_ptr() + 4 * (pool_words - 8) and last.out % 16 == 0   # a pointer inside the pool, aligned
+    assert all(over[i].M == ns[i % count] for i in range(4 * count - 1))
+    # a batch without nodes in the device table: M = 0 descriptors and QGTC_VIOL_M for that batch, the others are planned as before
+    hb0 = list(hb)
+    hb0[2] = QgtcBatch(hb[2].A, hb[2].X, hb[2].XR, hb[2].XC, hb[2].AT, None, 0, 0)
+    batches0 = torch.frombuffer(bytearray(bytes((QgtcBatch * count)(*hb0))), dtype=torch.uint8).cuda()
+    assert lib.qgtc_epoch_plan_fill(batches0.data_ptr(), count, ctypes.addressof(stages), 4, ctypes.addressof(weights), 2, pool.data_ptr(), pool_words,
+                                    descs.data_ptr(), st) == 0
+    assert lib.qgtc_last_batched_violation(ctypes.byref(prob), ctypes.byref(field), st) == 1 and (prob.value, field.value) == (2, 1)
+    zero_n = (QgtcProblem * (4 * count)).from_buffer_copy(descs.cpu().numpy().tobytes())
+    assert all(zero_n[s * count + 2].M == 0 for s in range(4)) and zero_n[0].M == ns[0] and zero_n[3].M == ns[3]
     # bad recipes are error codes
     stages[1].left = SRC_STAGE + 3
     assert lib.qgtc_epoch_plan_fill(batches.data_ptr(), count, ctypes.addressof(stages), 4, ctypes.addressof(weights), 2, pool.data_ptr(), pool_words,
@@ -507,6 +521,18 @@ def test_chain_entries_at_four_bits(lib, oracle, M, F, H, C, bitmaps):
             o.fill_(-7.0)
     lib.qgtc_last_batched_violation.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), vp]
     assert lib.qgtc_last_batched_violation(None, None, st) == 0
+    # the second product's descriptors are checked too: a stage_xw entry for another batch size is a chaining violation (the entry only
+    # takes `out` and N from it, so the product itself is unaffected)
+    bad = (QgtcProblem * (4 * count))(*(s0 + s1 + s2 + s3))
+    bad[3 * count + 1].M += 1
+    bad_descs = torch.frombuffer(bytearray(bytes(bad)), dtype=torch.uint8).cuda()
+    assert lib.qgtc_chain_aggregate(bad_descs.data_ptr() + 72 * count * 2, bad_descs.data_ptr() + 72 * count * 3, count, M, M, H, C, b, b, b, 2, c2.data_ptr(), 0x200, st) == 0
+    prob, field = ctypes.c_int(-1), ctypes.c_int(0)
+    assert lib.qgtc_last_batched_violation(ctypes.byref(prob), ctypes.byref(field), st) == 1 and (prob.value, field.value) == (1, 5)
+    # ... and the descriptors' N must EQUAL the width the host states (the stores are sized from it): stating H + 1 for these descriptors is recorded
+    if H + 1 <= 64:
+        assert lib.qgtc_chain_aggregate(d(0), d(1), count, M, M, F, H + 1, b, b, b, 1, c1.data_ptr(), 0x200, st) == 0
+        assert lib.qgtc_last_batched_violation(ctypes.byref(prob), ctypes.byref(field), st) == 1 and field.value == 3
     assert lib.qgtc_chain_aggregate(d(0), d(1), count, M, M, 65, H, b, b, b, 1, c1.data_ptr(), 0, st) == 1     # 4-bit chains: N <= 64
     assert lib.qgtc_chain_from_cols(dX.data_ptr(), dX.numel(), 10, 10, 5, XC.data_ptr(), XC.numel(), st) == 1   # at most four planes
     assert lib.qgtc_chain_from_cols(dX.data_ptr(), dX.numel(), M, F, b, XC.data_ptr(), 3, st) == 2
