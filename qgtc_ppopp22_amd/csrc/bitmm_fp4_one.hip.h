@@ -138,6 +138,11 @@ __global__ __launch_bounds__(64 * ONE_WAVES) void k_bitmm_fp4_one(
 #pragma unroll
                 for (int j = 0; j < CF; j++) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         } else {
+#ifdef QGTC_STAGGER_EXP   // timing-only experiment: the second wave of each SIMD (wv >= 4) out of phase with the first
+            if ((cfg & (1u << 30)) && wv >= 4) __builtin_amdgcn_s_sleep(6);
+            if ((cfg & (1u << 31))) { if (wv >= 4) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); }
+            if ((cfg & (1u << 27)) && wv >= 4) __builtin_amdgcn_s_sleep(12);
+#endif
             uint32_t xo[RF][NDA][4][4], wo[4][4];
             int xs[RF][NDA][4], ws[4];
 #pragma unroll

@@ -25,6 +25,9 @@ static int launch_one(const qgtc_problem &pr, int a, int w, int ob, int mode, bo
 #ifdef QGTC_ABL
                          | (getenv_flag("ABL_X") ? 1u << 28 : 0u) | (getenv_flag("ABL_W") ? 1u << 29 : 0u)
 #endif
+#ifdef QGTC_STAGGER_EXP
+                         | (getenv_flag("STAGGER_SLEEP") ? 1u << 30 : 0u) | (getenv_flag("STAGGER_PRIO") ? 1u << 31 : 0u) | (getenv_flag("STAGGER_SLEEP2") ? 1u << 27 : 0u)
+#endif
         ;
     const uint32_t xb = static_cast<uint32_t>(pr.x_words * 4u), wb = static_cast<uint32_t>(pr.w_words * 4u);
     const uint32_t ob_ = static_cast<uint32_t>(one_out_bytes(pr, ob, mode));
