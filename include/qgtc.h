@@ -206,6 +206,15 @@ int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stag
                            int max_N1, int max_N2, int a_bits, int t_bits, int act_bits, int w_bits, int out_bits,
                            int out_mode, unsigned flags, void *stream);
 
+/* Which kernel family a call takes - host only, no device work: the SAME rule functions the launchers use (qgtc_hip.hip:
+ * single_route / batched_route over the predicates of launch_common.hip.h), so documentation and tests can name the kernel
+ * behind a call shape (DESIGN.md section 5 is generated from these by tools/routing_table.py). mode 0 rows-layout bits, 1
+ * cols-layout bits, 2 float32; flags = the engine / zero-jump / chain flags of the launch. Returns a static string: a kernel
+ * family name ("k_bitmm", "k_bitmm_fp4_one", ...), "refused" (QGTC_EINVAL for chain-format flags no kernel can honour) or
+ * "invalid". */
+const char *qgtc_bitmm_route(int M, int K, int N, int bit1, int bit2, int output_bit, int mode, unsigned flags);
+const char *qgtc_bitmm_batched_route(int max_M, int max_K, int max_N, int bit1, int bit2, int output_bit, int mode, unsigned flags);
+
 /* Adjacency bit planes from an edge list — replaces the dense detour of sampler.py:80-101
  * (torch.sparse.FloatTensor(...).to_dense() then QGTC.val2bit(A, nbits, False, False)): the n x n
  * float matrix (5.9 MB for a 1213-node batch) is never materialised. `cells[i]` = row * W + col of

@@ -12,6 +12,7 @@ int qgtc_launch_mfma_batched(const qgtc_problem *prs, int count, int max_M, int 
                              int ob, int mode, hipStream_t st);
 // defined in qgtc_fp4.hip
 int qgtc_launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, bool zero_skip, hipStream_t st);
+bool qgtc_skinny_is_one(const qgtc_problem &pr, int ob, int mode);
 int qgtc_launch_fp4_wave(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode,
                          bool zero_skip, hipStream_t st);
 int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, hipStream_t st);

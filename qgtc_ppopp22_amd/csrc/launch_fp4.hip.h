@@ -58,6 +58,9 @@ static int launch_one(const qgtc_problem &pr, int a, int w, int ob, int mode, bo
     return QGTC_OK;
 }
 
+// (for qgtc_bitmm_route: which of the two narrow-operand kernels qgtc_launch_skinny picks)
+bool qgtc_skinny_is_one(const qgtc_problem &pr, int ob, int mode) { return one_ok(pr, ob, mode) && !getenv_flag("QGTC_NO_ONE"); }
+
 int qgtc_launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, bool zero_skip, hipStream_t st) {
     if (one_ok(pr, ob, mode) && !getenv_flag("QGTC_NO_ONE")) return launch_one(pr, a, w, ob, mode, zero_skip, st);
     MMShape sh = base_shape(a, w, ob, mode);

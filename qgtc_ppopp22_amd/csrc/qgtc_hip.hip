@@ -178,6 +178,38 @@ int qgtc_bit2val(const uint32_t *bits, size_t bits_words, int nbits, int H, int 
     return QGTC_OK;
 }
 
+// ---- which kernel family a single launch takes (one rule set for the launchers and for qgtc_bitmm_route) ---------------
+enum SingleRoute { RT_FP4_NARROW = 0, RT_FP4_WIDE, RT_MFMA_128, RT_POPCOUNT };
+static SingleRoute single_route(const qgtc_problem &pr, int a, int w, int ob, int mode, unsigned flags) {
+    const bool mf = (flags & QGTC_ENGINE_MFMA) != 0u, au = (flags & QGTC_ENGINE_AUTO) != 0u;
+    if (skinny_ok(pr.K, pr.N, a, w) && (mf || (au && auto_prefers_skinny(pr.M, pr.K, pr.N, a, w)))) return RT_FP4_NARROW;
+    if (wide_ok(pr, a, w, ob, mode) && (mf || (au && auto_prefers_wide(pr.M, pr.K, pr.N, a, w, mode)))) return RT_FP4_WIDE;
+    if ((mf && mfma_ok(a, w)) || (au && auto_prefers_mfma(pr.M, pr.K, pr.N, a, w))) return RT_MFMA_128;
+    return RT_POPCOUNT;
+}
+static int launch_single_route(const qgtc_problem &pr, int a, int w, int ob, int mode, unsigned flags, hipStream_t st) {
+    switch (single_route(pr, a, w, ob, mode, flags)) {
+        case RT_FP4_NARROW: return qgtc_launch_skinny(pr, a, w, ob, mode, !(flags & QGTC_NO_ZERO_SKIP), st);
+        case RT_FP4_WIDE: return qgtc_launch_wide(pr, a, w, ob, mode, st);
+        case RT_MFMA_128: return qgtc_launch_mfma(pr, a, w, ob, mode, st);
+        default: break;
+    }
+    if (flags & QGTC_NO_ZERO_SKIP) return dispatch_single<false>(pr, pr.K, a, w, ob, mode, st);
+    return dispatch_single<true>(pr, pr.K, a, w, ob, mode, st);
+}
+
+const char *qgtc_bitmm_route(int M, int K, int N, int bit1, int bit2, int output_bit, int mode, unsigned flags) {
+    if (M <= 0 || K <= 0 || N <= 0 || !bits_ok(bit1) || !bits_ok(bit2) || mode < 0 || mode > 2 || (mode != 2 && !bits_ok(output_bit))) return "invalid";
+    qgtc_problem pr{nullptr, nullptr, nullptr, qgtc_rows_words(M, K, bit1), qgtc_cols_words(K, N, bit2, 0), M, K, N, pad128(N), 0, nullptr};
+    const int ob = mode == 2 ? 1 : output_bit;
+    switch (single_route(pr, bit1, bit2, ob, mode, flags)) {
+        case RT_FP4_NARROW: return qgtc_skinny_is_one(pr, ob, mode) ? "k_bitmm_fp4_one" : "k_bitmm_fp4_skinny";
+        case RT_FP4_WIDE: return "k_bitmm_fp4_wide";
+        case RT_MFMA_128: return "k_bitmm_mfma";
+        default: return "k_bitmm";
+    }
+}
+
 int qgtc_bitmm2bit(const uint32_t *X, size_t x_words, const uint32_t *W, size_t w_words, int M,
                    int K, int N, int bit1, int bit2, int output_bit, uint32_t *out,
                    size_t out_words, unsigned flags, void *stream) {
@@ -188,16 +220,7 @@ int qgtc_bitmm2bit(const uint32_t *X, size_t x_words, const uint32_t *W, size_t 
     const size_t need = cols ? qgtc_cols_words(M, N, output_bit, 0) : qgtc_rows_words(M, N, output_bit);
     if (out_words < need) return QGTC_ESIZE;
     qgtc_problem pr{X, W, out, x_words, w_words, M, K, N, pad128(N), 0, nullptr};
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (skinny_ok(K, N, bit1, bit2) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_skinny(M, K, N, bit1, bit2))))
-        return qgtc_launch_skinny(pr, bit1, bit2, output_bit, cols ? 1 : 0, !(flags & QGTC_NO_ZERO_SKIP), st);
-    if (wide_ok(pr, bit1, bit2, output_bit, cols ? 1 : 0) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_wide(M, K, N, bit1, bit2, cols ? 1 : 0))))
-        return qgtc_launch_wide(pr, bit1, bit2, output_bit, cols ? 1 : 0, st);
-    if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma(M, K, N, bit1, bit2)))
-        return qgtc_launch_mfma(pr, bit1, bit2, output_bit, cols ? 1 : 0, st);
-    if (flags & QGTC_NO_ZERO_SKIP)
-        return dispatch_single<false>(pr, K, bit1, bit2, output_bit, cols ? 1 : 0, st);
-    return dispatch_single<true>(pr, K, bit1, bit2, output_bit, cols ? 1 : 0, st);
+    return launch_single_route(pr, bit1, bit2, output_bit, cols ? 1 : 0, flags, static_cast<hipStream_t>(stream));
 }
 
 int qgtc_bitmm2int(const uint32_t *X, size_t x_words, const uint32_t *W, size_t w_words, int M,
@@ -208,15 +231,7 @@ int qgtc_bitmm2int(const uint32_t *X, size_t x_words, const uint32_t *W, size_t 
     if (!words_ok(x_words, w_words)) return QGTC_EINVAL;
     if (out_elems < static_cast<size_t>(M) * N) return QGTC_ESIZE;
     qgtc_problem pr{X, W, out, x_words, w_words, M, K, N, pad_128 ? pad128(N) : pad8(N), 0, nullptr};
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (skinny_ok(K, N, bit1, bit2) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_skinny(M, K, N, bit1, bit2))))
-        return qgtc_launch_skinny(pr, bit1, bit2, 1, 2, !(flags & QGTC_NO_ZERO_SKIP), st);
-    if (wide_ok(pr, bit1, bit2, 1, 2) && ((flags & QGTC_ENGINE_MFMA) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_wide(M, K, N, bit1, bit2, 2))))
-        return qgtc_launch_wide(pr, bit1, bit2, 1, 2, st);
-    if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) || ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma(M, K, N, bit1, bit2)))
-        return qgtc_launch_mfma(pr, bit1, bit2, 1, 2, st);
-    if (flags & QGTC_NO_ZERO_SKIP) return dispatch_single<false>(pr, K, bit1, bit2, 1, 2, st);
-    return dispatch_single<true>(pr, K, bit1, bit2, 1, 2, st);
+    return launch_single_route(pr, bit1, bit2, 1, 2, flags, static_cast<hipStream_t>(stream));
 }
 
 int qgtc_bitmm2bit_profile(const uint32_t *X, size_t x_words, const uint32_t *W, size_t w_words,
@@ -262,6 +277,28 @@ int qgtc_tile_counters(const uint32_t *X, size_t x_words, int M, int K, int N, i
     return QGTC_OK;
 }
 
+// ---- which kernel family a grouped launch takes (one rule set for qgtc_bitmm_batched and qgtc_bitmm_batched_route) ------
+enum BatchedRoute { BR_REFUSED = 0, BR_XW_ROWS, BR_STRIP, BR_ROWS, BR_WAVE, BR_MFMA_128, BR_POPCOUNT };
+static BatchedRoute batched_route(int max_M, int max_K, int max_N, int bit1, int bit2, int ob_, int mode, unsigned flags) {
+    const bool engine = (flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) != 0u;
+    const bool rows_route = engine && ((flags & QGTC_ZERO_JUMP) || max_N <= 64 || max_K <= 256) && rows_ok(max_K, max_N, bit1, bit2, ob_, mode);
+    if (flags & (QGTC_CHAIN_CODES_IN | QGTC_CHAIN_CODES_OUT)) {
+        // the first X.W / the last aggregation of a 2-bit chain (quad-major T, bitmm_fp4_chain.hip.h): only the row-block
+        // kernels read and write that order, and a link that cannot would misread its neighbour's buffer - refused instead
+        const bool out_ok = (flags & QGTC_CHAIN_CODES_OUT) && !(flags & QGTC_CHAIN_CODES_IN) && engine && mode == 1 && ob_ == 2 && xw_rows_ok(max_K, max_N, bit1, bit2, ob_);
+        const bool in_ok = (flags & QGTC_CHAIN_CODES_IN) && !(flags & QGTC_CHAIN_CODES_OUT) && mode != 1 && bit2 == 2 && rows_route;
+        if (!out_ok && !in_ok) return BR_REFUSED;
+    }
+    if (engine && mode == 1 && xw_rows_ok(max_K, max_N, bit1, bit2, ob_)) return BR_XW_ROWS;     // X . W stages: row blocks
+    if (engine && mode == 1 && strip_ok(max_M, max_K, bit1, bit2, ob_)) return BR_STRIP;          // X . W stages: column strips
+    if (rows_route) return BR_ROWS;   // sparse left operands / narrow outputs / one or two k-quads: one workgroup per 32-row block
+    if (engine && fp4_wave_ok(max_K, max_N, bit1, bit2)) return BR_WAVE;                           // narrow outputs: one wave per 32 x 32 tile
+    if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) ||  // problems with a one-word bitmap jump zero tiles
+        ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma_batched(max_M, max_N, bit1, bit2)))
+        return BR_MFMA_128;
+    return BR_POPCOUNT;
+}
+
 int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int max_K, int max_N,
                        int bit1, int bit2, int output_bit, int mode, unsigned flags,
                        void *stream) {
@@ -275,35 +312,35 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
         if (crc != QGTC_OK) return crc;
         flags &= ~QGTC_CHECK_DESCRIPTORS;
     }
-    // K is per problem; the split-K factor and chunk size are chosen for the longest K. Any
-    // choice is correct; this only affects speed.
-    const int k_hint = max_K;
     const int ob_ = mode == 2 ? 1 : output_bit;
-    const bool engine = (flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) != 0u;
-    const bool rows_route = engine && ((flags & QGTC_ZERO_JUMP) || max_N <= 64 || max_K <= 256) && rows_ok(max_K, max_N, bit1, bit2, ob_, mode);
-    if (flags & (QGTC_CHAIN_CODES_IN | QGTC_CHAIN_CODES_OUT)) {
-        // the first X.W / the last aggregation of a 2-bit chain (quad-major T, bitmm_fp4_chain.hip.h): only the row-block
-        // kernels read and write that order, and a link that cannot would misread its neighbour's buffer - refused instead
-        const bool out_ok = (flags & QGTC_CHAIN_CODES_OUT) && !(flags & QGTC_CHAIN_CODES_IN) && engine && mode == 1 && ob_ == 2 && xw_rows_ok(max_K, max_N, bit1, bit2, ob_);
-        const bool in_ok = (flags & QGTC_CHAIN_CODES_IN) && !(flags & QGTC_CHAIN_CODES_OUT) && mode != 1 && bit2 == 2 && rows_route;
-        if (!out_ok && !in_ok) return QGTC_EINVAL;
+    const BatchedRoute route = batched_route(max_M, max_K, max_N, bit1, bit2, ob_, mode, flags);
+    switch (route) {
+        case BR_REFUSED: return QGTC_EINVAL;   // (a chain-format link that cannot keep the format would misread its neighbour's buffer)
+        case BR_XW_ROWS: return qgtc_launch_xw_rows(problems, count, max_M, bit1, bit2, ob_, (flags & QGTC_CHAIN_CODES_OUT) != 0u, st);
+        case BR_STRIP: return qgtc_launch_strip(problems, count, max_M, max_N, bit1, bit2, ob_, st);
+        case BR_ROWS: return qgtc_launch_rows(problems, count, max_M, max_N, bit1, bit2, ob_, mode, (flags & QGTC_CHAIN_CODES_IN) != 0u, st);
+        case BR_WAVE: return qgtc_launch_fp4_wave(problems, count, max_M, max_N, bit1, bit2, ob_, mode, !(flags & QGTC_NO_ZERO_SKIP), st);
+        case BR_MFMA_128: return qgtc_launch_mfma_batched(problems, count, max_M, max_K, max_N, bit1, bit2, ob_, mode, st);
+        default: break;
     }
-    if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && mode == 1 && xw_rows_ok(max_K, max_N, bit1, bit2, ob_))   // X . W stages: row blocks
-        return qgtc_launch_xw_rows(problems, count, max_M, bit1, bit2, ob_, (flags & QGTC_CHAIN_CODES_OUT) != 0u, st);
-    if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && mode == 1 && strip_ok(max_M, max_K, bit1, bit2, ob_))   // X . W stages: column strips
-        return qgtc_launch_strip(problems, count, max_M, max_N, bit1, bit2, ob_, st);
-    if (rows_route)   // sparse left operands / narrow outputs / one or two k-quads: one workgroup per 32-row block
-        return qgtc_launch_rows(problems, count, max_M, max_N, bit1, bit2, ob_, mode, (flags & QGTC_CHAIN_CODES_IN) != 0u, st);
-    if ((flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) && fp4_wave_ok(max_K, max_N, bit1, bit2))   // narrow outputs: one wave per 32 x 32 tile
-        return qgtc_launch_fp4_wave(problems, count, max_M, max_N, bit1, bit2, ob_, mode, !(flags & QGTC_NO_ZERO_SKIP), st);
-    if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) ||  // problems with a one-word bitmap jump zero tiles
-        ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma_batched(max_M, max_N, bit1, bit2)))
-        return qgtc_launch_mfma_batched(problems, count, max_M, max_K, max_N, bit1, bit2, ob_, mode, st);
-    if (flags & QGTC_NO_ZERO_SKIP)
-        return dispatch_batched<false, false>(problems, count, max_M, max_N, k_hint, bit1, bit2, ob_, mode, st);
+    // K is per problem; the split-K factor and chunk size are chosen for the longest K. Any choice is correct; this only affects speed.
+    if (flags & QGTC_NO_ZERO_SKIP) return dispatch_batched<false, false>(problems, count, max_M, max_N, max_K, bit1, bit2, ob_, mode, st);
     if (flags & QGTC_ZERO_JUMP)  // the descriptors carry occupancy bitmaps (qgtc_tile_occupancy)
-        return dispatch_batched<true, true>(problems, count, max_M, max_N, k_hint, bit1, bit2, ob_, mode, st);
-    return dispatch_batched<true, false>(problems, count, max_M, max_N, k_hint, bit1, bit2, ob_, mode, st);
+        return dispatch_batched<true, true>(problems, count, max_M, max_N, max_K, bit1, bit2, ob_, mode, st);
+    return dispatch_batched<true, false>(problems, count, max_M, max_N, max_K, bit1, bit2, ob_, mode, st);
+}
+
+const char *qgtc_bitmm_batched_route(int max_M, int max_K, int max_N, int bit1, int bit2, int output_bit, int mode, unsigned flags) {
+    if (max_M <= 0 || max_K <= 0 || max_N <= 0 || !bits_ok(bit1) || !bits_ok(bit2) || mode < 0 || mode > 2 || (mode != 2 && !bits_ok(output_bit))) return "invalid";
+    switch (batched_route(max_M, max_K, max_N, bit1, bit2, mode == 2 ? 1 : output_bit, mode, flags)) {
+        case BR_REFUSED: return "refused";
+        case BR_XW_ROWS: return "k_bitmm_fp4_xw_rows";
+        case BR_STRIP: return "k_bitmm_fp4_strip";
+        case BR_ROWS: return "k_bitmm_fp4_rows";
+        case BR_WAVE: return "k_bitmm_fp4_wave";
+        case BR_MFMA_128: return "k_bitmm_mfma_batched";
+        default: return "k_bitmm_batched";
+    }
 }
 
 int qgtc_gcn_layer_batched(const qgtc_problem *stage1, const qgtc_problem *stage2, int count, int max_M, int max_K1,

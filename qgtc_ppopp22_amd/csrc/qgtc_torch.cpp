@@ -716,7 +716,20 @@ struct EpochPlan {
         int codes;       // kinds 3 / 4: index of the pre-expanded weight (weight_codes)
     };
     std::vector<torch::Tensor> weight_codes;   // qgtc_expand_weights outputs, made by bind()
-    std::vector<torch::Tensor> As, Xs, Xrs;    // per-batch views of the packed batches (the loader route: views into pools)
+    std::vector<torch::Tensor> As, Xs, Xrs;    // per-batch views of the packed batches (the loader route: views into pools), made on first use
+    torch::Tensor pool_a, pool_x, pool_xr;     // the loader route's pools
+    std::vector<int64_t> off_a, off_x, off_xr;
+    int feat_cols = 0, feat_bits = 0;
+    void make_views() {   // 3 x count narrow + view calls: ~1 us each on the host - not inside a pack that an epoch clock may see
+        if (!As.empty() || !pool_a.defined()) return;
+        for (int i = 0; i < count; i++) {
+            const int n = nodes[i];
+            As.push_back(pool_a.narrow(0, off_a[i], off_a[i + 1] - off_a[i]).view({P8(n), S128(n) * 4}));                                              // QGTC_device.cu:115
+            Xs.push_back(pool_x.narrow(0, off_x[i], off_x[i + 1] - off_x[i]).view({static_cast<int64_t>(feat_bits) * S128(n) * 4, P128(feat_cols)}));   // QGTC_device.cu:97
+            if (pool_xr.defined())
+                Xrs.push_back(pool_xr.narrow(0, off_xr[i], static_cast<int64_t>(qgtc_rows_words(n, feat_cols, feat_bits))).view({static_cast<int64_t>(feat_bits) * P8(n), S128(feat_cols) * 4}));
+        }
+    }
     std::vector<qgtc_batch> host_batches;      // the per-batch table as uploaded (format_of)
     EpochPlan() = default;
 
@@ -920,10 +933,6 @@ struct EpochPlan {
             h[i].occ = b.occ;
             h[i].n = n;
             h[i].occ_words = (S128(n) + 63) / 64;
-            P.As.push_back(zero.narrow(0, a_off[i], a_off[i + 1] - a_off[i]).view({P8(n), S128(n) * 4}));                                   // QGTC_device.cu:115
-            P.Xs.push_back(xp.narrow(0, x_off[i], x_off[i + 1] - x_off[i]).view({static_cast<int64_t>(x_bits) * S128(n) * 4, P128(F)}));      // QGTC_device.cu:97
-            if (with_rows)
-                P.Xrs.push_back(xrp.narrow(0, xr_off[i], static_cast<int64_t>(qgtc_rows_words(n, F, x_bits))).view({static_cast<int64_t>(x_bits) * P8(n), S128(F) * 4}));
         }
         // both tables in ONE upload: [qgtc_loader_batch x count | qgtc_batch x count]
         const int64_t lt_bytes = static_cast<int64_t>(count * sizeof(qgtc_loader_batch)), bt_bytes = static_cast<int64_t>(count * sizeof(qgtc_batch));
@@ -948,6 +957,14 @@ struct EpochPlan {
         for (int i = 0; i < count; i++) all += static_cast<double>((ns[i] + 31) / 32) * S128(ns[i]);
         P.occupied = all > 0.0 ? static_cast<double>(set) / all : 1.0;
         P.jumping = P.occupied <= kJumpBelow;
+        P.pool_a = zero;
+        P.pool_x = xp;
+        if (with_rows) P.pool_xr = xrp;
+        P.off_a = a_off;
+        P.off_x = x_off;
+        P.off_xr = xr_off;
+        P.feat_cols = F;
+        P.feat_bits = x_bits;
         P.keep = {zero, tiles, occ, xp, xrp, xcp, tables, src, dst, feats};
         P.host_batches = h;
         return plan;
@@ -1366,9 +1383,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                     "handful of launches (qgtc_load_batches); .As / .Xs / .Xrs are the per-batch packed tensors (views into pools)")
         .def("format_of", &EpochPlan::format_of, py::arg("batch"), py::arg("which"),
              "one batch's operand in a loader format (SRC_A / SRC_X / SRC_XR / SRC_XC / SRC_AT, -1 = occupancy bitmap) as a flat non-owning tensor")
-        .def_readonly("As", &EpochPlan::As)
-        .def_readonly("Xs", &EpochPlan::Xs)
-        .def_readonly("Xrs", &EpochPlan::Xrs)
+        .def_property_readonly("As", [](EpochPlan &p) { p.make_views(); return p.As; })
+        .def_property_readonly("Xs", [](EpochPlan &p) { p.make_views(); return p.Xs; })
+        .def_property_readonly("Xrs", [](EpochPlan &p) { p.make_views(); return p.Xrs; })
         .def("bind", &EpochPlan::bind, py::arg("weights"), py::arg("stages"), py::arg("launches"), py::arg("expand") = std::vector<std::array<int, 5>>(),
              "weights: packed tensors; stages: (left, right, K, N, bit1, bit2, ob, mode, pad128, use_occ, fmt); launches: (kind, s1, s2, flags, "
              "codes); expand: (weight, K, N, nbits, order) per pre-expanded weight")

@@ -133,8 +133,9 @@ class ClusterIter:
         data = self.pack_now(qgtc)
         F = X.size(1)
         e0 = f0 = 0
+        As, Xs, Xrs = data.As, data.Xs, (data.Xrs if self._with_rows else None)   # (views into the pools, made on this first access)
         for i, n in enumerate(ns):
-            ct = ClusterTensor(data.As[i], data.Xs[i], data.Xrs[i] if self._with_rows else None)
+            ct = ClusterTensor(As[i], Xs[i], Xrs[i] if self._with_rows else None)
             if not self.resident:
                 ct = ct.cpu()                                    # sampler.py:104
             self.cTensor_li.append(ct)

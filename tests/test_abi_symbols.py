@@ -120,3 +120,32 @@ def test_epoch_pool_layout_is_host_side(lib, oracle):
     assert total == sum(sizes)
     assert list(offs) == [sum(sizes[:i]) for i in range(len(sizes))]
     assert lib.qgtc_epoch_pool_layout(None, 3, ctypes.addressof(stages), 3, None) == 0
+
+
+def test_route_functions_name_the_kernel_behind_a_call(lib):
+    """qgtc_bitmm_route / qgtc_bitmm_batched_route: host-only, the SAME rule functions the launchers switch on (qgtc_hip.hip:
+    single_route / batched_route), so the routing table of DESIGN.md (tools/routing_table.py) cannot drift from the code."""
+    lib.qgtc_bitmm_route.restype = lib.qgtc_bitmm_batched_route.restype = ctypes.c_char_p
+    POP, MFMA, AUTO, JUMP, CODES_OUT = 0x0, 0x8, 0x10, 0x4, 0x100
+    r = lambda *a: lib.qgtc_bitmm_route(*a).decode()             # noqa: E731
+    g = lambda *a: lib.qgtc_bitmm_batched_route(*a).decode()     # noqa: E731
+    # bench.py's step (BASELINE.json configs[1]): the FP4 narrow-operand kernel on the default engine, AND + popcount when asked
+    assert r(4096, 4096, 64, 1, 1, 1, 0, AUTO) == "k_bitmm_fp4_one" and r(4096, 4096, 64, 1, 1, 1, 0, POP) == "k_bitmm"
+    assert r(4096, 4096, 64, 1, 8, 8, 0, AUTO) == "k_bitmm_fp4_one"
+    assert r(32768, 32768, 64, 1, 1, 1, 0, AUTO) == "k_bitmm_fp4_skinny"           # K > 4096
+    assert r(4096, 4096, 1024, 1, 1, 1, 0, AUTO) == "k_bitmm_fp4_wide"
+    assert r(4096, 4096, 64, 8, 8, 8, 0, AUTO) == "k_bitmm_mfma"                   # 4096 * 255 * 255 >= 2^24: int8 form, int32 sums
+    assert r(512, 512, 64, 9, 2, 4, 0, MFMA) == "k_bitmm"                          # nine planes: AND + popcount only
+    assert r(0, 4, 4, 1, 1, 1, 0, AUTO) == "invalid" and r(4, 4, 4, 1, 1, 1, 3, AUTO) == "invalid"
+    assert g(1213, 128, 128, 2, 2, 2, 1, AUTO) == "k_bitmm_fp4_xw_rows"
+    assert g(1213, 1213, 128, 1, 2, 2, 0, AUTO | JUMP) == "k_bitmm_fp4_rows"
+    assert g(1213, 1213, 128, 1, 2, 2, 0, POP | JUMP) == "k_bitmm_batched"
+    assert g(1213, 128, 512, 2, 2, 2, 1, AUTO | CODES_OUT) == "refused"            # -> QGTC_EINVAL from qgtc_bitmm_batched
+    # the table in DESIGN.md is this tool's output
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "routing_table.py")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "k_bitmm_fp4_one" in out.stdout
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for line in out.stdout.strip().splitlines():
+        assert line in design, "DESIGN.md's routing table is stale: re-run tools/routing_table.py\n" + line

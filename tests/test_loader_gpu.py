@@ -46,13 +46,14 @@ def test_grouped_loader_equals_the_oracle_and_the_single_batch_entries(qgtc, ora
     plan = qgtc.EpochPlan.load(src, dst, ecounts, X, sizes, bits, True, chain, True, True)
     torch.cuda.synchronize()
     tiles_occupied = tiles_all = 0
+    pA, pX, pXr = plan.As, plan.Xs, plan.Xrs
     for i, n in enumerate(sizes):
         A = _dense(n, rows[i], cols[i])
         oA = oracle.val2bit(A, 1)
-        np.testing.assert_array_equal(to_np_u32(plan.As[i]), oA, err_msg=f"A of batch {i}")
-        np.testing.assert_array_equal(to_np_u32(plan.Xs[i]), oracle.val2bit(feats[i], bits, True), err_msg=f"X (cols) of batch {i}")
-        np.testing.assert_array_equal(to_np_u32(plan.Xrs[i]), oracle.val2bit(feats[i], bits, False), err_msg=f"X (rows) of batch {i}")
-        assert plan.As[i].shape == (oracle.rows_words(n, n, 1) // ((n + 127) // 128 * 4), (n + 127) // 128 * 4)
+        np.testing.assert_array_equal(to_np_u32(pA[i]), oA, err_msg=f"A of batch {i}")
+        np.testing.assert_array_equal(to_np_u32(pX[i]), oracle.val2bit(feats[i], bits, True), err_msg=f"X (cols) of batch {i}")
+        np.testing.assert_array_equal(to_np_u32(pXr[i]), oracle.val2bit(feats[i], bits, False), err_msg=f"X (rows) of batch {i}")
+        assert pA[i].shape == (oracle.rows_words(n, n, 1) // ((n + 127) // 128 * 4), (n + 127) // 128 * 4)
         # the formats of the grouped epoch against the single-batch entries on the SAME packed tensors
         dA = torch.from_numpy(oA.view(np.int32)).cuda()
         lib_tiles = _adj_tiles(qgtc, dA, n)
@@ -62,7 +63,7 @@ def test_grouped_loader_equals_the_oracle_and_the_single_batch_entries(qgtc, ora
         tiles_occupied += int(sum(bin(int(w) & (2 ** 64 - 1)).count("1") for w in occ.cpu().numpy().view(np.uint64)))
         tiles_all += ((n + 31) // 32) * ((n + 127) // 128)
         if chain:
-            assert torch.equal(plan.format_of(i, qgtc.SRC_XC), _chain_from_cols(qgtc, plan.Xs[i], n, F, bits)), f"X (chain) of batch {i}"
+            assert torch.equal(plan.format_of(i, qgtc.SRC_XC), _chain_from_cols(qgtc, pX[i], n, F, bits)), f"X (chain) of batch {i}"
     assert abs(plan.occupied_fraction - tiles_occupied / tiles_all) < 1e-12
     # out-of-range indices: skipped, and reported when asked
     bad_src = src.clone()
