@@ -831,3 +831,48 @@ def test_layer_plan_survives_engine_changes_between_runs(qgtc, oracle):
         for o, w in zip(g2.outs, want):
             np.testing.assert_array_equal(o.cpu().numpy(), w, err_msg=eng)
     qgtc.set_engine("auto")
+
+
+def test_lean_and_checked_entry_points_agree(qgtc, oracle):
+    """The four per-batch operators are METH_FASTCALL functions (qgtc_torch.cpp, namespace lean) that skip pybind11's casters,
+    the dispatcher and the device guard for the plain good case; the pybind11 functions stay reachable as QGTC.checked_*. Same
+    tensors (dtype, shape, words) from both on every engine, the reference's call forms included (7-argument bitMM2Int, defaulted
+    trailing bools, keywords - which the lean entries hand to the checked ones), and the same exceptions for bad calls."""
+    import torch
+    rng = np.random.default_rng(12)
+    for engine in ("auto", "popcount", "mfma"):
+        with use_engine(qgtc, engine):
+            for (M, K, N, a, w, ob) in ((300, 300, 64, 1, 2, 2), (37, 130, 10, 2, 2, 2), (1213, 128, 128, 2, 2, 2), (64, 4100, 33, 1, 1, 3), (9, 9, 9, 3, 5, 4)):
+                x = torch.from_numpy(rng.uniform(-1, 2 ** a + 1, size=(M, K)).astype(np.float32)).cuda()
+                y = torch.from_numpy(rng.uniform(-1, 2 ** w + 1, size=(K, N)).astype(np.float32)).cuda()
+                for args in ((a, False, False), (a, True, False), (a, True, True), (a,)):
+                    p, q = qgtc.val2bit(x, *args), qgtc.checked_val2bit(x, *args)
+                    assert p.dtype == q.dtype and p.shape == q.shape and torch.equal(p, q)
+                bx, bw = qgtc.val2bit(x, a, False, False), qgtc.val2bit(y, w, True, False)
+                np.testing.assert_array_equal(to_np_u32(bx), oracle.val2bit(x.cpu().numpy(), a, False, False))
+                for lean, checked in ((qgtc.bitMM2Bit, qgtc.checked_bitMM2Bit), (qgtc.bitMM2Bit_col, qgtc.checked_bitMM2Bit_col)):
+                    p, q = lean(bx, bw, M, K, N, a, w, ob), checked(bx, bw, M, K, N, a, w, ob)
+                    assert p.dtype == torch.int32 and p.shape == q.shape and torch.equal(p, q)
+                for tail in ((), (False,), (True,)):
+                    p, q = qgtc.bitMM2Int(bx, bw, M, K, N, a, w, *tail), qgtc.checked_bitMM2Int(bx, bw, M, K, N, a, w, *tail)
+                    assert p.dtype == torch.float32 and tuple(p.shape) == (M, N) and torch.equal(p, q)
+                assert torch.equal(qgtc.bitMM2Int(bx, bw, M, K, N, a, w, pad_128=True), qgtc.checked_bitMM2Int(bx, bw, M, K, N, a, w, True))
+                assert torch.equal(qgtc.val2bit(x, nbits=a, col_major=True), qgtc.checked_val2bit(x, a, True, False))
+    # bad calls raise the pybind11 functions' exceptions
+    bx = qgtc.val2bit(torch.ones((8, 8)).cuda(), 1, False, False)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        qgtc.bitMM2Bit(bx.cpu(), bx, 8, 8, 8, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="int32"):
+        qgtc.bitMM2Bit(bx.float(), bx, 8, 8, 8, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        qgtc.bitMM2Bit(bx.t(), bx, 8, 8, 8, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="bad dimensions"):
+        qgtc.bitMM2Bit(bx, bx, 0, 8, 8, 1, 1, 1)
+    with pytest.raises(RuntimeError):
+        qgtc.bitMM2Bit(bx, bx, 8, 8, 8, 1, 1, 40)          # output_bit beyond 32
+    with pytest.raises(TypeError):
+        qgtc.bitMM2Bit(bx, bx, 8, 8, 8, 1, 1)              # the reference's binding has no default here either
+    with pytest.raises(TypeError):
+        qgtc.bitMM2Bit(bx, bx, 8.5, 8, 8, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="float32"):
+        qgtc.val2bit(bx, 1, False, False)
