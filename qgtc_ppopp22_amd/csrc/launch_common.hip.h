@@ -15,6 +15,7 @@ int qgtc_launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, b
 bool qgtc_skinny_is_one(const qgtc_problem &pr, int ob, int mode);
 int qgtc_launch_fp4_wave(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode,
                          bool zero_skip, hipStream_t st);
+int qgtc_launch_fp4_wave_single(const qgtc_problem &pr, int a, int w, int ob, int mode, bool zero_skip, hipStream_t st);
 int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, hipStream_t st);
 int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode, bool qmajor_in, hipStream_t st);
 int qgtc_launch_xw_rows(const qgtc_problem *prs, int count, int max_M, int a, int w, int ob, bool qmajor_out, hipStream_t st);
@@ -203,6 +204,14 @@ inline bool rbw_chain_ok(int max_K, int N1, int N2, int t_bits, int act_bits, in
 inline bool fp4_wave_ok(int K, int N, int a, int w) {
     return N <= 64 && a <= 4 && w <= 8 && static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
 }
+
+// single launches with three or four left-hand planes and a narrow right operand: one wave per 32 x 32 tile (k_bitmm_fp4_wave_single).
+// QGTC_ENGINE_AUTO takes it for SMALL products only (the per-batch 4 x 4-bit products of the Batched-GIN chain: a few dozen tiles, one or
+// two super-steps of K each - launch-bound, where the 16-pass popcount kernel is not); larger ones keep the cost models below
+inline bool wave_single_ok(int M, int K, int N, int a, int w, int ob, int mode) {
+    return a > 2 && a <= 4 && w <= 8 && fp4_wave_ok(K, N, a, w) && (mode == 2 || (ob >= 1 && ob <= 23)) && M < (1 << 24) && !getenv_flag("QGTC_NO_WAVE1");
+}
+inline bool auto_prefers_wave_single(int M, int K, int N) { return static_cast<double>(M) * K * N <= 1213.0 * 1213.0 * 64.0; }
 
 // the MFMA engine handles up to 8 planes per operand (8: offset by 128, corrected in the epilogue)
 inline bool mfma_ok(int a, int w) { return a >= 1 && a <= 8 && w >= 1 && w <= 8; }

@@ -112,6 +112,26 @@ int qgtc_launch_fp4_wave(const qgtc_problem *prs, int count, int max_M, int max_
 }
 
 
+int qgtc_launch_fp4_wave_single(const qgtc_problem &pr, int a, int w, int ob, int mode, bool zero_skip, hipStream_t st) {
+    MMShape sh = base_shape(a, w, ob, mode);
+    sh.nowrap = 1;
+    const int zs = zero_skip ? 1 : 0;
+    const dim3 grid(((pr.M + 31) / 32) * ((pr.N + 31) / 32));   // 32 x 32 outputs per wave
+#define QGTC_FW1_LAUNCH(NA_, NW_)                                                                                       \
+    if (!done && a <= NA_ && w <= NW_) {                                                                                \
+        done = true;                                                                                                    \
+        if (mode == 2) hipLaunchKernelGGL((k_bitmm_fp4_wave_single<NA_, NW_, 2, 2, 2>), grid, dim3(64), 0, st, pr, sh, zs);      \
+        else if (mode == 1) hipLaunchKernelGGL((k_bitmm_fp4_wave_single<NA_, NW_, 1, 2, 2>), grid, dim3(64), 0, st, pr, sh, zs); \
+        else hipLaunchKernelGGL((k_bitmm_fp4_wave_single<NA_, NW_, 0, 2, 2>), grid, dim3(64), 0, st, pr, sh, zs);                \
+    }
+    bool done = false;
+    QGTC_FW1_LAUNCH(4, 4) QGTC_FW1_LAUNCH(4, 8)
+#undef QGTC_FW1_LAUNCH
+    if (!done) return QGTC_EINVAL;
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
 // grouped "X . W" stages with one k-quad of K and cols-layout output: one workgroup per 32-column strip (bitmm_fp4_strip.hip.h)
 int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, 1);
