@@ -21,9 +21,15 @@ def main():
     import QGTC as Q
 
     gin = os.environ.get("QGTC_SHARD_TEST_GIN") == "1"
-    res, _ = bench.epoch_leg(Q, rank, world, 0, dataset="tiny", bits=4 if gin else 2, hidden=64, gin=gin, full=False, psize=40,
-                             batch_size=4, only=("batched_correct_chain",))
-    print("SHARD_RESULT " + json.dumps({"rank": rank, "world": world, "res": res}), flush=True)
+    kw = dict(dataset="tiny", bits=4 if gin else 2, hidden=64, gin=gin, full=False, psize=40, batch_size=4, only=("batched_correct_chain",))
+    res, _ = bench.epoch_leg(Q, rank, world, 0, **kw)
+    # the same exchange with the REAL payload (--gather outputs: the per-batch float outputs, padded), and the weak-scaled leg
+    # (every rank all ten batches of its own graph, seed 2 + rank)
+    res_out, _ = bench.epoch_leg(Q, rank, world, 0, gather="outputs", **kw)
+    res_weak, _ = bench.epoch_leg(Q, rank, world, 0, weak=True, **kw)
+    res_weak_out, _ = bench.epoch_leg(Q, rank, world, 0, weak=True, gather="outputs", **kw)
+    print("SHARD_RESULT " + json.dumps({"rank": rank, "world": world, "res": res, "res_outputs": res_out, "res_weak": res_weak,
+                                        "res_weak_outputs": res_weak_out}), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

@@ -85,3 +85,19 @@ def test_two_live_ranks_gather_the_unsharded_epoch(two_rank_runs, gin):
         assert r["res"]["gathered_summaries"] == want, f"rank {r['rank']}"
         assert r["res"]["batched_correct_chain_ms"] > 0
     assert res[0]["res"]["batched_correct_chain_ms"] == res[1]["res"]["batched_correct_chain_ms"]   # the MAX over ranks
+    # --gather outputs: the float outputs themselves travelled (padded to the largest batch): the same (sum, numel) table from them
+    max_n = max(o.size(0) for o in outs)
+    for r in res:
+        ro = r["res_outputs"]
+        assert ro["gathered_batches"] == 10 and ro["gathered_output_bytes"] == 10 * max_n * outs[0].size(1) * 4
+        assert ro["gathered_summaries"] == want, f"rank {r['rank']} (outputs)"
+    # weak scaling: every rank ran all ten batches of ITS OWN graph (seed 2 + rank); 20 rows, rank-major, rank 0's = the unsharded run's
+    from qgtc_ppopp22_amd import graph as G
+    outs1 = driver.run(args, Q=Q, graph=G.make_graph("tiny", 40, seed=3))["outs"]
+    want1 = bench.batch_summaries(outs1).cpu().tolist()
+    assert want1 != want
+    for r in res:
+        for key in ("res_weak", "res_weak_outputs"):
+            rw = r[key]
+            assert rw["gathered_batches"] == 20, key
+            assert rw["gathered_summaries"][:10] == want and rw["gathered_summaries"][10:] == want1, f"rank {r['rank']} ({key})"
