@@ -110,8 +110,8 @@ EVENT_MIN_LAUNCHES = 200     # launches in the HIP-event window behind the timed
 def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams=1):
     """warmup untimed launches, then EXACTLY `steps` launches between barrier+synchronize pairs (the contract's timed
     region: wall seconds), then the SAME `steps` launches once more between two HIP events recorded on the stream the
-    kernels are launched on (the roofline's live launch duration). Returns (wall seconds, mean stream time per launch in
-    seconds, wall seconds of the event-bracketed region).
+    kernels are launched on, and max(1, K // 200) event-bracketed windows of 200 launches (the roofline's live launch duration: their
+    mean). Returns (wall seconds, mean stream time per launch in seconds, wall seconds of the event-bracketed K-launch region).
     Why two regions: recording the two events INSIDE the timed region costs 11-12 us of its wall clock whatever the host's
     wait policy (tools/steps20c.py: 84 us with them, 72 us without, for 20 launches that take 63 us on the stream) - the
     instrument would be a seventh of the measurement. The second region is issued right behind the first, same buffers,
@@ -148,15 +148,21 @@ def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams
     ev1.record()
     torch.cuda.synchronize()
     t3 = time.perf_counter()
-    per_launch = ev0.elapsed_time(ev1) * 1e-3 / steps
-    if steps < EVENT_MIN_LAUNCHES:
-        # a window of a few launches is mostly its own start-up (the first launch's latency, the event markers): the
-        # dominant kernel's AVERAGE launch duration comes from a window long enough to average over
+    # The dominant kernel's AVERAGE launch duration: windows of EVENT_MIN_LAUNCHES launches, each between its own pair of events and
+    # drained before the next - max(1, K // EVENT_MIN_LAUNCHES) of them, averaged. A window of a few launches is mostly its own
+    # start-up (the first launch's latency, the event markers); ONE window of a thousand launches and more between two timing events
+    # is an instrument artefact of the other kind (r04: 3.5 / 4.9 / 3.7 us per launch on three runs while the event-free region
+    # beside it ran at 3.0; r03's single sample had read 3.0 - tools/event_windows.py: a box whose chip has idled for 10 ms can stay
+    # 20-30 % slower on event-bracketed work for seconds while an event-free region beside it runs at full speed).
+    windows = max(1, steps // EVENT_MIN_LAUNCHES)
+    per_window = []
+    for _ in range(windows):
         ev0.record()
         enqueue(EVENT_MIN_LAUNCHES)
         ev1.record()
         torch.cuda.synchronize()
-        per_launch = ev0.elapsed_time(ev1) * 1e-3 / EVENT_MIN_LAUNCHES
+        per_window.append(ev0.elapsed_time(ev1) * 1e-3 / EVENT_MIN_LAUNCHES)
+    per_launch = sum(per_window) / len(per_window)
     return t1 - t0, per_launch, t3 - t2
 
 
@@ -692,10 +698,11 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_bitmm_fp4_one<1,%d,0,2,2>" % ({1: 1, 2: 2}.get(w, 4 if w <= 4 else 8)),
                     "achieved": round(algo_bytes / kern / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac_hbm,
                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(algo_bytes),
-                    "avg_launch_us": round(kern * 1e6, 3), "avg_launch_window": max(args.steps, EVENT_MIN_LAUNCHES),
-                    "avg_launch_source": "HIP events on the launch stream around max(K, %d) of the same launches issued right behind the timed "
-                                         "region (inside it the two event records cost 11-12 us of a 72 us window), divided by their "
-                                         "number: kernel + dependent-launch gap (~1.5 us), i.e. what a caller gets per launch" % EVENT_MIN_LAUNCHES,
+                    "avg_launch_us": round(kern * 1e6, 3),
+                    "avg_launch_window": "%d x %d launches" % (max(1, args.steps // EVENT_MIN_LAUNCHES), EVENT_MIN_LAUNCHES),
+                    "avg_launch_source": "HIP events on the launch stream around windows of %d of the same launches issued right behind the timed "
+                                         "region (inside it the two event records cost 11-12 us of a 72 us window), max(1, K // %d) windows "
+                                         "averaged: kernel + dependent-launch gap (~1.5 us), i.e. what a caller gets per launch" % (EVENT_MIN_LAUNCHES, EVENT_MIN_LAUNCHES),
                     "wall_ms_per_step_of_the_event_bracketed_region": round(wall_ev * 1e3 / args.steps, 6),
                     "frac_hbm": frac_hbm, "frac_mfma": round(eff_ops / kern / 1e12 / FP4_PEAK_TFLOPS, 5),
                     "floors_us": {"hbm": round(hbm_floor_us, 3), "mfma_fp4": round(mfma_floor_us, 3)},
