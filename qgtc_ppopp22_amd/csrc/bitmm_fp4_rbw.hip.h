@@ -217,6 +217,36 @@ __device__ __forceinline__ void rbw_store_codes(const f32x16 &acc, uint32_t *__r
 #endif
 }
 
+
+// float32 rows from a swapped product's accumulators: lane (fl, fh) holds of ITS row the columns col0 + 8 g + 4 fh + t in register
+// 4 g + t. Four consecutive columns are ONE 16-byte store where they exist (rows of 4 N bytes are only 4-byte aligned - N = 10 classes;
+// buffer stores take any dword alignment), a row's tail is an 8- and / or a 4-byte store. The first form stored every element on its
+// own whenever N % 4 != 0: ten 4-byte store instructions a row for the 10-class output layer, 0.9 us of its 4.45 us launch
+// (timing-only build, tools/rbw_bench).
+// BRANCH-FREE per lane: a lane that has nothing to store (row past M, columns past N) gets the offset 0xffffffff and the range check
+// drops it; the only branches are on wave-uniform column counts. With a per-lane `if (m < M)` around the stores hipcc sank the second
+// product's LDS reads and MFMAs INTO the branch - and an MFMA takes its operands from ALL lanes: the rows past M then supplied garbage
+// as W' lines (wrong columns 32 jn + fl for every fl past the last valid row of the block).
+__device__ __forceinline__ void rbw_store_f32_row(__amdgpu_buffer_rsrc_t ro, uint32_t row_off /* bytes, 0xffffffff = no row */, const f32x16 &acc,
+                                                  int col0, int fh, int N) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int rem0 = N - (col0 + 8 * g);        // wave-uniform: columns left from the half fh = 0's first one
+        if (rem0 <= 0) break;
+        const int rem = rem0 - 4 * fh;              // per lane
+        const uint32_t off = row_off == 0xffffffffu ? 0xffffffffu : row_off + static_cast<uint32_t>(col0 + 8 * g + 4 * fh) * 4u;
+        const u32x4 v = {__float_as_uint(acc[4 * g]), __float_as_uint(acc[4 * g + 1]), __float_as_uint(acc[4 * g + 2]), __float_as_uint(acc[4 * g + 3])};
+        if (rem0 >= 8) {
+            __builtin_amdgcn_raw_buffer_store_b128(v, ro, off, 0, 0);
+        } else {
+            const bool row = off != 0xffffffffu;   // (off + 8 below must not wrap a missing row's offset back into the buffer)
+            __builtin_amdgcn_raw_buffer_store_b128(v, ro, rem >= 4 ? off : 0xffffffffu, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{v.x, v.y}, ro, (rem == 2 || rem == 3) ? off : 0xffffffffu, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(rem == 3 ? v.z : v.x, ro, row && rem == 3 ? off + 8u : (rem == 1 ? off : 0xffffffffu), 0, 0);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // T = requant(X . W) for every cluster batch (main_qgtc.py:147, layout-correct form): X = packed rows-layout planes (K <=
 // 128), W pre-expanded (order 0), T in the chain format. A workgroup = four row blocks (one k-quad of T), a wave = one.
@@ -516,23 +546,10 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
 #endif
     RBW_STAMP(5);
     if constexpr (MODE2 == 0) {   // float32 [M, N] (kernel.h:915-930): registers 4 g .. 4 g + 3 are four consecutive columns of row m
-        if (m < M) {
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(pr.out, 0, static_cast<int>(static_cast<uint32_t>(M) * static_cast<uint32_t>(N) * 4u), 0x00020000);
+        const uint32_t row_off = m < M ? static_cast<uint32_t>(m) * static_cast<uint32_t>(N) * 4u : 0xffffffffu;
 #pragma unroll
-            for (int j = 0; j < NCB1; j++) {
-                float *dst = static_cast<float *>(pr.out) + static_cast<size_t>(m) * N + 32 * j;
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int e = 8 * g + 4 * fh;
-                    if ((N & 3) == 0 && 32 * j + e + 3 < N) {
-                        *reinterpret_cast<f32x4 *>(dst + e) = f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 4; t++)
-                            if (32 * j + e + t < N) dst[e + t] = acc[j][4 * g + t];   // (non-temporal here: 4.5 -> 5.8 us - partial lines go out one by one)
-                    }
-                }
-            }
-        }
+        for (int j = 0; j < NCB1; j++) rbw_store_f32_row(ro, row_off, acc[j], 32 * j, fh, N);
         return;
     } else {
         // ---- the aggregate's row as the second product's left operand, straight from the registers
@@ -563,15 +580,24 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
             f32x16 acc2 = f32x16_zero();
 #pragma unroll
             for (int mm = 0; mm < MH; mm++) {
+                // T' (MODE2 1): not swapped - lane = column 32 jn + fl of T', 16 rows in its registers: what a chain-format line takes.
+                // float32 rows (MODE2 2): SWAPPED - lane = row fl, registers 4 g .. 4 g + 3 = four consecutive columns, stored as vectors
+                // (rbw_store_f32_row; unswapped, a lane stored its column's 16 rows one float at a time: 16 store instructions per
+                // column block, 40 useful bytes each at 10 classes)
                 if constexpr (ND == 1) {
-                    acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_op(XA[mm][0], XA[mm][1], XA[mm][2], XA[mm][3]), fp4_op(w2_lds[(jn * 2 + mm) * 64 + lane]), acc2, 4, 4, 0, 128, 0, 128);   // not swapped: lane = column 32 jn + fl of T'
+                    const i32x8 xa = fp4_op(XA[mm][0], XA[mm][1], XA[mm][2], XA[mm][3]), wb = fp4_op(w2_lds[(jn * 2 + mm) * 64 + lane]);
+                    if constexpr (MODE2 == 2) acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb, xa, acc2, 4, 4, 0, 128, 0, 128);
+                    else acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa, wb, acc2, 4, 4, 0, 128, 0, 128);
                 } else {   // 4-bit aggregate x 4-bit W': two base-4 digits each, the E8M0 scales carry 4^(da + dw)
 #pragma unroll
                     for (int da = 0; da < 2; da++) {
                         const i32x8 xa = fp4_op((XA[mm][0] >> (2 * da)) & 0x33333333u, (XA[mm][1] >> (2 * da)) & 0x33333333u, (XA[mm][2] >> (2 * da)) & 0x33333333u, (XA[mm][3] >> (2 * da)) & 0x33333333u);
 #pragma unroll
-                        for (int dw = 0; dw < 2; dw++)
-                            acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa, fp4_op(w2_lds[((jn * 2 + mm) * 2 + dw) * 64 + lane]), acc2, 4, 4, 0, 128 + 2 * da, 0, 128 + 2 * dw);
+                        for (int dw = 0; dw < 2; dw++) {
+                            const i32x8 wb = fp4_op(w2_lds[((jn * 2 + mm) * 2 + dw) * 64 + lane]);
+                            if constexpr (MODE2 == 2) acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb, xa, acc2, 4, 4, 0, 128 + 2 * dw, 0, 128 + 2 * da);
+                            else acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa, wb, acc2, 4, 4, 0, 128 + 2 * da, 0, 128 + 2 * dw);
+                        }
                     }
                 }
             }
@@ -581,13 +607,8 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
         for (int jn = 0; jn < NCB2; jn++) {
             const f32x16 &acc2 = acc2s[jn];
             const int n2 = 32 * jn + fl;
-            if constexpr (MODE2 == 2) {   // float32 rows; branch-free stores (see bitmm_fp4_chain.hip.h: an MFMA reads all lanes' operands)
-                const uint32_t base = n2 < N2 ? (static_cast<uint32_t>(32 * rb) * static_cast<uint32_t>(N2) + static_cast<uint32_t>(n2)) * 4u : 0xffffffffu;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc2[r]), ro2, (base != 0xffffffffu && 32 * rb + row < M) ? base + static_cast<uint32_t>(row) * static_cast<uint32_t>(N2) * 4u : 0xffffffffu, 0, 0);
-                }
+            if constexpr (MODE2 == 2) {   // float32 rows of the swapped product: lane = row m, columns 32 jn + 8 g + 4 fh + t in register 4 g + t
+                rbw_store_f32_row(ro2, m < M ? static_cast<uint32_t>(m) * static_cast<uint32_t>(N2) * 4u : 0xffffffffu, acc2, 32 * jn, fh, N2);
             } else {
                 rbw_store_codes<OB2>(acc2, tbase + static_cast<size_t>(n2) * 4, fh, n2 < lines2);
             }

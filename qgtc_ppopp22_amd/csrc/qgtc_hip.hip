@@ -439,6 +439,8 @@ int qgtc_chain_aggregate(const qgtc_problem *stage_a, const qgtc_problem *stage_
     if (out_mode < 0 || out_mode > 2 || (out_mode != 0 && (!stage_xw || !w2_codes))) return QGTC_EINVAL;
     if (!rbw_chain_ok(max_K, N1, N2, t_bits, act_bits, out_bits, out_mode) || getenv_flag("QGTC_NO_RBW")) return QGTC_EINVAL;
     if (w2_codes && !aligned16(w2_codes)) return QGTC_EALIGN;
+    // (float32 outputs are written through a buffer descriptor with a 32-bit extent)
+    if (out_mode != 1 && static_cast<unsigned long long>(max_M) * static_cast<unsigned long long>(out_mode == 0 ? N1 : N2) * 4ull >= (1ull << 31)) return QGTC_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (flags & QGTC_CHECK_DESCRIPTORS) {
         const int crc = out_mode == 0 ? qgtc_launch_check_descriptors(stage_a, nullptr, count, max_M, max_K, N1, 0, 0, 0, st, N1, 0)

@@ -191,6 +191,19 @@ int main(int argc, char **argv) {
             if (!rc) rc = qgtc_chain_aggregate(st6[5], nullptr, count, n, n, C, 0, 2, 0, 0, 0, nullptr, 0, st);
             return rc;
         };
+        {   // the transform launch (X . W1) on its own
+            float bx = 1e9f;
+            for (int rep = 0; rep < 5; rep++) {
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < 200; i++) qgtc_chain_transform(st6[0], count, n, F, H, 2, 2, c1, 0, st);
+                CK(hipEventRecord(e1, st));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                bx = std::min(bx, ms);
+            }
+            printf("chain transform X.W1 alone: %.2f us per launch (200 eager launches, best of 5)\n", bx * 1e3 / 200);
+        }
         for (int variant = 0; variant < 1; variant++) {
             if (int rc = four()) { printf("epoch variant %d rc=%d %s\n", variant, rc, qgtc_strerror(rc)); continue; }
             CK(hipStreamSynchronize(st));
