@@ -276,15 +276,15 @@ __global__ __launch_bounds__(64 * ONE_WAVES) void k_bitmm_fp4_one(
     }
     ONE_STAMP(5);
     if (MODE == 2) {   // float32 [M,N] (reference kernel.h:915-930): four consecutive columns of a row
-        if (n_valid == 4 && (N & 3) == 0) {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum), ro, o_off, 0, 0);
+        // one store for a lane's four columns whatever N is (rows of 4 N bytes are dword-aligned only when N % 4 != 0 - the 10-class
+        // output layer; buffer stores take any dword alignment), a two- and / or a one-float store for a row's tail
+        const u32x4 v4 = __builtin_bit_cast(u32x4, sum);
+        if (n_valid == 4) {
+            __builtin_amdgcn_raw_buffer_store_b128(v4, ro, o_off, 0, 0);
         } else {
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-                if (e < n_valid) {
-                    const float v = sum[e];   // (bit-casting the vector element expression itself stores element 0)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, o_off + 4u * e, 0, 0);
-                }
+            if (n_valid >= 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2{v4.x, v4.y}, ro, o_off, 0, 0);
+            if (n_valid == 3) __builtin_amdgcn_raw_buffer_store_b32(v4.z, ro, o_off + 8u, 0, 0);
+            if (n_valid == 1) __builtin_amdgcn_raw_buffer_store_b32(v4.x, ro, o_off, 0, 0);
         }
     } else {
         // requantise (kernel.h:31-37,350: c > 2^ob ? 2^ob - 1 : c; the sums are exact integers in [0, 2^24) and

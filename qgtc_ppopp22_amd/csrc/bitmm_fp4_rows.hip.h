@@ -170,8 +170,10 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const int e = 8 * g + 4 * fh;
-                    if ((N & 3) == 0 && n0 + 32 * j + e + 3 < N) {   // one 16-byte store (scalar stores of a column run over 32 rows x 512 bytes)
-                        *reinterpret_cast<f32x4 *>(dst + e) = f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                    if (n0 + 32 * j + e + 3 < N) {   // one 16-byte store (scalar stores of a column run over 32 rows x 512 bytes); rows of 4 N
+                        // bytes are only dword-aligned when N % 4 != 0 (10 classes): the vector type says so, global stores take it
+                        typedef float f32x4_u4 __attribute__((ext_vector_type(4), aligned(4)));
+                        *reinterpret_cast<f32x4_u4 *>(dst + e) = f32x4_u4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
                     } else {
 #pragma unroll
                         for (int t = 0; t < 4; t++)
