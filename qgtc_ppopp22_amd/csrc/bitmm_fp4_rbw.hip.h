@@ -200,14 +200,19 @@ __device__ __forceinline__ void rbw_nibbles(const uint32_t (&P)[4], uint32_t &A,
 // codes of word (rb & 3) of line n2 of T' from the 16 values a lane holds of column n2 (not swapped: rows t + 8 gq + 4 fh)
 template <int OB>
 __device__ __forceinline__ void rbw_store_codes(const f32x16 &acc, uint32_t *__restrict__ dst, int fh, bool ok) {
+    uint32_t x[4];
+#ifdef QGTC_ABL_NOEPI   // timing-only (wrong codes): what do the re-quantisation, the packing and the half-wave exchange of a column block cost?
+#pragma unroll
+    for (int t = 0; t < 4; t++) x[t] = __float_as_uint(acc[t]);
+#else
     uint32_t qv[16], P[4];
     requant_pack16<OB>(acc, OB, P, qv);
-    uint32_t x[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         x[t] = (P[t] & (OB == 1 ? 0x01010101u : (OB == 2 ? 0x03030303u : 0x0f0f0f0fu))) << (4u - 4u * static_cast<uint32_t>(fh));   // nibble 7 - 2 gq - fh of dword 3 - t
         x[t] = or_with_partner_half(x[t]);
     }
+#endif
     // (non-temporal: nobody in THIS launch reads T', and what a launch leaves dirty in the L2s is written back at its end, before
     // the next launch may start - 6 MB of T' per 128-column launch: 6.20 -> 5.90 us. -DQGTC_RBW_PLAIN_STORES: the A/B build)
 #ifdef QGTC_RBW_PLAIN_STORES
