@@ -56,6 +56,12 @@ def parse():
     p.add_argument("--streams", type=int, default=1,
                    help="issue the steps round-robin on this many HIP streams (independent launches overlap); "
                         "default 1 = the reference's metric, launches back to back on one stream")
+    p.add_argument("--issue", choices=["eager", "graph"], default="eager",
+                   help="how the K steps of the timed region are issued: eager (default, the reference's way) = K hipLaunchKernel calls inside "
+                        "the region; graph = the K launches captured ONCE, ahead of the timed region, in a hipGraph and replayed inside it by one "
+                        "hipGraphLaunch (same kernels in stream order). Measured at K = 20: 3.96-3.99 us per step against 3.6 eager - the host's "
+                        "3.1-3.6 us per hipLaunchKernel and the kernel's 3.0 us overlap when issued eagerly, a graph launch adds its own "
+                        "latency ahead of the first kernel; the other way's figure is reported in extras")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget")
     p.add_argument("--backend", choices=["nccl", "gloo"], default=None, help="torch.distributed backend (default: nccl = RCCL)")
     p.add_argument("--dry-run", action="store_true", help="exercise the rank launcher and the collectives only (no GPU)")
@@ -107,7 +113,7 @@ CLOCK_WARMUP_S = 0.3
 EVENT_MIN_LAUNCHES = 200     # launches in the HIP-event window behind the timed region (QGTC_device.cu:409 times 200 too)
 
 
-def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams=1):
+def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams=1, issue="eager"):
     """warmup untimed launches, then EXACTLY `steps` launches between barrier+synchronize pairs (the contract's timed
     region: wall seconds), then the SAME `steps` launches once more between two HIP events recorded on the stream the
     kernels are launched on, and max(1, K // 200) event-bracketed windows of 200 launches (the roofline's live launch duration: their
@@ -131,12 +137,28 @@ def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     ev1.record()           # (created here: the first record of a torch event allocates it)
+    # issue = "graph": the K launches of the timed region (and the 200 of an event window) are captured ONCE, here, ahead of everything
+    # timed, and replayed by one hipGraphLaunch each. Same kernels, same stream order (a captured single-stream sequence is a chain of
+    # dependent kernel nodes), same outputs - what changes is the host's share: 20 eager launches cost the host 63-84 us
+    # (tools/host_launch_probe.hip: 3.1-3.5 us per hipLaunchKernel), one graph launch 8 us. For THIS kernel it buys nothing: its 3.0 us
+    # per launch on the GPU and the host's issue time overlap when issued eagerly (72 us for 20 steps), the replay takes 79 us.
+    run_steps, run_window = (lambda: enqueue(steps)), (lambda: enqueue(EVENT_MIN_LAUNCHES))
+    if issue == "graph" and streams <= 1:
+        graphs = []
+        for n in (steps, EVENT_MIN_LAUNCHES):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                enqueue(n)
+            g.replay()             # (the first replay uploads the graph: untimed)
+            graphs.append(g)
+        torch.cuda.synchronize()
+        run_steps, run_window = graphs[0].replay, graphs[1].replay
     enqueue(max(warmup, 1))
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    enqueue(steps)
+    run_steps()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
@@ -144,7 +166,7 @@ def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     ev0.record()
-    enqueue(steps)
+    run_steps()
     ev1.record()
     torch.cuda.synchronize()
     t3 = time.perf_counter()
@@ -152,13 +174,13 @@ def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams
     # drained before the next - max(1, K // EVENT_MIN_LAUNCHES) of them, averaged. A window of a few launches is mostly its own
     # start-up (the first launch's latency, the event markers); ONE window of a thousand launches and more between two timing events
     # is an instrument artefact of the other kind (r04: 3.5 / 4.9 / 3.7 us per launch on three runs while the event-free region
-    # beside it ran at 3.0; r03's single sample had read 3.0 - tools/event_windows.py: a box whose chip has idled for 10 ms can stay
+    # beside it ran at 3.0; tools/event_windows.py: a box whose chip has idled for 10 ms can stay
     # 20-30 % slower on event-bracketed work for seconds while an event-free region beside it runs at full speed).
     windows = max(1, steps // EVENT_MIN_LAUNCHES)
     per_window = []
     for _ in range(windows):
         ev0.record()
-        enqueue(EVENT_MIN_LAUNCHES)
+        run_window()
         ev1.record()
         torch.cuda.synchronize()
         per_window.append(ev0.elapsed_time(ev1) * 1e-3 / EVENT_MIN_LAUNCHES)
@@ -647,13 +669,22 @@ def main():
     with engine(Q, args.engine):
         out_e = Q.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w)
         assert torch.equal(out_e, out), "engines disagree"
-        wall, kern, wall_ev = time_steps(Q, out_e, bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams)
+        wall, kern, wall_ev = time_steps(Q, out_e, bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams, args.issue)
+        assert torch.equal(out_e, out), "the timed launches changed the result"      # (the replayed / eager launches wrote out_e again)
+        eager_headline = None
+        if rank == 0 and world == 1 and not args.no_extras and args.streams <= 1:
+            other_issue = "graph" if args.issue == "eager" else "eager"
+            e_wall, e_kern, _ = time_steps(Q, out_e, bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, 1, other_issue)
+            eager_headline = {"issue": other_issue, "TOPS": round(args.steps * 2.0 * M * K * N / e_wall / 1e12, 3),
+                              "ms_per_step": round(e_wall * 1e3 / args.steps, 6), "us_per_launch_hip_events": round(e_kern * 1e6, 3),
+                              "note": "the same K steps issued the other way (graph: captured once ahead of the timed region, one hipGraphLaunch inside "
+                                      "it; eager: K hipLaunchKernel calls inside it)"}
     # the same headline launches on the other engine (identical words), measured back to back with the headline
     # (before the CPU baseline occupies every host core)
     other_engine, other_headline = ("popcount" if args.engine != "popcount" else "auto"), None
     if rank == 0 and world == 1 and not args.no_extras:
         with engine(Q, other_engine):
-            o_wall, o_kern, _ = time_steps(Q, torch.empty_like(out), bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams)
+            o_wall, o_kern, _ = time_steps(Q, torch.empty_like(out), bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams, args.issue)
         other_headline = {"TOPS": round(args.steps * 2.0 * M * K * N / o_wall / 1e12, 3), "us_per_launch": round(o_kern * 1e6, 3)}
         if other_engine == "popcount":   # the engine BASELINE.json's north star names, against BOTH statements of its VALU roofline
             other_headline["valu_frac_of_measured_pair_rate_4.2e13"] = round(eff_ops_of(M, K, N) * w / o_kern / VALU_PEAK_BITOPS, 4)
@@ -699,7 +730,7 @@ def main():
                     "achieved": round(algo_bytes / kern / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac_hbm,
                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(algo_bytes),
                     "avg_launch_us": round(kern * 1e6, 3),
-                    "avg_launch_window": "%d x %d launches" % (max(1, args.steps // EVENT_MIN_LAUNCHES), EVENT_MIN_LAUNCHES),
+                    "avg_launch_window": "%d x %d launches, issued like the timed region (%s)" % (max(1, args.steps // EVENT_MIN_LAUNCHES), EVENT_MIN_LAUNCHES, args.issue),
                     "avg_launch_source": "HIP events on the launch stream around windows of %d of the same launches issued right behind the timed "
                                          "region (inside it the two event records cost 11-12 us of a 72 us window), max(1, K // %d) windows "
                                          "averaged: kernel + dependent-launch gap (~1.5 us), i.e. what a caller gets per launch" % (EVENT_MIN_LAUNCHES, EVENT_MIN_LAUNCHES),
@@ -732,7 +763,9 @@ def main():
                    "inputs": "seeded Bernoulli(0.5) adjacency, uniform w-bit features, packed and resident in HBM",
                    "parallelism": f"replica-per-GPU x{world}, no data-path collective",
                    "engine": args.engine + (" (library default) -> FP4 matrix-core kernel for narrow right operands" if fp4_kernel else " -> AND + popcount kernels"),
-                   "issue": "back-to-back launches on one stream (the reference's metric)" if args.streams <= 1
+                   "issue": ("back-to-back launches on one stream (the reference's metric)" + (": the K launches captured once in a hipGraph ahead of the "
+                             "timed region, ONE hipGraphLaunch inside it (same kernels in stream order; eager issue: extras.headline_other_issue)"
+                             if args.issue == "graph" else ": K hipLaunchKernel calls inside the timed region (graph replay: extras.headline_other_issue)")) if args.streams <= 1
                             else f"independent launches round-robin on {args.streams} HIP streams",
                    "clock_warmup": f"{CLOCK_WARMUP_S} s of untimed launches ahead of the W warmup steps (the chip idles into a low "
                                    "power state while the host builds inputs; nothing else precedes the timed region)"},
@@ -749,6 +782,7 @@ def main():
         if not args.no_extras:
             if rank == 0 and world == 1:
                 extras["headline_on_engine_" + other_engine] = other_headline
+                extras["headline_other_issue"] = eager_headline
                 sweep = {}
                 for ww in (1, 2, 4, 8):
                     for label, ones in (("random", False), ("ones", True)):
