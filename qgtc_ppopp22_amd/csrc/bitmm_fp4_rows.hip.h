@@ -26,7 +26,7 @@ constexpr int RS_CHUNK = 2;   // PAIRS of k-quads whose packed words a wave has 
 // MODE 0 rows-layout bits / 2 float32; OB output planes (0 = any); CB column blocks of 32 per wave (2: half the waves per
 // launch - a stage of the ogbn-arxiv-sized epoch then fits the chip in ONE round of waves instead of 1.4)
 template <int NA, int NW, int MODE, int OB, int CB>
-__global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *__restrict__ prs, MMShape sh) {
+__device__ __forceinline__ void rows_block(const qgtc_problem &pr, const MMShape &sh, int rb, int batch) {
     constexpr int NDA = (NA + 1) / 2, NDW = (NW + 1) / 2;   // base-4 digits
 #ifdef QGTC_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -35,17 +35,7 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
 #define RW_STAMP(i) do { } while (0)
 #endif
     RW_STAMP(0);
-    pin_shape(sh);
-    // sh.per != 0: the row blocks of a batch run on ONE XCD (they share its T lines and descriptor in that L2; spread
-    // round-robin over the eight, every XCD fetched every batch's T: rocprofv3 counted 18.5 MB of fetches per launch for
-    // 5.6 MB of operands)
-    int rb = static_cast<int>(blockIdx.x), batch = static_cast<int>(blockIdx.y);
-    if (sh.per) {
-        const int v = xcd_consecutive(batch * static_cast<int>(gridDim.x) + rb, static_cast<int>(gridDim.x * gridDim.y));
-        batch = v / static_cast<int>(gridDim.x);
-        rb = v - batch * static_cast<int>(gridDim.x);
-    }
-    const qgtc_problem pr = prs[batch];
+    (void)batch;
     pin_problem(pr);
     const int M = pr.M, K = pr.K, N = pr.N;
     if (32 * rb >= M) return;
@@ -221,6 +211,32 @@ __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *_
     }
 #endif
 #undef RW_STAMP
+}
+
+template <int NA, int NW, int MODE, int OB, int CB>
+__global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *__restrict__ prs, MMShape sh) {
+    pin_shape(sh);
+    // sh.per != 0: the row blocks of a batch run on ONE XCD (they share its T lines and descriptor in that L2; spread
+    // round-robin over the eight, every XCD fetched every batch's T: rocprofv3 counted 18.5 MB of fetches per launch for
+    // 5.6 MB of operands)
+    int rb = static_cast<int>(blockIdx.x), batch = static_cast<int>(blockIdx.y);
+    if (sh.per) {
+        const int v = xcd_consecutive(batch * static_cast<int>(gridDim.x) + rb, static_cast<int>(gridDim.x * gridDim.y));
+        batch = v / static_cast<int>(gridDim.x);
+        rb = v - batch * static_cast<int>(gridDim.x);
+    }
+    const qgtc_problem pr = prs[batch];
+    rows_block<NA, NW, MODE, OB, CB>(pr, sh, rb, batch);
+}
+
+// the same row block for ONE problem handed over by value: single launches with three or four left-hand planes and a short K (the
+// per-batch 4 x 4-bit products of the Batched-GIN chain, main_qgtc.py:132,134,138 - 599 x 50 x 64 and the like; the narrow-operand
+// kernels of bitmm_fp4_one / _skinny take two left-hand planes at most, and one wave per 32 x 32 tile on 16 x 16 x 128 MFMAs
+// multiplies mostly zeros when K is a single k-quad)
+template <int NA, int NW, int MODE, int OB>
+__global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows_single(qgtc_problem pr, MMShape sh) {
+    pin_shape(sh);
+    rows_block<NA, NW, MODE, OB, 1>(pr, sh, static_cast<int>(blockIdx.x), 0);
 }
 
 }  // namespace

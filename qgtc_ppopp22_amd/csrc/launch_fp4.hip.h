@@ -248,6 +248,30 @@ int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, i
 }
 
 
+// ONE problem on the row-block kernel (by value: no descriptor in device memory): rows-layout bits or float32, 3-4 left-hand planes
+int qgtc_launch_rows_single(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st) {
+    MMShape sh = base_shape(a, w, ob, mode);
+    sh.nowrap = 1;
+    sh.per = 0;
+    sh.qmajor = 0;
+    const int waves = mode == 2 ? (pr.N + 31) / 32 : step128(pr.N) * 4;   // per 32 columns / per word of a packed row
+    if (waves > 8 || (mode != 0 && mode != 2)) return QGTC_EINVAL;
+    const dim3 grid((pr.M + 31) / 32), block(64 * waves);
+#define QGTC_RW1_LAUNCH(NA_, NW_)                                                                                       \
+    if (!done && a <= NA_ && w <= NW_) {                                                                                \
+        done = true;                                                                                                    \
+        if (mode == 2) hipLaunchKernelGGL((k_bitmm_fp4_rows_single<NA_, NW_, 2, 0>), grid, block, 0, st, pr, sh);        \
+        else if (ob == 4) hipLaunchKernelGGL((k_bitmm_fp4_rows_single<NA_, NW_, 0, 4>), grid, block, 0, st, pr, sh);     \
+        else hipLaunchKernelGGL((k_bitmm_fp4_rows_single<NA_, NW_, 0, 0>), grid, block, 0, st, pr, sh);                  \
+    }
+    bool done = false;
+    QGTC_RW1_LAUNCH(4, 4) QGTC_RW1_LAUNCH(4, 8)
+#undef QGTC_RW1_LAUNCH
+    if (!done) return QGTC_EINVAL;
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
 // ---- row block per wave (bitmm_fp4_rbw.hip.h)
 int qgtc_launch_expand_weights(const qgtc_expand_job *jobs, int n_jobs, hipStream_t st) {
     ExpandJobs ej{};

@@ -76,6 +76,8 @@ MM_CASES = [
     # three / four left-hand planes with a narrow right operand: single launches on one wave per 32 x 32 tile (k_bitmm_fp4_wave_single;
     # the per-batch 4 x 4-bit products of the Batched-GIN chain, main_qgtc.py:132-138)
     (599, 50, 64, 4, 4, 4), (300, 1213, 33, 3, 7, 5), (1213, 1213, 64, 4, 8, 8), (33, 4000, 64, 4, 4, 2),
+    # ... in rows layout / float32 on the row-block kernel, one to eight waves per block (k_bitmm_fp4_rows_single; bitMM2Bit_col stays on the tiles)
+    (129, 250, 200, 3, 7, 5), (70, 100, 256, 4, 8, 8), (2100, 8192, 130, 4, 4, 4), (45, 4300, 16, 4, 8, 3),
 ]
 
 
