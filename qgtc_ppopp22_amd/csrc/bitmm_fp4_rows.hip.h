@@ -23,11 +23,14 @@ namespace {
 // ------------------------------------------------------------------------------------------
 constexpr int RS_CHUNK = 2;   // PAIRS of k-quads whose packed words a wave has in flight at once
 
-// MODE 0 rows-layout bits / 2 float32; OB output planes (0 = any); CB column blocks of 32 per wave (2: half the waves per
-// launch - a stage of the ogbn-arxiv-sized epoch then fits the chip in ONE round of waves instead of 1.4)
+// MODE 0 rows-layout bits / 1 cols-layout bits (single launches only: the operands are NOT swapped, a lane owns a column and 16
+// of the block's 32 rows - half a word of the column's line; a workgroup per WORD of a line, the padding ones included) / 2
+// float32; OB output planes (0 = any); CB column blocks of 32 per wave (2: half the waves per launch - a stage of the
+// ogbn-arxiv-sized epoch then fits the chip in ONE round of waves instead of 1.4)
 template <int NA, int NW, int MODE, int OB, int CB>
 __device__ __forceinline__ void rows_block(const qgtc_problem &pr, const MMShape &sh, int rb, int batch) {
     constexpr int NDA = (NA + 1) / 2, NDW = (NW + 1) / 2;   // base-4 digits
+    static_assert(MODE != 1 || CB == 1, "cols-layout output: one column block per wave");
 #ifdef QGTC_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define RW_STAMP(i) st_[i] = __builtin_amdgcn_s_memtime()
@@ -38,20 +41,20 @@ __device__ __forceinline__ void rows_block(const qgtc_problem &pr, const MMShape
     (void)batch;
     pin_problem(pr);
     const int M = pr.M, K = pr.K, N = pr.N;
-    if (32 * rb >= M) return;
+    if (MODE == 1 ? rb >= step128(M) * 4 : 32 * rb >= M) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 31, fh = lane >> 5;
     const int n0 = 32 * CB * wv;
     const int row_words = step128(N) * 4;
-    if (MODE == 0 ? CB * wv >= row_words : n0 >= N) return;  // nothing of this wave's words / columns exists
+    if (MODE == 0 ? CB * wv >= row_words : MODE == 1 ? n0 >= pad128(N) : n0 >= N) return;  // nothing of this wave's words / lines / columns exists
     const int kq = step128(K);
     const uint32_t row_bytes = static_cast<uint32_t>(kq) * 16u;
     // k-quads to visit (K <= 8192: one 64-bit word per 32-row tile)
     unsigned long long todo = kq >= 64 ? ~0ull : ((1ull << kq) - 1ull);
-    if (pr.occ) todo &= pr.occ[static_cast<size_t>(rb) * pr.occ_words];
+    if (pr.occ && 32 * rb < M) todo &= pr.occ[static_cast<size_t>(rb) * pr.occ_words];
     const bool cols_live = n0 < N;                           // (a padding word of the row: zeros, no arithmetic)
-    if (!cols_live) todo = 0ull;
+    if (!cols_live || 32 * rb >= M) todo = 0ull;             // (... or a padding word of a cols-layout line)
 #ifdef QGTC_STAMPS
     asm volatile("" ::"s"(todo));
     st_[6] = __builtin_popcountll(todo);
@@ -123,8 +126,12 @@ __device__ __forceinline__ void rows_block(const qgtc_problem &pr, const MMShape
                 for (int dw = 0; dw < NDW; dw++) {
                     const i32x8 wb = strip_operand<NW>(ww, dw);
 #pragma unroll
-                    for (int da = 0; da < NDA; da++)   // swapped: lane (fl, fh) register r holds C[row fl][column (r & 3) + 8 (r >> 2) + 4 fh]
-                        acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb, xa[da], acc[j], 4, 4, 0, 128 + 2 * dw, 0, 128 + 2 * da);
+                    for (int da = 0; da < NDA; da++) {
+                        if (MODE == 1)   // lane (fl, fh) register r holds C[row (r & 3) + 8 (r >> 2) + 4 fh][column fl]
+                            acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[da], wb, acc[j], 4, 4, 0, 128 + 2 * da, 0, 128 + 2 * dw);
+                        else             // swapped: lane (fl, fh) register r holds C[row fl][column (r & 3) + 8 (r >> 2) + 4 fh]
+                            acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb, xa[da], acc[j], 4, 4, 0, 128 + 2 * dw, 0, 128 + 2 * da);
+                    }
                 }
             }
         }
@@ -177,16 +184,18 @@ __device__ __forceinline__ void rows_block(const qgtc_problem &pr, const MMShape
     // rows layout [ob][PAD8(M)][STEP128(N)*4] (reference kernel.h:357-389): word (row, wv); column e of the block at bit
     // 31 - e = 8 (3 - gq) + (7 - t - 4 fh) with t = r & 3, gq = r >> 2: the values of one t a byte each (byte 3 - gq),
     // plane p of the four = one shift + AND; the partner lane (fl, fh ^ 1) holds the other 16 bits of the word
+    // cols layout [ob][PAD128(N)][STEP128(M)*4] (QGTC_device.cu:456): word (line n0 + fl, rb), the same expression with rows for columns
     const int ob = OB > 0 ? OB : sh.ob;
     const int rows_pad = pad8(M);
-    const size_t oplane = static_cast<size_t>(rows_pad) * row_words;
-    const bool store = fh == 0 && m < rows_pad;
+    const int line_words = step128(M) * 4, lines = pad128(N);
+    const size_t oplane = MODE == 1 ? static_cast<size_t>(lines) * line_words : static_cast<size_t>(rows_pad) * row_words;
+    const bool store = fh == 0 && (MODE == 1 ? n0 + fl < lines : m < rows_pad);
 #pragma unroll
     for (int j = 0; j < CB; j++) {
-        if (CB * wv + j >= row_words) break;   // (wave-uniform: the row has no such word)
+        if (MODE == 0 && CB * wv + j >= row_words) break;   // (wave-uniform: the row has no such word)
         uint32_t qv[16], P[4];
         requant_pack16<OB>(acc[j], ob, P, qv);
-        uint32_t *dst = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(m) * row_words + CB * wv + j;
+        uint32_t *dst = static_cast<uint32_t *>(pr.out) + (MODE == 1 ? static_cast<size_t>(n0 + fl) * line_words + rb : static_cast<size_t>(m) * row_words + CB * wv + j);
 #pragma unroll
         for (int p = 0; p < (OB > 0 ? OB : 32); p++) {
             if (OB == 0 && p >= ob) break;

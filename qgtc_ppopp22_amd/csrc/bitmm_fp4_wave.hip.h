@@ -248,11 +248,4 @@ __global__ __launch_bounds__(64) void k_bitmm_fp4_wave(const qgtc_problem *__res
     fw_tile<NA, NW, MODE, RF, CF>(pr, sh, zero_skip, static_cast<int>(blockIdx.x));
 }
 
-// the same tile for ONE problem handed over by value (single launches with three or four left-hand planes: the per-batch 4 x 4-bit
-// products of the Batched-GIN chain, main_qgtc.py:132,134,138 - the narrow-operand kernels of bitmm_fp4_one / _skinny take two at most)
-template <int NA, int NW, int MODE, int RF, int CF>
-__global__ __launch_bounds__(64) void k_bitmm_fp4_wave_single(qgtc_problem pr, MMShape sh, int zero_skip) {
-    fw_tile<NA, NW, MODE, RF, CF>(pr, sh, zero_skip, static_cast<int>(blockIdx.x));
-}
-
 }  // namespace

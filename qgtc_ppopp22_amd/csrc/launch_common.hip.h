@@ -15,7 +15,6 @@ int qgtc_launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, b
 bool qgtc_skinny_is_one(const qgtc_problem &pr, int ob, int mode);
 int qgtc_launch_fp4_wave(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode,
                          bool zero_skip, hipStream_t st);
-int qgtc_launch_fp4_wave_single(const qgtc_problem &pr, int a, int w, int ob, int mode, bool zero_skip, hipStream_t st);
 int qgtc_launch_rows_single(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st);
 int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, hipStream_t st);
 int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode, bool qmajor_in, hipStream_t st);
@@ -206,22 +205,18 @@ inline bool fp4_wave_ok(int K, int N, int a, int w) {
     return N <= 64 && a <= 4 && w <= 8 && static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
 }
 
-// single launches with three or four left-hand planes and a narrow right operand: one wave per 32 x 32 tile (k_bitmm_fp4_wave_single).
-// QGTC_ENGINE_AUTO takes it for SMALL products only (the per-batch 4 x 4-bit products of the Batched-GIN chain: a few dozen tiles, one or
-// two super-steps of K each - launch-bound, where the 16-pass popcount kernel is not); larger ones keep the cost models below
-inline bool wave_single_ok(int M, int K, int N, int a, int w, int ob, int mode) {
-    return a > 2 && a <= 4 && w <= 8 && fp4_wave_ok(K, N, a, w) && (mode == 2 || (ob >= 1 && ob <= 23)) && M < (1 << 24) && !getenv_flag("QGTC_NO_WAVE1");
-}
-inline bool auto_prefers_wave_single(int M, int K, int N) { return static_cast<double>(M) * K * N <= 1213.0 * 1213.0 * 64.0; }
-// ... and with rows-layout bits or float32 out (modes 0 / 2) the row-block kernel on ONE by-value problem (k_bitmm_fp4_rows_single:
-// 32 x 32 x 64 MFMAs, a wave per 32 columns of a 32-row block, no LDS). tools/rows1_sweep.py, 4 x 4 bits, M = 599 .. 16384, K = 128 .. 8192,
-// N = 16 .. 256: 2.8-3.0 us where the tile kernel above has a 7.8 us floor (599 x 50 x 64: 7.85 -> 2.83), and ahead of the 128-tile /
-// wide kernels the larger products took before (4096 x 4096 x 64: 16.0 against 35.2 us; 16384 x 8192 x 128: 63.8 against 77.9) - except
-// the eight-wave blocks of N > 128 on big operands (16384 x 1024 x 256: 18.6 against 16.6), which keep the cost models below
+// single launches with three or four left-hand planes (the narrow-operand kernels of bitmm_fp4_one / _skinny take two at most) and at
+// most 256 columns: the row-block kernel on ONE by-value problem (k_bitmm_fp4_rows_single: 32 x 32 x 64 MFMAs, a wave per 32 columns
+// of a 32-row block, no LDS; cols-layout output with the operands not swapped). The per-batch 4 x 4-bit products of the Batched-GIN
+// chain (main_qgtc.py:132,134,138): 599 x 50 x 64 in 2.83 us (a wave per 32 x 32 tile on 16 x 16 x 128 MFMAs, round 4's first route:
+// 7.85; popcount: 8.6). tools/rows1_sweep.py, 4 x 4 and 4 x 8 bits, M = 599 .. 16384, K = 128 .. 8192, N = 16 .. 256, all three
+// outputs: ahead of the 128-tile / wide kernels the larger products took before (4096 x 4096 x 64: 16.0 against 35.2 us;
+// 16384 x 8192 x 128: 63.8 against 77.9) - except the eight-wave blocks of N > 128 on big operands (16384 x 1024 x 256: 18.6
+// against 16.6), which keep the cost models below
 inline bool rows_single_ok(const qgtc_problem &pr, int a, int w, int ob, int mode) {
     const int M = pr.M, K = pr.K, N = pr.N;
-    const size_t out_bytes = mode == 2 ? static_cast<size_t>(M) * N * 4u : static_cast<size_t>(ob) * pad8(M) * step128(N) * 16u;   // (32-bit byte offsets)
-    return a > 2 && (mode == 0 || mode == 2) && rows_ok(K, N, a, w, ob, mode) && (N <= 128 || M <= 8192 || K <= 512) && M < (1 << 24) &&
+    const size_t out_bytes = mode == 2 ? static_cast<size_t>(M) * N * 4u : static_cast<size_t>(ob) * (mode == 1 ? pad128(N) : pad8(M)) * step128(mode == 1 ? M : N) * 16u;
+    return a > 2 && rows_ok(K, N, a, w, ob, mode == 1 ? 0 : mode) && (N <= 128 || M <= 8192 || K <= 512) && M < (1 << 24) &&
            pr.x_words < (1ull << 30) && pr.w_words < (1ull << 30) && out_bytes < (1ull << 32) && !getenv_flag("QGTC_NO_ROWS1");
 }
 

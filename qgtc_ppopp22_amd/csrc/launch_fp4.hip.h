@@ -112,26 +112,6 @@ int qgtc_launch_fp4_wave(const qgtc_problem *prs, int count, int max_M, int max_
 }
 
 
-int qgtc_launch_fp4_wave_single(const qgtc_problem &pr, int a, int w, int ob, int mode, bool zero_skip, hipStream_t st) {
-    MMShape sh = base_shape(a, w, ob, mode);
-    sh.nowrap = 1;
-    const int zs = zero_skip ? 1 : 0;
-    const dim3 grid(((pr.M + 31) / 32) * ((pr.N + 31) / 32));   // 32 x 32 outputs per wave
-#define QGTC_FW1_LAUNCH(NA_, NW_)                                                                                       \
-    if (!done && a <= NA_ && w <= NW_) {                                                                                \
-        done = true;                                                                                                    \
-        if (mode == 2) hipLaunchKernelGGL((k_bitmm_fp4_wave_single<NA_, NW_, 2, 2, 2>), grid, dim3(64), 0, st, pr, sh, zs);      \
-        else if (mode == 1) hipLaunchKernelGGL((k_bitmm_fp4_wave_single<NA_, NW_, 1, 2, 2>), grid, dim3(64), 0, st, pr, sh, zs); \
-        else hipLaunchKernelGGL((k_bitmm_fp4_wave_single<NA_, NW_, 0, 2, 2>), grid, dim3(64), 0, st, pr, sh, zs);                \
-    }
-    bool done = false;
-    QGTC_FW1_LAUNCH(4, 4) QGTC_FW1_LAUNCH(4, 8)
-#undef QGTC_FW1_LAUNCH
-    if (!done) return QGTC_EINVAL;
-    HIP_TRY(hipGetLastError());
-    return QGTC_OK;
-}
-
 // grouped "X . W" stages with one k-quad of K and cols-layout output: one workgroup per 32-column strip (bitmm_fp4_strip.hip.h)
 int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, 1);
@@ -248,25 +228,30 @@ int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, i
 }
 
 
-// ONE problem on the row-block kernel (by value: no descriptor in device memory): rows-layout bits or float32, 3-4 left-hand planes
+// ONE problem on the row-block kernel (by value: no descriptor in device memory): 3-4 left-hand planes, any of the three outputs
 int qgtc_launch_rows_single(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, mode);
     sh.nowrap = 1;
     sh.per = 0;
     sh.qmajor = 0;
-    const int waves = mode == 2 ? (pr.N + 31) / 32 : step128(pr.N) * 4;   // per 32 columns / per word of a packed row
-    if (waves > 8 || (mode != 0 && mode != 2)) return QGTC_EINVAL;
-    const dim3 grid((pr.M + 31) / 32), block(64 * waves);
-#define QGTC_RW1_LAUNCH(NA_, NW_)                                                                                       \
-    if (!done && a <= NA_ && w <= NW_) {                                                                                \
-        done = true;                                                                                                    \
-        if (mode == 2) hipLaunchKernelGGL((k_bitmm_fp4_rows_single<NA_, NW_, 2, 0>), grid, block, 0, st, pr, sh);        \
-        else if (ob == 4) hipLaunchKernelGGL((k_bitmm_fp4_rows_single<NA_, NW_, 0, 4>), grid, block, 0, st, pr, sh);     \
-        else hipLaunchKernelGGL((k_bitmm_fp4_rows_single<NA_, NW_, 0, 0>), grid, block, 0, st, pr, sh);                  \
+    // a wave per 32 columns (float32) / per word of a packed row (rows layout) / per 32 lines, the padding ones included (cols layout)
+    const int waves = mode == 2 ? (pr.N + 31) / 32 : mode == 1 ? pad128(pr.N) / 32 : step128(pr.N) * 4;
+    if (waves > 8 || mode < 0 || mode > 2) return QGTC_EINVAL;
+    const dim3 grid(mode == 1 ? step128(pr.M) * 4 : (pr.M + 31) / 32), block(64 * waves);   // (cols layout: a workgroup per word of a line)
+#define QGTC_RW1_GO(NA_, NW_, MODE_, OB_) hipLaunchKernelGGL((k_bitmm_fp4_rows_single<NA_, NW_, MODE_, OB_>), grid, block, 0, st, pr, sh)
+#define QGTC_RW1_LAUNCH(NA_, NW_)                                        \
+    if (!done && a <= NA_ && w <= NW_) {                                 \
+        done = true;                                                     \
+        if (mode == 2) QGTC_RW1_GO(NA_, NW_, 2, 0);                      \
+        else if (mode == 1 && ob == 4) QGTC_RW1_GO(NA_, NW_, 1, 4);      \
+        else if (mode == 1) QGTC_RW1_GO(NA_, NW_, 1, 0);                 \
+        else if (ob == 4) QGTC_RW1_GO(NA_, NW_, 0, 4);                   \
+        else QGTC_RW1_GO(NA_, NW_, 0, 0);                                \
     }
     bool done = false;
     QGTC_RW1_LAUNCH(4, 4) QGTC_RW1_LAUNCH(4, 8)
 #undef QGTC_RW1_LAUNCH
+#undef QGTC_RW1_GO
     if (!done) return QGTC_EINVAL;
     HIP_TRY(hipGetLastError());
     return QGTC_OK;

@@ -195,7 +195,7 @@ std::pair<torch::Tensor, double> profile_impl(const torch::Tensor &bit_X1, const
 // Enqueue `reps` launches writing into a caller-provided packed output (no allocation, no
 // synchronisation): the lean launch path used by bench.py and by steady-state serving loops.
 void bitMM2Bit_enqueue(torch::Tensor out, torch::Tensor bit_X1, torch::Tensor bit_X2, int M, int K,
-                       int N, int bit1, int bit2, int ob, int reps) {
+                       int N, int bit1, int bit2, int ob, int reps, bool cols) {
     CHECK_INPUT(out);
     CHECK_INPUT(bit_X1);
     CHECK_INPUT(bit_X2);
@@ -208,7 +208,7 @@ void bitMM2Bit_enqueue(torch::Tensor out, torch::Tensor bit_X1, torch::Tensor bi
     void *st = current_stream(bit_X1);
     for (int i = 0; i < reps; i++)
         check_rc(qgtc_bitmm2bit(words(bit_X1), bit_X1.numel(), words(bit_X2), bit_X2.numel(), M, K, N,
-                                bit1, bit2, ob, words_mut(out), out.numel(), mm_flags(), st),
+                                bit1, bit2, ob, words_mut(out), out.numel(), mm_flags() | (cols ? QGTC_OUT_COLS : 0u), st),
                  "bitMM2Bit_enqueue");
 }
 
@@ -1320,8 +1320,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("last_profile_ms", [] { return g_last_profile_ms.load(); });
     m.def("bitMM2Bit_enqueue_streams", &bitMM2Bit_enqueue_streams,
           "enqueue `reps` independent bitMM2Bit launches round-robin over len(outs) HIP streams (asynchronous)");
-    m.def("bitMM2Bit_enqueue", &bitMM2Bit_enqueue,
-          "enqueue `reps` bitMM2Bit launches into a preallocated output (asynchronous)");
+    m.def("bitMM2Bit_enqueue", &bitMM2Bit_enqueue, py::arg("out"), py::arg("bit_X1"), py::arg("bit_X2"), py::arg("M"), py::arg("K"), py::arg("N"),
+          py::arg("bit1"), py::arg("bit2"), py::arg("output_bit"), py::arg("reps"), py::arg("cols") = false,
+          "enqueue `reps` bitMM2Bit (cols: bitMM2Bit_col) launches into a preallocated output (asynchronous)");
     m.def("tile_counters", [](torch::Tensor x, int M, int K, int N, int bit1, int bit2) {
         CHECK_INPUT(x);
         check_bits_tensor(x, "x");

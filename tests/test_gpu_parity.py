@@ -73,10 +73,9 @@ MM_CASES = [
     (20, 300, 40, 9, 12, 4), (33, 130, 20, 17, 3, 8), (8, 128, 8, 10, 10, 12),
     # single-wave, 2-3 wave and 4-7 wave workgroups of the fixed kernels
     (64, 256, 64, 1, 1, 1), (64, 384, 64, 1, 2, 2), (40, 700, 33, 2, 2, 2), (50, 900, 70, 4, 4, 3),
-    # three / four left-hand planes with a narrow right operand: single launches on one wave per 32 x 32 tile (k_bitmm_fp4_wave_single;
-    # the per-batch 4 x 4-bit products of the Batched-GIN chain, main_qgtc.py:132-138)
+    # three / four left-hand planes: single launches on the row-block kernel (k_bitmm_fp4_rows_single; the per-batch 4 x 4-bit products
+    # of the Batched-GIN chain, main_qgtc.py:132-138), one to eight waves per block
     (599, 50, 64, 4, 4, 4), (300, 1213, 33, 3, 7, 5), (1213, 1213, 64, 4, 8, 8), (33, 4000, 64, 4, 4, 2),
-    # ... in rows layout / float32 on the row-block kernel, one to eight waves per block (k_bitmm_fp4_rows_single; bitMM2Bit_col stays on the tiles)
     (129, 250, 200, 3, 7, 5), (70, 100, 256, 4, 8, 8), (2100, 8192, 130, 4, 4, 4), (45, 4300, 16, 4, 8, 3),
 ]
 

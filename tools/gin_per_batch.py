@@ -1,6 +1,5 @@
 """Per-batch Batched-GIN epoch (main_qgtc.py:131-138 literally: 75 batches x six calls) on the default engine, with and without the
-single-launch row-block kernel for its 4 x 4-bit products (QGTC_NO_ROWS1=1 in a second process: the tile kernel; + QGTC_NO_WAVE1=1:
-the popcount kernel). The epoch is bound by the host's six calls per batch: the launch time below is what moves."""
+single-launch row-block kernel for its 4 x 4-bit products (QGTC_NO_ROWS1=1 in a second process: the popcount kernel). The epoch is bound by the host's six calls per batch: the launch time below is what moves."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +9,7 @@ g = G.make_graph("ppi", 1500)
 args = driver.build_parser().parse_args(["--dataset", "ppi", "--n-hidden", "64", "--n-classes", "10", "--bit_width", "4", "--use_QGTC", "--quiet", "--n-epochs", "20", "--run_GIN"])
 it = driver.make_iter(args, Q, g)
 ms = [driver.run(args, Q=Q, graph=g, it=it)["avg_epoch_ms"] for _ in range(6)][1:]
-print("NO_WAVE1" if os.environ.get("QGTC_NO_WAVE1") else "NO_ROWS1" if os.environ.get("QGTC_NO_ROWS1") else "rows1   ", "per-batch GIN epoch ms:", [round(m, 3) for m in ms], flush=True)
+print("NO_ROWS1" if os.environ.get("QGTC_NO_ROWS1") else "rows1   ", "per-batch GIN epoch ms:", [round(m, 3) for m in ms], flush=True)
 n = 599
 X = Q.val2bit(torch.rand(n, 50, device="cuda") * 16, 4, False, False)
 W = Q.val2bit(torch.rand(50, 64, device="cuda") * 16, 4, True, False)
