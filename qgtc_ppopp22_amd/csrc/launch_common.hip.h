@@ -205,7 +205,7 @@ inline bool fp4_wave_ok(int K, int N, int a, int w) {
     return N <= 64 && a <= 4 && w <= 8 && static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
 }
 
-// single launches with three or four left-hand planes (the narrow-operand kernels of bitmm_fp4_one / _skinny take two at most) and at
+// single launches with three to eight left-hand planes (the narrow-operand kernels of bitmm_fp4_one / _skinny take two at most) and at
 // most 256 columns: the row-block kernel on ONE by-value problem (k_bitmm_fp4_rows_single: 32 x 32 x 64 MFMAs, a wave per 32 columns
 // of a 32-row block, no LDS; cols-layout output with the operands not swapped). The per-batch 4 x 4-bit products of the Batched-GIN
 // chain (main_qgtc.py:132,134,138): 599 x 50 x 64 in 2.83 us (a wave per 32 x 32 tile on 16 x 16 x 128 MFMAs, round 4's first route:
@@ -216,7 +216,13 @@ inline bool fp4_wave_ok(int K, int N, int a, int w) {
 inline bool rows_single_ok(const qgtc_problem &pr, int a, int w, int ob, int mode) {
     const int M = pr.M, K = pr.K, N = pr.N;
     const size_t out_bytes = mode == 2 ? static_cast<size_t>(M) * N * 4u : static_cast<size_t>(ob) * (mode == 1 ? pad128(N) : pad8(M)) * step128(mode == 1 ? M : N) * 16u;
-    return a > 2 && rows_ok(K, N, a, w, ob, mode == 1 ? 0 : mode) && (N <= 128 || M <= 8192 || K <= 512) && M < (1 << 24) &&
+    const bool exact = static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;   // (8 x 8 bits: K <= 258 - the X . W products)
+    // five to eight left-hand planes run on the one <8, 8> instantiation (16 MFMAs per 64 elements of K whatever w is): the b x b-bit
+    // products of the drivers at --bit_width 5 .. 8 and anything small (tools/route_sweep.py: 1213 x 128 x 128 8 x 8 bits 27.9 -> 4.2 us,
+    // 4096 x 4096 x 64 5 x 5 bits 45.2 -> 32.1; but 8 x 1 bits 27.7 -> 32.7 and N = 256 5 x 5 bits 47.7 -> 54.6: those stay where they were)
+    const bool small = static_cast<double>(M) * K * N <= 1213.0 * 1213.0 * 128.0;
+    return a > 2 && a <= 8 && w <= 8 && K <= 8192 && N <= 256 && exact && (mode == 2 || (ob >= 1 && ob <= 23)) && !getenv_flag("QGTC_NO_ROWS") &&
+           (N <= 128 || M <= 8192 || K <= 512) && (a <= 4 || small || (w > 2 && N <= 128)) && M < (1 << 24) &&
            pr.x_words < (1ull << 30) && pr.w_words < (1ull << 30) && out_bytes < (1ull << 32) && !getenv_flag("QGTC_NO_ROWS1");
 }
 

@@ -228,7 +228,7 @@ int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, i
 }
 
 
-// ONE problem on the row-block kernel (by value: no descriptor in device memory): 3-4 left-hand planes, any of the three outputs
+// ONE problem on the row-block kernel (by value: no descriptor in device memory): 3-8 left-hand planes, any of the three outputs
 int qgtc_launch_rows_single(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, mode);
     sh.nowrap = 1;
@@ -239,17 +239,17 @@ int qgtc_launch_rows_single(const qgtc_problem &pr, int a, int w, int ob, int mo
     if (waves > 8 || mode < 0 || mode > 2) return QGTC_EINVAL;
     const dim3 grid(mode == 1 ? step128(pr.M) * 4 : (pr.M + 31) / 32), block(64 * waves);   // (cols layout: a workgroup per word of a line)
 #define QGTC_RW1_GO(NA_, NW_, MODE_, OB_) hipLaunchKernelGGL((k_bitmm_fp4_rows_single<NA_, NW_, MODE_, OB_>), grid, block, 0, st, pr, sh)
-#define QGTC_RW1_LAUNCH(NA_, NW_)                                        \
+#define QGTC_RW1_LAUNCH(NA_, NW_, OBS_)                                  \
     if (!done && a <= NA_ && w <= NW_) {                                 \
         done = true;                                                     \
         if (mode == 2) QGTC_RW1_GO(NA_, NW_, 2, 0);                      \
-        else if (mode == 1 && ob == 4) QGTC_RW1_GO(NA_, NW_, 1, 4);      \
+        else if (mode == 1 && ob == OBS_) QGTC_RW1_GO(NA_, NW_, 1, OBS_); \
         else if (mode == 1) QGTC_RW1_GO(NA_, NW_, 1, 0);                 \
-        else if (ob == 4) QGTC_RW1_GO(NA_, NW_, 0, 4);                   \
+        else if (ob == OBS_) QGTC_RW1_GO(NA_, NW_, 0, OBS_);             \
         else QGTC_RW1_GO(NA_, NW_, 0, 0);                                \
     }
     bool done = false;
-    QGTC_RW1_LAUNCH(4, 4) QGTC_RW1_LAUNCH(4, 8)
+    QGTC_RW1_LAUNCH(4, 4, 4) QGTC_RW1_LAUNCH(4, 8, 4) QGTC_RW1_LAUNCH(8, 8, 8)   // (b x b-bit X . W of the drivers, b = 3 .. 8)
 #undef QGTC_RW1_LAUNCH
 #undef QGTC_RW1_GO
     if (!done) return QGTC_EINVAL;

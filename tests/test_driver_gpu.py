@@ -22,7 +22,7 @@ def _args(extra):
 
 @pytest.mark.parametrize("chain", ["reference", "correct"])
 @pytest.mark.parametrize("gin", [False, True])
-@pytest.mark.parametrize("bits", [2, 4])
+@pytest.mark.parametrize("bits", [1, 2, 3, 4, 5, 8, 16, 32])   # (0_7a_eval_QGTC_cluster_GCN.py:10 is checked in with bitwidth = 32, 0_7b:10 with 2)
 @pytest.mark.parametrize("batched", [False, True])
 def test_epoch_outputs_match_oracle(qgtc, oracle, chain, gin, bits, batched):
     from qgtc_ppopp22_amd import driver, graph as G
@@ -42,7 +42,7 @@ def test_epoch_outputs_match_oracle(qgtc, oracle, chain, gin, bits, batched):
         np.testing.assert_array_equal(to_np_u32(ct.bit_X), bi["bit_X"])
         expect = oracle_chain(oracle, bi, W, bits, chain, gin)[-1]
         np.testing.assert_array_equal(res["outs"][cid].cpu().numpy(), expect)
-        if chain == "correct" and not gin:
+        if chain == "correct" and not gin and bits <= 8:
             np.testing.assert_array_equal(expect, integer_gcn_reference(bi["A"], bi["X"], 64, 10, bits, oracle))
 
 

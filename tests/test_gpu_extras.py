@@ -362,7 +362,7 @@ def test_fp4_narrow_kernels_sweep(qgtc, oracle):
 
 # ---------------------------------------------------------------------------------------------
 # The FP4 matrix-core kernels accumulate in float32; the library only routes a product to them while
-# K (2^a - 1)(2^w - 1) < 2^24 (launch_common.hip.h: skinny_ok / fp4_wave_ok / fp4_ok), i.e. while every partial sum
+# K (2^a - 1)(2^w - 1) < 2^24 (launch_common.hip.h: skinny_ok / fp4_wave_ok / fp4_ok / rows_single_ok), i.e. while every partial sum
 # is an exactly representable integer. That predicate is the whole safety case of those kernels (the reference
 # accumulates in int32, kernel.h:292-341), so it is tested at its edge with worst-case operands.
 # ---------------------------------------------------------------------------------------------
@@ -379,7 +379,7 @@ def _packed_pair(torch, oracle, qx, qw, a, w):
     return X, Wt, to_dev(torch, X, rows_shape(M, K, a)), to_dev(torch, Wt, cols_shape(K, N, w))
 
 
-@pytest.mark.parametrize("a,w", [(1, 8), (2, 8), (2, 2), (1, 1), (2, 4)])
+@pytest.mark.parametrize("a,w", [(1, 8), (2, 8), (2, 2), (1, 1), (2, 4), (4, 4), (4, 8), (5, 5), (6, 8), (8, 8)])   # (3-8 left planes: k_bitmm_fp4_rows_single)
 @pytest.mark.parametrize("engine", ["auto", "mfma"])
 def test_float32_exactness_bound_all_max_operands(qgtc, oracle, a, w, engine):
     """All-max X times all-max W at the LARGEST K the FP4 kernels are admitted for (every output = K (2^a-1)(2^w-1)
@@ -405,7 +405,7 @@ def test_float32_exactness_bound_all_max_operands(qgtc, oracle, a, w, engine):
         np.testing.assert_array_equal(to_np_u32(b), oracle.bitmm2bit(X, Wt, M, K, N, a, w, 8))
 
 
-@pytest.mark.parametrize("a,w", [(1, 8), (2, 8), (2, 2)])
+@pytest.mark.parametrize("a,w", [(1, 8), (2, 8), (2, 2), (4, 8), (6, 8), (8, 8)])
 def test_float32_sums_do_not_truncate_small_addends(qgtc, oracle, a, w):
     """A pattern aimed at the INSIDE of the block-scaled MFMA: most of K drives every accumulator close to 2^24 with
     all-max operands, then the remaining k-quads contribute products of every magnitude down to single 1 x 1 pairs
@@ -418,6 +418,7 @@ def test_float32_sums_do_not_truncate_small_addends(qgtc, oracle, a, w):
     K = _kmax(a, w)
     ma, mw = 2 ** a - 1, 2 ** w - 1
     for tail in (512, 4096 + 77):              # ragged tails, several super-steps
+        tail = min(tail, K // 2)               # (8 x 8 bits: K = 258)
         qx = np.full((M, K), ma, dtype=np.int32)
         qw = np.full((K, N), mw, dtype=np.int32)
         t0 = K - tail

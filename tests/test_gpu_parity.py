@@ -77,6 +77,8 @@ MM_CASES = [
     # of the Batched-GIN chain, main_qgtc.py:132-138), one to eight waves per block
     (599, 50, 64, 4, 4, 4), (300, 1213, 33, 3, 7, 5), (1213, 1213, 64, 4, 8, 8), (33, 4000, 64, 4, 4, 2),
     (129, 250, 200, 3, 7, 5), (70, 100, 256, 4, 8, 8), (2100, 8192, 130, 4, 4, 4), (45, 4300, 16, 4, 8, 3),
+    # five to eight left-hand planes (the b x b-bit X . W products of the drivers at --bit_width 5 .. 8) while float32 sums stay exact
+    (1213, 128, 128, 8, 8, 8), (599, 50, 64, 5, 5, 5), (300, 1000, 100, 6, 6, 4), (129, 258, 200, 8, 8, 8), (77, 259, 40, 8, 8, 8), (64, 500, 10, 7, 3, 9),
 ]
 
 

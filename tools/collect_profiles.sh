@@ -7,7 +7,7 @@
 set -u
 TAG=${1:-r03}
 shift
-TARGETS=${@:-headline popcount w8 epoch epoch_gin loader pack}
+TARGETS=${@:-headline popcount w8 gin_single epoch epoch_gin loader pack}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

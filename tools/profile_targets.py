@@ -1,6 +1,6 @@
 """One kernel family per invocation, for rocprofv3 (tools/collect_profiles.sh):
 
-    python3 tools/profile_targets.py headline|popcount|w8|epoch|epoch_gin|loader|loader_gin|pack|wide1|wide8k|wide2|wide4 [reps]
+    python3 tools/profile_targets.py headline|popcount|w8|gin_single|epoch|epoch_gin|loader|loader_gin|pack|wide1|wide8k|wide2|wide4 [reps]
 
 Runs the named workload `reps` times after a warm-up and prints one JSON line with the HIP-event time per launch
 (events recorded on the launch stream), so that the trace's per-kernel averages can be put beside it."""
@@ -26,16 +26,16 @@ def events(fn, reps):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-def gemm_target(M, K, N, w, reps, engine="auto"):
+def gemm_target(M, K, N, w, reps, engine="auto", a=1):
     Q.set_engine(engine)
     g = torch.Generator(device="cpu").manual_seed(3)
-    A = (torch.rand((M, K), generator=g) < 0.5).float().cuda()
+    A = torch.randint(0, 2 ** a, (M, K), generator=g).float().cuda()
     X = torch.randint(0, 2 ** w, (K, N), generator=g).float().cuda()
-    ba, bx = Q.val2bit(A, 1, False, False), Q.val2bit(X, w, True, False)
-    out = Q.bitMM2Bit(ba, bx, M, K, N, 1, w, w)
-    us = events(lambda: Q.bitMM2Bit_enqueue(out, ba, bx, M, K, N, 1, w, w, 1), reps)
-    algo = M * K / 8 + w * K * N / 8 + w * M * N / 8
-    return {"workload": f"bitMM2Bit {M}x{K}x{N} a=1 w={w}", "us_per_launch_hip_events": round(us, 3), "launches": reps + 1,
+    ba, bx = Q.val2bit(A, a, False, False), Q.val2bit(X, w, True, False)
+    out = Q.bitMM2Bit(ba, bx, M, K, N, a, w, w)
+    us = events(lambda: Q.bitMM2Bit_enqueue(out, ba, bx, M, K, N, a, w, w, 1), reps)
+    algo = a * M * K / 8 + w * K * N / 8 + w * M * N / 8
+    return {"workload": f"bitMM2Bit {M}x{K}x{N} a={a} w={w}", "us_per_launch_hip_events": round(us, 3), "launches": reps + 1,
             "algorithmic_bytes": int(algo), "eff_TOPS": round(2.0 * M * K * N / us / 1e6, 1)}
 
 
@@ -115,6 +115,8 @@ def main():
         r["valu_frac_of_survey_8d_peak"] = round(bitops / (r["us_per_launch_hip_events"] * 1e-6) / (7.864e13 * 32), 4)
     elif t == "w8":
         r = gemm_target(4096, 4096, 64, 8, reps)
+    elif t == "gin_single":   # a per-batch 4 x 4-bit product of the Batched-GIN chain (main_qgtc.py:132)
+        r = gemm_target(599, 50, 64, 4, reps, a=4)
     elif t == "wide1":
         r = gemm_target(4096, 4096, 1024, 1, reps)
     elif t == "wide8k":

@@ -36,6 +36,7 @@ SINGLE = [  # (what, M, K, N, a, w, ob, mode)
     ("per-batch bitMM2Int, 10 classes", 1213, 1213, 10, 1, 2, 1, 2),
     ("ppi GIN per-batch, 4 x 4 bits", 599, 50, 64, 4, 4, 4, 0),
     ("the same, layout-correct (bitMM2Bit_col)", 599, 50, 64, 4, 4, 4, 1),
+    ("per-batch X.W at --bit_width 8", 1213, 128, 128, 8, 8, 8, 0),
     ("4 x 4 bits, a 128-column right operand", 4096, 4096, 128, 4, 4, 4, 0),
     ("4 x 4 bits, 256 columns on big operands", 16384, 4096, 256, 4, 4, 4, 0),
     ("wide product, 2 x 2 bits", 8192, 4096, 1024, 2, 2, 2, 0),
