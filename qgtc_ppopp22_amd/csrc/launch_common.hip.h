@@ -165,9 +165,13 @@ inline bool strip_ok(int max_M, int max_K, int a, int w, int ob) {
 // grouped "A . (XW)" stages (rows-layout bits or float32 out, at most 256 columns): one workgroup per 32-row block of a
 // batch, visiting only the k-quads its occupancy word names (bitmm_fp4_rows.hip.h)
 inline bool rows_ok(int max_K, int max_N, int a, int w, int ob, int mode) {
-    return (mode == 0 || mode == 2) && max_K <= 8192 && max_N <= 256 && a <= 4 && w <= 8 && (mode == 2 || (ob >= 1 && ob <= 23)) &&
+    return (mode == 0 || mode == 2) && max_K <= 8192 && max_N <= 256 && a <= 8 && w <= 8 && (mode == 2 || (ob >= 1 && ob <= 23)) &&
            static_cast<double>(max_K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0 && !getenv_flag("QGTC_NO_ROWS");
 }
+// ... and cols-layout stages (the operands not swapped, a workgroup per word of a line): what neither _xw_rows / _strip (K <= 128, four
+// planes at most) nor _wave (N <= 64) takes - the X . W stages at --bit_width 5 .. 8 (ogbn-arxiv-sized, 8 bits: 27 us on the 128-tile
+// int8 kernel, 70 us on the popcount one for the class-count stage)
+inline bool rows_cols_ok(int max_K, int max_N, int a, int w, int ob) { return rows_ok(max_K, max_N, a, w, ob, 0) && !getenv_flag("QGTC_NO_ROWS_COLS"); }
 
 // grouped "X . W" stages by row blocks instead of column strips (k_bitmm_fp4_xw_rows)
 inline bool xw_rows_ok(int max_K, int max_N, int a, int w, int ob) {

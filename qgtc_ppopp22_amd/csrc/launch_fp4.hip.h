@@ -191,27 +191,33 @@ int qgtc_launch_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count,
     return QGTC_OK;
 }
 
-// grouped "A . (XW)" stages: one workgroup per 32-row block of a batch, only the occupied k-quads (bitmm_fp4_rows.hip.h)
+// grouped "A . (XW)" stages: one workgroup per 32-row block of a batch, only the occupied k-quads (bitmm_fp4_rows.hip.h); and grouped
+// cols-layout stages no narrower kernel takes (mode 1: five to eight left-hand planes - the X . W stages at --bit_width 5 .. 8 -, or
+// more than 128 bits of K with more than 64 columns): one workgroup per WORD of a line
 int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode, bool qmajor_in, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, mode);
     sh.nowrap = 1;
     sh.per = getenv_flag("QGTC_NO_XCD") ? 0 : 1;   // (here: row blocks of a batch on one XCD)
     sh.qmajor = qmajor_in ? 1 : 0;
-    const int blocks = mode == 2 ? (max_N + 31) / 32 : step128(max_N) * 4;   // 32-column blocks: per 32 columns / per word of a packed row
+    // 32-column blocks: per 32 columns / per word of a packed row / per 32 lines of the cols layout, the padding ones included
+    const int blocks = mode == 2 ? (max_N + 31) / 32 : mode == 1 ? pad128(max_N) / 32 : step128(max_N) * 4;
     // (two column blocks per wave - half the waves, one round of them on the chip instead of 1.4 - measured no faster:
     // 11.1 against 10.6 us on the ogbn-arxiv-sized A-stages; kept as a tuning switch)
-    const bool two = blocks >= 2 && getenv_flag("QGTC_ROWS_CB2");
+    const bool two = blocks >= 2 && mode != 1 && a <= 4 && getenv_flag("QGTC_ROWS_CB2");
     const int waves = two ? (blocks + 1) / 2 : blocks;
-    const dim3 grid((max_M + 31) / 32, count), block(64 * waves);
+    if (waves > 8) return QGTC_EINVAL;
+    const dim3 grid(mode == 1 ? step128(max_M) * 4 : (max_M + 31) / 32, count), block(64 * waves);
 #define QGTC_RW_GO(NA_, NW_, MODE_, OB_)                                                                                   \
     do {                                                                                                                    \
         if (two) hipLaunchKernelGGL((k_bitmm_fp4_rows<NA_, NW_, MODE_, OB_, 2>), grid, block, 0, st, prs, sh);               \
         else hipLaunchKernelGGL((k_bitmm_fp4_rows<NA_, NW_, MODE_, OB_, 1>), grid, block, 0, st, prs, sh);                   \
     } while (0)
+#define QGTC_RW_GO1(NA_, NW_, MODE_, OB_) hipLaunchKernelGGL((k_bitmm_fp4_rows<NA_, NW_, MODE_, OB_, 1>), grid, block, 0, st, prs, sh)
 #define QGTC_RW_LAUNCH(NA_, NW_)                                         \
     if (!done && a <= NA_ && w <= NW_) {                                 \
         done = true;                                                     \
         if (mode == 2) QGTC_RW_GO(NA_, NW_, 2, 0);                       \
+        else if (mode == 1) QGTC_RW_GO1(NA_, NW_, 1, 0);                 \
         else if (ob == 1) QGTC_RW_GO(NA_, NW_, 0, 1);                    \
         else if (ob == 2) QGTC_RW_GO(NA_, NW_, 0, 2);                    \
         else if (ob == 4) QGTC_RW_GO(NA_, NW_, 0, 4);                    \
@@ -220,7 +226,16 @@ int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, i
     }
     bool done = false;
     QGTC_RW_LAUNCH(1, 1) QGTC_RW_LAUNCH(1, 2) QGTC_RW_LAUNCH(1, 4) QGTC_RW_LAUNCH(1, 8) QGTC_RW_LAUNCH(2, 2) QGTC_RW_LAUNCH(4, 4) QGTC_RW_LAUNCH(4, 8)
+    if (!done && a <= 8 && w <= 8) {   // five to eight left-hand planes
+        done = true;
+        if (mode == 2) QGTC_RW_GO1(8, 8, 2, 0);
+        else if (mode == 1 && ob == 8) QGTC_RW_GO1(8, 8, 1, 8);
+        else if (mode == 1) QGTC_RW_GO1(8, 8, 1, 0);
+        else if (ob == 8) QGTC_RW_GO1(8, 8, 0, 8);
+        else QGTC_RW_GO1(8, 8, 0, 0);
+    }
 #undef QGTC_RW_LAUNCH
+#undef QGTC_RW_GO1
 #undef QGTC_RW_GO
     if (!done) return QGTC_EINVAL;
     HIP_TRY(hipGetLastError());

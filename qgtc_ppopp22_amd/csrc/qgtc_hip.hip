@@ -296,6 +296,7 @@ static BatchedRoute batched_route(int max_M, int max_K, int max_N, int bit1, int
     if (engine && mode == 1 && strip_ok(max_M, max_K, bit1, bit2, ob_)) return BR_STRIP;          // X . W stages: column strips
     if (rows_route) return BR_ROWS;   // sparse left operands / narrow outputs / one or two k-quads: one workgroup per 32-row block
     if (engine && fp4_wave_ok(max_K, max_N, bit1, bit2)) return BR_WAVE;                           // narrow outputs: one wave per 32 x 32 tile
+    if (engine && mode == 1 && rows_cols_ok(max_K, max_N, bit1, bit2, ob_)) return BR_ROWS;        // cols-layout stages nothing above takes
     if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) ||  // problems with a one-word bitmap jump zero tiles
         ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma_batched(max_M, max_N, bit1, bit2)))
         return BR_MFMA_128;
