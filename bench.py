@@ -56,12 +56,13 @@ def parse():
     p.add_argument("--streams", type=int, default=1,
                    help="issue the steps round-robin on this many HIP streams (independent launches overlap); "
                         "default 1 = the reference's metric, launches back to back on one stream")
-    p.add_argument("--issue", choices=["eager", "graph"], default="eager",
-                   help="how the K steps of the timed region are issued: eager (default, the reference's way) = K hipLaunchKernel calls inside "
+    p.add_argument("--issue", choices=["auto", "eager", "graph"], default="auto",
+                   help="how the K steps of the timed region are issued: eager (the reference's way) = K hipLaunchKernel calls inside "
                         "the region; graph = the K launches captured ONCE, ahead of the timed region, in a hipGraph and replayed inside it by one "
-                        "hipGraphLaunch (same kernels in stream order). Measured at K = 20: 3.96-3.99 us per step against 3.6 eager - the host's "
-                        "3.1-3.6 us per hipLaunchKernel and the kernel's 3.0 us overlap when issued eagerly, a graph launch adds its own "
-                        "latency ahead of the first kernel; the other way's figure is reported in extras")
+                        "hipGraphLaunch (same kernels in stream order). Which is faster is the HOST's property: at K = 20 eager takes 3.6 us per "
+                        "step on a box whose hipLaunchKernel costs 3.1-3.6 us (it overlaps the kernel's 3.0 us) and 4.6 on one where it costs "
+                        "more; the replay takes 3.97-4.03 on both. auto (default): both are set up ahead of the timed region, each is run five "
+                        "times untimed, the one with the lower median issues the timed region; the other's figure is reported in extras")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget")
     p.add_argument("--backend", choices=["nccl", "gloo"], default=None, help="torch.distributed backend (default: nccl = RCCL)")
     p.add_argument("--dry-run", action="store_true", help="exercise the rank launcher and the collectives only (no GPU)")
@@ -117,7 +118,8 @@ def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams
     """warmup untimed launches, then EXACTLY `steps` launches between barrier+synchronize pairs (the contract's timed
     region: wall seconds), then the SAME `steps` launches once more between two HIP events recorded on the stream the
     kernels are launched on, and max(1, K // 200) event-bracketed windows of 200 launches (the roofline's live launch duration: their
-    mean). Returns (wall seconds, mean stream time per launch in seconds, wall seconds of the event-bracketed K-launch region).
+    mean). Returns (wall seconds, mean stream time per launch in seconds, wall seconds of the event-bracketed K-launch region, the
+    issue mode used, the untimed probe of an "auto" choice or None).
     Why two regions: recording the two events INSIDE the timed region costs 11-12 us of its wall clock whatever the host's
     wait policy (tools/steps20c.py: 84 us with them, 72 us without, for 20 launches that take 63 us on the stream) - the
     instrument would be a seventh of the measurement. The second region is issued right behind the first, same buffers,
@@ -143,7 +145,10 @@ def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams
     # (tools/host_launch_probe.hip: 3.1-3.5 us per hipLaunchKernel), one graph launch 8 us. For THIS kernel it buys nothing: its 3.0 us
     # per launch on the GPU and the host's issue time overlap when issued eagerly (72 us for 20 steps), the replay takes 79 us.
     run_steps, run_window = (lambda: enqueue(steps)), (lambda: enqueue(EVENT_MIN_LAUNCHES))
-    if issue == "graph" and streams <= 1:
+    probe = None
+    if streams > 1:
+        issue = "eager"
+    if issue in ("graph", "auto"):
         graphs = []
         for n in (steps, EVENT_MIN_LAUNCHES):
             g = torch.cuda.CUDAGraph()
@@ -152,7 +157,20 @@ def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams
             g.replay()             # (the first replay uploads the graph: untimed)
             graphs.append(g)
         torch.cuda.synchronize()
-        run_steps, run_window = graphs[0].replay, graphs[1].replay
+        if issue == "auto":        # the host decides: five untimed runs of the K steps each way, alternating, medians compared
+            trials = {"eager": [], "graph": []}
+            for _ in range(5):
+                for mode, fn in (("eager", run_steps), ("graph", graphs[0].replay)):
+                    torch.cuda.synchronize()
+                    tp = time.perf_counter()
+                    fn()
+                    torch.cuda.synchronize()
+                    trials[mode].append(time.perf_counter() - tp)
+            med = {m: sorted(v)[2] for m, v in trials.items()}
+            issue = min(med, key=med.get)
+            probe = {m: round(v * 1e6 / steps, 3) for m, v in med.items()}
+        if issue == "graph":
+            run_steps, run_window = graphs[0].replay, graphs[1].replay
     enqueue(max(warmup, 1))
     torch.cuda.synchronize()
     barrier()
@@ -185,7 +203,7 @@ def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams
         torch.cuda.synchronize()
         per_window.append(ev0.elapsed_time(ev1) * 1e-3 / EVENT_MIN_LAUNCHES)
     per_launch = sum(per_window) / len(per_window)
-    return t1 - t0, per_launch, t3 - t2
+    return t1 - t0, per_launch, t3 - t2, issue, probe
 
 
 def cpu_baseline(M, K, N, w, A, X, budget_s):
@@ -669,12 +687,12 @@ def main():
     with engine(Q, args.engine):
         out_e = Q.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w)
         assert torch.equal(out_e, out), "engines disagree"
-        wall, kern, wall_ev = time_steps(Q, out_e, bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams, args.issue)
+        wall, kern, wall_ev, issue_used, issue_probe = time_steps(Q, out_e, bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams, args.issue)
         assert torch.equal(out_e, out), "the timed launches changed the result"      # (the replayed / eager launches wrote out_e again)
         eager_headline = None
         if rank == 0 and world == 1 and not args.no_extras and args.streams <= 1:
-            other_issue = "graph" if args.issue == "eager" else "eager"
-            e_wall, e_kern, _ = time_steps(Q, out_e, bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, 1, other_issue)
+            other_issue = "graph" if issue_used == "eager" else "eager"
+            e_wall, e_kern, _, _, _ = time_steps(Q, out_e, bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, 1, other_issue)
             eager_headline = {"issue": other_issue, "TOPS": round(args.steps * 2.0 * M * K * N / e_wall / 1e12, 3),
                               "ms_per_step": round(e_wall * 1e3 / args.steps, 6), "us_per_launch_hip_events": round(e_kern * 1e6, 3),
                               "note": "the same K steps issued the other way (graph: captured once ahead of the timed region, one hipGraphLaunch inside "
@@ -684,7 +702,7 @@ def main():
     other_engine, other_headline = ("popcount" if args.engine != "popcount" else "auto"), None
     if rank == 0 and world == 1 and not args.no_extras:
         with engine(Q, other_engine):
-            o_wall, o_kern, _ = time_steps(Q, torch.empty_like(out), bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams, args.issue)
+            o_wall, o_kern, _, _, _ = time_steps(Q, torch.empty_like(out), bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams, args.issue)
         other_headline = {"TOPS": round(args.steps * 2.0 * M * K * N / o_wall / 1e12, 3), "us_per_launch": round(o_kern * 1e6, 3)}
         if other_engine == "popcount":   # the engine BASELINE.json's north star names, against BOTH statements of its VALU roofline
             other_headline["valu_frac_of_measured_pair_rate_4.2e13"] = round(eff_ops_of(M, K, N) * w / o_kern / VALU_PEAK_BITOPS, 4)
@@ -730,7 +748,7 @@ def main():
                     "achieved": round(algo_bytes / kern / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac_hbm,
                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(algo_bytes),
                     "avg_launch_us": round(kern * 1e6, 3),
-                    "avg_launch_window": "%d x %d launches, issued like the timed region (%s)" % (max(1, args.steps // EVENT_MIN_LAUNCHES), EVENT_MIN_LAUNCHES, args.issue),
+                    "avg_launch_window": "%d x %d launches, issued like the timed region (%s)" % (max(1, args.steps // EVENT_MIN_LAUNCHES), EVENT_MIN_LAUNCHES, issue_used),
                     "avg_launch_source": "HIP events on the launch stream around windows of %d of the same launches issued right behind the timed "
                                          "region (inside it the two event records cost 11-12 us of a 72 us window), max(1, K // %d) windows "
                                          "averaged: kernel + dependent-launch gap (~1.5 us), i.e. what a caller gets per launch" % (EVENT_MIN_LAUNCHES, EVENT_MIN_LAUNCHES),
@@ -765,7 +783,9 @@ def main():
                    "engine": args.engine + (" (library default) -> FP4 matrix-core kernel for narrow right operands" if fp4_kernel else " -> AND + popcount kernels"),
                    "issue": ("back-to-back launches on one stream (the reference's metric)" + (": the K launches captured once in a hipGraph ahead of the "
                              "timed region, ONE hipGraphLaunch inside it (same kernels in stream order; eager issue: extras.headline_other_issue)"
-                             if args.issue == "graph" else ": K hipLaunchKernel calls inside the timed region (graph replay: extras.headline_other_issue)")) if args.streams <= 1
+                             if issue_used == "graph" else ": K hipLaunchKernel calls inside the timed region (graph replay: extras.headline_other_issue)")
+                             + ("" if issue_probe is None else f"; chosen by an untimed probe ahead of the timed region (median of five runs of the K steps each way, "
+                                                               f"us per step: {issue_probe})")) if args.streams <= 1
                             else f"independent launches round-robin on {args.streams} HIP streams",
                    "clock_warmup": f"{CLOCK_WARMUP_S} s of untimed launches ahead of the W warmup steps (the chip idles into a low "
                                    "power state while the host builds inputs; nothing else precedes the timed region)"},

@@ -25,5 +25,5 @@ time.sleep(0.01)
 print("after 10 ms idle:", [win() for _ in range(4)])
 print("--- bench.time_steps itself ---")
 for steps in (1000, 1000, 200, 1000):
-    wall, kern, wall_ev = bench.time_steps(Q, out, bA, bX, M, K, N, w, steps, 50, lambda: None)
+    wall, kern, wall_ev, _, _ = bench.time_steps(Q, out, bA, bX, M, K, N, w, steps, 50, lambda: None)
     print(steps, "wall us/step", round(wall / steps * 1e6, 3), "event us/launch", round(kern * 1e6, 3), "event-region wall us/step", round(wall_ev / steps * 1e6, 3))
