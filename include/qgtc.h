@@ -333,8 +333,9 @@ int qgtc_epoch_plan_fill(const qgtc_batch *batches, int count, const qgtc_stage 
  *                          out_mode 2: out_b = float32(requant(A_b . T_b) . W')        stage_xw[b] = {-, -, out_b [M, N2]}
  * A_b: rows layout (or, with QGTC_CHAIN_ADJ_TILES, the tile format of qgtc_adj_tiles_from_rows), ONE plane, K <= 8192
  * (occupancy bitmaps of the descriptors are followed); t_bits / act_bits /
- * out_bits = bits of T / of the aggregate / of T': all 2 with N, N2 <= 128 and 1- or 2-plane weights (t_bits also 1), or all
- * 4 with N, N2 <= 64 and 4-plane weights (Batched-GIN on ppi); qgtc_chain_transform: 2-bit only.
+ * out_bits = bits of T / of the aggregate / of T': 1 .. 4, act_bits == out_bits (= the planes of the weights: a chain has one
+ * width, main_qgtc.py's --bit_width), t_bits in the same format class (1 / 2 bits: one base-4 digit a nibble; 3 / 4 bits: two),
+ * N, N2 <= 128; qgtc_chain_transform: out_bits 1 .. 4, x_bits <= 2 (out_bits <= 2) or <= 4 (out_bits 3 / 4).
  * QGTC_EINVAL outside that range: callers fall back to qgtc_gcn_chain_batched. w_codes: qgtc_expand_weights order 0 for
  * qgtc_chain_transform (the left operand arrives as packed words), order 1 for qgtc_chain_aggregate (the left operand is
  * the aggregate in the registers of the wave that computed it). max_M is a hard precondition (QGTC_CHECK_DESCRIPTORS). */

@@ -192,7 +192,7 @@ __device__ __forceinline__ void rbw_pin(const qgtc_problem &pr) {
 // 16 re-quantised values (low OB bits of each byte of P) -> the two code dwords of a column block (see rbw_column)
 template <int OB>
 __device__ __forceinline__ void rbw_nibbles(const uint32_t (&P)[4], uint32_t &A, uint32_t &B) {
-    constexpr uint32_t mask = OB == 1 ? 0x01010101u : (OB == 2 ? 0x03030303u : 0x0f0f0f0fu);
+    constexpr uint32_t mask = ((1u << OB) - 1u) * 0x01010101u;   // (the low OB bits of a byte are the value: requant_pack16)
     A = (P[0] & mask) | ((P[1] & mask) << 4);
     B = (P[2] & mask) | ((P[3] & mask) << 4);
 }
@@ -209,7 +209,7 @@ __device__ __forceinline__ void rbw_store_codes(const f32x16 &acc, uint32_t *__r
     requant_pack16<OB>(acc, OB, P, qv);
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        x[t] = (P[t] & (OB == 1 ? 0x01010101u : (OB == 2 ? 0x03030303u : 0x0f0f0f0fu))) << (4u - 4u * static_cast<uint32_t>(fh));   // nibble 7 - 2 gq - fh of dword 3 - t
+        x[t] = (P[t] & (((1u << OB) - 1u) * 0x01010101u)) << (4u - 4u * static_cast<uint32_t>(fh));   // nibble 7 - 2 gq - fh of dword 3 - t
         x[t] = or_with_partner_half(x[t]);
     }
 #endif
@@ -259,6 +259,7 @@ __device__ __forceinline__ void rbw_store_f32_row(__amdgpu_buffer_rsrc_t ro, uin
 template <int NA, int OB, int NCB>
 __device__ __forceinline__ void rbw_xw_body(const qgtc_problem &pr, const u32x4 *__restrict__ w_codes, const RbwShape &sh, int grp) {
     constexpr int NDA = (NA + 1) / 2;
+    constexpr int NDW = OB > 2 ? 2 : 1;   // base-4 digits of W (a chain has ONE width: W has as many planes as T)
     const int M = pr.M, N = pr.N;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -275,11 +276,13 @@ __device__ __forceinline__ void rbw_xw_body(const qgtc_problem &pr, const u32x4 
         xl[0][p] = v.x;
         xl[1][p] = v.y;
     }
-    u32x4 wc[NCB][2];
+    u32x4 wc[NCB][2][NDW];
 #pragma unroll
     for (int jn = 0; jn < NCB; jn++)
 #pragma unroll
-        for (int h = 0; h < 2; h++) wc[jn][h] = w_codes[(jn * 2 + h) * 64 + lane];
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int dw = 0; dw < NDW; dw++) wc[jn][h][dw] = w_codes[((jn * 2 + h) * NDW + dw) * 64 + lane];
     i32x8 xa[2][NDA];
 #pragma unroll
     for (int h = 0; h < 2; h++)
@@ -294,7 +297,9 @@ __device__ __forceinline__ void rbw_xw_body(const qgtc_problem &pr, const u32x4 
         for (int h = 0; h < 2; h++)
 #pragma unroll
             for (int da = 0; da < NDA; da++)
-                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[h][da], fp4_op(wc[jn][h]), acc, 4, 4, 0, 128 + 2 * da, 0, 128);   // not swapped: lane = column 32 jn + fl
+#pragma unroll
+                for (int dw = 0; dw < NDW; dw++)
+                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[h][da], fp4_op(wc[jn][h][dw]), acc, 4, 4, 0, 128 + 2 * da, 0, 128 + 2 * dw);   // not swapped: lane = column 32 jn + fl
         accs[jn] = acc;
     }
 #pragma unroll

@@ -187,17 +187,16 @@ inline bool chain_ok(int max_K, int max_N1, int max_N2, int a, int w, int ob, in
 }
 
 // the chain entries (bitmm_fp4_rbw.hip.h): one wave per row block, T in the chain format, weights pre-expanded
-inline bool rbw_xw_ok(int K, int N, int x_bits, int out_bits) { return K >= 1 && K <= 128 && N >= 1 && N <= 128 && x_bits >= 1 && x_bits <= 2 && out_bits == 2; }
+// One width b = 1 .. 4 per chain (planes of X, W, T alike - what main_qgtc.py's --bit_width gives); 1 / 2 bits are one base-4 digit a
+// nibble, 3 / 4 bits two. N, N' <= 128; float32 sums exact (4 bits: K 15 < 2^24 for the aggregation, 128 x 15 x 15 for X . W).
+inline bool rbw_xw_ok(int K, int N, int x_bits, int out_bits) {
+    return K >= 1 && K <= 128 && N >= 1 && N <= 128 && out_bits >= 1 && out_bits <= 4 && x_bits >= 1 && x_bits <= (out_bits > 2 ? 4 : 2);
+}
 inline bool rbw_chain_ok(int max_K, int N1, int N2, int t_bits, int act_bits, int out_bits, int mode2) {
-    if (max_K < 1 || N1 < 1) return false;
-    if (t_bits == 4) {   // 4-bit values (two base-4 digits a nibble): the widths of the ppi epochs
-        if (N1 > 64 || static_cast<double>(max_K) * 15.0 >= 16777216.0 || max_K > 8192) return false;
-        if (mode2 == 0) return true;
-        return N2 >= 1 && N2 <= 64 && act_bits == 4 && (mode2 == 2 || out_bits == 4);
-    }
-    if (max_K > 8192 || N1 > 128 || (t_bits != 1 && t_bits != 2)) return false;
+    if (max_K < 1 || max_K > 8192 || N1 < 1 || N1 > 128 || t_bits < 1 || t_bits > 4) return false;
     if (mode2 == 0) return true;
-    return N2 >= 1 && N2 <= 128 && act_bits == 2 && (mode2 == 2 || out_bits == 2);
+    const bool wide = t_bits > 2;   // the format class of T, of the aggregate and of W' must agree
+    return N2 >= 1 && N2 <= 128 && act_bits >= 1 && act_bits <= 4 && (act_bits > 2) == wide && (mode2 == 2 || out_bits == act_bits);
 }
 
 // grouped launches on the matrix cores, one wave per 32 x 32 tile (bitmm_fp4_wave.hip.h): for NARROW outputs.

@@ -308,14 +308,22 @@ int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int N, int
     const int gx = static_cast<int>(grid.x), gy = static_cast<int>(grid.y);
     const u32x4 *wc = reinterpret_cast<const u32x4 *>(w_codes);
     const int ncb = (N + 31) / 32;
-    if (ob != 2 || a > 2) return QGTC_EINVAL;
-    switch (ncb) {
-        case 1: hipLaunchKernelGGL((k_rbw_xw<2, 2, 1>), grid, block, 0, st, prs, wc, per, a, gx, gy); break;
-        case 2: hipLaunchKernelGGL((k_rbw_xw<2, 2, 2>), grid, block, 0, st, prs, wc, per, a, gx, gy); break;
-        case 3: hipLaunchKernelGGL((k_rbw_xw<2, 2, 3>), grid, block, 0, st, prs, wc, per, a, gx, gy); break;
-        case 4: hipLaunchKernelGGL((k_rbw_xw<2, 2, 4>), grid, block, 0, st, prs, wc, per, a, gx, gy); break;
-        default: return QGTC_EINVAL;
+    if (ob < 1 || ob > 4 || a < 1 || a > (ob > 2 ? 4 : 2) || ncb < 1 || ncb > 4) return QGTC_EINVAL;
+    // column blocks 1 / 2 / 4 (three run as four: the lines past N are zeros); the 2-bit chain of the BASELINE epoch also has its own three
+#define QGTC_RBWX_GO(NA_, OB_, NCB_) hipLaunchKernelGGL((k_rbw_xw<NA_, OB_, NCB_>), grid, block, 0, st, prs, wc, per, a, gx, gy)
+#define QGTC_RBWX_OB(NA_, OB_)                                            \
+    if (ncb == 1) QGTC_RBWX_GO(NA_, OB_, 1);                              \
+    else if (ncb == 2) QGTC_RBWX_GO(NA_, OB_, 2);                         \
+    else if (ncb == 3 && OB_ == 2) QGTC_RBWX_GO(NA_, OB_, (OB_ == 2 ? 3 : 4)); \
+    else QGTC_RBWX_GO(NA_, OB_, 4)
+    switch (ob) {
+        case 1: QGTC_RBWX_OB(2, 1); break;
+        case 2: QGTC_RBWX_OB(2, 2); break;
+        case 3: QGTC_RBWX_OB(4, 3); break;
+        default: QGTC_RBWX_OB(4, 4); break;
     }
+#undef QGTC_RBWX_OB
+#undef QGTC_RBWX_GO
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
 }
@@ -330,56 +338,59 @@ int qgtc_launch_rows_to_tiles(const uint32_t *rows, size_t words, int M, int K, 
 
 int qgtc_launch_rbw_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int N1, int N2, int t_bits, int act_bits,
                           int out_bits, int mode2, const uint32_t *w2_codes, bool a_tiles, hipStream_t st) {
-    (void)act_bits;   // (1- and 2-bit T are the same codes: one base-4 digit per nibble)
-    (void)out_bits;
+    // One kernel family per WIDTH of the chain: OB = the planes of the re-quantised aggregate (= of W': a chain has one width), OB2 =
+    // those of T'. T's own planes only select the format class - 1- and 2-bit T are the same codes (one base-4 digit a nibble), 3- and
+    // 4-bit T two digits a nibble - which rbw_chain_ok has checked against the aggregate's.
     const int per = getenv_flag("QGTC_NO_XCD") ? 0 : 1, tiles = a_tiles ? 1 : 0;   // (row blocks of a batch on one XCD)
     const dim3 grid(step128(max_M), count), block(256);
     const int gx = static_cast<int>(grid.x), gy = static_cast<int>(grid.y);
     const u32x4 *wc = reinterpret_cast<const u32x4 *>(w2_codes);
     const int c1 = (N1 + 31) / 32, c2 = mode2 == 0 ? 1 : (N2 + 31) / 32;
-    if (t_bits == 4) {   // the 4-bit chains: N, N' <= 64
-#define QGTC_RBW4_GO(MODE2_, C1_, C2_) hipLaunchKernelGGL((k_rbw_chain<4, 4, MODE2_, C1_, C2_>), grid, block, 0, st, p1, p2, wc, per, tiles, gx, gy)
-        if (c1 > 2 || c2 > 2) return QGTC_EINVAL;
-        if (mode2 == 0) { if (c1 == 1) QGTC_RBW4_GO(0, 1, 1); else QGTC_RBW4_GO(0, 2, 1); }
-        else if (mode2 == 1) {
-            if (c1 == 1) { if (c2 == 1) QGTC_RBW4_GO(1, 1, 1); else QGTC_RBW4_GO(1, 1, 2); }
-            else { if (c2 == 1) QGTC_RBW4_GO(1, 2, 1); else QGTC_RBW4_GO(1, 2, 2); }
-        } else {
-            if (c1 == 1) { if (c2 == 1) QGTC_RBW4_GO(2, 1, 1); else QGTC_RBW4_GO(2, 1, 2); }
-            else { if (c2 == 1) QGTC_RBW4_GO(2, 2, 1); else QGTC_RBW4_GO(2, 2, 2); }
-        }
-#undef QGTC_RBW4_GO
-        HIP_TRY(hipGetLastError());
-        return QGTC_OK;
+    if (c1 < 1 || c1 > 4 || c2 < 1 || c2 > 4 || mode2 < 0 || mode2 > 2) return QGTC_EINVAL;
+    const int ob = mode2 == 0 ? t_bits : act_bits;   // (the float32 aggregation re-quantises nothing: the format class of T is all it needs)
+    (void)out_bits;                                  // (== act_bits: rbw_chain_ok)
+#define QGTC_RBW_GO(OB_, MODE2_, C1_, C2_) hipLaunchKernelGGL((k_rbw_chain<OB_, OB_, MODE2_, C1_, C2_>), grid, block, 0, st, p1, p2, wc, per, tiles, gx, gy)
+    // column blocks 1 / 2 / 4 (three run as four: lines past N are zeros, columns past N are not stored); the 2-bit family - the
+    // BASELINE epoch's - keeps its own three
+#define QGTC_RBW_C2(OB_, MODE2_, C1_)                                    \
+    switch (c2) {                                                        \
+        case 1: QGTC_RBW_GO(OB_, MODE2_, C1_, 1); break;                 \
+        case 2: QGTC_RBW_GO(OB_, MODE2_, C1_, 2); break;                 \
+        case 3: QGTC_RBW_GO(OB_, MODE2_, C1_, (OB_ == 2 ? 3 : 4)); break; \
+        default: QGTC_RBW_GO(OB_, MODE2_, C1_, 4); break;                \
     }
-#define QGTC_RBW_GO(MODE2_, C1_, C2_) hipLaunchKernelGGL((k_rbw_chain<2, 2, MODE2_, C1_, C2_>), grid, block, 0, st, p1, p2, wc, per, tiles, gx, gy)
-#define QGTC_RBW_C2(MODE2_, C1_)                       \
-    switch (c2) {                                      \
-        case 1: QGTC_RBW_GO(MODE2_, C1_, 1); break;    \
-        case 2: QGTC_RBW_GO(MODE2_, C1_, 2); break;    \
-        case 3: QGTC_RBW_GO(MODE2_, C1_, 3); break;    \
-        default: QGTC_RBW_GO(MODE2_, C1_, 4); break;   \
+#define QGTC_RBW_C1(OB_, MODE2_)                                         \
+    switch (c1) {                                                        \
+        case 1: QGTC_RBW_C2(OB_, MODE2_, 1) break;                       \
+        case 2: QGTC_RBW_C2(OB_, MODE2_, 2) break;                       \
+        case 3: QGTC_RBW_C2(OB_, MODE2_, (OB_ == 2 ? 3 : 4)) break;      \
+        default: QGTC_RBW_C2(OB_, MODE2_, 4) break;                      \
     }
-#define QGTC_RBW_C1(MODE2_)                            \
-    switch (c1) {                                      \
-        case 1: QGTC_RBW_C2(MODE2_, 1) break;          \
-        case 2: QGTC_RBW_C2(MODE2_, 2) break;          \
-        case 3: QGTC_RBW_C2(MODE2_, 3) break;          \
-        default: QGTC_RBW_C2(MODE2_, 4) break;         \
+#define QGTC_RBW_M0(OB_)                                                 \
+    switch (c1) {                                                        \
+        case 1: QGTC_RBW_GO(OB_, 0, 1, 1); break;                        \
+        case 2: QGTC_RBW_GO(OB_, 0, 2, 1); break;                        \
+        case 3: QGTC_RBW_GO(OB_, 0, (OB_ == 2 ? 3 : 4), 1); break;       \
+        default: QGTC_RBW_GO(OB_, 0, 4, 1); break;                       \
     }
-    if (c1 < 1 || c1 > 4 || c2 < 1 || c2 > 4) return QGTC_EINVAL;
-    if (mode2 == 0) {
-        switch (c1) {
-            case 1: QGTC_RBW_GO(0, 1, 1); break;
-            case 2: QGTC_RBW_GO(0, 2, 1); break;
-            case 3: QGTC_RBW_GO(0, 3, 1); break;
-            default: QGTC_RBW_GO(0, 4, 1); break;
-        }
-    } else if (mode2 == 1) {
-        QGTC_RBW_C1(1)
+#define QGTC_RBW_M12(OB_)                                                \
+    if (mode2 == 1) {                                                    \
+        QGTC_RBW_C1(OB_, 1)                                              \
+    } else {                                                             \
+        QGTC_RBW_C1(OB_, 2)                                              \
+    }
+    if (mode2 == 0) {   // (the float32 aggregation re-quantises nothing: one kernel per format class of T)
+        if (ob <= 2) { QGTC_RBW_M0(2) } else { QGTC_RBW_M0(4) }
     } else {
-        QGTC_RBW_C1(2)
+        switch (ob) {
+            case 1: QGTC_RBW_M12(1) break;
+            case 2: QGTC_RBW_M12(2) break;
+            case 3: QGTC_RBW_M12(3) break;
+            default: QGTC_RBW_M12(4) break;
+        }
     }
+#undef QGTC_RBW_M12
+#undef QGTC_RBW_M0
 #undef QGTC_RBW_C1
 #undef QGTC_RBW_C2
 #undef QGTC_RBW_GO

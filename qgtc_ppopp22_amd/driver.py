@@ -345,9 +345,9 @@ class PlannedEpoch:
         # the library's own routing switches that take the chain entries / chained pairs away (perf-only switches such as
         # QGTC_NO_XCD leave the route alone)
         switches = routing_switches()
-        if (fuse and chain == "correct" and chain_stages and not run_gin and not keep_aggregates and b == 2 and max(F, H, C) <= 128 and max_n <= 8192
+        if (fuse and chain == "correct" and chain_stages and not run_gin and not keep_aggregates and 1 <= b <= 4 and max(F, H, C) <= 128 and max_n <= 8192
                 and Q.get_engine() != "popcount" and not switches):
-            # The 2-bit Cluster-GCN chain on the chain entries (qgtc_chain_transform / qgtc_chain_aggregate): one wave per row
+            # The Cluster-GCN chain (1 .. 4 bits; the BASELINE epoch: 2) on the chain entries (qgtc_chain_transform / qgtc_chain_aggregate): one wave per row
             # block for the whole width, T between the launches as finished matrix-core operands, weights pre-expanded once
             # per plan. X.W1 | A.T1 + .W2 | A.T2 + .W3 | A.T3 -> float32: four launches.
             for i in (0, 2, 4):
@@ -358,9 +358,9 @@ class PlannedEpoch:
             if getattr(data, "a_tiles", False):   # the aggregations read the adjacency as 512-byte tiles
                 for i in (1, 3, 5):
                     stages[i] = (Q.SRC_AT,) + stages[i][1:]
-        elif (fuse and chain == "correct" and chain_stages and run_gin and not keep_aggregates and b == 4 and max(F, H, C) <= 64 and max_n <= 8192
+        elif (fuse and chain == "correct" and chain_stages and run_gin and not keep_aggregates and 1 <= b <= 4 and max(F, H, C) <= 128 and max_n <= 8192
                 and Q.get_engine() != "popcount" and not switches and getattr(data, "x_chain", False)):
-            # Batched-GIN at 4 bits on the same entries: A.X + .W1 | A.T1 + .W2 | A.T2 + .W3 -> float32, three launches; X in the
+            # Batched-GIN (1 .. 4 bits; the BASELINE epoch: 4) on the same entries: A.X + .W1 | A.T1 + .W2 | A.T2 + .W3 -> float32, three launches; X in the
             # chain format from the data loader (ClusterIter.epoch_data), T between the launches likewise
             stages[0] = (stages[0][0], Q.SRC_XC) + stages[0][2:]
             for i in (1, 3):

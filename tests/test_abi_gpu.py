@@ -373,14 +373,14 @@ class QgtcExpandJob(ctypes.Structure):
 
 @pytest.mark.parametrize("M,K,F,H,C,bitmaps", [(333, 333, 48, 128, 10, True), (150, 150, 128, 64, 128, False), (300, 150, 32, 100, 33, True),
                                                (150, 300, 100, 33, 70, True), (1213, 1213, 128, 128, 128, True), (40, 40, 7, 5, 3, False)])
-def test_chain_entries_with_raw_descriptors(lib, oracle, M, K, F, H, C, bitmaps):
+@pytest.mark.parametrize("b", [2, 1, 3, 4])     # one width per chain (main_qgtc.py's --bit_width); the BASELINE epoch: 2
+def test_chain_entries_with_raw_descriptors(lib, oracle, M, K, F, H, C, bitmaps, b):
     """qgtc_expand_weights + qgtc_chain_transform + qgtc_chain_aggregate through ctypes: T = requant(X . W1) in the chain's
     private format, T' = requant(requant(A . T) . W2) (out_mode 1), then float32(A2 . T') (out_mode 0) and
     float32(requant(A . T) . W2) (out_mode 2) against the oracle's public operators. Ragged sizes, widths that are not
     multiples of 32, non-square adjacencies (the diagonal k-quad does not exist for every row group), with and without
     occupancy bitmaps, three batches per launch."""
     import torch
-    b = 2
     lib.qgtc_weight_codes_words.restype = lib.qgtc_chain_words.restype = lib.qgtc_occupancy_words.restype = ctypes.c_size_t
     lib.qgtc_expand_weights.argtypes = [vp, ctypes.c_int, vp]
     lib.qgtc_chain_transform.argtypes = [vp, ctypes.c_int] + [ctypes.c_int] * 5 + [vp, ctypes.c_uint, vp]
@@ -451,13 +451,15 @@ def test_chain_entries_with_raw_descriptors(lib, oracle, M, K, F, H, C, bitmaps)
     assert lib.qgtc_last_batched_violation(None, None, st) == 0
     # outside the entries' range: error codes (callers fall back to qgtc_gcn_chain_batched)
     assert lib.qgtc_chain_transform(d(0), count, K, 129, H, b, b, c1.data_ptr(), 0, st) == 1          # K > 128
-    assert lib.qgtc_chain_transform(d(0), count, K, F, H, b, 4, c1.data_ptr(), 0, st) == 1            # 4-bit T
+    assert lib.qgtc_chain_transform(d(0), count, K, F, H, b, 5, c1.data_ptr(), 0, st) == 1            # 5-bit T
+    assert lib.qgtc_chain_transform(d(0), count, K, F, H, 3, 2, c1.data_ptr(), 0, st) == 1            # three planes of X into a one-digit chain
+    assert lib.qgtc_chain_aggregate(d(1), d(2), count, M, K, H, C, b, 5 - b, 5 - b, 1, c2.data_ptr(), 0, st) == 1   # T and the aggregate in different format classes
     assert lib.qgtc_chain_aggregate(d(1), d(2), count, M, K, 129, C, b, b, b, 1, c2.data_ptr(), 0, st) == 1
     assert lib.qgtc_chain_aggregate(d(1), None, count, M, K, H, C, b, b, b, 1, c2.data_ptr(), 0, st) == 1
     assert lib.qgtc_expand_weights(ctypes.addressof(jobs), 9, st) == 1
 
 
-@pytest.mark.parametrize("M,F,H,C,bitmaps", [(599, 50, 64, 10, True), (333, 64, 33, 64, False), (40, 7, 5, 3, True)])
+@pytest.mark.parametrize("M,F,H,C,bitmaps", [(599, 50, 64, 10, True), (333, 64, 33, 64, False), (40, 7, 5, 3, True), (333, 100, 128, 70, True)])
 def test_chain_entries_at_four_bits(lib, oracle, M, F, H, C, bitmaps):
     """The Batched-GIN shape of the chain entries (main_qgtc.py:131-138 with every right operand in the cols layout): X arrives in
     the PUBLIC cols layout and is converted once (qgtc_chain_from_cols, the data loader's step), then
@@ -533,7 +535,7 @@ def test_chain_entries_at_four_bits(lib, oracle, M, F, H, C, bitmaps):
     if H + 1 <= 64:
         assert lib.qgtc_chain_aggregate(d(0), d(1), count, M, M, F, H + 1, b, b, b, 1, c1.data_ptr(), 0x200, st) == 0
         assert lib.qgtc_last_batched_violation(ctypes.byref(prob), ctypes.byref(field), st) == 1 and field.value == 3
-    assert lib.qgtc_chain_aggregate(d(0), d(1), count, M, M, 65, H, b, b, b, 1, c1.data_ptr(), 0, st) == 1     # 4-bit chains: N <= 64
+    assert lib.qgtc_chain_aggregate(d(0), d(1), count, M, M, 129, H, b, b, b, 1, c1.data_ptr(), 0, st) == 1    # N <= 128
     assert lib.qgtc_chain_from_cols(dX.data_ptr(), dX.numel(), 10, 10, 5, XC.data_ptr(), XC.numel(), st) == 1   # at most four planes
     assert lib.qgtc_chain_from_cols(dX.data_ptr(), dX.numel(), M, F, b, XC.data_ptr(), 3, st) == 2
 
