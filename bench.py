@@ -284,7 +284,7 @@ def keep_clock_up(plan_run):
 
 
 def epoch_leg(Q, rank, world, device_index, dataset="ogbn-arxiv", bits=2, hidden=128, gin=False, full=True, psize=1500,
-              batch_size=20, only=None, weak=False, gather="summaries"):
+              batch_size=20, only=None, weak=False, gather="summaries", classes=10):
     """Epoch time (BASELINE.json configs 3/4/5): a synthetic graph of the dataset's size, 75 batches. Legs: per-batch launches
     (the reference's structure: six extension calls per batch), the same with the packed batches parked on the CPU and
     uploaded every iteration (main_qgtc.py:115), the same captured in a hipGraph, cluster_gcn.py's pack-inside-the-loop
@@ -295,7 +295,7 @@ def epoch_leg(Q, rank, world, device_index, dataset="ogbn-arxiv", bits=2, hidden
     `weak` True = every rank runs all 75 batches of ITS OWN graph of that size (seed + rank): per-GPU work fixed."""
     from qgtc_ppopp22_amd import dist as D, driver, graph as G
 
-    base = ["--dataset", dataset, "--n-hidden", str(hidden), "--n-classes", "10", "--bit_width", str(bits),
+    base = ["--dataset", dataset, "--n-hidden", str(hidden), "--n-classes", str(classes), "--bit_width", str(bits),
             "--use_QGTC", "--gpu", str(device_index), "--quiet", "--n-epochs", "20"] + (["--run_GIN"] if gin else [])
     base += ["--psize", str(psize), "--batch-size", str(batch_size)]
     n_batches = psize // batch_size
@@ -937,6 +937,19 @@ def main():
                                                   "ppi-sized 4-bit (configs[3]); ms_driver_style = main_qgtc.py:157-159's Avg. Epoch of the grouped plan, "
                                                   "kernel_us = HIP events around the launches, frac = dense algorithmic bytes / kernel time / 8 TB/s, "
                                                   "frac_on_traffic = counter bytes instead; loader_ms_once = the iterator's one-off packing (GPU time)")
+            if rank == 0 and world == 1:
+                # The ONE epoch table the reference publishes (README.md:84-89): Cluster-GCN, the script's settings -
+                # hidden 16, psize 1500, batch 20, 2 bits, each dataset's own --dim / --n-classes (0_7a_eval_QGTC_cluster_GCN.py:6-16,38-40:
+                # ppi and ogbn-arxiv run on main_qgtc.py's default 10 classes) - on synthetic graphs of those datasets' sizes
+                table = {}
+                for ds, cls, ref_ms in (("artist", 12, 263.646), ("soc-BlogCatalog", 39, 209.495), ("ppi", 10, 189.016), ("ogbn-arxiv", 10, 208.616)):
+                    e4, _ = epoch_leg(Q, rank, world, local, dataset=ds, bits=2, hidden=16, classes=cls, full=False,
+                                      only=("per_batch_reference_chain", "batched_correct_chain"))
+                    table[ds] = {"per_batch_unchanged_driver_ms": e4["per_batch_reference_chain_ms"], "grouped_correct_chain_ms": e4["batched_correct_chain_ms"],
+                                 "ref_sm86_ms": ref_ms}
+                table["note"] = ("README.md:84-89's table (it does not say whether its figures are the QGTC or the DGL run); synthetic SBM graphs with the "
+                                 "datasets' node / edge counts and feature widths, 75 cluster batches each")
+                extras["readme_cluster_gcn_table_hidden16_2bit"] = table
             if rank == 0 and world == 1:
                 from oracle.dgl_cpu_baseline import graphsage_cpu_epoch
                 from qgtc_ppopp22_amd import graph as G

@@ -14,10 +14,16 @@ import dataclasses
 
 import numpy as np
 
-# name -> (train nodes, avg out-degree, feature dim); public dataset facts quoted in SURVEY.md §8
+# name -> (train nodes, avg out-degree, feature dim); public dataset facts quoted in SURVEY.md §8. The other names are the datasets the
+# reference's scripts run (0_7a_eval_QGTC_cluster_GCN.py:12-16,38-42; README.md:84-89 publishes epoch times for artist and
+# soc-BlogCatalog): node / edge counts as published with those collections, feature widths = the scripts' own --dim values
 PRESETS = {
     "ogbn-arxiv": (90941, 7.0, 128),
     "ppi": (44906, 28.0, 50),
+    "artist": (50515, 32.4, 100),            # 1 638 396 edges
+    "soc-BlogCatalog": (88784, 23.6, 128),   # 2 093 195 edges
+    "Proteins": (43471, 3.7, 29),            # 162 088 edges
+    "ogbn-products": (196615, 25.0, 100),    # the training split; ~50 neighbours a node in the full graph, half of them inside the split
     "tiny": (2000, 6.0, 32),
 }
 
