@@ -13,10 +13,7 @@ int qgtc_launch_mfma_batched(const qgtc_problem *prs, int count, int max_M, int 
 // defined in qgtc_fp4.hip
 int qgtc_launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, bool zero_skip, hipStream_t st);
 bool qgtc_skinny_is_one(const qgtc_problem &pr, int ob, int mode);
-int qgtc_launch_fp4_wave(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode,
-                         bool zero_skip, hipStream_t st);
 int qgtc_launch_rows_single(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st);
-int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, hipStream_t st);
 int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode, bool qmajor_in, hipStream_t st);
 int qgtc_launch_xw_rows(const qgtc_problem *prs, int count, int max_M, int a, int w, int ob, bool qmajor_out, hipStream_t st);
 int qgtc_launch_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int w, int ob, int w2, int ob2, int mode2, bool discard, int codes, hipStream_t st);
@@ -153,27 +150,17 @@ inline bool auto_prefers_skinny(int M, int K, int N, int a, int w) {
     return true;
 }
 
-// grouped "X . W" stages of an epoch (one k-quad of K, cols-layout output): one workgroup per 32-column strip of a
-// batch, whole output lines written at once (bitmm_fp4_strip.hip.h). Measured on the ogbn-arxiv-sized epoch: 12 -> 5 us
-// per stage against the 128 x 128-tile kernel, and 11 -> 4 us for the 10-class stage against one wave per 32 x 32 tile.
-inline size_t strip_lds_bytes(int max_M, int ob) { return static_cast<size_t>(ob) * 32u * (step128(max_M) * 4u + 1u) * 4u; }
-inline bool strip_ok(int max_M, int max_K, int a, int w, int ob) {
-    return max_K <= 128 && a <= 4 && w <= 8 && ob >= 1 && ob <= 23 && strip_lds_bytes(max_M, ob) <= 64u * 1024u &&
-           !getenv_flag("QGTC_NO_STRIP");
-}
-
 // grouped "A . (XW)" stages (rows-layout bits or float32 out, at most 256 columns): one workgroup per 32-row block of a
 // batch, visiting only the k-quads its occupancy word names (bitmm_fp4_rows.hip.h)
 inline bool rows_ok(int max_K, int max_N, int a, int w, int ob, int mode) {
     return (mode == 0 || mode == 2) && max_K <= 8192 && max_N <= 256 && a <= 8 && w <= 8 && (mode == 2 || (ob >= 1 && ob <= 23)) &&
            static_cast<double>(max_K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0 && !getenv_flag("QGTC_NO_ROWS");
 }
-// ... and cols-layout stages (the operands not swapped, a workgroup per word of a line): what neither _xw_rows / _strip (K <= 128, four
-// planes at most) nor _wave (N <= 64) takes - the X . W stages at --bit_width 5 .. 8 (ogbn-arxiv-sized, 8 bits: 27 us on the 128-tile
-// int8 kernel, 70 us on the popcount one for the class-count stage)
+// ... and cols-layout stages (the operands not swapped, a workgroup per word of a line): every one that _xw_rows (K, N <= 128 at 2 / 4
+// bits) does not take - rounds 1-2 had a column-strip kernel (K <= 128) and a one-wave-per-tile kernel (N <= 64) for them
 inline bool rows_cols_ok(int max_K, int max_N, int a, int w, int ob) { return rows_ok(max_K, max_N, a, w, ob, 0) && !getenv_flag("QGTC_NO_ROWS_COLS"); }
 
-// grouped "X . W" stages by row blocks instead of column strips (k_bitmm_fp4_xw_rows)
+// grouped "X . W" stages with one k-quad of K at the epochs' widths (k_bitmm_fp4_xw_rows)
 inline bool xw_rows_ok(int max_K, int max_N, int a, int w, int ob) {
     return max_K <= 128 && max_N <= 128 && ((a <= 2 && w <= 2 && ob == 2) || (a <= 4 && w <= 4 && ob == 4)) && !getenv_flag("QGTC_NO_XWROWS");
 }
@@ -197,15 +184,6 @@ inline bool rbw_chain_ok(int max_K, int N1, int N2, int t_bits, int act_bits, in
     if (mode2 == 0) return true;
     const bool wide = t_bits > 2;   // the format class of T, of the aggregate and of W' must agree
     return N2 >= 1 && N2 <= 128 && act_bits >= 1 && act_bits <= 4 && (act_bits > 2) == wide && (mode2 == 2 || out_bits == act_bits);
-}
-
-// grouped launches on the matrix cores, one wave per 32 x 32 tile (bitmm_fp4_wave.hip.h): for NARROW outputs.
-// Measured on the epochs (tools/epoch_stages.py): the class-count stages (N = 10) 7.1 / 10.9 us against 13.8 / 12.6
-// for the popcount kernels, ppi's 1 x 4-bit A-stages at N = 50 14.3 against 16.3 for the 128-tile kernel; at
-// N = 128 the 128-tile kernel is ahead (12 / 18.5 us against 18 / 25), and 64 x 64 outputs per wave are worse
-// still (24 / 41 us: 2850 waves do not fill the chip).
-inline bool fp4_wave_ok(int K, int N, int a, int w) {
-    return N <= 64 && a <= 4 && w <= 8 && static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
 }
 
 // single launches with three to eight left-hand planes (the narrow-operand kernels of bitmm_fp4_one / _skinny take two at most) and at

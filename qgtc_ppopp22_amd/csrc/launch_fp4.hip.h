@@ -89,63 +89,6 @@ int qgtc_launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, b
     return QGTC_OK;
 }
 
-int qgtc_launch_fp4_wave(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode,
-                    bool zero_skip, hipStream_t st) {
-    MMShape sh = base_shape(a, w, ob, mode);
-    sh.nowrap = 1;
-    const int zs = zero_skip ? 1 : 0;
-    const dim3 grid(((max_M + 31) / 32) * ((max_N + 31) / 32), count);   // 32 x 32 outputs per wave
-#define QGTC_FW_LAUNCH(NA_, NW_)                                                                                 \
-    if (!done && a <= NA_ && w <= NW_) {                                                                         \
-        done = true;                                                                                             \
-        if (mode == 2) hipLaunchKernelGGL((k_bitmm_fp4_wave<NA_, NW_, 2, 2, 2>), grid, dim3(64), 0, st, prs, sh, zs);      \
-        else if (mode == 1) hipLaunchKernelGGL((k_bitmm_fp4_wave<NA_, NW_, 1, 2, 2>), grid, dim3(64), 0, st, prs, sh, zs); \
-        else hipLaunchKernelGGL((k_bitmm_fp4_wave<NA_, NW_, 0, 2, 2>), grid, dim3(64), 0, st, prs, sh, zs);                \
-    }
-    bool done = false;
-    QGTC_FW_LAUNCH(1, 1) QGTC_FW_LAUNCH(1, 2) QGTC_FW_LAUNCH(1, 4) QGTC_FW_LAUNCH(1, 8)
-    QGTC_FW_LAUNCH(2, 1) QGTC_FW_LAUNCH(2, 2) QGTC_FW_LAUNCH(2, 4) QGTC_FW_LAUNCH(2, 8)
-    QGTC_FW_LAUNCH(4, 4) QGTC_FW_LAUNCH(4, 8)   // ppi's 4 x 4-bit X.W stages
-#undef QGTC_FW_LAUNCH
-    HIP_TRY(hipGetLastError());
-    return QGTC_OK;
-}
-
-
-// grouped "X . W" stages with one k-quad of K and cols-layout output: one workgroup per 32-column strip (bitmm_fp4_strip.hip.h)
-int qgtc_launch_strip(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, hipStream_t st) {
-    MMShape sh = base_shape(a, w, ob, 1);
-    sh.nowrap = 1;
-    sh.per = getenv_flag("QGTC_NO_XCD") ? 0 : 1;   // (here: the workgroups of a batch on one XCD)
-    // a strip's rows can be split over several workgroups (gridDim.z): 300 whole strips on 256 CUs leave 44 CUs with two
-    // (the stage is bound by the epilogue's VALU work per CU), halves balance better. Measured on the ogbn-arxiv-sized
-    // epoch (75 batches x 4 strips): 1 / 2 / 3 / 4 parts 9.7 / 8.6 / 9.0 / 9.6 us per stage - every extra workgroup
-    // repeats the W loads and their latency
-    const int strips = pad128(max_N) / 32;
-    int parts = 1;
-    if (const char *e = std::getenv("QGTC_STRIP_PARTS")) parts = std::max(1, std::atoi(e));   // (tuning only)
-    else if (a <= 2 && w <= 2 && static_cast<long>(strips) * count < 512) parts = 2;   // (4-bit stages: 9.3 us whole, 10.5 split)
-    const dim3 grid(strips, count, parts), block(64 * ST_WAVES);
-    const size_t lds = strip_lds_bytes(max_M, ob);
-#define QGTC_ST_GO(NA_, NW_, OB_) hipLaunchKernelGGL((k_bitmm_fp4_strip<NA_, NW_, OB_>), grid, block, lds, st, prs, sh)
-#define QGTC_ST_LAUNCH(NA_, NW_)                                         \
-    if (!done && a <= NA_ && w <= NW_) {                                 \
-        done = true;                                                     \
-        if (ob == 1) QGTC_ST_GO(NA_, NW_, 1);                            \
-        else if (ob == 2) QGTC_ST_GO(NA_, NW_, 2);                       \
-        else if (ob == 4) QGTC_ST_GO(NA_, NW_, 4);                       \
-        else if (ob == 8) QGTC_ST_GO(NA_, NW_, 8);                       \
-        else QGTC_ST_GO(NA_, NW_, 0);                                    \
-    }
-    bool done = false;
-    QGTC_ST_LAUNCH(1, 1) QGTC_ST_LAUNCH(1, 2) QGTC_ST_LAUNCH(2, 2) QGTC_ST_LAUNCH(2, 4) QGTC_ST_LAUNCH(4, 4) QGTC_ST_LAUNCH(4, 8)
-#undef QGTC_ST_LAUNCH
-#undef QGTC_ST_GO
-    if (!done) return QGTC_EINVAL;
-    HIP_TRY(hipGetLastError());
-    return QGTC_OK;
-}
-
 // grouped "X . W" stages by row blocks (bitmm_fp4_chain.hip.h: k_bitmm_fp4_xw_rows): K <= 128, N <= 128, the plane counts of
 // the two epochs
 int qgtc_launch_xw_rows(const qgtc_problem *prs, int count, int max_M, int a, int w, int ob, bool qmajor_out, hipStream_t st) {

@@ -1,5 +1,5 @@
 // qgtc_fp4.hip — second translation unit of libqgtc_hip.so (compiled in parallel with qgtc_hip.hip): the FP4
-// matrix-core kernels for narrow right operands (bitmm_fp4_skinny.hip.h, bitmm_fp4_wave.hip.h) and their launchers.
+// matrix-core kernels for narrow right operands (bitmm_fp4_one / _skinny), the row-block kernels and their launchers.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -14,9 +14,8 @@
 #include "bitmm_popcount.hip.h"   // MMShape, requant, the DPP ORs (templates only: nothing is instantiated here)
 #include "bitmm_mfma.hip.h"       // expand_word_fp4, or_with_partner_half, vector types
 #include "bitmm_fp4_skinny.hip.h"
-#include "bitmm_fp4_wave.hip.h"
 #include "bitmm_fp4_one.hip.h"
-#include "bitmm_fp4_strip.hip.h"
+#include "fp4_rowblock.hip.h"
 #include "bitmm_fp4_rows.hip.h"
 #include "bitmm_fp4_chain.hip.h"
 #include "bitmm_fp4_rbw.hip.h"

@@ -23,9 +23,9 @@
 //   fp4_expand.hip.h         packed words -> E2M1 MFMA operands in place (one AND per dword; digits)
 //   bitmm_fp4_one.hip.h      the same for narrow right operands (N <= 256) and K <= 4096: the headline kernel
 //   bitmm_fp4_skinny.hip.h   the same for longer K: no LDS staging
-//   bitmm_fp4_wave.hip.h     grouped launches over cluster batches: one wave per 32 x 32 tile
-//   bitmm_fp4_strip.hip.h    grouped X . W stages (K <= 128, cols-layout output): one workgroup per 32-column strip
-//   bitmm_fp4_rows.hip.h     grouped A . (XW) stages (sparse left operand): one workgroup per 32-row block
+//   fp4_rowblock.hip.h       what the row-block kernels share (digit operands, the re-quantise + pack epilogue)
+//   bitmm_fp4_rows.hip.h     one workgroup per 32-row block: grouped stages (sparse left operands, narrow or many-plane products), single
+//                            launches with three to eight left-hand planes; all three outputs
 //   bitmm_fp4_chain.hip.h    an A . T stage with the next layer's X . W stage in its tail (qgtc_gcn_chain_batched)
 //   launch_common.hip.h      launch constants, kernel-family predicates (shared with qgtc_mfma.hip / qgtc_fp4.hip)
 //   launch.hip.h             split-K plan, kernel selection, launchers
@@ -54,9 +54,8 @@
 #include "launch_common.hip.h"
 #ifdef QGTC_SINGLE_TU   // tools/kbench.hip: everything in one translation unit
 #include "bitmm_fp4_skinny.hip.h"
-#include "bitmm_fp4_wave.hip.h"
 #include "bitmm_fp4_one.hip.h"
-#include "bitmm_fp4_strip.hip.h"
+#include "fp4_rowblock.hip.h"
 #include "bitmm_fp4_rows.hip.h"
 #include "bitmm_fp4_chain.hip.h"
 #include "bitmm_fp4_rbw.hip.h"
@@ -281,7 +280,7 @@ int qgtc_tile_counters(const uint32_t *X, size_t x_words, int M, int K, int N, i
 }
 
 // ---- which kernel family a grouped launch takes (one rule set for qgtc_bitmm_batched and qgtc_bitmm_batched_route) ------
-enum BatchedRoute { BR_REFUSED = 0, BR_XW_ROWS, BR_STRIP, BR_ROWS, BR_WAVE, BR_MFMA_128, BR_POPCOUNT };
+enum BatchedRoute { BR_REFUSED = 0, BR_XW_ROWS, BR_ROWS, BR_MFMA_128, BR_POPCOUNT };
 static BatchedRoute batched_route(int max_M, int max_K, int max_N, int bit1, int bit2, int ob_, int mode, unsigned flags) {
     const bool engine = (flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) != 0u;
     const bool rows_route = engine && ((flags & QGTC_ZERO_JUMP) || max_N <= 64 || max_K <= 256) && rows_ok(max_K, max_N, bit1, bit2, ob_, mode);
@@ -293,10 +292,11 @@ static BatchedRoute batched_route(int max_M, int max_K, int max_N, int bit1, int
         if (!out_ok && !in_ok) return BR_REFUSED;
     }
     if (engine && mode == 1 && xw_rows_ok(max_K, max_N, bit1, bit2, ob_)) return BR_XW_ROWS;     // X . W stages: row blocks
-    if (engine && mode == 1 && strip_ok(max_M, max_K, bit1, bit2, ob_)) return BR_STRIP;          // X . W stages: column strips
     if (rows_route) return BR_ROWS;   // sparse left operands / narrow outputs / one or two k-quads: one workgroup per 32-row block
-    if (engine && fp4_wave_ok(max_K, max_N, bit1, bit2)) return BR_WAVE;                           // narrow outputs: one wave per 32 x 32 tile
-    if (engine && mode == 1 && rows_cols_ok(max_K, max_N, bit1, bit2, ob_)) return BR_ROWS;        // cols-layout stages nothing above takes
+    // every other cols-layout stage the row blocks can take (tools/grouped_cols_sweep.py, 75 ragged batches: level with or ahead of the
+    // column-strip and one-wave-per-tile kernels of rounds 1-2 on every shape tried - 3 x 3 bits K = 128: 16.3 -> 10-13.5 us, 4 x 8 bits
+    // 24 -> 19-22, K = 256 N = 64 at 2 x 2 bits 12.6 -> 8.0 - which are deleted)
+    if (engine && mode == 1 && rows_cols_ok(max_K, max_N, bit1, bit2, ob_)) return BR_ROWS;
     if (((flags & QGTC_ENGINE_MFMA) && mfma_ok(bit1, bit2)) ||  // problems with a one-word bitmap jump zero tiles
         ((flags & QGTC_ENGINE_AUTO) && auto_prefers_mfma_batched(max_M, max_N, bit1, bit2)))
         return BR_MFMA_128;
@@ -321,9 +321,7 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
     switch (route) {
         case BR_REFUSED: return QGTC_EINVAL;   // (a chain-format link that cannot keep the format would misread its neighbour's buffer)
         case BR_XW_ROWS: return qgtc_launch_xw_rows(problems, count, max_M, bit1, bit2, ob_, (flags & QGTC_CHAIN_CODES_OUT) != 0u, st);
-        case BR_STRIP: return qgtc_launch_strip(problems, count, max_M, max_N, bit1, bit2, ob_, st);
         case BR_ROWS: return qgtc_launch_rows(problems, count, max_M, max_N, bit1, bit2, ob_, mode, (flags & QGTC_CHAIN_CODES_IN) != 0u, st);
-        case BR_WAVE: return qgtc_launch_fp4_wave(problems, count, max_M, max_N, bit1, bit2, ob_, mode, !(flags & QGTC_NO_ZERO_SKIP), st);
         case BR_MFMA_128: return qgtc_launch_mfma_batched(problems, count, max_M, max_K, max_N, bit1, bit2, ob_, mode, st);
         default: break;
     }
@@ -339,9 +337,7 @@ const char *qgtc_bitmm_batched_route(int max_M, int max_K, int max_N, int bit1, 
     switch (batched_route(max_M, max_K, max_N, bit1, bit2, mode == 2 ? 1 : output_bit, mode, flags)) {
         case BR_REFUSED: return "refused";
         case BR_XW_ROWS: return "k_bitmm_fp4_xw_rows";
-        case BR_STRIP: return "k_bitmm_fp4_strip";
         case BR_ROWS: return "k_bitmm_fp4_rows";
-        case BR_WAVE: return "k_bitmm_fp4_wave";
         case BR_MFMA_128: return "k_bitmm_mfma_batched";
         default: return "k_bitmm_batched";
     }

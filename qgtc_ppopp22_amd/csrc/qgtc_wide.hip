@@ -13,7 +13,7 @@
 #include "common.hip.h"
 #include "bitmm_popcount.hip.h"   // MMShape (templates only: nothing is instantiated here)
 #include "bitmm_mfma.hip.h"       // vector types
-#include "bitmm_fp4_strip.hip.h"  // requant_pack16
+#include "fp4_rowblock.hip.h"  // requant_pack16
 #include "fp4_expand.hip.h"
 #include "bitmm_fp4_wide.hip.h"
 #include "launch_common.hip.h"

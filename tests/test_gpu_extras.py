@@ -313,7 +313,7 @@ def test_jump_decision_is_made_on_the_device(qgtc, oracle):
 
 def test_fp4_narrow_kernels_sweep(qgtc, oracle):
     """The FP4 matrix-core kernels for narrow right operands (k_bitmm_fp4_skinny: single launches, N <= 256;
-    k_bitmm_fp4_wave: grouped launches, N <= 64) on shapes picked for their corners: K long enough for several
+    k_bitmm_fp4_rows: grouped launches) on shapes picked for their corners: K long enough for several
     super-steps per wave and ragged at every granularity (32 bits, 128 bits, 512 bits), 1..8 planes in base-4
     digits, all-zero row blocks (zero-tile skipping on and off), the float32-exactness bound (above it the
     other kernels must take over) - against the oracle, rows-layout bits and float32."""
@@ -362,7 +362,7 @@ def test_fp4_narrow_kernels_sweep(qgtc, oracle):
 
 # ---------------------------------------------------------------------------------------------
 # The FP4 matrix-core kernels accumulate in float32; the library only routes a product to them while
-# K (2^a - 1)(2^w - 1) < 2^24 (launch_common.hip.h: skinny_ok / fp4_wave_ok / fp4_ok / rows_single_ok), i.e. while every partial sum
+# K (2^a - 1)(2^w - 1) < 2^24 (launch_common.hip.h: skinny_ok / rows_ok / fp4_ok / rows_single_ok), i.e. while every partial sum
 # is an exactly representable integer. That predicate is the whole safety case of those kernels (the reference
 # accumulates in int32, kernel.h:292-341), so it is tested at its edge with worst-case operands.
 # ---------------------------------------------------------------------------------------------
@@ -443,7 +443,7 @@ def test_float32_sums_do_not_truncate_small_addends(qgtc, oracle, a, w):
 
 @pytest.mark.parametrize("a,w", [(4, 8), (2, 8), (4, 4)])
 def test_float32_exactness_bound_grouped(qgtc, oracle, a, w):
-    """The same edge for the grouped FP4 kernel (k_bitmm_fp4_wave: a <= 4, w <= 8, N <= 64): all-max operands at the
+    """The same edge for the grouped FP4 kernel (k_bitmm_fp4_rows: a <= 8, w <= 8, N <= 256): all-max operands at the
     largest admitted K and one above (decided from max_K of the launch), all three output modes."""
     import torch
     M, N = 40, 33
@@ -555,11 +555,11 @@ def test_gcn_layer_single_subgraph(qgtc, oracle, n, f_in, f_out, act, wb):
 
 
 
-def test_small_k_column_strip_kernel(qgtc, oracle):
-    """k_bitmm_fp4_strip (grouped launches, K <= 128, cols-layout output: the X . W stages of the epochs) against the
-    oracle: ragged rows (not a multiple of 32 / 128), K from 1 to 128, N from 1 column to several 128-line groups,
+def test_small_k_cols_layout_stages(qgtc, oracle):
+    """Grouped launches with K <= 128 and cols-layout output (the X . W stages of the epochs: k_bitmm_fp4_xw_rows at 2 / 4 bits,
+    k_bitmm_fp4_rows otherwise) against the oracle: ragged rows (not a multiple of 32 / 128), K from 1 to 128, N from 1 column to several 128-line groups,
     1..8 planes in base-4 digits, 1..10 output planes, all-zero row blocks, problems of different sizes in one launch
-    (the strips past a smaller problem's last column write its padding lines)."""
+    (the waves past a smaller problem's last column write its padding lines)."""
     import torch
     from helpers import rand_q, to_dev
     from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
