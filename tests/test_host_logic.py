@@ -20,6 +20,24 @@ def test_graph_is_deterministic_and_simple():
     assert 0.8 < inside < 0.99
 
 
+def test_presets_cover_the_datasets_the_reference_scripts_run():
+    """Every name of 0_7a_eval_QGTC_cluster_GCN.py:12-16,38-42 / README.md:84-89 has a synthetic stand-in with the script's own --dim,
+    and the four of the published epoch table cut into 75 batches of a size the grouped kernels take (<= 8192 nodes)."""
+    from qgtc_ppopp22_amd import graph as G
+
+    dims = {"Proteins": 29, "artist": 100, "soc-BlogCatalog": 128, "ppi": 50, "ogbn-arxiv": 128, "ogbn-products": 100}
+    for name, f in dims.items():
+        assert G.PRESETS[name][2] == f
+    for name in ("artist", "soc-BlogCatalog"):
+        g = G.make_graph(name, 1500)
+        assert g.n_nodes == G.PRESETS[name][0] and g.feat.shape == (g.n_nodes, dims[name]) and (g.src != g.dst).all()
+        par = G.partition_list(g, 1500)
+        sizes = [G.batch_nodes(par, c, 1500, 20).size for c in range(75)]
+        assert sum(sizes) == g.n_nodes and max(sizes) <= 8192
+    with pytest.raises(ValueError):
+        G.make_graph("no-such-dataset")
+
+
 def test_partitions_and_batches():
     from qgtc_ppopp22_amd import graph as G
 
