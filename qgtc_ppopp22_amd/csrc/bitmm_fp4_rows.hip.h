@@ -108,9 +108,24 @@ __device__ __forceinline__ void rows_block(const qgtc_problem &pr, const MMShape
             for (int p = 0; p < NW; p++)
                 wl[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rw, (q >= 0 && w_base[j] != 0xffffffffu && p < sh.w) ? static_cast<uint32_t>(p) * w_plane + ((sh.qmajor & 1) ? static_cast<uint32_t>(q * pr.w_lines + n0 + 32 * j + fl) * 16u : w_base[j] + ko) : 0xffffffffu, 0, 0);   // (quad-major T of a chain: bitmm_fp4_chain.hip.h)
     };
-    auto multiply = [&](const u32x4 (&xl)[NA], const u32x4 (&wl)[CB][NW]) {
+    // An ODD k-quad out (the only one of an X . W product with K <= 128; the commonest row block of a cluster batch has one beside its
+    // diagonal) is SHARED between the halves instead: half fh loads words 2 fh, 2 fh + 1 of both operands (8 bytes per lane and plane), TWO
+    // MFMAs per pair of digits cover its 128 bits - as a pair with a missing partner it was four, half of every operand zeros
+    // (tools/grouped_cols_sweep.py: the one-k-quad kernel k_bitmm_fp4_xw_rows was 20-40 % ahead of this one on K <= 128 for that reason).
+    auto load_single = [&](int q, u32x2 (&xl)[NA], u32x2 (&wl)[CB][NW]) {
+        const uint32_t ko = static_cast<uint32_t>(q) * 16u + 8u * static_cast<uint32_t>(fh);
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
+        for (int p = 0; p < NA; p++)
+            xl[p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, (q >= 0 && x_base != 0xffffffffu && p < sh.a) ? x_base + static_cast<uint32_t>(p) * x_plane + ko : 0xffffffffu, 0, 0));
+#pragma unroll
+        for (int j = 0; j < CB; j++)
+#pragma unroll
+            for (int p = 0; p < NW; p++)
+                wl[j][p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rw, (q >= 0 && w_base[j] != 0xffffffffu && p < sh.w) ? static_cast<uint32_t>(p) * w_plane + ((sh.qmajor & 1) ? static_cast<uint32_t>(q * pr.w_lines + n0 + 32 * j + fl) * 16u + 8u * static_cast<uint32_t>(fh) : w_base[j] + ko) : 0xffffffffu, 0, 0));
+    };
+    auto multiply = [&](const auto &xl, const auto &wl, auto nt) {   // nt words of every lane's load: 4 of a pair's k-quad, 2 of a shared one
+#pragma unroll
+        for (int t = 0; t < decltype(nt)::value; t++) {
             uint32_t xw[NA];
 #pragma unroll
             for (int p = 0; p < NA; p++) xw[p] = xl[p][t];
@@ -137,6 +152,16 @@ __device__ __forceinline__ void rows_block(const qgtc_problem &pr, const MMShape
         }
     };
     {
+        const std::integral_constant<int, 4> four;
+        const std::integral_constant<int, 2> two;
+        const bool odd = (__builtin_popcountll(left) & 1) != 0;   // (wave-uniform)
+        int qs = -1;
+        if (odd) {
+            qs = __builtin_ctzll(left);
+            left &= left - 1ull;
+        }
+        u32x2 xs_[NA], ws_[CB][NW];
+        if (odd) load_single(qs, xs_, ws_);   // (wave-uniform)
         u32x4 xa_[NA], wa_[CB][NW], xb_[NA], wb_[CB][NW];
         auto pa = take();
         load(pa.first, xa_, wa_);
@@ -144,14 +169,15 @@ __device__ __forceinline__ void rows_block(const qgtc_problem &pr, const MMShape
         asm volatile("" ::"v"(xa_[0]), "v"(wa_[0][0]));
         RW_STAMP(2);
 #endif
+        if (odd) multiply(xs_, ws_, two);   // (the first pair's loads are in flight)
         while (pa.second) {   // wave-uniform
             auto pb = take();
             if (pb.second) load(pb.first, xb_, wb_);
-            multiply(xa_, wa_);
+            multiply(xa_, wa_, four);
             if (!pb.second) break;
             pa = take();
             if (pa.second) load(pa.first, xa_, wa_);
-            multiply(xb_, wb_);
+            multiply(xb_, wb_, four);
         }
     }
 
