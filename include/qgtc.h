@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QGTC_ABI_VERSION 9
+#define QGTC_ABI_VERSION 10
 
 enum {
     QGTC_OK = 0,
@@ -55,9 +55,9 @@ enum {
                                   Grouped launches whose problems carry a one-word occupancy bitmap
                                   (K <= 8192) jump all-zero 128-row x 128-bit tiles */
 #define QGTC_ENGINE_AUTO 0x10u /* let rules fitted to MI355X measurements choose between the two engines */
-#define QGTC_CHAIN_DISCARD 0x40u    /* qgtc_gcn_chain_batched: the caller does not need stage_a's output itself */
-#define QGTC_CHAIN_CODES_IN 0x80u   /* qgtc_gcn_chain_batched / qgtc_bitmm_batched: the right operands were written by a launch with _CODES_OUT */
-#define QGTC_CHAIN_CODES_OUT 0x100u /* qgtc_gcn_chain_batched / qgtc_bitmm_batched (mode 1): the outputs are only read by a launch with _CODES_IN */
+#define QGTC_CHAIN_DISCARD 0x40u    /* qgtc_gcn_chain_batched: the caller does not need stage_a's output itself (a hint: it is written anyway) */
+/* (0x80, 0x100: flags of ABI <= 9 for a private T format between the one-launch chained pairs of rounds 2-3; that kernel family is gone -
+ * qgtc_chain_transform / qgtc_chain_aggregate are the chained form) */
 #define QGTC_CHAIN_ADJ_TILES 0x400u /* qgtc_chain_aggregate: the adjacencies (stage_a[b].X) are in the tile format of qgtc_adj_tiles_from_rows */
 #define QGTC_CHECK_DESCRIPTORS 0x200u /* grouped entry points: a small kernel (one thread per descriptor) ahead of the product compares every DEVICE
                                   descriptor with the stated max_M / max_K / max_N (and the chaining rules of the two-stage
@@ -190,17 +190,9 @@ int qgtc_gcn_layer_batched(const qgtc_problem *stage1, const qgtc_problem *stage
  * out_bits planes) or the output layer  float32(out_i . W')  (out_mode 2: [M, N'] floats, out_bits ignored; w_lines of the
  * descriptor as for qgtc_bitmm2int); W' cols layout with w_bits planes: stage_xw[i].X must be stage_a[i].out,
  * stage_xw[i].K = stage_a[i].N, stage_xw[i].M = stage_a[i].M. Word for word the result of qgtc_bitmm_batched(stage_a,
- * mode 0) followed by qgtc_bitmm_batched(stage_xw, mode out_mode) - both outputs are written. One launch (T' is row-local: a workgroup that has a
- * 32-row block of out_i multiplies it with W' right away) when QGTC_ENGINE_AUTO / _MFMA is set, a_bits = 1, both products
- * have at most 128 columns and the plane counts are 2 / 2 / 2 / 2 or 4 / 4 / 4 / 4 at most; else the two grouped launches.
- * QGTC_ZERO_JUMP applies to stage_a (its .occ bitmaps). QGTC_CHAIN_DISCARD: the aggregate itself is not wanted - the
- * one-launch kernel then neither packs nor stores stage_a[i].out (its contents are unspecified afterwards; the two-launch
- * route still writes it). QGTC_CHAIN_CODES_OUT / _IN: a T' that only the next launch of the chain reads may be left in the
- * kernels' own format (same buffer, same size: E2M1 codes in the 4-bit chains, bit planes in k-quad-major order in the
- * 2-bit ones; unspecified to the caller). A 2-bit chain's first X.W stage and last aggregation go through
- * qgtc_bitmm_batched with _CODES_OUT / _CODES_IN. Only the matrix-core row-block kernels read and write these formats: a
- * call with the flags that would take another route (engine flags absent, more than 128 columns, other plane counts)
- * returns QGTC_EINVAL rather than misread its neighbour's buffer.
+ * mode 0) followed by qgtc_bitmm_batched(stage_xw, mode out_mode), which is what it issues (ABI <= 9 had a one-launch kernel for some
+ * shapes; the epoch's chained form is qgtc_chain_transform / qgtc_chain_aggregate below). QGTC_ZERO_JUMP applies to stage_a (its .occ
+ * bitmaps).
  * max_* are hard preconditions as for qgtc_bitmm_batched. */
 int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stage_xw, int count, int max_M, int max_K,
                            int max_N1, int max_N2, int a_bits, int t_bits, int act_bits, int w_bits, int out_bits,
@@ -209,9 +201,8 @@ int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stag
 /* Which kernel family a call takes - host only, no device work: the SAME rule functions the launchers use (qgtc_hip.hip:
  * single_route / batched_route over the predicates of launch_common.hip.h), so documentation and tests can name the kernel
  * behind a call shape (DESIGN.md section 5 is generated from these by tools/routing_table.py). mode 0 rows-layout bits, 1
- * cols-layout bits, 2 float32; flags = the engine / zero-jump / chain flags of the launch. Returns a static string: a kernel
- * family name ("k_bitmm", "k_bitmm_fp4_one", ...), "refused" (QGTC_EINVAL for chain-format flags no kernel can honour) or
- * "invalid". */
+ * cols-layout bits, 2 float32; flags = the engine / zero-jump flags of the launch. Returns a static string: a kernel
+ * family name ("k_bitmm", "k_bitmm_fp4_one", ...) or "invalid". */
 const char *qgtc_bitmm_route(int M, int K, int N, int bit1, int bit2, int output_bit, int mode, unsigned flags);
 const char *qgtc_bitmm_batched_route(int max_M, int max_K, int max_N, int bit1, int bit2, int output_bit, int mode, unsigned flags);
 

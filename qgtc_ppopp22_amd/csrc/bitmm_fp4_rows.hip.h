@@ -106,7 +106,7 @@ __device__ __forceinline__ void rows_block(const qgtc_problem &pr, const MMShape
         for (int j = 0; j < CB; j++)
 #pragma unroll
             for (int p = 0; p < NW; p++)
-                wl[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rw, (q >= 0 && w_base[j] != 0xffffffffu && p < sh.w) ? static_cast<uint32_t>(p) * w_plane + ((sh.qmajor & 1) ? static_cast<uint32_t>(q * pr.w_lines + n0 + 32 * j + fl) * 16u : w_base[j] + ko) : 0xffffffffu, 0, 0);   // (quad-major T of a chain: bitmm_fp4_chain.hip.h)
+                wl[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rw, (q >= 0 && w_base[j] != 0xffffffffu && p < sh.w) ? static_cast<uint32_t>(p) * w_plane + (w_base[j] + ko) : 0xffffffffu, 0, 0);
     };
     // An ODD k-quad out (the only one of an X . W product with K <= 128; the commonest row block of a cluster batch has one beside its
     // diagonal) is SHARED between the halves instead: half fh loads words 2 fh, 2 fh + 1 of both operands (8 bytes per lane and plane), TWO
@@ -121,7 +121,7 @@ __device__ __forceinline__ void rows_block(const qgtc_problem &pr, const MMShape
         for (int j = 0; j < CB; j++)
 #pragma unroll
             for (int p = 0; p < NW; p++)
-                wl[j][p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rw, (q >= 0 && w_base[j] != 0xffffffffu && p < sh.w) ? static_cast<uint32_t>(p) * w_plane + ((sh.qmajor & 1) ? static_cast<uint32_t>(q * pr.w_lines + n0 + 32 * j + fl) * 16u + 8u * static_cast<uint32_t>(fh) : w_base[j] + ko) : 0xffffffffu, 0, 0));
+                wl[j][p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rw, (q >= 0 && w_base[j] != 0xffffffffu && p < sh.w) ? static_cast<uint32_t>(p) * w_plane + (w_base[j] + ko) : 0xffffffffu, 0, 0));
     };
     auto multiply = [&](const auto &xl, const auto &wl, auto nt) {   // nt words of every lane's load: 4 of a pair's k-quad, 2 of a shared one
 #pragma unroll
@@ -272,6 +272,77 @@ template <int NA, int NW, int MODE, int OB>
 __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows_single(qgtc_problem pr, MMShape sh) {
     pin_shape(sh);
     rows_block<NA, NW, MODE, OB, 1>(pr, sh, static_cast<int>(blockIdx.x), 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// A grouped "X . W" stage with ONE k-quad of K (K <= 128, N <= 128, cols-layout bits out) at the epochs' widths, fixed shape:
+// a workgroup = 32 rows of one batch, wave j = columns 32 j .. 32 j + 31,
+// the X words straight from global memory (8 bytes per lane and plane), no LDS, no barrier, no line-assembly pass: the
+// word of each of its 128 lines goes out as a 4-byte store, and those merge in the one L2 all row blocks of a batch share.
+// ------------------------------------------------------------------------------------------
+template <int NA, int NW, int OB>
+__global__ __launch_bounds__(64 * 4) __attribute__((amdgpu_waves_per_eu(NA <= 2 ? 8 : 4, 8))) void k_bitmm_fp4_xw_rows(
+    const qgtc_problem *__restrict__ prs, MMShape sh) {
+    constexpr int NDA = (NA + 1) / 2, NDW = (NW + 1) / 2;   // base-4 digits
+    pin_shape(sh);
+    int rb = static_cast<int>(blockIdx.x), batch = static_cast<int>(blockIdx.y);
+    if (sh.per) {
+        const int v = xcd_consecutive(batch * static_cast<int>(gridDim.x) + rb, static_cast<int>(gridDim.x * gridDim.y));
+        batch = v / static_cast<int>(gridDim.x);
+        rb = v - batch * static_cast<int>(gridDim.x);
+    }
+    const qgtc_problem pr = prs[batch];
+    pin_problem(pr);
+    const int M = pr.M, N = pr.N;
+    const int line_words = step128(M) * 4, lines = pad128(N);
+    if (rb >= line_words) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fl = lane & 31, fh = lane >> 5;
+    const int n = 32 * wv + fl, m = 32 * rb + fl;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(pr.X), 0, static_cast<int>(static_cast<uint32_t>(pr.x_words) * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(pr.W), 0, static_cast<int>(static_cast<uint32_t>(pr.w_words) * 4u), 0x00020000);
+    const uint32_t x_plane = static_cast<uint32_t>(pad8(M)) * 16u, w_plane = static_cast<uint32_t>(pr.w_lines) * 16u;
+    uint32_t xl[2][NA], wl[2][NW];   // [k half][plane]: words 2 fh, 2 fh + 1 of the lane's row / line
+#pragma unroll
+    for (int p = 0; p < NA; p++) {
+        const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, (m < M && p < sh.a) ? static_cast<uint32_t>(p) * x_plane + static_cast<uint32_t>(m) * 16u + 8u * fh : 0xffffffffu, 0, 0));
+        xl[0][p] = v.x;
+        xl[1][p] = v.y;
+    }
+#pragma unroll
+    for (int p = 0; p < NW; p++) {
+        const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rw, (n < N && p < sh.w) ? static_cast<uint32_t>(p) * w_plane + static_cast<uint32_t>(n) * 16u + 8u * fh : 0xffffffffu, 0, 0));
+        wl[0][p] = v.x;
+        wl[1][p] = v.y;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int da = 0; da < NDA; da++) {
+            const i32x8 xa = strip_operand<NA>(xl[h], da);   // not swapped: lane (fl, fh) register r holds C[row (r & 3) + 8 (r >> 2) + 4 fh][column fl]
+#pragma unroll
+            for (int dw = 0; dw < NDW; dw++) {
+                const i32x8 wb = strip_operand<NW>(wl[h], dw);
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa, wb, acc, 4, 4, 0, 128 + 2 * da, 0, 128 + 2 * dw);
+            }
+        }
+    uint32_t qv[16], P[4];
+    requant_pack16<OB>(acc, OB, P, qv);
+    const size_t oplane = static_cast<size_t>(lines) * line_words;
+    uint32_t *dst = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(n) * line_words + rb;
+#pragma unroll
+    for (int p = 0; p < OB; p++) {
+        uint32_t x = ((P[0] >> p) & 0x01010101u) << 3 | ((P[1] >> p) & 0x01010101u) << 2 | ((P[2] >> p) & 0x01010101u) << 1 | ((P[3] >> p) & 0x01010101u);
+        x <<= 4u - 4u * static_cast<uint32_t>(fh);
+        x = or_with_partner_half(x);
+        if (fh == 0 && n < lines) dst[p * oplane] = x;
+    }
 }
 
 }  // namespace

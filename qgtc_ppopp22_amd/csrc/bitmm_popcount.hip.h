@@ -66,15 +66,13 @@ struct MMShape {           // per-launch constants
     uint32_t inv_tiles_n;  // floor(2^32 / tiles_n), single launches only (tiles_n >= 2; else 0xffffffff)
     float maxv, maxm1;     // 2^ob and 2^ob - 1 as float (requant)
     int nowrap;            // K (2^a - 1)(2^w - 1) < 2^31: no accumulator can wrap negative
-    int qmajor;            // row-block kernels of a chain (bitmm_fp4_chain.hip.h): bit 0 the right operand is read, bit 1 the cols-layout
-                           // output is written, in QUAD-MAJOR order (qmajor_word below)
 };
 
 // Every launch constant a grouped kernel reads - the by-value shape and the grid (a HIDDEN kernel argument) - in scalar registers with
 // ONE round trip, and every field of a descriptor with one more: left alone hipcc loads them lazily, each use a dependent scalar-load
 // round trip ahead of the first global load (bitmm_fp4_rbw.hip.h measured 0.2 us of a 4.3 us launch).
 __device__ __forceinline__ void pin_shape(const MMShape &sh) {
-    asm volatile("" ::"s"(sh.a), "s"(sh.w), "s"(sh.ob), "s"(sh.mode), "s"(sh.per), "s"(sh.waves), "s"(sh.nowrap), "s"(sh.qmajor), "s"(gridDim.x), "s"(gridDim.y));
+    asm volatile("" ::"s"(sh.a), "s"(sh.w), "s"(sh.ob), "s"(sh.mode), "s"(sh.per), "s"(sh.waves), "s"(sh.nowrap), "s"(gridDim.x), "s"(gridDim.y));
 }
 __device__ __forceinline__ void pin_problem(const qgtc_problem &pr) {
     asm volatile("" ::"s"(pr.X), "s"(pr.W), "s"(pr.out), "s"(pr.x_words), "s"(pr.w_words), "s"(pr.M), "s"(pr.K), "s"(pr.N), "s"(pr.w_lines), "s"(pr.occ), "s"(pr.occ_words));

@@ -14,9 +14,8 @@ int qgtc_launch_mfma_batched(const qgtc_problem *prs, int count, int max_M, int 
 int qgtc_launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, bool zero_skip, hipStream_t st);
 bool qgtc_skinny_is_one(const qgtc_problem &pr, int ob, int mode);
 int qgtc_launch_rows_single(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st);
-int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode, bool qmajor_in, hipStream_t st);
-int qgtc_launch_xw_rows(const qgtc_problem *prs, int count, int max_M, int a, int w, int ob, bool qmajor_out, hipStream_t st);
-int qgtc_launch_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int w, int ob, int w2, int ob2, int mode2, bool discard, int codes, hipStream_t st);
+int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode, hipStream_t st);
+int qgtc_launch_xw_rows(const qgtc_problem *prs, int count, int max_M, int a, int w, int ob, hipStream_t st);
 
 // row block per wave (bitmm_fp4_rbw.hip.h), defined in qgtc_fp4.hip
 int qgtc_launch_expand_weights(const qgtc_expand_job *jobs, int n_jobs, hipStream_t st);
@@ -165,15 +164,6 @@ inline bool xw_rows_ok(int max_K, int max_N, int a, int w, int ob) {
     return max_K <= 128 && max_N <= 128 && ((a <= 2 && w <= 2 && ob == 2) || (a <= 4 && w <= 4 && ob == 4)) && !getenv_flag("QGTC_NO_XWROWS");
 }
 
-// an "A . T" stage followed by the next layer's "X . W" stage, in one launch (bitmm_fp4_chain.hip.h): one-plane A, at most
-// 128 columns in both products (the four words of a row of the first output are the whole K of the second), the plane
-// combinations of the two epochs (2-bit / 4-bit everything)
-inline bool chain_ok(int max_K, int max_N1, int max_N2, int a, int w, int ob, int w2, int ob2, int mode2) {
-    const bool planes = (ob == 2 && (mode2 == 2 || ob2 == 2) && w <= 2 && w2 <= 2) || (ob == 4 && (mode2 == 2 || ob2 == 4) && w <= 4 && w2 <= 4);
-    return a == 1 && planes && max_N1 <= 128 && max_N2 <= 128 && rows_ok(max_K, max_N1, a, w, ob, 0) && !getenv_flag("QGTC_NO_CHAIN");   // (float32 outputs: M N' < 2^30 by the 16 MB-scale batches this is for; the torch binding's pools are below 2^31 bytes)
-}
-
-// the chain entries (bitmm_fp4_rbw.hip.h): one wave per row block, T in the chain format, weights pre-expanded
 // One width b = 1 .. 4 per chain (planes of X, W, T alike - what main_qgtc.py's --bit_width gives); 1 / 2 bits are one base-4 digit a
 // nibble, 3 / 4 bits two. N, N' <= 128; float32 sums exact (4 bits: K 15 < 2^24 for the aggregation, 128 x 15 x 15 for X . W).
 inline bool rbw_xw_ok(int K, int N, int x_bits, int out_bits) {

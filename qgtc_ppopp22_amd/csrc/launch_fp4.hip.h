@@ -89,13 +89,12 @@ int qgtc_launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, b
     return QGTC_OK;
 }
 
-// grouped "X . W" stages by row blocks (bitmm_fp4_chain.hip.h: k_bitmm_fp4_xw_rows): K <= 128, N <= 128, the plane counts of
+// grouped "X . W" stages by row blocks (bitmm_fp4_rows.hip.h: k_bitmm_fp4_xw_rows): K <= 128, N <= 128, the plane counts of
 // the two epochs
-int qgtc_launch_xw_rows(const qgtc_problem *prs, int count, int max_M, int a, int w, int ob, bool qmajor_out, hipStream_t st) {
+int qgtc_launch_xw_rows(const qgtc_problem *prs, int count, int max_M, int a, int w, int ob, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, 1);
     sh.nowrap = 1;
     sh.per = getenv_flag("QGTC_NO_XCD") ? 0 : 1;
-    sh.qmajor = qmajor_out ? 2 : 0;
     const dim3 grid(step128(max_M) * 4, count), block(64 * 4);
     if (a <= 2 && w <= 2 && ob == 2) hipLaunchKernelGGL((k_bitmm_fp4_xw_rows<2, 2, 2>), grid, block, 0, st, prs, sh);
     else if (a <= 4 && w <= 4 && ob == 4) hipLaunchKernelGGL((k_bitmm_fp4_xw_rows<4, 4, 4>), grid, block, 0, st, prs, sh);
@@ -104,44 +103,13 @@ int qgtc_launch_xw_rows(const qgtc_problem *prs, int count, int max_M, int a, in
     return QGTC_OK;
 }
 
-// an "A . T" stage with the next layer's "X . W" stage in its tail (bitmm_fp4_chain.hip.h): w / ob = planes of T / of the
-// first product's output (= of the second product's left operand), w2 / ob2 = planes of W' / of T'
-int qgtc_launch_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int w, int ob, int w2, int ob2, int mode2, bool discard, int codes, hipStream_t st) {
-    MMShape sh = base_shape(1, w, ob, 0), sh2 = base_shape(ob, w2, mode2 == 2 ? 1 : ob2, mode2);
-    sh.nowrap = sh2.nowrap = 1;
-    sh.per = getenv_flag("QGTC_NO_XCD") ? 0 : 1;   // (here: row blocks of a batch on one XCD)
-    const dim3 grid(step128(max_M) * 4, count), block(64 * 4);   // a workgroup per word of T' (32 rows; the last ones padding)
-#define QGTC_CH_GO(NW_, OB_, NW2_, OB2_, MODE2_, CODES_)                                                                                      \
-    do {                                                                                                                                        \
-        if (discard) hipLaunchKernelGGL((k_bitmm_fp4_chain<NW_, OB_, NW2_, OB2_, MODE2_, true, CODES_>), grid, block, 0, st, p1, p2, sh, sh2);  \
-        else hipLaunchKernelGGL((k_bitmm_fp4_chain<NW_, OB_, NW2_, OB2_, MODE2_, false, CODES_>), grid, block, 0, st, p1, p2, sh, sh2);        \
-    } while (0)
-    // T / T' in the chain's own format (QGTC_CHAIN_CODES_IN / _OUT): E2M1 codes in the 4-bit kernels, quad-major bit planes
-    // in the 2-bit ones (a chain's launches all have the same widths)
-    const int cin = codes & 1, cout = codes & 2;
-    if (ob == 2) sh.qmajor = codes & 3;
-    if (mode2 == 2 && ob == 2 && w <= 2 && w2 <= 2) QGTC_CH_GO(2, 2, 2, 1, 2, 0);
-    else if (mode2 == 2 && ob == 4 && w <= 4 && w2 <= 4) { if (cin) QGTC_CH_GO(4, 4, 4, 1, 2, 1); else QGTC_CH_GO(4, 4, 4, 1, 2, 0); }
-    else if (mode2 == 1 && ob == 2 && ob2 == 2 && w <= 2 && w2 <= 2) QGTC_CH_GO(2, 2, 2, 2, 1, 0);
-    else if (mode2 == 1 && ob == 4 && ob2 == 4 && w <= 4 && w2 <= 4) {
-        if (cin && cout) QGTC_CH_GO(4, 4, 4, 4, 1, 3);
-        else if (cout) QGTC_CH_GO(4, 4, 4, 4, 1, 2);
-        else if (cin) QGTC_CH_GO(4, 4, 4, 4, 1, 1);
-        else QGTC_CH_GO(4, 4, 4, 4, 1, 0);
-    }
-#undef QGTC_CH_GO
-    HIP_TRY(hipGetLastError());
-    return QGTC_OK;
-}
-
 // grouped "A . (XW)" stages: one workgroup per 32-row block of a batch, only the occupied k-quads (bitmm_fp4_rows.hip.h); and grouped
 // cols-layout stages no narrower kernel takes (mode 1: five to eight left-hand planes - the X . W stages at --bit_width 5 .. 8 -, or
 // more than 128 bits of K with more than 64 columns): one workgroup per WORD of a line
-int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode, bool qmajor_in, hipStream_t st) {
+int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, int a, int w, int ob, int mode, hipStream_t st) {
     MMShape sh = base_shape(a, w, ob, mode);
     sh.nowrap = 1;
     sh.per = getenv_flag("QGTC_NO_XCD") ? 0 : 1;   // (here: row blocks of a batch on one XCD)
-    sh.qmajor = qmajor_in ? 1 : 0;
     // 32-column blocks: per 32 columns / per word of a packed row / per 32 lines of the cols layout, the padding ones included
     const int blocks = mode == 2 ? (max_N + 31) / 32 : mode == 1 ? pad128(max_N) / 32 : step128(max_N) * 4;
     // (two column blocks per wave - half the waves, one round of them on the chip instead of 1.4 - measured no faster:
@@ -191,7 +159,6 @@ int qgtc_launch_rows_single(const qgtc_problem &pr, int a, int w, int ob, int mo
     MMShape sh = base_shape(a, w, ob, mode);
     sh.nowrap = 1;
     sh.per = 0;
-    sh.qmajor = 0;
     // a wave per 32 columns (float32) / per word of a packed row (rows layout) / per 32 lines, the padding ones included (cols layout)
     const int waves = mode == 2 ? (pr.N + 31) / 32 : mode == 1 ? pad128(pr.N) / 32 : step128(pr.N) * 4;
     if (waves > 8 || mode < 0 || mode > 2) return QGTC_EINVAL;

@@ -17,7 +17,6 @@
 #include "bitmm_fp4_one.hip.h"
 #include "fp4_rowblock.hip.h"
 #include "bitmm_fp4_rows.hip.h"
-#include "bitmm_fp4_chain.hip.h"
 #include "bitmm_fp4_rbw.hip.h"
 #include "launch_common.hip.h"
 #include "launch_fp4.hip.h"

@@ -26,7 +26,6 @@
 //   fp4_rowblock.hip.h       what the row-block kernels share (digit operands, the re-quantise + pack epilogue)
 //   bitmm_fp4_rows.hip.h     one workgroup per 32-row block: grouped stages (sparse left operands, narrow or many-plane products), single
 //                            launches with three to eight left-hand planes; all three outputs
-//   bitmm_fp4_chain.hip.h    an A . T stage with the next layer's X . W stage in its tail (qgtc_gcn_chain_batched)
 //   launch_common.hip.h      launch constants, kernel-family predicates (shared with qgtc_mfma.hip / qgtc_fp4.hip)
 //   launch.hip.h             split-K plan, kernel selection, launchers
 //   qgtc_mfma.hip            second translation unit: the 128 x 128-tile matrix-core engine and its launchers
@@ -57,7 +56,6 @@
 #include "bitmm_fp4_one.hip.h"
 #include "fp4_rowblock.hip.h"
 #include "bitmm_fp4_rows.hip.h"
-#include "bitmm_fp4_chain.hip.h"
 #include "bitmm_fp4_rbw.hip.h"
 #include "fp4_expand.hip.h"
 #include "bitmm_fp4_wide.hip.h"
@@ -280,17 +278,10 @@ int qgtc_tile_counters(const uint32_t *X, size_t x_words, int M, int K, int N, i
 }
 
 // ---- which kernel family a grouped launch takes (one rule set for qgtc_bitmm_batched and qgtc_bitmm_batched_route) ------
-enum BatchedRoute { BR_REFUSED = 0, BR_XW_ROWS, BR_ROWS, BR_MFMA_128, BR_POPCOUNT };
+enum BatchedRoute { BR_XW_ROWS = 0, BR_ROWS, BR_MFMA_128, BR_POPCOUNT };
 static BatchedRoute batched_route(int max_M, int max_K, int max_N, int bit1, int bit2, int ob_, int mode, unsigned flags) {
     const bool engine = (flags & (QGTC_ENGINE_MFMA | QGTC_ENGINE_AUTO)) != 0u;
     const bool rows_route = engine && ((flags & QGTC_ZERO_JUMP) || max_N <= 64 || max_K <= 256) && rows_ok(max_K, max_N, bit1, bit2, ob_, mode);
-    if (flags & (QGTC_CHAIN_CODES_IN | QGTC_CHAIN_CODES_OUT)) {
-        // the first X.W / the last aggregation of a 2-bit chain (quad-major T, bitmm_fp4_chain.hip.h): only the row-block
-        // kernels read and write that order, and a link that cannot would misread its neighbour's buffer - refused instead
-        const bool out_ok = (flags & QGTC_CHAIN_CODES_OUT) && !(flags & QGTC_CHAIN_CODES_IN) && engine && mode == 1 && ob_ == 2 && xw_rows_ok(max_K, max_N, bit1, bit2, ob_);
-        const bool in_ok = (flags & QGTC_CHAIN_CODES_IN) && !(flags & QGTC_CHAIN_CODES_OUT) && mode != 1 && bit2 == 2 && rows_route;
-        if (!out_ok && !in_ok) return BR_REFUSED;
-    }
     if (engine && mode == 1 && xw_rows_ok(max_K, max_N, bit1, bit2, ob_)) return BR_XW_ROWS;     // X . W stages: row blocks
     if (rows_route) return BR_ROWS;   // sparse left operands / narrow outputs / one or two k-quads: one workgroup per 32-row block
     // every other cols-layout stage the row blocks can take (tools/grouped_cols_sweep.py, 75 ragged batches: level with or ahead of the
@@ -319,9 +310,8 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
     const int ob_ = mode == 2 ? 1 : output_bit;
     const BatchedRoute route = batched_route(max_M, max_K, max_N, bit1, bit2, ob_, mode, flags);
     switch (route) {
-        case BR_REFUSED: return QGTC_EINVAL;   // (a chain-format link that cannot keep the format would misread its neighbour's buffer)
-        case BR_XW_ROWS: return qgtc_launch_xw_rows(problems, count, max_M, bit1, bit2, ob_, (flags & QGTC_CHAIN_CODES_OUT) != 0u, st);
-        case BR_ROWS: return qgtc_launch_rows(problems, count, max_M, max_N, bit1, bit2, ob_, mode, (flags & QGTC_CHAIN_CODES_IN) != 0u, st);
+        case BR_XW_ROWS: return qgtc_launch_xw_rows(problems, count, max_M, bit1, bit2, ob_, st);
+        case BR_ROWS: return qgtc_launch_rows(problems, count, max_M, max_N, bit1, bit2, ob_, mode, st);
         case BR_MFMA_128: return qgtc_launch_mfma_batched(problems, count, max_M, max_K, max_N, bit1, bit2, ob_, mode, st);
         default: break;
     }
@@ -335,7 +325,6 @@ int qgtc_bitmm_batched(const qgtc_problem *problems, int count, int max_M, int m
 const char *qgtc_bitmm_batched_route(int max_M, int max_K, int max_N, int bit1, int bit2, int output_bit, int mode, unsigned flags) {
     if (max_M <= 0 || max_K <= 0 || max_N <= 0 || !bits_ok(bit1) || !bits_ok(bit2) || mode < 0 || mode > 2 || (mode != 2 && !bits_ok(output_bit))) return "invalid";
     switch (batched_route(max_M, max_K, max_N, bit1, bit2, mode == 2 ? 1 : output_bit, mode, flags)) {
-        case BR_REFUSED: return "refused";
         case BR_XW_ROWS: return "k_bitmm_fp4_xw_rows";
         case BR_ROWS: return "k_bitmm_fp4_rows";
         case BR_MFMA_128: return "k_bitmm_mfma_batched";
@@ -377,15 +366,7 @@ int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stag
         if (crc != QGTC_OK) return crc;
         flags &= ~QGTC_CHECK_DESCRIPTORS;
     }
-    // one launch on the matrix cores where the shapes and plane counts allow it (bitmm_fp4_chain.hip.h), else the two
-    // grouped launches it stands for
-    const bool codes = (flags & (QGTC_CHAIN_CODES_IN | QGTC_CHAIN_CODES_OUT)) != 0u;
-    if ((flags & (QGTC_ENGINE_AUTO | QGTC_ENGINE_MFMA)) && chain_ok(max_K, max_N1, max_N2, a_bits, t_bits, act_bits, w_bits, out_bits, out_mode) &&
-        (!codes || act_bits == 4 || (act_bits == 2 && (!(flags & QGTC_CHAIN_CODES_IN) || t_bits == 2) && (!(flags & QGTC_CHAIN_CODES_OUT) || out_mode == 1))))
-        // (the chain's own T format: E2M1 codes in the 4-bit kernels, quad-major planes in the 2-bit ones)
-        return qgtc_launch_chain(stage_a, stage_xw, count, max_M, t_bits, act_bits, w_bits, out_bits, out_mode, (flags & QGTC_CHAIN_DISCARD) != 0u,
-                                 ((flags & QGTC_CHAIN_CODES_IN) ? 1 : 0) | ((flags & QGTC_CHAIN_CODES_OUT) ? 2 : 0), static_cast<hipStream_t>(stream));
-    if (codes) return QGTC_EINVAL;   // (a link that cannot keep the format would misread its neighbour's buffer)
+    // (rounds 2-3 had a one-launch kernel for the pair; the chain entries below superseded it)
     int rc = qgtc_bitmm_batched(stage_a, count, max_M, max_K, max_N1, a_bits, t_bits, act_bits, 0, flags, stream);
     if (rc != QGTC_OK) return rc;
     return qgtc_bitmm_batched(stage_xw, count, max_M, max_N1, max_N2, act_bits, w_bits, out_mode == 2 ? 1 : out_bits, out_mode, flags & ~QGTC_ZERO_JUMP, stream);

@@ -413,7 +413,6 @@ struct BatchedGemm {
     torch::Tensor stats;  // device: [occupied, all] 32-row x 128-bit tiles of the left operands (zero_jump)
     int count = 0, max_M = 0, max_K = 0, max_N = 0, bit1 = 1, bit2 = 1, ob = 1, mode = 0;
     bool jump_asked = false;
-    int codes = 0;   // bit 0 / 1: QGTC_CHAIN_CODES_IN / _OUT for run() (the first / last launch of a chain that keeps T in the kernels' own format)
     static constexpr double kJumpBelow = 0.25;  // measured: at 19 % occupied tiles jumping gains 10 %, at 43 % it loses 15 %
 
     // Xs[i]: rows-layout left operand of problem i; Ws: one shared right operand (len 1) or one
@@ -571,7 +570,7 @@ struct BatchedGemm {
         c10::DeviceGuard guard(descs.device());
         check_rc(qgtc_bitmm_batched(reinterpret_cast<const qgtc_problem *>(descs.data_ptr()), count,
                                     max_M, max_K, max_N, bit1, bit2, ob, mode,
-                                    mm_flags() | (jump_asked ? QGTC_ZERO_JUMP : 0u) | ((codes & 1) ? QGTC_CHAIN_CODES_IN : 0u) | ((codes & 2) ? QGTC_CHAIN_CODES_OUT : 0u),
+                                    mm_flags() | (jump_asked ? QGTC_ZERO_JUMP : 0u),
                                     current_stream(descs)),
                  "BatchedGemm.run");
     }
@@ -614,11 +613,10 @@ struct FusedLayer {
 // rows-layout bits (mode 0) that are stage_xw's left operands; stage_xw produces cols-layout bits (mode 1).
 struct ChainedPair {
     std::shared_ptr<BatchedGemm> sa, sx;
-    bool discard = false;   // the aggregate itself is not wanted: stage_a's outputs are left unspecified (QGTC_CHAIN_DISCARD)
-    int codes = 0;          // bit 0 / 1: QGTC_CHAIN_CODES_IN / _OUT (T / T' in the kernel's operand format between chained calls)
+    bool discard = false;   // the aggregate itself is not wanted (QGTC_CHAIN_DISCARD: a hint)
 
-    ChainedPair(std::shared_ptr<BatchedGemm> stage_a, std::shared_ptr<BatchedGemm> stage_xw, bool discard_, int codes_)
-        : sa(std::move(stage_a)), sx(std::move(stage_xw)), discard(discard_), codes(codes_) {
+    ChainedPair(std::shared_ptr<BatchedGemm> stage_a, std::shared_ptr<BatchedGemm> stage_xw, bool discard_)
+        : sa(std::move(stage_a)), sx(std::move(stage_xw)), discard(discard_) {
         TORCH_CHECK(sa && sx, "ChainedPair needs two BatchedGemm plans");
         TORCH_CHECK(sa->count == sx->count, "both stages must cover the same cluster batches");
         TORCH_CHECK(sa->mode == 0, "the aggregation stage must produce rows-layout bits (mode 0)");
@@ -637,7 +635,7 @@ struct ChainedPair {
         check_rc(qgtc_gcn_chain_batched(reinterpret_cast<const qgtc_problem *>(sa->descs.data_ptr()),
                                         reinterpret_cast<const qgtc_problem *>(sx->descs.data_ptr()), sa->count,
                                         std::max(sa->max_M, sx->max_M), sa->max_K, sa->max_N, sx->max_N, sa->bit1, sa->bit2, sa->ob,
-                                        sx->bit2, sx->ob, sx->mode, mm_flags() | (sa->jump_asked ? QGTC_ZERO_JUMP : 0u) | (discard ? QGTC_CHAIN_DISCARD : 0u) | ((codes & 1) ? QGTC_CHAIN_CODES_IN : 0u) | ((codes & 2) ? QGTC_CHAIN_CODES_OUT : 0u),
+                                        sx->bit2, sx->ob, sx->mode, mm_flags() | (sa->jump_asked ? QGTC_ZERO_JUMP : 0u) | (discard ? QGTC_CHAIN_DISCARD : 0u),
                                         current_stream(sa->descs)),
                  "ChainedPair.run");
     }
@@ -1413,14 +1411,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.attr("SRC_STAGE") = static_cast<int>(QGTC_SRC_STAGE);
     m.attr("DIM_NODES") = static_cast<int>(QGTC_DIM_NODES);
     m.attr("CHAIN_DISCARD") = static_cast<int>(QGTC_CHAIN_DISCARD);
-    m.attr("CHAIN_CODES_IN") = static_cast<int>(QGTC_CHAIN_CODES_IN);
-    m.attr("CHAIN_CODES_OUT") = static_cast<int>(QGTC_CHAIN_CODES_OUT);
 
     py::class_<ChainedPair>(m, "ChainedPair")
-        .def(py::init<std::shared_ptr<BatchedGemm>, std::shared_ptr<BatchedGemm>, bool, int>(), py::arg("stage_a"), py::arg("stage_xw"), py::arg("discard") = false,
-             py::arg("codes") = 0)
+        .def(py::init<std::shared_ptr<BatchedGemm>, std::shared_ptr<BatchedGemm>, bool>(), py::arg("stage_a"), py::arg("stage_xw"), py::arg("discard") = false)
         .def_readonly("discard", &ChainedPair::discard)
-        .def("run", &ChainedPair::run, "A.(XW) of one layer and X.W of the next for every cluster batch, one launch where eligible")
+        .def("run", &ChainedPair::run, "A.(XW) of one layer and X.W of the next for every cluster batch (two grouped launches)")
         .def_property_readonly("outs", [](const ChainedPair &c) { return c.sx->outs; });
     py::class_<FusedLayer>(m, "FusedLayer")
         .def(py::init<std::shared_ptr<BatchedGemm>, std::shared_ptr<BatchedGemm>>(), py::arg("stage1"), py::arg("stage2"))
@@ -1439,8 +1434,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def("run_per_problem", &BatchedGemm::run_per_problem, py::arg("n_streams") = 1)
         .def_readonly("outs", &BatchedGemm::outs)
         .def_readonly("count", &BatchedGemm::count)
-        .def_readwrite("codes", &BatchedGemm::codes, "1: the right operands / 2: the outputs are in a chain's own format (QGTC_CHAIN_CODES_IN / _OUT): the "
-                       "first X.W stage / last aggregation of a chain of ChainedPair(..., codes) launches")
         .def_property_readonly("zero_jump", &BatchedGemm::zero_jump)
         .def_property_readonly("occupied_fraction", &BatchedGemm::occupied_fraction);
 }

@@ -91,7 +91,7 @@ def routing_switches() -> bool:
     def on(k):
         v = os.environ.get(k, "")
         return bool(v) and v[0] != "0"
-    return any(on(k) for k in ("QGTC_NO_RBW", "QGTC_NO_CHAIN", "QGTC_NO_ROWS", "QGTC_NO_XWROWS"))
+    return any(on(k) for k in ("QGTC_NO_RBW", "QGTC_NO_ROWS", "QGTC_NO_XWROWS"))
 
 
 def pack_weights(Q, feat, hidden, classes, bw, device):
@@ -252,26 +252,11 @@ class BatchedEpoch:
         self.launches = list(self.stages)
         self.discarded = set()   # stages whose outputs are not materialised
         if fuse and chain == "correct" and chain_stages:
-            # An aggregation stage and the NEXT layer's X.W stage are one call (Q.ChainedPair -> qgtc_gcn_chain_batched):
-            # X.W is row-local, so the workgroup that has a 32-row block of the aggregate multiplies it with W right away.
-            # GCN: X.W1 | A.T1 + X.W2 | A.T2 + X.W3 | A.T3 (four launches); GIN: A.X + X.W1 | A.T1 + X.W2 | A.T2 + X.W3 (three).
+            # An aggregation stage and the NEXT layer's X.W stage are one call (Q.ChainedPair -> qgtc_gcn_chain_batched: two grouped
+            # launches; the one-launch form of the pair is the chain entries of PlannedEpoch).
+            # GCN: X.W1 | A.T1 + X.W2 | A.T2 + X.W3 | A.T3 (four calls); GIN: A.X + X.W1 | A.T1 + X.W2 | A.T2 + X.W3 (three).
             pairs = [(1, 2), (3, 4)] if not run_gin else [(0, 1), (2, 3), (4, 5)]
-            # The aggregates themselves feed nothing but the X.W stage that rides on them: not materialised (keep_aggregates
-            # writes them, e.g. to compare every operator's output)
-            codes = {}
-            if (not keep_aggregates and (b == 2 or (run_gin and b == 4)) and max(F, H, C) <= 128 and max(n) <= 8192 and Q.get_engine() != "popcount" and
-                    not routing_switches()):   # (every launch inside the row-block kernels' range, no routing switch)
-                # Every T' is read by the next launch of the chain only: it stays in the kernels' own format
-                # (QGTC_CHAIN_CODES_OUT / _IN: E2M1 codes in the 4-bit chain - no expansion in the reader -, k-quad-major
-                # bit planes in the 2-bit ones - a wave's loads and stores of T touch 4 cache lines instead of 32). The
-                # library refuses the request where a launch could not keep the format.
-                codes = {0: 2, 2: 3, 4: 1} if run_gin else {0: 2, 1: 3, 3: 3, 5: 1}
-                if not run_gin:
-                    self.stages[0].codes, self.stages[5].codes = 2, 1
-            first = {i: Q.ChainedPair(self.stages[i], self.stages[j], not keep_aggregates, codes.get(i, 0)) for i, j in pairs}
-            self.discarded = set() if keep_aggregates else {i for i, _ in pairs}
-            if codes:
-                self.discarded |= {1, 3} if run_gin else {0, 2, 4}   # (the T's: the chain's own format, not the cols layout)
+            first = {i: Q.ChainedPair(self.stages[i], self.stages[j], not keep_aggregates) for i, j in pairs}
             second = {j for _, j in pairs}
             self.launches = [first.get(i, g) for i, g in enumerate(self.stages) if i not in second]
         elif fuse and chain == "correct":
@@ -372,20 +357,11 @@ class PlannedEpoch:
                 for i in (0, 2, 4):
                     stages[i] = (Q.SRC_AT,) + stages[i][1:]
         elif fuse and chain == "correct" and chain_stages:
-            # an aggregation stage and the NEXT layer's X.W stage are one call (qgtc_gcn_chain_batched), T between the
-            # launches of a chain in the kernels' own format where every launch can keep it (see BatchedEpoch)
+            # an aggregation stage and the NEXT layer's X.W stage are one call (qgtc_gcn_chain_batched)
             pairs = [(1, 2), (3, 4)] if not run_gin else [(0, 1), (2, 3), (4, 5)]
-            codes = {}
-            if (not keep_aggregates and (b == 2 or (run_gin and b == 4)) and max(F, H, C) <= 128 and max_n <= 8192 and Q.get_engine() != "popcount"
-                    and not switches):
-                codes = {0: 2, 2: 3, 4: 1} if run_gin else {0: 2, 1: 3, 3: 3, 5: 1}
-            flag = lambda c: ((Q.CHAIN_CODES_IN if c & 1 else 0) | (Q.CHAIN_CODES_OUT if c & 2 else 0))   # noqa: E731
-            first = {i: (1, i, j, (0 if keep_aggregates else Q.CHAIN_DISCARD) | flag(codes.get(i, 0)), 0) for i, j in pairs}
+            first = {i: (1, i, j, 0 if keep_aggregates else Q.CHAIN_DISCARD, 0) for i, j in pairs}
             second = {j for _, j in pairs}
-            launches = [first.get(i, (0, i, 0, flag(codes.get(i, 0)) if codes else 0, 0)) for i in range(6) if i not in second]
-            self.discarded = set() if keep_aggregates else {i for i, _ in pairs}
-            if codes:
-                self.discarded |= {1, 3} if run_gin else {0, 2, 4}
+            launches = [first.get(i, (0, i, 0, 0, 0)) for i in range(6) if i not in second]
         elif fuse and chain == "correct":
             pairs = [(0, 1), (2, 3), (4, 5)] if not run_gin else [(1, 2), (3, 4)]
             first = {i: (2, i, j, 0, 0) for i, j in pairs}

@@ -168,14 +168,6 @@ def test_chain_entry_with_raw_descriptors(lib, oracle, flags):
     assert lib.qgtc_gcn_chain_batched(None, descs.data_ptr(), count, 10, 10, 10, 10, 1, 2, 2, 2, 2, 1, flags, st) == 1
     assert lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr(), count, 10, 10, 10, 10, 1, 2, 2, 2, 0, 1, flags, st) == 1
     assert lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr(), count, 10, 10, 10, 10, 1, 2, 2, 2, 2, 0, flags, st) == 1
-    # T' in the chain's own format (QGTC_CHAIN_CODES_OUT 0x100 / _IN 0x80) exists in the one-launch kernels only: a call that could
-    # not keep the format is refused, not run with the flags dropped (its neighbour would misread the buffer)
-    assert lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr() + 72 * count, count, max(ns), max(ns), f1, f2, 1, 2, 2, 2, 2, 2, flags | 0x100, st) == 1   # (float32 out)
-    assert lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr() + 72 * count, count, max(ns), max(ns), f1, f2, 1, 1, 2, 2, 2, 1, flags | 0x80, st) == 1    # (one-plane T)
-    lib.qgtc_bitmm_batched.argtypes = [vp, ctypes.c_int] + [ctypes.c_int] * 3 + [ctypes.c_int] * 4 + [ctypes.c_uint, vp]
-    assert lib.qgtc_bitmm_batched(descs.data_ptr(), count, max(ns), max(ns), 512, 1, 2, 2, 0, flags | 0x80, st) == 1    # (512 columns: not the row-block kernel)
-    assert lib.qgtc_bitmm_batched(descs.data_ptr(), count, max(ns), 256, f2, 2, 2, 2, 1, flags | 0x100, st) == 1        # (K = 256: not the X.W row-block kernel)
-    assert lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr() + 72 * count, count, max(ns), max(ns), 256, f2, 1, 4, 4, 4, 4, 1, flags | 0x80, st) == 1
 
 
 class QgtcOperand(ctypes.Structure):

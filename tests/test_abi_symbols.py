@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_errors(lib):
-    assert lib.qgtc_abi_version() == 9
+    assert lib.qgtc_abi_version() == 10
     assert lib.qgtc_strerror(0) == b"ok"
     for code in range(1, 6):
         assert lib.qgtc_strerror(code) not in (b"ok", b"unknown error")
@@ -126,7 +126,7 @@ def test_route_functions_name_the_kernel_behind_a_call(lib):
     """qgtc_bitmm_route / qgtc_bitmm_batched_route: host-only, the SAME rule functions the launchers switch on (qgtc_hip.hip:
     single_route / batched_route), so the routing table of DESIGN.md (tools/routing_table.py) cannot drift from the code."""
     lib.qgtc_bitmm_route.restype = lib.qgtc_bitmm_batched_route.restype = ctypes.c_char_p
-    POP, MFMA, AUTO, JUMP, CODES_OUT = 0x0, 0x8, 0x10, 0x4, 0x100
+    POP, MFMA, AUTO, JUMP = 0x0, 0x8, 0x10, 0x4
     r = lambda *a: lib.qgtc_bitmm_route(*a).decode()             # noqa: E731
     g = lambda *a: lib.qgtc_bitmm_batched_route(*a).decode()     # noqa: E731
     # bench.py's step (BASELINE.json configs[1]): the FP4 narrow-operand kernel on the default engine, AND + popcount when asked
@@ -140,7 +140,7 @@ def test_route_functions_name_the_kernel_behind_a_call(lib):
     assert g(1213, 128, 128, 2, 2, 2, 1, AUTO) == "k_bitmm_fp4_xw_rows"
     assert g(1213, 1213, 128, 1, 2, 2, 0, AUTO | JUMP) == "k_bitmm_fp4_rows"
     assert g(1213, 1213, 128, 1, 2, 2, 0, POP | JUMP) == "k_bitmm_batched"
-    assert g(1213, 128, 512, 2, 2, 2, 1, AUTO | CODES_OUT) == "refused"            # -> QGTC_EINVAL from qgtc_bitmm_batched
+    assert g(1213, 128, 128, 8, 8, 8, 1, AUTO) == "k_bitmm_fp4_rows" and g(1213, 300, 512, 2, 2, 2, 1, AUTO) == "k_bitmm_mfma_batched"
     # the table in DESIGN.md is this tool's output
     import subprocess
     import sys

@@ -725,8 +725,8 @@ def test_headline_kernel_on_tall_tiles(qgtc, oracle, a, w):
 def test_chained_pair_matches_oracle(qgtc, oracle, f1, f2, act, wb, engine, zero_jump):
     """ChainedPair (out = requant(A . T), then T' = requant(out . W') in the cols layout) against the oracle's two
     products: ragged batches (fewer rows than a block, row counts that leave padding words in T'), widths inside and
-    outside the one-launch kernel's range (more than 128 columns, plane counts it is not built for, the popcount engine:
-    those take the two grouped launches), with and without occupancy bitmaps, run twice over poisoned outputs."""
+    outside the row-block kernels' range (more than 128 columns, the popcount engine), with and without occupancy bitmaps, run
+    three times over poisoned outputs."""
     import torch
     from helpers import rand_q, to_dev
     from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
@@ -750,7 +750,7 @@ def test_chained_pair_matches_oracle(qgtc, oracle, f1, f2, act, wb, engine, zero
         for mode2 in (1, 2):      # T' as cols-layout bits / the output layer's float32
             sa = qgtc.BatchedGemm(As, Ts, [(n, n, f1) for n in ns], 1, act, act, 0, True, zero_jump)
             sx = qgtc.BatchedGemm(sa.outs, [dW2], [(n, f1, f2) for n in ns], act, wb, act, mode2, True)
-            for rep in range(3):      # the last run with QGTC_CHAIN_DISCARD: the aggregate is not materialised, T' is the same
+            for rep in range(3):      # the last run with QGTC_CHAIN_DISCARD (a hint: T' is the same either way)
                 pair = qgtc.ChainedPair(sa, sx, rep == 2)
                 for o in list(sa.outs) + list(sx.outs):
                     o.fill_(-1 if o.dtype == torch.int32 else 7.0)

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import qgtc_ppopp22_amd
 
 ENGINE = {"popcount": 0x0, "mfma": 0x8, "auto": 0x10}
-ZERO_JUMP, CODES_IN, CODES_OUT = 0x4, 0x80, 0x100
+ZERO_JUMP = 0x4
 MODES = {0: "bits, rows", 1: "bits, cols", 2: "float32"}
 
 
@@ -55,8 +55,7 @@ GROUPED = [  # (what, max_M, max_K, max_N, a, w, ob, mode, extra flags)
     ("literal chain: rows-layout X.W (main_qgtc.py:147 grouped)", 1213, 128, 128, 2, 2, 2, 0, 0),
     ("wide grouped stage (N = 512)", 1213, 1213, 512, 1, 2, 2, 0, 0),
     ("8-bit grouped X.W", 1213, 128, 128, 8, 8, 8, 1, 0),
-    ("first X.W of a 2-bit chain, T left in the chain's order", 1213, 128, 128, 2, 2, 2, 1, CODES_OUT),
-    ("chain-format flags no kernel can honour", 1213, 128, 512, 2, 2, 2, 1, CODES_OUT),
+    ("3-bit grouped X.W (cols out, no fixed-shape kernel)", 1213, 128, 128, 3, 3, 3, 1, 0),
 ]
 
 
