@@ -117,8 +117,8 @@ EVENT_MIN_LAUNCHES = 200     # launches in the HIP-event window behind the timed
 def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams=1, issue="eager"):
     """warmup untimed launches, then EXACTLY `steps` launches between barrier+synchronize pairs (the contract's timed
     region: wall seconds), then the SAME `steps` launches once more between two HIP events recorded on the stream the
-    kernels are launched on, and max(1, K // 200) event-bracketed windows of 200 launches (the roofline's live launch duration: their
-    mean). Returns (wall seconds, mean stream time per launch in seconds, wall seconds of the event-bracketed K-launch region, the
+    kernels are launched on, and max(3, K // 200) event-bracketed windows of 200 launches (the roofline's live launch duration: their
+    MEDIAN). Returns (wall seconds, mean stream time per launch in seconds, wall seconds of the event-bracketed K-launch region, the
     issue mode used, the untimed probe of an "auto" choice or None).
     Why two regions: recording the two events INSIDE the timed region costs 11-12 us of its wall clock whatever the host's
     wait policy (tools/steps20c.py: 84 us with them, 72 us without, for 20 launches that take 63 us on the stream) - the
@@ -194,7 +194,7 @@ def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams
     # is an instrument artefact of the other kind (r04: 3.5 / 4.9 / 3.7 us per launch on three runs while the event-free region
     # beside it ran at 3.0; tools/event_windows.py: a box whose chip has idled for 10 ms can stay
     # 20-30 % slower on event-bracketed work for seconds while an event-free region beside it runs at full speed).
-    windows = max(1, steps // EVENT_MIN_LAUNCHES)
+    windows = max(3, steps // EVENT_MIN_LAUNCHES)   # (one window alone read 3.6-4.1 us on two of six boxes while the event-free region beside it ran at 3.0-3.1)
     per_window = []
     for _ in range(windows):
         ev0.record()
@@ -202,7 +202,7 @@ def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams
         ev1.record()
         torch.cuda.synchronize()
         per_window.append(ev0.elapsed_time(ev1) * 1e-3 / EVENT_MIN_LAUNCHES)
-    per_launch = sum(per_window) / len(per_window)
+    per_launch = sorted(per_window)[len(per_window) // 2]
     return t1 - t0, per_launch, t3 - t2, issue, probe
 
 
@@ -739,6 +739,11 @@ def main():
                 traffic = int(2 * 1024 * pm["FETCH_SIZE"]["mean"] + 1024 * pm["WRITE_SIZE"]["mean"])
         except (KeyError, ValueError, IndexError):
             traffic, rocprof, traffic_source = None, None, "none: " + traffic_source + " (unreadable)"
+    # The launches of the timed region run back to back on one stream: its wall clock per step (host issue and the final drain included) is
+    # an UPPER bound of the kernel's average launch duration. On some boxes the event-bracketed windows behind a long timed region read
+    # 3.6-4.1 us per launch beside 3.0-3.1 us per step of wall clock (r04, --steps 200): the instrument, not the kernel - the bound wins then.
+    kern_events, wall_per_step = kern, wall / args.steps
+    kern = min(kern_events, wall_per_step) if args.streams <= 1 else kern_events
     hbm_floor_us, mfma_floor_us = algo_bytes / (HBM_PEAK_GBS * 1e9) * 1e6, eff_ops / (FP4_PEAK_TFLOPS * 1e12) * 1e6
     frac_hbm = round(algo_bytes / kern / 1e9 / HBM_PEAK_GBS, 5)
     if fp4_kernel:
@@ -747,11 +752,12 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_bitmm_fp4_one<1,%d,0,2,2>" % ({1: 1, 2: 2}.get(w, 4 if w <= 4 else 8)),
                     "achieved": round(algo_bytes / kern / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac_hbm,
                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(algo_bytes),
-                    "avg_launch_us": round(kern * 1e6, 3),
-                    "avg_launch_window": "%d x %d launches, issued like the timed region (%s)" % (max(1, args.steps // EVENT_MIN_LAUNCHES), EVENT_MIN_LAUNCHES, issue_used),
+                    "avg_launch_us": round(kern * 1e6, 3), "avg_launch_us_hip_events": round(kern_events * 1e6, 3),
+                    "avg_launch_bound": "hip_events" if kern_events <= wall_per_step else "wall clock per step of the timed region (an upper bound of it; the event windows read more)",
+                    "avg_launch_window": "%d x %d launches, issued like the timed region (%s)" % (max(3, args.steps // EVENT_MIN_LAUNCHES), EVENT_MIN_LAUNCHES, issue_used),
                     "avg_launch_source": "HIP events on the launch stream around windows of %d of the same launches issued right behind the timed "
-                                         "region (inside it the two event records cost 11-12 us of a 72 us window), max(1, K // %d) windows "
-                                         "averaged: kernel + dependent-launch gap (~1.5 us), i.e. what a caller gets per launch" % (EVENT_MIN_LAUNCHES, EVENT_MIN_LAUNCHES),
+                                         "region (inside it the two event records cost 11-12 us of a 72 us window), the median of max(3, K // %d) "
+                                         "windows: kernel + dependent-launch gap (~1.5 us), i.e. what a caller gets per launch" % (EVENT_MIN_LAUNCHES, EVENT_MIN_LAUNCHES),
                     "wall_ms_per_step_of_the_event_bracketed_region": round(wall_ev * 1e3 / args.steps, 6),
                     "frac_hbm": frac_hbm, "frac_mfma": round(eff_ops / kern / 1e12 / FP4_PEAK_TFLOPS, 5),
                     "floors_us": {"hbm": round(hbm_floor_us, 3), "mfma_fp4": round(mfma_floor_us, 3)},

@@ -43,4 +43,5 @@ res["pmc_per_dispatch_mean"] = {k: {c: {"mean": sum(v) / len(v), "dispatches": l
 json.dump(res, open(f"{out}/summary_{t}.json", "w"), indent=1)
 print(t, "ok", [ (k["name"][:40], k["calls"], k["avg_ns"]) for k in res.get("kernel_stats", [])[:3]])
 PY
+  python3 $GRAFT_REPO_ROOT/tools/trace_medians.py $OUT $T
 done
