@@ -93,6 +93,12 @@ class Oracle:
         L.qo_bitmm2int.argtypes = [_u32p, sz, _u32p, sz, i, i, i, i, i, i, _f32p]
         L.qo_tile_counters.argtypes = [_u32p, sz, i, i, i, i, i, u64p, u64p]
         L.qo_num_threads.restype = i
+        # A checker's products are small and many: on a 256-thread host an OpenMP team of every hardware thread spends its time in the
+        # region barriers (a 32-bit Batched-GIN chain on the tiny test graph: 7 s with the 256-thread default this library gets when it
+        # is loaded BEFORE torch - which would have capped the process at the physical cores - against 0.4 s). bench.py's cpu_baseline
+        # probes its own thread count.
+        if not os.environ.get("OMP_NUM_THREADS") and self.num_threads() > 32:
+            self.set_num_threads(32)
 
     # -- sizes ---------------------------------------------------------------------------
     def rows_words(self, H, W, b):
