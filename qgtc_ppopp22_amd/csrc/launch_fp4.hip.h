@@ -128,6 +128,7 @@ int qgtc_launch_rows(const qgtc_problem *prs, int count, int max_M, int max_N, i
     if (!done && a <= NA_ && w <= NW_) {                                 \
         done = true;                                                     \
         if (mode == 2) QGTC_RW_GO(NA_, NW_, 2, 0);                       \
+        else if (mode == 1 && ob == NW_) QGTC_RW_GO1(NA_, NW_, 1, NW_);  \
         else if (mode == 1) QGTC_RW_GO1(NA_, NW_, 1, 0);                 \
         else if (ob == 1) QGTC_RW_GO(NA_, NW_, 0, 1);                    \
         else if (ob == 2) QGTC_RW_GO(NA_, NW_, 0, 2);                    \
