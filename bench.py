@@ -61,8 +61,9 @@ def parse():
                         "the region; graph = the K launches captured ONCE, ahead of the timed region, in a hipGraph and replayed inside it by one "
                         "hipGraphLaunch (same kernels in stream order). Which is faster is the HOST's property: at K = 20 eager takes 3.6 us per "
                         "step on a box whose hipLaunchKernel costs 3.1-3.6 us (it overlaps the kernel's 3.0 us) and 4.6 on one where it costs "
-                        "more; the replay takes 3.97-4.03 on both. auto (default): both are set up ahead of the timed region, each is run five "
-                        "times untimed, the one with the lower median issues the timed region; the other's figure is reported in extras")
+                        "more; the replay takes 3.97-4.03 on both. auto (default): five untimed eager runs ahead of the timed region; only if "
+                        "their median is above what a replay is known to take are the graphs built and both ways compared (five runs each); "
+                        "the other way's figure is reported in extras")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget")
     p.add_argument("--backend", choices=["nccl", "gloo"], default=None, help="torch.distributed backend (default: nccl = RCCL)")
     p.add_argument("--dry-run", action="store_true", help="exercise the rank launcher and the collectives only (no GPU)")
@@ -148,6 +149,25 @@ def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams
     probe = None
     if streams > 1:
         issue = "eager"
+
+    def trials(fn, n=5):   # untimed: median wall clock of n runs of the K steps
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - tp)
+        return sorted(ts)[n // 2]
+
+    if issue == "auto":
+        # The host decides. Eager first, in the state a plain eager run has (r04: on one box the eager launches read 6.5 us per step once
+        # the graphs below existed and 3.6 in a run that never captured one): only a host whose eager issue is slower than a replay is
+        # known to be (3.0 us per kernel + ~20 us per graph launch) gets the graphs built and both ways compared in that state.
+        eager_us = trials(run_steps) * 1e6 / steps
+        probe = {"eager": round(eager_us, 3)}
+        if eager_us <= 3.05 + 20.0 / steps:
+            issue = "eager"
     if issue in ("graph", "auto"):
         graphs = []
         for n in (steps, EVENT_MIN_LAUNCHES):
@@ -157,18 +177,10 @@ def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams
             g.replay()             # (the first replay uploads the graph: untimed)
             graphs.append(g)
         torch.cuda.synchronize()
-        if issue == "auto":        # the host decides: five untimed runs of the K steps each way, alternating, medians compared
-            trials = {"eager": [], "graph": []}
-            for _ in range(5):
-                for mode, fn in (("eager", run_steps), ("graph", graphs[0].replay)):
-                    torch.cuda.synchronize()
-                    tp = time.perf_counter()
-                    fn()
-                    torch.cuda.synchronize()
-                    trials[mode].append(time.perf_counter() - tp)
-            med = {m: sorted(v)[2] for m, v in trials.items()}
-            issue = min(med, key=med.get)
-            probe = {m: round(v * 1e6 / steps, 3) for m, v in med.items()}
+        if issue == "auto":
+            probe["graph"] = round(trials(graphs[0].replay) * 1e6 / steps, 3)
+            probe["eager_with_the_graphs_alive"] = round(trials(run_steps) * 1e6 / steps, 3)
+            issue = "graph" if probe["graph"] < probe["eager_with_the_graphs_alive"] else "eager"
         if issue == "graph":
             run_steps, run_window = graphs[0].replay, graphs[1].replay
     enqueue(max(warmup, 1))
@@ -790,8 +802,8 @@ def main():
                    "issue": ("back-to-back launches on one stream (the reference's metric)" + (": the K launches captured once in a hipGraph ahead of the "
                              "timed region, ONE hipGraphLaunch inside it (same kernels in stream order; eager issue: extras.headline_other_issue)"
                              if issue_used == "graph" else ": K hipLaunchKernel calls inside the timed region (graph replay: extras.headline_other_issue)")
-                             + ("" if issue_probe is None else f"; chosen by an untimed probe ahead of the timed region (median of five runs of the K steps each way, "
-                                                               f"us per step: {issue_probe})")) if args.streams <= 1
+                             + ("" if issue_probe is None else f"; chosen by an untimed probe ahead of the timed region (medians of five runs of the K steps, "
+                                                               f"us per step: {issue_probe}; the graphs are only built when eager is above 3.05 + 20 / K)")) if args.streams <= 1
                             else f"independent launches round-robin on {args.streams} HIP streams",
                    "clock_warmup": f"{CLOCK_WARMUP_S} s of untimed launches ahead of the W warmup steps (the chip idles into a low "
                                    "power state while the host builds inputs; nothing else precedes the timed region)"},
