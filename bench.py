@@ -968,6 +968,9 @@ def main():
                 table["note"] = ("README.md:84-89's table (it does not say whether its figures are the QGTC or the DGL run); synthetic SBM graphs with the "
                                  "datasets' node / edge counts and feature widths, 75 cluster batches each")
                 extras["readme_cluster_gcn_table_hidden16_2bit"] = table
+                # (the same four rows inside the part of the line the driver's record keeps: [unchanged per-batch loop, grouped plan, reference sm_86] ms)
+                line["roofline"]["epoch_readme_table_ms"] = {ds: [r["per_batch_unchanged_driver_ms"], r["grouped_correct_chain_ms"], r["ref_sm86_ms"]]
+                                                             for ds, r in table.items() if isinstance(r, dict)}
             if rank == 0 and world == 1:
                 from oracle.dgl_cpu_baseline import graphsage_cpu_epoch
                 from qgtc_ppopp22_amd import graph as G
