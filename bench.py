@@ -115,6 +115,12 @@ CLOCK_WARMUP_S = 0.3
 EVENT_MIN_LAUNCHES = 200     # launches in the HIP-event window behind the timed region (QGTC_device.cu:409 times 200 too)
 
 
+def replay_worth_probing(eager_us_per_step, steps):
+    """--issue auto: graphs are only built (and both ways compared) when the eager issue of the K steps is slower than a replay is known to
+    be on this chip - 3.0 us per kernel plus ~20 us per hipGraphLaunch (3.97-4.05 us per step at K = 20 on every box measured)."""
+    return eager_us_per_step > 3.05 + 20.0 / steps
+
+
 def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams=1, issue="eager"):
     """warmup untimed launches, then EXACTLY `steps` launches between barrier+synchronize pairs (the contract's timed
     region: wall seconds), then the SAME `steps` launches once more between two HIP events recorded on the stream the
@@ -166,7 +172,7 @@ def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams
         # known to be (3.0 us per kernel + ~20 us per graph launch) gets the graphs built and both ways compared in that state.
         eager_us = trials(run_steps) * 1e6 / steps
         probe = {"eager": round(eager_us, 3)}
-        if eager_us <= 3.05 + 20.0 / steps:
+        if not replay_worth_probing(eager_us, steps):
             issue = "eager"
     if issue in ("graph", "auto"):
         graphs = []

@@ -272,3 +272,14 @@ def test_bench_fails_loudly_on_a_rank_count_mismatch():
 def test_bench_parent_fails_when_a_rank_fails():
     out = _run_bench(["--gpus", "2", "--dry-run", "--backend", "gloo"], env_extra={"QGTC_BENCH_FAIL_RANK": "1"})
     assert out.returncode != 0
+
+
+def test_bench_issue_auto_builds_graphs_only_for_slow_hosts():
+    """bench.py --issue auto: a host that issues the 20 steps of the driver's run at 3.6-3.8 us per step stays eager without ever
+    capturing a graph (a replay takes 3.97-4.05 there); one at 4.3+ gets both ways compared; long regions need a replay to beat 3.15."""
+    import bench
+
+    assert not bench.replay_worth_probing(3.64, 20) and not bench.replay_worth_probing(3.85, 20)
+    assert bench.replay_worth_probing(4.33, 20) and bench.replay_worth_probing(6.5, 20)
+    assert not bench.replay_worth_probing(3.03, 200) and bench.replay_worth_probing(3.4, 200)
+    assert not bench.replay_worth_probing(3.0, 1000)
