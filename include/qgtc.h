@@ -312,13 +312,13 @@ int qgtc_epoch_plan_fill(const qgtc_batch *batches, int count, const qgtc_stage 
                          const qgtc_operand *weights, int n_weights, void *pool, size_t pool_words,
                          qgtc_problem *descs, void *stream);
 
-/* ---- The chain entries: one wave per 32-row block for the whole output width (2-bit Cluster-GCN epochs) -----------------
+/* ---- The chain entries: one wave per 32-row block for the whole output width (the grouped epochs at 1 .. 4 bits) ------------
  * Between the launches of a layout-correct epoch (X.W1 | A.T1 + .W2 | A.T2 + .W3 | A.T3, main_qgtc.py:147-154 with every
  * right operand in the cols layout) T is written by one launch and read by the next and by nobody else. These entries keep
  * it in a private CHAIN FORMAT - the finished matrix-core operand, qgtc_chain_words(M, N) words per batch, unspecified to
  * the caller - and take the weights PRE-EXPANDED (qgtc_expand_weights, once per plan; qgtc_weight_codes_words(N) words
  * each). Word for word (after decoding) the results of the public entries; only the last call's float32 output is public.
- *   qgtc_chain_transform:  T_b = requant(X_b . W)                stage[b] = {X_b rows layout (x_bits planes, K <= 128), -, T_b}
+ *   qgtc_chain_transform:  T_b = requant(X_b . W)                stage[b] = {X_b rows layout (x_bits planes, K <= 1024), -, T_b}
  *   qgtc_chain_aggregate:  out_mode 0: out_b = float32(A_b . T_b)                      stage_a[b] = {A_b, T_b, out_b}; stage_xw = NULL
  *                          out_mode 1: T'_b  = requant(requant(A_b . T_b) . W')        stage_a[b] = {A_b, T_b, -}, stage_xw[b] = {-, -, T'_b}
  *                          out_mode 2: out_b = float32(requant(A_b . T_b) . W')        stage_xw[b] = {-, -, out_b [M, N2]}
@@ -332,7 +332,7 @@ int qgtc_epoch_plan_fill(const qgtc_batch *batches, int count, const qgtc_stage 
  * the aggregate in the registers of the wave that computed it). max_M is a hard precondition (QGTC_CHECK_DESCRIPTORS). */
 typedef struct qgtc_expand_job {
     const uint32_t *W;   /* cols layout [K, N], nbits planes of w_lines lines */
-    uint32_t *codes;     /* qgtc_weight_codes_words(N, nbits) words */
+    uint32_t *codes;     /* qgtc_weight_codes_words(N, nbits) words; order 0 with K > 128: STEP128(K) times that (a table per k-quad) */
     uint64_t w_words;
     int32_t K, N, nbits, w_lines, order, reserved;
 } qgtc_expand_job;

@@ -62,7 +62,8 @@ struct ExpandJobs {
 __global__ __launch_bounds__(64) void k_expand_weights(ExpandJobs jobs) {
     const ExpandJob j = jobs.job[blockIdx.y];
     const int jn = static_cast<int>(blockIdx.x) >> 1, s = static_cast<int>(blockIdx.x) & 1;
-    if (jn >= j.ncb) return;
+    const int q = static_cast<int>(blockIdx.z);   // order 0 with K > 128: one table per k-quad of K, [k-quad][column block][k half][digit][lane]
+    if (jn >= j.ncb || q >= (j.order == 0 ? step128(j.K) : 1)) return;
     const int lane = threadIdx.x, fl = lane & 31, fh = lane >> 5;
     const int n = 32 * jn + fl;
     const int line_words = step128(j.K) * 4;
@@ -78,11 +79,11 @@ __global__ __launch_bounds__(64) void k_expand_weights(ExpandJobs jobs) {
         for (int d = 0; d < 4; d++)
             for (int i = 0; i < 8; i++) {
                 int c;
-                if (j.order == 0) c = 32 * (2 * fh + s) + 31 - (d + 4 * i);   // bit d + 4 i of word 2 fh + s = element 31 - (d + 4 i)
+                if (j.order == 0) c = 128 * q + 32 * (2 * fh + s) + 31 - (d + 4 * i);   // bit d + 4 i of word 2 fh + s of k-quad q = element 31 - (d + 4 i)
                 else c = rbw_column(s, fh, d, i);
                 out[d] |= (bit(2 * dg, c) | (bit(2 * dg + 1, c) << 1)) << (4 * i);
             }
-        *reinterpret_cast<u32x4 *>(j.codes + ((static_cast<size_t>(blockIdx.x) * nd + dg) * 64 + lane) * 4) = u32x4{out[0], out[1], out[2], out[3]};
+        *reinterpret_cast<u32x4 *>(j.codes + (((static_cast<size_t>(q) * j.ncb * 2 + blockIdx.x) * nd + dg) * 64 + lane) * 4) = u32x4{out[0], out[1], out[2], out[3]};
     }
 }
 
@@ -268,11 +269,12 @@ __device__ __forceinline__ void rbw_xw_body(const qgtc_problem &pr, const u32x4 
     const int lines = pad128(N);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(pr.X), 0, static_cast<int>(static_cast<uint32_t>(pr.x_words) * 4u), 0x00020000);
-    const uint32_t x_plane = static_cast<uint32_t>(pad8(M)) * 16u;
+    const int kq = step128(pr.K);   // (one k-quad for the epochs' feature widths; more - K up to 1024 - take the loop at the end)
+    const uint32_t row_bytes = static_cast<uint32_t>(kq) * 16u, x_plane = static_cast<uint32_t>(pad8(M)) * row_bytes;
     uint32_t xl[2][NA];   // [k half][plane]: words 2 fh, 2 fh + 1 of the lane's row
 #pragma unroll
     for (int p = 0; p < NA; p++) {
-        const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, (m < M && p < sh.a) ? static_cast<uint32_t>(p) * x_plane + static_cast<uint32_t>(m) * 16u + 8u * fh : 0xffffffffu, 0, 0));
+        const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, (m < M && p < sh.a) ? static_cast<uint32_t>(p) * x_plane + static_cast<uint32_t>(m) * row_bytes + 8u * fh : 0xffffffffu, 0, 0));
         xl[0][p] = v.x;
         xl[1][p] = v.y;
     }
@@ -301,6 +303,30 @@ __device__ __forceinline__ void rbw_xw_body(const qgtc_problem &pr, const u32x4 
                 for (int dw = 0; dw < NDW; dw++)
                     acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[h][da], fp4_op(wc[jn][h][dw]), acc, 4, 4, 0, 128 + 2 * da, 0, 128 + 2 * dw);   // not swapped: lane = column 32 jn + fl
         accs[jn] = acc;
+    }
+    for (int q = 1; q < kq; q++) {   // (wave-uniform) the further k-quads of a wide feature matrix: its words, that k-quad's weight table
+#pragma unroll
+        for (int p = 0; p < NA; p++) {
+            const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, (m < M && p < sh.a) ? static_cast<uint32_t>(p) * x_plane + static_cast<uint32_t>(m) * row_bytes + static_cast<uint32_t>(q) * 16u + 8u * fh : 0xffffffffu, 0, 0));
+            xl[0][p] = v.x;
+            xl[1][p] = v.y;
+        }
+        const u32x4 *wq = w_codes + static_cast<size_t>(q) * NCB * 2 * NDW * 64;
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int da = 0; da < NDA; da++) xa[h][da] = fp4_op(strip_operand<NA>(xl[h], da));
+#pragma unroll
+        for (int jn = 0; jn < NCB; jn++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int dw = 0; dw < NDW; dw++) {
+                    const u32x4 w = wq[((jn * 2 + h) * NDW + dw) * 64 + lane];
+#pragma unroll
+                    for (int da = 0; da < NDA; da++)
+                        accs[jn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[h][da], fp4_op(w), accs[jn], 4, 4, 0, 128 + 2 * da, 0, 128 + 2 * dw);
+                }
     }
 #pragma unroll
     for (int jn = 0; jn < NCB; jn++) {

@@ -186,13 +186,14 @@ int qgtc_launch_rows_single(const qgtc_problem &pr, int a, int w, int ob, int mo
 // ---- row block per wave (bitmm_fp4_rbw.hip.h)
 int qgtc_launch_expand_weights(const qgtc_expand_job *jobs, int n_jobs, hipStream_t st) {
     ExpandJobs ej{};
-    int most = 0;
+    int most = 0, most_kq = 1;
     for (int i = 0; i < n_jobs; i++) {
         const qgtc_expand_job &j = jobs[i];
         ej.job[i] = ExpandJob{j.W, j.codes, j.w_words, j.K, j.N, j.w_lines, j.nbits, j.order, (j.N + 31) / 32};
         most = std::max(most, (j.N + 31) / 32);
+        if (j.order == 0) most_kq = std::max(most_kq, step128(j.K));   // (a table per k-quad of K)
     }
-    hipLaunchKernelGGL(k_expand_weights, dim3(2 * most, n_jobs), dim3(64), 0, st, ej);
+    hipLaunchKernelGGL(k_expand_weights, dim3(2 * most, n_jobs, most_kq), dim3(64), 0, st, ej);
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
 }

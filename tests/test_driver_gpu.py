@@ -251,3 +251,23 @@ def test_north_star_alias_names_run_the_same_operators(qgtc, oracle):
     np.testing.assert_array_equal(to_np_u32(bA), oA)
     np.testing.assert_array_equal(to_np_u32(qgtc.mm_v1(bA, bX, n, n, F, 1, b, b)), oracle.bitmm2bit(oA, oX, n, n, F, 1, b, b))
     np.testing.assert_array_equal(qgtc.mm_v2(bA, bX, n, n, F, 1, b, True).cpu().numpy(), oracle.bitmm2int(oA, oX, n, n, F, 1, b, True))
+
+
+@pytest.mark.parametrize("bits", [2, 4])
+@pytest.mark.parametrize("dim", [300, 602])
+def test_wide_feature_matrix_stays_on_the_chain_entries(qgtc, oracle, bits, dim):
+    """More than 128 features (reddit has 602): the first X . W of the grouped Cluster-GCN plan loops over the k-quads of the feature
+    matrix (qgtc_chain_transform, K <= 1024) instead of sending the whole epoch to the six-launch route - four launches, the oracle's outputs."""
+    from qgtc_ppopp22_amd import driver, graph as G
+
+    graph = G.make_graph("tiny", PSIZE, dim=dim)
+    args = _args(["--chain", "correct", "--bit_width", str(bits), "--batched"])
+    res = driver.run(args, Q=qgtc, graph=graph)
+    assert res["plan"].n_launches == 4
+    random.seed(2)
+    par = G.partition_list(graph, PSIZE)
+    random.shuffle(par)
+    W = oracle_weights(oracle, dim, 64, 10, bits)
+    for cid in range(PSIZE // BS):
+        bi = oracle_batch_inputs(oracle, graph, par, cid, PSIZE, BS, bits)
+        np.testing.assert_array_equal(res["outs"][cid].cpu().numpy(), oracle_chain(oracle, bi, W, bits, "correct", False)[-1])
