@@ -318,7 +318,7 @@ int qgtc_epoch_plan_fill(const qgtc_batch *batches, int count, const qgtc_stage 
  * it in a private CHAIN FORMAT - the finished matrix-core operand, qgtc_chain_words(M, N) words per batch, unspecified to
  * the caller - and take the weights PRE-EXPANDED (qgtc_expand_weights, once per plan; qgtc_weight_codes_words(N) words
  * each). Word for word (after decoding) the results of the public entries; only the last call's float32 output is public.
- *   qgtc_chain_transform:  T_b = requant(X_b . W)                stage[b] = {X_b rows layout (x_bits planes, K <= 1024), -, T_b}
+ *   qgtc_chain_transform:  T_b = requant(X_b . W)                stage[b] = {X_b rows layout (x_bits planes, K <= 8192), -, T_b}
  *   qgtc_chain_aggregate:  out_mode 0: out_b = float32(A_b . T_b)                      stage_a[b] = {A_b, T_b, out_b}; stage_xw = NULL
  *                          out_mode 1: T'_b  = requant(requant(A_b . T_b) . W')        stage_a[b] = {A_b, T_b, -}, stage_xw[b] = {-, -, T'_b}
  *                          out_mode 2: out_b = float32(requant(A_b . T_b) . W')        stage_xw[b] = {-, -, out_b [M, N2]}

@@ -269,7 +269,7 @@ __device__ __forceinline__ void rbw_xw_body(const qgtc_problem &pr, const u32x4 
     const int lines = pad128(N);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(pr.X), 0, static_cast<int>(static_cast<uint32_t>(pr.x_words) * 4u), 0x00020000);
-    const int kq = step128(pr.K);   // (one k-quad for the epochs' feature widths; more - K up to 1024 - take the loop at the end)
+    const int kq = step128(pr.K);   // (one k-quad for the epochs' feature widths; more - K up to 8192 - take the loop at the end)
     const uint32_t row_bytes = static_cast<uint32_t>(kq) * 16u, x_plane = static_cast<uint32_t>(pad8(M)) * row_bytes;
     uint32_t xl[2][NA];   // [k half][plane]: words 2 fh, 2 fh + 1 of the lane's row
 #pragma unroll

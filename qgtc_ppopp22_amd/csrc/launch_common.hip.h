@@ -167,7 +167,7 @@ inline bool xw_rows_ok(int max_K, int max_N, int a, int w, int ob) {
 // One width b = 1 .. 4 per chain (planes of X, W, T alike - what main_qgtc.py's --bit_width gives); 1 / 2 bits are one base-4 digit a
 // nibble, 3 / 4 bits two. N, N' <= 128; float32 sums exact (4 bits: K 15 < 2^24 for the aggregation, 128 x 15 x 15 for X . W).
 inline bool rbw_xw_ok(int K, int N, int x_bits, int out_bits) {
-    return K >= 1 && K <= 1024 && N >= 1 && N <= 128 && out_bits >= 1 && out_bits <= 4 && x_bits >= 1 && x_bits <= (out_bits > 2 ? 4 : 2);   // (K > 128: a k-quad loop; 1024 x 15 x 15 < 2^24)
+    return K >= 1 && K <= 8192 && N >= 1 && N <= 128 && out_bits >= 1 && out_bits <= 4 && x_bits >= 1 && x_bits <= (out_bits > 2 ? 4 : 2);   // (K > 128: a k-quad loop; 8192 x 15 x 15 < 2^24)
 }
 inline bool rbw_chain_ok(int max_K, int N1, int N2, int t_bits, int act_bits, int out_bits, int mode2) {
     if (max_K < 1 || max_K > 8192 || N1 < 1 || N1 > 128 || t_bits < 1 || t_bits > 4) return false;

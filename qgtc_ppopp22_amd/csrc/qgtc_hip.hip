@@ -391,7 +391,7 @@ int qgtc_expand_weights(const qgtc_expand_job *jobs, int n_jobs, void *stream) {
     for (int i = 0; i < n_jobs; i++) {
         const qgtc_expand_job &j = jobs[i];
         if (!j.W || !j.codes || j.K <= 0 || j.N <= 0 || j.N > 128 || j.nbits < 1 || j.nbits > 4 || j.w_lines < j.N || (j.order != 0 && j.order != 1)) return QGTC_EINVAL;
-        if ((j.order == 0 && j.K > 1024) || (j.order == 1 && j.K > 128)) return QGTC_EINVAL;
+        if ((j.order == 0 && j.K > 8192) || (j.order == 1 && j.K > 128)) return QGTC_EINVAL;
         if (!aligned16(j.codes)) return QGTC_EALIGN;
     }
     return qgtc_launch_expand_weights(jobs, n_jobs, static_cast<hipStream_t>(stream));

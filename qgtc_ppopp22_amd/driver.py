@@ -330,7 +330,7 @@ class PlannedEpoch:
         # the library's own routing switches that take the chain entries / chained pairs away (perf-only switches such as
         # QGTC_NO_XCD leave the route alone)
         switches = routing_switches()
-        if (fuse and chain == "correct" and chain_stages and not run_gin and not keep_aggregates and 1 <= b <= 4 and F <= 1024 and max(H, C) <= 128 and max_n <= 8192
+        if (fuse and chain == "correct" and chain_stages and not run_gin and not keep_aggregates and 1 <= b <= 4 and F <= 8192 and max(H, C) <= 128 and max_n <= 8192
                 and Q.get_engine() != "popcount" and not switches):
             # The Cluster-GCN chain (1 .. 4 bits; the BASELINE epoch: 2) on the chain entries (qgtc_chain_transform / qgtc_chain_aggregate): one wave per row
             # block for the whole width, T between the launches as finished matrix-core operands, weights pre-expanded once

@@ -363,7 +363,7 @@ class QgtcExpandJob(ctypes.Structure):
                 ("nbits", ctypes.c_int32), ("w_lines", ctypes.c_int32), ("order", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
-@pytest.mark.parametrize("M,K,F,H,C,bitmaps", [(333, 333, 48, 128, 10, True), (150, 150, 128, 64, 128, False), (300, 150, 32, 100, 33, True), (200, 200, 602, 128, 41, True), (70, 70, 1024, 33, 7, False),
+@pytest.mark.parametrize("M,K,F,H,C,bitmaps", [(333, 333, 48, 128, 10, True), (150, 150, 128, 64, 128, False), (300, 150, 32, 100, 33, True), (200, 200, 602, 128, 41, True), (70, 70, 3703, 33, 7, False),
                                                (150, 300, 100, 33, 70, True), (1213, 1213, 128, 128, 128, True), (40, 40, 7, 5, 3, False)])
 @pytest.mark.parametrize("b", [2, 1, 3, 4])     # one width per chain (main_qgtc.py's --bit_width); the BASELINE epoch: 2
 def test_chain_entries_with_raw_descriptors(lib, oracle, M, K, F, H, C, bitmaps, b):
@@ -442,7 +442,7 @@ def test_chain_entries_with_raw_descriptors(lib, oracle, M, K, F, H, C, bitmaps,
     lib.qgtc_last_batched_violation.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), vp]
     assert lib.qgtc_last_batched_violation(None, None, st) == 0
     # outside the entries' range: error codes (callers fall back to qgtc_gcn_chain_batched)
-    assert lib.qgtc_chain_transform(d(0), count, K, 1025, H, b, b, c1.data_ptr(), 0, st) == 1         # K > 1024
+    assert lib.qgtc_chain_transform(d(0), count, K, 8193, H, b, b, c1.data_ptr(), 0, st) == 1         # K > 8192
     assert lib.qgtc_chain_transform(d(0), count, K, F, H, b, 5, c1.data_ptr(), 0, st) == 1            # 5-bit T
     assert lib.qgtc_chain_transform(d(0), count, K, F, H, 3, 2, c1.data_ptr(), 0, st) == 1            # three planes of X into a one-digit chain
     assert lib.qgtc_chain_aggregate(d(1), d(2), count, M, K, H, C, b, 5 - b, 5 - b, 1, c2.data_ptr(), 0, st) == 1   # T and the aggregate in different format classes

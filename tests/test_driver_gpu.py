@@ -254,10 +254,10 @@ def test_north_star_alias_names_run_the_same_operators(qgtc, oracle):
 
 
 @pytest.mark.parametrize("bits", [2, 4])
-@pytest.mark.parametrize("dim", [300, 602])
+@pytest.mark.parametrize("dim", [300, 1433])
 def test_wide_feature_matrix_stays_on_the_chain_entries(qgtc, oracle, bits, dim):
     """More than 128 features (reddit has 602): the first X . W of the grouped Cluster-GCN plan loops over the k-quads of the feature
-    matrix (qgtc_chain_transform, K <= 1024) instead of sending the whole epoch to the six-launch route - four launches, the oracle's outputs."""
+    matrix (qgtc_chain_transform, K <= 8192) instead of sending the whole epoch to the six-launch route - four launches, the oracle's outputs."""
     from qgtc_ppopp22_amd import driver, graph as G
 
     graph = G.make_graph("tiny", PSIZE, dim=dim)
