@@ -311,7 +311,7 @@ __device__ __forceinline__ void rbw_xw_body(const qgtc_problem &pr, const u32x4 
             xl[0][p] = v.x;
             xl[1][p] = v.y;
         }
-        const u32x4 *wq = w_codes + static_cast<size_t>(q) * NCB * 2 * NDW * 64;
+        const u32x4 *wq = w_codes + static_cast<size_t>(q) * (NCB == 3 ? 4 : NCB) * 2 * NDW * 64;   // (a table has weight_table_blocks(N) column blocks)
 #pragma unroll
         for (int h = 0; h < 2; h++)
 #pragma unroll

@@ -10,6 +10,10 @@ namespace {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+// column blocks (32 columns) a pre-expanded weight table of the chain entries has: three are kept as four - the kernels of every width
+// but the 2-bit family run three blocks as four (launch_fp4.hip.h) and read the fourth block's (all-zero) codes
+__host__ __device__ constexpr int weight_table_blocks(int N) { return (N + 31) / 32 == 3 ? 4 : (N + 31) / 32; }
+
 constexpr int TM = 32, TN = 32;  // workgroup tile of the bit-GEMM
 
 // ------------------------------------------------------------------------------------------

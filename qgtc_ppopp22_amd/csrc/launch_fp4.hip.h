@@ -189,8 +189,8 @@ int qgtc_launch_expand_weights(const qgtc_expand_job *jobs, int n_jobs, hipStrea
     int most = 0, most_kq = 1;
     for (int i = 0; i < n_jobs; i++) {
         const qgtc_expand_job &j = jobs[i];
-        ej.job[i] = ExpandJob{j.W, j.codes, j.w_words, j.K, j.N, j.w_lines, j.nbits, j.order, (j.N + 31) / 32};
-        most = std::max(most, (j.N + 31) / 32);
+        ej.job[i] = ExpandJob{j.W, j.codes, j.w_words, j.K, j.N, j.w_lines, j.nbits, j.order, weight_table_blocks(j.N)};   // (columns past N: zero codes)
+        most = std::max(most, weight_table_blocks(j.N));
         if (j.order == 0) most_kq = std::max(most_kq, step128(j.K));   // (a table per k-quad of K)
     }
     hipLaunchKernelGGL(k_expand_weights, dim3(2 * most, n_jobs, most_kq), dim3(64), 0, st, ej);

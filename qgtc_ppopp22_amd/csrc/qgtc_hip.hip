@@ -373,7 +373,7 @@ int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stag
 }
 
 size_t qgtc_weight_codes_words(int N, int nbits) {
-    return (N > 0 && nbits >= 1 && nbits <= 4) ? static_cast<size_t>((N + 31) / 32) * 2u * ((nbits + 1) / 2) * 64u * 4u : 0u;
+    return (N > 0 && nbits >= 1 && nbits <= 4) ? static_cast<size_t>(weight_table_blocks(N)) * 2u * ((nbits + 1) / 2) * 64u * 4u : 0u;
 }
 
 int qgtc_chain_from_cols(const uint32_t *cols, size_t cols_words, int H, int W, int nbits, uint32_t *chain, size_t chain_words,

@@ -363,7 +363,7 @@ class QgtcExpandJob(ctypes.Structure):
                 ("nbits", ctypes.c_int32), ("w_lines", ctypes.c_int32), ("order", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
-@pytest.mark.parametrize("M,K,F,H,C,bitmaps", [(333, 333, 48, 128, 10, True), (150, 150, 128, 64, 128, False), (300, 150, 32, 100, 33, True), (200, 200, 602, 128, 41, True), (70, 70, 3703, 33, 7, False),
+@pytest.mark.parametrize("M,K,F,H,C,bitmaps", [(333, 333, 48, 128, 10, True), (150, 150, 128, 64, 128, False), (300, 150, 32, 100, 33, True), (200, 200, 602, 128, 41, True), (70, 70, 3703, 33, 7, False), (120, 120, 300, 70, 90, True),
                                                (150, 300, 100, 33, 70, True), (1213, 1213, 128, 128, 128, True), (40, 40, 7, 5, 3, False)])
 @pytest.mark.parametrize("b", [2, 1, 3, 4])     # one width per chain (main_qgtc.py's --bit_width); the BASELINE epoch: 2
 def test_chain_entries_with_raw_descriptors(lib, oracle, M, K, F, H, C, bitmaps, b):

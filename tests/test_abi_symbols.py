@@ -117,6 +117,7 @@ def test_epoch_pool_layout_is_host_side(lib, oracle):
     lib.qgtc_adj_tiles_words.restype = ctypes.c_size_t                     # 512-byte tiles: [32-row block][k-quad][32 rows][4 words]
     assert lib.qgtc_adj_tiles_words(1213, 1213) == 38 * 10 * 128 and lib.qgtc_adj_tiles_words(1, 129) == 2 * 128 and lib.qgtc_adj_tiles_words(0, 5) == 0
     assert lib.qgtc_weight_codes_words(100, 2) == 4 * 2 * 64 * 4 and lib.qgtc_weight_codes_words(50, 4) == 2 * 2 * 2 * 64 * 4
+    assert lib.qgtc_weight_codes_words(70, 3) == 4 * 2 * 2 * 64 * 4      # three column blocks are kept as four (the fourth: zero codes)
     assert total == sum(sizes)
     assert list(offs) == [sum(sizes[:i]) for i in range(len(sizes))]
     assert lib.qgtc_epoch_pool_layout(None, 3, ctypes.addressof(stages), 3, None) == 0
