@@ -532,7 +532,7 @@ def test_chain_entries_at_four_bits(lib, oracle, M, F, H, C, bitmaps):
     assert lib.qgtc_chain_from_cols(dX.data_ptr(), dX.numel(), M, F, b, XC.data_ptr(), 3, st) == 2
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(80))
 def test_chain_entries_random_sweep(lib, oracle, seed):
     """Random shapes through the chain entries against the oracle: node counts around the 32 / 128 boundaries (and below 32), widths
     around the 32-column blocks, 2-bit (N <= 128) and 4-bit (N <= 64) chains, adjacency density from empty to dense, K != M, pooled
@@ -551,18 +551,21 @@ def test_chain_entries_random_sweep(lib, oracle, seed):
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P128 = lambda x: (x + 127) // 128 * 128   # noqa: E731
     tiles = seed % 2 == 1
-    b = int(rng.choice([2, 2, 4]))
-    wmax = 128 if b == 2 else 64
+    b = int(rng.choice([1, 2, 2, 3, 4, 4]))      # one width per chain
+    use_xw = bool(rng.integers(0, 2))            # T from qgtc_chain_transform (X . W1), or a data-loader operand converted from the cols layout
+    wmax = 128
     pick = lambda hi: int(rng.choice([1, 7, 31, 32, 33, 63, 64, 65, 96, 127, 128, int(rng.integers(1, hi + 1))]))   # noqa: E731
     F, H, C = min(pick(wmax), wmax), min(pick(wmax), wmax), min(pick(wmax), wmax)
+    if use_xw and rng.integers(0, 3) == 0:
+        F = int(rng.choice([129, 256, 300, 602, int(rng.integers(129, 900))]))   # more than one k-quad of features
     count = int(rng.integers(1, 5))
     bitmaps = bool(rng.integers(0, 2))
     density = float(rng.choice([0.0, 0.01, 0.05, 0.5, 1.0]))
     W1, W2 = oracle.pack(rand_q(rng, F, H, b), b, True), oracle.pack(rand_q(rng, H, C, b), b, True)
     dW1, dW2 = torch.from_numpy(W1.view(np.int32)).cuda(), torch.from_numpy(W2.view(np.int32)).cuda()
-    c1 = torch.full((int(lib.qgtc_weight_codes_words(H, b)),), -1, dtype=torch.int32, device="cuda")
+    c1 = torch.full((int(lib.qgtc_weight_codes_words(H, b)) * ((F + 127) // 128),), -1, dtype=torch.int32, device="cuda")
     c2 = torch.full((int(lib.qgtc_weight_codes_words(C, b)),), -1, dtype=torch.int32, device="cuda")
-    jobs = (QgtcExpandJob * 2)(QgtcExpandJob(dW1.data_ptr(), c1.data_ptr(), dW1.numel(), F, H, b, P128(H), 0 if b == 2 else 1, 0),
+    jobs = (QgtcExpandJob * 2)(QgtcExpandJob(dW1.data_ptr(), c1.data_ptr(), dW1.numel(), min(F, 128) if not use_xw else F, H, b, P128(H), 0 if use_xw else 1, 0),
                                QgtcExpandJob(dW2.data_ptr(), c2.data_ptr(), dW2.numel(), H, C, b, P128(C), 1, 0))
     assert lib.qgtc_expand_weights(ctypes.addressof(jobs), 2, st) == 0
     keep, sx, sa, sw, sf, want, ms, ks = [], [], [], [], [], [], [], []
@@ -575,12 +578,12 @@ def test_chain_entries_random_sweep(lib, oracle, seed):
         A = oracle.pack(qa, 1, False)
         dA = torch.from_numpy(A.view(np.int32)).cuda()
         T = torch.full((int(lib.qgtc_chain_words(k, H)),), -1, dtype=torch.int32, device="cuda")     # requant(X . W1), or the converted X'
-        if b == 2:    # T = requant(X . W1): X [k, F] rows layout
+        if use_xw:    # T = requant(X . W1): X [k, F] rows layout
             X = oracle.pack(rand_q(rng, k, F, b), b, False)
             dX = torch.from_numpy(X.view(np.int32)).cuda()
             sx.append(QgtcProblem(dX.data_ptr(), dW1.data_ptr(), T.data_ptr(), dX.numel(), dW1.numel(), k, F, H, P128(H), 0, None))
             t_o = oracle.bitmm2bit(X, W1, k, F, H, b, b, b, col=True)
-        else:         # 4 bits: T = a data-loader operand [k, H] converted from the public cols layout
+        else:         # T = a data-loader operand [k, H] converted from the public cols layout
             t_o = oracle.pack(rand_q(rng, k, H, b), b, True)
             dX = torch.from_numpy(t_o.view(np.int32)).cuda()
             assert lib.qgtc_chain_from_cols(dX.data_ptr(), dX.numel(), k, H, b, T.data_ptr(), T.numel(), st) == 0
@@ -607,16 +610,16 @@ def test_chain_entries_random_sweep(lib, oracle, seed):
         sf.append(QgtcProblem(None, dW2.data_ptr(), out.data_ptr(), 0, dW2.numel(), m, H, C, P128(C), 0, None))
         h_o = oracle.bitmm2bit(A, t_o, m, k, H, 1, b, b)
         want.append((out, oracle.bitmm2int(h_o, W2, m, H, C, b, b, True)))
-    host = (QgtcProblem * (3 * count))(*((sx if b == 2 else sa) + sa + sf))
+    host = (QgtcProblem * (3 * count))(*((sx if use_xw else sa) + sa + sf))
     descs = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
     d = lambda i: descs.data_ptr() + 72 * count * i       # noqa: E731
-    if b == 2:
+    if use_xw:
         rc = lib.qgtc_chain_transform(d(0), count, max(ks), F, H, b, b, c1.data_ptr(), 0x200, st)
         assert rc == 0, lib.qgtc_strerror(rc)
     rc = lib.qgtc_chain_aggregate(d(1), d(2), count, max(ms), max(ks), H, C, b, b, b, 2, c2.data_ptr(), 0x200 | (0x400 if tiles else 0), st)
     assert rc == 0, lib.qgtc_strerror(rc)
     torch.cuda.synchronize()
     for i, (o, w) in enumerate(want):
-        np.testing.assert_array_equal(o.cpu().numpy().reshape(w.shape), w, err_msg=f"seed {seed} b={b} F={F} H={H} C={C} m={ms[i]} k={ks[i]} density={density} bitmaps={bitmaps}")
+        np.testing.assert_array_equal(o.cpu().numpy().reshape(w.shape), w, err_msg=f"seed {seed} b={b} xw={use_xw} F={F} H={H} C={C} m={ms[i]} k={ks[i]} density={density} bitmaps={bitmaps}")
     lib.qgtc_last_batched_violation.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), vp]
     assert lib.qgtc_last_batched_violation(None, None, st) == 0
