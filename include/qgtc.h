@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define QGTC_ABI_VERSION 10
+#define QGTC_ABI_VERSION 11
 
 enum {
     QGTC_OK = 0,
@@ -316,8 +316,8 @@ int qgtc_epoch_plan_fill(const qgtc_batch *batches, int count, const qgtc_stage 
  * Between the launches of a layout-correct epoch (X.W1 | A.T1 + .W2 | A.T2 + .W3 | A.T3, main_qgtc.py:147-154 with every
  * right operand in the cols layout) T is written by one launch and read by the next and by nobody else. These entries keep
  * it in a private CHAIN FORMAT - the finished matrix-core operand, qgtc_chain_words(M, N) words per batch, unspecified to
- * the caller - and take the weights PRE-EXPANDED (qgtc_expand_weights, once per plan; qgtc_weight_codes_words(N) words
- * each). Word for word (after decoding) the results of the public entries; only the last call's float32 output is public.
+ * the caller - and take the weights PRE-EXPANDED (qgtc_expand_weights, once per plan; qgtc_weight_codes_words(K, N, nbits,
+ * order) words each, stated to the entry as the job's `codes_words`: a table too small for the job is QGTC_ESIZE, never a write). Word for word (after decoding) the results of the public entries; only the last call's float32 output is public.
  *   qgtc_chain_transform:  T_b = requant(X_b . W)                stage[b] = {X_b rows layout (x_bits planes, K <= 8192), -, T_b}
  *   qgtc_chain_aggregate:  out_mode 0: out_b = float32(A_b . T_b)                      stage_a[b] = {A_b, T_b, out_b}; stage_xw = NULL
  *                          out_mode 1: T'_b  = requant(requant(A_b . T_b) . W')        stage_a[b] = {A_b, T_b, -}, stage_xw[b] = {-, -, T'_b}
@@ -329,14 +329,18 @@ int qgtc_epoch_plan_fill(const qgtc_batch *batches, int count, const qgtc_stage 
  * N, N2 <= 128; qgtc_chain_transform: out_bits 1 .. 4, x_bits <= 2 (out_bits <= 2) or <= 4 (out_bits 3 / 4).
  * QGTC_EINVAL outside that range: callers fall back to qgtc_gcn_chain_batched. w_codes: qgtc_expand_weights order 0 for
  * qgtc_chain_transform (the left operand arrives as packed words), order 1 for qgtc_chain_aggregate (the left operand is
- * the aggregate in the registers of the wave that computed it). max_M is a hard precondition (QGTC_CHECK_DESCRIPTORS). */
+ * the aggregate in the registers of the wave that computed it). max_M is a hard precondition (QGTC_CHECK_DESCRIPTORS).
+ * qgtc_chain_transform's K is the K the weights were expanded for and EVERY descriptor's K must equal it: the kernel takes its
+ * k-quad count and the stride of the weight tables from this argument, never from a descriptor (a larger descriptor K cannot
+ * walk past the tables; QGTC_CHECK_DESCRIPTORS reports the mismatch). */
 typedef struct qgtc_expand_job {
     const uint32_t *W;   /* cols layout [K, N], nbits planes of w_lines lines */
-    uint32_t *codes;     /* qgtc_weight_codes_words(N, nbits) words; order 0 with K > 128: STEP128(K) times that (a table per k-quad) */
+    uint32_t *codes;     /* out: qgtc_weight_codes_words(K, N, nbits, order) words (order 0: a table per k-quad of K) */
     uint64_t w_words;
-    int32_t K, N, nbits, w_lines, order, reserved;
+    int32_t K, N, nbits, w_lines, order;
+    uint32_t codes_words; /* capacity of `codes` in 32-bit words (ABI 11; was `reserved`): checked against the line above */
 } qgtc_expand_job;
-size_t qgtc_weight_codes_words(int N, int nbits);
+size_t qgtc_weight_codes_words(int K, int N, int nbits, int order);   /* (ABI 10 took (N, nbits) and left the per-k-quad factor to the caller) */
 size_t qgtc_chain_words(int M, int N);
 /* A cols-layout right operand (the public format: X of sampler.py:99, [H, W] with nbits <= 4 planes) in the chain format:
  * what a data loader does once beside the packing when the epoch's FIRST product is an aggregation (Batched-GIN: A . X,

@@ -258,7 +258,7 @@ __device__ __forceinline__ void rbw_store_f32_row(__amdgpu_buffer_rsrc_t ro, uin
 // 128), W pre-expanded (order 0), T in the chain format. A workgroup = four row blocks (one k-quad of T), a wave = one.
 // ------------------------------------------------------------------------------------------
 template <int NA, int OB, int NCB>
-__device__ __forceinline__ void rbw_xw_body(const qgtc_problem &pr, const u32x4 *__restrict__ w_codes, const RbwShape &sh, int grp) {
+__device__ __forceinline__ void rbw_xw_body(const qgtc_problem &pr, const u32x4 *__restrict__ w_codes, const RbwShape &sh, int grp, int kq_tables) {
     constexpr int NDA = (NA + 1) / 2;
     constexpr int NDW = OB > 2 ? 2 : 1;   // base-4 digits of W (a chain has ONE width: W has as many planes as T)
     const int M = pr.M, N = pr.N;
@@ -269,8 +269,11 @@ __device__ __forceinline__ void rbw_xw_body(const qgtc_problem &pr, const u32x4 
     const int lines = pad128(N);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(pr.X), 0, static_cast<int>(static_cast<uint32_t>(pr.x_words) * 4u), 0x00020000);
-    const int kq = step128(pr.K);   // (one k-quad for the epochs' feature widths; more - K up to 8192 - take the loop at the end)
-    const uint32_t row_bytes = static_cast<uint32_t>(kq) * 16u, x_plane = static_cast<uint32_t>(pad8(M)) * row_bytes;
+    // k-quads: the count the HOST stated (the K the weight tables were expanded for - w_codes is a raw pointer, so the loop bound must
+    // not come from a descriptor). X's own row stride is the descriptor's; where the two disagree the buffer range check of rx and the
+    // clamp below keep every read inside what exists. One k-quad for the epochs' feature widths; more - K up to 8192 - take the loop.
+    const int kq_x = step128(pr.K), kq = kq_tables < kq_x ? kq_tables : kq_x;
+    const uint32_t row_bytes = static_cast<uint32_t>(kq_x) * 16u, x_plane = static_cast<uint32_t>(pad8(M)) * row_bytes;
     uint32_t xl[2][NA];   // [k half][plane]: words 2 fh, 2 fh + 1 of the lane's row
 #pragma unroll
     for (int p = 0; p < NA; p++) {
@@ -336,7 +339,7 @@ __device__ __forceinline__ void rbw_xw_body(const qgtc_problem &pr, const u32x4 
 }
 
 template <int NA, int OB, int NCB>
-__global__ __launch_bounds__(256) void k_rbw_xw(const qgtc_problem *__restrict__ prs, const u32x4 *__restrict__ w_codes, int per, int a_planes, int gx, int gy) {
+__global__ __launch_bounds__(256) void k_rbw_xw(const qgtc_problem *__restrict__ prs, const u32x4 *__restrict__ w_codes, int per, int a_planes, int gx, int gy, int kq_tables) {
     // (scalar kernel arguments only: a struct by value is not preloaded into SGPRs - its fields were s_load round trips of their own)
     int grp, batch;
     rbw_ids(per, gx, gy, grp, batch);
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256) void k_rbw_xw(const qgtc_problem *__restrict__
     rbw_pin(pr);
     if (grp >= step128(pr.M)) return;
     const RbwShape sh{per, a_planes, 0};
-    rbw_xw_body<NA, OB, NCB>(pr, w_codes, sh, grp);
+    rbw_xw_body<NA, OB, NCB>(pr, w_codes, sh, grp, kq_tables);
 }
 
 // ------------------------------------------------------------------------------------------

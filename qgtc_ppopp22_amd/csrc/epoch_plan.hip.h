@@ -182,25 +182,26 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_epoch_plan_fill(const qgtc_bat
 // 1's output, K2 = N1); 3: one stage whose `out` is not used; 4: the pair of qgtc_chain_aggregate with a second product - p1 = the
 // aggregation (its `out` unused), p2 = the transform whose OUTPUT is all the entry uses (non-NULL, 16-byte aligned: the kernels
 // store 16 bytes a lane; M = p1's M). exact_N1 / exact_N2 != 0: the chain entries size their stores from the HOST's N, so the
-// descriptors' N must EQUAL it. The first violation (lowest problem index, then lowest field code) wins: record = problem * 8 +
+// descriptors' N must EQUAL it; exact_K1 != 0 (qgtc_chain_transform: the weight tables were expanded for the host's K) likewise for
+// stage 1's K. The first violation (lowest problem index, then lowest field code) wins: record = problem * 8 +
 // field, kept with atomicMin (INT_MAX = none).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_check_descriptors(const qgtc_problem *__restrict__ p1, const qgtc_problem *__restrict__ p2, int count,
                                                            int max_M, int max_K1, int max_N1, int max_K2, int max_N2, int kind,
-                                                           int exact_N1, int exact_N2, int *__restrict__ record) {
+                                                           int exact_N1, int exact_N2, int exact_K1, int *__restrict__ record) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
         int field = QGTC_VIOL_NONE;
-        auto one = [&](const qgtc_problem &p, int mk, int mn, int exact_n, bool out_used) {
+        auto one = [&](const qgtc_problem &p, int mk, int mn, int exact_n, bool out_used, int exact_k = 0) {
             if (field) return;
             if (p.M <= 0 || p.M > max_M) field = QGTC_VIOL_M;
-            else if (p.K <= 0 || p.K > mk) field = QGTC_VIOL_K;
+            else if (p.K <= 0 || p.K > mk || (exact_k && p.K != exact_k)) field = QGTC_VIOL_K;
             else if (p.N <= 0 || p.N > mn || (exact_n && p.N != exact_n)) field = QGTC_VIOL_N;
             else if (!p.X || !p.W || (reinterpret_cast<uintptr_t>(p.X) & 15u) || (reinterpret_cast<uintptr_t>(p.W) & 15u) ||
                      (out_used && (!p.out || (reinterpret_cast<uintptr_t>(p.out) & 15u))) || p.x_words >= (1ull << 30) || p.w_words >= (1ull << 30))
                 field = QGTC_VIOL_POINTER;
         };
         const qgtc_problem a = p1[i];
-        one(a, max_K1, max_N1, exact_N1, kind != 3 && kind != 4);
+        one(a, max_K1, max_N1, exact_N1, kind != 3 && kind != 4, exact_K1);
         if (p2 && kind == 4) {
             const qgtc_problem b = p2[i];
             if (!field) {

@@ -21,7 +21,7 @@ int qgtc_launch_xw_rows(const qgtc_problem *prs, int count, int max_M, int a, in
 int qgtc_launch_expand_weights(const qgtc_expand_job *jobs, int n_jobs, hipStream_t st);
 int qgtc_launch_cols_to_chain(const uint32_t *cols, size_t words, int H, int W, int nbits, uint32_t *chain, hipStream_t st);
 int qgtc_launch_cols_to_chain_batched(const qgtc_loader_batch *batches, int count, int max_n, int W, int nbits, hipStream_t st);
-int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int N, int a, int ob, const uint32_t *w_codes, hipStream_t st);
+int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int K, int N, int a, int ob, const uint32_t *w_codes, hipStream_t st);
 int qgtc_launch_rbw_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int N1, int N2, int t_bits, int act_bits,
                           int out_bits, int mode2, const uint32_t *w2_codes, bool a_tiles, hipStream_t st);
 int qgtc_launch_rows_to_tiles(const uint32_t *rows, size_t words, int M, int K, uint32_t *tiles, hipStream_t st);
@@ -31,7 +31,7 @@ int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hip
 // defined in qgtc_epoch.hip: QGTC_CHECK_DESCRIPTORS (kind 0 one stage / 1 layer / 2 chain / 3 one stage, `out` unused / 4 the pair of
 // qgtc_chain_aggregate; p2 may be NULL; exact_N*: the descriptors' N must equal it)
 int qgtc_launch_check_descriptors(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int max_K1, int max_N1,
-                                  int max_K2, int max_N2, int kind, hipStream_t st, int exact_N1 = 0, int exact_N2 = 0);
+                                  int max_K2, int max_N2, int kind, hipStream_t st, int exact_N1 = 0, int exact_N2 = 0, int exact_K1 = 0);
 
 namespace {
 
@@ -165,7 +165,7 @@ inline bool xw_rows_ok(int max_K, int max_N, int a, int w, int ob) {
 }
 
 // One width b = 1 .. 4 per chain (planes of X, W, T alike - what main_qgtc.py's --bit_width gives); 1 / 2 bits are one base-4 digit a
-// nibble, 3 / 4 bits two. N, N' <= 128; float32 sums exact (4 bits: K 15 < 2^24 for the aggregation, 128 x 15 x 15 for X . W).
+// nibble, 3 / 4 bits two. N, N' <= 128; float32 sums exact (4 bits: K 15 < 2^24 for the aggregation, 8192 x 15 x 15 < 2^24 for X . W with its k-quad loop).
 inline bool rbw_xw_ok(int K, int N, int x_bits, int out_bits) {
     return K >= 1 && K <= 8192 && N >= 1 && N <= 128 && out_bits >= 1 && out_bits <= 4 && x_bits >= 1 && x_bits <= (out_bits > 2 ? 4 : 2);   // (K > 128: a k-quad loop; 8192 x 15 x 15 < 2^24)
 }

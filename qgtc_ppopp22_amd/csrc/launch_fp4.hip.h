@@ -214,15 +214,15 @@ int qgtc_launch_cols_to_chain_batched(const qgtc_loader_batch *batches, int coun
     return QGTC_OK;
 }
 
-int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int N, int a, int ob, const uint32_t *w_codes, hipStream_t st) {
+int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int K, int N, int a, int ob, const uint32_t *w_codes, hipStream_t st) {
     const int per = getenv_flag("QGTC_NO_XCD") ? 0 : 1;   // (the workgroups of a batch on one XCD)
     const dim3 grid(step128(max_M), count), block(256);
     const int gx = static_cast<int>(grid.x), gy = static_cast<int>(grid.y);
     const u32x4 *wc = reinterpret_cast<const u32x4 *>(w_codes);
-    const int ncb = (N + 31) / 32;
+    const int ncb = (N + 31) / 32, kq = step128(K);   // (the k-quads of the WEIGHT TABLES: launch-uniform, preloaded into an SGPR)
     if (ob < 1 || ob > 4 || a < 1 || a > (ob > 2 ? 4 : 2) || ncb < 1 || ncb > 4) return QGTC_EINVAL;
     // column blocks 1 / 2 / 4 (three run as four: the lines past N are zeros); the 2-bit chain of the BASELINE epoch also has its own three
-#define QGTC_RBWX_GO(NA_, OB_, NCB_) hipLaunchKernelGGL((k_rbw_xw<NA_, OB_, NCB_>), grid, block, 0, st, prs, wc, per, a, gx, gy)
+#define QGTC_RBWX_GO(NA_, OB_, NCB_) hipLaunchKernelGGL((k_rbw_xw<NA_, OB_, NCB_>), grid, block, 0, st, prs, wc, per, a, gx, gy, kq)
 #define QGTC_RBWX_OB(NA_, OB_)                                            \
     if (ncb == 1) QGTC_RBWX_GO(NA_, OB_, 1);                              \
     else if (ncb == 2) QGTC_RBWX_GO(NA_, OB_, 2);                         \

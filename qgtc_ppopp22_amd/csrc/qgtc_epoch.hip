@@ -46,12 +46,12 @@ int record_for_current_device(int **out, bool create) {
 
 // called by the grouped entry points of qgtc_hip.hip when QGTC_CHECK_DESCRIPTORS is set (declared in launch_common.hip.h)
 int qgtc_launch_check_descriptors(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int max_K1, int max_N1,
-                                  int max_K2, int max_N2, int kind, hipStream_t st, int exact_N1, int exact_N2) {
+                                  int max_K2, int max_N2, int kind, hipStream_t st, int exact_N1, int exact_N2, int exact_K1) {
     int *rec = nullptr;
     const int rc = record_for_current_device(&rec, true);
     if (rc != QGTC_OK) return rc;
     hipLaunchKernelGGL(k_check_descriptors, dim3((count + 255) / 256), dim3(256), 0, st, p1, p2, count, max_M, max_K1, max_N1,
-                       max_K2, max_N2, kind, exact_N1, exact_N2, rec);
+                       max_K2, max_N2, kind, exact_N1, exact_N2, exact_K1, rec);
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
 }

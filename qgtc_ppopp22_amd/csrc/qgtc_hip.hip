@@ -372,8 +372,10 @@ int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stag
     return qgtc_bitmm_batched(stage_xw, count, max_M, max_N1, max_N2, act_bits, w_bits, out_mode == 2 ? 1 : out_bits, out_mode, flags & ~QGTC_ZERO_JUMP, stream);
 }
 
-size_t qgtc_weight_codes_words(int N, int nbits) {
-    return (N > 0 && nbits >= 1 && nbits <= 4) ? static_cast<size_t>(weight_table_blocks(N)) * 2u * ((nbits + 1) / 2) * 64u * 4u : 0u;
+size_t qgtc_weight_codes_words(int K, int N, int nbits, int order) {
+    if (K <= 0 || N <= 0 || nbits < 1 || nbits > 4 || (order != 0 && order != 1)) return 0u;
+    const size_t table = static_cast<size_t>(weight_table_blocks(N)) * 2u * ((nbits + 1) / 2) * 64u * 4u;
+    return table * (order == 0 ? static_cast<size_t>(step128(K)) : 1u);   // order 0: a table per k-quad of K
 }
 
 int qgtc_chain_from_cols(const uint32_t *cols, size_t cols_words, int H, int W, int nbits, uint32_t *chain, size_t chain_words,
@@ -393,6 +395,7 @@ int qgtc_expand_weights(const qgtc_expand_job *jobs, int n_jobs, void *stream) {
         if (!j.W || !j.codes || j.K <= 0 || j.N <= 0 || j.N > 128 || j.nbits < 1 || j.nbits > 4 || j.w_lines < j.N || (j.order != 0 && j.order != 1)) return QGTC_EINVAL;
         if ((j.order == 0 && j.K > 8192) || (j.order == 1 && j.K > 128)) return QGTC_EINVAL;
         if (!aligned16(j.codes)) return QGTC_EALIGN;
+        if (j.codes_words < qgtc_weight_codes_words(j.K, j.N, j.nbits, j.order)) return QGTC_ESIZE;   // (ABI 11: the capacity travels with the job)
     }
     return qgtc_launch_expand_weights(jobs, n_jobs, static_cast<hipStream_t>(stream));
 }
@@ -404,10 +407,10 @@ int qgtc_chain_transform(const qgtc_problem *stage, int count, int max_M, int K,
     if (!aligned16(w_codes)) return QGTC_EALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (flags & QGTC_CHECK_DESCRIPTORS) {
-        const int crc = qgtc_launch_check_descriptors(stage, nullptr, count, max_M, K, N, 0, 0, 0, st, N, 0);
+        const int crc = qgtc_launch_check_descriptors(stage, nullptr, count, max_M, K, N, 0, 0, 0, st, N, 0, K);   // (every descriptor's K == the K of the weight tables)
         if (crc != QGTC_OK) return crc;
     }
-    return qgtc_launch_rbw_xw(stage, count, max_M, N, x_bits, out_bits, w_codes, st);
+    return qgtc_launch_rbw_xw(stage, count, max_M, K, N, x_bits, out_bits, w_codes, st);
 }
 
 int qgtc_chain_aggregate(const qgtc_problem *stage_a, const qgtc_problem *stage_xw, int count, int max_M, int max_K, int N1,

@@ -997,9 +997,11 @@ struct EpochPlan {
                 const auto &e = expand[i];
                 TORCH_CHECK(e[0] >= 0 && e[0] < nw, "bad weight index");
                 const torch::Tensor &w = weights[e[0]];
-                torch::Tensor codes = torch::empty({static_cast<int64_t>(qgtc_weight_codes_words(e[2], e[3]) * (e[4] == 0 ? (e[1] + 127) / 128 : 1))}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
+                const int64_t cap = static_cast<int64_t>(qgtc_weight_codes_words(e[1], e[2], e[3], e[4]));
+                TORCH_CHECK(cap > 0, "EpochPlan.bind: bad pre-expanded weight (K, N, bits, order)");
+                torch::Tensor codes = torch::empty({cap}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
                 jobs[i] = qgtc_expand_job{words(w), words_mut(codes), static_cast<uint64_t>(w.numel()), e[1], e[2], e[3],
-                                          static_cast<int32_t>(w.numel() / (static_cast<int64_t>(e[3]) * S128(e[1]) * 4)), e[4], 0};
+                                          static_cast<int32_t>(w.numel() / (static_cast<int64_t>(e[3]) * S128(e[1]) * 4)), e[4], static_cast<uint32_t>(cap)};
                 weight_codes.push_back(codes);
             }
             check_rc(qgtc_expand_weights(jobs, static_cast<int>(expand.size()), current_stream(batches)), "EpochPlan.bind (weights)");

@@ -13,13 +13,16 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: str | None = None):
+def init_from_env(backend: str | None = None, force_group: bool = False):
     """Initialise torch.distributed from RANK/WORLD_SIZE/LOCAL_RANK/MASTER_* (torchrun). Returns
-    (rank, world_size, local_rank); a single process needs no process group."""
+    (rank, world_size, local_rank). A single process needs no process group and gets none - unless `force_group`
+    (or QGTC_FORCE_COLLECTIVES=1) asks for one: with a group alive every gather / reduce below runs its real collective
+    even at world size 1, which is how the RCCL path is exercised on a one-GPU box (tests/test_aa_rccl_world1.py)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    force_group = force_group or os.environ.get("QGTC_FORCE_COLLECTIVES", "0") not in ("", "0")
+    if (world > 1 or force_group) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -28,6 +31,22 @@ def init_from_env(backend: str | None = None):
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def collectives_live(world: int) -> bool:
+    """The exchange functions below skip their collective only when there is nobody to talk to AND no process group: a
+    group that was set up at world size 1 (force_group) still gets the real call."""
+    return world > 1 or dist.is_initialized()
+
+
+def world_size() -> int:
+    """Ranks the process group actually has (1 without a group): bench.py prints it as `ranks_seen`."""
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def shard_round_robin(n_batches: int, rank: int, world: int):
@@ -43,7 +62,7 @@ def gather_batch_summaries(local: torch.Tensor, n_batches: int, rank: int, world
     """End-of-epoch gather. `local` is [n_local, D] (one row of D summary values — checksum, shape,
     timing — per batch this rank owns, in shard order). Returns [n_batches, D] on every rank, rows
     in global batch order. One all_gather on buffers padded to the largest shard."""
-    if world == 1:
+    if not collectives_live(world):
         return local
     if local.is_cuda and dist.get_backend() == "gloo":
         # (two ranks sharing one GPU in the tests: RCCL refuses duplicate devices, gloo gathers host buffers)
@@ -61,7 +80,7 @@ def gather_batch_summaries(local: torch.Tensor, n_batches: int, rank: int, world
 
 def gather_replica_summaries(local: torch.Tensor, world: int) -> torch.Tensor:
     """Weak scaling (every rank ran ALL its own batches): [n, D] per rank -> [world * n, D], rank-major, on every rank."""
-    if world == 1:
+    if not collectives_live(world):
         return local
     if local.is_cuda and dist.get_backend() == "gloo":
         return gather_replica_summaries(local.cpu(), world).to(local.device)
@@ -70,22 +89,27 @@ def gather_replica_summaries(local: torch.Tensor, world: int) -> torch.Tensor:
     return out
 
 
-def gather_batch_outputs(outs, n_batches: int, rank: int, world: int, replicas: bool = False):
+def gather_batch_outputs(outs, n_batches: int, rank: int, world: int, replicas: bool = False, device=None, classes: int | None = None):
     """SURVEY.md 8e's exchange with the REAL payload: the per-batch float32 outputs of an epoch ([n_i, C] each), gathered
     to every rank with one all_gather_into_tensor on buffers padded to the largest batch (and, sharded, to the largest
     shard), plus the node counts (one more small all_gather: the batches are ragged).
     Sharded (replicas False): rank r holds batches r, r + world, ..; returns ([n_batches, max_n, C], nodes[n_batches]) in
-    global batch order. Replicas (weak scaling): every rank holds n_batches of its own; returns [world * n_batches, ..]."""
-    dev = outs[0].device if outs else torch.device("cpu")
-    C = outs[0].size(1) if outs else 1
+    global batch order. Replicas (weak scaling): every rank holds n_batches of its own; returns [world * n_batches, ..].
+    `device` / `classes`: where the buffers live and the outputs' column count - pass them whenever a rank may own NO batch
+    (fewer batches than ranks): such a rank must still enter the collectives with a zero buffer of the common shape and
+    placement (a rank that guessed cpu / 1 column would hang RCCL)."""
+    dev = torch.device(device) if device is not None else (outs[0].device if outs else torch.device("cpu"))
+    C = int(classes) if classes is not None else (outs[0].size(1) if outs else 1)
+    assert all(o.size(1) == C for o in outs), "every batch output must have `classes` columns"
     if dist.is_initialized() and dev.type == "cuda" and dist.get_backend() == "gloo":
-        g, nodes = gather_batch_outputs([o.cpu() for o in outs], n_batches, rank, world, replicas)
-        return g.to(dev), nodes
+        g, nodes = gather_batch_outputs([o.cpu() for o in outs], n_batches, rank, world, replicas, torch.device("cpu"), C)
+        return g.to(dev), nodes.to(dev)
+    live = collectives_live(world)
     per = n_batches if replicas else (n_batches + world - 1) // world
     local_n = torch.zeros(per, dtype=torch.int64, device=dev)
     if outs:
         local_n[: len(outs)] = torch.tensor([o.size(0) for o in outs], dtype=torch.int64, device=dev)
-    if world == 1:
+    if not live:
         all_n = local_n.view(1, per)
     else:
         all_n = torch.empty((world, per), dtype=torch.int64, device=dev)
@@ -94,7 +118,7 @@ def gather_batch_outputs(outs, n_batches: int, rank: int, world: int, replicas: 
     buf = torch.zeros((per, max_n, C), dtype=torch.float32, device=dev)
     for i, o in enumerate(outs):
         buf[i, : o.size(0)] = o
-    if world == 1:
+    if not live:
         allbuf = buf.view(1, per, max_n, C)
     else:
         allbuf = torch.empty((world, per, max_n, C), dtype=torch.float32, device=dev)

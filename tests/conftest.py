@@ -13,9 +13,9 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    """tests/test_aa_two_ranks_one_gpu.py starts its rank processes before this process initialises the GPU: keep it
+    """tests/test_aa_*.py start child processes (ranks, a world-1 RCCL group) before this process initialises the GPU: keep them
     ahead of every other test whatever the collection order."""
-    items.sort(key=lambda it: 0 if "test_aa_two_ranks_one_gpu" in it.nodeid else 1)
+    items.sort(key=lambda it: 0 if "test_aa_" in it.nodeid else 1)
 
 
 @pytest.fixture(scope="session")

@@ -360,7 +360,7 @@ def test_epoch_plan_filled_on_the_device_with_raw_pointers(lib, oracle):
 
 class QgtcExpandJob(ctypes.Structure):
     _fields_ = [("W", ctypes.c_void_p), ("codes", ctypes.c_void_p), ("w_words", ctypes.c_uint64), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
-                ("nbits", ctypes.c_int32), ("w_lines", ctypes.c_int32), ("order", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("nbits", ctypes.c_int32), ("w_lines", ctypes.c_int32), ("order", ctypes.c_int32), ("codes_words", ctypes.c_uint32)]
 
 
 @pytest.mark.parametrize("M,K,F,H,C,bitmaps", [(333, 333, 48, 128, 10, True), (150, 150, 128, 64, 128, False), (300, 150, 32, 100, 33, True), (200, 200, 602, 128, 41, True), (70, 70, 3703, 33, 7, False), (120, 120, 300, 70, 90, True),
@@ -383,10 +383,10 @@ def test_chain_entries_with_raw_descriptors(lib, oracle, M, K, F, H, C, bitmaps,
     P128 = lambda x: (x + 127) // 128 * 128   # noqa: E731
     W1, W2 = oracle.pack(rand_q(rng, F, H, b), b, True), oracle.pack(rand_q(rng, H, C, b), b, True)
     dW1, dW2 = torch.from_numpy(W1.view(np.int32)).cuda(), torch.from_numpy(W2.view(np.int32)).cuda()
-    c1 = torch.full((int(lib.qgtc_weight_codes_words(H, b)) * ((F + 127) // 128),), -1, dtype=torch.int32, device="cuda")   # (a table per k-quad of F)
-    c2 = torch.full((int(lib.qgtc_weight_codes_words(C, b)),), -1, dtype=torch.int32, device="cuda")
-    jobs = (QgtcExpandJob * 2)(QgtcExpandJob(dW1.data_ptr(), c1.data_ptr(), dW1.numel(), F, H, b, P128(H), 0, 0),
-                               QgtcExpandJob(dW2.data_ptr(), c2.data_ptr(), dW2.numel(), H, C, b, P128(C), 1, 0))
+    c1 = torch.full((int(lib.qgtc_weight_codes_words(F, H, b, 0)),), -1, dtype=torch.int32, device="cuda")   # (a table per k-quad of F)
+    c2 = torch.full((int(lib.qgtc_weight_codes_words(H, C, b, 1)),), -1, dtype=torch.int32, device="cuda")
+    jobs = (QgtcExpandJob * 2)(QgtcExpandJob(dW1.data_ptr(), c1.data_ptr(), dW1.numel(), F, H, b, P128(H), 0, c1.numel()),
+                               QgtcExpandJob(dW2.data_ptr(), c2.data_ptr(), dW2.numel(), H, C, b, P128(C), 1, c2.numel()))
     assert lib.qgtc_expand_weights(ctypes.addressof(jobs), 2, st) == 0
     count = 3
     keep, s_x, s_a, s_xw, s_a2, s_f, want = [dW1, dW2, c1, c2], [], [], [], [], [], []
@@ -449,6 +449,24 @@ def test_chain_entries_with_raw_descriptors(lib, oracle, M, K, F, H, C, bitmaps,
     assert lib.qgtc_chain_aggregate(d(1), d(2), count, M, K, 129, C, b, b, b, 1, c2.data_ptr(), 0, st) == 1
     assert lib.qgtc_chain_aggregate(d(1), None, count, M, K, H, C, b, b, b, 1, c2.data_ptr(), 0, st) == 1
     assert lib.qgtc_expand_weights(ctypes.addressof(jobs), 9, st) == 1
+    # ADVICE r4 / ABI 11: the capacity of `codes` travels with the job - a table sized for ONE k-quad (what ABI 10's two-argument size
+    # helper returned) is QGTC_ESIZE for a K of several, never a device write past the buffer
+    one_kq = int(lib.qgtc_weight_codes_words(128, H, b, 0))
+    assert int(lib.qgtc_weight_codes_words(F, H, b, 0)) == one_kq * ((F + 127) // 128) and int(lib.qgtc_weight_codes_words(F, H, b, 1)) == one_kq
+    small = (QgtcExpandJob * 1)(QgtcExpandJob(dW1.data_ptr(), c1.data_ptr(), dW1.numel(), F, H, b, P128(H), 0, one_kq - 1))
+    assert lib.qgtc_expand_weights(ctypes.addressof(small), 1, st) == 2, "QGTC_ESIZE"
+    if F > 128:
+        small[0].codes_words = one_kq
+        assert lib.qgtc_expand_weights(ctypes.addressof(small), 1, st) == 2
+        # a descriptor whose K names more k-quads than the tables hold: the kernel's loop bound is the HOST's K (no read past w_codes),
+        # and QGTC_CHECK_DESCRIPTORS reports the mismatch
+        rc = lib.qgtc_chain_transform(d(0), count, K, 128, H, b, b, c1.data_ptr(), 0, st)
+        assert rc == 0, lib.qgtc_strerror(rc)
+        torch.cuda.synchronize()
+        assert lib.qgtc_chain_transform(d(0), count, K, 128, H, b, b, c1.data_ptr(), CHECK, st) == 0     # (the check is asynchronous: its record says)
+        prob, field = ctypes.c_int(-2), ctypes.c_int(-2)
+        assert lib.qgtc_last_batched_violation(ctypes.byref(prob), ctypes.byref(field), st) == 1      # QGTC_EINVAL: a violation is on record
+        assert prob.value == 0 and field.value == 2, (prob.value, field.value)     # QGTC_VIOL_K of problem 0
 
 
 @pytest.mark.parametrize("M,F,H,C,bitmaps", [(599, 50, 64, 10, True), (333, 64, 33, 64, False), (40, 7, 5, 3, True), (333, 100, 128, 70, True)])
@@ -469,10 +487,10 @@ def test_chain_entries_at_four_bits(lib, oracle, M, F, H, C, bitmaps):
     P128, P8 = (lambda x: (x + 127) // 128 * 128), (lambda x: (x + 7) // 8 * 8)   # noqa: E731
     W1, W2 = oracle.pack(rand_q(rng, F, H, b), b, True), oracle.pack(rand_q(rng, H, C, b), b, True, True)
     dW1, dW2 = torch.from_numpy(W1.view(np.int32)).cuda(), torch.from_numpy(W2.view(np.int32)).cuda()
-    c1 = torch.full((int(lib.qgtc_weight_codes_words(H, b)),), -1, dtype=torch.int32, device="cuda")
-    c2 = torch.full((int(lib.qgtc_weight_codes_words(C, b)),), -1, dtype=torch.int32, device="cuda")
-    jobs = (QgtcExpandJob * 2)(QgtcExpandJob(dW1.data_ptr(), c1.data_ptr(), dW1.numel(), F, H, b, P128(H), 1, 0),
-                               QgtcExpandJob(dW2.data_ptr(), c2.data_ptr(), dW2.numel(), H, C, b, P8(C), 1, 0))
+    c1 = torch.full((int(lib.qgtc_weight_codes_words(F, H, b, 1)),), -1, dtype=torch.int32, device="cuda")
+    c2 = torch.full((int(lib.qgtc_weight_codes_words(H, C, b, 1)),), -1, dtype=torch.int32, device="cuda")
+    jobs = (QgtcExpandJob * 2)(QgtcExpandJob(dW1.data_ptr(), c1.data_ptr(), dW1.numel(), F, H, b, P128(H), 1, c1.numel()),
+                               QgtcExpandJob(dW2.data_ptr(), c2.data_ptr(), dW2.numel(), H, C, b, P8(C), 1, c2.numel()))
     assert lib.qgtc_expand_weights(ctypes.addressof(jobs), 2, st) == 0
     count = 3
     keep, s0, s1, s2, s3, want = [], [], [], [], [], []
@@ -563,10 +581,10 @@ def test_chain_entries_random_sweep(lib, oracle, seed):
     density = float(rng.choice([0.0, 0.01, 0.05, 0.5, 1.0]))
     W1, W2 = oracle.pack(rand_q(rng, F, H, b), b, True), oracle.pack(rand_q(rng, H, C, b), b, True)
     dW1, dW2 = torch.from_numpy(W1.view(np.int32)).cuda(), torch.from_numpy(W2.view(np.int32)).cuda()
-    c1 = torch.full((int(lib.qgtc_weight_codes_words(H, b)) * ((F + 127) // 128),), -1, dtype=torch.int32, device="cuda")
-    c2 = torch.full((int(lib.qgtc_weight_codes_words(C, b)),), -1, dtype=torch.int32, device="cuda")
-    jobs = (QgtcExpandJob * 2)(QgtcExpandJob(dW1.data_ptr(), c1.data_ptr(), dW1.numel(), min(F, 128) if not use_xw else F, H, b, P128(H), 0 if use_xw else 1, 0),
-                               QgtcExpandJob(dW2.data_ptr(), c2.data_ptr(), dW2.numel(), H, C, b, P128(C), 1, 0))
+    c1 = torch.full((int(lib.qgtc_weight_codes_words(F, H, b, 0)),), -1, dtype=torch.int32, device="cuda")
+    c2 = torch.full((int(lib.qgtc_weight_codes_words(H, C, b, 1)),), -1, dtype=torch.int32, device="cuda")
+    jobs = (QgtcExpandJob * 2)(QgtcExpandJob(dW1.data_ptr(), c1.data_ptr(), dW1.numel(), min(F, 128) if not use_xw else F, H, b, P128(H), 0 if use_xw else 1, c1.numel()),
+                               QgtcExpandJob(dW2.data_ptr(), c2.data_ptr(), dW2.numel(), H, C, b, P128(C), 1, c2.numel()))
     assert lib.qgtc_expand_weights(ctypes.addressof(jobs), 2, st) == 0
     keep, sx, sa, sw, sf, want, ms, ks = [], [], [], [], [], [], [], []
     for i in range(count):

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_errors(lib):
-    assert lib.qgtc_abi_version() == 10
+    assert lib.qgtc_abi_version() == 11
     assert lib.qgtc_strerror(0) == b"ok"
     for code in range(1, 6):
         assert lib.qgtc_strerror(code) not in (b"ok", b"unknown error")
@@ -116,8 +116,10 @@ def test_epoch_pool_layout_is_host_side(lib, oracle):
     assert [lib.qgtc_chain_words(n, 100) for n in ns] == [(n + 127) // 128 * 128 * 16 for n in ns]
     lib.qgtc_adj_tiles_words.restype = ctypes.c_size_t                     # 512-byte tiles: [32-row block][k-quad][32 rows][4 words]
     assert lib.qgtc_adj_tiles_words(1213, 1213) == 38 * 10 * 128 and lib.qgtc_adj_tiles_words(1, 129) == 2 * 128 and lib.qgtc_adj_tiles_words(0, 5) == 0
-    assert lib.qgtc_weight_codes_words(100, 2) == 4 * 2 * 64 * 4 and lib.qgtc_weight_codes_words(50, 4) == 2 * 2 * 2 * 64 * 4
-    assert lib.qgtc_weight_codes_words(70, 3) == 4 * 2 * 2 * 64 * 4      # three column blocks are kept as four (the fourth: zero codes)
+    assert lib.qgtc_weight_codes_words(128, 100, 2, 1) == 4 * 2 * 64 * 4 and lib.qgtc_weight_codes_words(64, 50, 4, 1) == 2 * 2 * 2 * 64 * 4
+    assert lib.qgtc_weight_codes_words(128, 70, 3, 0) == 4 * 2 * 2 * 64 * 4      # three column blocks are kept as four (the fourth: zero codes)
+    assert lib.qgtc_weight_codes_words(602, 128, 2, 0) == 5 * 4 * 2 * 64 * 4     # order 0: a table per k-quad of K (ABI 11)
+    assert lib.qgtc_weight_codes_words(602, 128, 2, 1) == 4 * 2 * 64 * 4 and lib.qgtc_weight_codes_words(0, 128, 2, 0) == 0
     assert total == sum(sizes)
     assert list(offs) == [sum(sizes[:i]) for i in range(len(sizes))]
     assert lib.qgtc_epoch_pool_layout(None, 3, ctypes.addressof(stages), 3, None) == 0

@@ -151,41 +151,85 @@ def test_zerotile_row_from_the_driver_log(qgtc, capfd):
     assert 0.0 < row["per_epoch_ratio"] < 1.0
 
 
-@pytest.mark.parametrize("dataset,bits,hidden,gin", [("ogbn-arxiv", 2, 128, False), ("ppi", 4, 64, True)])
-def test_full_size_epoch_matches_oracle_and_per_batch_launches(qgtc, oracle, dataset, bits, hidden, gin):
-    """BASELINE.json configs 3 / 4 at the size bench.py times: the ogbn-arxiv-sized graph (75 cluster batches of ~1213
-    nodes, F = H = 128, 2-bit, Cluster-GCN) and the ppi-sized one (75 x ~599, F = 50, H = 64, 4-bit, Batched-GIN),
-    layout-correct chain, grouped launches on the default engine. Three batches are checked against the oracle's
-    chain (every one of the six operators' final float output), all 75 against the per-batch launches."""
-    import torch
+def _full_size(dataset, bits, hidden, gin, chain, psize=1500, bs=20):
     from qgtc_ppopp22_amd import driver, graph as G
 
-    psize, bs = 1500, 20
     base = ["--dataset", dataset, "--psize", str(psize), "--batch-size", str(bs), "--n-hidden", str(hidden),
-            "--n-classes", "10", "--bit_width", str(bits), "--n-epochs", "1", "--use_QGTC", "--quiet", "--chain", "correct"]
+            "--n-classes", "10", "--bit_width", str(bits), "--n-epochs", "1", "--use_QGTC", "--quiet", "--chain", chain]
     if gin:
         base.append("--run_GIN")
     graph = G.make_graph(dataset, psize)
-    grouped = driver.run(driver.build_parser().parse_args(base + ["--batched"]), Q=qgtc, graph=graph)
-    assert qgtc.get_engine() == "auto"
-    per_batch = driver.run(driver.build_parser().parse_args(base), Q=qgtc, graph=graph)
-    assert len(grouped["outs"]) == len(per_batch["outs"]) == psize // bs == 75
-    for i, (x, y) in enumerate(zip(grouped["outs"], per_batch["outs"])):
-        assert torch.equal(x, y), f"batch {i}"
     random.seed(2)
     par = G.partition_list(graph, psize)
     random.shuffle(par)
+    return driver, base, graph, par
+
+
+@pytest.mark.parametrize("chain", ["correct", "reference"])
+@pytest.mark.parametrize("dataset,bits,hidden,gin", [("ogbn-arxiv", 2, 128, False), ("ppi", 4, 64, True)])
+def test_full_size_epoch_matches_oracle_on_every_batch(qgtc, oracle, dataset, bits, hidden, gin, chain):
+    """BASELINE.json configs 2 / 3 at the size bench.py times: the ogbn-arxiv-sized graph (75 cluster batches of ~1213 nodes,
+    F = H = 128, 2-bit, Cluster-GCN) and the ppi-sized one (75 x ~599, F = 50, H = 64, 4-bit, Batched-GIN), grouped launches
+    on the default engine. ALL 75 batches against the oracle's chain - the layout-correct chain AND the reference's literal
+    one (main_qgtc.py:147-154 / :131-138 as an unchanged driver issues them: mis-laid operands, over-reads included) - and
+    against the per-batch launches (three batches were checked, the rest only HIP against HIP)."""
+    import torch
+
+    driver, base, graph, par = _full_size(dataset, bits, hidden, gin, chain)
+    grouped = driver.run(driver.build_parser().parse_args(base + ["--batched"]), Q=qgtc, graph=graph)
+    assert qgtc.get_engine() == "auto"
+    per_batch = driver.run(driver.build_parser().parse_args(base), Q=qgtc, graph=graph)
+    assert len(grouped["outs"]) == len(per_batch["outs"]) == 75
     W = oracle_weights(oracle, graph.feat.shape[1], hidden, 10, bits)
     sizes = []
-    for cid in (0, 37, 74):
-        bi = oracle_batch_inputs(oracle, graph, par, cid, psize, bs, bits)
+    for cid in range(75):
+        bi = oracle_batch_inputs(oracle, graph, par, cid, 1500, 20, bits)
         sizes.append(bi["n"])
         ct = grouped["iter"].cTensor_li[cid]
-        np.testing.assert_array_equal(to_np_u32(ct.bit_A), bi["bit_A"])
-        expect = oracle_chain(oracle, bi, W, bits, "correct", gin)[-1]
-        np.testing.assert_array_equal(grouped["outs"][cid].cpu().numpy(), expect, err_msg=f"batch {cid}")
-        assert grouped["outs"][cid].abs().sum().item() > 0
+        np.testing.assert_array_equal(to_np_u32(ct.bit_A), bi["bit_A"], err_msg=f"A of batch {cid}")
+        np.testing.assert_array_equal(to_np_u32(ct.bit_X), bi["bit_X"], err_msg=f"X of batch {cid}")
+        expect = oracle_chain(oracle, bi, W, bits, chain, gin)[-1]
+        np.testing.assert_array_equal(grouped["outs"][cid].cpu().numpy(), expect, err_msg=f"grouped, batch {cid}")
+        np.testing.assert_array_equal(per_batch["outs"][cid].cpu().numpy(), expect, err_msg=f"per batch, batch {cid}")
+        if chain == "correct":
+            assert grouped["outs"][cid].abs().sum().item() > 0
     assert min(sizes) > (1100 if dataset == "ogbn-arxiv" else 500)
+
+
+@pytest.mark.parametrize("dataset,nodes_per_batch", [("ogbn-products", 2500), ("Proteins", 500)])
+def test_other_datasets_of_the_reference_scripts_at_their_sizes(qgtc, oracle, dataset, nodes_per_batch):
+    """The other graphs the reference's scripts run (0_7a_eval_QGTC_cluster_GCN.py:12-16,41; 4_8_zero_tile_jumping.py:34) at
+    their sizes: ogbn-products-sized cluster batches have n ~ 2.6 k nodes (K > 2048: more than 16 k-quads per row block - the
+    loader's one-row-at-a-time path, longer occupancy words), Proteins-sized ones ~580 nodes and 29 features. Grouped,
+    layout-correct 2-bit Cluster-GCN epoch, hidden 128: three batches against the oracle's chain, all of them against the
+    per-batch launches; and the zero-tile counters of the first batch against the oracle's tile census."""
+    import torch
+
+    bits, hidden = 2, 128
+    driver, base, graph, par = _full_size(dataset, bits, hidden, False, "correct")
+    grouped = driver.run(driver.build_parser().parse_args(base + ["--batched"]), Q=qgtc, graph=graph)
+    per_batch = driver.run(driver.build_parser().parse_args(base), Q=qgtc, graph=graph)
+    assert len(grouped["outs"]) == 75 and all(torch.equal(x, y) for x, y in zip(grouped["outs"], per_batch["outs"]))
+    W = oracle_weights(oracle, graph.feat.shape[1], hidden, 10, bits)
+    for cid in (0, 37, 74):
+        bi = oracle_batch_inputs(oracle, graph, par, cid, 1500, 20, bits)
+        assert bi["n"] > nodes_per_batch
+        ct = grouped["iter"].cTensor_li[cid]
+        np.testing.assert_array_equal(to_np_u32(ct.bit_A), bi["bit_A"])
+        np.testing.assert_array_equal(to_np_u32(ct.bit_X), bi["bit_X"])
+        np.testing.assert_array_equal(grouped["outs"][cid].cpu().numpy(), oracle_chain(oracle, bi, W, bits, "correct", False)[-1], err_msg=f"batch {cid}")
+    # `--zerotile_jump` (main_qgtc.py:142-145) on the first batch: printed counters = the oracle's census of 8-row x 128-bit tile steps
+    bi = oracle_batch_inputs(oracle, graph, par, 0, 1500, 20, bits)
+    n = bi["n"]
+    total, nonzero = oracle.tile_counters(bi["bit_A"], n, n, hidden, 1, bits)
+    ct = grouped["iter"].cTensor_li[0]
+    Wd = driver.pack_weights(qgtc, graph.feat.shape[1], hidden, 10, bits, torch.device("cuda"))
+    t0 = qgtc.bitMM2Bit(ct.bit_X, Wd["W1"], n, graph.feat.shape[1], hidden, bits, bits, bits)
+    qgtc.reset_counters()
+    qgtc.bitMM2Bit_base_cnt(ct.bit_A, t0, n, n, hidden, 1, bits, bits)
+    qgtc.bitMM2Bit_zerojump_cnt(ct.bit_A, t0, n, n, hidden, 1, bits, bits)
+    assert tuple(qgtc.get_counters()) == (total, nonzero) and 0 < nonzero < total
+    qgtc.reset_counters()
 
 
 @pytest.mark.parametrize("gin", [False, True, 2])

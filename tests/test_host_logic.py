@@ -260,6 +260,8 @@ def test_bench_dry_run_world8_gathers_75_ragged_batches():
     assert ex["replica_output_first_values"] == [float(100 * r + j) for r in range(8) for j in range(3)]   # rank-major
     assert ex["replica_summaries"] == [[float(r), float(j)] for r in range(8) for j in range(3)]
     assert ex["rank_checksums"] == [1000.0 + r for r in range(8)]
+    # ONE batch over eight ranks - seven ranks own nothing and still enter the collectives with the common shape
+    assert ex["one_batch_shape"] == [1, 1190, 10] and ex["one_batch_nodes"] == [1190] and line["ranks_seen"] == 8
 
 
 def test_bench_fails_loudly_on_a_rank_count_mismatch():
@@ -274,12 +276,88 @@ def test_bench_parent_fails_when_a_rank_fails():
     assert out.returncode != 0
 
 
-def test_bench_issue_auto_builds_graphs_only_for_slow_hosts():
-    """bench.py --issue auto: a host that issues the 20 steps of the driver's run at 3.6-3.8 us per step stays eager without ever
-    capturing a graph (a replay takes 3.97-4.05 there); one at 4.3+ gets both ways compared; long regions need a replay to beat 3.15."""
+def _worst_case_line():
+    """bench.py's line assembled from the same functions main() uses, with every optional block present and wide values."""
+    import argparse
+
+    import bench
+    from benchmarks import epochs, headline
+
+    args = argparse.Namespace(steps=100000, warmup=1000, engine="popcount", issue="eager", streams=1)
+    rf = headline.roofline_block(4096, 4096, 64, 1, 3.123456e-6, 3.654321e-6, True)
+    rf.update({"traffic": 123456789, "traffic_source": "profiles/r05/summary_headline.json (pmc, sources 0123456789ab)",
+               "rocprof": {"file": "profiles/r05/kernel_stats_headline.csv", "avg_us": 3594.681, "min_us": 2640.123}})
+    ep = {"batched_correct_chain_ms": 0.0226123, "per_batch_reference_chain_ms": 1.8511123,
+          "roofline_of_the_grouped_correct_chain": {
+              "kernel_us_per_epoch": 17.87123, "launches_per_epoch": 4, "algorithmic_bytes_per_epoch": 72270000123,
+              "loader_us_per_iterator_hip_events": 145.123, "host_weight_pack_and_plan_bind_ms": 0.04123,
+              "roofline": {"traffic": 43800000123, "frac": 0.50512, "frac_on_traffic": 0.30612}}}
+    rf.update(epochs.flat_epoch_scalars("gcn", ep))
+    rf.update(epochs.flat_epoch_scalars("gin", ep))
+    line = bench.compose_line(args, 8, 8, 4096, 4096, 64, 1, 12345.678, 0.123456, True, rf)
+    line["cpu_baseline"] = {"value": 0.9312, "unit": "TOPS", "cores": 256, "kind": "port",
+                            "sample": "full 4096x4096x64 1-bit call, 3 x 400 reps (10 s), median; OpenMP C oracle, 32 of 256 threads",
+                            "dgl_style_fp32_epoch_ms": 12345.67, "dgl_cores": 128,
+                            "dgl_sample": "ogbn-arxiv-sized graph, 15 of 75 batches x5; torch-CPU GraphSAGE-sum x3"}
+    line["parity_vs_oracle"] = True
+    line["rccl_world1"] = {"ok": True, "backend": "nccl", "ranks_seen": 1, "gather_outputs_ms": 123.45}
+    line["extras_file"] = "gpurun_out/bench_extras.json"
+    return line
+
+
+def test_bench_line_stays_small_and_machine_readable():
+    """the driver could not parse a 25 KB line. The printed line carries the contract's fields + roofline (with both
+    epochs as flat scalars) + cpu_baseline (with the DGL-style epoch inside) in under 4096 bytes, strictly JSON, no prose."""
+    import json
+
     import bench
 
-    assert not bench.replay_worth_probing(3.64, 20) and not bench.replay_worth_probing(3.85, 20)
-    assert bench.replay_worth_probing(4.33, 20) and bench.replay_worth_probing(6.5, 20)
-    assert not bench.replay_worth_probing(3.03, 200) and bench.replay_worth_probing(3.4, 200)
-    assert not bench.replay_worth_probing(3.0, 1000)
+    line = bench.shrink(_worst_case_line())
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_LIMIT, len(text)
+    back = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in back, k
+    assert set(back["config"]) == {"workload", "inputs", "parallelism", "engine", "issue"} and back["config"]["issue"] == "eager"
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch",
+              "avg_launch_us", "rocprof", "epoch_gcn_ms", "epoch_gcn_kernel_us", "epoch_gcn_frac", "epoch_gin_ms", "epoch_gin_kernel_us"):
+        assert k in back["roofline"], k
+    assert back["roofline"]["frac"] == pytest.approx(back["roofline"]["achieved"] / back["roofline"]["peak"], rel=1e-3)
+    assert {"value", "unit", "cores", "kind", "sample", "dgl_style_fp32_epoch_ms", "dgl_cores"} <= set(back["cpu_baseline"])
+    assert all(len(v) < 120 for v in back["config"].values())
+    # a line that would not fit loses optional keys, never the contract's
+    fat = _worst_case_line()
+    fat["rccl_world1"]["pad"] = "x" * 5000
+    slim = bench.shrink(fat)
+    assert len(json.dumps(slim)) < bench.LINE_LIMIT and "rccl_world1" not in slim and "roofline" in slim and "cpu_baseline" in slim
+
+
+def test_bench_default_issue_is_the_references_loop():
+    """QGTC_device.cu:407-418 issues its launches eagerly; so does bench.py unless told otherwise (no probing, no best-of-two)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.argv=['bench.py']; import bench; a = bench.parse(); print(a.issue, a.gpus, a.engine)"
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+    assert out.stdout.split() == ["eager", "1", "auto"], out.stderr[-500:]
+
+
+def test_quiet_fd1_keeps_c_printf_off_stdout():
+    """The counter operators print with C printf (qgtc_torch.cpp, as kernel.h:19,27 do); a pipe-buffered printf surfaces at exit,
+    BEHIND the JSON line, unless file descriptor 1 itself is parked and C stdio flushed - what benchmarks.common.quiet_fd1 does."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import ctypes, sys; sys.path.insert(0, %r)\n"
+            "from benchmarks.common import quiet_fd1\n"
+            "libc = ctypes.CDLL(None)\n"
+            "print('first')\n"
+            "with quiet_fd1():\n"
+            "    libc.printf(b'counter_global: 7\\n'); print('python inside')\n"
+            "print('{\"last\": 1}')\n") % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert out.stdout.splitlines() == ["first", '{"last": 1}']

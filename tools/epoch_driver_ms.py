@@ -7,7 +7,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-import bench
+from benchmarks import epochs as bench
 import QGTC as Q
 
 only = ("batched_correct_chain", "batched_reference_chain")
