@@ -34,26 +34,20 @@ namespace {
 // (in-kernel stamps, tools/rbw_bench.hip). Size: step128(M) * pad128(N) * 16 words.
 // ------------------------------------------------------------------------------------------
 
-// lane (fl, fh) of the first product holds, per column block j, the values of columns 32 j + t + 8 gq + 4 fh in register
-// 4 gq + t. requant_pack16 puts them a byte each: P[t] byte 3 - gq. Two dwords per block: nibble 2 b + u of dword A (t = u)
-// and of dword B (t = 2 + u) is the value of byte b = 3 - gq. K index of the second product (MFMA m, half fh, dword d,
-// nibble i): column 32 (2 m + (d >> 1)) + (2 (d & 1) + (i & 1)) + 8 (3 - (i >> 1)) + 4 fh.
-__host__ __device__ constexpr int rbw_column(int m, int fh, int d, int i) {
-    return 32 * (2 * m + (d >> 1)) + (2 * (d & 1) + (i & 1)) + 8 * (3 - (i >> 1)) + 4 * fh;
-}
 
 // ------------------------------------------------------------------------------------------
 // Pre-expanded weights. order 0: the right operand of X . W where X arrives as packed words (K <= 128: one k-quad) - table
 // [column block jn][k half h][lane] of 16 bytes: the codes of word 2 fh + h of line 32 jn + fl (what strip_operand gives).
 // order 1: the right operand of (aggregate) . W' in the register order above - table [jn][m][lane]: dword d nibble i = the
 // value of W'[rbw_column(m, fh, d, i)][32 jn + fl]. One table per base-4 digit (planes 2 dg, 2 dg + 1) of the weight:
-// entry ((jn * 2 + s) * ND + dg) * 64 + lane, ND = ceil(nbits / 2) (1- and 2-bit weights: one digit; 4-bit: two).
+// entry ((jn * MS + s) * ND + dg) * 64 + lane, ND = ceil(nbits / 2) (1- and 2-bit weights: one digit; 4-bit: two; 8-bit: four),
+// MS = 2 (order 0: the halves of a k-quad; order 1 with K <= 128: the two MFMAs of 64 columns) or 4 (order 1, 128 < K <= 256).
 // ------------------------------------------------------------------------------------------
 struct ExpandJob {
     const uint32_t *W;
     uint32_t *codes;
     unsigned long long w_words;
-    int K, N, w_lines, nbits, order, ncb;
+    int K, N, w_lines, nbits, order, ncb, ms;
 };
 struct ExpandJobs {
     ExpandJob job[QGTC_MAX_WEIGHTS];
@@ -61,7 +55,7 @@ struct ExpandJobs {
 
 __global__ __launch_bounds__(64) void k_expand_weights(ExpandJobs jobs) {
     const ExpandJob j = jobs.job[blockIdx.y];
-    const int jn = static_cast<int>(blockIdx.x) >> 1, s = static_cast<int>(blockIdx.x) & 1;
+    const int jn = static_cast<int>(blockIdx.x) / j.ms, s = static_cast<int>(blockIdx.x) % j.ms;
     const int q = static_cast<int>(blockIdx.z);   // order 0 with K > 128: one table per k-quad of K, [k-quad][column block][k half][digit][lane]
     if (jn >= j.ncb || q >= (j.order == 0 ? step128(j.K) : 1)) return;
     const int lane = threadIdx.x, fl = lane & 31, fh = lane >> 5;
@@ -83,46 +77,42 @@ __global__ __launch_bounds__(64) void k_expand_weights(ExpandJobs jobs) {
                 else c = rbw_column(s, fh, d, i);
                 out[d] |= (bit(2 * dg, c) | (bit(2 * dg + 1, c) << 1)) << (4 * i);
             }
-        *reinterpret_cast<u32x4 *>(j.codes + (((static_cast<size_t>(q) * j.ncb * 2 + blockIdx.x) * nd + dg) * 64 + lane) * 4) = u32x4{out[0], out[1], out[2], out[3]};
+        *reinterpret_cast<u32x4 *>(j.codes + (((static_cast<size_t>(q) * j.ncb * j.ms + blockIdx.x) * nd + dg) * 64 + lane) * 4) = u32x4{out[0], out[1], out[2], out[3]};
     }
-}
-
-// An FP4 MFMA operand from its four dwords: the instruction takes a 256-bit register tuple but reads only the first 128
-// bits of an FP4 operand - the upper half is left UNDEFINED (zeros there cost four v_mov per operand, a third of this
-// kernel's VALU instructions in its first build)
-__device__ __forceinline__ i32x8 fp4_op(const u32x4 &v) {
-    const i32x4 t = __builtin_bit_cast(i32x4, v);
-    return __builtin_shufflevector(t, t, 0, 1, 2, 3, -1, -1, -1, -1);
-}
-__device__ __forceinline__ i32x8 fp4_op(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return fp4_op(u32x4{a, b, c, d}); }
-__device__ __forceinline__ i32x8 fp4_op(const i32x8 &v) { return __builtin_shufflevector(v, v, 0, 1, 2, 3, -1, -1, -1, -1); }
-__device__ __forceinline__ f32x16 f32x16_zero() {
-    f32x16 z;
-#pragma unroll
-    for (int r = 0; r < 16; r++) z[r] = 0.0f;
-    return z;
 }
 
 // A cols-layout operand (public format: [plane][line n][word], QGTC_device.cu:97) -> the chain format, for right operands
 // the DATA LOADER supplies (Batched-GIN's first product is A . X, main_qgtc.py:131, X packed by sampler.py:99): done once
 // beside the packing. One thread per (k-quad, word, line): nibble i of dword d = sum_p bit (d + 4 i) of plane p's word << p.
+// More than four planes (5 .. 8 bits, bitmm_fp4_rbx.hip.h): a second array of the same shape behind the first holds planes 4 .. 7.
+__device__ __forceinline__ u32x4 chain_nibbles(const uint32_t (&r)[4], int np) {
+    uint32_t out[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        if (p >= np) break;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t sh = d > p ? r[p] >> (d - p) : (d < p ? r[p] << (p - d) : r[p]);   // bits d + 4 i to bits p + 4 i
+            out[d] |= sh & (0x11111111u << p);
+        }
+    }
+    return u32x4{out[0], out[1], out[2], out[3]};
+}
 __global__ __launch_bounds__(256) void k_cols_to_chain(const uint32_t *__restrict__ cols, unsigned long long words, int H, int W, int nbits,
                                                        uint32_t *__restrict__ chain) {
     const int lines = pad128(W), line_words = step128(H) * 4;
     const size_t plane = static_cast<size_t>(lines) * line_words, total = static_cast<size_t>(line_words) * lines;
     for (size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += static_cast<size_t>(gridDim.x) * blockDim.x) {
         const int n = static_cast<int>(t % lines), wj = static_cast<int>(t / lines);   // wj = 4 q + j
-        uint32_t out[4] = {0u, 0u, 0u, 0u};
-        for (int p = 0; p < nbits && p < 4; p++) {
-            const size_t wi = p * plane + static_cast<size_t>(n) * line_words + wj;
-            const uint32_t r = (n < W && wi < words) ? cols[wi] : 0u;
+        for (int hv = 0; 4 * hv < nbits && hv < 2; hv++) {
+            uint32_t r[4];
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const uint32_t sh = d > p ? r >> (d - p) : (d < p ? r << (p - d) : r);   // bits d + 4 i to bits p + 4 i
-                out[d] |= sh & (0x11111111u << p);
+            for (int p = 0; p < 4; p++) {
+                const size_t wi = (4 * hv + p) * plane + static_cast<size_t>(n) * line_words + wj;
+                r[p] = (4 * hv + p < nbits && n < W && wi < words) ? cols[wi] : 0u;
             }
+            *reinterpret_cast<u32x4 *>(chain + (static_cast<size_t>(hv) * total + static_cast<size_t>(wj) * lines + n) * 4) = chain_nibbles(r, nbits - 4 * hv);
         }
-        *reinterpret_cast<u32x4 *>(chain + (static_cast<size_t>(wj) * lines + n) * 4) = u32x4{out[0], out[1], out[2], out[3]};
     }
 }
 
@@ -134,16 +124,12 @@ __global__ __launch_bounds__(256) void k_cols_to_chain_batched(const qgtc_loader
     const size_t plane = static_cast<size_t>(lines) * line_words, total = static_cast<size_t>(line_words) * lines;
     for (size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += static_cast<size_t>(gridDim.x) * blockDim.x) {
         const int n = static_cast<int>(t % lines), wj = static_cast<int>(t / lines);
-        uint32_t out[4] = {0u, 0u, 0u, 0u};
-        for (int p = 0; p < nbits && p < 4; p++) {
-            const uint32_t r = n < W ? b.X[p * plane + static_cast<size_t>(n) * line_words + wj] : 0u;
+        for (int hv = 0; 4 * hv < nbits && hv < 2; hv++) {
+            uint32_t r[4];
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const uint32_t sh = d > p ? r >> (d - p) : (d < p ? r << (p - d) : r);
-                out[d] |= sh & (0x11111111u << p);
-            }
+            for (int p = 0; p < 4; p++) r[p] = (4 * hv + p < nbits && n < W) ? b.X[(4 * hv + p) * plane + static_cast<size_t>(n) * line_words + wj] : 0u;
+            *reinterpret_cast<u32x4 *>(b.XC + (static_cast<size_t>(hv) * total + static_cast<size_t>(wj) * lines + n) * 4) = chain_nibbles(r, nbits - 4 * hv);
         }
-        *reinterpret_cast<u32x4 *>(b.XC + (static_cast<size_t>(wj) * lines + n) * 4) = u32x4{out[0], out[1], out[2], out[3]};
     }
 }
 
@@ -164,38 +150,6 @@ __global__ __launch_bounds__(256) void k_rows_to_tiles(const uint32_t *__restric
         if (32 * rb + r < pad8(M) && src + 4u <= words) v = *reinterpret_cast<const u32x4 *>(rows + src);
         *reinterpret_cast<u32x4 *>(tiles + t * 4u) = v;
     }
-}
-
-struct RbwShape {
-    int per;      // != 0: all workgroups of a batch on one XCD
-    int a;        // planes of the packed left operand (k_rbw_xw)
-    int tiles;    // k_rbw_chain: the adjacency is in the tile format of k_rows_to_tiles (else the rows layout)
-};
-
-// (gx, gy = the grid, handed over as kernel arguments: gridDim lives in the HIDDEN kernel arguments, which are not preloaded into
-// scalar registers with the wave - reading it was one more dependent scalar-load round trip ahead of the descriptor's)
-__device__ __forceinline__ void rbw_ids(int per, int gx, int gy, int &grp, int &batch) {
-    grp = static_cast<int>(blockIdx.x);
-    batch = static_cast<int>(blockIdx.y);
-    if (per) {
-        const int v = xcd_consecutive(batch * gx + grp, gx * gy);
-        batch = v / gx;
-        grp = v - batch * gx;
-    }
-}
-
-// every field of a descriptor in scalar registers NOW: left alone, the compiler loads M, tests the early exit and fetches the rest
-// behind the branch - two dependent round trips where one does
-__device__ __forceinline__ void rbw_pin(const qgtc_problem &pr) {
-    asm volatile("" ::"s"(pr.X), "s"(pr.W), "s"(pr.out), "s"(pr.x_words), "s"(pr.w_words), "s"(pr.K), "s"(pr.N), "s"(pr.occ), "s"(pr.occ_words));
-}
-
-// 16 re-quantised values (low OB bits of each byte of P) -> the two code dwords of a column block (see rbw_column)
-template <int OB>
-__device__ __forceinline__ void rbw_nibbles(const uint32_t (&P)[4], uint32_t &A, uint32_t &B) {
-    constexpr uint32_t mask = ((1u << OB) - 1u) * 0x01010101u;   // (the low OB bits of a byte are the value: requant_pack16)
-    A = (P[0] & mask) | ((P[1] & mask) << 4);
-    B = (P[2] & mask) | ((P[3] & mask) << 4);
 }
 
 // codes of word (rb & 3) of line n2 of T' from the 16 values a lane holds of column n2 (not swapped: rows t + 8 gq + 4 fh)
@@ -223,35 +177,6 @@ __device__ __forceinline__ void rbw_store_codes(const f32x16 &acc, uint32_t *__r
 #endif
 }
 
-
-// float32 rows from a swapped product's accumulators: lane (fl, fh) holds of ITS row the columns col0 + 8 g + 4 fh + t in register
-// 4 g + t. Four consecutive columns are ONE 16-byte store where they exist (rows of 4 N bytes are only 4-byte aligned - N = 10 classes;
-// buffer stores take any dword alignment), a row's tail is an 8- and / or a 4-byte store. The first form stored every element on its
-// own whenever N % 4 != 0: ten 4-byte store instructions a row for the 10-class output layer, 0.9 us of its 4.45 us launch
-// (timing-only build, tools/rbw_bench).
-// BRANCH-FREE per lane: a lane that has nothing to store (row past M, columns past N) gets the offset 0xffffffff and the range check
-// drops it; the only branches are on wave-uniform column counts. With a per-lane `if (m < M)` around the stores hipcc sank the second
-// product's LDS reads and MFMAs INTO the branch - and an MFMA takes its operands from ALL lanes: the rows past M then supplied garbage
-// as W' lines (wrong columns 32 jn + fl for every fl past the last valid row of the block).
-__device__ __forceinline__ void rbw_store_f32_row(__amdgpu_buffer_rsrc_t ro, uint32_t row_off /* bytes, 0xffffffff = no row */, const f32x16 &acc,
-                                                  int col0, int fh, int N) {
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const int rem0 = N - (col0 + 8 * g);        // wave-uniform: columns left from the half fh = 0's first one
-        if (rem0 <= 0) break;
-        const int rem = rem0 - 4 * fh;              // per lane
-        const uint32_t off = row_off == 0xffffffffu ? 0xffffffffu : row_off + static_cast<uint32_t>(col0 + 8 * g + 4 * fh) * 4u;
-        const u32x4 v = {__float_as_uint(acc[4 * g]), __float_as_uint(acc[4 * g + 1]), __float_as_uint(acc[4 * g + 2]), __float_as_uint(acc[4 * g + 3])};
-        if (rem0 >= 8) {
-            __builtin_amdgcn_raw_buffer_store_b128(v, ro, off, 0, 0);
-        } else {
-            const bool row = off != 0xffffffffu;   // (off + 8 below must not wrap a missing row's offset back into the buffer)
-            __builtin_amdgcn_raw_buffer_store_b128(v, ro, rem >= 4 ? off : 0xffffffffu, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{v.x, v.y}, ro, (rem == 2 || rem == 3) ? off : 0xffffffffu, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(rem == 3 ? v.z : v.x, ro, row && rem == 3 ? off + 8u : (rem == 1 ? off : 0xffffffffu), 0, 0);
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // T = requant(X . W) for every cluster batch (main_qgtc.py:147, layout-correct form): X = packed rows-layout planes (K <=

@@ -17,6 +17,7 @@
 #include "bitmm_fp4_one.hip.h"
 #include "fp4_rowblock.hip.h"
 #include "bitmm_fp4_rows.hip.h"
+#include "fp4_rbw_common.hip.h"
 #include "bitmm_fp4_rbw.hip.h"
 #include "launch_common.hip.h"
 #include "launch_fp4.hip.h"
