@@ -305,7 +305,7 @@ typedef struct qgtc_stage {
     int32_t mode;        /* 0 rows-layout bits, 1 cols-layout bits, 2 float32 */
     int32_t pad128;      /* mode 2: the right operand's planes have PAD128(N) lines (else PAD8(N)) */
     int32_t use_occ;     /* carry the batch's occupancy bitmap (left must be QGTC_SRC_A or QGTC_SRC_AT) */
-    int32_t fmt;         /* mode 1 only: 0 = the cols layout, 1 = the chain format of qgtc_chain_* (qgtc_chain_words(n, N) words) */
+    int32_t fmt;         /* mode 1 only: 0 = the cols layout, 1 = the chain format of qgtc_chain_* (qgtc_chain_words(n, N, ob) words) */
 } qgtc_stage;
 size_t qgtc_epoch_pool_layout(const int32_t *nodes, int count, const qgtc_stage *stages, int n_stages, uint64_t *offsets);
 int qgtc_epoch_plan_fill(const qgtc_batch *batches, int count, const qgtc_stage *stages, int n_stages,
@@ -315,7 +315,7 @@ int qgtc_epoch_plan_fill(const qgtc_batch *batches, int count, const qgtc_stage 
 /* ---- The chain entries: one wave per 32-row block for the whole output width (the grouped epochs at 1 .. 4 bits) ------------
  * Between the launches of a layout-correct epoch (X.W1 | A.T1 + .W2 | A.T2 + .W3 | A.T3, main_qgtc.py:147-154 with every
  * right operand in the cols layout) T is written by one launch and read by the next and by nobody else. These entries keep
- * it in a private CHAIN FORMAT - the finished matrix-core operand, qgtc_chain_words(M, N) words per batch, unspecified to
+ * it in a private CHAIN FORMAT - the finished matrix-core operand, qgtc_chain_words(M, N, bits) words per batch, unspecified to
  * the caller - and take the weights PRE-EXPANDED (qgtc_expand_weights, once per plan; qgtc_weight_codes_words(K, N, nbits,
  * order) words each, stated to the entry as the job's `codes_words`: a table too small for the job is QGTC_ESIZE, never a write). Word for word (after decoding) the results of the public entries; only the last call's float32 output is public.
  *   qgtc_chain_transform:  T_b = requant(X_b . W)                stage[b] = {X_b rows layout (x_bits planes, K <= 8192), -, T_b}
@@ -327,6 +327,9 @@ int qgtc_epoch_plan_fill(const qgtc_batch *batches, int count, const qgtc_stage 
  * out_bits = bits of T / of the aggregate / of T': 1 .. 4, act_bits == out_bits (= the planes of the weights: a chain has one
  * width, main_qgtc.py's --bit_width), t_bits in the same format class (1 / 2 bits: one base-4 digit a nibble; 3 / 4 bits: two),
  * N, N2 <= 128; qgtc_chain_transform: out_bits 1 .. 4, x_bits <= 2 (out_bits <= 2) or <= 4 (out_bits 3 / 4).
+ * ABI 11 widens both entries (bitmm_fp4_rbx.hip.h): one width of 5 .. 8 bits per chain (x_bits <= 8; N, N2 <= 128; the X . W product's
+ * float32 sums must stay exact: K (2^x_bits - 1)(2^out_bits - 1) < 2^24, i.e. K <= 258 at 8 x 8 bits), or 1 .. 4 bits with up to 256
+ * columns on either side (--n-hidden up to 256); qgtc_expand_weights accordingly nbits <= 8, N <= 256, K <= 256 for order 1.
  * QGTC_EINVAL outside that range: callers fall back to qgtc_gcn_chain_batched. w_codes: qgtc_expand_weights order 0 for
  * qgtc_chain_transform (the left operand arrives as packed words), order 1 for qgtc_chain_aggregate (the left operand is
  * the aggregate in the registers of the wave that computed it). max_M is a hard precondition (QGTC_CHECK_DESCRIPTORS).
@@ -341,10 +344,10 @@ typedef struct qgtc_expand_job {
     uint32_t codes_words; /* capacity of `codes` in 32-bit words (ABI 11; was `reserved`): checked against the line above */
 } qgtc_expand_job;
 size_t qgtc_weight_codes_words(int K, int N, int nbits, int order);   /* (ABI 10 took (N, nbits) and left the per-k-quad factor to the caller) */
-size_t qgtc_chain_words(int M, int N);
+size_t qgtc_chain_words(int M, int N, int bits);   /* (ABI 11: 5 .. 8-bit values take two arrays of the 4-bit form) */
 /* A cols-layout right operand (the public format: X of sampler.py:99, [H, W] with nbits <= 4 planes) in the chain format:
  * what a data loader does once beside the packing when the epoch's FIRST product is an aggregation (Batched-GIN: A . X,
- * main_qgtc.py:131). chain: qgtc_chain_words(H, W) words. */
+ * main_qgtc.py:131). chain: qgtc_chain_words(H, W, nbits) words; nbits <= 8. */
 int qgtc_chain_from_cols(const uint32_t *cols, size_t cols_words, int H, int W, int nbits, uint32_t *chain, size_t chain_words,
                          void *stream);
 int qgtc_expand_weights(const qgtc_expand_job *jobs, int n_jobs, void *stream);
@@ -392,7 +395,7 @@ typedef struct qgtc_loader_batch {
     uint64_t *occ;     /* out or NULL: qgtc_occupancy_words(n, n) 64-bit words */
     uint32_t *X;       /* out or NULL: cols layout [n, F], x_bits planes, qgtc_cols_words(n, F, x_bits, 0) words */
     uint32_t *XR;      /* out or NULL: rows layout [n, F], x_bits planes, qgtc_rows_words(n, F, x_bits) words */
-    uint32_t *XC;      /* out or NULL: chain format, qgtc_chain_words(n, F) words (needs X) */
+    uint32_t *XC;      /* out or NULL: chain format, qgtc_chain_words(n, F, x_bits) words (needs X) */
 } qgtc_loader_batch;
 int qgtc_load_batches(const qgtc_loader_batch *batches, int count, int max_n, uint64_t max_edges, const int64_t *src,
                       const int64_t *dst, const float *feats, int F, int x_bits, void *zero, size_t zero_bytes,

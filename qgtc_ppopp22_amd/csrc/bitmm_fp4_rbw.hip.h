@@ -40,7 +40,7 @@ namespace {
 // [column block jn][k half h][lane] of 16 bytes: the codes of word 2 fh + h of line 32 jn + fl (what strip_operand gives).
 // order 1: the right operand of (aggregate) . W' in the register order above - table [jn][m][lane]: dword d nibble i = the
 // value of W'[rbw_column(m, fh, d, i)][32 jn + fl]. One table per base-4 digit (planes 2 dg, 2 dg + 1) of the weight:
-// entry ((jn * MS + s) * ND + dg) * 64 + lane, ND = ceil(nbits / 2) (1- and 2-bit weights: one digit; 4-bit: two; 8-bit: four),
+// entry ((jn * MS + s) * ND + dg) * 64 + lane, ND = chain_digits(nbits) (1- and 2-bit weights: one digit; 3 / 4-bit: two; 5 .. 8-bit: four),
 // MS = 2 (order 0: the halves of a k-quad; order 1 with K <= 128: the two MFMAs of 64 columns) or 4 (order 1, 128 < K <= 256).
 // ------------------------------------------------------------------------------------------
 struct ExpandJob {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64) void k_expand_weights(ExpandJobs jobs) {
         const size_t wi = p * plane + static_cast<size_t>(n) * line_words + (c >> 5);
         return wi < j.w_words ? (j.W[wi] >> (31 - (c & 31))) & 1u : 0u;
     };
-    const int nd = (j.nbits + 1) / 2;
+    const int nd = chain_digits(j.nbits);
     for (int dg = 0; dg < nd; dg++) {
         uint32_t out[4] = {0u, 0u, 0u, 0u};
         for (int d = 0; d < 4; d++)

@@ -11,8 +11,15 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 // column blocks (32 columns) a pre-expanded weight table of the chain entries has: three are kept as four - the kernels of every width
-// but the 2-bit family run three blocks as four (launch_fp4.hip.h) and read the fourth block's (all-zero) codes
-__host__ __device__ constexpr int weight_table_blocks(int N) { return (N + 31) / 32 == 3 ? 4 : (N + 31) / 32; }
+// but the 2-bit family run three blocks as four (launch_fp4.hip.h) and read the fourth block's (all-zero) codes -, five to seven as
+// eight (bitmm_fp4_rbx.hip.h: up to 256 columns)
+__host__ __device__ constexpr int weight_table_blocks(int N) { return (N + 31) / 32 == 3 ? 4 : ((N + 31) / 32 > 4 ? 8 : (N + 31) / 32); }
+// 64-column slices of K per column block in a table: the two halves of a k-quad (order 0) / the MFMAs of the second product (order 1:
+// two up to 128 columns of K, four up to 256)
+__host__ __device__ constexpr int weight_table_slices(int K, int order) { return (order == 1 && K > 128) ? 4 : 2; }
+// base-4 digits of a value in the chain entries' formats: 1 (1 / 2 bits), 2 (3 / 4 bits), 4 (5 .. 8 bits - the kernels of that class run
+// four digits whatever the width is; the top digits of 5- and 6-bit values are zero)
+__host__ __device__ constexpr int chain_digits(int bits) { return bits <= 2 ? 1 : (bits <= 4 ? 2 : 4); }
 
 constexpr int TM = 32, TN = 32;  // workgroup tile of the bit-GEMM
 

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_val2bit_jobs(PackJobs jobs) {
 // ------------------------------------------------------------------------------------------
 __host__ __device__ inline unsigned long long stage_out_words(const qgtc_stage &st, int n) {
     if (st.mode == 2) return (static_cast<unsigned long long>(n) * st.N + 3ull) & ~3ull;
-    if (st.mode == 1 && st.fmt == 1) return static_cast<unsigned long long>(step128(n)) * pad128(st.N) * 16ull;   // chain format (bitmm_fp4_rbw.hip.h)
+    if (st.mode == 1 && st.fmt == 1) return static_cast<unsigned long long>(step128(n)) * pad128(st.N) * 16ull * (st.ob > 4 ? 2ull : 1ull);   // chain format (qgtc_chain_words)
     if (st.mode == 1) return static_cast<unsigned long long>(st.ob) * step128(n) * 4ull * pad128(st.N);
     return static_cast<unsigned long long>(st.ob) * pad8(n) * step128(st.N) * 4ull;
 }

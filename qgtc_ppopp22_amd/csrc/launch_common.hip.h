@@ -22,6 +22,10 @@ int qgtc_launch_expand_weights(const qgtc_expand_job *jobs, int n_jobs, hipStrea
 int qgtc_launch_cols_to_chain(const uint32_t *cols, size_t words, int H, int W, int nbits, uint32_t *chain, hipStream_t st);
 int qgtc_launch_cols_to_chain_batched(const qgtc_loader_batch *batches, int count, int max_n, int W, int nbits, hipStream_t st);
 int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int K, int N, int a, int ob, const uint32_t *w_codes, hipStream_t st);
+// defined in qgtc_chainx.hip (bitmm_fp4_rbx.hip.h: 5 .. 8 bits, up to 256 columns)
+int qgtc_launch_rbx_xw(const qgtc_problem *prs, int count, int max_M, int K, int N, int a, int ob, const uint32_t *w_codes, hipStream_t st);
+int qgtc_launch_rbx_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int N1, int N2, int t_bits, int act_bits,
+                          int mode2, const uint32_t *w2_codes, bool a_tiles, hipStream_t st);
 int qgtc_launch_rbw_chain(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int N1, int N2, int t_bits, int act_bits,
                           int out_bits, int mode2, const uint32_t *w2_codes, bool a_tiles, hipStream_t st);
 int qgtc_launch_rows_to_tiles(const uint32_t *rows, size_t words, int M, int K, uint32_t *tiles, hipStream_t st);
@@ -174,6 +178,24 @@ inline bool rbw_chain_ok(int max_K, int N1, int N2, int t_bits, int act_bits, in
     if (mode2 == 0) return true;
     const bool wide = t_bits > 2;   // the format class of T, of the aggregate and of W' must agree
     return N2 >= 1 && N2 <= 128 && act_bits >= 1 && act_bits <= 4 && (act_bits > 2) == wide && (mode2 == 2 || out_bits == act_bits);
+}
+
+// The same entries beyond those widths (bitmm_fp4_rbx.hip.h): one width of 5 .. 8 bits per chain with N, N' <= 128 (four base-4 digits a
+// value), or 1 .. 4 bits with up to 256 columns on either side. The float32 sums stay exact: K (2^a - 1)(2^w - 1) < 2^24 is checked for
+// the X . W product (8 x 8 bits: K <= 258); the aggregation has K <= 8192 x 255 and the second product N1 <= 256 x 255 x 255 < 2^24.
+inline int chain_class(int bits) { return chain_digits(bits); }
+inline bool rbx_xw_ok(int K, int N, int x_bits, int out_bits) {
+    if (K < 1 || K > 8192 || N < 1 || out_bits < 1 || out_bits > 8 || x_bits < 1 || x_bits > 2 * chain_class(out_bits)) return false;
+    if (static_cast<double>(K) * ((1 << x_bits) - 1) * ((1 << out_bits) - 1) >= 16777216.0) return false;
+    return out_bits > 4 ? N <= 128 : (N > 128 && N <= 256);   // (1 .. 4 bits at N <= 128 are k_rbw_xw's)
+}
+inline bool rbx_chain_ok(int max_K, int N1, int N2, int t_bits, int act_bits, int out_bits, int mode2) {
+    if (max_K < 1 || max_K > 8192 || N1 < 1 || t_bits < 1 || t_bits > 8) return false;
+    const int cls = chain_class(t_bits), lim = cls == 4 ? 128 : 256;
+    if (N1 > lim) return false;
+    if (mode2 == 0) return cls == 4 || N1 > 128;
+    if (N2 < 1 || N2 > lim || act_bits < 1 || act_bits > 8 || chain_class(act_bits) != cls || (mode2 == 1 && out_bits != act_bits)) return false;
+    return cls == 4 || N1 > 128 || N2 > 128;
 }
 
 // single launches with three to eight left-hand planes (the narrow-operand kernels of bitmm_fp4_one / _skinny take two at most) and at

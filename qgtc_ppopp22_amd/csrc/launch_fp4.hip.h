@@ -189,17 +189,18 @@ int qgtc_launch_expand_weights(const qgtc_expand_job *jobs, int n_jobs, hipStrea
     int most = 0, most_kq = 1;
     for (int i = 0; i < n_jobs; i++) {
         const qgtc_expand_job &j = jobs[i];
-        ej.job[i] = ExpandJob{j.W, j.codes, j.w_words, j.K, j.N, j.w_lines, j.nbits, j.order, weight_table_blocks(j.N)};   // (columns past N: zero codes)
-        most = std::max(most, weight_table_blocks(j.N));
+        const int ms = weight_table_slices(j.K, j.order);
+        ej.job[i] = ExpandJob{j.W, j.codes, j.w_words, j.K, j.N, j.w_lines, j.nbits, j.order, weight_table_blocks(j.N), ms};   // (columns past N: zero codes)
+        most = std::max(most, weight_table_blocks(j.N) * ms);
         if (j.order == 0) most_kq = std::max(most_kq, step128(j.K));   // (a table per k-quad of K)
     }
-    hipLaunchKernelGGL(k_expand_weights, dim3(2 * most, n_jobs, most_kq), dim3(64), 0, st, ej);
+    hipLaunchKernelGGL(k_expand_weights, dim3(most, n_jobs, most_kq), dim3(64), 0, st, ej);
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
 }
 
 int qgtc_launch_cols_to_chain(const uint32_t *cols, size_t words, int H, int W, int nbits, uint32_t *chain, hipStream_t st) {
-    const size_t total = static_cast<size_t>(step128(H)) * 4u * pad128(W);
+    const size_t total = static_cast<size_t>(step128(H)) * 4u * pad128(W);   // (threads: one per 16 bytes of ONE array; a thread writes both arrays of a 5 .. 8-bit X)
     hipLaunchKernelGGL(k_cols_to_chain, dim3(static_cast<unsigned>(std::min<size_t>((total + 255) / 256, 4096))), dim3(256), 0, st, cols,
                        static_cast<unsigned long long>(words), H, W, nbits, chain);
     HIP_TRY(hipGetLastError());

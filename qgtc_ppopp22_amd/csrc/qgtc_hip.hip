@@ -373,27 +373,29 @@ int qgtc_gcn_chain_batched(const qgtc_problem *stage_a, const qgtc_problem *stag
 }
 
 size_t qgtc_weight_codes_words(int K, int N, int nbits, int order) {
-    if (K <= 0 || N <= 0 || nbits < 1 || nbits > 4 || (order != 0 && order != 1)) return 0u;
-    const size_t table = static_cast<size_t>(weight_table_blocks(N)) * 2u * ((nbits + 1) / 2) * 64u * 4u;
+    if (K <= 0 || N <= 0 || N > 256 || nbits < 1 || nbits > 8 || (order != 0 && order != 1) || (order == 1 && K > 256)) return 0u;
+    const size_t table = static_cast<size_t>(weight_table_blocks(N)) * weight_table_slices(K, order) * chain_digits(nbits) * 64u * 4u;
     return table * (order == 0 ? static_cast<size_t>(step128(K)) : 1u);   // order 0: a table per k-quad of K
 }
 
 int qgtc_chain_from_cols(const uint32_t *cols, size_t cols_words, int H, int W, int nbits, uint32_t *chain, size_t chain_words,
                          void *stream) {
-    if (!cols || !chain || H <= 0 || W <= 0 || nbits < 1 || nbits > 4) return QGTC_EINVAL;
-    if (chain_words < qgtc_chain_words(H, W)) return QGTC_ESIZE;
+    if (!cols || !chain || H <= 0 || W <= 0 || nbits < 1 || nbits > 8) return QGTC_EINVAL;
+    if (chain_words < qgtc_chain_words(H, W, nbits)) return QGTC_ESIZE;
     if (!aligned16(chain)) return QGTC_EALIGN;
     return qgtc_launch_cols_to_chain(cols, cols_words, H, W, nbits, chain, static_cast<hipStream_t>(stream));
 }
 
-size_t qgtc_chain_words(int M, int N) { return (M > 0 && N > 0) ? static_cast<size_t>(step128(M)) * pad128(N) * 16u : 0u; }
+size_t qgtc_chain_words(int M, int N, int bits) {   // 5 .. 8 bits: two arrays of the 4-bit form (bitmm_fp4_rbx.hip.h)
+    return (M > 0 && N > 0 && bits >= 1 && bits <= 8) ? static_cast<size_t>(step128(M)) * pad128(N) * 16u * (bits > 4 ? 2u : 1u) : 0u;
+}
 
 int qgtc_expand_weights(const qgtc_expand_job *jobs, int n_jobs, void *stream) {
     if (!jobs || n_jobs <= 0 || n_jobs > QGTC_MAX_WEIGHTS) return QGTC_EINVAL;
     for (int i = 0; i < n_jobs; i++) {
         const qgtc_expand_job &j = jobs[i];
-        if (!j.W || !j.codes || j.K <= 0 || j.N <= 0 || j.N > 128 || j.nbits < 1 || j.nbits > 4 || j.w_lines < j.N || (j.order != 0 && j.order != 1)) return QGTC_EINVAL;
-        if ((j.order == 0 && j.K > 8192) || (j.order == 1 && j.K > 128)) return QGTC_EINVAL;
+        if (!j.W || !j.codes || j.K <= 0 || j.N <= 0 || j.N > 256 || j.nbits < 1 || j.nbits > 8 || j.w_lines < j.N || (j.order != 0 && j.order != 1)) return QGTC_EINVAL;
+        if ((j.order == 0 && j.K > 8192) || (j.order == 1 && j.K > 256)) return QGTC_EINVAL;
         if (!aligned16(j.codes)) return QGTC_EALIGN;
         if (j.codes_words < qgtc_weight_codes_words(j.K, j.N, j.nbits, j.order)) return QGTC_ESIZE;   // (ABI 11: the capacity travels with the job)
     }
@@ -403,13 +405,15 @@ int qgtc_expand_weights(const qgtc_expand_job *jobs, int n_jobs, void *stream) {
 int qgtc_chain_transform(const qgtc_problem *stage, int count, int max_M, int K, int N, int x_bits, int out_bits,
                          const uint32_t *w_codes, unsigned flags, void *stream) {
     if (!stage || !w_codes || count <= 0 || count > 65535 || max_M <= 0) return QGTC_EINVAL;
-    if (!rbw_xw_ok(K, N, x_bits, out_bits) || getenv_flag("QGTC_NO_RBW")) return QGTC_EINVAL;
+    const bool narrow = rbw_xw_ok(K, N, x_bits, out_bits);   // (1 .. 4 bits, N <= 128: k_rbw_xw; else 5 .. 8 bits / up to 256 columns: k_rbx_xw)
+    if ((!narrow && !rbx_xw_ok(K, N, x_bits, out_bits)) || getenv_flag("QGTC_NO_RBW")) return QGTC_EINVAL;
     if (!aligned16(w_codes)) return QGTC_EALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (flags & QGTC_CHECK_DESCRIPTORS) {
         const int crc = qgtc_launch_check_descriptors(stage, nullptr, count, max_M, K, N, 0, 0, 0, st, N, 0, K);   // (every descriptor's K == the K of the weight tables)
         if (crc != QGTC_OK) return crc;
     }
+    if (!narrow) return qgtc_launch_rbx_xw(stage, count, max_M, K, N, x_bits, out_bits, w_codes, st);
     return qgtc_launch_rbw_xw(stage, count, max_M, K, N, x_bits, out_bits, w_codes, st);
 }
 
@@ -418,7 +422,8 @@ int qgtc_chain_aggregate(const qgtc_problem *stage_a, const qgtc_problem *stage_
                          unsigned flags, void *stream) {
     if (!stage_a || count <= 0 || count > 65535 || max_M <= 0) return QGTC_EINVAL;
     if (out_mode < 0 || out_mode > 2 || (out_mode != 0 && (!stage_xw || !w2_codes))) return QGTC_EINVAL;
-    if (!rbw_chain_ok(max_K, N1, N2, t_bits, act_bits, out_bits, out_mode) || getenv_flag("QGTC_NO_RBW")) return QGTC_EINVAL;
+    const bool narrow = rbw_chain_ok(max_K, N1, N2, t_bits, act_bits, out_bits, out_mode);
+    if ((!narrow && !rbx_chain_ok(max_K, N1, N2, t_bits, act_bits, out_bits, out_mode)) || getenv_flag("QGTC_NO_RBW")) return QGTC_EINVAL;
     if (w2_codes && !aligned16(w2_codes)) return QGTC_EALIGN;
     // (float32 outputs are written through a buffer descriptor with a 32-bit extent)
     if (out_mode != 1 && static_cast<unsigned long long>(max_M) * static_cast<unsigned long long>(out_mode == 0 ? N1 : N2) * 4ull >= (1ull << 31)) return QGTC_EINVAL;
@@ -428,6 +433,9 @@ int qgtc_chain_aggregate(const qgtc_problem *stage_a, const qgtc_problem *stage_
                                       : qgtc_launch_check_descriptors(stage_a, stage_xw, count, max_M, max_K, N1, N1, N2, 4, st, N1, N2);
         if (crc != QGTC_OK) return crc;
     }
+    if (!narrow)
+        return qgtc_launch_rbx_chain(stage_a, out_mode == 0 ? nullptr : stage_xw, count, max_M, N1, N2, t_bits, act_bits, out_mode, w2_codes,
+                                     (flags & QGTC_CHAIN_ADJ_TILES) != 0u, st);
     return qgtc_launch_rbw_chain(stage_a, out_mode == 0 ? nullptr : stage_xw, count, max_M, N1, N2, t_bits, act_bits, out_bits, out_mode, w2_codes,
                                  (flags & QGTC_CHAIN_ADJ_TILES) != 0u, st);
 }
@@ -561,7 +569,7 @@ int qgtc_load_batches(const qgtc_loader_batch *batches, int count, int max_n, ui
         }
         HIP_TRY(hipGetLastError());
         if (formats & QGTC_LOAD_X_CHAIN) {   // the chain format of the entries that have an XC (from the cols layout just written)
-            if (x_bits > 4) return QGTC_EINVAL;
+            if (x_bits > 8) return QGTC_EINVAL;
             const int rc = qgtc_launch_cols_to_chain_batched(batches, count, max_n, F, x_bits, st);
             if (rc != QGTC_OK) return rc;
         }

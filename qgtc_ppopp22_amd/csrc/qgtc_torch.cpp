@@ -803,8 +803,8 @@ struct EpochPlan {
             h[i].XR = Xrs.empty() ? qgtc_operand{nullptr, 0} : operand(Xrs[i], "Xr");
             h[i].XC = qgtc_operand{nullptr, 0};
             if (x_chain_bits > 0) {
-                TORCH_CHECK(x_cols > 0 && x_chain_bits <= 4, "x_chain_bits in 1..4 and the feature count");
-                torch::Tensor xc = torch::empty({static_cast<int64_t>(qgtc_chain_words(ns[i], x_cols))}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
+                TORCH_CHECK(x_cols > 0 && x_chain_bits <= 8, "x_chain_bits in 1..8 and the feature count");
+                torch::Tensor xc = torch::empty({static_cast<int64_t>(qgtc_chain_words(ns[i], x_cols, x_chain_bits))}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
                 check_rc(qgtc_chain_from_cols(words(Xs[i]), Xs[i].numel(), ns[i], x_cols, x_chain_bits, words_mut(xc), xc.numel(), current_stream(xc)), "EpochPlan (X in the chain format)");
                 h[i].XC = qgtc_operand{words(xc), static_cast<uint64_t>(xc.numel())};
                 keep.push_back(xc);
@@ -861,7 +861,7 @@ struct EpochPlan {
         TORCH_CHECK(src.device() == feats.device() && dst.device() == feats.device(), "src, dst and feats must share a device");
         const int count = static_cast<int>(ns.size());
         TORCH_CHECK(count > 0 && count <= 65535 && static_cast<int>(edge_counts.size()) == count, "1..65535 cluster batches, one edge count each");
-        TORCH_CHECK(x_bits >= 1 && x_bits <= 32 && (x_chain_bits == 0 || (x_chain_bits == x_bits && x_bits <= 4)), "bad bit widths");
+        TORCH_CHECK(x_bits >= 1 && x_bits <= 32 && (x_chain_bits == 0 || (x_chain_bits == x_bits && x_bits <= 8)), "bad bit widths");
         const int F = static_cast<int>(feats.size(1));
         const auto dev = feats.device();
         c10::DeviceGuard guard(dev);
@@ -883,7 +883,7 @@ struct EpochPlan {
             o_off[i + 1] = o_off[i] + static_cast<int64_t>(qgtc_occupancy_words(n, n));
             x_off[i + 1] = x_off[i] + static_cast<int64_t>(qgtc_cols_words(n, F, x_bits, 0));
             xr_off[i + 1] = xr_off[i] + (with_rows ? r4(static_cast<int64_t>(qgtc_rows_words(n, F, x_bits))) : 0);
-            xc_off[i + 1] = xc_off[i] + (x_chain_bits ? static_cast<int64_t>(qgtc_chain_words(n, F)) : 0);
+            xc_off[i + 1] = xc_off[i] + (x_chain_bits ? static_cast<int64_t>(qgtc_chain_words(n, F, x_chain_bits)) : 0);
             e_off[i + 1] = e_off[i] + edge_counts[i];
             f_off[i + 1] = f_off[i] + n;
             max_e = std::max<int64_t>(max_e, edge_counts[i]);

@@ -305,6 +305,21 @@ def _stage_recipes(Q, chain, run_gin, F, H, C, b):
             (S(2), W(1), H, H, b, b, b, 1, 0, 0), (A, S(3), N_, H, 1, b, b, 0, 0, 1), (S(4), W(2), H, C, b, b, 1, 2, 0, 0)]
 
 
+def chain_entries_cover(b: int, F: int, H: int, C: int, run_gin: bool, max_n: int) -> bool:
+    """Can the chain entries (qgtc_chain_transform / qgtc_chain_aggregate) run this epoch? One width b per chain: 1 .. 4 bits with up
+    to 256 hidden units / classes, 5 .. 8 bits with up to 128 (include/qgtc.h); cluster batches of at most 8192 nodes; Cluster-GCN's
+    first product X . W1 loops over the k-quads of up to 8192 features while its float32 sums stay exact (F (2^b - 1)^2 < 2^24: 258
+    features at 8 bits); Batched-GIN's X is the right operand of an aggregation, so F is bounded like H."""
+    if not 1 <= b <= 8 or max_n > 8192:
+        return False
+    lim = 256 if b <= 4 else 128
+    if max(H, C) > lim:
+        return False
+    if run_gin:
+        return F <= lim
+    return F <= 8192 and F * ((1 << b) - 1) ** 2 < (1 << 24)
+
+
 class PlannedEpoch:
     """The grouped epoch on a device-filled plan (Q.EpochPlan): what BatchedEpoch builds on the host - 6 x 75 descriptors,
     pooled outputs, occupancy bitmaps - is split into the data loader's part (`data`, made once beside the packing:
@@ -330,9 +345,10 @@ class PlannedEpoch:
         # the library's own routing switches that take the chain entries / chained pairs away (perf-only switches such as
         # QGTC_NO_XCD leave the route alone)
         switches = routing_switches()
-        if (fuse and chain == "correct" and chain_stages and not run_gin and not keep_aggregates and 1 <= b <= 4 and F <= 8192 and max(H, C) <= 128 and max_n <= 8192
+        covered = chain_entries_cover(b, F, H, C, run_gin, max_n)
+        if (fuse and chain == "correct" and chain_stages and not run_gin and not keep_aggregates and covered
                 and Q.get_engine() != "popcount" and not switches):
-            # The Cluster-GCN chain (1 .. 4 bits; the BASELINE epoch: 2) on the chain entries (qgtc_chain_transform / qgtc_chain_aggregate): one wave per row
+            # The Cluster-GCN chain (1 .. 8 bits; the BASELINE epoch: 2) on the chain entries (qgtc_chain_transform / qgtc_chain_aggregate): one wave per row
             # block for the whole width, T between the launches as finished matrix-core operands, weights pre-expanded once
             # per plan. X.W1 | A.T1 + .W2 | A.T2 + .W3 | A.T3 -> float32: four launches.
             for i in (0, 2, 4):
@@ -343,9 +359,9 @@ class PlannedEpoch:
             if getattr(data, "a_tiles", False):   # the aggregations read the adjacency as 512-byte tiles
                 for i in (1, 3, 5):
                     stages[i] = (Q.SRC_AT,) + stages[i][1:]
-        elif (fuse and chain == "correct" and chain_stages and run_gin and not keep_aggregates and 1 <= b <= 4 and max(F, H, C) <= 128 and max_n <= 8192
+        elif (fuse and chain == "correct" and chain_stages and run_gin and not keep_aggregates and covered
                 and Q.get_engine() != "popcount" and not switches and getattr(data, "x_chain", False)):
-            # Batched-GIN (1 .. 4 bits; the BASELINE epoch: 4) on the same entries: A.X + .W1 | A.T1 + .W2 | A.T2 + .W3 -> float32, three launches; X in the
+            # Batched-GIN (1 .. 8 bits; the BASELINE epoch: 4) on the same entries: A.X + .W1 | A.T1 + .W2 | A.T2 + .W3 -> float32, three launches; X in the
             # chain format from the data loader (ClusterIter.epoch_data), T between the launches likewise
             stages[0] = (stages[0][0], Q.SRC_XC) + stages[0][2:]
             for i in (1, 3):

@@ -73,13 +73,11 @@ class ClusterIter:
         self._epoch_data = None
         self.x_in_chain_format = False
         feat = g.feat.shape[1]
-        # X also in the chain format of the chain entries when an epoch's first product is A . X (Batched-GIN) and the
-        # widths are the ones those entries cover (4 bits, at most 64 features); the adjacencies also as 512-byte tiles for
-        # the aggregation launches of those entries (2-bit Cluster-GCN, 4-bit Batched-GIN)
-        # the chain entries take one width b = 1 .. 4 per chain and at most 128 columns (driver.PlannedEpoch): Batched-GIN's first product
-        # reads X in the chain format, every aggregation the adjacency as 512-byte tiles
-        self._x_chain = bit_width if (run_GIN and 1 <= bit_width <= 4 and feat <= 128) else 0
-        self._a_tiles = self._x_chain > 0 or (not run_GIN and 1 <= bit_width <= 4)
+        # the chain entries take one width b per chain: 1 .. 4 bits with up to 256 columns, 5 .. 8 bits with up to 128
+        # (driver.chain_entries_cover): Batched-GIN's first product reads X in the chain format, every aggregation the adjacency as
+        # 512-byte tiles
+        self._x_chain = bit_width if (run_GIN and 1 <= bit_width <= 8 and feat <= (256 if bit_width <= 4 else 128)) else 0
+        self._a_tiles = self._x_chain > 0 or (not run_GIN and 1 <= bit_width <= 8)
         self._with_rows = with_rows_X
         if grouped and not dense_adjacency and self.batch_ids:
             self._pack_grouped(qgtc, keep_raw)

@@ -363,9 +363,17 @@ class QgtcExpandJob(ctypes.Structure):
                 ("nbits", ctypes.c_int32), ("w_lines", ctypes.c_int32), ("order", ctypes.c_int32), ("codes_words", ctypes.c_uint32)]
 
 
+def _chain_covered(b, F, H, C):
+    """include/qgtc.h (ABI 11): 1 .. 4 bits with up to 256 columns, 5 .. 8 bits with up to 128 and an exact X . W (F (2^b - 1)^2 < 2^24)."""
+    return max(H, C) <= (256 if b <= 4 else 128) and F <= 8192 and F * ((1 << b) - 1) ** 2 < (1 << 24)
+
+
 @pytest.mark.parametrize("M,K,F,H,C,bitmaps", [(333, 333, 48, 128, 10, True), (150, 150, 128, 64, 128, False), (300, 150, 32, 100, 33, True), (200, 200, 602, 128, 41, True), (70, 70, 3703, 33, 7, False), (120, 120, 300, 70, 90, True),
-                                               (150, 300, 100, 33, 70, True), (1213, 1213, 128, 128, 128, True), (40, 40, 7, 5, 3, False)])
-@pytest.mark.parametrize("b", [2, 1, 3, 4])     # one width per chain (main_qgtc.py's --bit_width); the BASELINE epoch: 2
+                                               (150, 300, 100, 33, 70, True), (1213, 1213, 128, 128, 128, True), (40, 40, 7, 5, 3, False),
+                                               # ABI 11: 129 .. 256 hidden units / classes (main_qgtc.py:31: --n-hidden is free)
+                                               (333, 333, 48, 256, 10, True), (150, 300, 128, 200, 256, False), (300, 150, 300, 40, 130, True), (1213, 1213, 128, 256, 256, True),
+                                               (200, 200, 64, 160, 16, True)])
+@pytest.mark.parametrize("b", [2, 1, 3, 4, 5, 6, 7, 8])     # one width per chain (main_qgtc.py's --bit_width; 2_7c_QGTC_GEMM_INT8.py:15 sweeps 1 .. 8); the BASELINE epoch: 2
 def test_chain_entries_with_raw_descriptors(lib, oracle, M, K, F, H, C, bitmaps, b):
     """qgtc_expand_weights + qgtc_chain_transform + qgtc_chain_aggregate through ctypes: T = requant(X . W1) in the chain's
     private format, T' = requant(requant(A . T) . W2) (out_mode 1), then float32(A2 . T') (out_mode 0) and
@@ -373,6 +381,8 @@ def test_chain_entries_with_raw_descriptors(lib, oracle, M, K, F, H, C, bitmaps,
     multiples of 32, non-square adjacencies (the diagonal k-quad does not exist for every row group), with and without
     occupancy bitmaps, three batches per launch."""
     import torch
+    if not _chain_covered(b, F, H, C):
+        pytest.skip("outside the chain entries' range at this width (callers fall back to the grouped GEMMs)")
     lib.qgtc_weight_codes_words.restype = lib.qgtc_chain_words.restype = lib.qgtc_occupancy_words.restype = ctypes.c_size_t
     lib.qgtc_expand_weights.argtypes = [vp, ctypes.c_int, vp]
     lib.qgtc_chain_transform.argtypes = [vp, ctypes.c_int] + [ctypes.c_int] * 5 + [vp, ctypes.c_uint, vp]
@@ -399,8 +409,8 @@ def test_chain_entries_with_raw_descriptors(lib, oracle, M, K, F, H, C, bitmaps,
         qa2 = (rng.random((m, m)) < 0.05).astype(np.int32)
         X, A, A2 = oracle.pack(qx, b, False), oracle.pack(qa, 1, False), oracle.pack(qa2, 1, False)
         dX, dA, dA2 = (torch.from_numpy(t.view(np.int32)).cuda() for t in (X, A, A2))
-        T = torch.full((int(lib.qgtc_chain_words(k, H)),), -1, dtype=torch.int32, device="cuda")
-        T2 = torch.full((int(lib.qgtc_chain_words(m, C)),), -1, dtype=torch.int32, device="cuda")
+        T = torch.full((int(lib.qgtc_chain_words(k, H, b)),), -1, dtype=torch.int32, device="cuda")
+        T2 = torch.full((int(lib.qgtc_chain_words(m, C, b)),), -1, dtype=torch.int32, device="cuda")
         out0 = torch.full((m * C,), -7.0, dtype=torch.float32, device="cuda")
         out2 = torch.full((m * C,), -7.0, dtype=torch.float32, device="cuda")
         occ = occ2 = None
@@ -443,10 +453,13 @@ def test_chain_entries_with_raw_descriptors(lib, oracle, M, K, F, H, C, bitmaps,
     assert lib.qgtc_last_batched_violation(None, None, st) == 0
     # outside the entries' range: error codes (callers fall back to qgtc_gcn_chain_batched)
     assert lib.qgtc_chain_transform(d(0), count, K, 8193, H, b, b, c1.data_ptr(), 0, st) == 1         # K > 8192
-    assert lib.qgtc_chain_transform(d(0), count, K, F, H, b, 5, c1.data_ptr(), 0, st) == 1            # 5-bit T
+    assert lib.qgtc_chain_transform(d(0), count, K, F, H, b, 9, c1.data_ptr(), 0, st) == 1            # 9-bit T
     assert lib.qgtc_chain_transform(d(0), count, K, F, H, 3, 2, c1.data_ptr(), 0, st) == 1            # three planes of X into a one-digit chain
+    assert lib.qgtc_chain_transform(d(0), count, K, 300, 128, 8, 8, c1.data_ptr(), 0, st) == 1        # 8 x 8 bits over 300 features: float32 sums inexact
+    assert lib.qgtc_chain_transform(d(0), count, K, 128, 129, 8, 8, c1.data_ptr(), 0, st) == 1        # 5 .. 8 bits: at most 128 columns
     assert lib.qgtc_chain_aggregate(d(1), d(2), count, M, K, H, C, b, 5 - b, 5 - b, 1, c2.data_ptr(), 0, st) == 1   # T and the aggregate in different format classes
-    assert lib.qgtc_chain_aggregate(d(1), d(2), count, M, K, 129, C, b, b, b, 1, c2.data_ptr(), 0, st) == 1
+    assert lib.qgtc_chain_aggregate(d(1), d(2), count, M, K, 257, C, b, b, b, 1, c2.data_ptr(), 0, st) == 1
+    assert lib.qgtc_chain_aggregate(d(1), d(2), count, M, K, 129, C, 8, 8, 8, 1, c2.data_ptr(), 0, st) == 1
     assert lib.qgtc_chain_aggregate(d(1), None, count, M, K, H, C, b, b, b, 1, c2.data_ptr(), 0, st) == 1
     assert lib.qgtc_expand_weights(ctypes.addressof(jobs), 9, st) == 1
     # ADVICE r4 / ABI 11: the capacity of `codes` travels with the job - a table sized for ONE k-quad (what ABI 10's two-argument size
@@ -469,14 +482,18 @@ def test_chain_entries_with_raw_descriptors(lib, oracle, M, K, F, H, C, bitmaps,
         assert prob.value == 0 and field.value == 2, (prob.value, field.value)     # QGTC_VIOL_K of problem 0
 
 
-@pytest.mark.parametrize("M,F,H,C,bitmaps", [(599, 50, 64, 10, True), (333, 64, 33, 64, False), (40, 7, 5, 3, True), (333, 100, 128, 70, True)])
-def test_chain_entries_at_four_bits(lib, oracle, M, F, H, C, bitmaps):
+@pytest.mark.parametrize("M,F,H,C,bitmaps", [(599, 50, 64, 10, True), (333, 64, 33, 64, False), (40, 7, 5, 3, True), (333, 100, 128, 70, True),
+                                             (300, 200, 256, 130, True), (150, 29, 160, 10, False)])
+@pytest.mark.parametrize("b", [4, 8, 5, 3])
+def test_chain_entries_at_four_bits(lib, oracle, M, F, H, C, bitmaps, b):
     """The Batched-GIN shape of the chain entries (main_qgtc.py:131-138 with every right operand in the cols layout): X arrives in
     the PUBLIC cols layout and is converted once (qgtc_chain_from_cols, the data loader's step), then
     T1 = requant(requant(A . X) . W1) (out_mode 1), out = float32(requant(A . T1) . W2) (out_mode 2) - 4-bit values, two base-4
-    digits a nibble, 4-plane weights (W2 in val2bit's output_layer form: PAD8 lines) - against the oracle."""
+    digits a nibble, 4-plane weights (W2 in val2bit's output_layer form: PAD8 lines) - against the oracle. ABI 11: the same at 5 .. 8 bits
+    (X converted into two arrays of the 4-bit form) and with up to 256 columns at 3 / 4 bits."""
     import torch
-    b = 4
+    if max(F, H, C) > (256 if b <= 4 else 128):
+        pytest.skip("outside the chain entries' range at this width")
     lib.qgtc_weight_codes_words.restype = lib.qgtc_chain_words.restype = lib.qgtc_occupancy_words.restype = ctypes.c_size_t
     lib.qgtc_expand_weights.argtypes = [vp, ctypes.c_int, vp]
     lib.qgtc_chain_from_cols.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
@@ -500,9 +517,9 @@ def test_chain_entries_at_four_bits(lib, oracle, M, F, H, C, bitmaps):
         qa = (rng.random((m, m)) < 0.05).astype(np.int32)
         X, A = oracle.pack(qx, b, True), oracle.pack(qa, 1, False)
         dX, dA = torch.from_numpy(X.view(np.int32)).cuda(), torch.from_numpy(A.view(np.int32)).cuda()
-        XC = torch.full((int(lib.qgtc_chain_words(m, F)),), -1, dtype=torch.int32, device="cuda")
+        XC = torch.full((int(lib.qgtc_chain_words(m, F, b)),), -1, dtype=torch.int32, device="cuda")
         assert lib.qgtc_chain_from_cols(dX.data_ptr(), dX.numel(), m, F, b, XC.data_ptr(), XC.numel(), st) == 0
-        T1 = torch.full((int(lib.qgtc_chain_words(m, H)),), -1, dtype=torch.int32, device="cuda")
+        T1 = torch.full((int(lib.qgtc_chain_words(m, H, b)),), -1, dtype=torch.int32, device="cuda")
         out = torch.full((m * C,), -7.0, dtype=torch.float32, device="cuda")
         occ = None
         if bitmaps:
@@ -542,20 +559,23 @@ def test_chain_entries_at_four_bits(lib, oracle, M, F, H, C, bitmaps):
     prob, field = ctypes.c_int(-1), ctypes.c_int(0)
     assert lib.qgtc_last_batched_violation(ctypes.byref(prob), ctypes.byref(field), st) == 1 and (prob.value, field.value) == (1, 5)
     # ... and the descriptors' N must EQUAL the width the host states (the stores are sized from it): stating H + 1 for these descriptors is recorded
-    if H + 1 <= 64:
+    if H + 1 <= 64 and b == 4:
         assert lib.qgtc_chain_aggregate(d(0), d(1), count, M, M, F, H + 1, b, b, b, 1, c1.data_ptr(), 0x200, st) == 0
         assert lib.qgtc_last_batched_violation(ctypes.byref(prob), ctypes.byref(field), st) == 1 and field.value == 3
-    assert lib.qgtc_chain_aggregate(d(0), d(1), count, M, M, 129, H, b, b, b, 1, c1.data_ptr(), 0, st) == 1    # N <= 128
-    assert lib.qgtc_chain_from_cols(dX.data_ptr(), dX.numel(), 10, 10, 5, XC.data_ptr(), XC.numel(), st) == 1   # at most four planes
+    assert lib.qgtc_chain_aggregate(d(0), d(1), count, M, M, 257, H, b, b, b, 1, c1.data_ptr(), 0, st) == 1    # N <= 256
+    assert lib.qgtc_chain_aggregate(d(0), d(1), count, M, M, 129, H, 8, 8, 8, 1, c1.data_ptr(), 0, st) == 1    # 5 .. 8 bits: N <= 128
+    assert lib.qgtc_chain_from_cols(dX.data_ptr(), dX.numel(), 10, 10, 9, XC.data_ptr(), XC.numel(), st) == 1   # at most eight planes
     assert lib.qgtc_chain_from_cols(dX.data_ptr(), dX.numel(), M, F, b, XC.data_ptr(), 3, st) == 2
 
 
-@pytest.mark.parametrize("seed", range(80))
+@pytest.mark.parametrize("seed", range(150))
 def test_chain_entries_random_sweep(lib, oracle, seed):
     """Random shapes through the chain entries against the oracle: node counts around the 32 / 128 boundaries (and below 32), widths
     around the 32-column blocks, 2-bit (N <= 128) and 4-bit (N <= 64) chains, adjacency density from empty to dense, K != M, pooled
     and absent bitmaps, the adjacency in the rows layout (even seeds) or as tiles (odd seeds: qgtc_adj_tiles_from_rows, checked word
-    for word, + QGTC_CHAIN_ADJ_TILES) - X.W (or the converted X) -> aggregation + transform -> float32 aggregation."""
+    for word, + QGTC_CHAIN_ADJ_TILES) - X.W (or the converted X) -> aggregation + transform -> float32 aggregation.
+    Seeds 80 .. 149 (ABI 11): chains of 5 .. 8 bits (four base-4 digits a value, N <= 128, X . W within the float32-exact range) and
+    1 .. 4-bit chains with 129 .. 256 columns on at least one side."""
     import torch
     rng = np.random.default_rng(1000 + seed)
     lib.qgtc_weight_codes_words.restype = lib.qgtc_chain_words.restype = lib.qgtc_occupancy_words.restype = ctypes.c_size_t
@@ -569,13 +589,21 @@ def test_chain_entries_random_sweep(lib, oracle, seed):
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P128 = lambda x: (x + 127) // 128 * 128   # noqa: E731
     tiles = seed % 2 == 1
-    b = int(rng.choice([1, 2, 2, 3, 4, 4]))      # one width per chain
+    wide = seed >= 80 and seed % 2 == 0          # 1 .. 4 bits with more than 128 columns somewhere
+    many = seed >= 80 and not wide               # 5 .. 8 bits
+    b = int(rng.choice([5, 6, 7, 8, 8])) if many else int(rng.choice([1, 2, 2, 3, 4, 4]))      # one width per chain
     use_xw = bool(rng.integers(0, 2))            # T from qgtc_chain_transform (X . W1), or a data-loader operand converted from the cols layout
     wmax = 128
     pick = lambda hi: int(rng.choice([1, 7, 31, 32, 33, 63, 64, 65, 96, 127, 128, int(rng.integers(1, hi + 1))]))   # noqa: E731
     F, H, C = min(pick(wmax), wmax), min(pick(wmax), wmax), min(pick(wmax), wmax)
+    if wide:
+        big = lambda: int(rng.choice([129, 160, 161, 192, 255, 256, int(rng.integers(129, 257))]))   # noqa: E731
+        which = int(rng.integers(0, 3))
+        H, C = (big() if which != 1 else H), (big() if which != 0 else C)
     if use_xw and rng.integers(0, 3) == 0:
         F = int(rng.choice([129, 256, 300, 602, int(rng.integers(129, 900))]))   # more than one k-quad of features
+    if use_xw:
+        F = min(F, ((1 << 24) - 1) // ((1 << b) - 1) ** 2)                        # the X . W product's float32 sums stay exact
     count = int(rng.integers(1, 5))
     bitmaps = bool(rng.integers(0, 2))
     density = float(rng.choice([0.0, 0.01, 0.05, 0.5, 1.0]))
@@ -595,7 +623,7 @@ def test_chain_entries_random_sweep(lib, oracle, seed):
         qa = (rng.random((m, k)) < density).astype(np.int32)
         A = oracle.pack(qa, 1, False)
         dA = torch.from_numpy(A.view(np.int32)).cuda()
-        T = torch.full((int(lib.qgtc_chain_words(k, H)),), -1, dtype=torch.int32, device="cuda")     # requant(X . W1), or the converted X'
+        T = torch.full((int(lib.qgtc_chain_words(k, H, b)),), -1, dtype=torch.int32, device="cuda")     # requant(X . W1), or the converted X'
         if use_xw:    # T = requant(X . W1): X [k, F] rows layout
             X = oracle.pack(rand_q(rng, k, F, b), b, False)
             dX = torch.from_numpy(X.view(np.int32)).cuda()
@@ -605,7 +633,7 @@ def test_chain_entries_random_sweep(lib, oracle, seed):
             t_o = oracle.pack(rand_q(rng, k, H, b), b, True)
             dX = torch.from_numpy(t_o.view(np.int32)).cuda()
             assert lib.qgtc_chain_from_cols(dX.data_ptr(), dX.numel(), k, H, b, T.data_ptr(), T.numel(), st) == 0
-        T2 = torch.full((int(lib.qgtc_chain_words(m, C)),), -1, dtype=torch.int32, device="cuda")
+        T2 = torch.full((int(lib.qgtc_chain_words(m, C, b)),), -1, dtype=torch.int32, device="cuda")
         out = torch.full((m * C,), -7.0, dtype=torch.float32, device="cuda")
         occ = None
         if bitmaps:

@@ -112,14 +112,19 @@ def test_epoch_pool_layout_is_host_side(lib, oracle):
     offs = (ctypes.c_uint64 * (4 * len(ns)))()
     total = lib.qgtc_epoch_pool_layout(ctypes.addressof(nodes), len(ns), ctypes.addressof(stages), 4, ctypes.addressof(offs))
     sizes = [oracle.cols_words(n, 128, 2, False) for n in ns] + [oracle.rows_words(n, 128, 3) for n in ns] + [(n * 10 + 3) // 4 * 4 for n in ns] \
-        + [lib.qgtc_chain_words(n, 100) for n in ns]                       # fmt 1: the chain format of qgtc_chain_*
-    assert [lib.qgtc_chain_words(n, 100) for n in ns] == [(n + 127) // 128 * 128 * 16 for n in ns]
+        + [lib.qgtc_chain_words(n, 100, 2) for n in ns]                       # fmt 1: the chain format of qgtc_chain_*
+    assert [lib.qgtc_chain_words(n, 100, 2) for n in ns] == [(n + 127) // 128 * 128 * 16 for n in ns]
     lib.qgtc_adj_tiles_words.restype = ctypes.c_size_t                     # 512-byte tiles: [32-row block][k-quad][32 rows][4 words]
     assert lib.qgtc_adj_tiles_words(1213, 1213) == 38 * 10 * 128 and lib.qgtc_adj_tiles_words(1, 129) == 2 * 128 and lib.qgtc_adj_tiles_words(0, 5) == 0
     assert lib.qgtc_weight_codes_words(128, 100, 2, 1) == 4 * 2 * 64 * 4 and lib.qgtc_weight_codes_words(64, 50, 4, 1) == 2 * 2 * 2 * 64 * 4
     assert lib.qgtc_weight_codes_words(128, 70, 3, 0) == 4 * 2 * 2 * 64 * 4      # three column blocks are kept as four (the fourth: zero codes)
     assert lib.qgtc_weight_codes_words(602, 128, 2, 0) == 5 * 4 * 2 * 64 * 4     # order 0: a table per k-quad of K (ABI 11)
-    assert lib.qgtc_weight_codes_words(602, 128, 2, 1) == 4 * 2 * 64 * 4 and lib.qgtc_weight_codes_words(0, 128, 2, 0) == 0
+    assert lib.qgtc_weight_codes_words(128, 128, 2, 1) == 4 * 2 * 64 * 4 and lib.qgtc_weight_codes_words(0, 128, 2, 0) == 0
+    # ABI 11's wider chains: 129 .. 256 columns of K in the second product take four 64-column slices a column block, five to seven
+    # column blocks are kept as eight; 5 .. 8-bit weights are four base-4 digits; T at 5 .. 8 bits is two arrays of the 4-bit form
+    assert lib.qgtc_weight_codes_words(200, 200, 2, 1) == 8 * 4 * 64 * 4 and lib.qgtc_weight_codes_words(602, 128, 2, 1) == 0
+    assert lib.qgtc_weight_codes_words(128, 128, 8, 1) == 4 * 2 * 4 * 64 * 4 and lib.qgtc_weight_codes_words(128, 128, 5, 0) == 4 * 2 * 4 * 64 * 4
+    assert lib.qgtc_chain_words(1213, 128, 8) == 2 * lib.qgtc_chain_words(1213, 128, 4) and lib.qgtc_chain_words(1213, 200, 2) == 10 * 256 * 16
     assert total == sum(sizes)
     assert list(offs) == [sum(sizes[:i]) for i in range(len(sizes))]
     assert lib.qgtc_epoch_pool_layout(None, 3, ctypes.addressof(stages), 3, None) == 0

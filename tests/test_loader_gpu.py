@@ -101,7 +101,7 @@ def _adj_tiles(qgtc, dA, n):
 def _chain_from_cols(qgtc, dX, n, F, bits):
     import torch
     lib = _lib()
-    words = lib.qgtc_chain_words(n, F)
+    words = lib.qgtc_chain_words(n, F, bits)
     out = torch.empty(words, dtype=torch.int32, device="cuda")
     vp, sz = ctypes.c_void_p, ctypes.c_size_t
     lib.qgtc_chain_from_cols.argtypes = [vp, sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, sz, vp]

@@ -18,7 +18,7 @@ int main(int argc, char **argv) {
     const double extra = argc > 6 ? atof(argv[6]) : 0.03;
     const int bits = getenv("BITS") ? atoi(getenv("BITS")) : 2;   // 2 (N1, N2 <= 128) or 4 (<= 64): the widths of the two epochs
     std::mt19937 rng(3);
-    const size_t aw = qgtc_rows_words(n, n, 1), tw = qgtc_chain_words(n, N1), t2w = mode2 == 1 ? qgtc_chain_words(n, N2) : (size_t)n * (mode2 == 0 ? N1 : N2);
+    const size_t aw = qgtc_rows_words(n, n, 1), tw = qgtc_chain_words(n, N1, bits), t2w = mode2 == 1 ? qgtc_chain_words(n, N2, bits) : (size_t)n * (mode2 == 0 ? N1 : N2);
     const int rw = (n + 127) / 128 * 4;
     std::vector<uint32_t> ha(aw, 0u);
     std::bernoulli_distribution far(extra);
@@ -148,7 +148,7 @@ int main(int argc, char **argv) {
     }
     if (getenv("EPOCH")) {   // the Cluster-GCN epoch (four chain-entry launches) on the same synthetic batches, F = H = 128, C = 10
         const int F = 128, H = 128, C = 10;
-        const size_t xw_ = qgtc_rows_words(n, F, 2), th = qgtc_chain_words(n, H), tc = qgtc_chain_words(n, C);
+        const size_t xw_ = qgtc_rows_words(n, F, 2), th = qgtc_chain_words(n, H, bits), tc = qgtc_chain_words(n, C, bits);
         uint32_t *dX, *dT1, *dT2, *dT3, *dW1, *dW2, *dW3, *c1, *c2, *c3;
         float *dout;
         CK(hipMalloc(&dX, xw_ * 4 * count)); CK(hipMalloc(&dT1, th * 4 * count)); CK(hipMalloc(&dT2, th * 4 * count)); CK(hipMalloc(&dT3, tc * 4 * count));
