@@ -465,7 +465,7 @@ def test_chain_entries_with_raw_descriptors(lib, oracle, M, K, F, H, C, bitmaps,
     # ADVICE r4 / ABI 11: the capacity of `codes` travels with the job - a table sized for ONE k-quad (what ABI 10's two-argument size
     # helper returned) is QGTC_ESIZE for a K of several, never a device write past the buffer
     one_kq = int(lib.qgtc_weight_codes_words(128, H, b, 0))
-    assert int(lib.qgtc_weight_codes_words(F, H, b, 0)) == one_kq * ((F + 127) // 128) and int(lib.qgtc_weight_codes_words(F, H, b, 1)) == one_kq
+    assert int(lib.qgtc_weight_codes_words(F, H, b, 0)) == one_kq * ((F + 127) // 128) and int(lib.qgtc_weight_codes_words(min(F, 128), H, b, 1)) == one_kq
     small = (QgtcExpandJob * 1)(QgtcExpandJob(dW1.data_ptr(), c1.data_ptr(), dW1.numel(), F, H, b, P128(H), 0, one_kq - 1))
     assert lib.qgtc_expand_weights(ctypes.addressof(small), 1, st) == 2, "QGTC_ESIZE"
     if F > 128:
