@@ -87,46 +87,52 @@ __global__ __launch_bounds__(256) void k_rbx_xw(const qgtc_problem *__restrict__
         const_cast<uint32_t *>(pr.X), 0, static_cast<int>(static_cast<uint32_t>(pr.x_words) * 4u), 0x00020000);
     const int kq_x = step128(pr.K), kq = kq_tables < kq_x ? kq_tables : kq_x;   // (the loop bound is the HOST's: w_codes is a raw pointer)
     const uint32_t row_bytes = static_cast<uint32_t>(kq_x) * 16u, x_plane = static_cast<uint32_t>(pad8(M)) * row_bytes;
-    f32x16 accs[NCB];
-#pragma unroll
-    for (int jn = 0; jn < NCB; jn++) accs[jn] = f32x16_zero();
-    for (int q = 0; q < kq; q++) {   // (wave-uniform)
-        uint32_t xl[2][NA];   // [k half][plane]: words 2 fh, 2 fh + 1 of k-quad q of the lane's row
-#pragma unroll
-        for (int p = 0; p < NA; p++) {
-            const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, (m < M && p < a_planes) ? static_cast<uint32_t>(p) * x_plane + static_cast<uint32_t>(m) * row_bytes + static_cast<uint32_t>(q) * 16u + 8u * fh : 0xffffffffu, 0, 0));
-            xl[0][p] = v.x;
-            xl[1][p] = v.y;
-        }
-        const u32x4 *wq = w_codes + static_cast<size_t>(q) * table_blocks * 2 * NDW * 64;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            i32x8 xa[NDA];
-#pragma unroll
-            for (int da = 0; da < NDA; da++) xa[da] = fp4_op(strip_operand<NA>(xl[h], da));
-#pragma unroll
-            for (int jn = 0; jn < NCB; jn++)
-#pragma unroll
-                for (int dw = 0; dw < NDW; dw++) {
-                    const u32x4 w = wq[((jn * 2 + h) * NDW + dw) * 64 + lane];
-#pragma unroll
-                    for (int da = 0; da < NDA; da++)
-                        accs[jn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[da], fp4_op(w), accs[jn], 4, 4, 0, 128 + 2 * da, 0, 128 + 2 * dw);   // not swapped: lane = column 32 jn + fl
-                }
-        }
-    }
     const size_t half_words = static_cast<size_t>(step128(M)) * lines * 16u;
     uint32_t *tbase = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(grp * 4 + wv) * lines * 4;   // word wv of k-quad grp
+    // PASSES of at most four column blocks: eight blocks' accumulators (128 registers) leave one wave per SIMD, and a launch of 750
+    // four-wave workgroups then runs in three rounds on 256 CUs. A pass re-reads the lane's words of X (8 bytes a plane) and expands them again.
+    constexpr int JP = NCB > 4 ? 4 : NCB;
 #pragma unroll
-    for (int jn = 0; jn < NCB; jn++) {
-        const int n = 32 * jn + fl;
-        uint32_t P[4], H[4];
-        rbx_requant(accs[jn], ob, P);
-        rbx_half(P, 0, H);
-        rbx_store_codes(H, tbase + static_cast<size_t>(n) * 4, fh, n < lines);
-        if (ob > 4) {   // (launch-uniform)
-            rbx_half(P, 1, H);
-            rbx_store_codes(H, tbase + half_words + static_cast<size_t>(n) * 4, fh, n < lines);
+    for (int jp = 0; jp < NCB; jp += JP) {
+        f32x16 accs[JP];
+#pragma unroll
+        for (int jn = 0; jn < JP; jn++) accs[jn] = f32x16_zero();
+        for (int q = 0; q < kq; q++) {   // (wave-uniform)
+            uint32_t xl[2][NA];   // [k half][plane]: words 2 fh, 2 fh + 1 of k-quad q of the lane's row
+#pragma unroll
+            for (int p = 0; p < NA; p++) {
+                const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, (m < M && p < a_planes) ? static_cast<uint32_t>(p) * x_plane + static_cast<uint32_t>(m) * row_bytes + static_cast<uint32_t>(q) * 16u + 8u * fh : 0xffffffffu, 0, 0));
+                xl[0][p] = v.x;
+                xl[1][p] = v.y;
+            }
+            const u32x4 *wq = w_codes + static_cast<size_t>(q) * table_blocks * 2 * NDW * 64;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                i32x8 xa[NDA];
+#pragma unroll
+                for (int da = 0; da < NDA; da++) xa[da] = fp4_op(strip_operand<NA>(xl[h], da));
+#pragma unroll
+                for (int jn = 0; jn < JP; jn++)
+#pragma unroll
+                    for (int dw = 0; dw < NDW; dw++) {
+                        const u32x4 w = wq[(((jp + jn) * 2 + h) * NDW + dw) * 64 + lane];
+#pragma unroll
+                        for (int da = 0; da < NDA; da++)
+                            accs[jn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[da], fp4_op(w), accs[jn], 4, 4, 0, 128 + 2 * da, 0, 128 + 2 * dw);   // not swapped: lane = column 32 (jp + jn) + fl
+                    }
+            }
+        }
+#pragma unroll
+        for (int jn = 0; jn < JP; jn++) {
+            const int n = 32 * (jp + jn) + fl;
+            uint32_t P[4], H[4];
+            rbx_requant(accs[jn], ob, P);
+            rbx_half(P, 0, H);
+            rbx_store_codes(H, tbase + static_cast<size_t>(n) * 4, fh, n < lines);
+            if (ob > 4) {   // (launch-uniform)
+                rbx_half(P, 1, H);
+                rbx_store_codes(H, tbase + half_words + static_cast<size_t>(n) * 4, fh, n < lines);
+            }
         }
     }
 }
@@ -137,8 +143,13 @@ __global__ __launch_bounds__(256) void k_rbx_xw(const qgtc_problem *__restrict__
 //   MODE2 2: out = float32(requant(A . T) . W') [M, N2]
 // ND: digits of T's values (and of the aggregate's and of W''s: a chain has one width). NCB1 / NCB2: column blocks of T / of the output.
 // ------------------------------------------------------------------------------------------
+// (which instantiations get 256 registers a wave instead of 168: the ones hipcc spills at three waves per SIMD - resource report of
+// -Rpass-analysis=kernel-resource-usage; the eight-by-eight ones hold 64 KB of W' in LDS and run two workgroups a CU anyway)
+constexpr bool rbx_two_waves(int nd, int mode2, int ncb1, int ncb2) {
+    return (nd >= 2 && ncb1 * nd >= 16) || ncb1 * ncb2 == 64 || (nd == 1 && mode2 == 2 && ncb1 == 8 && ncb2 == 1);
+}
 template <int ND, int MODE2, int NCB1, int NCB2>
-__global__ __launch_bounds__(256) void k_rbx_chain(const qgtc_problem *__restrict__ prs, const qgtc_problem *__restrict__ prs2, const u32x4 *__restrict__ w2_codes,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(rbx_two_waves(ND, MODE2, NCB1, NCB2) ? 2 : 3, 4))) void k_rbx_chain(const qgtc_problem *__restrict__ prs, const qgtc_problem *__restrict__ prs2, const u32x4 *__restrict__ w2_codes,
                                                    int per, int tiles, int gx, int gy, int ob) {
     constexpr int NH = ND > 2 ? 2 : 1;            // arrays of T (nibble planes of a value)
     constexpr int DPN = ND > 1 ? 2 : 1;           // digits in a nibble
@@ -189,45 +200,14 @@ __global__ __launch_bounds__(256) void k_rbx_chain(const qgtc_problem *__restric
     if constexpr (MODE2 != 0) __syncthreads();
     if (MODE2 != 1 && 32 * rb >= M) return;   // (float32 rows: no rows here; T' still needs its padding words)
 
-    // ---- first product: acc[j] = (A . T)[row fl][columns 32 j + t + 8 gq + 4 fh], swapped operands
-    f32x16 acc[NCB1];
-#pragma unroll
-    for (int j = 0; j < NCB1; j++) acc[j] = f32x16_zero();
+    // ---- first product: acc[j] = (A . T)[row fl][columns 32 j + t + 8 gq + 4 fh], swapped operands - in PASSES of at most four column
+    // blocks of T (k_rbx_xw has the reason); a pass walks the occupied k-quads again (8 bytes of A a lane and k-quad, its own lines of T)
     bool any = false;   // (wave-uniform)
+    unsigned long long occupied = 0ull;
     if (32 * rb < M) {
         const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(todo)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(todo >> 32));
-        unsigned long long left = (static_cast<unsigned long long>(hi) << 32) | lo;
-        any = left != 0ull;
-        constexpr int JG = NCB1 * NH > 8 ? 4 : NCB1;   // column blocks whose loads of T are in flight together
-        while (left != 0ull) {
-            const int q = __builtin_ctzll(left);
-            left &= left - 1ull;
-            const u32x2 xs = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, x_base != 0xffffffffu ? x_base + static_cast<uint32_t>(q) * xq_bytes + 8u * fh : 0xffffffffu, 0, 0));
-            const uint32_t t_lane = (static_cast<uint32_t>(q) * 4u * static_cast<uint32_t>(lines) + static_cast<uint32_t>(2 * fh * lines + fl)) * 16u;   // word 2 fh of k-quad q, line fl
-#pragma unroll
-            for (int j0 = 0; j0 < NCB1; j0 += JG) {
-                u32x4 tl[JG][2][NH];
-#pragma unroll
-                for (int j = 0; j < JG; j++)
-#pragma unroll
-                    for (int h = 0; h < 2; h++)
-#pragma unroll
-                        for (int hv = 0; hv < NH; hv++)
-                            tl[j][h][hv] = __builtin_amdgcn_raw_buffer_load_b128(rt, t_lane + static_cast<uint32_t>(hv) * half_bytes + static_cast<uint32_t>(h * lines + 32 * (j0 + j)) * 16u, 0, 0);
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const uint32_t xw[1] = {xs[h]};
-                    const i32x8 xa = fp4_op(strip_operand<1>(xw, 0));
-#pragma unroll
-                    for (int j = 0; j < JG; j++)
-#pragma unroll
-                        for (int hv = 0; hv < NH; hv++)
-#pragma unroll
-                            for (int dd = 0; dd < DPN; dd++)
-                                acc[j0 + j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(rbx_digit<ND>(tl[j][h][hv], dd), xa, acc[j0 + j], 4, 4, 0, 128 + 2 * (2 * hv + dd), 0, 128);
-                }
-            }
-        }
+        occupied = (static_cast<unsigned long long>(hi) << 32) | lo;
+        any = occupied != 0ull;
     }
     if (!any) {
         // No occupied k-quad, or a padding block of T': zeros out
@@ -250,34 +230,72 @@ __global__ __launch_bounds__(256) void k_rbx_chain(const qgtc_problem *__restric
         }
         return;
     }
-    if constexpr (MODE2 == 0) {   // float32 [M, N] (kernel.h:915-930)
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(pr.out, 0, static_cast<int>(static_cast<uint32_t>(M) * static_cast<uint32_t>(N) * 4u), 0x00020000);
-        const uint32_t row_off = m < M ? static_cast<uint32_t>(m) * static_cast<uint32_t>(N) * 4u : 0xffffffffu;
-#pragma unroll
-        for (int j = 0; j < NCB1; j++) rbw_store_f32_row(ro, row_off, acc[j], 32 * j, fh, N);
-        return;
-    } else {
-        // ---- the aggregate's row as the second product's left operand, straight from the registers: XA[hv][mm] = the nibble codes of
-        // bits 4 hv .. 4 hv + 3 of the lane's 32 values of column blocks 2 mm, 2 mm + 1 (rbw_column's order)
-        uint32_t XA[NH][MH][4];
+    // the aggregate's row as the second product's left operand, straight from the registers: XA[hv][mm] = the nibble codes of bits
+    // 4 hv .. 4 hv + 3 of the lane's 32 values of column blocks 2 mm, 2 mm + 1 (rbw_column's order)
+    uint32_t XA[NH][MH][4];
+    if constexpr (MODE2 != 0) {
 #pragma unroll
         for (int hv = 0; hv < NH; hv++)
 #pragma unroll
             for (int mm = 0; mm < MH; mm++)
 #pragma unroll
                 for (int d = 0; d < 4; d++) XA[hv][mm][d] = 0u;
+    }
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(pr.out, 0, MODE2 == 0 ? static_cast<int>(static_cast<uint32_t>(M) * static_cast<uint32_t>(N) * 4u) : 0, 0x00020000);
+    constexpr int JP = NCB1 > 4 ? 4 : NCB1;
 #pragma unroll
-        for (int j = 0; j < NCB1; j++) {
-            uint32_t P[4];
-            rbx_requant(acc[j], ob, P);
+    for (int jp = 0; jp < NCB1; jp += JP) {
+        f32x16 acc[JP];
 #pragma unroll
-            for (int hv = 0; hv < NH; hv++) {
-                uint32_t H[4];
-                rbx_half(P, hv, H);
-                XA[hv][j >> 1][2 * (j & 1)] = H[0] | (H[1] << 4);
-                XA[hv][j >> 1][2 * (j & 1) + 1] = H[2] | (H[3] << 4);
+        for (int j = 0; j < JP; j++) acc[j] = f32x16_zero();
+        unsigned long long left = occupied;
+        while (left != 0ull) {
+            const int q = __builtin_ctzll(left);
+            left &= left - 1ull;
+            const u32x2 xs = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, x_base != 0xffffffffu ? x_base + static_cast<uint32_t>(q) * xq_bytes + 8u * fh : 0xffffffffu, 0, 0));
+            const uint32_t t_lane = (static_cast<uint32_t>(q) * 4u * static_cast<uint32_t>(lines) + static_cast<uint32_t>(2 * fh * lines + fl)) * 16u;   // word 2 fh of k-quad q, line fl
+            u32x4 tl[JP][2][NH];
+#pragma unroll
+            for (int j = 0; j < JP; j++)
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int hv = 0; hv < NH; hv++)
+                        tl[j][h][hv] = __builtin_amdgcn_raw_buffer_load_b128(rt, t_lane + static_cast<uint32_t>(hv) * half_bytes + static_cast<uint32_t>(h * lines + 32 * (jp + j)) * 16u, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t xw[1] = {xs[h]};
+                const i32x8 xa = fp4_op(strip_operand<1>(xw, 0));
+#pragma unroll
+                for (int j = 0; j < JP; j++)
+#pragma unroll
+                    for (int hv = 0; hv < NH; hv++)
+#pragma unroll
+                        for (int dd = 0; dd < DPN; dd++)
+                            acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(rbx_digit<ND>(tl[j][h][hv], dd), xa, acc[j], 4, 4, 0, 128 + 2 * (2 * hv + dd), 0, 128);
             }
         }
+        if constexpr (MODE2 == 0) {   // float32 [M, N] (kernel.h:915-930)
+            const uint32_t row_off = m < M ? static_cast<uint32_t>(m) * static_cast<uint32_t>(N) * 4u : 0xffffffffu;
+#pragma unroll
+            for (int j = 0; j < JP; j++) rbw_store_f32_row(ro, row_off, acc[j], 32 * (jp + j), fh, N);
+        } else {
+#pragma unroll
+            for (int j = 0; j < JP; j++) {
+                uint32_t P[4];
+                rbx_requant(acc[j], ob, P);
+#pragma unroll
+                for (int hv = 0; hv < NH; hv++) {
+                    uint32_t H[4];
+                    rbx_half(P, hv, H);
+                    XA[hv][(jp + j) >> 1][2 * ((jp + j) & 1)] = H[0] | (H[1] << 4);
+                    XA[hv][(jp + j) >> 1][2 * ((jp + j) & 1) + 1] = H[2] | (H[3] << 4);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (a pass ends here: interleaved with the next one, the two passes' loads and accumulators were live together)
+    }
+    if constexpr (MODE2 != 0) {
         const int N2 = pr2.N, lines2 = pad128(N2);
         const size_t half2 = static_cast<size_t>(step128(M)) * lines2 * 16u;
         uint32_t *tbase = static_cast<uint32_t *>(pr2.out) + static_cast<size_t>(grp * 4 + wv) * lines2 * 4;   // word wv of k-quad grp
@@ -322,6 +340,7 @@ __global__ __launch_bounds__(256) void k_rbx_chain(const qgtc_problem *__restric
                     }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);   // (a group of output column blocks ends here)
         }
     }
 }
