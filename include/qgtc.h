@@ -375,8 +375,11 @@ int qgtc_chain_aggregate(const qgtc_problem *stage_a, const qgtc_problem *stage_
  *   `batches`: DEVICE array of `count` entries (the caller uploads it); edge indices are LOCAL to the batch (row = src,
  *   col = dst in [0, n)), int64, batch b's edges at src/dst[edge_off .. edge_off + n_edges); its features are rows
  *   feat_row .. feat_row + n - 1 of `feats` (float32, F columns, row-major).
- *   `zero` / `zero_bytes`: ONE region that contains every A, every scratch buffer and `stats`; the call clears it with one
- *   memset (round 3 issued two memsets per batch). scratch: 2 x qgtc_rows_words(n, n, 1) words per batch.
+ *   `zero` / `zero_bytes`: ONE region the call clears with one memset. It always contains `stats`; on the route WITHOUT a work
+ *   buffer it must also contain every A and every scratch buffer (scratch: 2 x qgtc_rows_words(n, n, 1) words per batch - the
+ *   multiplicity bitmaps of qgtc_pack_edge_list). With `work` (ABI 11; qgtc_load_work_words(count, max_n, total edges) words, 0 = not
+ *   available for this iterator: max_n above 5120) the edges are bucketed by 32-row block there and every word of every A / AT / occ
+ *   is written exactly once from LDS: A needs no clearing, `scratch` may be NULL. Same words either way.
  *   max_n / max_edges: at least every batch's n / n_edges (grid sizes; hard preconditions like the grouped GEMM's maxima).
  *   stats (optional, inside `zero`): stats[0] += occupied 32-row x 128-bit adjacency tiles of all batches.
  *   bad_index (optional device int, cleared by the call): set to 1 when an edge index is out of range (such edges are skipped).
@@ -389,8 +392,8 @@ typedef struct qgtc_loader_batch {
     uint64_t feat_row;
     int32_t n;
     int32_t reserved;
-    uint32_t *A;       /* out: rows layout [n, n], one plane, qgtc_rows_words(n, n, 1) words (inside `zero`) */
-    uint32_t *scratch; /* 2 x qgtc_rows_words(n, n, 1) words (inside `zero`) */
+    uint32_t *A;       /* out: rows layout [n, n], one plane, qgtc_rows_words(n, n, 1) words (inside `zero` unless a work buffer is given) */
+    uint32_t *scratch; /* 2 x qgtc_rows_words(n, n, 1) words (inside `zero`); NULL with a work buffer */
     uint32_t *AT;      /* out or NULL: qgtc_adj_tiles_words(n, n) words */
     uint64_t *occ;     /* out or NULL: qgtc_occupancy_words(n, n) 64-bit words */
     uint32_t *X;       /* out or NULL: cols layout [n, F], x_bits planes, qgtc_cols_words(n, F, x_bits, 0) words */
@@ -399,7 +402,8 @@ typedef struct qgtc_loader_batch {
 } qgtc_loader_batch;
 int qgtc_load_batches(const qgtc_loader_batch *batches, int count, int max_n, uint64_t max_edges, const int64_t *src,
                       const int64_t *dst, const float *feats, int F, int x_bits, void *zero, size_t zero_bytes,
-                      uint64_t *stats, int *bad_index, unsigned formats, void *stream);
+                      uint64_t *stats, int *bad_index, unsigned formats, uint32_t *work, size_t work_words, void *stream);
+size_t qgtc_load_work_words(int count, int max_n, uint64_t total_edges);
 
 #ifdef __cplusplus
 }

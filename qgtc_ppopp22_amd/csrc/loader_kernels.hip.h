@@ -79,6 +79,136 @@ __global__ __launch_bounds__(256) void k_load_finish(const qgtc_loader_batch *__
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The adjacency WITHOUT dense multiplicity bitmaps (round 5; VERDICT r4 weak 10: k_load_finish moved 73 MB for 14 MB of adjacency).
+// The route above sets one device-scope atomic per edge into a zeroed bitmap (537 k atomics: 18 us on the ogbn-arxiv-sized iterator -
+// tools/atomic_probe.hip: the memory side takes ~18 G of them a second wherever they land), needs the three bitmaps cleared
+// (41 MB of memset) and reads all three back densely to write rows + tiles (k_load_finish: 43 us). Here:
+//   k_load_sort   one workgroup per batch buckets the batch's edges by 32-ROW BLOCK: histogram in LDS, scan, scatter of the edges as
+//                 32-bit (row in block, column) words into the caller's work buffer - no global atomic, the edge list read twice;
+//   k_load_tiles  one wave per (batch, row block) builds the block's 32 x n bits in LDS from its bucket (LDS atomics; the three
+//                 multiplicity bitmaps of k_edge_list_count live THERE: a few KB) and writes every word of the block's rows, its
+//                 512-byte tiles and its occupancy word exactly once: nothing to clear first, nothing read back.
+// Same words as the route above (tests/test_loader_gpu.py compares both with the oracle). Limits: max_n <= LOAD_SORT_MAX_N (the three
+// bitmaps of a row block in 64 KB of LDS); larger batches take the route above.
+// ------------------------------------------------------------------------------------------
+constexpr int LOAD_SORT_MAX_KQ = 40, LOAD_SORT_MAX_N = LOAD_SORT_MAX_KQ * 128;   // 3 x 40 x 512 bytes = 60 KB of LDS a row block
+constexpr int LOAD_SORT_THREADS = 1024;
+
+// work: [count x (RB + 1) bucket offsets | the buckets of batch 0 | batch 1 | ..] with RB = row blocks of the largest batch; batch b's
+// edges sit at the offset its edge list has in src / dst. A batch whose buckets would not fit in work_words is skipped and reported.
+__global__ __launch_bounds__(LOAD_SORT_THREADS) void k_load_sort(const qgtc_loader_batch *__restrict__ tb, const int64_t *__restrict__ src,
+                                                                 const int64_t *__restrict__ dst, uint32_t *__restrict__ work,
+                                                                 unsigned long long work_words, int rb_max, int count, int *__restrict__ bad) {
+    __shared__ unsigned hist[LOAD_SORT_MAX_N / 32 + 1];
+    __shared__ unsigned wave_sum[LOAD_SORT_THREADS / 64];
+    const qgtc_loader_batch b = tb[blockIdx.x];
+    const int n = b.n, tid = threadIdx.x, tiles_m = (n + 31) / 32;
+    uint32_t *offs = work + static_cast<size_t>(blockIdx.x) * (rb_max + 1);
+    uint32_t *bucket = work + static_cast<size_t>(count) * (rb_max + 1) + b.edge_off;
+    const bool fits = static_cast<unsigned long long>(count) * (rb_max + 1) + b.edge_off + b.n_edges <= work_words && tiles_m <= rb_max;
+    for (int i = tid; i <= rb_max; i += LOAD_SORT_THREADS) hist[i] = 0u;
+    __syncthreads();
+    if (!fits) {
+        if (tid == 0 && bad) *bad = 1;
+        for (int i = tid; i <= rb_max; i += LOAD_SORT_THREADS) offs[i] = 0u;   // (empty buckets: the batch's adjacency comes out zero)
+        return;
+    }
+    const int64_t *s = src + b.edge_off, *d = dst + b.edge_off;
+    for (unsigned long long e = tid; e < b.n_edges; e += LOAD_SORT_THREADS) {
+        const int64_t r = s[e], c = d[e];
+        if (r < 0 || r >= n || c < 0 || c >= n) {
+            if (bad) *bad = 1;
+            continue;
+        }
+        atomicAdd(&hist[static_cast<int>(r) >> 5], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the (at most LOAD_SORT_MAX_N / 32 = 160) bucket sizes: one element a thread, wave scans + the waves' totals
+    {
+        const unsigned v = tid < tiles_m ? hist[tid] : 0u;
+        unsigned incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(incl, o);
+            if ((tid & 63) >= o) incl += t;
+        }
+        if ((tid & 63) == 63) wave_sum[tid >> 6] = incl;
+        __syncthreads();
+        unsigned before = 0u;
+        for (int w = 0; w < (tid >> 6); w++) before += wave_sum[w];
+        __syncthreads();
+        if (tid <= rb_max) {
+            const unsigned start = tid < tiles_m ? before + incl - v : 0u;
+            hist[tid] = start;            // now the bucket's cursor
+            if (tid < tiles_m) offs[tid] = start;
+        }
+        if (tid == tiles_m - 1) {         // the end of the last bucket; the unused tail of the table points there too
+            for (int i = tiles_m; i <= rb_max; i++) offs[i] = before + incl;
+        }
+    }
+    __syncthreads();
+    for (unsigned long long e = tid; e < b.n_edges; e += LOAD_SORT_THREADS) {
+        const int64_t r = s[e], c = d[e];
+        if (r < 0 || r >= n || c < 0 || c >= n) continue;
+        const unsigned slot = atomicAdd(&hist[static_cast<int>(r) >> 5], 1u);
+        bucket[slot] = (static_cast<uint32_t>(r) & 31u) << 27 | static_cast<uint32_t>(c);
+    }
+}
+
+// One wave (a 64-thread workgroup) per (row block, batch). LDS: t1 | t2 | t3, each [32 rows][kq k-quads][4 words] of the block.
+__global__ __launch_bounds__(64) void k_load_tiles(const qgtc_loader_batch *__restrict__ tb, const uint32_t *__restrict__ work, int rb_max, int count,
+                                                   unsigned long long *__restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const qgtc_loader_batch b = tb[blockIdx.y];
+    const int n = b.n, kq = step128(n), tiles_m = (n + 31) / 32, rb = blockIdx.x, lane = threadIdx.x;
+    if (rb >= tiles_m) return;
+    const int row_words = kq * 4, tw = 32 * row_words;   // words of one bitmap of the block
+    uint32_t *t1 = lds, *t2 = lds + tw, *t3 = lds + 2 * tw;
+    for (int i = lane; i < 3 * tw / 4; i += 64) reinterpret_cast<u32x4 *>(lds)[i] = u32x4{0u, 0u, 0u, 0u};
+    const uint32_t *offs = work + static_cast<size_t>(blockIdx.y) * (rb_max + 1);
+    const uint32_t *bucket = work + static_cast<size_t>(count) * (rb_max + 1) + b.edge_off;
+    const unsigned e0 = offs[rb], e1 = offs[rb + 1];
+    __syncthreads();
+    for (unsigned e = e0 + lane; e < e1; e += 64) {
+        const uint32_t pk = bucket[e];
+        const int r = static_cast<int>(pk >> 27), c = static_cast<int>(pk & 0x07ffffffu);
+        const uint32_t bit = 1u << (31 - (c & 31));
+        const int wi = r * row_words + (c >> 5);
+        if (atomicOr(&t1[wi], bit) & bit)                        // multiplicities 1, 2, >= 3 land in t1, t2, t3 (k_edge_list_count)
+            if (atomicOr(&t2[wi], bit) & bit) atomicOr(&t3[wi], bit);
+    }
+    __syncthreads();
+    // rows layout: [row][k-quad] - consecutive units of a row are contiguous (every row below pad8(n) is written, zeros past the edges)
+    const int units = 32 * kq, rows_here = min(32, pad8(n) - 32 * rb);
+    uint32_t *rows_out = b.A + static_cast<size_t>(32 * rb) * row_words;
+    for (int u = lane; u < units; u += 64) {
+        const int r = u / kq;
+        const u32x4 a = reinterpret_cast<const u32x4 *>(t1)[u], c2 = reinterpret_cast<const u32x4 *>(t2)[u], c3 = reinterpret_cast<const u32x4 *>(t3)[u];
+        const u32x4 v = {a.x & (~c2.x | c3.x), a.y & (~c2.y | c3.y), a.z & (~c2.z | c3.z), a.w & (~c2.w | c3.w)};   // the 1-bit quantiser's image of 1, 2, >= 3: 1, 0, 1
+        reinterpret_cast<u32x4 *>(t1)[u] = v;
+        if (r < rows_here) reinterpret_cast<u32x4 *>(rows_out)[u] = v;
+    }
+    __syncthreads();
+    // tiles [k-quad][32 rows][4 words] (512 contiguous bytes a tile) and the occupancy bits: lanes 0 .. 31 = the rows of k-quad 2 i, 32 .. 63 of 2 i + 1
+    unsigned long long mask_lo = 0ull;   // (kq <= 40: one 64-bit word per row block)
+    uint32_t *tile_out = b.AT ? b.AT + static_cast<size_t>(rb) * kq * 128u : nullptr;
+    for (int q0 = 0; q0 < kq; q0 += 2) {
+        const int q = q0 + (lane >> 5), r = lane & 31;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (q < kq) v = reinterpret_cast<const u32x4 *>(t1)[r * kq + q];
+        if (tile_out && q < kq) reinterpret_cast<u32x4 *>(tile_out)[q * 32 + r] = v;
+        const unsigned long long bal = __ballot(((v.x | v.y) | (v.z | v.w)) != 0u);
+        if (bal & 0xffffffffull) mask_lo |= 1ull << q0;
+        if (bal >> 32) mask_lo |= 1ull << (q0 + 1);
+    }
+    if (lane == 0) {
+        if (b.occ) b.occ[rb] = mask_lo;
+        if (stats && mask_lo) atomicAdd(stats, static_cast<unsigned long long>(__popcll(mask_lo)));
+    }
+}
+
 // val2bit of every batch's features (rows feat_row .. feat_row + n - 1 of `feats`, F columns): the cols layout the reference
 // packs (sampler.py:99) and the rows layout the layout-correct chain's first X.W reads. Same device code as the single
 // launches (pack_kernels.hip.h), so the same words; V4 = the float4 path (F % 4 == 0).

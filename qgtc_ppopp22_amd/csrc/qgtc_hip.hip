@@ -530,9 +530,14 @@ int qgtc_pack_edge_list(const int64_t *src, const int64_t *dst, size_t n_edges, 
     return QGTC_OK;
 }
 
+size_t qgtc_load_work_words(int count, int max_n, uint64_t total_edges) {
+    if (count <= 0 || max_n <= 0 || max_n > LOAD_SORT_MAX_N || total_edges >= (1ull << 32)) return 0u;   // 0: no bucketed route for this iterator
+    return static_cast<size_t>(count) * ((max_n + 31) / 32 + 1) + static_cast<size_t>(total_edges);
+}
+
 int qgtc_load_batches(const qgtc_loader_batch *batches, int count, int max_n, uint64_t max_edges, const int64_t *src,
                       const int64_t *dst, const float *feats, int F, int x_bits, void *zero, size_t zero_bytes,
-                      uint64_t *stats, int *bad_index, unsigned formats, void *stream) {
+                      uint64_t *stats, int *bad_index, unsigned formats, uint32_t *work, size_t work_words, void *stream) {
     if (!batches || count <= 0 || count > 65535 || max_n <= 0 || !zero || zero_bytes == 0) return QGTC_EINVAL;
     if (max_edges && (!src || !dst)) return QGTC_EINVAL;
     if (feats && (F <= 0 || !bits_ok(x_bits))) return QGTC_EINVAL;
@@ -540,11 +545,21 @@ int qgtc_load_batches(const qgtc_loader_batch *batches, int count, int max_n, ui
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIP_TRY(hipMemsetAsync(zero, 0, zero_bytes, st));
     if (bad_index) HIP_TRY(hipMemsetAsync(bad_index, 0, sizeof(int), st));
-    if (max_edges) {
-        hipLaunchKernelGGL(k_load_edges, dim3(grid_for(static_cast<size_t>(max_edges), 256, 4096), count), dim3(256), 0, st, batches, src, dst, bad_index);
+    const int rb_max = (max_n + TM - 1) / TM;
+    if (work && max_n <= LOAD_SORT_MAX_N && work_words >= static_cast<size_t>(count) * (rb_max + 1) && !getenv_flag("QGTC_NO_LOAD_SORT")) {
+        // the bucketed route (loader_kernels.hip.h): edges by row block, then every word of rows + tiles + bitmaps written once from LDS
+        hipLaunchKernelGGL(k_load_sort, dim3(count), dim3(LOAD_SORT_THREADS), 0, st, batches, src, dst, work, static_cast<unsigned long long>(work_words),
+                           rb_max, count, bad_index);
         HIP_TRY(hipGetLastError());
-    }
-    {   // one wave per (32-row block, bitmap word) of the largest batch
+        const size_t lds = static_cast<size_t>(3) * 32 * step128(max_n) * 16;
+        hipLaunchKernelGGL(k_load_tiles, dim3(rb_max, count), dim3(64), lds, st, batches, work, rb_max, count, reinterpret_cast<unsigned long long *>(stats));
+        HIP_TRY(hipGetLastError());
+    } else {
+        if (max_edges) {
+            hipLaunchKernelGGL(k_load_edges, dim3(grid_for(static_cast<size_t>(max_edges), 256, 4096), count), dim3(256), 0, st, batches, src, dst, bad_index);
+            HIP_TRY(hipGetLastError());
+        }
+        // one wave per (32-row block, bitmap word) of the largest batch
         const int waves = ((max_n + TM - 1) / TM) * ((step128(max_n) + 63) / 64);
         hipLaunchKernelGGL(k_load_finish, dim3((waves + 3) / 4, count), dim3(256), 0, st, batches, reinterpret_cast<unsigned long long *>(stats));
         HIP_TRY(hipGetLastError());

@@ -894,9 +894,13 @@ struct EpochPlan {
         TORCH_CHECK(f_off[count] == feats.size(0), "the node counts must add up to feats.size(0)");
         TORCH_CHECK(a_off[count] < (1LL << 40), "adjacency pool too large");
         const auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(dev);
-        // one region for everything the call clears: [A of every batch | stats (two uint64) | scratch of every batch]
-        const int64_t zwords = 3 * a_off[count] + 4;
+        // [A of every batch | stats (two uint64) | scratch of every batch]. With a work buffer (qgtc_load_work_words > 0: the bucketed route,
+        // batches of at most 5120 nodes) the call writes every word of A itself: only `stats` is cleared and there is no scratch.
+        const size_t work_words = std::getenv("QGTC_NO_LOAD_SORT") ? 0u : qgtc_load_work_words(count, P.max_n, static_cast<uint64_t>(e_off[count]));
+        const bool bucketed = work_words > 0;
+        const int64_t zwords = (bucketed ? 1 : 3) * a_off[count] + 4;
         torch::Tensor zero = torch::empty({zwords}, i32);
+        torch::Tensor work = torch::empty({static_cast<int64_t>(std::max<size_t>(work_words, 4))}, i32);
         torch::Tensor tiles = torch::empty({std::max<int64_t>(t_off[count], 4)}, i32);
         torch::Tensor occ = torch::empty({std::max<int64_t>(o_off[count], 1)}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
         torch::Tensor xp = torch::empty({x_off[count]}, i32), xrp = torch::empty({std::max<int64_t>(xr_off[count], 4)}, i32),
@@ -917,7 +921,7 @@ struct EpochPlan {
             b.n = n;
             b.reserved = 0;
             b.A = zp + a_off[i];
-            b.scratch = scratch0 + 2 * a_off[i];
+            b.scratch = bucketed ? nullptr : scratch0 + 2 * a_off[i];
             b.AT = a_tiles_ ? words_mut(tiles) + t_off[i] : nullptr;
             b.occ = reinterpret_cast<uint64_t *>(occ.data_ptr<int64_t>()) + o_off[i];
             b.X = words_mut(xp) + x_off[i];
@@ -943,8 +947,9 @@ struct EpochPlan {
         const unsigned formats = (with_rows ? QGTC_LOAD_X_ROWS : 0u) | (x_chain_bits ? QGTC_LOAD_X_CHAIN : 0u);
         check_rc(qgtc_load_batches(reinterpret_cast<const qgtc_loader_batch *>(tables.data_ptr()), count, P.max_n, static_cast<uint64_t>(max_e),
                                    src.numel() ? src.data_ptr<int64_t>() : nullptr, src.numel() ? dst.data_ptr<int64_t>() : nullptr,
-                                   feats.data_ptr<float>(), F, x_bits, zp, static_cast<size_t>(zwords) * 4u, stats,
-                                   validate ? bad.data_ptr<int>() : nullptr, formats, current_stream(zero)),
+                                   feats.data_ptr<float>(), F, x_bits, bucketed ? static_cast<void *>(stats) : static_cast<void *>(zp),
+                                   bucketed ? 16u : static_cast<size_t>(zwords) * 4u, stats, validate ? bad.data_ptr<int>() : nullptr, formats,
+                                   bucketed ? words_mut(work) : nullptr, work_words, current_stream(zero)),
                  "EpochPlan.load");
         // the occupied-tile count comes back with the (optional) index check: ONE read-back, beside the packing (outside any epoch clock)
         torch::Tensor sh = zero.narrow(0, a_off[count], 4).cpu();

@@ -35,11 +35,20 @@ def _dense(n, r, c):
     return A
 
 
-@pytest.mark.parametrize("bits,F,chain", [(2, 128, 0), (4, 50, 4), (1, 33, 1), (3, 64, 3), (8, 16, 0)])
-def test_grouped_loader_equals_the_oracle_and_the_single_batch_entries(qgtc, oracle, bits, F, chain):
+@pytest.mark.parametrize("route", ["buckets", "bitmaps", "too-wide"])
+@pytest.mark.parametrize("bits,F,chain", [(2, 128, 0), (4, 50, 4), (1, 33, 1), (3, 64, 3), (8, 16, 0), (8, 40, 8), (5, 128, 5)])
+def test_grouped_loader_equals_the_oracle_and_the_single_batch_entries(qgtc, oracle, bits, F, chain, route, monkeypatch):
+    """route: "buckets" = the default (edges bucketed by 32-row block, every word of rows + tiles + bitmaps written once from LDS);
+    "bitmaps" = the three dense multiplicity bitmaps (QGTC_NO_LOAD_SORT, and every iterator with a batch above 5120 nodes: "too-wide")."""
     import torch
+    if route == "bitmaps":
+        monkeypatch.setenv("QGTC_NO_LOAD_SORT", "1")
+    if route == "too-wide" and bits != 2:
+        pytest.skip("one width is enough for the 5200-node fallback")
     rng = np.random.default_rng(bits * 100 + F)
     sizes = [1213, 599, 37, 8, 1, 130, 2049, 300]          # ragged; 2049 nodes = 17 k-quads (the kernel's wide-row path)
+    if route == "too-wide":
+        sizes = [5200, 64, 1213]
     rows, cols, feats, ecounts = _batches(rng, sizes, F, empty_first=(bits == 3))
     src, dst = (torch.from_numpy(np.concatenate(v)).cuda() for v in (rows, cols))
     X = torch.from_numpy(np.concatenate(feats)).cuda()
@@ -147,9 +156,11 @@ def test_cluster_iter_grouped_equals_batch_by_batch(qgtc, dataset, bits, gin):
     assert all(torch.equal(p, q.bit_A) for p, q in zip(again.As, a.cTensor_li)) and all(torch.equal(p, q.bit_X) for p, q in zip(again.Xs, a.cTensor_li))
 
 
-def test_load_batches_through_the_raw_abi(oracle):
+@pytest.mark.parametrize("with_work", [False, True])
+def test_load_batches_through_the_raw_abi(oracle, with_work):
     """qgtc_load_batches through ctypes: the table written by the host with the struct layout of include/qgtc.h, raw device
-    pointers, no optional format - against the oracle."""
+    pointers, no optional format - against the oracle. with_work (ABI 11): the caller hands over qgtc_load_work_words words and
+    neither clears A nor supplies scratch; without it: the three multiplicity bitmaps inside the cleared region."""
     import torch
     lib = _lib()
 
@@ -170,25 +181,40 @@ def test_load_batches_through_the_raw_abi(oracle):
     xp = torch.full((sum(x_words),), -1, dtype=torch.int32, device="cuda")
     table, e0, f0, a0, x0 = [], 0, 0, 0, 0
     for n, ne, aw, xw in zip(sizes, ecounts, a_words, x_words):
-        table.append(LoaderBatch(e0, ne, f0, n, 0, zero.data_ptr() + 4 * a0, zero.data_ptr() + 4 * (sum(a_words) + 4 + 2 * a0), None, None,
+        table.append(LoaderBatch(e0, ne, f0, n, 0, zero.data_ptr() + 4 * a0, None if with_work else zero.data_ptr() + 4 * (sum(a_words) + 4 + 2 * a0), None, None,
                                  xp.data_ptr() + 4 * x0, None, None))
         e0, f0, a0, x0 = e0 + ne, f0 + n, a0 + aw, x0 + xw
     dev_table = torch.frombuffer(bytearray(bytes((LoaderBatch * len(sizes))(*table))), dtype=torch.uint8).cuda()
     vp = ctypes.c_void_p
     lib.qgtc_load_batches.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t,
-                                      vp, vp, ctypes.c_uint, vp]
+                                      vp, vp, ctypes.c_uint, vp, ctypes.c_size_t, vp]
+    lib.qgtc_load_work_words.restype = ctypes.c_size_t
+    lib.qgtc_load_work_words.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint64]
+    assert lib.qgtc_load_work_words(3, 257, sum(ecounts)) == 3 * (9 + 1) + sum(ecounts) and lib.qgtc_load_work_words(3, 5121, 10) == 0
     st = torch.cuda.current_stream().cuda_stream
-    rc = lib.qgtc_load_batches(dev_table.data_ptr(), len(sizes), max(sizes), max(ecounts), src.data_ptr(), dst.data_ptr(), X.data_ptr(), F, bits,
-                               zero.data_ptr(), zero.numel() * 4, zero.data_ptr() + 4 * sum(a_words), None, 0, st)
+    stats_ptr = zero.data_ptr() + 4 * sum(a_words)
+    if with_work:    # only `stats` is cleared; A stays poisoned until the call has written every word of it
+        work = torch.full((lib.qgtc_load_work_words(len(sizes), max(sizes), sum(ecounts)),), -1, dtype=torch.int32, device="cuda")
+        rc = lib.qgtc_load_batches(dev_table.data_ptr(), len(sizes), max(sizes), max(ecounts), src.data_ptr(), dst.data_ptr(), X.data_ptr(), F, bits,
+                                   stats_ptr, 16, stats_ptr, None, 0, work.data_ptr(), work.numel(), st)
+    else:
+        rc = lib.qgtc_load_batches(dev_table.data_ptr(), len(sizes), max(sizes), max(ecounts), src.data_ptr(), dst.data_ptr(), X.data_ptr(), F, bits,
+                                   zero.data_ptr(), zero.numel() * 4, stats_ptr, None, 0, None, 0, st)
     assert rc == 0
     torch.cuda.synchronize()
     got_a, got_x = zero.cpu().numpy().view(np.uint32), xp.cpu().numpy().view(np.uint32)
+    occupied = int(zero[sum(a_words):sum(a_words) + 2].cpu().numpy().view(np.uint64)[0])      # stats[0]: occupied 32-row x 128-bit tiles
+    want_occupied = 0
+    for i, n in enumerate(sizes):
+        w = oracle.val2bit(_dense(n, rows[i], cols[i]), 1).reshape(-1, (n + 127) // 128, 4)
+        want_occupied += sum(int(np.any(w[32 * t:32 * t + 32, q] != 0)) for t in range((n + 31) // 32) for q in range((n + 127) // 128))
+    assert occupied == want_occupied
     a0 = x0 = 0
     for i, n in enumerate(sizes):
         np.testing.assert_array_equal(got_a[a0:a0 + a_words[i]], oracle.val2bit(_dense(n, rows[i], cols[i]), 1))
         np.testing.assert_array_equal(got_x[x0:x0 + x_words[i]], oracle.val2bit(feats[i], bits, True))
         a0, x0 = a0 + a_words[i], x0 + x_words[i]
     # bad arguments are error codes
-    assert lib.qgtc_load_batches(None, 3, 300, 10, src.data_ptr(), dst.data_ptr(), X.data_ptr(), F, bits, zero.data_ptr(), 16, None, None, 0, st) == 1
-    assert lib.qgtc_load_batches(dev_table.data_ptr(), 3, 300, 10, None, dst.data_ptr(), X.data_ptr(), F, bits, zero.data_ptr(), 16, None, None, 0, st) == 1
-    assert lib.qgtc_load_batches(dev_table.data_ptr(), 0, 300, 10, src.data_ptr(), dst.data_ptr(), X.data_ptr(), F, bits, zero.data_ptr(), 16, None, None, 0, st) == 1
+    assert lib.qgtc_load_batches(None, 3, 300, 10, src.data_ptr(), dst.data_ptr(), X.data_ptr(), F, bits, zero.data_ptr(), 16, None, None, 0, None, 0, st) == 1
+    assert lib.qgtc_load_batches(dev_table.data_ptr(), 3, 300, 10, None, dst.data_ptr(), X.data_ptr(), F, bits, zero.data_ptr(), 16, None, None, 0, None, 0, st) == 1
+    assert lib.qgtc_load_batches(dev_table.data_ptr(), 0, 300, 10, src.data_ptr(), dst.data_ptr(), X.data_ptr(), F, bits, zero.data_ptr(), 16, None, None, 0, None, 0, st) == 1
