@@ -283,6 +283,14 @@ __global__ __launch_bounds__(256) void k_rbw_xw(const qgtc_problem *__restrict__
 //   MODE2 1: T' = requant(requant(A . T) . W')        chain format
 //   MODE2 2: out = float32(requant(A . T) . W')       [M, N2]
 // ------------------------------------------------------------------------------------------
+// -DQGTC_ABL_HALFWORK (timing-only, wrong sums; tools/rbw_bench): a wave does HALF of its matrix-core work and re-quantises half of its
+// column blocks - the ceiling of what a 16-row-block form of these kernels (twice the waves, half the chain a wave)
+// could take off a launch: its loads, its barrier and its dependent round trips stay as they are.
+#ifdef QGTC_ABL_HALFWORK
+#define RBW_HALF(cond) if (cond)
+#else
+#define RBW_HALF(cond)
+#endif
 #ifdef QGTC_RBW_STAMPS   // tools/rbw_bench.hip: s_memtime at the phases of a wave, kept in scalar registers
 #define RBW_STAMP(i) st_[i] = __builtin_amdgcn_s_memtime()
 #else
@@ -402,6 +410,7 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
             auto multiply_pair = [&]() {
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
+                    RBW_HALF(t < 2) {
                     const uint32_t xw[1] = {xl[t]};
                     const i32x8 xa = fp4_op(strip_operand<1>(xw, 0));
 #pragma unroll
@@ -415,6 +424,7 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
                                                                                      xa, acc[j], 4, 4, 0, 130, 0, 128);
                         }
                     }
+                    }
                 }
             };
             RBW_STAMP(3);
@@ -423,7 +433,7 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
             // operand of these MFMAs (64 v_mov less per row block) on every path
             if (!has_diag) xd = u32x2{0u, 0u};
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
+            for (int h = 0; h < 2; h++) RBW_HALF(h == 0) {
                 const uint32_t xw[1] = {xd[h]};
                 const i32x8 xa = fp4_op(strip_operand<1>(xw, 0));
 #pragma unroll
@@ -465,7 +475,7 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
 #pragma unroll
                     for (int h = 0; h < 2; h++) tl[j][h] = __builtin_amdgcn_raw_buffer_load_b128(rt, t_lane, (h * 128 + 32 * j) * 16, AUX);
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
+                for (int h = 0; h < 2; h++) RBW_HALF(h == 0) {
                     const uint32_t xw[1] = {xs[h]};
                     const i32x8 xa = fp4_op(strip_operand<1>(xw, 0));
 #pragma unroll
@@ -523,7 +533,7 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
 #pragma unroll
             for (int d = 0; d < 4; d++) XA[mm][d] = 0u;
 #pragma unroll
-        for (int j = 0; j < NCB1; j++) {
+        for (int j = 0; j < NCB1; j++) RBW_HALF(NCB1 == 1 || (j & 1) == 0) {
             uint32_t qv[16], P[4];
             requant_pack16<OB>(acc[j], OB, P, qv);
             rbw_nibbles<OB>(P, XA[j >> 1][2 * (j & 1)], XA[j >> 1][2 * (j & 1) + 1]);
@@ -543,7 +553,7 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
         for (int jn = 0; jn < NCB2; jn++) {
             f32x16 acc2 = f32x16_zero();
 #pragma unroll
-            for (int mm = 0; mm < MH; mm++) {
+            for (int mm = 0; mm < MH; mm++) RBW_HALF(NCB2 == 1 || (jn & 1) == 0) {
                 // T' (MODE2 1): not swapped - lane = column 32 jn + fl of T', 16 rows in its registers: what a chain-format line takes.
                 // float32 rows (MODE2 2): SWAPPED - lane = row fl, registers 4 g .. 4 g + 3 = four consecutive columns, stored as vectors
                 // (rbw_store_f32_row; unswapped, a lane stored its column's 16 rows one float at a time: 16 store instructions per
@@ -568,7 +578,7 @@ __device__ __forceinline__ void rbw_chain_body(const qgtc_problem &pr, const qgt
             acc2s[jn] = acc2;
         }
 #pragma unroll
-        for (int jn = 0; jn < NCB2; jn++) {
+        for (int jn = 0; jn < NCB2; jn++) RBW_HALF(NCB2 == 1 || (jn & 1) == 0) {
             const f32x16 &acc2 = acc2s[jn];
             const int n2 = 32 * jn + fl;
             if constexpr (MODE2 == 2) {   // float32 rows of the swapped product: lane = row m, columns 32 jn + 8 g + 4 fh + t in register 4 g + t

@@ -96,19 +96,22 @@ __global__ __launch_bounds__(256) void k_load_finish(const qgtc_loader_batch *__
 constexpr int LOAD_SORT_MAX_KQ = 40, LOAD_SORT_MAX_N = LOAD_SORT_MAX_KQ * 128;   // 3 x 40 x 512 bytes = 60 KB of LDS a row block
 constexpr int LOAD_SORT_THREADS = 1024;
 
-// work: [count x (RB + 1) bucket offsets | the buckets of batch 0 | batch 1 | ..] with RB = row blocks of the largest batch; batch b's
-// edges sit at the offset its edge list has in src / dst. A batch whose buckets would not fit in work_words is skipped and reported.
+// work: [count x (RB + 1) bucket offsets | the buckets of batch 0 | batch 1 | .. (total_edges_pad words: the edge count rounded up to
+// even) | count 64-bit per-batch tile counters] with RB = row blocks of the largest batch; batch b's edges sit at the offset its edge
+// list has in src / dst. A batch whose buckets would not fit is skipped and reported.
 __global__ __launch_bounds__(LOAD_SORT_THREADS) void k_load_sort(const qgtc_loader_batch *__restrict__ tb, const int64_t *__restrict__ src,
                                                                  const int64_t *__restrict__ dst, uint32_t *__restrict__ work,
-                                                                 unsigned long long work_words, int rb_max, int count, int *__restrict__ bad) {
+                                                                 unsigned long long work_words, int rb_max, int count, unsigned long long total_edges_pad,
+                                                                 int *__restrict__ bad) {
     __shared__ unsigned hist[LOAD_SORT_MAX_N / 32 + 1];
     __shared__ unsigned wave_sum[LOAD_SORT_THREADS / 64];
     const qgtc_loader_batch b = tb[blockIdx.x];
     const int n = b.n, tid = threadIdx.x, tiles_m = (n + 31) / 32;
     uint32_t *offs = work + static_cast<size_t>(blockIdx.x) * (rb_max + 1);
     uint32_t *bucket = work + static_cast<size_t>(count) * (rb_max + 1) + b.edge_off;
-    const bool fits = static_cast<unsigned long long>(count) * (rb_max + 1) + b.edge_off + b.n_edges <= work_words && tiles_m <= rb_max;
+    const bool fits = b.edge_off + b.n_edges <= total_edges_pad && tiles_m <= rb_max;   // (the host sized the three parts of `work`)
     for (int i = tid; i <= rb_max; i += LOAD_SORT_THREADS) hist[i] = 0u;
+    if (tid == 0) reinterpret_cast<unsigned long long *>(work + static_cast<size_t>(count) * (rb_max + 1) + total_edges_pad)[blockIdx.x] = 0ull;   // k_load_tiles' per-batch count
     __syncthreads();
     if (!fits) {
         if (tid == 0 && bad) *bad = 1;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(LOAD_SORT_THREADS) void k_load_sort(const qgtc_load
 
 // One wave (a 64-thread workgroup) per (row block, batch). LDS: t1 | t2 | t3, each [32 rows][kq k-quads][4 words] of the block.
 __global__ __launch_bounds__(64) void k_load_tiles(const qgtc_loader_batch *__restrict__ tb, const uint32_t *__restrict__ work, int rb_max, int count,
-                                                   unsigned long long *__restrict__ stats) {
+                                                   unsigned long long total_edges_pad, unsigned long long *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const qgtc_loader_batch b = tb[blockIdx.y];
     const int n = b.n, kq = step128(n), tiles_m = (n + 31) / 32, rb = blockIdx.x, lane = threadIdx.x;
@@ -205,7 +208,14 @@ __global__ __launch_bounds__(64) void k_load_tiles(const qgtc_loader_batch *__re
     }
     if (lane == 0) {
         if (b.occ) b.occ[rb] = mask_lo;
-        if (stats && mask_lo) atomicAdd(stats, static_cast<unsigned long long>(__popcll(mask_lo)));
+        // the occupied-tile count: per batch first (a 64-bit word of the work buffer: arrivals << 32 | sum, cleared by k_load_sort), and the
+        // LAST row block of a batch adds the batch's total to stats[0]. Every row block adding to stats[0] itself was 2850 device-scope
+        // atomics on ONE address - they serialise at ~15 ns each: 42 of this kernel's 45 us (and of k_load_finish's 43).
+        if (stats) {
+            unsigned long long *cnt = reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(work) + static_cast<size_t>(count) * (rb_max + 1) + total_edges_pad) + blockIdx.y;
+            const unsigned long long old = atomicAdd(cnt, (1ull << 32) | static_cast<unsigned long long>(__popcll(mask_lo)));
+            if (static_cast<int>(old >> 32) == tiles_m - 1) atomicAdd(stats, (old & 0xffffffffull) + static_cast<unsigned long long>(__popcll(mask_lo)));
+        }
     }
 }
 
@@ -219,6 +229,20 @@ __global__ __launch_bounds__(256) void k_load_x_cols(const qgtc_loader_batch *__
     if (!b.X) return;
     val2bit_cols_body<NB>(feats + b.feat_row * static_cast<size_t>(F), b.n, F, nbits, ub, ubm1, b.X, pad128(F), step128(b.n) * 4,
                           (static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, (static_cast<long>(gridDim.x) * blockDim.x) >> 6);
+}
+
+// both layouts of X from ONE read of the features (val2bit_cols_rows_body); batches without an XR take the cols-only body
+template <int NB>
+__global__ __launch_bounds__(256) void k_load_x_both(const qgtc_loader_batch *__restrict__ tb, const float *__restrict__ feats, int F, int nbits,
+                                                     float ub, float ubm1) {
+    const qgtc_loader_batch b = tb[blockIdx.y];
+    if (!b.X) return;
+    const long wave = (static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, nwaves = (static_cast<long>(gridDim.x) * blockDim.x) >> 6;
+    if (b.XR)
+        val2bit_cols_rows_body<NB>(feats + b.feat_row * static_cast<size_t>(F), b.n, F, nbits, ub, ubm1, b.X, pad128(F), step128(b.n) * 4, b.XR, pad8(b.n),
+                                   step128(F) * 4, wave, nwaves);
+    else
+        val2bit_cols_body<NB>(feats + b.feat_row * static_cast<size_t>(F), b.n, F, nbits, ub, ubm1, b.X, pad128(F), step128(b.n) * 4, wave, nwaves);
 }
 
 template <bool V4>

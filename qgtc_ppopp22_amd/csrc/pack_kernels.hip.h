@@ -146,6 +146,57 @@ __device__ __forceinline__ void val2bit_cols_body(const float *__restrict__ x, i
     }
 }
 
+// The same unit with the ROWS layout written beside the cols layout (the data loader wants both of X: sampler.py:99's bit_X and the
+// left operand of the layout-correct chain's first X . W): the 32 x 64 quantised values are in registers once - a ballot over the lanes
+// (= 64 columns) of row rr's plane p IS the two rows-layout words of that row, kept by lane rr. One read of X
+// instead of two (round 4: 14.6 + 19.6 us for the ogbn-arxiv-sized iterator's 46.5 MB of features).
+template <int NB>
+__device__ __forceinline__ void val2bit_cols_rows_body(const float *__restrict__ x, int H, int W, int nbits, float ub, float ubm1,
+                                                       uint32_t *__restrict__ out, int lines, int line_words, uint32_t *__restrict__ rows_out,
+                                                       int rows_pad, int row_words, long wave, long nwaves) {
+    const int lane = threadIdx.x & 63;
+    const int cchunks = (lines + 63) >> 6;
+    const long units = static_cast<long>(cchunks) * line_words;
+    const size_t plane = static_cast<size_t>(lines) * line_words, rplane = static_cast<size_t>(rows_pad) * row_words;
+    for (long u = wave; u < units; u += nwaves) {
+        const int cg = static_cast<int>(u % cchunks);
+        const int rw = static_cast<int>(u / cchunks);
+        const int c = cg * 64 + lane;
+        float v[32];
+#pragma unroll
+        for (int rr = 0; rr < 32; rr++) {
+            const int r = rw * 32 + rr;
+            v[rr] = (r < H && c < W) ? x[static_cast<size_t>(r) * W + c] : 0.0f;   // quantises to 0
+        }
+        uint32_t q[32];
+#pragma unroll
+        for (int rr = 0; rr < 32; rr++) q[rr] = quant1(v[rr], ub, ubm1);
+        const int r_mine = rw * 32 + (lane & 31);
+#pragma unroll
+        for (int p = 0; p < NB; p++) {
+            if (p >= nbits) break;   // (launch-uniform)
+            uint32_t wd = 0u, lo = 0u, hi = 0u;
+#pragma unroll
+            for (int rr = 0; rr < 32; rr++) {
+                const uint32_t bit = (q[rr] >> p) & 1u;
+                wd |= bit << (31 - rr);
+                const unsigned long long m = __ballot(bit != 0u);
+                // lane rr keeps the ballot (a select on a constant lane mask; an inline v_writelane_b32 here returned a wrong word in one
+                // lane of 64 - inline asm is opaque to hipcc's hazard recogniser)
+                lo = lane == rr ? static_cast<uint32_t>(m) : lo;
+                hi = lane == rr ? static_cast<uint32_t>(m >> 32) : hi;
+            }
+            if (c < lines) out[p * plane + static_cast<size_t>(c) * line_words + rw] = wd;
+            // lane rr < 32: columns 64 cg .. 64 cg + 63 of row 32 rw + rr = words 2 cg, 2 cg + 1 (element i of a word at bit 31 - i)
+            if (lane < 32 && r_mine < rows_pad && 2 * cg < row_words) {
+                uint32_t *dst = rows_out + p * rplane + static_cast<size_t>(r_mine) * row_words + 2 * cg;
+                if (2 * cg + 1 < row_words) *reinterpret_cast<u32x2 *>(dst) = u32x2{__brev(lo), __brev(hi)};
+                else *dst = __brev(lo);
+            }
+        }
+    }
+}
+
 template <int NB>
 __global__ __launch_bounds__(256) void k_val2bit_cols(const float *__restrict__ x, int H, int W,
                                                       int nbits, float ub, float ubm1,

@@ -56,10 +56,13 @@
 #include "bitmm_fp4_one.hip.h"
 #include "fp4_rowblock.hip.h"
 #include "bitmm_fp4_rows.hip.h"
+#include "fp4_rbw_common.hip.h"
 #include "bitmm_fp4_rbw.hip.h"
+#include "bitmm_fp4_rbx.hip.h"
 #include "fp4_expand.hip.h"
 #include "bitmm_fp4_wide.hip.h"
 #include "launch_fp4.hip.h"
+#include "launch_chainx.hip.h"
 #include "launch_mfma.hip.h"
 #include "launch_wide.hip.h"
 #endif
@@ -530,9 +533,14 @@ int qgtc_pack_edge_list(const int64_t *src, const int64_t *dst, size_t n_edges, 
     return QGTC_OK;
 }
 
+// work buffer of the bucketed loader: [count x (RB + 1) bucket offsets | buckets | count 64-bit per-batch tile counters]; the bucket
+// region is padded by one word when that makes the counters 8-byte aligned
+static size_t load_work_offsets(int count, int max_n) { return static_cast<size_t>(count) * ((max_n + 31) / 32 + 1); }
+static size_t load_work_edges(int count, int max_n, uint64_t total_edges) { return static_cast<size_t>(total_edges) + ((load_work_offsets(count, max_n) + total_edges) & 1u); }
 size_t qgtc_load_work_words(int count, int max_n, uint64_t total_edges) {
     if (count <= 0 || max_n <= 0 || max_n > LOAD_SORT_MAX_N || total_edges >= (1ull << 32)) return 0u;   // 0: no bucketed route for this iterator
-    return static_cast<size_t>(count) * ((max_n + 31) / 32 + 1) + static_cast<size_t>(total_edges);
+    // [bucket offsets | buckets (an even number of words: the counters behind them are 64-bit) | per-batch tile counters]
+    return load_work_offsets(count, max_n) + load_work_edges(count, max_n, total_edges) + 2u * static_cast<size_t>(count);
 }
 
 int qgtc_load_batches(const qgtc_loader_batch *batches, int count, int max_n, uint64_t max_edges, const int64_t *src,
@@ -546,13 +554,17 @@ int qgtc_load_batches(const qgtc_loader_batch *batches, int count, int max_n, ui
     HIP_TRY(hipMemsetAsync(zero, 0, zero_bytes, st));
     if (bad_index) HIP_TRY(hipMemsetAsync(bad_index, 0, sizeof(int), st));
     const int rb_max = (max_n + TM - 1) / TM;
-    if (work && max_n <= LOAD_SORT_MAX_N && work_words >= static_cast<size_t>(count) * (rb_max + 1) && !getenv_flag("QGTC_NO_LOAD_SORT")) {
+    const size_t work_fixed = load_work_offsets(count, max_n) + 2u * static_cast<size_t>(count);
+    if (work && max_n <= LOAD_SORT_MAX_N && work_words >= work_fixed && !(reinterpret_cast<uintptr_t>(work) & 7u) && !getenv_flag("QGTC_NO_LOAD_SORT")) {
+        size_t edges_pad = work_words - work_fixed;                                    // what the caller left for the buckets (a batch that does not fit is reported)
+        if ((load_work_offsets(count, max_n) + edges_pad) & 1u) edges_pad -= 1u;       // the counters behind them stay 8-byte aligned
         // the bucketed route (loader_kernels.hip.h): edges by row block, then every word of rows + tiles + bitmaps written once from LDS
         hipLaunchKernelGGL(k_load_sort, dim3(count), dim3(LOAD_SORT_THREADS), 0, st, batches, src, dst, work, static_cast<unsigned long long>(work_words),
-                           rb_max, count, bad_index);
+                           rb_max, count, static_cast<unsigned long long>(edges_pad), bad_index);
         HIP_TRY(hipGetLastError());
         const size_t lds = static_cast<size_t>(3) * 32 * step128(max_n) * 16;
-        hipLaunchKernelGGL(k_load_tiles, dim3(rb_max, count), dim3(64), lds, st, batches, work, rb_max, count, reinterpret_cast<unsigned long long *>(stats));
+        hipLaunchKernelGGL(k_load_tiles, dim3(rb_max, count), dim3(64), lds, st, batches, work, rb_max, count, static_cast<unsigned long long>(edges_pad),
+                           reinterpret_cast<unsigned long long *>(stats));
         HIP_TRY(hipGetLastError());
     } else {
         if (max_edges) {
@@ -566,21 +578,29 @@ int qgtc_load_batches(const qgtc_loader_batch *batches, int count, int max_n, ui
     }
     if (feats) {
         const float ub = std::ldexp(1.0f, x_bits), ubm1 = ub - 1.0f;
-        {   // cols layout (k_val2bit_cols): a wave per (64-line chunk, 32-row word)
-            const size_t units = static_cast<size_t>((pad128(F) + 63) / 64) * (step128(max_n) * 4);
-            const dim3 g(grid_for(units, 4, 8192), count), b(256);
+        // cols layout (k_val2bit_cols): a wave per (64-line chunk, 32-row word); with the rows layout wanted and at most 8 planes the same
+        // waves write it too (k_load_x_both: the features are read once), else a second pass (k_val2bit_rows_v4 / k_val2bit_rows)
+        const size_t units = static_cast<size_t>((pad128(F) + 63) / 64) * (step128(max_n) * 4);
+        const dim3 g(grid_for(units, 4, 8192), count), b(256);
+        const bool both = (formats & QGTC_LOAD_X_ROWS) && x_bits <= 8 && !getenv_flag("QGTC_NO_LOAD_BOTH");
+        if (both) {
+            if (x_bits <= 1) hipLaunchKernelGGL(k_load_x_both<1>, g, b, 0, st, batches, feats, F, x_bits, ub, ubm1);
+            else if (x_bits <= 2) hipLaunchKernelGGL(k_load_x_both<2>, g, b, 0, st, batches, feats, F, x_bits, ub, ubm1);
+            else if (x_bits <= 4) hipLaunchKernelGGL(k_load_x_both<4>, g, b, 0, st, batches, feats, F, x_bits, ub, ubm1);
+            else hipLaunchKernelGGL(k_load_x_both<8>, g, b, 0, st, batches, feats, F, x_bits, ub, ubm1);
+        } else {
             if (x_bits <= 1) hipLaunchKernelGGL(k_load_x_cols<1>, g, b, 0, st, batches, feats, F, x_bits, ub, ubm1);
             else if (x_bits <= 2) hipLaunchKernelGGL(k_load_x_cols<2>, g, b, 0, st, batches, feats, F, x_bits, ub, ubm1);
             else if (x_bits <= 4) hipLaunchKernelGGL(k_load_x_cols<4>, g, b, 0, st, batches, feats, F, x_bits, ub, ubm1);
             else if (x_bits <= 8) hipLaunchKernelGGL(k_load_x_cols<8>, g, b, 0, st, batches, feats, F, x_bits, ub, ubm1);
             else hipLaunchKernelGGL(k_load_x_cols<32>, g, b, 0, st, batches, feats, F, x_bits, ub, ubm1);
-        }
-        if (formats & QGTC_LOAD_X_ROWS) {   // rows layout (k_val2bit_rows_v4 / k_val2bit_rows): a wave per (row, 256-column chunk)
-            const size_t units = static_cast<size_t>(pad8(max_n)) * ((step128(F) * 4 + 7) / 8);
-            if ((F & 3) == 0 && aligned16(feats))
-                hipLaunchKernelGGL(k_load_x_rows<true>, dim3(grid_for((units + 1) / 2, 4, 8192), count), dim3(256), 0, st, batches, feats, F, x_bits, ub, ubm1);
-            else
-                hipLaunchKernelGGL(k_load_x_rows<false>, dim3(grid_for(units, 4, 8192), count), dim3(256), 0, st, batches, feats, F, x_bits, ub, ubm1);
+            if (formats & QGTC_LOAD_X_ROWS) {   // rows layout (k_val2bit_rows_v4 / k_val2bit_rows): a wave per (row, 256-column chunk)
+                const size_t runits = static_cast<size_t>(pad8(max_n)) * ((step128(F) * 4 + 7) / 8);
+                if ((F & 3) == 0 && aligned16(feats))
+                    hipLaunchKernelGGL(k_load_x_rows<true>, dim3(grid_for((runits + 1) / 2, 4, 8192), count), dim3(256), 0, st, batches, feats, F, x_bits, ub, ubm1);
+                else
+                    hipLaunchKernelGGL(k_load_x_rows<false>, dim3(grid_for(runits, 4, 8192), count), dim3(256), 0, st, batches, feats, F, x_bits, ub, ubm1);
+            }
         }
         HIP_TRY(hipGetLastError());
         if (formats & QGTC_LOAD_X_CHAIN) {   // the chain format of the entries that have an XC (from the cols layout just written)

@@ -49,12 +49,12 @@ int main(int argc, char **argv) {
     size_t set = 0;
     for (auto v : hocc) set += __builtin_popcountll(v);
     printf("adjacency: %zu of %zu 32-row x 128-bit tiles occupied (%.3f), %.2f k-quads per row block\n", set, occw * ((n + 127) / 128), (double)set / (occw * ((n + 127) / 128)), (double)set / occw);
-    const size_t ww = qgtc_cols_words(N1, N2, bits, 0), wcw = qgtc_weight_codes_words(N2, bits);
+    const size_t ww = qgtc_cols_words(N1, N2, bits, 0), wcw = qgtc_weight_codes_words(N1, N2, bits, 1);
     std::vector<uint32_t> hw(ww);
     for (auto &v : hw) v = rng();
     CK(hipMalloc(&dW, ww * 4)); CK(hipMalloc(&dWc, wcw * 4));
     CK(hipMemcpy(dW, hw.data(), ww * 4, hipMemcpyHostToDevice));
-    qgtc_expand_job ej{dW, dWc, ww, N1, N2, bits, (N2 + 127) / 128 * 128, 1, 0};
+    qgtc_expand_job ej{dW, dWc, ww, N1, N2, bits, (N2 + 127) / 128 * 128, 1, static_cast<uint32_t>(wcw)};
     if (int rc = qgtc_expand_weights(&ej, 1, nullptr)) { printf("expand rc=%d\n", rc); return 1; }
     const bool tiles = getenv("TILES") != nullptr;   // the adjacency as 512-byte tiles (qgtc_adj_tiles_from_rows + QGTC_CHAIN_ADJ_TILES)
     const size_t atw = qgtc_adj_tiles_words(n, n);
@@ -163,8 +163,9 @@ int main(int argc, char **argv) {
         for (auto &v : hw3) v = rng();
         CK(hipMalloc(&dW1, w1 * 4)); CK(hipMalloc(&dW2, w2 * 4)); CK(hipMalloc(&dW3, w3 * 4));
         CK(hipMemcpy(dW1, hw1.data(), w1 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW2, hw2.data(), w2 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW3, hw3.data(), w3 * 4, hipMemcpyHostToDevice));
-        CK(hipMalloc(&c1, qgtc_weight_codes_words(H, 2) * 4)); CK(hipMalloc(&c2, qgtc_weight_codes_words(H, 2) * 4)); CK(hipMalloc(&c3, qgtc_weight_codes_words(C, 2) * 4));
-        qgtc_expand_job ej3[3] = {{dW1, c1, w1, F, H, 2, 128, 0, 0}, {dW2, c2, w2, H, H, 2, 128, 1, 0}, {dW3, c3, w3, H, C, 2, 128, 1, 0}};
+        const size_t k1 = qgtc_weight_codes_words(F, H, 2, 0), k2 = qgtc_weight_codes_words(H, H, 2, 1), k3 = qgtc_weight_codes_words(H, C, 2, 1);
+        CK(hipMalloc(&c1, k1 * 4)); CK(hipMalloc(&c2, k2 * 4)); CK(hipMalloc(&c3, k3 * 4));
+        qgtc_expand_job ej3[3] = {{dW1, c1, w1, F, H, 2, 128, 0, (uint32_t)k1}, {dW2, c2, w2, H, H, 2, 128, 1, (uint32_t)k2}, {dW3, c3, w3, H, C, 2, 128, 1, (uint32_t)k3}};
         if (int rc = qgtc_expand_weights(ej3, 3, nullptr)) { printf("expand rc=%d\n", rc); return 1; }
         std::vector<qgtc_problem> hs(6 * count);
         for (int b = 0; b < count; b++) {
