@@ -119,13 +119,38 @@ __global__ __launch_bounds__(LOAD_SORT_THREADS) void k_load_sort(const qgtc_load
         return;
     }
     const int64_t *s = src + b.edge_off, *d = dst + b.edge_off;
-    for (unsigned long long e = tid; e < b.n_edges; e += LOAD_SORT_THREADS) {
-        const int64_t r = s[e], c = d[e];
-        if (r < 0 || r >= n || c < 0 || c >= n) {
-            if (bad) *bad = 1;
-            continue;
+    // A batch of at most EPT x 1024 edges (the cluster batches of the reference's datasets have 2 - 70 k) is read ONCE: every load issued
+    // before the first is used, the packed edges stay in registers over the scan. Longer lists are read twice, edge by edge.
+    constexpr int EPT = 8;
+    const bool resident = b.n_edges <= static_cast<unsigned long long>(EPT) * LOAD_SORT_THREADS;   // (workgroup-uniform)
+    uint32_t pk[EPT];
+    int bucket_of[EPT];
+    if (resident) {
+        int64_t rr[EPT], cc[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const unsigned long long e = static_cast<unsigned long long>(k) * LOAD_SORT_THREADS + tid;
+            rr[k] = e < b.n_edges ? s[e] : -1;
+            cc[k] = e < b.n_edges ? d[e] : 0;
         }
-        atomicAdd(&hist[static_cast<int>(r) >> 5], 1u);
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const unsigned long long e = static_cast<unsigned long long>(k) * LOAD_SORT_THREADS + tid;
+            const bool ok = rr[k] >= 0 && rr[k] < n && cc[k] >= 0 && cc[k] < n;
+            if (e < b.n_edges && !ok && bad) *bad = 1;
+            bucket_of[k] = ok ? static_cast<int>(rr[k]) >> 5 : -1;
+            pk[k] = (static_cast<uint32_t>(rr[k]) & 31u) << 27 | static_cast<uint32_t>(cc[k]);
+            if (ok) atomicAdd(&hist[bucket_of[k]], 1u);
+        }
+    } else {
+        for (unsigned long long e = tid; e < b.n_edges; e += LOAD_SORT_THREADS) {
+            const int64_t r = s[e], c = d[e];
+            if (r < 0 || r >= n || c < 0 || c >= n) {
+                if (bad) *bad = 1;
+                continue;
+            }
+            atomicAdd(&hist[static_cast<int>(r) >> 5], 1u);
+        }
     }
     __syncthreads();
     // exclusive scan of the (at most LOAD_SORT_MAX_N / 32 = 160) bucket sizes: one element a thread, wave scans + the waves' totals
@@ -152,11 +177,17 @@ __global__ __launch_bounds__(LOAD_SORT_THREADS) void k_load_sort(const qgtc_load
         }
     }
     __syncthreads();
-    for (unsigned long long e = tid; e < b.n_edges; e += LOAD_SORT_THREADS) {
-        const int64_t r = s[e], c = d[e];
-        if (r < 0 || r >= n || c < 0 || c >= n) continue;
-        const unsigned slot = atomicAdd(&hist[static_cast<int>(r) >> 5], 1u);
-        bucket[slot] = (static_cast<uint32_t>(r) & 31u) << 27 | static_cast<uint32_t>(c);
+    if (resident) {
+#pragma unroll
+        for (int k = 0; k < EPT; k++)
+            if (bucket_of[k] >= 0) bucket[atomicAdd(&hist[bucket_of[k]], 1u)] = pk[k];
+    } else {
+        for (unsigned long long e = tid; e < b.n_edges; e += LOAD_SORT_THREADS) {
+            const int64_t r = s[e], c = d[e];
+            if (r < 0 || r >= n || c < 0 || c >= n) continue;
+            const unsigned slot = atomicAdd(&hist[static_cast<int>(r) >> 5], 1u);
+            bucket[slot] = (static_cast<uint32_t>(r) & 31u) << 27 | static_cast<uint32_t>(c);
+        }
     }
 }
 
@@ -191,7 +222,7 @@ __global__ __launch_bounds__(64) void k_load_tiles(const qgtc_loader_batch *__re
         const u32x4 a = reinterpret_cast<const u32x4 *>(t1)[u], c2 = reinterpret_cast<const u32x4 *>(t2)[u], c3 = reinterpret_cast<const u32x4 *>(t3)[u];
         const u32x4 v = {a.x & (~c2.x | c3.x), a.y & (~c2.y | c3.y), a.z & (~c2.z | c3.z), a.w & (~c2.w | c3.w)};   // the 1-bit quantiser's image of 1, 2, >= 3: 1, 0, 1
         reinterpret_cast<u32x4 *>(t1)[u] = v;
-        if (r < rows_here) reinterpret_cast<u32x4 *>(rows_out)[u] = v;
+        if (r < rows_here) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(rows_out) + u);   // (nobody in this launch reads it back)
     }
     __syncthreads();
     // tiles [k-quad][32 rows][4 words] (512 contiguous bytes a tile) and the occupancy bits: lanes 0 .. 31 = the rows of k-quad 2 i, 32 .. 63 of 2 i + 1
@@ -201,7 +232,7 @@ __global__ __launch_bounds__(64) void k_load_tiles(const qgtc_loader_batch *__re
         const int q = q0 + (lane >> 5), r = lane & 31;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (q < kq) v = reinterpret_cast<const u32x4 *>(t1)[r * kq + q];
-        if (tile_out && q < kq) reinterpret_cast<u32x4 *>(tile_out)[q * 32 + r] = v;
+        if (tile_out && q < kq) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(tile_out) + (q * 32 + r));
         const unsigned long long bal = __ballot(((v.x | v.y) | (v.z | v.w)) != 0u);
         if (bal & 0xffffffffull) mask_lo |= 1ull << q0;
         if (bal >> 32) mask_lo |= 1ull << (q0 + 1);
