@@ -15,11 +15,12 @@ from .common import (CLOCK_WARMUP_S, EVENT_MIN_LAUNCHES, FP4_PEAK_TFLOPS, HBM_PE
 def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams=1, issue="eager"):
     """`warmup` untimed launches, then EXACTLY `steps` launches between barrier + synchronize pairs (wall seconds), then
     max(3, steps // 200) windows of 200 of the same launches, each between its own pair of HIP events on the launch
-    stream (their MEDIAN = the kernel's average launch duration: kernel + dependent-launch gap). The events stay OUT of
-    the timed region: recording two of them costs 11-12 us of a 72 us region.
+    stream (their MEDIAN = the kernel's average launch duration: kernel + dependent-launch gap) - issued like the timed region
+    and, for the eager issue, once more replayed from a graph captured behind it. The events stay OUT of the timed region:
+    recording two of them costs 11-12 us of a 72 us region.
     issue: "eager" (default, the reference's loop) = K hipLaunchKernel calls inside the region; "graph" = the K launches
     captured once AHEAD of the region and replayed by one hipGraphLaunch inside it (same kernels in stream order).
-    Returns (wall seconds, seconds per launch from the event windows)."""
+    Returns (wall seconds, {how the window was issued: seconds per launch})."""
     if streams > 1:
         outs = [out] + [torch.empty_like(out) for _ in range(streams - 1)]
         enqueue = lambda n: Q.bitMM2Bit_enqueue_streams(outs, bit_A, bit_X, M, K, N, 1, w, w, n)  # noqa: E731
@@ -55,14 +56,29 @@ def time_steps(Q, out, bit_A, bit_X, M, K, N, w, steps, warmup, barrier, streams
     t1 = time.perf_counter()
     barrier()
     # ---- the roofline's live launch duration: event-bracketed windows right behind it ----
-    per_window = []
-    for _ in range(max(3, steps // EVENT_MIN_LAUNCHES)):
-        ev0.record()
-        run_window()
-        ev1.record()
+    def windows(run):
+        per_window = []
+        for _ in range(max(3, steps // EVENT_MIN_LAUNCHES)):
+            ev0.record()
+            run()
+            ev1.record()
+            torch.cuda.synchronize()
+            per_window.append(ev0.elapsed_time(ev1) * 1e-3 / EVENT_MIN_LAUNCHES)
+        return sorted(per_window)[len(per_window) // 2]
+
+    per_launch = {"hip_events_" + issue: windows(run_window)}
+    if issue == "eager" and streams <= 1:
+        # The same 200 launches replayed from a hipGraph captured HERE, behind the timed region (a capture ahead of it slowed the eager
+        # launches on one box): no host in the loop. On a box whose host issues a launch in 3.6 us the eager windows read 3.6 us per
+        # launch for a kernel that takes 3.0 (r05: 3.63 eager, 3.07 replayed) - the host's figure, not the kernel's. Both are upper
+        # bounds of the kernel's average launch duration; the roofline takes the smaller.
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            enqueue(EVENT_MIN_LAUNCHES)
+        g.replay()
         torch.cuda.synchronize()
-        per_window.append(ev0.elapsed_time(ev1) * 1e-3 / EVENT_MIN_LAUNCHES)
-    return t1 - t0, sorted(per_window)[len(per_window) // 2]
+        per_launch["hip_events_graph_replay"] = windows(g.replay)
+    return t1 - t0, per_launch
 
 
 def algorithmic_bytes(M, K, N, w):
@@ -70,20 +86,23 @@ def algorithmic_bytes(M, K, N, w):
     return 1 * M * K / 8 + w * K * N / 8 + w * M * N / 8
 
 
-def roofline_block(M, K, N, w, kern_s, wall_per_step_s, fp4_kernel, single_stream=True):
+def roofline_block(M, K, N, w, per_launch, wall_per_step_s, fp4_kernel, single_stream=True):
     """`roofline` of the line for the dominant kernel. `achieved` = algorithmic bytes per launch / the kernel's average launch
-    duration. The timed region's own wall clock per step bounds that duration from above (its launches run back to back on
-    one stream); when the event windows read more than it (an instrument artefact seen on some boxes) the bound is used and
-    `avg_launch_from` says so."""
+    duration. Every figure we have is an UPPER bound of that duration - HIP-event windows of 200 launches issued eagerly (host in
+    the loop) or replayed from a graph, and the timed region's own wall clock per step (its launches run back to back on one
+    stream) - so the smallest is used and `avg_launch_from` names it; all of them are in `avg_launch_candidates_us`."""
     algo = algorithmic_bytes(M, K, N, w)
-    kern = min(kern_s, wall_per_step_s) if single_stream else kern_s
+    cands = dict(per_launch)
+    if single_stream:
+        cands["wall_per_step"] = wall_per_step_s
+    src = min(cands, key=cands.get)
+    kern = cands[src]
     eff_ops = 2.0 * M * K * N
     frac = round(algo / kern / 1e9 / HBM_PEAK_GBS, 5)
     rf = {"bound": "hbm", "kernel": None, "achieved": round(algo / kern / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
           "frac": frac, "traffic": None, "traffic_source": "none: only the 1-bit workload on the default engine is profiled",
-          "algorithmic_bytes_per_launch": int(algo), "avg_launch_us": round(kern * 1e6, 3),
-          "avg_launch_from": "hip_events" if (kern_s <= wall_per_step_s or not single_stream) else "wall_per_step",
-          "avg_launch_us_hip_events": round(kern_s * 1e6, 3), "rocprof": None}
+          "algorithmic_bytes_per_launch": int(algo), "avg_launch_us": round(kern * 1e6, 3), "avg_launch_from": src,
+          "avg_launch_candidates_us": {k: round(v * 1e6, 3) for k, v in cands.items()}, "rocprof": None}
     if fp4_kernel:
         # k_bitmm_fp4_one: v_mfma_scale_f32_16x16x128_f8f6f4 on E2M1 codes of the bit planes. The larger of its two floors is the
         # HBM one (2.16 MB / 8 TB/s = 0.27 us against 2.1 Gop / 10 PF = 0.21 us), so that is the bound named.
@@ -112,6 +131,7 @@ def other_engine_block(M, K, N, w, wall_s, kern_s, steps, popcount):
     """The same K steps on the other engine (identical words): the AND + popcount kernels against BOTH statements of their VALU
     roofline when that is the other engine."""
     eff_ops = 2.0 * M * K * N
+    kern_s = min(kern_s.values()) if isinstance(kern_s, dict) else kern_s
     blk = {"TOPS": round(steps * eff_ops / wall_s / 1e12, 3), "us_per_launch": round(kern_s * 1e6, 3)}
     if popcount:
         blk["valu_frac_of_measured_pair_rate_4.2e13"] = round(eff_ops * w / kern_s / VALU_PEAK_BITOPS, 4)

@@ -284,7 +284,7 @@ def _worst_case_line():
     from benchmarks import epochs, headline
 
     args = argparse.Namespace(steps=100000, warmup=1000, engine="popcount", issue="eager", streams=1)
-    rf = headline.roofline_block(4096, 4096, 64, 1, 3.123456e-6, 3.654321e-6, True)
+    rf = headline.roofline_block(4096, 4096, 64, 1, {"hip_events_eager": 3.623456e-6, "hip_events_graph_replay": 3.073456e-6}, 3.654321e-6, True)
     rf.update({"traffic": 123456789, "traffic_source": "profiles/r05/summary_headline.json (pmc, sources 0123456789ab)",
                "rocprof": {"file": "profiles/r05/kernel_stats_headline.csv", "avg_us": 3594.681, "min_us": 2640.123}})
     ep = {"batched_correct_chain_ms": 0.0226123, "per_batch_reference_chain_ms": 1.8511123,
@@ -324,6 +324,7 @@ def test_bench_line_stays_small_and_machine_readable():
               "avg_launch_us", "rocprof", "epoch_gcn_ms", "epoch_gcn_kernel_us", "epoch_gcn_frac", "epoch_gin_ms", "epoch_gin_kernel_us"):
         assert k in back["roofline"], k
     assert back["roofline"]["frac"] == pytest.approx(back["roofline"]["achieved"] / back["roofline"]["peak"], rel=1e-3)
+    assert back["roofline"]["avg_launch_from"] == "hip_events_graph_replay" and back["roofline"]["avg_launch_us"] == pytest.approx(3.073, abs=1e-3)
     assert {"value", "unit", "cores", "kind", "sample", "dgl_style_fp32_epoch_ms", "dgl_cores"} <= set(back["cpu_baseline"])
     assert all(len(v) < 120 for v in back["config"].values())
     # a line that would not fit loses optional keys, never the contract's
