@@ -19,7 +19,9 @@ namespace {
 //   * ONE code path per k-quad: every occupied k-quad of the adjacency row block is shared between the wave's halves (half fh takes
 //     words 2 fh, 2 fh + 1 of both operands - the lone-k-quad form of k_rbw_chain); no diagonal staging, no pairs. These widths are off
 //     the BASELINE epochs: the simple form, exact, bounded by the same launch gap + one dependent chain per wave.
-//   * the re-quantisation takes its width at RUN time (ob): one kernel per (digits, column blocks), not per width.
+//   * the re-quantisation takes its width at RUN time (ob): one kernel per (digits, column blocks), not per width. (Skipping the zero
+//     top digits of 5- and 6-bit values with launch-uniform branches around the MFMAs was measured: 0.060 -> 0.058 ms per epoch at
+//     5 / 6 bits, 0.060 -> 0.068 at 7 / 8 - the branches cost the full-width case its MFMA interleaving. Not kept.)
 // ------------------------------------------------------------------------------------------
 
 // 16 sums -> bytes: P[t] byte 3 - gq = requant(register 4 gq + t) & (2^ob - 1) (kernel.h:31-37,350: c > 2^ob ? 2^ob - 1 : c; c == 2^ob
@@ -72,7 +74,6 @@ template <int NA, int NDW, int NCB>
 __global__ __launch_bounds__(256) void k_rbx_xw(const qgtc_problem *__restrict__ prs, const u32x4 *__restrict__ w_codes, int per, int a_planes, int gx, int gy,
                                                 int kq_tables, int ob, int table_blocks) {
     constexpr int NDA = (NA + 1) / 2;
-    const int ndig = (ob + 1) / 2, nda = (a_planes + 1) / 2;   // digits that can be non-zero (the kernels of 5 .. 8 bits run 3 or 4)
     int grp, batch;
     rbw_ids(per, gx, gy, grp, batch);
     const qgtc_problem pr = prs[batch];
@@ -116,11 +117,10 @@ __global__ __launch_bounds__(256) void k_rbx_xw(const qgtc_problem *__restrict__
                 for (int jn = 0; jn < JP; jn++)
 #pragma unroll
                     for (int dw = 0; dw < NDW; dw++) {
-                        if (NDW > 2 && dw >= ndig) break;   // (launch-uniform: the top digits of 5- and 6-bit values are zero)
                         const u32x4 w = wq[(((jp + jn) * 2 + h) * NDW + dw) * 64 + lane];
 #pragma unroll
                         for (int da = 0; da < NDA; da++)
-                            if (NDA <= 2 || da < nda) accs[jn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[da], fp4_op(w), accs[jn], 4, 4, 0, 128 + 2 * da, 0, 128 + 2 * dw);   // not swapped: lane = column 32 (jp + jn) + fl
+                            accs[jn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[da], fp4_op(w), accs[jn], 4, 4, 0, 128 + 2 * da, 0, 128 + 2 * dw);   // not swapped: lane = column 32 (jp + jn) + fl
                     }
             }
         }
@@ -152,7 +152,7 @@ constexpr bool rbx_two_waves(int nd, int mode2, int ncb1, int ncb2) {
 }
 template <int ND, int MODE2, int NCB1, int NCB2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(rbx_two_waves(ND, MODE2, NCB1, NCB2) ? 2 : 3, 4))) void k_rbx_chain(const qgtc_problem *__restrict__ prs, const qgtc_problem *__restrict__ prs2, const u32x4 *__restrict__ w2_codes,
-                                                   int per, int tiles, int gx, int gy, int ob, int t_bits) {
+                                                   int per, int tiles, int gx, int gy, int ob) {
     constexpr int NH = ND > 2 ? 2 : 1;            // arrays of T (nibble planes of a value)
     constexpr int DPN = ND > 1 ? 2 : 1;           // digits in a nibble
     constexpr int MH = (NCB1 + 1) / 2;            // MFMAs (64 elements of K each) of the second product
@@ -172,7 +172,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(rbx_two_wav
     const int fl = lane & 31, fh = lane >> 5;
     const int rb = 4 * grp + wv, m = 32 * rb + fl;
     const int kq = step128(K), lines = pad128(N);
-    const int ndig = (ob + 1) / 2, ndig_t = (t_bits + 1) / 2;   // digits that can be non-zero in the aggregate / W' and in T (ND = 4 covers 5 .. 8 bits: 3 or 4)
     // W' once per workgroup through LDS (every load issued before the first LDS write)
     if constexpr (MODE2 != 0) {
         constexpr int NI = (W2N + 255) / 256;
@@ -275,8 +274,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(rbx_two_wav
                     for (int hv = 0; hv < NH; hv++)
 #pragma unroll
                         for (int dd = 0; dd < DPN; dd++)
-                            if (ND <= 2 || 2 * hv + dd < ndig_t)   // (launch-uniform: the top digit of 5- and 6-bit values is zero)
-                                acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(rbx_digit<ND>(tl[j][h][hv], dd), xa, acc[j], 4, 4, 0, 128 + 2 * (2 * hv + dd), 0, 128);
+                            acc[j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(rbx_digit<ND>(tl[j][h][hv], dd), xa, acc[j], 4, 4, 0, 128 + 2 * (2 * hv + dd), 0, 128);
             }
         }
         if constexpr (MODE2 == 0) {   // float32 [M, N] (kernel.h:915-930)
@@ -316,12 +314,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(rbx_two_wav
                 for (int mm = 0; mm < MH; mm++)
 #pragma unroll
                     for (int da = 0; da < ND; da++) {
-                        if (ND > 2 && da >= ndig) break;
                         const u32x4 xv = {XA[da / DPN][mm][0], XA[da / DPN][mm][1], XA[da / DPN][mm][2], XA[da / DPN][mm][3]};
                         const i32x8 xa = rbx_digit<ND>(xv, da % DPN);
 #pragma unroll
                         for (int dw = 0; dw < ND; dw++) {
-                            if (ND > 2 && dw >= ndig) break;
                             const i32x8 wb = fp4_op(w2_lds[((jn * MS + mm) * ND + dw) * 64 + lane]);
                             // T' (MODE2 1): not swapped - lane = column 32 jn + fl of T'; float32 rows (MODE2 2): swapped - lane = row fl
                             if constexpr (MODE2 == 2) acc2 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb, xa, acc2, 4, 4, 0, 128 + 2 * dw, 0, 128 + 2 * da);

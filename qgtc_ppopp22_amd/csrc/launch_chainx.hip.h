@@ -44,7 +44,7 @@ int qgtc_launch_rbx_chain(const qgtc_problem *p1, const qgtc_problem *p2, int co
     const int bits = mode2 == 0 ? t_bits : act_bits;          // (the format class of T and the aggregate's width agree: rbx_chain_ok)
     const int nd = bits <= 2 ? 1 : (bits <= 4 ? 2 : 4);
     if (mode2 < 0 || mode2 > 2 || (nd == 4 && (c1 > 4 || c2 > 4))) return QGTC_EINVAL;
-#define QGTC_RBX_GO(ND_, MODE2_, C1_, C2_) hipLaunchKernelGGL((k_rbx_chain<ND_, MODE2_, C1_, C2_>), grid, block, 0, st, p1, p2, wc, per, tiles, gx, gy, bits, t_bits)
+#define QGTC_RBX_GO(ND_, MODE2_, C1_, C2_) hipLaunchKernelGGL((k_rbx_chain<ND_, MODE2_, C1_, C2_>), grid, block, 0, st, p1, p2, wc, per, tiles, gx, gy, bits)
 #define QGTC_RBX_C2(ND_, MODE2_, C1_)                      \
     switch (c2) {                                          \
         case 1: QGTC_RBX_GO(ND_, MODE2_, C1_, 1); break;   \

@@ -669,3 +669,39 @@ def test_chain_entries_random_sweep(lib, oracle, seed):
         np.testing.assert_array_equal(o.cpu().numpy().reshape(w.shape), w, err_msg=f"seed {seed} b={b} xw={use_xw} F={F} H={H} C={C} m={ms[i]} k={ks[i]} density={density} bitmaps={bitmaps}")
     lib.qgtc_last_batched_violation.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), vp]
     assert lib.qgtc_last_batched_violation(None, None, st) == 0
+
+
+@pytest.mark.parametrize("t_bits,act_bits,H", [(8, 6, 64), (5, 8, 128), (7, 5, 33), (1, 2, 200), (4, 3, 256), (3, 4, 64), (2, 1, 100)])
+def test_chain_aggregate_with_different_widths_inside_a_format_class(lib, oracle, t_bits, act_bits, H):
+    """qgtc_chain_aggregate takes T's width (t_bits) and the aggregate's (act_bits = the planes of W') separately; they only have to
+    share a format class (1 / 2 bits, 3 / 4 bits, 5 .. 8 bits). T from the public cols layout (qgtc_chain_from_cols), then
+    out = float32(requant(A . T) . W') (out_mode 2) against the oracle - the 5 .. 8-bit kernels skip zero top digits per operand."""
+    import torch
+    lib.qgtc_weight_codes_words.restype = lib.qgtc_chain_words.restype = lib.qgtc_occupancy_words.restype = ctypes.c_size_t
+    lib.qgtc_expand_weights.argtypes = [vp, ctypes.c_int, vp]
+    lib.qgtc_chain_from_cols.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+    lib.qgtc_chain_aggregate.argtypes = [vp, vp, ctypes.c_int] + [ctypes.c_int] * 8 + [vp, ctypes.c_uint, vp]
+    rng = np.random.default_rng(100 * t_bits + act_bits)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P128 = lambda x: (x + 127) // 128 * 128   # noqa: E731
+    m, k, C = 333, 270, 40
+    W2 = oracle.pack(rand_q(rng, H, C, act_bits), act_bits, True)
+    dW2 = torch.from_numpy(W2.view(np.int32)).cuda()
+    c2 = torch.full((int(lib.qgtc_weight_codes_words(H, C, act_bits, 1)),), -1, dtype=torch.int32, device="cuda")
+    jobs = (QgtcExpandJob * 1)(QgtcExpandJob(dW2.data_ptr(), c2.data_ptr(), dW2.numel(), H, C, act_bits, P128(C), 1, c2.numel()))
+    assert lib.qgtc_expand_weights(ctypes.addressof(jobs), 1, st) == 0
+    qa = (rng.random((m, k)) < 0.05).astype(np.int32)
+    A = oracle.pack(qa, 1, False)
+    t_o = oracle.pack(rand_q(rng, k, H, t_bits), t_bits, True)
+    dA, dT0 = torch.from_numpy(A.view(np.int32)).cuda(), torch.from_numpy(t_o.view(np.int32)).cuda()
+    T = torch.full((int(lib.qgtc_chain_words(k, H, t_bits)),), -1, dtype=torch.int32, device="cuda")
+    assert lib.qgtc_chain_from_cols(dT0.data_ptr(), dT0.numel(), k, H, t_bits, T.data_ptr(), T.numel(), st) == 0
+    out = torch.full((m * C,), -7.0, dtype=torch.float32, device="cuda")
+    host = (QgtcProblem * 2)(QgtcProblem(dA.data_ptr(), T.data_ptr(), None, dA.numel(), T.numel(), m, k, H, P128(H), 0, None),
+                             QgtcProblem(None, dW2.data_ptr(), out.data_ptr(), 0, dW2.numel(), m, H, C, P128(C), 0, None))
+    descs = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
+    rc = lib.qgtc_chain_aggregate(descs.data_ptr(), descs.data_ptr() + 72, 1, m, k, H, C, t_bits, act_bits, act_bits, 2, c2.data_ptr(), 0x200, st)
+    assert rc == 0, lib.qgtc_strerror(rc)
+    torch.cuda.synchronize()
+    h_o = oracle.bitmm2bit(A, t_o, m, k, H, 1, t_bits, act_bits)
+    np.testing.assert_array_equal(out.cpu().numpy().reshape(m, C), oracle.bitmm2int(h_o, W2, m, H, C, act_bits, act_bits, True))
