@@ -659,12 +659,18 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
         k_reset();
         return k_take(0, 0);  // an empty slice (or an all-zero row tile) has no stage at all
     };
+    // generic kernel: did the CURRENT X plane block (pa0 .. pa0 + ab - 1) show a set bit anywhere in this wave's k slice? Known after the
+    // block's first pass (pw0 == 0); an all-zero block - 29 of the 32 planes of N(0,1) features quantised at --bit_width 32 - skips its
+    // other W plane blocks: their stages would load 2 x ab planes each and multiply nothing
+    bool xblk_nz = false;
     auto next_stage = [&](const Stage &prev) -> Stage {
         Stage st = k_take(prev.pa0, prev.pw0);
         if (st.valid) return st;
         // the k range is exhausted: next plane block (generic kernel only), restart the k iteration
         int pa0 = prev.pa0, pw0 = prev.pw0 + wb;
+        if (GEN && ZS && prev.pw0 == 0 && !xblk_nz) pw0 = sh.w;   // (wave-uniform)
         if (pw0 >= sh.w) {
+            xblk_nz = false;
             pw0 = 0;
             pa0 += ab;
             if (pa0 >= sh.a) return st;  // invalid
@@ -746,10 +752,17 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
             nzm[u] = 0ull;
             if (u >= nsx + nsw) continue;
             if ((v_in >> u) & 1u) region[s_lds[u]] = pre[u];
-            if (ZS && u < nsx) nzm[u] = __ballot(((pre[u].x | pre[u].y) | (pre[u].z | pre[u].w)) != 0u);
+            // (the generic kernel also takes the ballots of its W tiles: at 16 / 32 planes most planes of BOTH operands are all zero -
+            // the reference's checked-in script runs --bit_width 32, where all-ones weights have one non-zero plane of 32)
+            if (ZS && (GEN || u < nsx)) nzm[u] = __ballot(((pre[u].x | pre[u].y) | (pre[u].z | pre[u].w)) != 0u);
         }
         if (it == 0) STAMP(3);
         const Stage now = cur;
+        if (GEN && ZS && now.pw0 == 0) {
+#pragma unroll
+            for (int u = 0; u < GPT; u++)
+                if (u < nsx) xblk_nz = xblk_nz || nzm[u] != 0ull;
+        }
         cur = next_stage(now);
         // the next stage's loads fly while this one is multiplied
         if (cur.valid) issue(cur.pa0, cur.pw0, cur.i0, cur.i1, cur.i2, cur.i3, cur.nk);
@@ -821,15 +834,20 @@ __device__ __forceinline__ void mm_tile(const qgtc_problem &pr, const MMShape &s
             }
         } else {
             const int na = min(ab, sh.a - now.pa0), nw = min(wb, sh.w - now.pw0);
-            uint32_t occ = 0u;  // bit pa: X plane tile pa of the stage has a set bit
+            uint32_t occ = 0u, wocc = 0u;  // bit p: X / W plane tile p of the stage has a set bit (slot u holds planes 2 u, 2 u + 1)
 #pragma unroll
-            for (int u = 0; u < GPT / 2; u++)
-                occ |= ((nzm[u] & 0xffffffffull) ? (1u << (2 * u)) : 0u) | ((nzm[u] >> 32) ? (2u << (2 * u)) : 0u);
+            for (int u = 0; u < GPT; u++) {
+                if (u >= nsx + nsw) continue;
+                const uint32_t two = ((nzm[u] & 0xffffffffull) ? 1u : 0u) | ((nzm[u] >> 32) ? 2u : 0u);
+                if (u < nsx) occ |= two << (2 * u);
+                else wocc |= two << (2 * (u - nsx));
+            }
             for (int pa = 0; pa < na; pa++) {
                 if (ZS && !((occ >> pa) & 1u)) continue;
                 u32x4 xg[MR];
                 read_x(pa, xg);
                 for (int pw = 0; pw < nw; pw++) {
+                    if (ZS && !((wocc >> pw) & 1u)) continue;
                     u32x4 wg[MC];
                     read_w(pw, wg);
 #pragma unroll

@@ -5,7 +5,7 @@
 # gpurun_out/prof_<tag>/summary_<target>.json; copy what is to be judged into profiles/.
 #   tools/collect_profiles.sh <tag> [targets...]
 set -u
-TAG=${1:-r03}
+TAG=${1:-r05}
 shift
 TARGETS=${@:-headline popcount w8 gin_single epoch epoch_gin loader pack}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
