@@ -333,15 +333,16 @@ torch::Tensor pack_edges(torch::Tensor src, torch::Tensor dst, const int height,
     c10::DeviceGuard guard(src.device());
     const auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(src.device());
     if (nbits == 1) {
-        // the adjacency case: raw edge list, no sort / unique, no host round trip unless validate asks for one. One allocation
-        // [out | scratch] (one memset in the library); the result is a view of its first third.
+        // the adjacency case: raw edge list, no sort / unique, no host round trip unless validate asks for one. The result owns exactly
+        // its own words; the two scratch bitmaps are a separate allocation that goes back to the caching allocator when this call
+        // returns (round 4 returned a view of one [out | scratch] allocation: every adjacency a caller kept pinned three times its size).
         const int64_t words = static_cast<int64_t>(P8(height)) * S128(width) * 4;
-        auto buf = torch::empty({3 * words}, i32);
-        auto out = buf.narrow(0, 0, words).view({static_cast<int64_t>(P8(height)), S128(width) * 4});
+        auto out = torch::empty({static_cast<int64_t>(P8(height)), S128(width) * 4}, i32);
+        auto scratch = torch::empty({2 * words}, i32);
         torch::Tensor bad;
         if (validate) bad = torch::empty({1}, i32);
         check_rc(qgtc_pack_edge_list(src.numel() ? src.data_ptr<int64_t>() : nullptr, src.numel() ? dst.data_ptr<int64_t>() : nullptr,
-                                     src.numel(), height, width, words_mut(buf), words, words_mut(buf) + words,
+                                     src.numel(), height, width, words_mut(out), words, words_mut(scratch),
                                      2 * words, validate ? bad.data_ptr<int>() : nullptr, current_stream(src)),
                  "pack_edges");
         if (validate) TORCH_CHECK(bad.item<int>() == 0, "edge index out of range");

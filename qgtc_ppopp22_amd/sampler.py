@@ -126,10 +126,12 @@ class ClusterIter:
             feats.append(g.feat[nodes])
             ns.append(int(nodes.size))
             ecounts.append(int(row.size))
-        src = torch.from_numpy(np.concatenate(rows)).to(self.device)
-        dst = torch.from_numpy(np.concatenate(cols)).to(self.device)
-        X = torch.from_numpy(np.ascontiguousarray(np.concatenate(feats), dtype=np.float32)).to(self.device)
-        self.raw_src, self.raw_dst, self.raw_feats, self.raw_nodes, self.raw_edge_counts = src, dst, X, ns, ecounts
+        # the concatenated raw arrays: on the host always, on the device while they are needed (the pack below; afterwards only when
+        # keep_raw asks for per-batch raw views or a driver packs inside its epoch loop: pack_now uploads them again on demand)
+        self._raw_host = (np.concatenate(rows), np.concatenate(cols), np.ascontiguousarray(np.concatenate(feats), dtype=np.float32))
+        self.raw_nodes, self.raw_edge_counts = ns, ecounts
+        self._upload_raw()
+        src, dst, X = self.raw_src, self.raw_dst, self.raw_feats
         data = self.pack_now(qgtc)
         F = X.size(1)
         e0 = f0 = 0
@@ -149,12 +151,21 @@ class ClusterIter:
         if self.resident:
             self._epoch_data = data
             self.x_in_chain_format = self._x_chain > 0
+        if not keep_raw:
+            self.raw_src = self.raw_dst = self.raw_feats = None      # (46 MB of float features for the ogbn-arxiv-sized iterator)
+
+    def _upload_raw(self):
+        r, c, x = self._raw_host
+        self.raw_src, self.raw_dst = torch.from_numpy(r).to(self.device), torch.from_numpy(c).to(self.device)
+        self.raw_feats = torch.from_numpy(x).to(self.device)
 
     def pack_now(self, qgtc=None):
         """Pack every batch again from the resident raw arrays (one EpochPlan.load call): what a driver that packs INSIDE its
         epoch loop (cluster_gcn.py:151-227) pays per epoch in the grouped form. Returns the new EpochPlan."""
         if qgtc is None:
             import QGTC as qgtc
+        if getattr(self, "raw_src", None) is None:
+            self._upload_raw()       # (kept from here on: a driver that packs inside its epoch loop calls this every epoch)
         return qgtc.EpochPlan.load(self.raw_src, self.raw_dst, self.raw_edge_counts, self.raw_feats, self.raw_nodes, self.bit_width,
                                    self._with_rows, self._x_chain, self._a_tiles, False)
 
