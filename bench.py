@@ -125,6 +125,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU (run `python bench.py --gpus N` " \
                                "or torch.distributed.run with --nproc-per-node N)"
+    if os.environ.get("QGTC_BENCH_SHARE_GPU", "0") not in ("", "0"):
+        local = 0                              # test hook (tests/test_aa_bench_two_ranks.py): every rank on cuda:0, collectives over gloo
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     import QGTC as Q

@@ -16,7 +16,7 @@ def launch_ranks(args, script) -> int:
     LOCAL_RANK picks one) BEFORE this process makes any GPU call, wait for them, and fail if any of them fails. Rank 0
     prints the JSON line straight to our stdout."""
     n = args.gpus
-    if not args.dry_run:
+    if not args.dry_run and os.environ.get("QGTC_BENCH_SHARE_GPU", "0") in ("", "0"):
         have = torch.cuda.device_count()       # counting devices does not initialise the GPU
         if have < n:
             print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
