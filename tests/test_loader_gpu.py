@@ -35,7 +35,7 @@ def _dense(n, r, c):
     return A
 
 
-@pytest.mark.parametrize("route", ["buckets", "bitmaps", "too-wide"])
+@pytest.mark.parametrize("route", ["buckets", "bitmaps", "too-wide", "widest-buckets"])
 @pytest.mark.parametrize("bits,F,chain", [(2, 128, 0), (4, 50, 4), (1, 33, 1), (3, 64, 3), (8, 16, 0), (8, 40, 8), (5, 128, 5)])
 def test_grouped_loader_equals_the_oracle_and_the_single_batch_entries(qgtc, oracle, bits, F, chain, route, monkeypatch):
     """route: "buckets" = the default (edges bucketed by 32-row block, every word of rows + tiles + bitmaps written once from LDS);
@@ -43,12 +43,14 @@ def test_grouped_loader_equals_the_oracle_and_the_single_batch_entries(qgtc, ora
     import torch
     if route == "bitmaps":
         monkeypatch.setenv("QGTC_NO_LOAD_SORT", "1")
-    if route == "too-wide" and bits != 2:
-        pytest.skip("one width is enough for the 5200-node fallback")
+    if route in ("too-wide", "widest-buckets") and bits != 2:
+        pytest.skip("one width is enough for the 5200-node fallback / the 5100-node batch (40 k-quads: 60 KB of LDS a row block)")
     rng = np.random.default_rng(bits * 100 + F)
     sizes = [1213, 599, 37, 8, 1, 130, 2049, 300]          # ragged; 2049 nodes = 17 k-quads (the kernel's wide-row path)
     if route == "too-wide":
         sizes = [5200, 64, 1213]
+    if route == "widest-buckets":
+        sizes = [5100, 64, 1213]
     rows, cols, feats, ecounts = _batches(rng, sizes, F, empty_first=(bits == 3))
     src, dst = (torch.from_numpy(np.concatenate(v)).cuda() for v in (rows, cols))
     X = torch.from_numpy(np.concatenate(feats)).cuda()
