@@ -1,7 +1,7 @@
 // tools/kbench.hip — standalone (no torch) kernel bench + phase-stamp dump for the bit-GEMM.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude [-DQGTC_STAMPS] -o /tmp/kbench tools/kbench.hip
 //   /tmp/kbench M K N a w ob reps [density]
-//   env: NOZS=1 (no zero-tile skipping), MFMA=1 (matrix-core engine),
+//   env: NOZS=1 (no zero-tile skipping), MFMA=1 (matrix-core engine), XPLANES=n / WPLANES=n (planes n .. are all zero),
 //        GROUPED=count (count copies of the problem in one grouped launch; X gets dense 64 x 64
 //        diagonal blocks + `density` elsewhere, like a cluster batch), JUMP=1 (with occupancy bitmaps),
 //        MODE=0|1|2 (grouped only: rows bits, cols bits, float)
@@ -26,6 +26,10 @@ int main(int argc, char **argv) {
     std::bernoulli_distribution bern(density);
     for (auto &v : hx) { uint32_t t = 0; for (int b = 0; b < 32; b++) t |= (uint32_t)bern(rng) << b; v = t; }
     for (auto &v : hw) v = rng();
+    // XPLANES / WPLANES: only that many low planes carry bits (the rest all zero) - what wide --bit_width operands look like (features
+    // quantised at 32 bits are 0 .. 4: three of 32 planes; all-ones weights: one)
+    if (const char *e = getenv("XPLANES")) std::fill(hx.begin() + (size_t)atoi(e) * (xw / a), hx.end(), 0u);
+    if (const char *e = getenv("WPLANES")) std::fill(hw.begin() + (size_t)atoi(e) * (ww / w), hw.end(), 0u);
     uint32_t *dx, *dw, *dout;
     CK(hipMalloc(&dx, xw * 4)); CK(hipMalloc(&dw, ww * 4)); CK(hipMalloc(&dout, ow * 4));
     CK(hipMemcpy(dx, hx.data(), xw * 4, hipMemcpyHostToDevice));
