@@ -705,3 +705,54 @@ def test_chain_aggregate_with_different_widths_inside_a_format_class(lib, oracle
     torch.cuda.synchronize()
     h_o = oracle.bitmm2bit(A, t_o, m, k, H, 1, t_bits, act_bits)
     np.testing.assert_array_equal(out.cpu().numpy().reshape(m, C), oracle.bitmm2int(h_o, W2, m, H, C, act_bits, act_bits, True))
+
+
+@pytest.mark.parametrize("b", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_chain_aggregate_requantises_at_the_clamp_boundary(lib, oracle, b):
+    """kernel.h:31-37,350 on the chain entries: a sum c > 2^b becomes 2^b - 1, c == 2^b SURVIVES and packs as 0 (only the low b bits are
+    kept), c < 2^b is itself. Sums of exactly 2^b - 1, 2^b, 2^b + 1 and 3 x 2^b are built from two / three adjacency bits on known T
+    values and read back through an identity W' (out_mode 2): float32(requant(A . T) . I) - against the oracle and the closed form.
+    8 bits is the case a saturating byte conversion gets wrong (256 -> 255 instead of 0)."""
+    import torch
+    lib.qgtc_weight_codes_words.restype = lib.qgtc_chain_words.restype = ctypes.c_size_t
+    lib.qgtc_expand_weights.argtypes = [vp, ctypes.c_int, vp]
+    lib.qgtc_chain_from_cols.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]
+    lib.qgtc_chain_aggregate.argtypes = [vp, vp, ctypes.c_int] + [ctypes.c_int] * 8 + [vp, ctypes.c_uint, vp]
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P128 = lambda x: (x + 127) // 128 * 128   # noqa: E731
+    m = k = 70
+    H = C = 40
+    top = (1 << b) - 1
+    qt = np.zeros((k, H), dtype=np.int32)
+    qa = np.zeros((m, k), dtype=np.int32)
+    # column c of T: rows 0, 1, 2 hold values whose partial sums hit the boundary cases on rows 0 .. 3 of A
+    qt[0, :] = top                    # row 0 of A = {0}            -> 2^b - 1
+    qt[1, :] = 1                      # row 1 of A = {0, 1}         -> 2^b      (packs as 0)
+    qt[2, :] = 1                      # row 2 of A = {0, 1, 2}      -> 2^b + 1  (clamps to 2^b - 1)
+    qt[3:6, :] = top                  # row 3 of A = {0, 3, 4, 5}   -> 4 (2^b - 1) > 2^b for b >= 2 (b = 1: 4 > 2 as well)
+    qa[0, 0] = 1
+    qa[1, :2] = 1
+    qa[2, :3] = 1
+    qa[3, [0, 3, 4, 5]] = 1
+    qw = np.eye(H, C, dtype=np.int32)
+    A, T0, W2 = oracle.pack(qa, 1, False), oracle.pack(qt, b, True), oracle.pack(qw, b, True)
+    dA, dT0, dW2 = (torch.from_numpy(t.view(np.int32)).cuda() for t in (A, T0, W2))
+    c2 = torch.full((int(lib.qgtc_weight_codes_words(H, C, b, 1)),), -1, dtype=torch.int32, device="cuda")
+    jobs = (QgtcExpandJob * 1)(QgtcExpandJob(dW2.data_ptr(), c2.data_ptr(), dW2.numel(), H, C, b, P128(C), 1, c2.numel()))
+    assert lib.qgtc_expand_weights(ctypes.addressof(jobs), 1, st) == 0
+    T = torch.full((int(lib.qgtc_chain_words(k, H, b)),), -1, dtype=torch.int32, device="cuda")
+    assert lib.qgtc_chain_from_cols(dT0.data_ptr(), dT0.numel(), k, H, b, T.data_ptr(), T.numel(), st) == 0
+    out = torch.full((m * C,), -7.0, dtype=torch.float32, device="cuda")
+    host = (QgtcProblem * 2)(QgtcProblem(dA.data_ptr(), T.data_ptr(), None, dA.numel(), T.numel(), m, k, H, P128(H), 0, None),
+                             QgtcProblem(None, dW2.data_ptr(), out.data_ptr(), 0, dW2.numel(), m, H, C, P128(C), 0, None))
+    descs = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
+    rc = lib.qgtc_chain_aggregate(descs.data_ptr(), descs.data_ptr() + 72, 1, m, k, H, C, b, b, b, 2, c2.data_ptr(), 0x200, st)
+    assert rc == 0, lib.qgtc_strerror(rc)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(m, C)
+    h_o = oracle.bitmm2bit(A, T0, m, k, H, 1, b, b)
+    np.testing.assert_array_equal(got, oracle.bitmm2int(h_o, W2, m, H, C, b, b, True))
+    want_rows = [top, 0, top, top] if b > 1 else [1, 0, 1, 1]      # (b = 1: 2^b - 1 = 1; rows 2, 3 exceed 2 and clamp to 1)
+    for r, wv in enumerate(want_rows):
+        assert (got[r] == wv).all(), (b, r, got[r][:4], wv)
+    assert (got[4:] == 0).all()
