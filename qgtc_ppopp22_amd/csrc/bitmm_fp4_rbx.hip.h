@@ -93,13 +93,27 @@ __global__ __launch_bounds__(256) void k_rbx_xw(const qgtc_problem *__restrict__
     uint32_t *tbase = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(grp * 4 + wv) * lines * 4;   // word wv of k-quad grp
     // PASSES of at most four column blocks: eight blocks' accumulators (128 registers) leave one wave per SIMD, and a launch of 750
     // four-wave workgroups then runs in three rounds on 256 CUs. A pass re-reads the lane's words of X (8 bytes a plane) and expands them again.
+    // The k-quad's weight table goes through LDS once per workgroup: at 8 bits it is 32 KB, and every wave fetching it for itself was
+    // 96 MB of L2 reads a launch (ogbn-arxiv-sized epoch: X . W1 at 8 bits 15.4 us).
     constexpr int JP = NCB > 4 ? 4 : NCB;
+    constexpr int WN = JP * 2 * NDW * 64, NI = (WN + 255) / 256;   // a pass's part of the table: JP column blocks
+    __shared__ __attribute__((aligned(16))) u32x4 w_lds[WN];
 #pragma unroll
     for (int jp = 0; jp < NCB; jp += JP) {
         f32x16 accs[JP];
 #pragma unroll
         for (int jn = 0; jn < JP; jn++) accs[jn] = f32x16_zero();
-        for (int q = 0; q < kq; q++) {   // (wave-uniform)
+        for (int q = 0; q < kq; q++) {   // (workgroup-uniform)
+            {
+                const u32x4 *wq = w_codes + (static_cast<size_t>(q) * table_blocks + jp) * 2 * NDW * 64;
+                u32x4 wreg[NI];
+#pragma unroll
+                for (int i = 0; i < NI; i++) wreg[i] = (i * 256 + tid < WN) ? wq[i * 256 + tid] : u32x4{0u, 0u, 0u, 0u};
+                if (q > 0 || jp > 0) __syncthreads();      // (the previous part of the table is still being read)
+#pragma unroll
+                for (int i = 0; i < NI; i++)
+                    if (i * 256 + tid < WN) w_lds[i * 256 + tid] = wreg[i];
+            }
             uint32_t xl[2][NA];   // [k half][plane]: words 2 fh, 2 fh + 1 of k-quad q of the lane's row
 #pragma unroll
             for (int p = 0; p < NA; p++) {
@@ -107,7 +121,7 @@ __global__ __launch_bounds__(256) void k_rbx_xw(const qgtc_problem *__restrict__
                 xl[0][p] = v.x;
                 xl[1][p] = v.y;
             }
-            const u32x4 *wq = w_codes + static_cast<size_t>(q) * table_blocks * 2 * NDW * 64;
+            __syncthreads();
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 i32x8 xa[NDA];
@@ -117,7 +131,7 @@ __global__ __launch_bounds__(256) void k_rbx_xw(const qgtc_problem *__restrict__
                 for (int jn = 0; jn < JP; jn++)
 #pragma unroll
                     for (int dw = 0; dw < NDW; dw++) {
-                        const u32x4 w = wq[(((jp + jn) * 2 + h) * NDW + dw) * 64 + lane];
+                        const u32x4 w = w_lds[((jn * 2 + h) * NDW + dw) * 64 + lane];
 #pragma unroll
                         for (int da = 0; da < NDA; da++)
                             accs[jn] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[da], fp4_op(w), accs[jn], 4, 4, 0, 128 + 2 * da, 0, 128 + 2 * dw);   // not swapped: lane = column 32 (jp + jn) + fl
