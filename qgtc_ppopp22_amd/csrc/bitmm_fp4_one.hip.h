@@ -226,7 +226,10 @@ __global__ __launch_bounds__(64 * ONE_WAVES) void k_bitmm_fp4_one(
         if (MODE == 0) {   // row words past the last column tile (rows layout [ob][PAD8(M)][STEP128(N)*4])
             const int rows_pad = pad8(M), row_words = step128(N) * 4;
             const int w_next = (n0 + 16 * CF + 31) >> 5;
-            if (blockIdx.y == gridDim.y - 1 && w_next < row_words) {
+            // (the grid from the problem's shape, as launch_one sizes it: gridDim is a HIDDEN kernel argument - reading it makes the kernel's
+            // argument segment 312 bytes instead of 56, five lines instead of one for hipLaunchKernel to write through the PCIe BAR:
+            // tools/kernarg_probe.hip measured up to 0.9 us of host time per launch)
+            if (static_cast<int>(blockIdx.y) == (N + 16 * CF - 1) / (16 * CF) - 1 && w_next < row_words) {
                 const int nx = row_words - w_next;
                 for (int e = t; e < ob * 16 * RF * nx; e += nt) {
                     const int x = e % nx, r = (e / nx) % (16 * RF), p = e / (nx * 16 * RF);
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(64 * ONE_WAVES) void k_bitmm_fp4_one(
         } else if (MODE == 1) {   // cols layout [ob][PAD128(N)][STEP128(M)*4]: words past the last row tile, lines past the last column tile
             const int lines = pad128(N), line_words = step128(M) * 4;
             const size_t oplane = static_cast<size_t>(lines) * line_words;
-            const bool last_m = blockIdx.x == gridDim.x - 1, last_n = blockIdx.y == gridDim.y - 1;
+            const bool last_m = static_cast<int>(blockIdx.x) == (M + 16 * RF - 1) / (16 * RF) - 1, last_n = static_cast<int>(blockIdx.y) == (N + 16 * CF - 1) / (16 * CF) - 1;
             const int word1 = m0 >> 5, w_core1 = min(line_words, word1 + 1);
             if (last_m && w_core1 < line_words) {
                 for (int e = t; e < ob * 16 * CF; e += nt) {

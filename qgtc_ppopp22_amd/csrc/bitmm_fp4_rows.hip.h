@@ -251,6 +251,7 @@ __device__ __forceinline__ void rows_block(const qgtc_problem &pr, const MMShape
 template <int NA, int NW, int MODE, int OB, int CB>
 __global__ __launch_bounds__(64 * 8) void k_bitmm_fp4_rows(const qgtc_problem *__restrict__ prs, MMShape sh) {
     pin_shape(sh);
+    pin_grid();
     // sh.per != 0: the row blocks of a batch run on ONE XCD (they share its T lines and descriptor in that L2; spread
     // round-robin over the eight, every XCD fetched every batch's T: rocprofv3 counted 18.5 MB of fetches per launch for
     // 5.6 MB of operands)
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(64 * 4) __attribute__((amdgpu_waves_per_eu(NA <= 2 
     const qgtc_problem *__restrict__ prs, MMShape sh) {
     constexpr int NDA = (NA + 1) / 2, NDW = (NW + 1) / 2;   // base-4 digits
     pin_shape(sh);
+    pin_grid();
     int rb = static_cast<int>(blockIdx.x), batch = static_cast<int>(blockIdx.y);
     if (sh.per) {
         const int v = xcd_consecutive(batch * static_cast<int>(gridDim.x) + rb, static_cast<int>(gridDim.x * gridDim.y));

@@ -190,7 +190,8 @@ __global__ __launch_bounds__(64 * SK_WAVES) void k_bitmm_fp4_skinny(qgtc_problem
             if (rq == 0 && n1 < lines && word1 < line_words) dst1[0] = wrd;
         }
         // zero what no tile computes: words past the last row tile, lines past the last column tile
-        const bool last_m = blockIdx.x == gridDim.x - 1, last_n = blockIdx.y == gridDim.y - 1;
+        // (the grid from the shape, as qgtc_launch_skinny sizes it - gridDim is a hidden kernel argument: bitmm_fp4_one.hip.h)
+        const bool last_m = static_cast<int>(blockIdx.x) == (M + TR - 1) / TR - 1, last_n = static_cast<int>(blockIdx.y) == (N + 31) / 32 - 1;
         const int w_core1 = min(line_words, word1 + 1);
         if (last_m && w_core1 < line_words) {
             for (int e = tid; e < sh.ob * 32; e += 256) {
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void k_bitmm_fp4_skinny(qgtc_problem
     const uint32_t sh_n = 28u - 4u * static_cast<uint32_t>(quad & 7);
     const int word = (n0 >> 5) + (quad >> 3);
     // the last column tile also zeroes the row words past it (the kernels write every word of the output)
-    const int extra = (blockIdx.y == gridDim.y - 1 && quad == QPR - 8) ? row_words - word - 1 : 0;
+    const int extra = (static_cast<int>(blockIdx.y) == (N + 31) / 32 - 1 && quad == QPR - 8) ? row_words - word - 1 : 0;
     uint32_t *dst = static_cast<uint32_t *>(pr.out) + static_cast<size_t>(m) * row_words + word;
     for (int p = 0; p < sh.ob; p++, dst += oplane) {
         const uint32_t nib = (((q[0] >> p) & 1u) << 3) | (((q[1] >> p) & 1u) << 2) | (((q[2] >> p) & 1u) << 1) | ((q[3] >> p) & 1u);

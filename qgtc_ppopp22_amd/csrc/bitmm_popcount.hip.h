@@ -72,8 +72,11 @@ struct MMShape {           // per-launch constants
 // ONE round trip, and every field of a descriptor with one more: left alone hipcc loads them lazily, each use a dependent scalar-load
 // round trip ahead of the first global load (bitmm_fp4_rbw.hip.h measured 0.2 us of a 4.3 us launch).
 __device__ __forceinline__ void pin_shape(const MMShape &sh) {
-    asm volatile("" ::"s"(sh.a), "s"(sh.w), "s"(sh.ob), "s"(sh.mode), "s"(sh.per), "s"(sh.waves), "s"(sh.nowrap), "s"(gridDim.x), "s"(gridDim.y));
+    asm volatile("" ::"s"(sh.a), "s"(sh.w), "s"(sh.ob), "s"(sh.mode), "s"(sh.per), "s"(sh.waves), "s"(sh.nowrap));
 }
+// (the grouped kernels that re-map their ids read the grid; the single-problem kernels must not - a kernel that reads gridDim carries the
+// 256 bytes of hidden arguments in its argument segment, and hipLaunchKernel writes that segment through the PCIe BAR per launch)
+__device__ __forceinline__ void pin_grid() { asm volatile("" ::"s"(gridDim.x), "s"(gridDim.y)); }
 __device__ __forceinline__ void pin_problem(const qgtc_problem &pr) {
     asm volatile("" ::"s"(pr.X), "s"(pr.W), "s"(pr.out), "s"(pr.x_words), "s"(pr.w_words), "s"(pr.M), "s"(pr.K), "s"(pr.N), "s"(pr.w_lines), "s"(pr.occ), "s"(pr.occ_words));
 }

@@ -58,9 +58,10 @@ template <int UNROLL>
 __global__ __launch_bounds__(256) void k_val2bit_rows_v4(const float *__restrict__ x, int H, int W,
                                                          int nbits, float ub, float ubm1,
                                                          uint32_t *__restrict__ out, int rows_pad,
-                                                         int row_words) {
-    val2bit_rows_v4_body<UNROLL>(x, H, W, nbits, ub, ubm1, out, rows_pad, row_words, (blockIdx.x * blockDim.x + threadIdx.x) >> 6,
-                                 (gridDim.x * blockDim.x) >> 6);
+                                                         int row_words, int nwaves) {
+    // (nwaves = 4 x the grid, handed over: gridDim and blockDim are HIDDEN kernel arguments - a kernel that reads them has a 312-byte
+    // argument segment for hipLaunchKernel to write instead of 60; bitmm_fp4_one.hip.h, tools/kernarg_probe.hip)
+    val2bit_rows_v4_body<UNROLL>(x, H, W, nbits, ub, ubm1, out, rows_pad, row_words, (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -101,9 +102,8 @@ __device__ __forceinline__ void val2bit_rows_body(const float *__restrict__ x, i
 __global__ __launch_bounds__(256) void k_val2bit_rows(const float *__restrict__ x, int H, int W,
                                                       int nbits, float ub, float ubm1,
                                                       uint32_t *__restrict__ out, int rows_pad,
-                                                      int row_words) {
-    val2bit_rows_body(x, H, W, nbits, ub, ubm1, out, rows_pad, row_words, (static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6,
-                      (static_cast<long>(gridDim.x) * blockDim.x) >> 6);
+                                                      int row_words, int nwaves) {
+    val2bit_rows_body(x, H, W, nbits, ub, ubm1, out, rows_pad, row_words, (static_cast<long>(blockIdx.x) * 256 + threadIdx.x) >> 6, static_cast<long>(nwaves));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -201,9 +201,8 @@ template <int NB>
 __global__ __launch_bounds__(256) void k_val2bit_cols(const float *__restrict__ x, int H, int W,
                                                       int nbits, float ub, float ubm1,
                                                       uint32_t *__restrict__ out, int lines,
-                                                      int line_words) {
-    val2bit_cols_body<NB>(x, H, W, nbits, ub, ubm1, out, lines, line_words, (static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6,
-                          (static_cast<long>(gridDim.x) * blockDim.x) >> 6);
+                                                      int line_words, int nwaves) {
+    val2bit_cols_body<NB>(x, H, W, nbits, ub, ubm1, out, lines, line_words, (static_cast<long>(blockIdx.x) * 256 + threadIdx.x) >> 6, static_cast<long>(nwaves));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -212,10 +211,9 @@ __global__ __launch_bounds__(256) void k_val2bit_cols(const float *__restrict__ 
 __global__ __launch_bounds__(256) void k_bit2val(const uint32_t *__restrict__ bits,
                                                  unsigned long long words, int nbits, int H, int W,
                                                  int col_major, size_t plane, int line_words,
-                                                 int32_t *__restrict__ out) {
+                                                 int32_t *__restrict__ out, unsigned nthreads) {
     const size_t total = static_cast<size_t>(H) * W;
-    for (size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
-         idx += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    for (size_t idx = static_cast<size_t>(blockIdx.x) * 256u + threadIdx.x; idx < total; idx += nthreads) {
         const int r = static_cast<int>(idx / W), c = static_cast<int>(idx % W);
         const int line = col_major ? c : r, pos = col_major ? r : c;
         uint32_t v = 0;
