@@ -3,6 +3,8 @@
 # pass, then - in SEPARATE passes, counters never share a run with a trace - --pmc FETCH_SIZE, --pmc WRITE_SIZE and an
 # LDS / VALU / MFMA activity pass. The program itself follows `--` (python3, no wrapper). Summaries land in
 # gpurun_out/prof_<tag>/summary_<target>.json; copy what is to be judged into profiles/.
+# Every pass runs under `timeout 300`: a profiler pass that aborts can sit in its finalisation until the box is taken away (one did, on
+# TA_* counters, for 25 minutes).
 #   tools/collect_profiles.sh <tag> [targets...]
 set -u
 TAG=${1:-r05}
@@ -13,10 +15,10 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for T in $TARGETS; do
   REPS=200; [ "$T" = "epoch" -o "$T" = "epoch_gin" -o "$T" = "loader" -o "$T" = "loader_gin" ] && REPS=20; case "$T" in wide*) REPS=50;; esac
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$T -- python3 $GRAFT_REPO_ROOT/tools/profile_targets.py $T $REPS > $OUT/run_trace_$T.json 2> $OUT/trace_$T.err
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$T -- python3 $GRAFT_REPO_ROOT/tools/profile_targets.py $T $REPS > $OUT/run_trace_$T.json 2> $OUT/trace_$T.err
   for C in FETCH_SIZE WRITE_SIZE "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
     N=$(echo $C | tr ' ' '_')
-    rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${T}_$N -- python3 $GRAFT_REPO_ROOT/tools/profile_targets.py $T 20 > $OUT/run_pmc_${T}_$N.json 2> $OUT/pmc_${T}_$N.err
+    timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${T}_$N -- python3 $GRAFT_REPO_ROOT/tools/profile_targets.py $T 20 > $OUT/run_pmc_${T}_$N.json 2> $OUT/pmc_${T}_$N.err
   done
   python3 - <<PY
 import csv, glob, json, collections, sys
