@@ -24,11 +24,19 @@ __device__ __forceinline__ void val2bit_rows_v4_body(const float *__restrict__ x
     const uint32_t sh_n = 28 - 4 * (lane & 7);
     for (uint32_t u0 = wave * UNROLL; u0 < units; u0 += nwaves * UNROLL) {
         float4 v[UNROLL];
+        int rk[UNROLL], chk[UNROLL];   // (row, 256-column chunk) of unit u0 + k: ONE division per pass, the rest by carry (a division by a
+        rk[0] = static_cast<int>(u0 / chunks);   // run-time value is a dozen quarter-rate multiplies; it was done twice per unit)
+        chk[0] = static_cast<int>(u0 - static_cast<uint32_t>(rk[0]) * chunks);
+#pragma unroll
+        for (int k = 1; k < UNROLL; k++) {
+            const bool wrap = chk[k - 1] + 1 == chunks;
+            chk[k] = wrap ? 0 : chk[k - 1] + 1;
+            rk[k] = wrap ? rk[k - 1] + 1 : rk[k - 1];
+        }
 #pragma unroll
         for (int k = 0; k < UNROLL; k++) {
             const uint32_t u = u0 + k;
-            const int r = static_cast<int>(u / chunks), ch = static_cast<int>(u % chunks);
-            const int c = ch * 256 + lane * 4;
+            const int r = rk[k], c = chk[k] * 256 + lane * 4;
             v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (u < units && r < H && c < W)  // W % 4 == 0: the quad is entirely inside or outside
                 v[k] = *reinterpret_cast<const float4 *>(x + static_cast<size_t>(r) * W + c);
@@ -37,11 +45,10 @@ __device__ __forceinline__ void val2bit_rows_v4_body(const float *__restrict__ x
         for (int k = 0; k < UNROLL; k++) {
             const uint32_t u = u0 + k;
             if (u >= units) break;  // wave-uniform
-            const int r = static_cast<int>(u / chunks), ch = static_cast<int>(u % chunks);
-            const int c = ch * 256 + lane * 4;
-            const bool in = r < H && c < W;
-            const uint32_t q0 = in ? quant1(v[k].x, ub, ubm1) : 0u, q1 = in ? quant1(v[k].y, ub, ubm1) : 0u;
-            const uint32_t q2 = in ? quant1(v[k].z, ub, ubm1) : 0u, q3 = in ? quant1(v[k].w, ub, ubm1) : 0u;
+            const int r = rk[k], ch = chk[k];
+            // (outside the matrix the quad was left at 0.0f, which quantises to 0: no select, and no branch around the quantisation)
+            const uint32_t q0 = quant1(v[k].x, ub, ubm1), q1 = quant1(v[k].y, ub, ubm1);
+            const uint32_t q2 = quant1(v[k].z, ub, ubm1), q3 = quant1(v[k].w, ub, ubm1);
             const int wi = ch * 8 + (lane >> 3);
             uint32_t *dst = out + static_cast<size_t>(r) * row_words + wi;
             for (int p = 0; p < nbits; p++, dst += plane) {
@@ -106,6 +113,19 @@ __global__ __launch_bounds__(256) void k_val2bit_rows(const float *__restrict__ 
     val2bit_rows_body(x, H, W, nbits, ub, ubm1, out, rows_pad, row_words, (static_cast<long>(blockIdx.x) * 256 + threadIdx.x) >> 6, static_cast<long>(nwaves));
 }
 
+// unit u -> (u % n, u / n): units are counted in 64 bits (a 2^31-row matrix is legal), but a 64-bit division by a run-time value is ~100
+// instructions per unit - taken only when the count does not fit 32 bits (launch-uniform)
+__device__ __forceinline__ void split_unit(long u, int n, bool small, int &rem, int &quo) {
+    if (small) {
+        const uint32_t u32 = static_cast<uint32_t>(u), q = u32 / static_cast<uint32_t>(n);
+        quo = static_cast<int>(q);
+        rem = static_cast<int>(u32 - q * static_cast<uint32_t>(n));
+    } else {
+        quo = static_cast<int>(u / n);
+        rem = static_cast<int>(u % n);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // val2bit, cols layout: out[p][c][r>>5] bit(31-(r&31)) = bit p of quant(x[r][c])
 // One wave per (64-column chunk, 32-row group): lane = column, 32 coalesced row reads in flight, each
@@ -118,9 +138,10 @@ __device__ __forceinline__ void val2bit_cols_body(const float *__restrict__ x, i
     const int cchunks = (lines + 63) >> 6;
     const long units = static_cast<long>(cchunks) * line_words;
     const size_t plane = static_cast<size_t>(lines) * line_words;
+    const bool small = units < (1l << 31);
     for (long u = wave; u < units; u += nwaves) {
-        const int cg = static_cast<int>(u % cchunks);
-        const int rw = static_cast<int>(u / cchunks);
+        int cg, rw;
+        split_unit(u, cchunks, small, cg, rw);
         const int c = cg * 64 + lane;
         uint32_t wd[NB];
 #pragma unroll
@@ -146,53 +167,73 @@ __device__ __forceinline__ void val2bit_cols_body(const float *__restrict__ x, i
     }
 }
 
+// 32 x 32 bit-matrix transpose over the 32 lanes of a half-wave (both halves at once): afterwards bit b of lane i's word is what bit i of
+// lane b's word was. Five butterfly stages (Hacker's Delight 7-3 across lanes): exchange with lane i ^ j (ds_swizzle: the LDS crossbar, no
+// memory), keep the diagonal blocks, take the partner's off-diagonal block moved by j bits - a ROTATE does the move for both kinds of lane,
+// as the bits that would wrap are masked off. `li` = lane & 31; the masks and rotate counts depend on the lane only (hoisted out of loops).
+template <int J>
+__device__ __forceinline__ uint32_t transpose32_stage(uint32_t x, int li) {
+    constexpr uint32_t M = J == 16 ? 0x0000ffffu : J == 8 ? 0x00ff00ffu : J == 4 ? 0x0f0f0f0fu : J == 2 ? 0x33333333u : 0x55555555u;   // bits b with (b & J) == 0
+    const uint32_t p = static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(x), (J << 10) | 0x1f));   // lane ^ J within its 32
+    const bool hi = (li & J) != 0;
+    const uint32_t keep = hi ? ~M : M;
+    const uint32_t moved = p & keep;
+    return (x & keep) | __builtin_amdgcn_alignbit(moved, moved, hi ? J : 32 - J);   // hi lanes: >> J, the others: << J
+}
+__device__ __forceinline__ uint32_t transpose32_lanes(uint32_t x, int li) {
+    x = transpose32_stage<16>(x, li);
+    x = transpose32_stage<8>(x, li);
+    x = transpose32_stage<4>(x, li);
+    x = transpose32_stage<2>(x, li);
+    return transpose32_stage<1>(x, li);
+}
+
 // The same unit with the ROWS layout written beside the cols layout (the data loader wants both of X: sampler.py:99's bit_X and the
-// left operand of the layout-correct chain's first X . W): the 32 x 64 quantised values are in registers once - a ballot over the lanes
-// (= 64 columns) of row rr's plane p IS the two rows-layout words of that row, kept by lane rr. One read of X
-// instead of two (round 4: 14.6 + 19.6 us for the ogbn-arxiv-sized iterator's 46.5 MB of features).
+// left operand of the layout-correct chain's first X . W): the 32 x 64 quantised values are in registers once, and the cols-layout word a
+// lane has assembled for its column (row rr at bit 31 - rr) is one row of a 32 x 32 bit matrix whose TRANSPOSE is the rows layout: after
+// transpose32_lanes lane i of a half holds, bit b = column b of the half's 32, the word of row 31 - i - bit-reversed, a rows-layout word.
+// 22 operations a plane. (Round 5's first form took a ballot per row and plane and a select on a lane mask into the lane that keeps it: 160
+// operations a plane and 128 scalar registers of ballots - rocprofv3: 1371 VALU instructions a unit, v_readlane / v_writelane spills of
+// scalar registers, 8.2 M wave instructions = 13 of the launch's 21 us.) One read of X instead of two (round 4: 14.6 + 19.6 us for the
+// ogbn-arxiv-sized iterator's 46.5 MB of features). The loads are buffer loads: rows past H and columns past W come back as 0.0f - which
+// quantises to 0 - from the range check instead of from a branch around every load. x_bytes = H * W * 4 < 2^31 (the caller's check).
 template <int NB>
 __device__ __forceinline__ void val2bit_cols_rows_body(const float *__restrict__ x, int H, int W, int nbits, float ub, float ubm1,
                                                        uint32_t *__restrict__ out, int lines, int line_words, uint32_t *__restrict__ rows_out,
                                                        int rows_pad, int row_words, long wave, long nwaves) {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, li = lane & 31, half = lane >> 5;
     const int cchunks = (lines + 63) >> 6;
     const long units = static_cast<long>(cchunks) * line_words;
     const size_t plane = static_cast<size_t>(lines) * line_words, rplane = static_cast<size_t>(rows_pad) * row_words;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, static_cast<int>(static_cast<uint32_t>(H) * static_cast<uint32_t>(W) * 4u), 0x00020000);
+    const uint32_t row_bytes = static_cast<uint32_t>(W) * 4u;
+    const bool small = units < (1l << 31);
     for (long u = wave; u < units; u += nwaves) {
-        const int cg = static_cast<int>(u % cchunks);
-        const int rw = static_cast<int>(u / cchunks);
+        int cg, rw;
+        split_unit(u, cchunks, small, cg, rw);
         const int c = cg * 64 + lane;
+        // (a column past W: an offset no row's bytes bring back into range)
+        const uint32_t lane_off = c < W ? static_cast<uint32_t>(c) * 4u : 0x80000000u;
         float v[32];
 #pragma unroll
-        for (int rr = 0; rr < 32; rr++) {
-            const int r = rw * 32 + rr;
-            v[rr] = (r < H && c < W) ? x[static_cast<size_t>(r) * W + c] : 0.0f;   // quantises to 0
-        }
-        uint32_t q[32];
+        for (int rr = 0; rr < 32; rr++)
+            v[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, lane_off + static_cast<uint32_t>(rw * 32 + rr) * row_bytes, 0, 0));
+        uint32_t wd[NB];
 #pragma unroll
-        for (int rr = 0; rr < 32; rr++) q[rr] = quant1(v[rr], ub, ubm1);
-        const int r_mine = rw * 32 + (lane & 31);
+        for (int p = 0; p < NB; p++) wd[p] = 0u;
+#pragma unroll
+        for (int rr = 0; rr < 32; rr++) {
+            const uint32_t q = quant1(v[rr], ub, ubm1);
+#pragma unroll
+            for (int p = 0; p < NB; p++) wd[p] |= ((q >> p) & 1u) << (31 - rr);
+        }
+        const int r_mine = rw * 32 + 31 - li, w_mine = 2 * cg + half;
 #pragma unroll
         for (int p = 0; p < NB; p++) {
             if (p >= nbits) break;   // (launch-uniform)
-            uint32_t wd = 0u, lo = 0u, hi = 0u;
-#pragma unroll
-            for (int rr = 0; rr < 32; rr++) {
-                const uint32_t bit = (q[rr] >> p) & 1u;
-                wd |= bit << (31 - rr);
-                const unsigned long long m = __ballot(bit != 0u);
-                // lane rr keeps the ballot (a select on a constant lane mask; an inline v_writelane_b32 here returned a wrong word in one
-                // lane of 64 - inline asm is opaque to hipcc's hazard recogniser)
-                lo = lane == rr ? static_cast<uint32_t>(m) : lo;
-                hi = lane == rr ? static_cast<uint32_t>(m >> 32) : hi;
-            }
-            if (c < lines) out[p * plane + static_cast<size_t>(c) * line_words + rw] = wd;
-            // lane rr < 32: columns 64 cg .. 64 cg + 63 of row 32 rw + rr = words 2 cg, 2 cg + 1 (element i of a word at bit 31 - i)
-            if (lane < 32 && r_mine < rows_pad && 2 * cg < row_words) {
-                uint32_t *dst = rows_out + p * rplane + static_cast<size_t>(r_mine) * row_words + 2 * cg;
-                if (2 * cg + 1 < row_words) *reinterpret_cast<u32x2 *>(dst) = u32x2{__brev(lo), __brev(hi)};
-                else *dst = __brev(lo);
-            }
+            if (c < lines) out[p * plane + static_cast<size_t>(c) * line_words + rw] = wd[p];
+            const uint32_t t = __brev(transpose32_lanes(wd[p], li));
+            if (r_mine < rows_pad && w_mine < row_words) rows_out[p * rplane + static_cast<size_t>(r_mine) * row_words + w_mine] = t;
         }
     }
 }

@@ -583,7 +583,9 @@ int qgtc_load_batches(const qgtc_loader_batch *batches, int count, int max_n, ui
         // waves write it too (k_load_x_both: the features are read once), else a second pass (k_val2bit_rows_v4 / k_val2bit_rows)
         const size_t units = static_cast<size_t>((pad128(F) + 63) / 64) * (step128(max_n) * 4);
         const dim3 g(grid_for(units, 4, 8192), count), b(256);
-        const bool both = (formats & QGTC_LOAD_X_ROWS) && x_bits <= 8 && !getenv_flag("QGTC_NO_LOAD_BOTH");
+        // (k_load_x_both reads a batch's features through a buffer resource with 32-bit offsets, the padding rows' included)
+        const bool both = (formats & QGTC_LOAD_X_ROWS) && x_bits <= 8 && static_cast<size_t>(pad128(max_n) + 32) * F * 4u < (1ull << 31) &&
+                          !getenv_flag("QGTC_NO_LOAD_BOTH");
         if (both) {
             if (x_bits <= 1) hipLaunchKernelGGL(k_load_x_both<1>, g, b, 0, st, batches, feats, F, x_bits, ub, ubm1);
             else if (x_bits <= 2) hipLaunchKernelGGL(k_load_x_both<2>, g, b, 0, st, batches, feats, F, x_bits, ub, ubm1);

@@ -24,6 +24,7 @@ Three ways to run the same math:
 from __future__ import annotations
 
 import argparse
+import sys
 import os
 import random
 import time
@@ -469,8 +470,10 @@ def _run_epochs(args, Q, it, feat_size, b, device):
             printed_counter.append(Q.get_counters()[1])
         row = zerotile_row(args.dataset, printed_global, printed_counter)
         if not args.quiet:
-            print(ZEROTILE_HEADER)
-            print(row["line"])
+            # (on stderr: stdout is the log the reference's parse_counter.py reads, and a line with the word `dataset` in it that is not
+            # the Namespace line stops that script - parse_counter.py:11-13 indexes the line's second comma field)
+            print(ZEROTILE_HEADER, file=sys.stderr)
+            print(row["line"], file=sys.stderr)
         return {"avg_epoch_ms": float("nan"), "outs": [], "iter": it, "counters": Q.get_counters(), "zerotile": row}
 
     if getattr(args, "pack_on_the_fly", False) and args.batched:
@@ -526,7 +529,7 @@ def _run_epochs(args, Q, it, feat_size, b, device):
         end_time = time.time()
         avg = (end_time - start_time) * 1000 / args.n_epochs
         if not args.quiet:
-            print("Avg. Epoch: {:.3f} ms".format(avg))       # main_qgtc.py:159
+            print(AVG_EPOCH_FORMAT.format(avg))
         return {"avg_epoch_ms": avg, "outs": plan.outs, "iter": it, "plan": plan}   # (the per-batch views are made here, after the clock)
     if args.batched or args.streams > 0:
         cts = [c.to(device) for c in it.cTensor_li]
@@ -559,14 +562,40 @@ def _run_epochs(args, Q, it, feat_size, b, device):
     end_time = time.time()
     avg = (end_time - start_time) * 1000 / args.n_epochs
     if not args.quiet:
-        print("Avg. Epoch: {:.3f} ms".format(avg))       # main_qgtc.py:159
+        print(AVG_EPOCH_FORMAT.format(avg))
     return {"avg_epoch_ms": avg, "outs": outs, "iter": it}
+
+
+# The reference's drivers `print(args)` (main_qgtc.py:42, cluster_gcn.py:45) and its log parsers pick the dataset's name out of that line BY
+# POSITION: parse_time.py:12 takes comma-field 2 of main_qgtc.py's line (and skips lines of fewer than five fields), parse_counter.py:13
+# comma-field 1 of cluster_gcn.py's (4_8_zero_tile_jumping.py:20-41 runs that script). Those positions are the ones of the Python the reference
+# ran on (3.7 / 3.8: argparse.Namespace printed its keys SORTED: batch_size, bit_width, dataset, .. and batch_size, dataset, ..); today's
+# argparse prints them in the order they were added (dataset first). So the line is composed here, from each script's own keys, sorted.
+MAIN_QGTC_KEYS = sorted(["dataset", "gpu", "n_epochs", "batch_size", "psize", "dim", "n_hidden", "n_classes", "n_layers", "bit_width",
+                         "use_pp", "regular", "run_GIN", "use_QGTC", "zerotile_jump"])                      # main_qgtc.py:21-39
+CLUSTER_GCN_KEYS = sorted(["dataset", "gpu", "n_epochs", "batch_size", "psize", "dim", "n_hidden", "n_classes", "n_layers",
+                           "use_pp", "regular", "use_PyG", "run_GIN", "use_QGTC", "zerotile_jump"])         # cluster_gcn.py:25-42
+AVG_EPOCH_FORMAT = "Avg. Epoch: {:.3f} ms"          # main_qgtc.py:159; parse_time.py:15-17 reads the number between ':' and 'ms'
+
+
+def args_line(args) -> str:
+    """The `Namespace(...)` line of the reference's driver this run stands in for: cluster_gcn.py's with --zerotile_jump (the zero-tile
+    profile is that script's, read by parse_counter.py), main_qgtc.py's otherwise (read by parse_time.py)."""
+    keys = CLUSTER_GCN_KEYS if args.zerotile_jump else MAIN_QGTC_KEYS
+    return "Namespace(" + ", ".join("{}={!r}".format(k, getattr(args, k, False)) for k in keys) + ")"
+
+
+def extra_flags_line(args) -> str:
+    """This driver's own flags, on a line of their own (no word of it is one the reference's parsers look for)."""
+    ours = [k for k in vars(args) if k not in MAIN_QGTC_KEYS and k not in CLUSTER_GCN_KEYS]
+    return "qgtc-mi355x flags: " + ", ".join("{}={!r}".format(k, getattr(args, k)) for k in ours)
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
     if not args.quiet:
-        print(args)   # main_qgtc.py:42 — parse_time.py greps `dataset=` from this line
+        print(args_line(args))   # main_qgtc.py:42 / cluster_gcn.py:45
+        print(extra_flags_line(args))
     return run(args)
 
 

@@ -139,12 +139,14 @@ def test_zerotile_row_from_the_driver_log(qgtc, capfd):
     args = driver.build_parser().parse_args(["--dataset", "tiny", "--psize", str(PSIZE), "--batch-size", str(BS),
                                              "--n-hidden", "64", "--use_QGTC", "--zerotile_jump"])
     res = driver.run(args, Q=qgtc)
-    out = capfd.readouterr().out.splitlines()
+    cap = capfd.readouterr()
+    out, err = cap.out.splitlines(), cap.err.splitlines()
     gl = [int(l.split(":")[1]) for l in out if l.startswith("counter_global:")]
     cn = [int(l.split(":")[1]) for l in out if l.startswith("counter:")]
     assert len(gl) == len(cn) == PSIZE // BS
     row = res["zerotile"]
-    assert driver.ZEROTILE_HEADER in out and row["line"] in out
+    assert driver.ZEROTILE_HEADER in err and row["line"] in err     # (the summary goes to stderr: stdout stays what parse_counter.py reads)
+    assert not any("dataset" in l for l in out)
     assert row["non_jumping"] == sum(gl) and row["jumping"] == sum(cn)
     assert row["line"] == "tiny , {} , {} , {:.3f}".format(sum(gl), sum(cn), sum(cn) / sum(gl))
     assert (row["per_epoch_non_jumping"], row["per_epoch_jumping"]) == (gl[-1], cn[-1]) == tuple(res["counters"])
