@@ -108,7 +108,7 @@ __device__ __forceinline__ void wave_runs(int key, int &run_start, int &run_len)
 }
 
 // work: [count x (RB + 1) bucket offsets | the buckets of batch 0 | batch 1 | .. (total_edges_pad words: the edge count rounded up to
-// even) | count 64-bit per-batch tile counters] with RB = row blocks of the largest batch; batch b's edges sit at the offset its edge
+// even) | count x RB occupied-tile counts, one per row block] with RB = row blocks of the largest batch; batch b's edges sit at the offset its edge
 // list has in src / dst. A batch whose buckets would not fit is skipped and reported.
 __global__ __launch_bounds__(LOAD_SORT_THREADS) void k_load_sort(const qgtc_loader_batch *__restrict__ tb, const int64_t *__restrict__ src,
                                                                  const int64_t *__restrict__ dst, uint32_t *__restrict__ work,
@@ -122,7 +122,6 @@ __global__ __launch_bounds__(LOAD_SORT_THREADS) void k_load_sort(const qgtc_load
     uint32_t *bucket = work + static_cast<size_t>(count) * (rb_max + 1) + b.edge_off;
     const bool fits = b.edge_off + b.n_edges <= total_edges_pad && tiles_m <= rb_max;   // (the host sized the three parts of `work`)
     for (int i = tid; i <= rb_max; i += LOAD_SORT_THREADS) hist[i] = 0u;
-    if (tid == 0) reinterpret_cast<unsigned long long *>(work + static_cast<size_t>(count) * (rb_max + 1) + total_edges_pad)[blockIdx.x] = 0ull;   // k_load_tiles' per-batch count
     __syncthreads();
     if (!fits) {
         if (tid == 0 && bad) *bad = 1;
@@ -219,22 +218,36 @@ __global__ __launch_bounds__(64) void k_load_tiles(const qgtc_loader_batch *__re
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const qgtc_loader_batch b = tb[blockIdx.y];
     const int n = b.n, kq = step128(n), tiles_m = (n + 31) / 32, rb = blockIdx.x, lane = threadIdx.x;
-    if (rb >= tiles_m) return;
+    // the block's occupied-tile count goes to its own word behind the buckets (k_load_stats sums them): no atomic
+    uint32_t *tile_count = const_cast<uint32_t *>(work) + static_cast<size_t>(count) * (rb_max + 1) + total_edges_pad + static_cast<size_t>(blockIdx.y) * rb_max + rb;
+    if (rb >= tiles_m) {
+        if (lane == 0 && stats) *tile_count = 0u;
+        return;
+    }
     const int row_words = kq * 4, tw = 32 * row_words;   // words of one bitmap of the block
     uint32_t *t1 = lds, *t2 = lds + tw, *t3 = lds + 2 * tw;
-    for (int i = lane; i < 3 * tw / 4; i += 64) reinterpret_cast<u32x4 *>(lds)[i] = u32x4{0u, 0u, 0u, 0u};
     const uint32_t *offs = work + static_cast<size_t>(blockIdx.y) * (rb_max + 1);
     const uint32_t *bucket = work + static_cast<size_t>(count) * (rb_max + 1) + b.edge_off;
     const unsigned e0 = offs[rb], e1 = offs[rb + 1];
+    // the first 256 edges of the bucket (a row block of the epochs' graphs has ~190) are IN FLIGHT while the bitmaps are cleared: loaded
+    // behind the barrier they were a memory round trip of their own in every wave's chain
+    constexpr int PRE = 4;
+    uint32_t pre[PRE];
+#pragma unroll
+    for (int i = 0; i < PRE; i++) pre[i] = e0 + 64u * i + lane < e1 ? bucket[e0 + 64u * i + lane] : 0xffffffffu;
+    for (int i = lane; i < 3 * tw / 4; i += 64) reinterpret_cast<u32x4 *>(lds)[i] = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
-    for (unsigned e = e0 + lane; e < e1; e += 64) {
-        const uint32_t pk = bucket[e];
+    auto place = [&](uint32_t pk) {
         const int r = static_cast<int>(pk >> 27), c = static_cast<int>(pk & 0x07ffffffu);
         const uint32_t bit = 1u << (31 - (c & 31));
         const int wi = r * row_words + (c >> 5);
         if (atomicOr(&t1[wi], bit) & bit)                        // multiplicities 1, 2, >= 3 land in t1, t2, t3 (k_edge_list_count)
             if (atomicOr(&t2[wi], bit) & bit) atomicOr(&t3[wi], bit);
-    }
+    };
+#pragma unroll
+    for (int i = 0; i < PRE; i++)
+        if (e0 + 64u * i + lane < e1) place(pre[i]);
+    for (unsigned e = e0 + 64u * PRE + lane; e < e1; e += 64) place(bucket[e]);
     __syncthreads();
     // rows layout: [row][k-quad] - consecutive units of a row are contiguous (every row below pad8(n) is written, zeros past the edges)
     const int units = 32 * kq, rows_here = min(32, pad8(n) - 32 * rb);
@@ -261,15 +274,25 @@ __global__ __launch_bounds__(64) void k_load_tiles(const qgtc_loader_batch *__re
     }
     if (lane == 0) {
         if (b.occ) b.occ[rb] = mask_lo;
-        // the occupied-tile count: per batch first (a 64-bit word of the work buffer: arrivals << 32 | sum, cleared by k_load_sort), and the
-        // LAST row block of a batch adds the batch's total to stats[0]. Every row block adding to stats[0] itself was 2850 device-scope
-        // atomics on ONE address - they serialise at ~15 ns each: 42 of this kernel's 45 us (and of k_load_finish's 43).
-        if (stats) {
-            unsigned long long *cnt = reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(work) + static_cast<size_t>(count) * (rb_max + 1) + total_edges_pad) + blockIdx.y;
-            const unsigned long long old = atomicAdd(cnt, (1ull << 32) | static_cast<unsigned long long>(__popcll(mask_lo)));
-            if (static_cast<int>(old >> 32) == tiles_m - 1) atomicAdd(stats, (old & 0xffffffffull) + static_cast<unsigned long long>(__popcll(mask_lo)));
-        }
+        // the occupied-tile count: a plain store to the block's own word; k_load_stats, behind this launch, adds them all to stats[0].
+        // Round 5's first forms: every row block adding to stats[0] itself = 2850 device-scope atomics on ONE address, serialised at
+        // ~15 ns each: 42 of 45 us (and of round 4's k_load_finish); then per-batch 64-bit counters whose returned old value named the
+        // batch's last row block: an atomic that RETURNS is a round trip to the memory side at the very end of every wave - 5.6 of
+        // 16 us (timing build without it: 10.4); the same adds not waited for still cost 3.5.
+        if (stats) *tile_count = static_cast<uint32_t>(__popcll(mask_lo));
     }
+}
+
+// stats[0] += the occupied-tile counts k_load_tiles left per row block (`words` of them; one workgroup)
+__global__ __launch_bounds__(256) void k_load_stats(const uint32_t *__restrict__ counts, int words, unsigned long long *__restrict__ stats) {
+    __shared__ unsigned part[4];
+    unsigned s = 0u;
+    for (int i = threadIdx.x; i < words; i += 256) s += counts[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(stats, static_cast<unsigned long long>(part[0]) + part[1] + part[2] + part[3]);
 }
 
 // val2bit of every batch's features (rows feat_row .. feat_row + n - 1 of `feats`, F columns): the cols layout the reference

@@ -537,11 +537,12 @@ int qgtc_pack_edge_list(const int64_t *src, const int64_t *dst, size_t n_edges, 
 // work buffer of the bucketed loader: [count x (RB + 1) bucket offsets | buckets | count 64-bit per-batch tile counters]; the bucket
 // region is padded by one word when that makes the counters 8-byte aligned
 static size_t load_work_offsets(int count, int max_n) { return static_cast<size_t>(count) * ((max_n + 31) / 32 + 1); }
+static size_t load_work_counts(int count, int max_n) { return static_cast<size_t>(count) * ((max_n + 31) / 32); }
 static size_t load_work_edges(int count, int max_n, uint64_t total_edges) { return static_cast<size_t>(total_edges) + ((load_work_offsets(count, max_n) + total_edges) & 1u); }
 size_t qgtc_load_work_words(int count, int max_n, uint64_t total_edges) {
     if (count <= 0 || max_n <= 0 || max_n > LOAD_SORT_MAX_N || total_edges >= (1ull << 32)) return 0u;   // 0: no bucketed route for this iterator
-    // [bucket offsets | buckets (an even number of words: the counters behind them are 64-bit) | per-batch tile counters]
-    return load_work_offsets(count, max_n) + load_work_edges(count, max_n, total_edges) + 2u * static_cast<size_t>(count);
+    // [bucket offsets | buckets (an even number of words) | one occupied-tile count per row block of every batch]
+    return load_work_offsets(count, max_n) + load_work_edges(count, max_n, total_edges) + load_work_counts(count, max_n);
 }
 
 int qgtc_load_batches(const qgtc_loader_batch *batches, int count, int max_n, uint64_t max_edges, const int64_t *src,
@@ -555,10 +556,10 @@ int qgtc_load_batches(const qgtc_loader_batch *batches, int count, int max_n, ui
     HIP_TRY(hipMemsetAsync(zero, 0, zero_bytes, st));
     if (bad_index) HIP_TRY(hipMemsetAsync(bad_index, 0, sizeof(int), st));
     const int rb_max = (max_n + TM - 1) / TM;
-    const size_t work_fixed = load_work_offsets(count, max_n) + 2u * static_cast<size_t>(count);
+    const size_t work_fixed = load_work_offsets(count, max_n) + load_work_counts(count, max_n);
     if (work && max_n <= LOAD_SORT_MAX_N && work_words >= work_fixed && !(reinterpret_cast<uintptr_t>(work) & 7u) && !getenv_flag("QGTC_NO_LOAD_SORT")) {
         size_t edges_pad = work_words - work_fixed;                                    // what the caller left for the buckets (a batch that does not fit is reported)
-        if ((load_work_offsets(count, max_n) + edges_pad) & 1u) edges_pad -= 1u;       // the counters behind them stay 8-byte aligned
+        if ((load_work_offsets(count, max_n) + edges_pad) & 1u) edges_pad -= 1u;       // (an even number of words, as qgtc_load_work_words counts them)
         // the bucketed route (loader_kernels.hip.h): edges by row block, then every word of rows + tiles + bitmaps written once from LDS
         hipLaunchKernelGGL(k_load_sort, dim3(count), dim3(LOAD_SORT_THREADS), 0, st, batches, src, dst, work, static_cast<unsigned long long>(work_words),
                            rb_max, count, static_cast<unsigned long long>(edges_pad), bad_index);
@@ -566,6 +567,9 @@ int qgtc_load_batches(const qgtc_loader_batch *batches, int count, int max_n, ui
         const size_t lds = static_cast<size_t>(3) * 32 * step128(max_n) * 16;
         hipLaunchKernelGGL(k_load_tiles, dim3(rb_max, count), dim3(64), lds, st, batches, work, rb_max, count, static_cast<unsigned long long>(edges_pad),
                            reinterpret_cast<unsigned long long *>(stats));
+        if (stats)
+            hipLaunchKernelGGL(k_load_stats, dim3(1), dim3(256), 0, st, work + static_cast<size_t>(count) * (rb_max + 1) + edges_pad, count * rb_max,
+                               reinterpret_cast<unsigned long long *>(stats));
         HIP_TRY(hipGetLastError());
     } else {
         if (max_edges) {

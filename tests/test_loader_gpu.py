@@ -192,7 +192,7 @@ def test_load_batches_through_the_raw_abi(oracle, with_work):
                                       vp, vp, ctypes.c_uint, vp, ctypes.c_size_t, vp]
     lib.qgtc_load_work_words.restype = ctypes.c_size_t
     lib.qgtc_load_work_words.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint64]
-    assert lib.qgtc_load_work_words(3, 257, sum(ecounts)) == 3 * (9 + 1) + sum(ecounts) + (sum(ecounts) & 1) + 2 * 3 and lib.qgtc_load_work_words(3, 5121, 10) == 0
+    assert lib.qgtc_load_work_words(3, 257, sum(ecounts)) == 3 * (9 + 1) + sum(ecounts) + (sum(ecounts) & 1) + 3 * 9 and lib.qgtc_load_work_words(3, 5121, 10) == 0
     st = torch.cuda.current_stream().cuda_stream
     stats_ptr = zero.data_ptr() + 4 * sum(a_words)
     if with_work:    # only `stats` is cleared; A stays poisoned until the call has written every word of it
