@@ -131,7 +131,7 @@ __global__ __launch_bounds__(LOAD_SORT_THREADS) void k_load_sort(const qgtc_load
     const int64_t *s = src + b.edge_off, *d = dst + b.edge_off;
     // A batch of at most EPT x 1024 edges (the cluster batches of the reference's datasets have 2 - 70 k) is read ONCE: every load issued
     // before the first is used, the packed edges stay in registers over the scan. Longer lists are read twice, edge by edge.
-    constexpr int EPT = 8;
+    constexpr int EPT = 8, CH = 4;
     const bool resident = b.n_edges <= static_cast<unsigned long long>(EPT) * LOAD_SORT_THREADS;   // (workgroup-uniform)
     uint32_t pk[EPT];
     int bucket_of[EPT];
@@ -158,13 +158,26 @@ __global__ __launch_bounds__(LOAD_SORT_THREADS) void k_load_sort(const qgtc_load
             if (ok && (tid & 63) == run_start) atomicAdd(&hist[bucket_of[k]], static_cast<unsigned>(run_len));
         }
     } else {
-        for (unsigned long long e = tid; e < b.n_edges; e += LOAD_SORT_THREADS) {
-            const int64_t r = s[e], c = d[e];
-            if (r < 0 || r >= n || c < 0 || c >= n) {
-                if (bad) *bad = 1;
-                continue;
+        // (in passes of CH x 1024 edges, every load of a pass issued before the first is used, and the same one-atomic-per-run histogram:
+        // edge by edge with an atomic each, the ppi-sized iterator's 17 k-edge batches took 24 us - SQ_LDS_BANK_CONFLICT 1.39 M cycles)
+        for (unsigned long long e0 = 0; e0 < b.n_edges; e0 += static_cast<unsigned long long>(CH) * LOAD_SORT_THREADS) {   // (workgroup-uniform)
+            int64_t rr[CH], cc[CH];
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const unsigned long long e = e0 + static_cast<unsigned long long>(k) * LOAD_SORT_THREADS + tid;
+                rr[k] = e < b.n_edges ? s[e] : -1;
+                cc[k] = e < b.n_edges ? d[e] : 0;
             }
-            atomicAdd(&hist[static_cast<int>(r) >> 5], 1u);
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const unsigned long long e = e0 + static_cast<unsigned long long>(k) * LOAD_SORT_THREADS + tid;
+                const bool ok = rr[k] >= 0 && rr[k] < n && cc[k] >= 0 && cc[k] < n;
+                if (e < b.n_edges && !ok && bad) *bad = 1;
+                const int bk = ok ? static_cast<int>(rr[k]) >> 5 : -1;
+                int run_start, run_len;
+                wave_runs(bk, run_start, run_len);
+                if (ok && (tid & 63) == run_start) atomicAdd(&hist[bk], static_cast<unsigned>(run_len));
+            }
         }
     }
     __syncthreads();
@@ -203,11 +216,25 @@ __global__ __launch_bounds__(LOAD_SORT_THREADS) void k_load_sort(const qgtc_load
             if (bucket_of[k] >= 0) bucket[base + static_cast<unsigned>((tid & 63) - run_start)] = pk[k];
         }
     } else {
-        for (unsigned long long e = tid; e < b.n_edges; e += LOAD_SORT_THREADS) {
-            const int64_t r = s[e], c = d[e];
-            if (r < 0 || r >= n || c < 0 || c >= n) continue;
-            const unsigned slot = atomicAdd(&hist[static_cast<int>(r) >> 5], 1u);
-            bucket[slot] = (static_cast<uint32_t>(r) & 31u) << 27 | static_cast<uint32_t>(c);
+        for (unsigned long long e0 = 0; e0 < b.n_edges; e0 += static_cast<unsigned long long>(CH) * LOAD_SORT_THREADS) {
+            int64_t rr[CH], cc[CH];
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const unsigned long long e = e0 + static_cast<unsigned long long>(k) * LOAD_SORT_THREADS + tid;
+                rr[k] = e < b.n_edges ? s[e] : -1;
+                cc[k] = e < b.n_edges ? d[e] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const bool ok = rr[k] >= 0 && rr[k] < n && cc[k] >= 0 && cc[k] < n;
+                const int bk = ok ? static_cast<int>(rr[k]) >> 5 : -1;
+                int run_start, run_len;
+                wave_runs(bk, run_start, run_len);
+                unsigned base = 0u;
+                if (ok && (tid & 63) == run_start) base = atomicAdd(&hist[bk], static_cast<unsigned>(run_len));
+                base = __shfl(base, run_start);
+                if (ok) bucket[base + static_cast<unsigned>((tid & 63) - run_start)] = (static_cast<uint32_t>(rr[k]) & 31u) << 27 | static_cast<uint32_t>(cc[k]);
+            }
         }
     }
 }
@@ -283,16 +310,27 @@ __global__ __launch_bounds__(64) void k_load_tiles(const qgtc_loader_batch *__re
     }
 }
 
-// stats[0] += the occupied-tile counts k_load_tiles left per row block (`words` of them; one workgroup)
-__global__ __launch_bounds__(256) void k_load_stats(const uint32_t *__restrict__ counts, int words, unsigned long long *__restrict__ stats) {
-    __shared__ unsigned part[4];
+// stats[0] += the occupied-tile counts k_load_tiles left per row block (`words` of them; one workgroup of 1024; four loads a thread in
+// flight at once - as a plain `s += counts[i]` loop of 256 threads the twelve loads of a thread went out one behind the other: 4.9 us)
+__global__ __launch_bounds__(1024) void k_load_stats(const uint32_t *__restrict__ counts, int words, unsigned long long *__restrict__ stats) {
+    __shared__ unsigned part[16];
     unsigned s = 0u;
-    for (int i = threadIdx.x; i < words; i += 256) s += counts[i];
+    for (int i0 = threadIdx.x; i0 < words; i0 += 4096) {
+        unsigned v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = i0 + 1024 * k < words ? counts[i0 + 1024 * k] : 0u;
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(stats, static_cast<unsigned long long>(part[0]) + part[1] + part[2] + part[3]);
+    if (threadIdx.x < 16) {
+        unsigned t = part[threadIdx.x];
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+        if (threadIdx.x == 0) atomicAdd(stats, static_cast<unsigned long long>(t));
+    }
 }
 
 // val2bit of every batch's features (rows feat_row .. feat_row + n - 1 of `feats`, F columns): the cols layout the reference

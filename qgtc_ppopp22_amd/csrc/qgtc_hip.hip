@@ -568,7 +568,7 @@ int qgtc_load_batches(const qgtc_loader_batch *batches, int count, int max_n, ui
         hipLaunchKernelGGL(k_load_tiles, dim3(rb_max, count), dim3(64), lds, st, batches, work, rb_max, count, static_cast<unsigned long long>(edges_pad),
                            reinterpret_cast<unsigned long long *>(stats));
         if (stats)
-            hipLaunchKernelGGL(k_load_stats, dim3(1), dim3(256), 0, st, work + static_cast<size_t>(count) * (rb_max + 1) + edges_pad, count * rb_max,
+            hipLaunchKernelGGL(k_load_stats, dim3(1), dim3(1024), 0, st, work + static_cast<size_t>(count) * (rb_max + 1) + edges_pad, count * rb_max,
                                reinterpret_cast<unsigned long long *>(stats));
         HIP_TRY(hipGetLastError());
     } else {
