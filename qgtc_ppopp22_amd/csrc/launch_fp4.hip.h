@@ -32,13 +32,13 @@ static int launch_one(const qgtc_problem &pr, int a, int w, int ob, int mode, bo
     const uint32_t xb = static_cast<uint32_t>(pr.x_words * 4u), wb = static_cast<uint32_t>(pr.w_words * 4u);
     const uint32_t ob_ = static_cast<uint32_t>(one_out_bytes(pr, ob, mode));
 #define QGTC_ONE_GO(NA_, NW_, MODE_, RF_)                                                                          \
-    hipLaunchKernelGGL((k_bitmm_fp4_one<NA_, NW_, MODE_, RF_, 2>), grid, block, 0, st, pr.X, pr.W, pr.out, xb, wb, ob_, pr.M, \
+    QGTC_LAUNCH((k_bitmm_fp4_one<NA_, NW_, MODE_, RF_, 2>), grid, block, 0, st, pr.X, pr.W, pr.out, xb, wb, ob_, pr.M, \
                        pr.K, pr.N, pr.w_lines, cfg)
 #define QGTC_ONE_TALL(NA_, NW_)                                                                                               \
     if (!done && tall && a <= NA_ && w <= NW_) {                                                                               \
         done = true;                                                                                                           \
-        if (mode == 2) hipLaunchKernelGGL((k_bitmm_fp4_one<NA_, NW_, 2, 4, 1>), grid, block, 0, st, pr.X, pr.W, pr.out, xb, wb, ob_, pr.M, pr.K, pr.N, pr.w_lines, cfg); \
-        else hipLaunchKernelGGL((k_bitmm_fp4_one<NA_, NW_, 0, 4, 1>), grid, block, 0, st, pr.X, pr.W, pr.out, xb, wb, ob_, pr.M, pr.K, pr.N, pr.w_lines, cfg);           \
+        if (mode == 2) QGTC_LAUNCH((k_bitmm_fp4_one<NA_, NW_, 2, 4, 1>), grid, block, 0, st, pr.X, pr.W, pr.out, xb, wb, ob_, pr.M, pr.K, pr.N, pr.w_lines, cfg); \
+        else QGTC_LAUNCH((k_bitmm_fp4_one<NA_, NW_, 0, 4, 1>), grid, block, 0, st, pr.X, pr.W, pr.out, xb, wb, ob_, pr.M, pr.K, pr.N, pr.w_lines, cfg);           \
     }
 #define QGTC_ONE_LAUNCH(NA_, NW_)                                       \
     if (!done && a <= NA_ && w <= NW_) {                                \
@@ -72,13 +72,13 @@ int qgtc_launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, b
     if (!done && a <= NA_ && w <= NW_) {                                                                           \
         done = true;                                                                                               \
         if (mode == 1) {                                                                                           \
-            hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 1, 2, 2>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh, zs);            \
+            QGTC_LAUNCH((k_bitmm_fp4_skinny<NA_, NW_, 1, 2, 2>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh, zs);            \
         } else if (mode == 2) {                                                                                    \
-            if (wide) hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 2, 2, 2>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh, zs);  \
-            else hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 2, 1, 2>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh, zs);       \
+            if (wide) QGTC_LAUNCH((k_bitmm_fp4_skinny<NA_, NW_, 2, 2, 2>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh, zs);  \
+            else QGTC_LAUNCH((k_bitmm_fp4_skinny<NA_, NW_, 2, 1, 2>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh, zs);       \
         } else {                                                                                                   \
-            if (wide) hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 0, 2, 2>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh, zs);  \
-            else hipLaunchKernelGGL((k_bitmm_fp4_skinny<NA_, NW_, 0, 1, 2>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh, zs);       \
+            if (wide) QGTC_LAUNCH((k_bitmm_fp4_skinny<NA_, NW_, 0, 2, 2>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh, zs);  \
+            else QGTC_LAUNCH((k_bitmm_fp4_skinny<NA_, NW_, 0, 1, 2>), grid, dim3(64 * SK_WAVES), 0, st, pr, sh, zs);       \
         }                                                                                                          \
     }
     bool done = false;
@@ -164,7 +164,7 @@ int qgtc_launch_rows_single(const qgtc_problem &pr, int a, int w, int ob, int mo
     const int waves = mode == 2 ? (pr.N + 31) / 32 : mode == 1 ? pad128(pr.N) / 32 : step128(pr.N) * 4;
     if (waves > 8 || mode < 0 || mode > 2) return QGTC_EINVAL;
     const dim3 grid(mode == 1 ? step128(pr.M) * 4 : (pr.M + 31) / 32), block(64 * waves);   // (cols layout: a workgroup per word of a line)
-#define QGTC_RW1_GO(NA_, NW_, MODE_, OB_) hipLaunchKernelGGL((k_bitmm_fp4_rows_single<NA_, NW_, MODE_, OB_>), grid, block, 0, st, pr, sh)
+#define QGTC_RW1_GO(NA_, NW_, MODE_, OB_) QGTC_LAUNCH((k_bitmm_fp4_rows_single<NA_, NW_, MODE_, OB_>), grid, block, 0, st, pr, sh)
 #define QGTC_RW1_LAUNCH(NA_, NW_, OBS_)                                  \
     if (!done && a <= NA_ && w <= NW_) {                                 \
         done = true;                                                     \
@@ -223,7 +223,7 @@ int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int K, int
     const int ncb = (N + 31) / 32, kq = step128(K);   // (the k-quads of the WEIGHT TABLES: launch-uniform, preloaded into an SGPR)
     if (ob < 1 || ob > 4 || a < 1 || a > (ob > 2 ? 4 : 2) || ncb < 1 || ncb > 4) return QGTC_EINVAL;
     // column blocks 1 / 2 / 4 (three run as four: the lines past N are zeros); the 2-bit chain of the BASELINE epoch also has its own three
-#define QGTC_RBWX_GO(NA_, OB_, NCB_) hipLaunchKernelGGL((k_rbw_xw<NA_, OB_, NCB_>), grid, block, 0, st, prs, wc, per, a, gx, gy, kq)
+#define QGTC_RBWX_GO(NA_, OB_, NCB_) QGTC_LAUNCH((k_rbw_xw<NA_, OB_, NCB_>), grid, block, 0, st, prs, wc, per, a, gx, gy, kq)
 #define QGTC_RBWX_OB(NA_, OB_)                                            \
     if (ncb == 1) QGTC_RBWX_GO(NA_, OB_, 1);                              \
     else if (ncb == 2) QGTC_RBWX_GO(NA_, OB_, 2);                         \
@@ -262,7 +262,7 @@ int qgtc_launch_rbw_chain(const qgtc_problem *p1, const qgtc_problem *p2, int co
     if (c1 < 1 || c1 > 4 || c2 < 1 || c2 > 4 || mode2 < 0 || mode2 > 2) return QGTC_EINVAL;
     const int ob = mode2 == 0 ? t_bits : act_bits;   // (the float32 aggregation re-quantises nothing: the format class of T is all it needs)
     (void)out_bits;                                  // (== act_bits: rbw_chain_ok)
-#define QGTC_RBW_GO(OB_, MODE2_, C1_, C2_) hipLaunchKernelGGL((k_rbw_chain<OB_, OB_, MODE2_, C1_, C2_>), grid, block, 0, st, p1, p2, wc, per, tiles, gx, gy)
+#define QGTC_RBW_GO(OB_, MODE2_, C1_, C2_) QGTC_LAUNCH((k_rbw_chain<OB_, OB_, MODE2_, C1_, C2_>), grid, block, 0, st, p1, p2, wc, per, tiles, gx, gy)
     // column blocks 1 / 2 / 4 (three run as four: lines past N are zeros, columns past N are not stored); the 2-bit family - the
     // BASELINE epoch's - keeps its own three
 #define QGTC_RBW_C2(OB_, MODE2_, C1_)                                    \

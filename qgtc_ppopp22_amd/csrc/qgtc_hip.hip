@@ -129,14 +129,14 @@ int qgtc_val2bit(const float *x, int H, int W, int nbits, int col_major, int out
             // 8192^2 50.4 -> 45.6 us = 6.1 TB/s: more, shorter waves hide the HBM latency better than deeper unrolling
             if (units <= 8192u * 8u) {
                 const unsigned g = grid_for((units + 1) / 2, 4, 8192);
-                hipLaunchKernelGGL(k_val2bit_rows_v4<2>, dim3(g), dim3(256), 0, st, x, H, W, nbits, ub, ubm1, out, rows_pad, row_words, static_cast<int>(4u * g));
+                QGTC_LAUNCH(k_val2bit_rows_v4<2>, dim3(g), dim3(256), 0, st, x, H, W, nbits, ub, ubm1, out, rows_pad, row_words, static_cast<int>(4u * g));
             } else {
                 const unsigned g = grid_for((units + 3) / 4, 4, 8192);
-                hipLaunchKernelGGL(k_val2bit_rows_v4<4>, dim3(g), dim3(256), 0, st, x, H, W, nbits, ub, ubm1, out, rows_pad, row_words, static_cast<int>(4u * g));
+                QGTC_LAUNCH(k_val2bit_rows_v4<4>, dim3(g), dim3(256), 0, st, x, H, W, nbits, ub, ubm1, out, rows_pad, row_words, static_cast<int>(4u * g));
             }
         } else {
             const unsigned g = grid_for(units, 4);
-            hipLaunchKernelGGL(k_val2bit_rows, dim3(g), dim3(256), 0, st, x, H, W, nbits, ub, ubm1, out, rows_pad, row_words, static_cast<int>(4u * g));
+            QGTC_LAUNCH(k_val2bit_rows, dim3(g), dim3(256), 0, st, x, H, W, nbits, ub, ubm1, out, rows_pad, row_words, static_cast<int>(4u * g));
         }
     } else {
         if (out_words < qgtc_cols_words(H, W, nbits, output_layer)) return QGTC_ESIZE;
@@ -145,15 +145,15 @@ int qgtc_val2bit(const float *x, int H, int W, int nbits, int col_major, int out
         const dim3 g(grid_for(units, 4, 8192)), b(256);   // (cap 2048 -> 8192: 8192^2 49.1 -> 41.4 us = 6.7 TB/s)
         const int nw = static_cast<int>(4u * g.x);
         if (nbits <= 1)
-            hipLaunchKernelGGL(k_val2bit_cols<1>, g, b, 0, st, x, H, W, nbits, ub, ubm1, out, lines, line_words, nw);
+            QGTC_LAUNCH(k_val2bit_cols<1>, g, b, 0, st, x, H, W, nbits, ub, ubm1, out, lines, line_words, nw);
         else if (nbits <= 2)
-            hipLaunchKernelGGL(k_val2bit_cols<2>, g, b, 0, st, x, H, W, nbits, ub, ubm1, out, lines, line_words, nw);
+            QGTC_LAUNCH(k_val2bit_cols<2>, g, b, 0, st, x, H, W, nbits, ub, ubm1, out, lines, line_words, nw);
         else if (nbits <= 4)
-            hipLaunchKernelGGL(k_val2bit_cols<4>, g, b, 0, st, x, H, W, nbits, ub, ubm1, out, lines, line_words, nw);
+            QGTC_LAUNCH(k_val2bit_cols<4>, g, b, 0, st, x, H, W, nbits, ub, ubm1, out, lines, line_words, nw);
         else if (nbits <= 8)
-            hipLaunchKernelGGL(k_val2bit_cols<8>, g, b, 0, st, x, H, W, nbits, ub, ubm1, out, lines, line_words, nw);
+            QGTC_LAUNCH(k_val2bit_cols<8>, g, b, 0, st, x, H, W, nbits, ub, ubm1, out, lines, line_words, nw);
         else
-            hipLaunchKernelGGL(k_val2bit_cols<32>, g, b, 0, st, x, H, W, nbits, ub, ubm1, out, lines, line_words, nw);
+            QGTC_LAUNCH(k_val2bit_cols<32>, g, b, 0, st, x, H, W, nbits, ub, ubm1, out, lines, line_words, nw);
     }
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
@@ -174,7 +174,7 @@ int qgtc_bit2val(const uint32_t *bits, size_t bits_words, int nbits, int H, int 
     }
     const size_t total = static_cast<size_t>(H) * W;
     const unsigned g = grid_for(total, 256);
-    hipLaunchKernelGGL(k_bit2val, dim3(g), dim3(256), 0, st, bits, static_cast<unsigned long long>(bits_words), nbits, H, W, col_major, plane, line_words, out, 256u * g);
+    QGTC_LAUNCH(k_bit2val, dim3(g), dim3(256), 0, st, bits, static_cast<unsigned long long>(bits_words), nbits, H, W, col_major, plane, line_words, out, 256u * g);
     HIP_TRY(hipGetLastError());
     return QGTC_OK;
 }

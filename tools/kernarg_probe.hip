@@ -48,6 +48,18 @@ int main() {
         run("lean (56-byte kernarg)", [&] { hipLaunchKernelGGL(k_lean, dim3(grid), dim3(256), 0, 0, a, b, o, 1u, 2u, 3u, 4, 5, 6, 7, 0u); });
         run("implicit (312-byte kernarg)", [&] { hipLaunchKernelGGL(k_implicit, dim3(grid), dim3(256), 0, 0, a, b, o, 1u, 2u, 3u, 4, 5, 6, 7, 0u); });
         run("lean (56-byte kernarg)", [&] { hipLaunchKernelGGL(k_lean, dim3(grid), dim3(256), 0, 0, a, b, o, 1u, 2u, 3u, 4, 5, 6, 7, 0u); });
+        // the same kernel through the module API: function handle resolved once, arguments handed over as ONE packed buffer
+        hipFunction_t fn;
+        if (hipGetFuncBySymbol(&fn, reinterpret_cast<const void *>(k_lean)) == hipSuccess) {
+            struct __attribute__((packed)) Args { const uint32_t *a, *b; uint32_t *o; uint32_t x, y, z; int M, K, N, L; uint32_t cfg; } args{a, b, o, 1u, 2u, 3u, 4, 5, 6, 7, 0u};
+            size_t size = sizeof(args);
+            void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+            run("lean, hipModuleLaunchKernel", [&] { hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, 0, nullptr, extra); });
+            void *params[] = {&args.a, &args.b, &args.o, &args.x, &args.y, &args.z, &args.M, &args.K, &args.N, &args.L, &args.cfg};
+            run("lean, module API, param array", [&] { hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, 0, params, nullptr); });
+        } else {
+            printf("hipGetFuncBySymbol failed\n");
+        }
     }
     return 0;
 }
