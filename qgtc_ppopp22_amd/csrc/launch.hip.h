@@ -46,7 +46,7 @@ int launch_single(const qgtc_problem &pr, const Plan &pl, hipStream_t st) {
     sh.inv_tiles_n = tiles_n > 1 ? static_cast<uint32_t>((1ull << 32) / tiles_n) : 0xffffffffu;
     QGTC_LAUNCH((k_bitmm<QW, NA, NW, ZS>), dim3(tiles_m * tiles_n), dim3(64 * pl.waves), pl.lds,
                        st, pr, sh, tiles_m, tiles_n);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     return QGTC_OK;
 }
 

@@ -70,6 +70,17 @@ inline bool getenv_flag_now(const char *name) {
 // 2.76 on a slower host) - the eager issue loops (the reference's K launches back to back, an unchanged driver's 450 calls an epoch) are
 // bound by exactly that. Arguments are converted to the kernel's own parameter types first (the module API reads them through pointers).
 // QGTC_NO_MODULE_LAUNCH=1, or a runtime without the lookup: the ordinary hipLaunchKernelGGL.
+inline hipError_t &launch_error_slot() {
+    static thread_local hipError_t e = hipSuccess;
+    return e;
+}
+// what the QGTC_LAUNCHes of this thread since the last call returned (the first failure), in place of a hipGetLastError() API call per launch
+inline hipError_t launch_status() {
+    hipError_t &e = launch_error_slot();
+    const hipError_t r = e;
+    e = hipSuccess;
+    return r;
+}
 template <auto Kern>
 struct KernelLaunch;
 template <class... P, void (*Kern)(P...)>
@@ -89,9 +100,12 @@ struct KernelLaunch<Kern> {
     static void go(dim3 grid, dim3 block, unsigned lds, hipStream_t st, P... p) {
         if (hipFunction_t fn = handle()) {
             void *params[] = {const_cast<void *>(static_cast<const void *>(&p))...};
-            (void)hipModuleLaunchKernel(fn, grid.x, grid.y, grid.z, block.x, block.y, block.z, lds, st, params, nullptr);   // (errors: hipGetLastError at the call site)
+            const hipError_t e = hipModuleLaunchKernel(fn, grid.x, grid.y, grid.z, block.x, block.y, block.z, lds, st, params, nullptr);
+            if (e != hipSuccess && launch_error_slot() == hipSuccess) launch_error_slot() = e;
         } else {
             hipLaunchKernelGGL(Kern, grid, block, lds, st, p...);
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess && launch_error_slot() == hipSuccess) launch_error_slot() = e;
         }
     }
 };

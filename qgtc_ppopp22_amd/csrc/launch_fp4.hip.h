@@ -54,7 +54,7 @@ static int launch_one(const qgtc_problem &pr, int a, int w, int ob, int mode, bo
 #undef QGTC_ONE_LAUNCH
 #undef QGTC_ONE_TALL
 #undef QGTC_ONE_GO
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     return QGTC_OK;
 }
 
@@ -85,7 +85,7 @@ int qgtc_launch_skinny(const qgtc_problem &pr, int a, int w, int ob, int mode, b
     QGTC_SK_LAUNCH(1, 1) QGTC_SK_LAUNCH(1, 2) QGTC_SK_LAUNCH(1, 4) QGTC_SK_LAUNCH(1, 8)
     QGTC_SK_LAUNCH(2, 1) QGTC_SK_LAUNCH(2, 2) QGTC_SK_LAUNCH(2, 4) QGTC_SK_LAUNCH(2, 8)
 #undef QGTC_SK_LAUNCH
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     return QGTC_OK;
 }
 
@@ -179,7 +179,7 @@ int qgtc_launch_rows_single(const qgtc_problem &pr, int a, int w, int ob, int mo
 #undef QGTC_RW1_LAUNCH
 #undef QGTC_RW1_GO
     if (!done) return QGTC_EINVAL;
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     return QGTC_OK;
 }
 
@@ -237,7 +237,7 @@ int qgtc_launch_rbw_xw(const qgtc_problem *prs, int count, int max_M, int K, int
     }
 #undef QGTC_RBWX_OB
 #undef QGTC_RBWX_GO
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     return QGTC_OK;
 }
 
@@ -307,6 +307,6 @@ int qgtc_launch_rbw_chain(const qgtc_problem *p1, const qgtc_problem *p2, int co
 #undef QGTC_RBW_C1
 #undef QGTC_RBW_C2
 #undef QGTC_RBW_GO
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     return QGTC_OK;
 }

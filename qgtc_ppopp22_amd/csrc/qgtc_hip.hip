@@ -155,7 +155,7 @@ int qgtc_val2bit(const float *x, int H, int W, int nbits, int col_major, int out
         else
             QGTC_LAUNCH(k_val2bit_cols<32>, g, b, 0, st, x, H, W, nbits, ub, ubm1, out, lines, line_words, nw);
     }
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     return QGTC_OK;
 }
 
@@ -175,7 +175,7 @@ int qgtc_bit2val(const uint32_t *bits, size_t bits_words, int nbits, int H, int 
     const size_t total = static_cast<size_t>(H) * W;
     const unsigned g = grid_for(total, 256);
     QGTC_LAUNCH(k_bit2val, dim3(g), dim3(256), 0, st, bits, static_cast<unsigned long long>(bits_words), nbits, H, W, col_major, plane, line_words, out, 256u * g);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     return QGTC_OK;
 }
 
