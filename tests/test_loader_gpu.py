@@ -85,6 +85,35 @@ def test_grouped_loader_equals_the_oracle_and_the_single_batch_entries(qgtc, ora
         qgtc.EpochPlan.load(src, dst, ecounts[:-1] + [ecounts[-1] + 1], X, sizes, bits)
 
 
+
+@pytest.mark.parametrize("seed", range(16))
+def test_grouped_loader_random_shapes_equal_the_oracle(qgtc, oracle, seed):
+    """Random batch counts, sizes, feature widths (odd, below and above a 64-column chunk) and bit widths: the adjacency and BOTH layouts of
+    X - the rows layout comes out of a 32 x 32 bit transpose over the lanes of the cols-layout words (pack_kernels.hip.h::transpose32_lanes)."""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    sizes = [int(v) for v in rng.integers(1, 900, int(rng.integers(1, 5)))]
+    if seed % 4 == 0:
+        sizes.append(1700)                       # (up to 13 600 edges: the passes of k_load_sort beyond its register-resident form)
+    F, bits = int(rng.integers(1, 200)), int(rng.integers(1, 9))
+    rows, cols, feats, ecounts = _batches(rng, sizes, F, empty_first=(seed % 5 == 0))
+    src, dst = (torch.from_numpy(np.concatenate(v)).cuda() for v in (rows, cols))
+    X = torch.from_numpy(np.concatenate(feats)).cuda()
+    plan = qgtc.EpochPlan.load(src, dst, ecounts, X, sizes, bits, True, 0, True, True)
+    torch.cuda.synchronize()
+    occupied = 0
+    for i, n in enumerate(sizes):
+        oA = oracle.val2bit(_dense(n, rows[i], cols[i]), 1)
+        np.testing.assert_array_equal(to_np_u32(plan.As[i]), oA, err_msg=f"A of batch {i} (sizes {sizes}, F {F}, {bits} bits)")
+        np.testing.assert_array_equal(to_np_u32(plan.Xs[i]), oracle.val2bit(feats[i], bits, True), err_msg=f"X (cols) of batch {i} (F {F}, {bits} bits)")
+        np.testing.assert_array_equal(to_np_u32(plan.Xrs[i]), oracle.val2bit(feats[i], bits, False), err_msg=f"X (rows) of batch {i} (F {F}, {bits} bits)")
+        occ = qgtc.tile_occupancy(torch.from_numpy(oA.view(np.int32)).cuda(), n, n, 1)
+        assert torch.equal(plan.format_of(i, -1), occ), f"bitmap of batch {i}"
+        occupied += int(sum(bin(int(w) & (2 ** 64 - 1)).count("1") for w in occ.cpu().numpy().view(np.uint64)))
+    tiles_all = sum(((n + 31) // 32) * ((n + 127) // 128) for n in sizes)
+    assert abs(plan.occupied_fraction - occupied / tiles_all) < 1e-12       # (k_load_stats: the sum of the per-row-block counts)
+
+
 _LIB = None
 
 
