@@ -1,6 +1,6 @@
 """In-tree build of the native pieces (called by __graft_entry__.build()).
 
-  libqgtc_hip.so                    hipcc --offload-arch=gfx950  csrc/qgtc_hip.hip + qgtc_mfma.hip + qgtc_fp4.hip + qgtc_wide.hip + qgtc_epoch.hip + qgtc_chainx.hip (six translation
+  libqgtc_hip.so                    hipcc --offload-arch=gfx950  csrc/qgtc_hip.hip + qgtc_mfma.hip + qgtc_fp4.hip + qgtc_wide.hip + qgtc_epoch.hip + qgtc_chainx.hip + qgtc_stream.hip (seven translation
                                     units compiled in parallel; they include csrc/*.hip.h, the kernels)
   QGTC.cpython-*.so                 g++                          csrc/qgtc_torch.cpp (pybind11 binding)
 
@@ -39,7 +39,7 @@ def _run(cmd: list[str]) -> None:
     subprocess.run(cmd, check=True)
 
 
-HIP_UNITS = ("qgtc_hip.hip", "qgtc_mfma.hip", "qgtc_fp4.hip", "qgtc_wide.hip", "qgtc_epoch.hip", "qgtc_chainx.hip")   # translation units of libqgtc_hip.so, compiled in parallel
+HIP_UNITS = ("qgtc_hip.hip", "qgtc_mfma.hip", "qgtc_fp4.hip", "qgtc_wide.hip", "qgtc_epoch.hip", "qgtc_chainx.hip", "qgtc_stream.hip")   # translation units of libqgtc_hip.so, compiled in parallel
 
 
 OBJ_DIR = os.path.join(PKG, "build")    # objects + dependency files of the translation units (git- and gpurun-ignored)

@@ -32,6 +32,8 @@ int qgtc_launch_rows_to_tiles(const uint32_t *rows, size_t words, int M, int K, 
 
 // defined in qgtc_wide.hip
 int qgtc_launch_wide(const qgtc_problem &pr, int a, int w, int ob, int mode, hipStream_t st);
+// defined in qgtc_stream.hip (bitmm_fp4_stream.hip.h: one-plane operands, long K, at most 256 columns)
+int qgtc_launch_stream(const qgtc_problem &pr, int ob, int mode, bool zero_skip, hipStream_t st);
 // defined in qgtc_epoch.hip: QGTC_CHECK_DESCRIPTORS (kind 0 one stage / 1 layer / 2 chain / 3 one stage, `out` unused / 4 the pair of
 // qgtc_chain_aggregate; p2 may be NULL; exact_N*: the descriptors' N must equal it)
 int qgtc_launch_check_descriptors(const qgtc_problem *p1, const qgtc_problem *p2, int count, int max_M, int max_K1, int max_N1,
@@ -125,15 +127,17 @@ inline MMShape base_shape(int a, int w, int ob, int mode) {
     return sh;
 }
 
-// no int32 accumulator of a product with this K can wrap (then requantisation needs no sign test)
+// no int32 accumulator of a product with this K can wrap (then requantisation needs no sign test). Every bound on a sum in this file counts
+// the WHOLE k-quads of a line, PAD128(K) bits: the kernels AND and multiply the padding bits of the last k-quad as the reference does
+// (kernel.h:301-308), and operands that do not come from val2bit may carry set bits there (tests/test_edge_domain_gpu.py: raw words, K = 1).
 inline int no_wrap(int K, int a, int w) {
     if (a > 16 || w > 16) return 0;
-    return static_cast<double>(K) * ((1u << a) - 1u) * ((1u << w) - 1u) < 2147483648.0;
+    return static_cast<double>(pad128(K)) * ((1u << a) - 1u) * ((1u << w) - 1u) < 2147483648.0;
 }
 
 // the FP4 form of the matrix-core engine: 2-bit values at most and float32 sums that stay exact
 inline bool fp4_ok(int K, int a, int w) {
-    return a <= 2 && w <= 2 && static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
+    return a <= 2 && w <= 2 && static_cast<double>(pad128(K)) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
 }
 
 // wide right operands; 1, 2, 4 or 8 planes on one side with 1 or 2 on the other (a stage of 4 x 4 planes and up does
@@ -144,7 +148,7 @@ inline bool wide_ok(const qgtc_problem &pr, int a, int w, int ob, int mode) {
                                        : static_cast<size_t>(ob) * (mode == 1 ? pad128(pr.N) : pad8(pr.M)) * step128(mode == 1 ? pr.M : pr.N) * 16u;
     const int nl = mode == 1 ? w : a, nr = mode == 1 ? a : w;   // planes of the operand that supplies the output lines / bits
     const bool planes = ((nl == 1 || nl == 2) && (nr == 1 || nr == 2 || nr == 4 || nr == 8)) || ((nl == 4 || nl == 8) && (nr == 1 || nr == 2));
-    return planes && static_cast<double>(pr.K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0 && (mode == 2 || (ob >= 1 && ob <= 23)) &&
+    return planes && static_cast<double>(pad128(pr.K)) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0 && (mode == 2 || (ob >= 1 && ob <= 23)) &&
            pr.x_words < (1ull << 30) && pr.w_words < (1ull << 30) && out_bytes < (1ull << 32) && !getenv_flag("QGTC_NO_WIDE");
 }
 // The kernel is bound by VALU issue: per MFMA and SIMD 7.8 ns + 1.55 ns per VALU operation, two waves
@@ -187,8 +191,27 @@ inline bool auto_prefers_wide(int M, int K, int N, int a, int w, int mode) {
 // (plane capacities 1 / 2 for X and 1 / 2 / 4 / 8 for W are instantiated; float32 sums must stay exact)
 inline bool skinny_ok(int K, int N, int a, int w) {
     return N <= 256 && a <= 2 && w <= 8 &&
-           static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
+           static_cast<double>(pad128(K)) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;
 }
+// one-plane operands with K beyond k_bitmm_fp4_one's 4096 (5_9_adjmatrix_size.py's M = K = 8192 .. 32768): the long-K kernel that reads
+// the adjacency once (bitmm_fp4_stream.hip.h) instead of k_bitmm_fp4_skinny's 32 x 32 tiles
+inline bool stream_ok(const qgtc_problem &pr, int a, int w, int ob, int mode) {
+    const size_t out_bytes = mode == 2 ? static_cast<size_t>(pr.M) * pr.N * 4u
+                                       : static_cast<size_t>(ob) * (mode == 1 ? pad128(pr.N) : pad8(pr.M)) * step128(mode == 1 ? pr.M : pr.N) * 16u;
+    // (operands below 2 GiB: a DMA piece's offset may run 128 lines past the operand before the range check drops it)
+    return a == 1 && w == 1 && pr.N <= 256 && pr.K > 4096 && pad128(pr.K) < (1 << 24) && pr.M < (1 << 24) && pr.x_words < (1ull << 29) && pr.w_words < (1ull << 29) &&
+           out_bytes < (1ull << 32) && !getenv_flag("QGTC_NO_STREAM");
+}
+
+// QGTC_ENGINE_AUTO: where the long-K kernel measured ahead of k_bitmm_fp4_skinny (tools/stream_route_sweep.sh, M = 1024 .. 65536, K = 8192 ..
+// 32768, N = 16 .. 256: 84 shapes): its 64-row tiles need rows to fill the chip (16384 x 16384 x 64 12.1 against 20.8 us, 8192 x 8192 x 16
+// 5.8 against 5.4), its column tiles of 64 columns pay from two tiles up (4096 x 32768 x 256 18.9 against 36.2, 1024 x 32768 x 256 16.4
+// against 11.1)
+inline bool auto_prefers_stream(int M, int K, int N) {
+    if (N > 64) return static_cast<long long>((N + 63) / 64) * M >= 8192;
+    return M >= 16384 || (M >= 8192 && N > 32 && K > 8192);
+}
+
 // QGTC_ENGINE_AUTO: measured against the popcount kernels on the reference's micro-benchmark shapes
 // (1024 / 2048 / 4096 square, N = 16 / 32 / 64, 1- and 2-bit): ahead on all of them (4096 x 4096 x 64:
 // 4.0 us against 4.8 at 1 bit, 4.8 against 7.1 at 2 bits)
@@ -203,7 +226,7 @@ inline bool auto_prefers_skinny(int M, int K, int N, int a, int w) {
 // batch, visiting only the k-quads its occupancy word names (bitmm_fp4_rows.hip.h)
 inline bool rows_ok(int max_K, int max_N, int a, int w, int ob, int mode) {
     return (mode == 0 || mode == 2) && max_K <= 8192 && max_N <= 256 && a <= 8 && w <= 8 && (mode == 2 || (ob >= 1 && ob <= 23)) &&
-           static_cast<double>(max_K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0 && !getenv_flag("QGTC_NO_ROWS");
+           static_cast<double>(pad128(max_K)) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0 && !getenv_flag("QGTC_NO_ROWS");
 }
 // ... and cols-layout stages (the operands not swapped, a workgroup per word of a line): every one that _xw_rows (K, N <= 128 at 2 / 4
 // bits) does not take - rounds 1-2 had a column-strip kernel (K <= 128) and a one-wave-per-tile kernel (N <= 64) for them
@@ -232,7 +255,7 @@ inline bool rbw_chain_ok(int max_K, int N1, int N2, int t_bits, int act_bits, in
 inline int chain_class(int bits) { return chain_digits(bits); }
 inline bool rbx_xw_ok(int K, int N, int x_bits, int out_bits) {
     if (K < 1 || K > 8192 || N < 1 || out_bits < 1 || out_bits > 8 || x_bits < 1 || x_bits > 2 * chain_class(out_bits)) return false;
-    if (static_cast<double>(K) * ((1 << x_bits) - 1) * ((1 << out_bits) - 1) >= 16777216.0) return false;
+    if (static_cast<double>(pad128(K)) * ((1 << x_bits) - 1) * ((1 << out_bits) - 1) >= 16777216.0) return false;
     return out_bits > 4 ? N <= 128 : (N > 128 && N <= 256);   // (1 .. 4 bits at N <= 128 are k_rbw_xw's)
 }
 inline bool rbx_chain_ok(int max_K, int N1, int N2, int t_bits, int act_bits, int out_bits, int mode2) {
@@ -255,7 +278,7 @@ inline bool rbx_chain_ok(int max_K, int N1, int N2, int t_bits, int act_bits, in
 inline bool rows_single_ok(const qgtc_problem &pr, int a, int w, int ob, int mode) {
     const int M = pr.M, K = pr.K, N = pr.N;
     const size_t out_bytes = mode == 2 ? static_cast<size_t>(M) * N * 4u : static_cast<size_t>(ob) * (mode == 1 ? pad128(N) : pad8(M)) * step128(mode == 1 ? M : N) * 16u;
-    const bool exact = static_cast<double>(K) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;   // (8 x 8 bits: K <= 258 - the X . W products)
+    const bool exact = static_cast<double>(pad128(K)) * ((1 << a) - 1) * ((1 << w) - 1) < 16777216.0;   // (8 x 8 bits: K <= 258 - the X . W products)
     // five to eight left-hand planes run on the one <8, 8> instantiation (16 MFMAs per 64 elements of K whatever w is): the b x b-bit
     // products of the drivers at --bit_width 5 .. 8 and anything small (tools/route_sweep.py: 1213 x 128 x 128 8 x 8 bits 27.9 -> 4.2 us,
     // 4096 x 4096 x 64 5 x 5 bits 45.2 -> 32.1; but 8 x 1 bits 27.7 -> 32.7 and N = 256 5 x 5 bits 47.7 -> 54.6: those stay where they were)

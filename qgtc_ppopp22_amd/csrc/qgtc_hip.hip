@@ -61,10 +61,12 @@
 #include "bitmm_fp4_rbx.hip.h"
 #include "fp4_expand.hip.h"
 #include "bitmm_fp4_wide.hip.h"
+#include "bitmm_fp4_stream.hip.h"
 #include "launch_fp4.hip.h"
 #include "launch_chainx.hip.h"
 #include "launch_mfma.hip.h"
 #include "launch_wide.hip.h"
+#include "launch_stream.hip.h"
 #endif
 #include "launch.hip.h"
 
@@ -180,9 +182,10 @@ int qgtc_bit2val(const uint32_t *bits, size_t bits_words, int nbits, int H, int 
 }
 
 // ---- which kernel family a single launch takes (one rule set for the launchers and for qgtc_bitmm_route) ---------------
-enum SingleRoute { RT_FP4_NARROW = 0, RT_FP4_ROWS, RT_FP4_WIDE, RT_MFMA_128, RT_POPCOUNT };
+enum SingleRoute { RT_FP4_NARROW = 0, RT_FP4_STREAM, RT_FP4_ROWS, RT_FP4_WIDE, RT_MFMA_128, RT_POPCOUNT };
 static SingleRoute single_route(const qgtc_problem &pr, int a, int w, int ob, int mode, unsigned flags) {
     const bool mf = (flags & QGTC_ENGINE_MFMA) != 0u, au = (flags & QGTC_ENGINE_AUTO) != 0u;
+    if (stream_ok(pr, a, w, ob, mode) && (mf || (au && auto_prefers_stream(pr.M, pr.K, pr.N)))) return RT_FP4_STREAM;
     if (skinny_ok(pr.K, pr.N, a, w) && (mf || (au && auto_prefers_skinny(pr.M, pr.K, pr.N, a, w)))) return RT_FP4_NARROW;
     if (rows_single_ok(pr, a, w, ob, mode) && (mf || au)) return RT_FP4_ROWS;
     if (wide_ok(pr, a, w, ob, mode) && (mf || (au && auto_prefers_wide(pr.M, pr.K, pr.N, a, w, mode)))) return RT_FP4_WIDE;
@@ -192,6 +195,7 @@ static SingleRoute single_route(const qgtc_problem &pr, int a, int w, int ob, in
 static int launch_single_route(const qgtc_problem &pr, int a, int w, int ob, int mode, unsigned flags, hipStream_t st) {
     switch (single_route(pr, a, w, ob, mode, flags)) {
         case RT_FP4_NARROW: return qgtc_launch_skinny(pr, a, w, ob, mode, !(flags & QGTC_NO_ZERO_SKIP), st);
+        case RT_FP4_STREAM: return qgtc_launch_stream(pr, ob, mode, !(flags & QGTC_NO_ZERO_SKIP), st);
         case RT_FP4_ROWS: return qgtc_launch_rows_single(pr, a, w, ob, mode, st);
         case RT_FP4_WIDE: return qgtc_launch_wide(pr, a, w, ob, mode, st);
         case RT_MFMA_128: return qgtc_launch_mfma(pr, a, w, ob, mode, st);
@@ -207,6 +211,7 @@ const char *qgtc_bitmm_route(int M, int K, int N, int bit1, int bit2, int output
     const int ob = mode == 2 ? 1 : output_bit;
     switch (single_route(pr, bit1, bit2, ob, mode, flags)) {
         case RT_FP4_NARROW: return qgtc_skinny_is_one(pr, ob, mode) ? "k_bitmm_fp4_one" : "k_bitmm_fp4_skinny";
+        case RT_FP4_STREAM: return "k_bitmm_fp4_stream";
         case RT_FP4_ROWS: return "k_bitmm_fp4_rows_single";
         case RT_FP4_WIDE: return "k_bitmm_fp4_wide";
         case RT_MFMA_128: return "k_bitmm_mfma";

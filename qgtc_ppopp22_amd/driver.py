@@ -309,8 +309,9 @@ def _stage_recipes(Q, chain, run_gin, F, H, C, b):
 def chain_entries_cover(b: int, F: int, H: int, C: int, run_gin: bool, max_n: int) -> bool:
     """Can the chain entries (qgtc_chain_transform / qgtc_chain_aggregate) run this epoch? One width b per chain: 1 .. 4 bits with up
     to 256 hidden units / classes, 5 .. 8 bits with up to 128 (include/qgtc.h); cluster batches of at most 8192 nodes; Cluster-GCN's
-    first product X . W1 loops over the k-quads of up to 8192 features while its float32 sums stay exact (F (2^b - 1)^2 < 2^24: 258
-    features at 8 bits); Batched-GIN's X is the right operand of an aggregation, so F is bounded like H."""
+    first product X . W1 loops over the k-quads of up to 8192 features while its float32 sums stay exact (PAD128(F) (2^b - 1)^2 < 2^24 -
+    the library counts whole k-quads, launch_common.hip.h::no_wrap: 256 features at 8 bits); Batched-GIN's X is the right operand of an
+    aggregation, so F is bounded like H."""
     if not 1 <= b <= 8 or max_n > 8192:
         return False
     lim = 256 if b <= 4 else 128
@@ -318,7 +319,7 @@ def chain_entries_cover(b: int, F: int, H: int, C: int, run_gin: bool, max_n: in
         return False
     if run_gin:
         return F <= lim
-    return F <= 8192 and F * ((1 << b) - 1) ** 2 < (1 << 24)
+    return F <= 8192 and (F + 127) // 128 * 128 * ((1 << b) - 1) ** 2 < (1 << 24)
 
 
 class PlannedEpoch:

@@ -140,7 +140,10 @@ def test_route_functions_name_the_kernel_behind_a_call(lib):
     # bench.py's step (BASELINE.json configs[1]): the FP4 narrow-operand kernel on the default engine, AND + popcount when asked
     assert r(4096, 4096, 64, 1, 1, 1, 0, AUTO) == "k_bitmm_fp4_one" and r(4096, 4096, 64, 1, 1, 1, 0, POP) == "k_bitmm"
     assert r(4096, 4096, 64, 1, 8, 8, 0, AUTO) == "k_bitmm_fp4_one"
-    assert r(32768, 32768, 64, 1, 1, 1, 0, AUTO) == "k_bitmm_fp4_skinny"           # K > 4096
+    assert r(32768, 32768, 64, 1, 1, 1, 0, AUTO) == "k_bitmm_fp4_stream"           # 5_9's largest: the long-K kernel (round 6)
+    assert r(16384, 16384, 256, 1, 1, 1, 1, AUTO) == "k_bitmm_fp4_stream" and r(32768, 32768, 1024, 1, 1, 1, 0, AUTO) == "k_bitmm_fp4_wide"
+    assert r(4096, 8192, 64, 1, 1, 1, 0, AUTO) == "k_bitmm_fp4_skinny" and r(4096, 8192, 64, 1, 1, 1, 0, MFMA) == "k_bitmm_fp4_stream"   # few rows
+    assert r(32768, 32768, 64, 1, 2, 2, 0, AUTO) == "k_bitmm_fp4_skinny"           # more than one plane: K > 4096 stays there
     assert r(4096, 4096, 1024, 1, 1, 1, 0, AUTO) == "k_bitmm_fp4_wide"
     assert r(4096, 4096, 64, 8, 8, 8, 0, AUTO) == "k_bitmm_mfma"                   # 4096 * 255 * 255 >= 2^24: int8 form, int32 sums
     assert r(512, 512, 64, 9, 2, 4, 0, MFMA) == "k_bitmm"                          # nine planes: AND + popcount only

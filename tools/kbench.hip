@@ -1,7 +1,7 @@
 // tools/kbench.hip — standalone (no torch) kernel bench + phase-stamp dump for the bit-GEMM.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude [-DQGTC_STAMPS] -o /tmp/kbench tools/kbench.hip
 //   /tmp/kbench M K N a w ob reps [density]
-//   env: NOZS=1 (no zero-tile skipping), MFMA=1 (matrix-core engine), XPLANES=n / WPLANES=n (planes n .. are all zero),
+//   env: NOZS=1 (no zero-tile skipping), MFMA=1 (matrix-core engine), AUTO=1 (the default engine's rules), XPLANES=n / WPLANES=n (planes n .. are all zero),
 //        GROUPED=count (count copies of the problem in one grouped launch; X gets dense 64 x 64
 //        diagonal blocks + `density` elsewhere, like a cluster batch), JUMP=1 (with occupancy bitmaps),
 //        MODE=0|1|2 (grouped only: rows bits, cols bits, float)
@@ -34,7 +34,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&dx, xw * 4)); CK(hipMalloc(&dw, ww * 4)); CK(hipMalloc(&dout, ow * 4));
     CK(hipMemcpy(dx, hx.data(), xw * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dw, hw.data(), ww * 4, hipMemcpyHostToDevice));
-    const unsigned flags = (getenv("NOZS") ? QGTC_NO_ZERO_SKIP : 0u) | (getenv("MFMA") ? QGTC_ENGINE_MFMA : 0u);
+    const unsigned flags = (getenv("NOZS") ? QGTC_NO_ZERO_SKIP : 0u) | (getenv("MFMA") ? QGTC_ENGINE_MFMA : 0u) | (getenv("AUTO") ? QGTC_ENGINE_AUTO : 0u);
     float ms = 0, best = 1e30f;
     if (const char *g = getenv("GROUPED")) {
         const int count = atoi(g), mode = getenv("MODE") ? atoi(getenv("MODE")) : 0;
@@ -117,12 +117,16 @@ int main(int argc, char **argv) {
 #ifdef QGTC_STAMPS
     std::vector<unsigned long long> st(1024 * 16);
     CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8));
-    for (int b : {0, 1, 100, 255, 600, 900, 1023}) {
+    std::vector<int> slots = {0, 1, 100, 255, 600, 900, 1023};
+    if (getenv("SLOTS16")) slots = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};   // (kernels that record a slot per wave)
+    for (int b : slots) {
         printf("block %3d:", b);
         unsigned long long t0 = st[b * 16];
         for (int s = 0; s < 16; s++) {
             unsigned long long t = st[b * 16 + s];
-            if (t >= t0 && t - t0 < 100000000ull) printf(" [%d]%llu", s, t - t0);
+            if (s == 14 && st[b * 16 + 13] && t > st[b * 16 + 13]) printf(" [loop: %.2f us, %.3f GHz]", (t - st[b * 16 + 13]) * 0.01, (double)(st[b * 16 + 11] - t0) / ((t - st[b * 16 + 13]) * 10.0));
+            else if (s == 13) continue;
+            else if (t >= t0 && t - t0 < 100000000ull) printf(" [%d]%llu", s, t - t0);
             else if (s >= 8 && t && st[b * 16 + 8]) printf(" [%d]%lld", s, (long long)(t - st[b * 16 + 8]));
         }
         printf("\n");

@@ -30,6 +30,10 @@ SINGLE = [  # (what, M, K, N, a, w, ob, mode)
     ("5_9 adjacency study, N = 256", 4096, 4096, 256, 1, 1, 1, 0),
     ("5_9 adjacency study, N = 1024", 4096, 4096, 1024, 1, 1, 1, 0),
     ("5_9's largest K (32768: float32 sums still exact at 1 bit)", 32768, 32768, 64, 1, 1, 1, 0),
+    ("5_9 at 16384, N = 256 (four column tiles of the long-K kernel)", 16384, 16384, 256, 1, 1, 1, 0),
+    ("5_9's largest shape (QGTC_module/logs/profile_new.log:26)", 32768, 32768, 1024, 1, 1, 1, 0),
+    ("long K, few rows", 4096, 8192, 64, 1, 1, 1, 0),
+    ("long K, two-bit features", 32768, 32768, 64, 1, 2, 2, 0),
     ("per-batch X.W of the arxiv epoch (main_qgtc.py:147)", 1213, 128, 128, 2, 2, 2, 0),
     ("per-batch A.(XW) (main_qgtc.py:148)", 1213, 1213, 128, 1, 2, 2, 0),
     ("per-batch bitMM2Bit_col (layout-correct chain)", 1213, 128, 128, 2, 2, 2, 1),
