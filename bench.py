@@ -136,7 +136,7 @@ def main():
     A, X, bit_A, bit_X = make_workload(Q, M, K, N, w, device, seed=3 + rank)
     with engine(Q, "popcount"):
         out = Q.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w)   # AND + popcount kernels: the words every engine must produce
-    extras = {}
+    extras, pop_block = {}, None
     with engine(Q, args.engine):
         out_e = Q.bitMM2Bit(bit_A, bit_X, M, K, N, 1, w, w)
         assert torch.equal(out_e, out), "engines disagree"
@@ -152,6 +152,7 @@ def main():
         with engine(Q, other_engine):
             o_wall, o_kern = headline.time_steps(Q, torch.empty_like(out), bit_A, bit_X, M, K, N, w, args.steps, args.warmup, D.barrier, args.streams, args.issue)
         extras["headline_on_engine_" + other_engine] = headline.other_engine_block(M, K, N, w, o_wall, o_kern, args.steps, other_engine == "popcount")
+        pop_block = extras["headline_on_engine_" + other_engine] if other_engine == "popcount" else None
     # which kernel runs at this shape: the FP4 matrix-core kernel when the float32 sums stay exact (K (2^a - 1)(2^w - 1) < 2^24)
     fp4_kernel = args.engine != "popcount" and w <= 8 and K * (2 ** w - 1) < 2 ** 24
     wall_max = D.max_over_ranks(wall, device)
@@ -160,6 +161,12 @@ def main():
     sums = D.gather_batch_summaries(csum, world, rank, world)       # result checksum of every rank (the path's only collective)
     roofline = headline.roofline_block(M, K, N, w, kern, wall / args.steps, fp4_kernel, args.streams <= 1)
     line = compose_line(args, world, D.world_size(), M, K, N, w, value, wall_max, fp4_kernel, roofline)
+    if solo and pop_block is not None:
+        # the mechanism BASELINE.json's north star names (AND + v_bcnt, engine "popcount") on the same workload, beside the default engine's
+        # figure: microseconds per launch and its fraction of SURVEY 8d's VALU roofline / of the pair rate tools/valu_peak.hip measures
+        line["roofline"].update({"popcount_us": pop_block["us_per_launch"], "popcount_TOPS": pop_block["TOPS"],
+                                 "popcount_valu_frac": pop_block["valu_frac_of_survey_8d_peak_7.864e13"],
+                                 "popcount_valu_frac_of_measured_pair_rate": pop_block["valu_frac_of_measured_pair_rate_4.2e13"]})
 
     try:
         if solo:
@@ -169,6 +176,7 @@ def main():
             if rccl is not None:
                 line["rccl_world1"] = {k: rccl.get(k) for k in ("ok", "backend", "ranks_seen", "gather_outputs_ms")}
                 extras["rccl_world1"] = rccl
+            line["roofline"].update(headline.big_adjacency_scalars(Q, device))
             if not args.no_tables:
                 extras.update(tables.all_tables(Q, device, M, K, N))
         if not args.no_extras:

@@ -20,7 +20,7 @@ VALU_PEAK_BITOPS = 4.2e13 * 32
 VALU_PEAK_BITOPS_SURVEY = 7.864e13 * 32
 FP4_PEAK_TFLOPS = 10000.0        # MI355X_MICROARCH.md: ~10 PF dense FP4 / FP6 MFMA
 
-PROFILE_DIR = "profiles/r05"
+PROFILE_DIR = "profiles/r06"
 CLOCK_WARMUP_S = 0.3
 EVENT_MIN_LAUNCHES = 200     # launches per HIP-event window (QGTC_device.cu:409 times 200 too)
 

@@ -127,6 +127,29 @@ def roofline_block(M, K, N, w, per_launch, wall_per_step_s, fp4_kernel, single_s
     return rf
 
 
+def big_adjacency_scalars(Q, device):
+    """Flat scalars for the line's `roofline`: the throughput-bound half of the reference's adjacency-size study
+    (5_9_adjmatrix_size.py:15-18: M = K = 32768, 1 bit; QGTC_module/logs/profile_new.log:26) - the one place of this path where the
+    HBM roofline binds: the packed adjacency alone is 128 MiB. 50 launches between two HIP events, median of three windows, seeded
+    random bits, default engine (k_bitmm_fp4_stream up to 256 columns, k_bitmm_fp4_wide at 1024)."""
+    out = {}
+    g = torch.Generator(device=device).manual_seed(3)
+    M = K = 32768
+    A = (torch.rand((M, K), generator=g, device=device) < 0.5).float()
+    ba = Q.val2bit(A, 1, False, False)
+    del A
+    for N in (16, 64, 1024):
+        X = (torch.rand((K, N), generator=g, device=device) < 0.5).float()
+        bx = Q.val2bit(X, 1, True, False)
+        Q.profile(ba, bx, M, K, N, 1, 1, 1, 5)
+        us = sorted(Q.profile(ba, bx, M, K, N, 1, 1, 1, 50) for _ in range(3))[1] * 1e3 / 50
+        algo = M * K / 8 + K * N / 8 + M * N / 8
+        out[f"adj32768_n{N}_us"] = round(us, 2)
+        out[f"adj32768_n{N}_hbm_frac"] = round(algo / (us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)
+        out[f"adj32768_n{N}_fp4_frac"] = round(2.0 * M * K * N / (us * 1e-6) / (FP4_PEAK_TFLOPS * 1e12), 4)
+    return out
+
+
 def other_engine_block(M, K, N, w, wall_s, kern_s, steps, popcount):
     """The same K steps on the other engine (identical words): the AND + popcount kernels against BOTH statements of their VALU
     roofline when that is the other engine."""

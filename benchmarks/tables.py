@@ -55,14 +55,30 @@ def micro_bench_table(Q, device):
     return out
 
 
+ADJ_SIZES = (128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768)   # 5_9_adjmatrix_size.py:15: M = K = 2^7 .. 2^15
+
+
 def adj_size_table(Q, device):
-    """5_9_adjmatrix_size.py: 1 bit, M = K in 1024 / 2048 / 4096, N = 16 .. 1024, all-ones inputs."""
+    """5_9_adjmatrix_size.py:15-18: 1 bit, M = K = 2^7 .. 2^15, N = 16 .. 1024, all-ones inputs made on the device (README publishes
+    1024 / 2048 / 4096; QGTC_module/logs/profile_new.log:26 records m = k = 32768, n = 1024). Per cell: both engines, and where the
+    default engine's launch stands against the two rooflines that can bind it - the HBM one on the call's algorithmic bytes
+    (M K / 8 + K N / 8 + M N / 8: it is the bound from M = K = 16384 up at N <= 64, where the adjacency alone is 32 - 128 MiB) and
+    the dense FP4 matrix-core one (2 M K N / 10 PFLOP/s: the bound of the wide columns)."""
+    from .common import FP4_PEAK_TFLOPS, HBM_PEAK_GBS
     out = {}
     for nn, ref in REF_ADJ.items():
         row = {}
-        for mi, mk in enumerate((1024, 2048, 4096)):
-            _, _, ba, bx = make_workload(Q, mk, mk, nn, 1, device, seed=3, ones=True)
-            row[f"M{mk}"] = dict(ref_sm86=ref[mi], **both_engines(Q, ba, bx, mk, mk, nn, 1))
+        for mk in ADJ_SIZES:
+            ba = Q.val2bit(torch.ones((mk, mk), device=device), 1, False, False)
+            bx = Q.val2bit(torch.ones((mk, nn), device=device), 1, True, False)
+            published = {1024: 0, 2048: 1, 4096: 2}
+            cell = dict(ref_sm86=ref[published[mk]] if mk in published else None, **both_engines(Q, ba, bx, mk, mk, nn, 1))
+            us = 2.0 * mk * mk * nn / (cell["TOPS"] * 1e6)
+            cell["us_per_launch"] = round(us, 3)
+            cell["hbm_frac"] = round((mk * mk / 8 + mk * nn / 8 + mk * nn / 8) / (us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)
+            cell["fp4_frac"] = round(cell["TOPS"] / FP4_PEAK_TFLOPS, 4)
+            row[f"M{mk}"] = cell
+            del ba, bx
         out[f"N{nn}"] = row
     return out
 

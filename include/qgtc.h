@@ -379,7 +379,9 @@ int qgtc_chain_aggregate(const qgtc_problem *stage_a, const qgtc_problem *stage_
  *   buffer it must also contain every A and every scratch buffer (scratch: 2 x qgtc_rows_words(n, n, 1) words per batch - the
  *   multiplicity bitmaps of qgtc_pack_edge_list). With `work` (ABI 11; qgtc_load_work_words(count, max_n, total edges) words, 0 = not
  *   available for this iterator: max_n above 5120) the edges are bucketed by 32-row block there and every word of every A / AT / occ
- *   is written exactly once from LDS: A needs no clearing, `scratch` may be NULL. Same words either way.
+ *   is written exactly once from LDS: A needs no clearing, `scratch` may be NULL. Same words either way. qgtc_load_work_words decides
+ *   the route: a work buffer that cannot serve (max_n above 5120: QGTC_EINVAL; not 8-byte aligned: QGTC_EALIGN; fewer words than the
+ *   fixed part of the layout: QGTC_ESIZE) is an error - the call never falls back to the route whose cleared region it was not given.
  *   max_n / max_edges: at least every batch's n / n_edges (grid sizes; hard preconditions like the grouped GEMM's maxima).
  *   stats (optional, inside `zero`): stats[0] += occupied 32-row x 128-bit adjacency tiles of all batches.
  *   bad_index (optional device int, cleared by the call): set to 1 when an edge index is out of range (such edges are skipped).

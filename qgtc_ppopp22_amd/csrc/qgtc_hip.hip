@@ -545,7 +545,11 @@ static size_t load_work_offsets(int count, int max_n) { return static_cast<size_
 static size_t load_work_counts(int count, int max_n) { return static_cast<size_t>(count) * ((max_n + 31) / 32); }
 static size_t load_work_edges(int count, int max_n, uint64_t total_edges) { return static_cast<size_t>(total_edges) + ((load_work_offsets(count, max_n) + total_edges) & 1u); }
 size_t qgtc_load_work_words(int count, int max_n, uint64_t total_edges) {
-    if (count <= 0 || max_n <= 0 || max_n > LOAD_SORT_MAX_N || total_edges >= (1ull << 32)) return 0u;   // 0: no bucketed route for this iterator
+    // 0: no bucketed route for this iterator. THE decider of the route: a caller that gets 0 here passes work = NULL and the
+    // cleared region with A and scratch inside; one that passes a work buffer gets the bucketed route or an error, never the other route
+    // silently. QGTC_NO_LOAD_SORT (tests / tools: the bitmap route on iterators that would be bucketed) is read here, on every call, and
+    // nowhere else.
+    if (count <= 0 || max_n <= 0 || max_n > LOAD_SORT_MAX_N || total_edges >= (1ull << 32) || getenv_flag_now("QGTC_NO_LOAD_SORT")) return 0u;
     // [bucket offsets | buckets (an even number of words) | one occupied-tile count per row block of every batch]
     return load_work_offsets(count, max_n) + load_work_edges(count, max_n, total_edges) + load_work_counts(count, max_n);
 }
@@ -562,7 +566,12 @@ int qgtc_load_batches(const qgtc_loader_batch *batches, int count, int max_n, ui
     if (bad_index) HIP_TRY(hipMemsetAsync(bad_index, 0, sizeof(int), st));
     const int rb_max = (max_n + TM - 1) / TM;
     const size_t work_fixed = load_work_offsets(count, max_n) + load_work_counts(count, max_n);
-    if (work && max_n <= LOAD_SORT_MAX_N && work_words >= work_fixed && !(reinterpret_cast<uintptr_t>(work) & 7u) && !getenv_flag("QGTC_NO_LOAD_SORT")) {
+    if (work) {   // a work buffer that cannot serve is an error, not a reason to take the route whose `zero` region the caller did not supply
+        if (max_n > LOAD_SORT_MAX_N) return QGTC_EINVAL;
+        if (reinterpret_cast<uintptr_t>(work) & 7u) return QGTC_EALIGN;
+        if (work_words < work_fixed) return QGTC_ESIZE;
+    }
+    if (work) {
         size_t edges_pad = work_words - work_fixed;                                    // what the caller left for the buckets (a batch that does not fit is reported)
         if ((load_work_offsets(count, max_n) + edges_pad) & 1u) edges_pad -= 1u;       // (an even number of words, as qgtc_load_work_words counts them)
         // the bucketed route (loader_kernels.hip.h): edges by row block, then every word of rows + tiles + bitmaps written once from LDS

@@ -897,7 +897,7 @@ struct EpochPlan {
         const auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(dev);
         // [A of every batch | stats (two uint64) | scratch of every batch]. With a work buffer (qgtc_load_work_words > 0: the bucketed route,
         // batches of at most 5120 nodes) the call writes every word of A itself: only `stats` is cleared and there is no scratch.
-        const size_t work_words = std::getenv("QGTC_NO_LOAD_SORT") ? 0u : qgtc_load_work_words(count, P.max_n, static_cast<uint64_t>(e_off[count]));
+        const size_t work_words = qgtc_load_work_words(count, P.max_n, static_cast<uint64_t>(e_off[count]));   // (0: the bitmap route - the library decides)
         const bool bucketed = work_words > 0;
         const int64_t zwords = (bucketed ? 1 : 3) * a_off[count] + 4;
         torch::Tensor zero = torch::empty({zwords}, i32);

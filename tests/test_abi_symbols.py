@@ -160,3 +160,16 @@ def test_route_functions_name_the_kernel_behind_a_call(lib):
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     for line in out.stdout.strip().splitlines():
         assert line in design, "DESIGN.md's routing table is stale: re-run tools/routing_table.py\n" + line
+
+
+def test_the_library_alone_decides_the_loaders_route(lib, monkeypatch):
+    """qgtc_load_work_words is the one decider (it reads QGTC_NO_LOAD_SORT on every call): 0 = the bitmap route, whatever was asked before."""
+    lib.qgtc_load_work_words.restype = ctypes.c_size_t
+    lib.qgtc_load_work_words.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint64]
+    assert lib.qgtc_load_work_words(3, 257, 1000) > 0
+    monkeypatch.setenv("QGTC_NO_LOAD_SORT", "1")
+    assert lib.qgtc_load_work_words(3, 257, 1000) == 0
+    monkeypatch.setenv("QGTC_NO_LOAD_SORT", "0")
+    assert lib.qgtc_load_work_words(3, 257, 1000) > 0
+    monkeypatch.delenv("QGTC_NO_LOAD_SORT")
+    assert lib.qgtc_load_work_words(3, 257, 1000) > 0

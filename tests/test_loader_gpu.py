@@ -249,3 +249,11 @@ def test_load_batches_through_the_raw_abi(oracle, with_work):
     assert lib.qgtc_load_batches(None, 3, 300, 10, src.data_ptr(), dst.data_ptr(), X.data_ptr(), F, bits, zero.data_ptr(), 16, None, None, 0, None, 0, st) == 1
     assert lib.qgtc_load_batches(dev_table.data_ptr(), 3, 300, 10, None, dst.data_ptr(), X.data_ptr(), F, bits, zero.data_ptr(), 16, None, None, 0, None, 0, st) == 1
     assert lib.qgtc_load_batches(dev_table.data_ptr(), 0, 300, 10, src.data_ptr(), dst.data_ptr(), X.data_ptr(), F, bits, zero.data_ptr(), 16, None, None, 0, None, 0, st) == 1
+    # a work buffer that cannot serve is an error, never a silent switch to the route whose cleared region was not supplied
+    if with_work:
+        args = (dev_table.data_ptr(), len(sizes), max(sizes), max(ecounts), src.data_ptr(), dst.data_ptr(), X.data_ptr(), F, bits, stats_ptr, 16, stats_ptr, None, 0)
+        assert lib.qgtc_load_batches(*args, work.data_ptr() + 4, work.numel() - 1, st) == 3          # QGTC_EALIGN: not 8-byte aligned
+        assert lib.qgtc_load_batches(*args, work.data_ptr(), 10, st) == 2                            # QGTC_ESIZE: below the fixed part of the layout
+        assert lib.qgtc_load_batches(dev_table.data_ptr(), len(sizes), 6000, max(ecounts), src.data_ptr(), dst.data_ptr(), X.data_ptr(), F, bits, stats_ptr, 16,
+                                     stats_ptr, None, 0, work.data_ptr(), work.numel(), st) == 1     # QGTC_EINVAL: batches above 5120 nodes have no bucketed route
+        torch.cuda.synchronize()

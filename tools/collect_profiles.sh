@@ -7,14 +7,14 @@
 # TA_* counters, for 25 minutes).
 #   tools/collect_profiles.sh <tag> [targets...]
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 shift
-TARGETS=${@:-headline popcount w8 gin_single epoch epoch_gin loader pack}
+TARGETS=${@:-headline popcount w8 gin_single epoch epoch_gin loader pack big big16 big1024}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for T in $TARGETS; do
-  REPS=200; [ "$T" = "epoch" -o "$T" = "epoch_gin" -o "$T" = "loader" -o "$T" = "loader_gin" ] && REPS=20; case "$T" in wide*) REPS=50;; esac
+  REPS=200; [ "$T" = "epoch" -o "$T" = "epoch_gin" -o "$T" = "loader" -o "$T" = "loader_gin" ] && REPS=20; case "$T" in wide*|big*) REPS=50;; esac
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$T -- python3 $GRAFT_REPO_ROOT/tools/profile_targets.py $T $REPS > $OUT/run_trace_$T.json 2> $OUT/trace_$T.err
   for C in FETCH_SIZE WRITE_SIZE "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
     N=$(echo $C | tr ' ' '_')

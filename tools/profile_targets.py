@@ -1,6 +1,6 @@
 """One kernel family per invocation, for rocprofv3 (tools/collect_profiles.sh):
 
-    python3 tools/profile_targets.py headline|popcount|w8|gin_single|epoch|epoch_gin|loader|loader_gin|pack|wide1|wide8k|wide2|wide4 [reps]
+    python3 tools/profile_targets.py headline|popcount|w8|gin_single|epoch|epoch_gin|loader|loader_gin|pack|wide1|wide8k|wide2|wide4|big|big16|big1024 [reps]
 
 Runs the named workload `reps` times after a warm-up and prints one JSON line with the HIP-event time per launch
 (events recorded on the launch stream), so that the trace's per-kernel averages can be put beside it."""
@@ -28,15 +28,17 @@ def events(fn, reps):
 
 def gemm_target(M, K, N, w, reps, engine="auto", a=1):
     Q.set_engine(engine)
-    g = torch.Generator(device="cpu").manual_seed(3)
-    A = torch.randint(0, 2 ** a, (M, K), generator=g).float().cuda()
-    X = torch.randint(0, 2 ** w, (K, N), generator=g).float().cuda()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    A = torch.randint(0, 2 ** a, (M, K), generator=g, device="cuda").float()     # (made on the device: 4 GiB of float32 at 32768 x 32768)
+    X = torch.randint(0, 2 ** w, (K, N), generator=g, device="cuda").float()
     ba, bx = Q.val2bit(A, a, False, False), Q.val2bit(X, w, True, False)
     out = Q.bitMM2Bit(ba, bx, M, K, N, a, w, w)
     us = events(lambda: Q.bitMM2Bit_enqueue(out, ba, bx, M, K, N, a, w, w, 1), reps)
     algo = a * M * K / 8 + w * K * N / 8 + w * M * N / 8
+    del A, X
     return {"workload": f"bitMM2Bit {M}x{K}x{N} a={a} w={w}", "us_per_launch_hip_events": round(us, 3), "launches": reps + 1,
-            "algorithmic_bytes": int(algo), "eff_TOPS": round(2.0 * M * K * N / us / 1e6, 1)}
+            "algorithmic_bytes": int(algo), "eff_TOPS": round(2.0 * M * K * N / us / 1e6, 1),
+            "hbm_frac_of_8TBs": round(algo / (us * 1e-6) / 8e12, 4), "fp4_frac_of_10PF": round(2.0 * M * K * N / (us * 1e-6) / 1e16, 4)}
 
 
 def epoch_target(gin, reps):
@@ -117,6 +119,12 @@ def main():
         r = gemm_target(4096, 4096, 64, 8, reps)
     elif t == "gin_single":   # a per-batch 4 x 4-bit product of the Batched-GIN chain (main_qgtc.py:132)
         r = gemm_target(599, 50, 64, 4, reps, a=4)
+    elif t == "big":       # the throughput-bound half of 5_9_adjmatrix_size.py: the adjacency is 128 MiB (k_bitmm_fp4_stream)
+        r = gemm_target(32768, 32768, 64, 1, reps)
+    elif t == "big16":
+        r = gemm_target(32768, 32768, 16, 1, reps)
+    elif t == "big1024":   # QGTC_module/logs/profile_new.log:26 (k_bitmm_fp4_wide)
+        r = gemm_target(32768, 32768, 1024, 1, reps)
     elif t == "wide1":
         r = gemm_target(4096, 4096, 1024, 1, reps)
     elif t == "wide8k":
