@@ -364,8 +364,8 @@ class QgtcExpandJob(ctypes.Structure):
 
 
 def _chain_covered(b, F, H, C):
-    """include/qgtc.h (ABI 11): 1 .. 4 bits with up to 256 columns, 5 .. 8 bits with up to 128 and an exact X . W (F (2^b - 1)^2 < 2^24)."""
-    return max(H, C) <= (256 if b <= 4 else 128) and F <= 8192 and F * ((1 << b) - 1) ** 2 < (1 << 24)
+    """include/qgtc.h (ABI 11): 1 .. 4 bits with up to 256 columns, 5 .. 8 bits with up to 128 and an exact X . W (PAD128(F) (2^b - 1)^2 < 2^24)."""
+    return max(H, C) <= (256 if b <= 4 else 128) and F <= 8192 and (F + 127) // 128 * 128 * ((1 << b) - 1) ** 2 < (1 << 24)
 
 
 @pytest.mark.parametrize("M,K,F,H,C,bitmaps", [(333, 333, 48, 128, 10, True), (150, 150, 128, 64, 128, False), (300, 150, 32, 100, 33, True), (200, 200, 602, 128, 41, True), (70, 70, 3703, 33, 7, False), (120, 120, 300, 70, 90, True),
@@ -603,7 +603,8 @@ def test_chain_entries_random_sweep(lib, oracle, seed):
     if use_xw and rng.integers(0, 3) == 0:
         F = int(rng.choice([129, 256, 300, 602, int(rng.integers(129, 900))]))   # more than one k-quad of features
     if use_xw:
-        F = min(F, ((1 << 24) - 1) // ((1 << b) - 1) ** 2)                        # the X . W product's float32 sums stay exact
+        # the X . W product's float32 sums stay exact - counted over WHOLE k-quads (PAD128(F): launch_common.hip.h::no_wrap)
+        F = min(F, ((1 << 24) - 1) // ((1 << b) - 1) ** 2 // 128 * 128)
     count = int(rng.integers(1, 5))
     bitmaps = bool(rng.integers(0, 2))
     density = float(rng.choice([0.0, 0.01, 0.05, 0.5, 1.0]))

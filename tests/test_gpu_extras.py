@@ -370,6 +370,14 @@ def _kmax(a, w):
     return (2 ** 24 - 1) // ((2 ** a - 1) * (2 ** w - 1))
 
 
+def _k_edges(a, w):
+    """The largest K the FP4 kernels are admitted for - the library counts whole k-quads, PAD128(K) (2^a - 1)(2^w - 1) < 2^24, since round 6
+    (launch_common.hip.h::no_wrap: padding bits are multiplied like any others) - and one above; then the largest K whose sums are exact at
+    all and one above (by then on the int32 kernels)."""
+    km = _kmax(a, w)
+    return sorted({max(km // 128 * 128, 1), km // 128 * 128 + 1, km, km + 1})
+
+
 def _packed_pair(torch, oracle, qx, qw, a, w):
     from helpers import to_dev
     from qgtc_ppopp22_amd.shapes import cols_shape, rows_shape
@@ -387,7 +395,7 @@ def test_float32_exactness_bound_all_max_operands(qgtc, oracle, a, w, engine):
     float32 output, exact packed output, and equal to the oracle."""
     import torch
     M, N = 20, 24
-    for K in (_kmax(a, w), _kmax(a, w) + 1):
+    for K in _k_edges(a, w):
         if a == 1 and w == 1:
             K = min(K, 3000000)     # 2^24 - 1 bits of K per row is only a size issue, not an exactness one
         qx = np.full((M, K), 2 ** a - 1, dtype=np.int32)
@@ -447,7 +455,7 @@ def test_float32_exactness_bound_grouped(qgtc, oracle, a, w):
     largest admitted K and one above (decided from max_K of the launch), all three output modes."""
     import torch
     M, N = 40, 33
-    for K in (_kmax(a, w), _kmax(a, w) + 1):
+    for K in _k_edges(a, w):
         rng = np.random.default_rng(K)
         qx = np.full((M, K), 2 ** a - 1, dtype=np.int32)
         qw = np.full((K, N), 2 ** w - 1, dtype=np.int32)
