@@ -94,8 +94,29 @@ int with_kernel(int a, int w, int K, int ob, int mode, long total_tiles, Plan *p
               std::integral_constant<int, 0>{});
 }
 
+// more than eight LEFT-hand planes on a single launch (bitmm_planes.hip.h: census of the set planes, then only those): the b x b-bit X . W
+// products of a --bit_width 9 .. 32 epoch - 1213 x 128 x 16 at 32 x 32 planes 27 -> 11-13 us. Measured level or behind the generic kernel
+// where the left operand has few planes (the 1 x 32-plane aggregations: 31 against 29 us) and on grouped launches (2850 tiles at 78 KB
+// of LDS each: 1.1 against 0.55 ms an epoch): those stay on k_bitmm<1, 0, 0>.
+inline bool planes_route(int a, int w, bool grouped) { (void)w; return a > 8 && !grouped && !getenv_flag("QGTC_NO_PLANES"); }
+template <bool BATCHED>
+int launch_planes(const qgtc_problem *prs, const qgtc_problem &pr1, int count, int max_M, int max_N, int a, int w, int ob, int mode, hipStream_t st) {
+    static PerDeviceOnce attr;
+    const int arc = attr.run([]() -> int {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bitmm_planes<BATCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sizeof(PlanesLds))));
+        return QGTC_OK;
+    });
+    if (arc != QGTC_OK) return arc;
+    const MMShape sh = base_shape(a, w, ob, mode);
+    const int tiles = ((max_M + 31) / 32) * ((max_N + 31) / 32);
+    hipLaunchKernelGGL((k_bitmm_planes<BATCHED>), dim3(tiles, BATCHED ? count : 1), dim3(PL_THREADS), sizeof(PlanesLds), st, prs, pr1, sh);
+    HIP_TRY(hipGetLastError());
+    return QGTC_OK;
+}
+
 template <bool ZS>
 int dispatch_single(const qgtc_problem &pr, int K, int a, int w, int ob, int mode, hipStream_t st) {
+    if (ZS && planes_route(a, w, false)) return launch_planes<false>(nullptr, pr, 1, pr.M, pr.N, a, w, ob, mode, st);
     Plan pl;
     const long tiles = static_cast<long>((pr.M + TM - 1) / TM) * ((pr.N + TN - 1) / TN);
     return with_kernel<ZS>(a, w, K, ob, mode, tiles, &pl, [&](auto qw, auto na, auto nw) {
@@ -106,6 +127,7 @@ int dispatch_single(const qgtc_problem &pr, int K, int a, int w, int ob, int mod
 template <bool ZS, bool OCC>
 int dispatch_batched(const qgtc_problem *prs, int count, int max_M, int max_N, int K_hint, int a,
                      int w, int ob, int mode, hipStream_t st) {
+    if (ZS && planes_route(a, w, true)) return launch_planes<true>(prs, qgtc_problem{}, count, max_M, max_N, a, w, ob, mode, st);
     Plan pl;
     const long tiles = static_cast<long>(count) * ((max_M + TM - 1) / TM) * ((max_N + TN - 1) / TN);
     return with_kernel<ZS>(a, w, K_hint, ob, mode, tiles, &pl, [&](auto qw, auto na, auto nw) {

@@ -49,6 +49,7 @@
 #include "tile_stats_kernels.hip.h"
 #include "loader_kernels.hip.h"
 #include "bitmm_popcount.hip.h"
+#include "bitmm_planes.hip.h"
 #include "bitmm_mfma.hip.h"
 #include "launch_common.hip.h"
 #ifdef QGTC_SINGLE_TU   // tools/kbench.hip: everything in one translation unit
