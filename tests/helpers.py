@@ -1,5 +1,7 @@
-"""Shared input generators for the parity tests."""
+"""Shared input generators for the parity tests, and the ctypes mirrors of include/qgtc.h's structs (what a cgo / JNI / plain-C host would
+declare) for the tests that drive the C-ABI with raw device pointers."""
 import contextlib
+import ctypes
 
 import numpy as np
 
@@ -123,3 +125,63 @@ def integer_gcn_reference(A, X, H, C, b, oracle):
     h = cl(qa @ cl(qx @ one(X.shape[1], H)))
     h = cl(qa @ cl(h @ one(H, H)))
     return (qa @ cl(h @ one(H, C))).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# include/qgtc.h through ctypes
+# ---------------------------------------------------------------------------------------------
+class QgtcProblem(ctypes.Structure):
+    """struct qgtc_problem"""
+    _fields_ = [("X", ctypes.c_void_p), ("W", ctypes.c_void_p), ("out", ctypes.c_void_p), ("x_words", ctypes.c_uint64),
+                ("w_words", ctypes.c_uint64), ("M", ctypes.c_int32), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
+                ("w_lines", ctypes.c_int32), ("occ_words", ctypes.c_int32), ("occ", ctypes.c_void_p)]
+
+
+class QgtcOperand(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("words", ctypes.c_uint64)]
+
+
+class QgtcBatch(ctypes.Structure):
+    """struct qgtc_batch - what the data loader knows of one cluster batch"""
+    _fields_ = [("A", QgtcOperand), ("X", QgtcOperand), ("XR", QgtcOperand), ("XC", QgtcOperand), ("AT", QgtcOperand), ("occ", ctypes.c_void_p),
+                ("n", ctypes.c_int32), ("occ_words", ctypes.c_int32)]
+
+
+class QgtcStage(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in ("left", "right", "K", "N", "bit1", "bit2", "ob", "mode", "pad128", "use_occ", "fmt")]
+
+
+class QgtcPackJob(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_words", ctypes.c_uint64), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("nbits", ctypes.c_int32), ("col_major", ctypes.c_int32), ("output_layer", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class QgtcExpandJob(ctypes.Structure):
+    _fields_ = [("W", ctypes.c_void_p), ("codes", ctypes.c_void_p), ("w_words", ctypes.c_uint64), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
+                ("nbits", ctypes.c_int32), ("w_lines", ctypes.c_int32), ("order", ctypes.c_int32), ("codes_words", ctypes.c_uint32)]
+
+
+class QgtcLoaderBatch(ctypes.Structure):
+    """struct qgtc_loader_batch (88 bytes)"""
+    _fields_ = [("edge_off", ctypes.c_uint64), ("n_edges", ctypes.c_uint64), ("feat_row", ctypes.c_uint64), ("n", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)] + [(k, ctypes.c_void_p) for k in ("A", "scratch", "AT", "occ", "X", "XR", "XC")]
+
+
+ENGINE_FLAGS = {"popcount": 0x0, "mfma": 0x8, "auto": 0x10}
+
+
+def c_library():
+    """libqgtc_hip.so as ctypes sees it (no GPU needed to load it or to call its host-only entries)."""
+    import qgtc_ppopp22_amd
+
+    L = ctypes.CDLL(qgtc_ppopp22_amd.lib_path())
+    L.qgtc_bitmm_route.restype = L.qgtc_bitmm_batched_route.restype = ctypes.c_char_p
+    for f in (L.qgtc_rows_words, L.qgtc_cols_words, L.qgtc_adj_tiles_words, L.qgtc_chain_words, L.qgtc_weight_codes_words, L.qgtc_occupancy_words,
+              L.qgtc_load_work_words):
+        f.restype = ctypes.c_size_t
+    return L
+
+
+def kernel_behind(M, K, N, a=1, w=1, ob=1, mode=0, engine="auto"):
+    """The kernel family a single launch of this shape takes (qgtc_bitmm_route: the rule functions the launchers switch on)."""
+    return c_library().qgtc_bitmm_route(M, K, N, a, w, ob, mode, ENGINE_FLAGS[engine]).decode()

@@ -7,7 +7,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from helpers import rand_q
+from helpers import QgtcBatch, QgtcExpandJob, QgtcOperand, QgtcPackJob, QgtcProblem, QgtcStage, rand_q
 
 pytestmark = pytest.mark.gpu
 
@@ -76,11 +76,6 @@ def test_c_abi_with_raw_device_pointers(lib, oracle, M, K, N, a, w, ob, flags):
     assert lib.qgtc_bitmm2bit(bx.data_ptr(), xw_, bw.data_ptr(), ww_, M, K, N, a, w, ob, out.data_ptr(), ow - 1, flags, st) == 2
 
 
-class QgtcProblem(ctypes.Structure):
-    """include/qgtc.h: struct qgtc_problem (the layout a cgo / JNI / plain-C host would declare)."""
-    _fields_ = [("X", ctypes.c_void_p), ("W", ctypes.c_void_p), ("out", ctypes.c_void_p), ("x_words", ctypes.c_uint64),
-                ("w_words", ctypes.c_uint64), ("M", ctypes.c_int32), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
-                ("w_lines", ctypes.c_int32), ("occ_words", ctypes.c_int32), ("occ", ctypes.c_void_p)]
 
 
 @pytest.mark.parametrize("flags", [0x0, 0x10, 0x8], ids=["popcount", "auto", "mfma"])
@@ -170,23 +165,12 @@ def test_chain_entry_with_raw_descriptors(lib, oracle, flags):
     assert lib.qgtc_gcn_chain_batched(descs.data_ptr(), descs.data_ptr(), count, 10, 10, 10, 10, 1, 2, 2, 2, 2, 0, flags, st) == 1
 
 
-class QgtcOperand(ctypes.Structure):
-    _fields_ = [("ptr", ctypes.c_void_p), ("words", ctypes.c_uint64)]
 
 
-class QgtcBatch(ctypes.Structure):
-    """include/qgtc.h: struct qgtc_batch - what the data loader knows of one cluster batch."""
-    _fields_ = [("A", QgtcOperand), ("X", QgtcOperand), ("XR", QgtcOperand), ("XC", QgtcOperand), ("AT", QgtcOperand), ("occ", ctypes.c_void_p),
-                ("n", ctypes.c_int32), ("occ_words", ctypes.c_int32)]
 
 
-class QgtcStage(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_int32) for k in ("left", "right", "K", "N", "bit1", "bit2", "ob", "mode", "pad128", "use_occ", "fmt")]
 
 
-class QgtcPackJob(ctypes.Structure):
-    _fields_ = [("x", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_words", ctypes.c_uint64), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
-                ("nbits", ctypes.c_int32), ("col_major", ctypes.c_int32), ("output_layer", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 SRC_A, SRC_X, SRC_XR, SRC_WEIGHT, SRC_STAGE, DIM_NODES = 0, 1, 2, 16, 32, -1
@@ -358,9 +342,6 @@ def test_epoch_plan_filled_on_the_device_with_raw_pointers(lib, oracle):
     torch.cuda.synchronize()
 
 
-class QgtcExpandJob(ctypes.Structure):
-    _fields_ = [("W", ctypes.c_void_p), ("codes", ctypes.c_void_p), ("w_words", ctypes.c_uint64), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
-                ("nbits", ctypes.c_int32), ("w_lines", ctypes.c_int32), ("order", ctypes.c_int32), ("codes_words", ctypes.c_uint32)]
 
 
 def _chain_covered(b, F, H, C):

@@ -99,8 +99,7 @@ def test_epoch_pool_layout_is_host_side(lib, oracle):
     """Entry points that do no device work: the pool rule of a device-filled epoch plan (outputs in (stage, batch)
     order, each a multiple of four words, sizes = the reference's allocation rules QGTC_device.cu:223,456,507) and the size
     helpers of the chain / tile formats."""
-    class Stage(ctypes.Structure):
-        _fields_ = [(k, ctypes.c_int32) for k in ("left", "right", "K", "N", "bit1", "bit2", "ob", "mode", "pad128", "use_occ", "fmt")]
+    from helpers import QgtcStage as Stage
 
     lib.qgtc_epoch_pool_layout.restype = ctypes.c_size_t
     lib.qgtc_epoch_pool_layout.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]

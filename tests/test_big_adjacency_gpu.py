@@ -9,7 +9,7 @@ word for word - whole words of both packed layouts - and ALL rows through the in
 import numpy as np
 import pytest
 
-from helpers import to_np_u32, use_engine
+from helpers import kernel_behind, to_np_u32, use_engine
 from qgtc_ppopp22_amd.shapes import P8, P128, S128
 
 pytestmark = pytest.mark.gpu
@@ -100,15 +100,6 @@ def test_32768_squared_times_1024_sampled_rows_and_row_checksums(qgtc, oracle, k
                 assert torch.equal(back, want_back), f"decoded bits vs float output, ob={ob} {eng}"
 
 
-def _route(M, K, N, flags):
-    import ctypes
-
-    import qgtc_ppopp22_amd
-    lib = ctypes.CDLL(qgtc_ppopp22_amd.lib_path())
-    lib.qgtc_bitmm_route.restype = ctypes.c_char_p
-    return lib.qgtc_bitmm_route(M, K, N, 1, 1, 1, 0, flags).decode()
-
-
 def test_long_k_kernel_on_ragged_shapes(qgtc, oracle):
     """k_bitmm_fp4_stream's edges against the oracle (engine "mfma": the kernel wherever it applies; "auto" keeps small M on
     k_bitmm_fp4_skinny): K one bit past / short of its 128-byte blocks and 256- / 512-byte groups, rows and columns off every tile size,
@@ -118,7 +109,7 @@ def test_long_k_kernel_on_ragged_shapes(qgtc, oracle):
     qgtc.set_engine("mfma")
     for (M, K, N) in ((70, 4097, 1), (129, 6143, 17), (200, 8191, 64), (64, 4224, 65), (333, 5000, 130), (1000, 12289, 200), (65, 16385, 256),
                       (31, 20000, 33), (16400, 8200, 48)):
-        assert _route(M, K, N, 0x8) == "k_bitmm_fp4_stream"
+        assert kernel_behind(M, K, N, engine="mfma") == "k_bitmm_fp4_stream"
         for density in (0.5, 0.002, 0.0):
             qx = (rng.random((M, K)) < density).astype(np.int32)
             qw = (rng.random((K, N)) < 0.5).astype(np.int32)

@@ -195,9 +195,7 @@ def test_load_batches_through_the_raw_abi(oracle, with_work):
     import torch
     lib = _lib()
 
-    class LoaderBatch(ctypes.Structure):
-        _fields_ = [("edge_off", ctypes.c_uint64), ("n_edges", ctypes.c_uint64), ("feat_row", ctypes.c_uint64), ("n", ctypes.c_int32),
-                    ("reserved", ctypes.c_int32)] + [(k, ctypes.c_void_p) for k in ("A", "scratch", "AT", "occ", "X", "XR", "XC")]
+    from helpers import QgtcLoaderBatch as LoaderBatch
 
     assert ctypes.sizeof(LoaderBatch) == 88
     lib.qgtc_rows_words.restype = lib.qgtc_cols_words.restype = ctypes.c_size_t
