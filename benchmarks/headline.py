@@ -147,6 +147,16 @@ def big_adjacency_scalars(Q, device):
         out[f"adj32768_n{N}_us"] = round(us, 2)
         out[f"adj32768_n{N}_hbm_frac"] = round(algo / (us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)
         out[f"adj32768_n{N}_fp4_frac"] = round(2.0 * M * K * N / (us * 1e-6) / (FP4_PEAK_TFLOPS * 1e12), 4)
+    # HBM-side bytes of the 64-column launch from the committed counters (2 x FETCH_SIZE + WRITE_SIZE KiB, as for the headline), when they
+    # were collected from these kernel sources
+    prof, _src = profile_summary("big")
+    try:
+        if prof is not None:
+            pm = [v for k, v in prof["pmc_per_dispatch_mean"].items() if "k_bitmm_fp4_stream" in k][0]
+            out["adj32768_n64_traffic"] = int(2 * 1024 * pm["FETCH_SIZE"]["mean"] + 1024 * pm["WRITE_SIZE"]["mean"])
+            out["adj32768_n64_algo_bytes"] = int(M * K / 8 + K * 64 / 8 + M * 64 / 8)
+    except (KeyError, ValueError, IndexError):
+        pass
     return out
 
 
