@@ -114,11 +114,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_stream(
     const uint32_t voff_x = static_cast<uint32_t>(m0 + rr) * row_bytes + swz, voff_w = static_cast<uint32_t>(n0 + rr) * row_bytes + swz;
 #endif
     const int ng = (kq + GQ - 1) / GQ;
-    auto issue_one = [&](int g, int j) {   // DMA j of this wave for group g -> stage g % STAGES; groups past the last are not fetched
-        if (g >= ng) return;               // (wave-uniform; the last group's wait counts on that: publish)
-#ifdef QGTC_STREAM_TUNE   // timing-only (ABL_NODMA=1): no piece is fetched at all - the loop's barriers, fragment reads, expansions and MFMAs alone
-        if ((cfg >> 10) & 1u) return;
-#endif
+    auto issue_one = [&](int g, int j) {   // DMA j of this wave for group g -> stage g % STAGES (the callers never ask for a group past the last)
         const uint32_t base = lds0 + static_cast<uint32_t>(g % STAGES) * STAGE;
         const uint32_t ko = static_cast<uint32_t>(g) * GB;
         const int p = wv + ST_WAVES * j;   // (scalar; X's pieces are a multiple of eight: rounds j < XP / 8 are X's for every wave)
@@ -131,7 +127,13 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_stream(
                    real ? ko + static_cast<uint32_t>(8 * (pw / BPG)) * row_bytes + 128u * (pw % BPG) : 0xfffffff0u);
         }
     };
-    auto issue = [&](int g) {
+#ifdef QGTC_STREAM_TUNE   // timing-only (ABL_NODMA=1): no piece is fetched at all - the loop's barriers, fragment reads, expansions and MFMAs alone
+    const bool no_dma = ((cfg >> 10) & 1u) != 0u;
+#else
+    constexpr bool no_dma = false;
+#endif
+    auto issue = [&](int g) {   // (wave-uniform; the last group's wait counts on groups past the last not being fetched: publish)
+        if (g >= ng || no_dma) return;
 #pragma unroll
         for (int j = 0; j < DMAS; j++) issue_one(g, j);
     };
@@ -192,47 +194,98 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_stream(
         }
     };
     // ... and the DMAs of group gn = g + STAGES - 1 go out BETWEEN the MFMAs of group g - 1, one per two blocks of CF MFMAs: issued in
-    // a burst behind the barrier they held both waves of every SIMD at once (~100 cycles a piece, stamps: 590 of a group's 4100)
+    // a burst behind the barrier they held both waves of every SIMD at once (~100 cycles a piece, stamps: 590 of a group's 4100).
+    //
+    // The order of a step's instructions is written out and pinned (sched_barrier), one MFMA and then ONE operand expansion (four ANDs)
+    // and one or two of the step's shifts: the vector issue of a SIMD is as scarce here as its matrix pipe (8 cycles an MFMA + 4 a VALU
+    // operation = 28 of the 32 an MFMA runs), and hipcc's own order - the expansions of a bit s in bursts of twelve, MFMAs back to back,
+    // the operand registers of an MFMA in flight rewritten right behind it - ran 47 cycles per MFMA and SIMD with no DMA, read or
+    // barrier in the loop (tools/mfma_overlap.hip: 42.8 / 37.2 for one / two waves in isolation, 38.0 / 35.9 in this order).
+    // The MFMAs of a bit s go (a0,b0) (a0,b1) (a1,b1) (a1,b0): one new operand each. The gaps behind them make a1(s), a0(s+1), b0(s+1),
+    // b1(s+1) in the OTHER register set (s & 1), so no expansion writes what an MFMA in flight reads; the gaps behind step 0's last
+    // MFMAs make step 1's first three operands.
     constexpr int DH = (DMAS + 1) / 2;   // DMAs that go out under step u = 0; the rest under u = 1
-    auto multiply = [&](const u32x4 (&xr)[2][RF], const u32x4 (&wr)[2][CF], int gn) {
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
+    constexpr int MN = 4 * RF * CF, EN = 4 * (RF + CF), EP = 3, SN = 4 * (RF + CF);   // per step: MFMAs, expansions (the first EP ahead of MFMA 0), shifts
+    // dma: group gn's DMAs go out between the MFMAs (a template flag, not a branch: a branch between two MFMAs splits the block the order is pinned in)
+    auto multiply = [&](auto dma, const u32x4 (&xr)[2][RF], const u32x4 (&wr)[2][CF], int gn) {
+        constexpr bool DMA = decltype(dma)::value;
+        i32x4 A[2][RF], B[2][CF];
+        u32x4 xs[RF], ws[CF];
+        // expansion e of step u, in the order the MFMAs need them: bit s = e / (RF + CF), then a0, b0, (b1,) a1
+        auto expand = [&](int u, int e) {
+            const int s = e / (RF + CF), o = e % (RF + CF);
+            const uint32_t mask = s < 3 ? 0x11111111u << s : 0x11111111u;
+            const bool is_a = o == 0 || o == RF + CF - 1;
+            const int f = is_a ? (o == 0 ? 0 : 1) : o - 1;
+            const u32x4 v = is_a ? (s < 3 ? xr[u][f] : xs[f]) : (s < 3 ? wr[u][f] : ws[f]);
+            const i32x4 r = {static_cast<int>(v.x & mask), static_cast<int>(v.y & mask), static_cast<int>(v.z & mask), static_cast<int>(v.w & mask)};
+            if (is_a) A[s & 1][f] = r; else B[s & 1][f] = r;
+        };
+        // shift z of step u (bit 3 of a nibble is E2M1's sign: it is multiplied as bit 0 of the word >> 3): xs0, ws0, (ws1,) xs1 - the order bit 3's expansions follow
+        auto shift = [&](int u, int z) {
+            const int o = z >> 2, el = z & 3;
+            if (o == 0) xs[0][el] = xr[u][0][el] >> 3;
+            else if (o == RF + CF - 1) xs[1][el] = xr[u][1][el] >> 3;
+            else ws[o - 1][el] = wr[u][o - 1][el] >> 3;
+        };
+        auto skipped = [&](int u) {   // wave-uniform: an all-zero 64 rows x 256-bit step of X is skipped
             uint32_t any = 0u;
 #pragma unroll
             for (int i = 0; i < RF; i++) any |= (xr[u][i].x | xr[u][i].y) | (xr[u][i].z | xr[u][i].w);
-            // wave-uniform: an all-zero 64 rows x 256-bit step of X is skipped
-            if (zero_skip && __ballot(any != 0u) == 0ull) {
+            return zero_skip && __ballot(any != 0u) == 0ull;
+        };
+        auto first = [&](int u) {
+#pragma unroll
+            for (int e = 0; e < EP; e++) expand(u, e);
+        };
+        auto dmas = [&](int u) {
+            if (DMA) {
 #pragma unroll
                 for (int j = u * DH; j < (u ? DMAS : DH); j++) issue_one(gn, j);
-                continue;
             }
+        };
+        auto step = [&](int u) {   // step u's first EP operands are made
+            __builtin_amdgcn_sched_barrier(0);
+            int made = EP, shifted = 0;
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const uint32_t mask = s < 3 ? 0x11111111u << s : 0x11111111u;
+            for (int n = 0; n < MN; n++) {
+                const int s = n / (RF * CF), q = n % (RF * CF);
+                const int i = q / CF, j = CF == 2 ? ((q == 1 || q == 2) ? 1 : 0) : 0;
                 const int sc = s < 3 ? 128 - s : 128;   // E8M0: code 1 << s counts as 1
-                i32x8 b8[CF];
+                const i32x8 a8 = __builtin_shufflevector(A[s & 1][i], A[s & 1][i], 0, 1, 2, 3, -1, -1, -1, -1);   // (an FP4 operand is the first 128 bits of the register tuple)
+                const i32x8 b8 = __builtin_shufflevector(B[s & 1][j], B[s & 1][j], 0, 1, 2, 3, -1, -1, -1, -1);
+                // cbsz = blgp = 4: E2M1 operands; lane (fl, hf) register r holds C[row 32 i + 8 (r >> 2) + 4 hf + (r & 3)][column 32 j + fl]
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i][j], 4, 4, 0, sc, 0, sc);
+                // the gap behind MFMA n: the expansions MFMA n + 2 .. needs (CF = 2: one a gap; CF = 1: two, one, two, ..)
+                const int want = CF == 2 ? EP + n + 1 : EP + (3 * (n + 1) + 1) / 2;
 #pragma unroll
-                for (int j = 0; j < CF; j++) {
-                    const u32x4 v = s < 3 ? wr[u][j] : wr[u][j] >> 3;
-                    const i32x4 b4 = {static_cast<int>(v.x & mask), static_cast<int>(v.y & mask), static_cast<int>(v.z & mask), static_cast<int>(v.w & mask)};
-                    b8[j] = __builtin_shufflevector(b4, b4, 0, 1, 2, 3, -1, -1, -1, -1);   // (an FP4 operand is the first 128 bits of the register tuple)
-                }
+                for (int e = 0; e < 2; e++)
+                    if (made < EN && made < want) expand(u, made++);
+                const int want_z = CF == 2 ? (n >= 10 ? SN : (SN * (n + 1) + 10) / 11) : 3 * (n + 1);
 #pragma unroll
-                for (int i = 0; i < RF; i++) {
-                    const u32x4 v = s < 3 ? xr[u][i] : xr[u][i] >> 3;
-                    const i32x4 a4 = {static_cast<int>(v.x & mask), static_cast<int>(v.y & mask), static_cast<int>(v.z & mask), static_cast<int>(v.w & mask)};
-                    const i32x8 a8 = __builtin_shufflevector(a4, a4, 0, 1, 2, 3, -1, -1, -1, -1);
-#pragma unroll
-                    for (int j = 0; j < CF; j++)
-                        // cbsz = blgp = 4: E2M1 operands; lane (fl, hf) register r holds C[row 32 i + 8 (r >> 2) + 4 hf + (r & 3)][column 32 j + fl]
-                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[j], acc[i][j], 4, 4, 0, sc, 0, sc);
-                    const int blk = 2 * s + i;   // block 0 .. 7 of this step; a DMA behind blocks 0, 2, 4, 6 (and 1, 3, .. if there are more)
+                for (int z = 0; z < 3; z++)
+                    if (shifted < SN && shifted < want_z) shift(u, shifted++);
+                if (u == 0 && n >= MN - EP) expand(1, n - (MN - EP));   // step 1's first operands (bit 0: register set 0, which bit 3 does not use)
+                const int blk = n / CF;   // block 0 .. 7 of this step; a DMA behind blocks 0, 2, 4, 6 (and 1, 3, .. if there are more)
+                if (DMA && n % CF == CF - 1) {
                     if (blk % 2 == 0 && u * DH + blk / 2 < (u ? DMAS : DH)) issue_one(gn, u * DH + blk / 2);
                     if (blk % 2 == 1 && u * DH + 4 + blk / 2 < (u ? DMAS : DH)) issue_one(gn, u * DH + 4 + blk / 2);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        if (skipped(0)) {
+            dmas(0);
+            first(1);
+        } else {
+            first(0);
+            step(0);
         }
+        if (skipped(1)) dmas(1);
+        else step(1);
     };
+    using with_dma = std::integral_constant<bool, true>;
+    using without_dma = std::integral_constant<bool, false>;
     // The fragment reads of group g are issued right behind its barrier and consumed an iteration later, under the MFMAs of group
     // g - 1: all eight waves of the CU pass the same barrier, so nothing else would cover a read's latency (first form: 39 us at
     // 32768 x 32768 x 64 where the DMAs alone take 24 and the MFMAs alone 24).
@@ -241,29 +294,38 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_stream(
     fetch(0, xa, wa);
     issue(STAGES - 1);
     int g = 1;
-    for (; g + 1 < ng; g += 2) {
+    for (; g + STAGES < ng && !no_dma; g += 2) {   // both multiplies of a trip have a group to fetch
         publish(g);
         fetch(g, xb, wb);
-        multiply(xa, wa, g + STAGES - 1);
+        multiply(with_dma{}, xa, wa, g + STAGES - 1);
 #ifdef QGTC_STAMPS
         asm volatile("" : "+v"(acc[0][0]));
         if (g == 5) ST_STAMP(6);
 #endif
         publish(g + 1);
         fetch(g + 1, xa, wa);
-        multiply(xb, wb, g + STAGES);
+        multiply(with_dma{}, xb, wb, g + STAGES);
 #ifdef QGTC_STAMPS
         asm volatile("" : "+v"(acc[0][0]));
         if (g == 5) ST_STAMP(10);
 #endif
     }
+    for (; g + 1 < ng; g += 2) {   // the last trips: at most one group is still to be fetched (wave-uniform branches around whole multiplies)
+        publish(g);
+        fetch(g, xb, wb);
+        if (g + STAGES - 1 < ng && !no_dma) multiply(with_dma{}, xa, wa, g + STAGES - 1);
+        else multiply(without_dma{}, xa, wa, ng);
+        publish(g + 1);
+        fetch(g + 1, xa, wa);
+        multiply(without_dma{}, xb, wb, ng);
+    }
     if (g < ng) {
         publish(g);
         fetch(g, xb, wb);
-        multiply(xa, wa, ng);
-        multiply(xb, wb, ng);
+        multiply(without_dma{}, xa, wa, ng);
+        multiply(without_dma{}, xb, wb, ng);
     } else {
-        multiply(xa, wa, ng);
+        multiply(without_dma{}, xa, wa, ng);
     }
 #ifdef QGTC_STAMPS
     asm volatile("" : "+v"(acc[0][0]));

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void k_like(int iters, unsigned long long *cyc
         for (int i = 0; i < RF; i++) asm volatile("" : "+v"(xr[i]));   // (fresh words every step, as from LDS)
 #pragma unroll
         for (int j = 0; j < CF; j++) asm volatile("" : "+v"(wr[j]));
-        if (FORM == 0) {
+        if (FORM == 0 || FORM == 3) {
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const int sc = s < 3 ? 128 - s : 128;
@@ -92,6 +92,45 @@ __global__ __launch_bounds__(512) void k_like(int iters, unsigned long long *cyc
 #pragma unroll
                     for (int j = 0; j < CF; j++) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8[j], acc[i][j], 4, 4, 0, sc, 0, sc);
                 }
+            }
+            if (FORM == 3) {   // the same step, scheduled as one MFMA, then five VALU operations (the NEXT operands), 4 RF CF times
+#pragma unroll
+                for (int n = 0; n < 4 * RF * CF; n++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, (4 * (RF + CF) * 5 / 4 + RF * CF - 1) / (RF * CF), 0);   // VALU
+                }
+            }
+        } else if (FORM == 4) {
+            // one MFMA, then ONE operand expansion (four ANDs) and one or two of the step's sixteen shifts, pinned with sched_barrier: the
+            // MFMAs of a bit s go (a0,b0) (a0,b1) (a1,b1) (a1,b0); the gaps behind them make a1(s), a0(s+1), b0(s+1), b1(s+1) in the OTHER
+            // register set, so no expansion writes what an MFMA in flight reads
+            static_assert(FORM != 4 || CF == 2, "the snake is written for 2 x 2 fragments");
+            i32x4 A[2][2], B[2][2];
+            u32x4 xs[2], ws[2];
+            int shifts = 0;
+            auto shift_one = [&](int n) {   // shift n of the sixteen: xs0, ws0, ws1, xs1 - the order the s = 3 expansions need them
+                const int f = n >> 2, e = n & 3;
+                if (f == 0) xs[0][e] = xr[0][e] >> 3; else if (f == 1) ws[0][e] = wr[0][e] >> 3; else if (f == 2) ws[1][e] = wr[1][e] >> 3; else xs[1][e] = xr[1][e] >> 3;
+            };
+            auto expa = [&](int i, int s2) { const unsigned m = s2 < 3 ? 0x11111111u << s2 : 0x11111111u; const u32x4 v = s2 < 3 ? xr[i] : xs[i];
+                                             A[s2 & 1][i] = i32x4{(int)(v.x & m), (int)(v.y & m), (int)(v.z & m), (int)(v.w & m)}; };
+            auto expb = [&](int j, int s2) { const unsigned m = s2 < 3 ? 0x11111111u << s2 : 0x11111111u; const u32x4 v = s2 < 3 ? wr[j] : ws[j];
+                                             B[s2 & 1][j] = i32x4{(int)(v.x & m), (int)(v.y & m), (int)(v.z & m), (int)(v.w & m)}; };
+            expa(0, 0); expb(0, 0); expb(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < 16; n++) {
+                const int s2 = n >> 2, q = n & 3, sc = s2 < 3 ? 128 - s2 : 128;
+                const int i = q >> 1, j = (q == 1 || q == 2) ? 1 : 0;
+                const i32x8 a8 = __builtin_shufflevector(A[s2 & 1][i], A[s2 & 1][i], 0, 1, 2, 3, -1, -1, -1, -1);
+                const i32x8 b8 = __builtin_shufflevector(B[s2 & 1][j], B[s2 & 1][j], 0, 1, 2, 3, -1, -1, -1, -1);
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i][j], 4, 4, 0, sc, 0, sc);
+                if (q == 0) expa(1, s2);
+                else if (s2 < 3) { if (q == 1) expa(0, s2 + 1); else if (q == 2) expb(0, s2 + 1); else expb(1, s2 + 1); }
+                const int target = n >= 10 ? 16 : (16 * (n + 1) + 10) / 11;
+#pragma unroll
+                for (int z = 0; z < 2; z++) if (shifts < target) shift_one(shifts++);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             // software-pipelined by hand: the operands of MFMA group n + 1 are expanded right behind the MFMAs of group n and kept apart from them
@@ -151,6 +190,115 @@ int run_like(int waves, unsigned long long *d, int *sink) {
     return 0;
 }
 
+// Producer / consumer roles: waves 0-3 (one a SIMD) multiply - per group of K one barrier, then four steps of 16 MFMAs in the pinned order
+// (one MFMA, one expansion, a shift or two), the fragments of step u + 1 read from LDS under the MFMAs of step u - while waves 4-7 do
+// nothing but fetch: twelve LDS-DMA pieces a wave and group (48 KB a workgroup and group: the long-K kernel's 128 x 256-byte X tile +
+// 64 x 256 bytes of W) out of a buffer larger than the caches. DMA = 0: the producers only meet the barrier.
+typedef int rsrc4 __attribute__((ext_vector_type(4)));
+template <int DMA>
+__global__ __launch_bounds__(512) void k_roles(int groups, const unsigned *src, unsigned src_bytes, unsigned long long *cycles, int *sink) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int STAGE = 48 * 1024;
+    f32x16 acc[2][2] = {};
+    unsigned long long t0 = 0, t1 = 0;
+    if (wv >= 4) {   // producer
+        const rsrc4 rs = {(int)(uintptr_t)src, (int)(((uintptr_t)src >> 32) & 0xffffu), (int)src_bytes, 0x00020000};
+        const unsigned lds0 = (unsigned)(uintptr_t)lds;
+        const unsigned voff = lane * 16u;
+        auto issue = [&](int g) {
+            if (!DMA) return;
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                const unsigned dst = lds0 + (g % 3) * STAGE + ((wv - 4) * 12 + j) * 1024u;
+                const unsigned soff = (blockIdx.x * (unsigned)groups + g) * (unsigned)STAGE + ((wv - 4) * 12 + j) * 1024u;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "s"(dst), "v"(voff), "s"(rs), "s"(soff) : "memory");
+            }
+        };
+        issue(0); issue(1);
+        for (int g = 0; g < groups; g++) {
+            if (DMA) { if (g + 1 < groups) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            __builtin_amdgcn_s_barrier();
+            if (g + 2 < groups) issue(g + 2);
+        }
+    } else {
+        auto rd = [&](int g, int u, u32x4 (&xr)[2], u32x4 (&wr)[2]) {
+            const unsigned char *st = lds + (g % 3) * STAGE + lane * 16 + u * 4096 + wv * 8192;
+            xr[0] = *reinterpret_cast<const u32x4 *>(st); xr[1] = *reinterpret_cast<const u32x4 *>(st + 1024);
+            wr[0] = *reinterpret_cast<const u32x4 *>(st + 2048); wr[1] = *reinterpret_cast<const u32x4 *>(st + 3072);
+        };
+        i32x4 A[2][2], B[2][2];
+        u32x4 xs[2], ws[2];
+        auto step = [&](const u32x4 (&xr)[2], const u32x4 (&wr)[2], const u32x4 (&xn)[2], const u32x4 (&wn)[2]) {
+            int shifts = 0;
+            auto shift_one = [&](int n) {
+                const int f = n >> 2, e = n & 3;
+                if (f == 0) xs[0][e] = xr[0][e] >> 3; else if (f == 1) ws[0][e] = wr[0][e] >> 3; else if (f == 2) ws[1][e] = wr[1][e] >> 3; else xs[1][e] = xr[1][e] >> 3;
+            };
+            auto expa = [&](const u32x4 (&x)[2], int i, int s2) { const unsigned m = s2 < 3 ? 0x11111111u << s2 : 0x11111111u; const u32x4 v = s2 < 3 ? x[i] : xs[i];
+                                             A[s2 & 1][i] = i32x4{(int)(v.x & m), (int)(v.y & m), (int)(v.z & m), (int)(v.w & m)}; };
+            auto expb = [&](const u32x4 (&w)[2], int j, int s2) { const unsigned m = s2 < 3 ? 0x11111111u << s2 : 0x11111111u; const u32x4 v = s2 < 3 ? w[j] : ws[j];
+                                             B[s2 & 1][j] = i32x4{(int)(v.x & m), (int)(v.y & m), (int)(v.z & m), (int)(v.w & m)}; };
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < 16; n++) {
+                const int s2 = n >> 2, q = n & 3, sc = s2 < 3 ? 128 - s2 : 128;
+                const int i = q >> 1, j = (q == 1 || q == 2) ? 1 : 0;
+                const i32x8 a8 = __builtin_shufflevector(A[s2 & 1][i], A[s2 & 1][i], 0, 1, 2, 3, -1, -1, -1, -1);
+                const i32x8 b8 = __builtin_shufflevector(B[s2 & 1][j], B[s2 & 1][j], 0, 1, 2, 3, -1, -1, -1, -1);
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i][j], 4, 4, 0, sc, 0, sc);
+                asm volatile("" : "+v"(acc[i][j]));   // (pins the MFMA ahead of the gap's VALU operations: volatile asms keep their order)
+                if (q == 0) { expa(xr, 1, s2); asm volatile("" : "+v"(A[s2 & 1][1])); }
+                else if (s2 < 3) { if (q == 1) { expa(xr, 0, s2 + 1); asm volatile("" : "+v"(A[(s2 + 1) & 1][0])); } else if (q == 2) { expb(wr, 0, s2 + 1); asm volatile("" : "+v"(B[(s2 + 1) & 1][0])); } else { expb(wr, 1, s2 + 1); asm volatile("" : "+v"(B[(s2 + 1) & 1][1])); } }
+                else { if (q == 1) { expa(xn, 0, 0); asm volatile("" : "+v"(A[0][0])); } else if (q == 2) { expb(wn, 0, 0); asm volatile("" : "+v"(B[0][0])); } else { expb(wn, 1, 0); asm volatile("" : "+v"(B[0][1])); } }   // the next step's first operands
+                const int target = n >= 10 ? 16 : (16 * (n + 1) + 10) / 11;
+#pragma unroll
+                for (int z = 0; z < 2; z++) if (shifts < target) shift_one(shifts++);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        u32x4 xa[2], wa[2], xb[2], wb[2];
+        __builtin_amdgcn_s_barrier();   // group 0
+        t0 = __builtin_amdgcn_s_memtime();
+        rd(0, 0, xa, wa);
+        A[0][0] = i32x4{(int)(xa[0].x & 0x11111111u), (int)(xa[0].y & 0x11111111u), (int)(xa[0].z & 0x11111111u), (int)(xa[0].w & 0x11111111u)};
+        B[0][0] = i32x4{(int)(wa[0].x & 0x11111111u), (int)(wa[0].y & 0x11111111u), (int)(wa[0].z & 0x11111111u), (int)(wa[0].w & 0x11111111u)};
+        B[0][1] = i32x4{(int)(wa[1].x & 0x11111111u), (int)(wa[1].y & 0x11111111u), (int)(wa[1].z & 0x11111111u), (int)(wa[1].w & 0x11111111u)};
+        for (int g = 0; g < groups; g++) {
+            rd(g, 1, xb, wb); step(xa, wa, xb, wb);
+            rd(g, 2, xa, wa); step(xb, wb, xa, wa);
+            rd(g, 3, xb, wb); step(xa, wa, xb, wb);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (g + 1 < groups) { __builtin_amdgcn_s_barrier(); rd(g + 1, 0, xa, wa); }
+            step(xb, wb, xa, wa);
+        }
+        asm volatile("" : "+v"(acc[0][0]));
+        t1 = __builtin_amdgcn_s_memtime();
+    }
+    if (lane == 0) cycles[blockIdx.x * 16 + wv] = t1 - t0;
+    float sm = 0;
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) sm += acc[i][j][1];
+    if (sm == 12345.0f) *sink = 1;
+}
+template <int DMA>
+int run_roles(unsigned long long *d, int *sink, const unsigned *src, unsigned src_bytes) {
+    unsigned long long h[16];
+    const int groups = 16;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_roles<DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess) return 1;
+    for (int rep = 0; rep < 3; rep++) {
+        hipLaunchKernelGGL((k_roles<DMA>), dim3(256), dim3(512), 144 * 1024, 0, groups, src, src_bytes, d, sink);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("roles: launch failed\n"); return 1; }
+    }
+    if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    unsigned long long mx = 0;
+    for (int i = 0; i < 4; i++) mx = h[i] > mx ? h[i] : mx;
+    printf("roles (4 multiplying waves, 4 fetching%s), %d groups of 64 MFMAs a wave: %6.1f cycles per MFMA and SIMD, %llu cycles a group\n", DMA ? "" : " - DMAs off", groups,
+           (double)mx / (64.0 * groups), mx / groups);
+    return 0;
+}
+
 template <int V, int AGPR, int DEP, int PRIO>
 __global__ __launch_bounds__(512) void k(int iters, unsigned long long *cycles, int *sink, unsigned seed) {
     i32x4 x[4], w[2];
@@ -205,8 +353,16 @@ int run(int waves, unsigned long long *d, int *sink) {
 int main() {
     unsigned long long *d; int *sink;
     CK(hipMalloc(&d, 256 * 16 * 8)); CK(hipMalloc(&sink, 4));
+    {
+        const unsigned src_bytes = 256u * 16u * 48u * 1024u;   // 192 MiB: every workgroup its own 768 KB
+        unsigned *src;
+        CK(hipMalloc(&src, src_bytes)); CK(hipMemset(src, 0x5a, src_bytes));
+        run_roles<1>(d, sink, src, src_bytes); run_roles<0>(d, sink, src, src_bytes);
+        CK(hipFree(src));
+        if (getenv("ROLES_ONLY")) return 0;
+    }
     for (int waves : {4, 8}) {
-        run_like<0, 2>(waves, d, sink); run_like<1, 2>(waves, d, sink); run_like<2, 2>(waves, d, sink); run_like<0, 4>(waves, d, sink); run_like<2, 4>(waves, d, sink);
+        run_like<0, 2>(waves, d, sink); run_like<1, 2>(waves, d, sink); run_like<2, 2>(waves, d, sink); run_like<3, 2>(waves, d, sink); run_like<4, 2>(waves, d, sink); run_like<0, 4>(waves, d, sink); run_like<2, 4>(waves, d, sink); run_like<3, 4>(waves, d, sink);
         if (getenv("LIKE_ONLY")) continue;
         run<0, 0, 0, 0>(waves, d, sink); run<4, 0, 1, 0>(waves, d, sink); run<5, 0, 1, 0>(waves, d, sink); run<8, 0, 1, 0>(waves, d, sink);
         run<5, 0, 0, 0>(waves, d, sink); run<0, 1, 0, 0>(waves, d, sink); run<5, 1, 1, 0>(waves, d, sink); run<8, 1, 1, 0>(waves, d, sink);
