@@ -190,6 +190,48 @@ int run_like(int waves, unsigned long long *d, int *sink) {
     return 0;
 }
 
+// What the operands' DATA does to a bare MFMA loop (no VALU work at all): cycles per MFMA and the clock the chip holds (s_memtime / s_memrealtime).
+// PAT 0: small integers (mostly zero nibbles); 1: random bits (every E2M1 code); 2: random bits masked to one bit a nibble (what the in-place expansion feeds)
+template <int PAT>
+__global__ __launch_bounds__(512) void k_data(int iters, unsigned long long *cycles, int *sink, unsigned seed) {
+    i32x4 x[4], w[2];
+    auto rnd = [&](unsigned k) { unsigned h = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u) ^ (k * 2246822519u) ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16; return h; };
+    for (int i = 0; i < 4; i++) for (int e = 0; e < 4; e++) x[i][e] = PAT == 0 ? (int)(i + e + 1) : PAT == 1 ? (int)rnd(i * 4 + e) : (int)(rnd(i * 4 + e) & 0x22222222u);
+    for (int i = 0; i < 2; i++) for (int e = 0; e < 4; e++) w[i][e] = PAT == 0 ? (int)(i + e + 5) : PAT == 1 ? (int)rnd(100 + i * 4 + e) : (int)(rnd(100 + i * 4 + e) & 0x22222222u);
+    f32x16 d[4][2] = {};
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const i32x8 a8 = __builtin_shufflevector(x[u >> 1], x[u >> 1], 0, 1, 2, 3, -1, -1, -1, -1);
+            const i32x8 b8 = __builtin_shufflevector(w[u & 1], w[u & 1], 0, 1, 2, 3, -1, -1, -1, -1);
+            d[u >> 1][u & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, d[u >> 1][u & 1], 4, 4, 0, 127, 0, 127);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) { cycles[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0; if (threadIdx.x == 0) cycles[blockIdx.x * 16 + 15] = r1 - r0; }
+    float sm = 0;
+    for (int u = 0; u < 8; u++) sm += d[u >> 1][u & 1][1];
+    if (sm == 12345.0f) *sink = 1;
+}
+template <int PAT>
+int run_data(int waves, unsigned long long *d, int *sink) {
+    unsigned long long h[16];
+    const int iters = 4000;
+    for (int rep = 0; rep < 2; rep++) {
+        hipLaunchKernelGGL((k_data<PAT>), dim3(256), dim3(64 * waves), 0, 0, iters, d, sink, 12345u);
+        if (hipDeviceSynchronize() != hipSuccess) return 1;
+    }
+    if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    unsigned long long mx = 0;
+    for (int i = 0; i < waves; i++) mx = h[i] > mx ? h[i] : mx;
+    printf("bare MFMAs, %d wave(s)/SIMD, operands %s: %6.1f cycles per MFMA and SIMD at %.3f GHz = %.1f ns per MFMA\n", waves / 4,
+           PAT == 0 ? "small integers" : PAT == 1 ? "random bits" : "random bits, one bit a nibble", (double)mx / (8.0 * iters) / (waves / 4), (double)h[0] / (double)h[15] * 0.1,
+           (double)h[15] * 10.0 / (8.0 * iters) / (waves / 4));
+    return 0;
+}
+
 // Producer / consumer roles: waves 0-3 (one a SIMD) multiply - per group of K one barrier, then four steps of 16 MFMAs in the pinned order
 // (one MFMA, one expansion, a shift or two), the fragments of step u + 1 read from LDS under the MFMAs of step u - while waves 4-7 do
 // nothing but fetch: twelve LDS-DMA pieces a wave and group (48 KB a workgroup and group: the long-K kernel's 128 x 256-byte X tile +
@@ -359,6 +401,7 @@ int main() {
         CK(hipMalloc(&src, src_bytes)); CK(hipMemset(src, 0x5a, src_bytes));
         run_roles<1>(d, sink, src, src_bytes); run_roles<0>(d, sink, src, src_bytes);
         CK(hipFree(src));
+        for (int waves : {4, 8}) { run_data<0>(waves, d, sink); run_data<1>(waves, d, sink); run_data<2>(waves, d, sink); }
         if (getenv("ROLES_ONLY")) return 0;
     }
     for (int waves : {4, 8}) {
