@@ -204,12 +204,14 @@ inline bool stream_ok(const qgtc_problem &pr, int a, int w, int ob, int mode) {
 }
 
 // QGTC_ENGINE_AUTO: where the long-K kernel measured ahead of k_bitmm_fp4_skinny (tools/stream_route_sweep.sh, M = 1024 .. 65536, K = 8192 ..
-// 32768, N = 16 .. 256: 84 shapes): its 64-row tiles need rows to fill the chip (16384 x 16384 x 64 12.1 against 20.8 us, 8192 x 8192 x 16
-// 5.8 against 5.4), its column tiles of 64 columns pay from two tiles up (4096 x 32768 x 256 18.9 against 36.2, 1024 x 32768 x 256 16.4
-// against 11.1)
+// 32768, N = 16 .. 256: 105 shapes): its 64-row tiles need rows to fill the chip (16384 x 16384 x 64 11.2 against 20.8 us, 8192 x 8192 x 32
+// 6.0 against 6.2, 8192 x 8192 x 16 6.0 against 5.4; below that a workgroup's walk over K is bound by the latency of its three stages:
+// 2048 x 32768 x 64 15.8 against 10.6), its column tiles of 64 columns pay from two tiles up (4096 x 32768 x 256 18.0 against 36.1,
+// 1024 x 32768 x 256 16.1 against 11.0)
 inline bool auto_prefers_stream(int M, int K, int N) {
+    (void)K;
     if (N > 64) return static_cast<long long>((N + 63) / 64) * M >= 8192;
-    return M >= 16384 || (M >= 8192 && N > 32 && K > 8192);
+    return M >= 16384 || (M >= 8192 && N > 16);
 }
 
 // QGTC_ENGINE_AUTO: measured against the popcount kernels on the reference's micro-benchmark shapes

@@ -125,3 +125,39 @@ def test_long_k_kernel_on_ragged_shapes(qgtc, oracle):
         Wt8 = oracle.pack(qw, 1, True, True)
         dW8 = torch.from_numpy(Wt8.view(np.int32).reshape(S128(K) * 4, P8(N))).cuda()
         np.testing.assert_array_equal(qgtc.bitMM2Int(dX, dW8, M, K, N, 1, 1, False).cpu().numpy(), oracle.bitmm2int(X, Wt8, M, K, N, 1, 1, False))
+    qgtc.set_engine("auto")
+
+
+def test_long_k_kernel_random_shape_sweep(qgtc, oracle):
+    """Forty seeded random shapes (M 1 .. 3000, K 4097 .. 20000, N 1 .. 256) on k_bitmm_fp4_stream (engine "mfma") against the oracle: the rows-
+    layout bits at a random ob, the float output, and the 128-row tiles (QGTC_STREAM_RF=4: what big launches run) on the shapes with more than
+    32 columns. Left operands: random density, with whole all-zero row blocks and an all-zero span of K (the zero-step skip on real boundaries)."""
+    import os
+    import torch
+    rng = np.random.default_rng(2022)
+    qgtc.set_engine("mfma")
+    try:
+        for case in range(40):
+            M, K, N = int(rng.integers(1, 3001)), int(rng.integers(4097, 20001)), int(rng.integers(1, 257))
+            ob = int(rng.integers(1, 25))
+            assert kernel_behind(M, K, N, engine="mfma") == "k_bitmm_fp4_stream"
+            qx = (rng.random((M, K)) < rng.choice([0.5, 0.05, 0.001])).astype(np.int32)
+            if M > 200:
+                qx[100:100 + int(rng.integers(1, M - 100))] = 0           # whole tiles of zero rows
+            k0 = int(rng.integers(0, K - 1024))
+            qx[:, k0:k0 + int(rng.integers(256, 1024))] = 0              # a span of K that is zero for every row
+            qw = (rng.random((K, N)) < 0.5).astype(np.int32)
+            X, Wt = oracle.pack(qx, 1, False), oracle.pack(qw, 1, True)
+            dX = torch.from_numpy(X.view(np.int32).reshape(P8(M), S128(K) * 4)).cuda()
+            dW = torch.from_numpy(Wt.view(np.int32).reshape(S128(K) * 4, P128(N))).cuda()
+            want_f, want_b = oracle.bitmm2int(X, Wt, M, K, N, 1, 1, True), oracle.bitmm2bit(X, Wt, M, K, N, 1, 1, ob)
+            for rf in (None, "4") if N > 32 else (None,):
+                if rf:
+                    os.environ["QGTC_STREAM_RF"] = rf
+                try:
+                    np.testing.assert_array_equal(qgtc.bitMM2Int(dX, dW, M, K, N, 1, 1, True).cpu().numpy(), want_f, err_msg=f"case {case} {M}x{K}x{N} rf={rf}")
+                    np.testing.assert_array_equal(to_np_u32(qgtc.bitMM2Bit(dX, dW, M, K, N, 1, 1, ob)), want_b, err_msg=f"case {case} {M}x{K}x{N} ob={ob} rf={rf}")
+                finally:
+                    os.environ.pop("QGTC_STREAM_RF", None)
+    finally:
+        qgtc.set_engine("auto")

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <utility>
+#include <type_traits>
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -232,6 +234,102 @@ int run_data(int waves, unsigned long long *d, int *sink) {
     return 0;
 }
 
+// The long-K kernel's step for RF x CF fragments in the order bitmm_fp4_stream.hip.h pins (tables of tools/stream_schedule.py), alone in a loop:
+// one wave a SIMD, fragments constant. MODE 0: as in the kernel; 1: the same MFMAs with exactly four ANDs behind each (no shifts, flat);
+// 2: the kernel's order on two accumulators only; 3: MFMAs only
+template <int RF, int CF> constexpr int t_exp_by(int n) {
+    if constexpr (RF == 2 && CF == 2) { constexpr int t[] = {4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19}; return t[n]; }
+    else { constexpr int t[] = {4, 4, 5, 5, 6, 7, 8, 9, 10, 10, 11, 11, 12, 13, 14, 15, 16, 16, 17, 17, 18, 19, 20, 21, 22, 22, 23, 23, 24, 25, 26, 27}; return t[n]; }
+}
+template <int RF, int CF> constexpr int t_shift_by(int n) {
+    if constexpr (RF == 2 && CF == 2) { constexpr int t[] = {0, 0, 0, 0, 0, 2, 4, 6, 8, 10, 12, 16, 16, 16, 16, 16}; return t[n]; }
+    else { constexpr int t[] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 4, 6, 8, 14, 16, 20, 22, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24}; return t[n]; }
+}
+template <class F, int... I> __device__ __forceinline__ void t_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void t_for(F &&f) { t_for_impl(f, std::make_integer_sequence<int, N>{}); }
+template <int RF, int CF, int MODE>
+__global__ __launch_bounds__(512) void k_step(int iters, unsigned long long *cycles, int *sink, unsigned seed) {
+    if (threadIdx.x >= 256) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); return; }   // (launched with 512 threads: four more waves that only wait at the barriers)
+    u32x4 xr[RF], wr[CF], x0[RF], w0[CF];
+    for (int i = 0; i < RF; i++) x0[i] = u32x4{seed * 3 + threadIdx.x + i, seed * 77 + i, 0x9e3779b9u * (threadIdx.x + i), 0x85ebca6bu + i};
+    for (int i = 0; i < CF; i++) w0[i] = u32x4{0xc2b2ae35u * (threadIdx.x + 1), seed + 6u + i, 0x27d4eb2fu + i, threadIdx.x};
+    f32x16 acc[RF][CF] = {};
+    constexpr int MN = 4 * RF * CF, OPB = RF + CF, EN = 4 * OPB, EP = 3;
+    i32x4 A[4], B[2][CF];
+    auto expand = [&](auto e_) {
+        constexpr int e = decltype(e_)::value % EN, s = e / OPB, o = e % OPB;
+        constexpr unsigned mask = s < 3 ? 0x11111111u << s : 0x11111111u;
+        constexpr bool is_a = o == 0 || o > CF;
+        constexpr int f = o == 0 ? 0 : (o > CF ? o - CF : o - 1);
+        u32x4 v;
+        if constexpr (is_a) v = xr[f]; else v = wr[f];
+        const i32x4 r = {(int)(v.x & mask), (int)(v.y & mask), (int)(v.z & mask), (int)(v.w & mask)};
+        if constexpr (is_a) { A[(s * RF + f) & 3] = r; asm volatile("" : "+v"(A[(s * RF + f) & 3])); }
+        else { B[s & 1][f] = r; asm volatile("" : "+v"(B[s & 1][f])); }
+    };
+    auto shift = [&](auto z_) {
+        constexpr int z = decltype(z_)::value, o = z >> 2, el = z & 3;
+        constexpr bool is_a = o == 0 || o > CF;
+        constexpr int f = o == 0 ? 0 : (o > CF ? o - CF : o - 1);
+        if constexpr (is_a) { xr[f][el] >>= 3; if constexpr (el == 3) asm volatile("" : "+v"(xr[f])); }
+        else { wr[f][el] >>= 3; if constexpr (el == 3) asm volatile("" : "+v"(wr[f])); }
+    };
+    for (int i = 0; i < RF; i++) xr[i] = x0[i];
+    for (int i = 0; i < CF; i++) wr[i] = w0[i];
+    t_for<EP>([&](auto e_) { expand(e_); });
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+        for (int i = 0; i < RF; i++) { xr[i] = x0[i]; asm volatile("" : "+v"(xr[i])); }
+        for (int i = 0; i < CF; i++) { wr[i] = w0[i]; asm volatile("" : "+v"(wr[i])); }
+        __builtin_amdgcn_sched_barrier(0);
+        t_for<MN>([&](auto n_) {
+            constexpr int n = decltype(n_)::value, s = n / (RF * CF), q = n % (RF * CF);
+            constexpr int i = q / CF, j = (i & 1) ? CF - 1 - q % CF : q % CF;
+            constexpr int sc = s < 3 ? 128 - s : 128;
+            const i32x4 a4 = A[(s * RF + i) & 3], b4 = B[s & 1][j];
+            const i32x8 a8 = __builtin_shufflevector(a4, a4, 0, 1, 2, 3, -1, -1, -1, -1);
+            const i32x8 b8 = __builtin_shufflevector(b4, b4, 0, 1, 2, 3, -1, -1, -1, -1);
+            constexpr int ai = MODE == 2 ? (i & 1) : i, aj = MODE == 2 ? 0 : j;
+            acc[ai][aj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[ai][aj], 4, 4, 0, sc, 0, sc);
+            if constexpr (MODE == 0 || MODE == 2) {
+                constexpr int e0 = n == 0 ? EP : t_exp_by<RF, CF>(n == 0 ? 0 : n - 1), e1 = t_exp_by<RF, CF>(n);
+                t_for<e1 - e0>([&](auto k_) { expand(std::integral_constant<int, e0 + decltype(k_)::value>{}); });
+                constexpr int z0 = n == 0 ? 0 : t_shift_by<RF, CF>(n == 0 ? 0 : n - 1), z1 = t_shift_by<RF, CF>(n);
+                t_for<z1 - z0>([&](auto k_) { shift(std::integral_constant<int, z0 + decltype(k_)::value>{}); });
+            } else if constexpr (MODE == 1) {
+                // four ANDs behind every MFMA: the operand MFMA n + 2 reads (the real order needs fewer: this is the flat version of its VALU load)
+                constexpr int n2 = (n + 2) % MN, s2 = n2 / (RF * CF), q2 = n2 % (RF * CF), i2 = q2 / CF, j2 = (i2 & 1) ? CF - 1 - q2 % CF : q2 % CF;
+                constexpr unsigned mask = 0x11111111u << (s2 % 3);
+                if constexpr (n % 2 == 0) { const u32x4 v = xr[i2]; A[(s2 * RF + i2) & 3] = i32x4{(int)(v.x & mask), (int)(v.y & mask), (int)(v.z & mask), (int)(v.w & mask)}; asm volatile("" : "+v"(A[(s2 * RF + i2) & 3])); }
+                else { const u32x4 v = wr[j2]; B[s2 & 1][j2] = i32x4{(int)(v.x & mask), (int)(v.y & mask), (int)(v.z & mask), (int)(v.w & mask)}; asm volatile("" : "+v"(B[s2 & 1][j2])); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (blockDim.x == 512) __builtin_amdgcn_s_barrier();
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
+    float sm = 0;
+    for (int i = 0; i < RF; i++) for (int j = 0; j < CF; j++) sm += acc[i][j][1];
+    if (sm == 12345.0f) *sink = 1;
+}
+template <int RF, int CF, int MODE>
+int run_step(unsigned long long *d, int *sink, int threads = 256) {
+    unsigned long long h[16];
+    const int iters = 400;
+    for (int rep = 0; rep < 2; rep++) {
+        hipLaunchKernelGGL((k_step<RF, CF, MODE>), dim3(256), dim3(threads), 0, 0, iters, d, sink, 7u);
+        if (hipDeviceSynchronize() != hipSuccess) return 1;
+    }
+    if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    unsigned long long mx = 0;
+    for (int i = 0; i < 4; i++) mx = h[i] > mx ? h[i] : mx;
+    printf("the pinned step, %d x %d fragments, one wave a SIMD%s, %s: %6.1f cycles per MFMA\n", RF, CF, threads == 512 ? " + one waiting at a barrier" : "",
+           MODE == 0 ? "as in the kernel" : MODE == 1 ? "four ANDs behind every MFMA, no shifts" : MODE == 2 ? "as in the kernel on two accumulators" : "MFMAs only", (double)mx / ((double)(4 * RF * CF) * iters));
+    return 0;
+}
+
 // Producer / consumer roles: waves 0-3 (one a SIMD) multiply - per group of K one barrier, then four steps of 16 MFMAs in the pinned order
 // (one MFMA, one expansion, a shift or two), the fragments of step u + 1 read from LDS under the MFMAs of step u - while waves 4-7 do
 // nothing but fetch: twelve LDS-DMA pieces a wave and group (48 KB a workgroup and group: the long-K kernel's 128 x 256-byte X tile +
@@ -401,6 +499,10 @@ int main() {
         CK(hipMalloc(&src, src_bytes)); CK(hipMemset(src, 0x5a, src_bytes));
         run_roles<1>(d, sink, src, src_bytes); run_roles<0>(d, sink, src, src_bytes);
         CK(hipFree(src));
+        run_step<4, 2, 0>(d, sink, 512); run_step<4, 2, 3>(d, sink, 512);
+        run_step<4, 2, 0>(d, sink); run_step<4, 2, 1>(d, sink); run_step<4, 2, 2>(d, sink); run_step<4, 2, 3>(d, sink);
+        run_step<2, 2, 0>(d, sink); run_step<2, 2, 1>(d, sink); run_step<2, 2, 3>(d, sink);
+        if (getenv("STEP_ONLY")) return 0;
         for (int waves : {4, 8}) { run_data<0>(waves, d, sink); run_data<1>(waves, d, sink); run_data<2>(waves, d, sink); }
         if (getenv("ROLES_ONLY")) return 0;
     }

@@ -7,10 +7,12 @@ for S in ${SIZES:-32768}; do
 for n in ${NS:-64}; do
 echo "== $S x $S x $n"
 echo -n "default                             "; MFMA=1 /tmp/kb $S $S $n 1 1 1 20
-echo -n "X all zero (zero skip)              "; MFMA=1 /tmp/kb $S $S $n 1 1 1 20 0.0
-echo -n "no DMA, NOZS                        "; NOZS=1 ABL_NODMA=1 MFMA=1 /tmp/kb $S $S $n 1 1 1 20
-echo -n "no DMA, no barrier, NOZS            "; NOZS=1 ABL_NODMA=1 ABL_NOBAR=1 MFMA=1 /tmp/kb $S $S $n 1 1 1 20
-echo -n "no DMA, no fragment reads, NOZS     "; NOZS=1 ABL_NODMA=1 ABL_NOLDS=1 MFMA=1 /tmp/kb $S $S $n 1 1 1 20
-echo -n "no DMA, no reads, no barrier, NOZS  "; NOZS=1 ABL_NODMA=1 ABL_NOLDS=1 ABL_NOBAR=1 MFMA=1 /tmp/kb $S $S $n 1 1 1 20
+echo -n "all-ones X                          "; MFMA=1 /tmp/kb $S $S $n 1 1 1 20 1.0
+echo -n "no zero-step test (NOZS)            "; NOZS=1 MFMA=1 /tmp/kb $S $S $n 1 1 1 20
+echo -n "X all zero (every step skipped)     "; MFMA=1 /tmp/kb $S $S $n 1 1 1 20 0.0
+echo -n "X out of L2 (ABL_X)                 "; ABL_X=1 MFMA=1 /tmp/kb $S $S $n 1 1 1 20
+echo -n "no DMA at all (ABL_NODMA), NOZS     "; NOZS=1 ABL_NODMA=1 MFMA=1 /tmp/kb $S $S $n 1 1 1 20
+echo -n "128-row tiles (QGTC_STREAM_RF=4)    "; QGTC_STREAM_RF=4 MFMA=1 /tmp/kb $S $S $n 1 1 1 20
+echo -n "64-row tiles (QGTC_STREAM_RF=2)     "; QGTC_STREAM_RF=2 MFMA=1 /tmp/kb $S $S $n 1 1 1 20
 done
 done
