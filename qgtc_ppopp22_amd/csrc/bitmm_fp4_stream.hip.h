@@ -229,17 +229,21 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_stream(
             if constexpr (is_a) { xr[f][el] >>= 3; if constexpr (el == 3) asm volatile("" : "+v"(xr[f])); }
             else { wr[f][el] >>= 3; if constexpr (el == 3) asm volatile("" : "+v"(wr[f])); }
         };
-        auto skipped = [&](const u32x4 (&xr)[RF]) {   // wave-uniform: an all-zero 32 RF rows x 256-bit step of X is skipped
+        // wave-uniform: an all-zero 32 RF rows x 256-bit step of X is skipped. The OR of a step's fragments is made a step AHEAD, in a gap of
+        // the step before (any_of; at 4 x 2 a gap that has no expansion: free); at the step itself only the ballot is left - ahead of
+        // the step the eight ORs cost the one multiplying wave of a SIMD 0.7 us a launch
+        auto any_of = [&](const u32x4 (&xr)[RF]) {
             uint32_t any = 0u;
 #pragma unroll
             for (int i = 0; i < RF; i++) any |= (xr[i].x | xr[i].y) | (xr[i].z | xr[i].w);
-            return zero_skip && __ballot(any != 0u) == 0ull;
+            return any;
         };
+        auto skipped = [&](uint32_t any) { return zero_skip && __ballot(any != 0u) == 0ull; };
         auto first = [&](u32x4 (&xr)[RF], u32x4 (&wr)[CF]) {
             st_for<EP>([&](auto e_) { expand(e_, xr, wr); });
         };
         // one step: its first EP operands are made; with next: the next step's fragments (nx, nw), whose first EP operands its last gaps make
-        auto step = [&](auto with_next, u32x4 (&xr)[RF], u32x4 (&wr)[CF], u32x4 (&nx)[RF], u32x4 (&nw)[CF]) {
+        auto step = [&](auto with_next, u32x4 (&xr)[RF], u32x4 (&wr)[CF], u32x4 (&nx)[RF], u32x4 (&nw)[CF], uint32_t &any_next) {
             constexpr bool NEXT = decltype(with_next)::value;
             __builtin_amdgcn_sched_barrier(0);
             st_for<MN>([&](auto n_) {
@@ -259,14 +263,25 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_stream(
                 });
                 constexpr int z0 = n == 0 ? 0 : st_shift_by<RF, CF>(n == 0 ? 0 : n - 1), z1 = st_shift_by<RF, CF>(n);
                 st_for<z1 - z0>([&](auto k_) { shift(std::integral_constant<int, z0 + decltype(k_)::value>{}, xr, wr); });
+                if constexpr (NEXT && n == MN - 7) {   // (the next fragments landed long ago)
+                    any_next = any_of(nx);
+                    asm volatile("" : "+v"(any_next));
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
         using with_next = std::integral_constant<bool, true>;
         using last_step = std::integral_constant<bool, false>;
+        uint32_t any_now = 0u;   // the OR of the fragments the next multiply takes
         auto multiply = [&](u32x4 (&xr)[RF], u32x4 (&wr)[CF], u32x4 (&nx)[RF], u32x4 (&nw)[CF]) {
-            if (skipped(xr)) first(nx, nw);
-            else step(with_next{}, xr, wr, nx, nw);
+            uint32_t any_next;
+            if (skipped(any_now)) {
+                first(nx, nw);
+                any_next = any_of(nx);
+            } else {
+                step(with_next{}, xr, wr, nx, nw, any_next);
+            }
+            any_now = any_next;
         };
         // A group's barrier says: its pieces have landed, for every wave. The fragments of step u + 1 are read under the MFMAs of step u,
         // the first step of group g + 1 under the last of group g (behind barrier g + 1): nothing else covers a read's latency.
@@ -292,12 +307,13 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_bitmm_fp4_stream(
         ST_STAMP(2);
         fetch(any_group{}, 0, 0, xp, wp);
         first(xp, wp);
+        any_now = any_of(xp);
         int g = 0;
         for (; g + 2 < ng; g++) trip(not_last{}, g);
         for (; g + 1 < ng; g++) trip(any_group{}, g);            // (at most one trip: the one that fetches from the last group)
         fetch(any_group{}, g, 1, xq, wq);
         multiply(xp, wp, xq, wq);                                // (ng - 1, 0)
-        if (!skipped(xq)) step(last_step{}, xq, wq, xp, wp);     // (ng - 1, 1)
+        if (!skipped(any_now)) step(last_step{}, xq, wq, xp, wp, any_now);     // (ng - 1, 1)
 #ifdef QGTC_STAMPS
         asm volatile("" : "+v"(acc[0][0]));
 #endif
